@@ -1,0 +1,234 @@
+"""ctypes front-end of the CPU oracle (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module; the product package never does.  See oracle/qecmc_oracle.h.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    src = [os.path.join(_HERE, f) for f in ("qecmc_oracle.c", "qecmc_oracle.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "liboracle.so"])
+    return so
+
+
+class _Rng(C.Structure):
+    _fields_ = [("mode", C.c_int), ("stream", C.POINTER(C.c_double)), ("pos", C.c_uint64),
+                ("len", C.c_uint64), ("consumed", C.c_uint64), ("seed", C.c_uint64),
+                ("syndrome", C.c_uint32), ("c_stream", C.c_uint32), ("c_sub", C.c_uint32),
+                ("c_k", C.c_uint64), ("c_valid", C.c_int), ("c_w", C.c_uint32 * 4)]
+
+
+class _Ladder(C.Structure):
+    _fields_ = [("L", C.c_int), ("Nc", C.c_int), ("nq", C.c_int), ("p_logical", C.c_double),
+                ("p_ladder", C.POINTER(C.c_double)), ("p_diff", C.POINTER(C.c_double)),
+                ("states", C.POINTER(C.c_uint8)), ("flags", C.POINTER(C.c_uint8)),
+                ("tops0", C.c_uint64), ("step_index", C.c_uint64), ("scratch", C.POINTER(C.c_uint8))]
+
+
+class PteqResult(C.Structure):
+    _fields_ = [("counts", C.c_uint32 * 16), ("samples", C.c_uint64), ("tops0", C.c_uint64),
+                ("steps_done", C.c_uint64), ("converged", C.c_int), ("percent", C.c_uint8 * 16)]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        u8p = C.POINTER(C.c_uint8)
+        _LIB.orc_toric_apply_stabilizer.argtypes = [C.c_int, u8p, u8p, C.c_int, C.c_int, C.c_int]
+        _LIB.orc_toric_apply_stabilizer.restype = C.c_int
+        _LIB.orc_toric_apply_logical.argtypes = [C.c_int, u8p, u8p, C.c_int, C.c_int, C.c_int, C.c_int]
+        _LIB.orc_toric_apply_logical.restype = C.c_int
+        _LIB.orc_count_errors.argtypes = [C.c_size_t, u8p]
+        _LIB.orc_count_errors.restype = C.c_int64
+        _LIB.orc_toric_eq_class.argtypes = [C.c_int, u8p]
+        _LIB.orc_toric_eq_class.restype = C.c_int
+        _LIB.orc_toric_to_class.argtypes = [C.c_int, u8p, u8p, C.c_int]
+        _LIB.orc_toric_to_class.restype = None
+        _LIB.orc_toric_syndrome.argtypes = [C.c_int, u8p, u8p]
+        _LIB.orc_toric_syndrome.restype = None
+        _LIB.orc_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        _LIB.orc_philox4x32_10.restype = None
+        _LIB.orc_rng_init_stream.argtypes = [C.POINTER(_Rng), C.POINTER(C.c_double), C.c_uint64]
+        _LIB.orc_rng_init_philox.argtypes = [C.POINTER(_Rng), C.c_uint64, C.c_uint32]
+        _LIB.orc_toric_chain_update.argtypes = [C.c_int, u8p, C.c_double, C.c_double, C.c_uint64,
+                                                C.POINTER(_Rng), C.c_uint32, C.c_uint64, u8p]
+        _LIB.orc_toric_chain_update.restype = None
+        _LIB.orc_toric_ladder_new.argtypes = [C.c_int, u8p, C.c_double, C.c_int, C.c_double]
+        _LIB.orc_toric_ladder_new.restype = C.POINTER(_Ladder)
+        _LIB.orc_ladder_free.argtypes = [C.POINTER(_Ladder)]
+        _LIB.orc_toric_ladder_step.argtypes = [C.POINTER(_Ladder), C.c_uint64, C.POINTER(_Rng)]
+        _LIB.orc_toric_pteq.argtypes = [C.c_int, u8p, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_double, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(_Rng),
+                                        C.POINTER(PteqResult), u8p]
+        _LIB.orc_toric_pteq.restype = None
+        _LIB.orc_toric_pteq_batch.argtypes = [C.c_int, u8p, C.c_uint64, C.c_uint32, C.c_double, C.c_int,
+                                              C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int,
+                                              C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
+                                              C.POINTER(C.c_uint64), u8p]
+        _LIB.orc_toric_pteq_batch.restype = None
+    return _LIB
+
+
+def _u8(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+def _m(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    return a
+
+
+class Rng:
+    """Uniform source: Rng.stream(array) or Rng.philox(seed, syndrome)."""
+
+    def __init__(self):
+        self.c = _Rng()
+        self._keep = None
+
+    @classmethod
+    def stream(cls, values):
+        r = cls()
+        r._keep = np.ascontiguousarray(values, dtype=np.float64)
+        lib().orc_rng_init_stream(C.byref(r.c), r._keep.ctypes.data_as(C.POINTER(C.c_double)), r._keep.size)
+        return r
+
+    @classmethod
+    def philox(cls, seed, syndrome=0):
+        r = cls()
+        lib().orc_rng_init_philox(C.byref(r.c), seed, syndrome)
+        return r
+
+    @property
+    def consumed(self):
+        return int(self.c.consumed)
+
+
+def philox4x32_10(ctr, key):
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    o = (C.c_uint32 * 4)()
+    lib().orc_philox4x32_10(c, k, o)
+    return [int(x) for x in o]
+
+
+# ---- toric stencils ---------------------------------------------------------
+def toric_apply_stabilizer(m, row, col, op):
+    m = _m(m); L = m.shape[1]; out = np.empty_like(m)
+    dE = lib().orc_toric_apply_stabilizer(L, _u8(m), _u8(out), row, col, op)
+    return out, dE
+
+
+def toric_apply_logical(m, op, layer, xpos=0, zpos=0):
+    m = _m(m); L = m.shape[1]; out = np.empty_like(m)
+    dE = lib().orc_toric_apply_logical(L, _u8(m), _u8(out), op, layer, xpos, zpos)
+    return out, dE
+
+
+def count_errors(m):
+    m = _m(m)
+    return int(lib().orc_count_errors(m.size, _u8(m)))
+
+
+def toric_eq_class(m):
+    m = _m(m)
+    return int(lib().orc_toric_eq_class(m.shape[1], _u8(m)))
+
+
+def toric_to_class(m, eq):
+    m = _m(m); out = np.empty_like(m)
+    lib().orc_toric_to_class(m.shape[1], _u8(m), _u8(out), eq)
+    return out
+
+
+def toric_syndrome(m):
+    m = _m(m); out = np.empty_like(m)
+    lib().orc_toric_syndrome(m.shape[1], _u8(m), _u8(out))
+    return out
+
+
+# ---- chain / ladder / PTEQ --------------------------------------------------
+def toric_chain_update(m, p, p_logical, iters, rng, slot=0, k0=0):
+    m = _m(m).copy(); L = m.shape[1]
+    scratch = np.empty_like(m)
+    lib().orc_toric_chain_update(L, _u8(m), p, p_logical, iters, C.byref(rng.c), slot, k0, _u8(scratch))
+    return m
+
+
+class ToricLadder:
+    def __init__(self, init, p_bottom, Nc, p_logical=0.0):
+        init = _m(init)
+        self.L = init.shape[1]; self.Nc = Nc; self.nq = init.size
+        self._p = lib().orc_toric_ladder_new(self.L, _u8(init), p_bottom, Nc, p_logical)
+
+    def __del__(self):
+        if getattr(self, "_p", None):
+            lib().orc_ladder_free(self._p)
+            self._p = None
+
+    def step(self, iters, rng):
+        lib().orc_toric_ladder_step(self._p, iters, C.byref(rng.c))
+
+    @property
+    def states(self):
+        a = np.ctypeslib.as_array(self._p.contents.states, shape=(self.Nc * self.nq,))
+        return a.reshape(self.Nc, 2, self.L, self.L).copy()
+
+    @property
+    def flags(self):
+        return np.ctypeslib.as_array(self._p.contents.flags, shape=(self.Nc,)).copy()
+
+    @property
+    def tops0(self):
+        return int(self._p.contents.tops0)
+
+    @property
+    def p_ladder(self):
+        return np.ctypeslib.as_array(self._p.contents.p_ladder, shape=(self.Nc,)).copy()
+
+    @property
+    def p_diff(self):
+        return np.ctypeslib.as_array(self._p.contents.p_diff, shape=(self.Nc - 1,)).copy()
+
+
+def toric_pteq(init, p, Nc=None, SEQ=2, TOPS=10, tops_burn=2, eps=0.1, steps=1000, iters=10,
+               conv_criteria=None, rng=None, return_states=False):
+    init = _m(init); L = init.shape[1]; Nc = Nc or L
+    res = PteqResult()
+    fin = np.empty((Nc,) + init.shape, dtype=np.uint8)
+    lib().orc_toric_pteq(L, _u8(init), p, Nc, SEQ, TOPS, tops_burn, eps, steps, iters,
+                         1 if conv_criteria == "error_based" else 0, C.byref(rng.c), C.byref(res), _u8(fin))
+    out = dict(counts=np.array(res.counts[:], dtype=np.uint32), samples=int(res.samples),
+               tops0=int(res.tops0), steps_done=int(res.steps_done), converged=bool(res.converged),
+               percent=np.array(res.percent[:], dtype=np.uint8))
+    if return_states:
+        out["states"] = fin
+    return out
+
+
+def toric_pteq_batch(init, p, Nc, steps, iters=10, tops_burn=2, seed=0, first_syndrome=0, n_threads=0,
+                     return_states=False):
+    init = _m(init); N = init.shape[0]; L = init.shape[2]
+    counts = np.zeros((N, 16), dtype=np.uint32)
+    samples = np.zeros(N, dtype=np.uint64)
+    tops0 = np.zeros(N, dtype=np.uint64)
+    fin = np.empty((N, Nc) + init.shape[1:], dtype=np.uint8) if return_states else None
+    lib().orc_toric_pteq_batch(L, _u8(init), N, first_syndrome, p, Nc, tops_burn, steps, iters, seed, n_threads,
+                               counts.ctypes.data_as(C.POINTER(C.c_uint32)),
+                               samples.ctypes.data_as(C.POINTER(C.c_uint64)),
+                               tops0.ctypes.data_as(C.POINTER(C.c_uint64)),
+                               _u8(fin) if fin is not None else None)
+    out = dict(counts=counts, samples=samples, tops0=tops0)
+    if return_states:
+        out["states"] = fin
+    return out

@@ -1,0 +1,419 @@
+/*
+ * qecmc_oracle.c -- CPU oracle (TEST INFRASTRUCTURE ONLY, see qecmc_oracle.h).
+ *
+ * A plain-C restatement of the reference hot path, written from the reference's
+ * behaviour (file:line citations are relative to /root/reference).  It keeps the
+ * reference's random-scan semantics, draw order and floating-point formulas so
+ * that, fed the same uniform stream, it reproduces the reference bit for bit
+ * (fixtures F1/F2/F4 under tests/golden/).
+ *
+ * Parity status: PINNED by tests/test_oracle_golden.py.
+ */
+#include "qecmc_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------ */
+/* Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1,2,3", */
+/* SC'11; Random123 v1.x constants).  Published algorithm, restated here.     */
+/* ------------------------------------------------------------------------ */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+    uint32_t k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+void orc_rng_init_stream(orc_rng *r, const double *stream, uint64_t len)
+{
+    memset(r, 0, sizeof *r);
+    r->mode = 0; r->stream = stream; r->len = len;
+}
+
+void orc_rng_init_philox(orc_rng *r, uint64_t seed, uint32_t syndrome)
+{
+    memset(r, 0, sizeof *r);
+    r->mode = 1; r->seed = seed; r->syndrome = syndrome;
+}
+
+/* One uniform in [0,1).  Stream mode ignores the address and just takes the
+ * next injected double (the reference has a single global `random` stream).
+ * Philox mode: u = word `w` of block (k, sub) of `stream_id`, times 2^-32. */
+static double orc_draw(orc_rng *r, uint32_t stream_id, uint64_t k, uint32_t sub, int w)
+{
+    r->consumed++;
+    if (r->mode == 0) {
+        if (r->pos >= r->len) abort();   /* fixture stream exhausted: a test bug */
+        return r->stream[r->pos++];
+    }
+    if (!(r->c_valid && r->c_stream == stream_id && r->c_k == k && r->c_sub == sub)) {
+        uint32_t ctr[4], key[2];
+        ctr[0] = (uint32_t)k;
+        ctr[1] = (uint32_t)((k >> 32) & 0xFFFFu) | (sub << 16);
+        ctr[2] = r->syndrome;
+        ctr[3] = stream_id;
+        key[0] = (uint32_t)r->seed;
+        key[1] = (uint32_t)(r->seed >> 32);
+        orc_philox4x32_10(ctr, key, r->c_w);
+        r->c_stream = stream_id; r->c_k = k; r->c_sub = sub; r->c_valid = 1;
+    }
+    return (double)r->c_w[w] * (1.0 / 4294967296.0);
+}
+
+#define ORC_SWAP_STREAM 0x100u
+
+/* ------------------------------------------------------------------------ */
+/* toric stencils                                                            */
+/* ------------------------------------------------------------------------ */
+static inline int wrap(int a, int L) { a %= L; return a < 0 ? a + L : a; }
+
+/* one qubit ^= op with the reference's error-count bookkeeping
+ * (toric_model.py:275-282 / :208-217) */
+static inline int flip_qubit(uint8_t *q, int op)
+{
+    uint8_t old = *q, neu = (uint8_t)(old ^ op);
+    *q = neu;
+    if (old && !neu) return -1;
+    if (neu && !old) return 1;
+    return 0;
+}
+
+/* _apply_stabilizer, src/toric_model.py:256-284.  op=1 touches
+ * (1,r,c),(1,r,c-1),(0,r,c),(0,r-1,c); op=3 touches (1,r,c),(0,r,c),(0,r,c+1),(1,r+1,c).
+ * The reference reads old values from the INPUT matrix and writes into a copy. */
+int orc_toric_apply_stabilizer(int L, const uint8_t *in, uint8_t *out, int row, int col, int op)
+{
+    const int LL = L * L;
+    int lay[4], rr[4], cc[4];
+    if (op == 1) {
+        lay[0] = 1; lay[1] = 1; lay[2] = 0; lay[3] = 0;
+        rr[0] = row; rr[1] = row; rr[2] = row; rr[3] = wrap(row - 1, L);
+        cc[0] = col; cc[1] = wrap(col - 1, L); cc[2] = col; cc[3] = col;
+    } else {
+        lay[0] = 1; lay[1] = 0; lay[2] = 0; lay[3] = 1;
+        rr[0] = row; rr[1] = row; rr[2] = row; rr[3] = wrap(row + 1, L);
+        cc[0] = col; cc[1] = col; cc[2] = wrap(col + 1, L); cc[3] = col;
+    }
+    if (out != in) memcpy(out, in, (size_t)2 * LL);
+    int dE = 0;
+    for (int i = 0; i < 4; ++i) {
+        int idx = lay[i] * LL + rr[i] * L + cc[i];
+        uint8_t old = in == out ? out[idx] : in[idx];
+        uint8_t neu = (uint8_t)(old ^ op);
+        out[idx] = neu;
+        if (old && !neu) dE -= 1;
+        else if (neu && !old) dE += 1;
+    }
+    return dE;
+}
+
+/* _apply_logical, src/toric_model.py:179-225.  Layer 0: X on row X_pos, Z on
+ * column Z_pos; layer 1 is the transpose (:201-202).  X and Z updates are
+ * interleaved per index exactly as in the reference loop (:219-223). */
+int orc_toric_apply_logical(int L, const uint8_t *in, uint8_t *out, int op, int layer, int xpos, int zpos)
+{
+    const int LL = L * L;
+    if (out != in) memcpy(out, in, (size_t)2 * LL);
+    if (op == 0) return 0;
+    int do_x = (op == 1 || op == 2);
+    int do_z = (op == 3 || op == 2);
+    uint8_t *m = out + layer * LL;
+    int dE = 0;
+    for (int i = 0; i < L; ++i) {
+        if (do_x) {
+            int r = xpos, c = i;
+            dE += flip_qubit(layer == 0 ? &m[r * L + c] : &m[c * L + r], 1);
+        }
+        if (do_z) {
+            int r = i, c = zpos;
+            dE += flip_qubit(layer == 0 ? &m[r * L + c] : &m[c * L + r], 3);
+        }
+    }
+    return dE;
+}
+
+/* _count_errors, src/toric_model.py:174-176 */
+int64_t orc_count_errors(size_t nq, const uint8_t *in)
+{
+    int64_t n = 0;
+    for (size_t i = 0; i < nq; ++i) n += in[i] != 0;
+    return n;
+}
+
+/* _define_equivalence_class, src/toric_model.py:317-351 */
+int orc_toric_eq_class(int L, const uint8_t *in)
+{
+    const int LL = L * L;
+    int cnt[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    for (int l = 0; l < 2; ++l)
+        for (int i = 0; i < LL; ++i) cnt[l][in[l * LL + i] & 3]++;
+    int x1 = (cnt[0][1] + cnt[0][2]) % 2, z1 = (cnt[0][3] + cnt[0][2]) % 2;
+    int x2 = (cnt[1][1] + cnt[1][2]) % 2, z2 = (cnt[1][3] + cnt[1][2]) % 2;
+    return x1 + z1 * 2 + x2 * 4 + z2 * 8;
+}
+
+/* _to_class, src/toric_model.py:354-377 */
+void orc_toric_to_class(int L, const uint8_t *in, uint8_t *out, int eq)
+{
+    int diff = eq ^ orc_toric_eq_class(L, in);
+    int x = (0xA & diff) >> 1;
+    int ops = diff ^ x;
+    int ops2 = ops >> 2, ops1 = ops & 3;
+    if (out != in) memcpy(out, in, (size_t)2 * L * L);
+    orc_toric_apply_logical(L, out, out, ops1, 0, 0, 0);
+    orc_toric_apply_logical(L, out, out, ops2, 1, 0, 0);
+}
+
+/* Toric_code.syndrom, src/toric_model.py:58-101.  defects_out uint8[2][L][L]:
+ * [0] vertex defects (Y/Z parity), [1] plaquette defects (X/Y parity). */
+void orc_toric_syndrome(int L, const uint8_t *in, uint8_t *defects_out)
+{
+    const int LL = L * L;
+    const uint8_t *q0 = in, *q1 = in + LL;
+    for (int r = 0; r < L; ++r)
+        for (int c = 0; c < L; ++c) {
+#define YZ(m, rr, cc) (((m)[wrap(rr, L) * L + wrap(cc, L)] == 2) || ((m)[wrap(rr, L) * L + wrap(cc, L)] == 3))
+#define XY(m, rr, cc) (((m)[wrap(rr, L) * L + wrap(cc, L)] == 1) || ((m)[wrap(rr, L) * L + wrap(cc, L)] == 2))
+            int charge0 = YZ(q0, r, c) ^ YZ(q0, r - 1, c);  /* roll(+1, axis 0)  :66  */
+            int charge1 = YZ(q1, r, c) ^ YZ(q1, r, c - 1);  /* roll(+1, axis 1)  :73  */
+            int flux0 = XY(q0, r, c) ^ XY(q0, r, c + 1);    /* roll(-1, axis 1)  :86  */
+            int flux1 = XY(q1, r, c) ^ XY(q1, r + 1, c);    /* roll(-1, axis 0)  :94  */
+#undef YZ
+#undef XY
+            defects_out[r * L + c] = (uint8_t)(charge0 ^ charge1);
+            defects_out[LL + r * L + c] = (uint8_t)(flux0 ^ flux1);
+        }
+}
+
+/* ------------------------------------------------------------------------ */
+/* Chain.update_chain, src/mcmc.py:19-43                                      */
+/* ------------------------------------------------------------------------ */
+
+/* _apply_random_stabilizer, src/toric_model.py:287-296: three draws row, col, op */
+static int toric_random_stabilizer(int L, const uint8_t *in, uint8_t *out, orc_rng *rng,
+                                   uint32_t slot, uint64_t k, int w_row, int w_col, int w_op)
+{
+    int row = (int)(orc_draw(rng, slot, k, 0, w_row) * L);
+    int col = (int)(orc_draw(rng, slot, k, 0, w_col) * L);
+    int op = (int)(orc_draw(rng, slot, k, 0, w_op) * 2);
+    if (op == 0) op = 3;
+    return orc_toric_apply_stabilizer(L, in, out, row, col, op);
+}
+
+/* _apply_random_logical, src/toric_model.py:228-253: op0, op1 first, then per
+ * layer X_pos iff op in {1,2}, Z_pos iff op in {3,2}. */
+static int toric_random_logical(int L, const uint8_t *in, uint8_t *out, orc_rng *rng,
+                                uint32_t slot, uint64_t k)
+{
+    int ops[2];
+    ops[0] = (int)(orc_draw(rng, slot, k, 0, 1) * 4);
+    ops[1] = (int)(orc_draw(rng, slot, k, 0, 2) * 4);
+    int nb = 0, dE = 0;
+    if (out != in) memcpy(out, in, (size_t)2 * L * L);
+    for (int layer = 0; layer < 2; ++layer) {
+        int op = ops[layer], xpos = 0, zpos = 0;
+        if (op == 1 || op == 2) xpos = (int)(orc_draw(rng, slot, k, 1, nb++) * L);
+        if (op == 3 || op == 2) zpos = (int)(orc_draw(rng, slot, k, 1, nb++) * L);
+        dE += orc_toric_apply_logical(L, out, out, op, layer, xpos, zpos);
+    }
+    return dE;
+}
+
+void orc_toric_chain_update(int L, uint8_t *state, double p, double p_logical, uint64_t iters,
+                            orc_rng *rng, uint32_t slot, uint64_t k0, uint8_t *scratch)
+{
+    const size_t nq = (size_t)2 * L * L;
+    const double factor = (p / 3.0) / (1.0 - p);                  /* mcmc.py:16 */
+    if (p_logical != 0) {                                          /* mcmc.py:20 */
+        for (uint64_t j = 0; j < iters; ++j) {
+            uint64_t k = k0 + j;
+            int dE;
+            if (orc_draw(rng, slot, k, 0, 0) < p_logical)          /* mcmc.py:23 */
+                dE = toric_random_logical(L, state, scratch, rng, slot, k);
+            else
+                dE = toric_random_stabilizer(L, state, scratch, rng, slot, k, 1, 2, 3);
+            if (p >= 0.75 || dE <= 0) {                            /* mcmc.py:30 */
+                memcpy(state, scratch, nq);
+                continue;
+            }
+            if (orc_draw(rng, slot, k, 2, 0) < pow(factor, (double)dE))   /* mcmc.py:34 */
+                memcpy(state, scratch, nq);
+        }
+    } else {
+        for (uint64_t j = 0; j < iters; ++j) {                     /* mcmc.py:38 */
+            uint64_t k = k0 + j;
+            int dE = toric_random_stabilizer(L, state, scratch, rng, slot, k, 0, 1, 2);
+            if (orc_draw(rng, slot, k, 0, 3) < pow(factor, (double)dE))   /* mcmc.py:42 */
+                memcpy(state, scratch, nq);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* Ladder, src/mcmc.py:49-103                                                 */
+/* ------------------------------------------------------------------------ */
+static void fill_ladder_p(double p_bottom, double p_top, int Nc, double *p_ladder, double *p_diff)
+{
+    /* np.linspace(p_bottom, p_top, Nc): y[i] = i*step + start, y[-1] = stop */
+    if (Nc == 1) {
+        p_ladder[0] = p_bottom;
+        return;
+    }
+    double step = (p_top - p_bottom) / (double)(Nc - 1);
+    for (int i = 0; i < Nc; ++i) p_ladder[i] = (double)i * step + p_bottom;
+    p_ladder[Nc - 1] = p_top;
+    for (int i = 0; i < Nc - 1; ++i)                               /* mcmc.py:69 */
+        p_diff[i] = (p_ladder[i] * (1 - p_ladder[i + 1])) / (p_ladder[i + 1] * (1 - p_ladder[i]));
+}
+
+orc_ladder *orc_toric_ladder_new(int L, const uint8_t *init, double p_bottom, int Nc, double p_logical)
+{
+    orc_ladder *ld = (orc_ladder *)calloc(1, sizeof *ld);
+    ld->L = L; ld->Nc = Nc; ld->nq = 2 * L * L; ld->p_logical = p_logical;
+    ld->p_ladder = (double *)calloc((size_t)Nc, sizeof(double));
+    ld->p_diff = (double *)calloc((size_t)(Nc > 1 ? Nc - 1 : 1), sizeof(double));
+    ld->states = (uint8_t *)malloc((size_t)Nc * ld->nq);
+    ld->flags = (uint8_t *)calloc((size_t)Nc, 1);
+    ld->scratch = (uint8_t *)malloc((size_t)ld->nq);
+    fill_ladder_p(p_bottom, 0.75, Nc, ld->p_ladder, ld->p_diff);    /* mcmc.py:62-69 */
+    for (int c = 0; c < Nc; ++c) memcpy(ld->states + (size_t)c * ld->nq, init, (size_t)ld->nq); /* :72 */
+    ld->flags[Nc - 1] = 1;                                          /* mcmc.py:75 */
+    return ld;
+}
+
+void orc_ladder_free(orc_ladder *ld)
+{
+    if (!ld) return;
+    free(ld->p_ladder); free(ld->p_diff); free(ld->states); free(ld->flags); free(ld->scratch);
+    free(ld);
+}
+
+/* Ladder.step(iters), src/mcmc.py:94-103 */
+void orc_toric_ladder_step(orc_ladder *ld, uint64_t iters, orc_rng *rng)
+{
+    const int Nc = ld->Nc, nq = ld->nq;
+    const uint64_t k0 = ld->step_index * iters;
+    for (int c = 0; c < Nc; ++c)                                    /* update_ladder :81-83 */
+        orc_toric_chain_update(ld->L, ld->states + (size_t)c * nq, ld->p_ladder[c],
+                               c == Nc - 1 ? ld->p_logical : 0.0, iters, rng, (uint32_t)c, k0,
+                               ld->scratch);
+    for (int i = Nc - 2; i >= 0; --i) {                             /* :96 */
+        int64_t ne_lo = orc_count_errors((size_t)nq, ld->states + (size_t)i * nq);
+        int64_t ne_hi = orc_count_errors((size_t)nq, ld->states + (size_t)(i + 1) * nq);
+        int flip;
+        if (ne_hi < ne_lo) flip = 1;                                /* _r_flip :146 */
+        else flip = orc_draw(rng, ORC_SWAP_STREAM, ld->step_index, (uint32_t)i >> 2, i & 3)
+                    < pow(ld->p_diff[i], (double)(ne_hi - ne_lo));  /* :149 */
+        if (flip) {                                                 /* :98-99 */
+            memcpy(ld->scratch, ld->states + (size_t)i * nq, (size_t)nq);
+            memcpy(ld->states + (size_t)i * nq, ld->states + (size_t)(i + 1) * nq, (size_t)nq);
+            memcpy(ld->states + (size_t)(i + 1) * nq, ld->scratch, (size_t)nq);
+            uint8_t f = ld->flags[i]; ld->flags[i] = ld->flags[i + 1]; ld->flags[i + 1] = f;
+        }
+    }
+    ld->flags[Nc - 1] = 1;                                          /* :100 */
+    if (ld->flags[0] == 1) { ld->tops0++; ld->flags[0] = 0; }       /* :101-103 */
+    ld->step_index++;
+}
+
+/* ------------------------------------------------------------------------ */
+/* decoders.PTEQ, decoders.py:25-89, and conv_crit_error_based_PT :93-105     */
+/* ------------------------------------------------------------------------ */
+static double mean_range(const double *a, uint64_t lo, uint64_t hi)
+{
+    /* np.average of integer-valued doubles: the sum is exact, order irrelevant.
+     * Empty slice -> NaN (numpy warns and returns nan; comparisons are False). */
+    if (hi <= lo) return NAN;
+    double s = 0;
+    for (uint64_t i = lo; i < hi; ++i) s += a[i];
+    return s / (double)(hi - lo);
+}
+
+void orc_toric_pteq(int L, const uint8_t *init, double p, int Nc, int SEQ, int TOPS, int tops_burn,
+                    double eps, uint64_t steps, uint64_t iters, int conv_mode, orc_rng *rng,
+                    orc_pteq_result *res, uint8_t *final_states)
+{
+    orc_ladder *ld = orc_toric_ladder_new(L, init, p, Nc, 0.5);     /* decoders.py:52 */
+    uint64_t since_burn = 0, resulting_burn_in = 0, recorded = 0;
+    uint64_t conv_start = 0, conv_streak = 0;
+    uint32_t eq[16];
+    memset(eq, 0, sizeof eq);
+    double *series = conv_mode ? (double *)calloc((size_t)steps, sizeof(double)) : NULL;
+    int converged = 0;
+    uint64_t step;
+    for (step = 0; step < steps; ++step) {                          /* :55 */
+        orc_toric_ladder_step(ld, iters, rng);                      /* :57 */
+        int cur = orc_toric_eq_class(L, ld->states);                /* :60 */
+        if (ld->tops0 >= (uint64_t)tops_burn) {                     /* :63 */
+            since_burn = step - resulting_burn_in;
+            eq[cur] += 1;                                           /* :66-67 (running row) */
+            recorded = since_burn + 1;
+            if (series) series[since_burn] = (double)orc_count_errors((size_t)ld->nq, ld->states);
+        } else {
+            resulting_burn_in += 1;                                 /* :71 */
+        }
+        if (conv_mode == 1 && ld->tops0 >= (uint64_t)TOPS) {        /* :74 */
+            uint64_t l = since_burn + 1;
+            double q2 = mean_range(series, l / 4, l / 2);
+            double q4 = mean_range(series, 3 * l / 4, l);
+            double err = fabs(q2 - q4);
+            if (err < eps) {                                        /* :102 */
+                if (conv_streak >= (uint64_t)SEQ) { converged = 1; step++; break; }
+                conv_streak = ld->tops0 - conv_start;               /* :79 */
+            } else {
+                conv_streak = 0;                                    /* :81-82 */
+                conv_start = ld->tops0;
+            }
+        }
+    }
+    memcpy(res->counts, eq, sizeof eq);
+    res->samples = recorded;
+    res->tops0 = ld->tops0;
+    res->steps_done = step;
+    res->converged = converged;
+    for (int i = 0; i < 16; ++i)                                    /* :89 */
+        res->percent[i] = (uint8_t)((double)eq[i] / (double)(since_burn + 1) * 100.0);
+    if (final_states) memcpy(final_states, ld->states, (size_t)Nc * ld->nq);
+    free(series);
+    orc_ladder_free(ld);
+}
+
+void orc_toric_pteq_batch(int L, const uint8_t *init, uint64_t N, uint32_t first_syndrome, double p,
+                          int Nc, int tops_burn, uint64_t steps, uint64_t iters, uint64_t seed,
+                          int n_threads, uint32_t *counts_out, uint64_t *samples_out,
+                          uint64_t *tops0_out, uint8_t *final_states)
+{
+    const size_t nq = (size_t)2 * L * L;
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#else
+    (void)n_threads;
+#endif
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t s = 0; s < (int64_t)N; ++s) {
+        orc_rng rng;
+        orc_rng_init_philox(&rng, seed, first_syndrome + (uint32_t)s);
+        orc_pteq_result res;
+        orc_toric_pteq(L, init + (size_t)s * nq, p, Nc, 2, 10, tops_burn, 0.1, steps, iters, 0, &rng,
+                       &res, final_states ? final_states + (size_t)s * Nc * nq : NULL);
+        memcpy(counts_out + (size_t)s * 16, res.counts, sizeof res.counts);
+        samples_out[s] = res.samples;
+        tops0_out[s] = res.tops0;
+    }
+}

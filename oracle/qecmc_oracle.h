@@ -1,0 +1,112 @@
+/*
+ * qecmc_oracle.h -- CPU oracle for the MCMC equivalence-class sampler hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a plain-C restatement of the reference's
+ * algorithm (QEC-project-2020/MCMC-QEC-toric-RL: src/toric_model.py,
+ * src/mcmc.py, decoders.py:25-105), used as the checker in tests/, in
+ * __graft_entry__.smoke() and as bench.py's `cpu_baseline` leg.  Nothing in
+ * the product package (mcmc-qec-toric-rl_amd/) may include, link or call it.
+ *
+ * Parity status: PINNED.  Every function below is checked against vectors
+ * captured from the reference itself (imported in the build container with an
+ * identity-decorator numba stub, see tests/golden/gen_golden.py):
+ *   F1  deterministic known-answer vectors for all stencil functions,
+ *   F2  stream-injected exact trajectories of Chain.update_chain / Ladder.step
+ *       / the PTEQ bookkeeping loop (uniform stream injected into `random`),
+ *   F4  the BASELINE config-1 plumbing vector.
+ *
+ * Pauli encoding 0=I 1=X 2=Y 3=Z, composition = XOR (toric_model.py:277).
+ * Toric state: uint8[2][L][L] C-order (toric_model.py:12).
+ */
+#ifndef QECMC_ORACLE_H
+#define QECMC_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- uniform source -------------------------------------------------------
+ * mode 0: injected stream of doubles, consumed strictly in reference call
+ *         order (this is how F2 pins the draw order of src/mcmc.py:19-43).
+ * mode 1: Philox4x32-10 counter RNG, u = word * 2^-32, with the
+ *         (stream, k, sub, word) addressing documented in DESIGN.md §RNG.
+ */
+typedef struct orc_rng {
+    int mode;
+    const double *stream;
+    uint64_t pos, len;
+    uint64_t consumed;       /* number of uniforms drawn (both modes) */
+    uint64_t seed;
+    uint32_t syndrome;       /* global syndrome index (Philox ctr[2]) */
+    /* one-block cache for mode 1 */
+    uint32_t c_stream, c_sub;
+    uint64_t c_k;
+    int c_valid;
+    uint32_t c_w[4];
+} orc_rng;
+
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+void orc_rng_init_stream(orc_rng *r, const double *stream, uint64_t len);
+void orc_rng_init_philox(orc_rng *r, uint64_t seed, uint32_t syndrome);
+
+/* ---- toric stencils (src/toric_model.py) -------------------------------- */
+int     orc_toric_apply_stabilizer(int L, const uint8_t *in, uint8_t *out, int row, int col, int op);
+int     orc_toric_apply_logical(int L, const uint8_t *in, uint8_t *out, int op, int layer, int xpos, int zpos);
+int64_t orc_count_errors(size_t nq, const uint8_t *in);
+int     orc_toric_eq_class(int L, const uint8_t *in);
+void    orc_toric_to_class(int L, const uint8_t *in, uint8_t *out, int eq);
+void    orc_toric_syndrome(int L, const uint8_t *in, uint8_t *defects_out);
+
+/* ---- chain / ladder / PTEQ (src/mcmc.py, decoders.py) -------------------- */
+typedef struct orc_ladder {
+    int L, Nc, nq;
+    double p_logical;
+    double *p_ladder;    /* [Nc]   */
+    double *p_diff;      /* [Nc-1] */
+    uint8_t *states;     /* [Nc][nq], slot order (chains[i].code.qubit_matrix) */
+    uint8_t *flags;      /* [Nc] */
+    uint64_t tops0;
+    uint64_t step_index; /* ladder steps done so far (Philox addressing) */
+    uint8_t *scratch;    /* [nq] */
+} orc_ladder;
+
+/* Chain.update_chain(iters), src/mcmc.py:19-43.  `slot`/`k0` only address the
+ * Philox stream (mode 1): proposal j of this call is proposal k0+j of `slot`. */
+void orc_toric_chain_update(int L, uint8_t *state, double p, double p_logical,
+                            uint64_t iters, orc_rng *rng, uint32_t slot, uint64_t k0,
+                            uint8_t *scratch);
+
+orc_ladder *orc_toric_ladder_new(int L, const uint8_t *init, double p_bottom, int Nc, double p_logical);
+void        orc_ladder_free(orc_ladder *ld);
+void        orc_toric_ladder_step(orc_ladder *ld, uint64_t iters, orc_rng *rng);
+
+typedef struct orc_pteq_result {
+    uint32_t counts[16];   /* eq[since_burn]   (decoders.py:42,66-67) */
+    uint64_t samples;      /* since_burn + 1 if anything was recorded, else 0 */
+    uint64_t tops0;
+    uint64_t steps_done;
+    int converged;
+    uint8_t percent[16];   /* decoders.py:89 */
+} orc_pteq_result;
+
+/* decoders.PTEQ (decoders.py:25-89).  conv_mode 0 = conv_criteria None (fixed
+ * `steps`), 1 = 'error_based'.  final_states (nullable) receives [Nc][nq]. */
+void orc_toric_pteq(int L, const uint8_t *init, double p, int Nc, int SEQ, int TOPS, int tops_burn,
+                    double eps, uint64_t steps, uint64_t iters, int conv_mode, orc_rng *rng,
+                    orc_pteq_result *res, uint8_t *final_states);
+
+/* N independent PTEQ runs (one per syndrome, Philox keyed by first_syndrome+i),
+ * spread over `n_threads` OpenMP threads.  This is the timed CPU baseline. */
+void orc_toric_pteq_batch(int L, const uint8_t *init /*[N][nq]*/, uint64_t N, uint32_t first_syndrome,
+                          double p, int Nc, int tops_burn, uint64_t steps, uint64_t iters,
+                          uint64_t seed, int n_threads,
+                          uint32_t *counts_out /*[N][16]*/, uint64_t *samples_out /*[N]*/,
+                          uint64_t *tops0_out /*[N]*/, uint8_t *final_states /*nullable [N][Nc][nq]*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

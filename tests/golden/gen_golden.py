@@ -1,0 +1,269 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by importing the reference.
+
+Runs ONLY in the build container (needs /root/reference; no-op elsewhere).  The
+reference is pure Python + numba; numba is not installed here, so an
+identity-decorator `numba` stub (created in a temp dir, outside the read-only
+reference tree) lets the reference modules import and run as plain NumPy/Python
+(SURVEY.md §8c).  Nothing from the reference is copied: the fixtures hold only
+inputs and the reference's outputs.
+
+    python tests/golden/gen_golden.py [--only f1,f2,f3,f4]
+
+Fixtures
+  f1_toric.npz    deterministic known-answer vectors for the toric stencils
+  f2_toric.npz    stream-injected exact trajectories (Chain / Ladder / PTEQ);
+                  uniform streams are random.Random(seed).random() so only the
+                  seed is stored
+  f3_toric.npz    replica-averaged PTEQ class histograms (statistical)
+  f4_config1.npz  BASELINE config-1 plumbing vector
+"""
+import argparse
+import os
+import random
+import sys
+import tempfile
+
+import numpy as np
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def import_reference():
+    shim = tempfile.mkdtemp(prefix="numba_stub_")
+    os.makedirs(os.path.join(shim, "numba"))
+    with open(os.path.join(shim, "numba", "__init__.py"), "w") as f:
+        f.write("def _deco(*a, **k):\n"
+                "    if len(a) == 1 and callable(a[0]) and not k:\n"
+                "        return a[0]\n"
+                "    return lambda f: f\n"
+                "njit = jit = _deco\n")
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    sys.path.insert(0, shim)
+    os.chdir(tempfile.mkdtemp(prefix="refcwd_"))
+    import src.toric_model as tm
+    import src.mcmc as mc
+    import decoders as dec
+    return tm, mc, dec
+
+
+class Stream:
+    """random.Random(seed).random with a draw counter; installed over the
+    reference's two aliases of `random`."""
+
+    def __init__(self, seed):
+        self.r = random.Random(seed)
+        self.n = 0
+
+    def __call__(self):
+        self.n += 1
+        return self.r.random()
+
+
+def install(stream, tm):
+    random.random = stream          # `rand.random()` in src/mcmc.py
+    tm.random = stream              # `from random import random` in src/toric_model.py
+
+
+_ORIG_RANDOM = random.random
+
+
+def restore(tm):
+    random.random = _ORIG_RANDOM
+    tm.random = _ORIG_RANDOM
+
+
+def rand_matrix(rng, L, p):
+    m = np.zeros((2, L, L), dtype=np.uint8)
+    err = rng.random((2, L, L)) < p
+    m[err] = rng.integers(1, 4, size=int(err.sum()), dtype=np.uint8)
+    return m
+
+
+# --------------------------------------------------------------------------- F1
+def gen_f1(tm):
+    rng = np.random.default_rng(20200915)
+    out = {}
+    for L in (3, 5, 9):
+        for rep, p in enumerate((0.15, 0.45)):
+            tag = f"L{L}_{rep}"
+            m = rand_matrix(rng, L, p)
+            code = tm.Toric_code(L)
+            code.qubit_matrix = m.copy()
+            out[f"{tag}_m"] = m
+            out[f"{tag}_count"] = np.int64(code.count_errors())
+            out[f"{tag}_class"] = np.int64(code.define_equivalence_class())
+            code.syndrom()
+            out[f"{tag}_defects"] = np.asarray(code.defect_matrix, dtype=np.uint8)
+            st_new, st_dE = [], []
+            for op in (1, 3):
+                for r in range(L):
+                    for c in range(L):
+                        new, dE = code.apply_stabilizer(r, c, op)
+                        st_new.append(new); st_dE.append(dE)
+            out[f"{tag}_stab_new"] = np.array(st_new, dtype=np.uint8)     # [2*L*L,2,L,L] order (op,r,c)
+            out[f"{tag}_stab_dE"] = np.array(st_dE, dtype=np.int64)
+            lg_new, lg_dE, lg_arg = [], [], []
+            for op in range(4):
+                for layer in (0, 1):
+                    for xp in range(L):
+                        for zp in range(L):
+                            new, dE = tm._apply_logical(m, op, layer, xp, zp)
+                            lg_new.append(new); lg_dE.append(dE); lg_arg.append((op, layer, xp, zp))
+            out[f"{tag}_log_new"] = np.array(lg_new, dtype=np.uint8)
+            out[f"{tag}_log_dE"] = np.array(lg_dE, dtype=np.int64)
+            out[f"{tag}_log_arg"] = np.array(lg_arg, dtype=np.int64)
+            out[f"{tag}_to_class"] = np.array([code.to_class(eq) for eq in range(16)], dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, "f1_toric.npz"), **out)
+    print("f1_toric.npz", len(out), "arrays")
+
+
+# --------------------------------------------------------------------------- F2
+def gen_f2(tm, mc, dec):
+    rng = np.random.default_rng(7)
+    out = {}
+    cases = []
+    # Chain.update_chain: non-top and top variants (src/mcmc.py:19-43)
+    for i, (L, p, p_logical, iters, perr) in enumerate([
+            (3, 0.5, 0.0, 25, 0.3), (5, 0.10, 0.0, 400, 0.1), (9, 0.15, 0.0, 600, 0.15),
+            (9, 0.40, 0.0, 600, 0.15), (3, 0.75, 0.5, 25, 0.3), (5, 0.75, 0.5, 300, 0.1),
+            (9, 0.75, 0.5, 300, 0.15), (5, 0.30, 0.5, 300, 0.1), (9, 0.20, 0.25, 300, 0.15)]):
+        m = rand_matrix(rng, L, perr)
+        seed = 1000 + i
+        code = tm.Toric_code(L); code.qubit_matrix = m.copy()
+        ch = mc.Chain(p, code); ch.p_logical = p_logical
+        s = Stream(seed); install(s, tm)
+        ch.update_chain(iters)
+        restore(tm)
+        tag = f"chain{i}"
+        out[f"{tag}_init"] = m
+        out[f"{tag}_final"] = ch.code.qubit_matrix.astype(np.uint8)
+        out[f"{tag}_par"] = np.array([L, p, p_logical, iters, seed, s.n], dtype=np.float64)
+        cases.append(tag)
+    # Ladder.step (src/mcmc.py:94-103)
+    for i, (L, p, Nc, iters, nstep, perr) in enumerate([
+            (3, 0.3, 4, 5, 40, 0.3), (5, 0.10, 5, 10, 60, 0.10), (9, 0.15, 8, 10, 40, 0.15),
+            (5, 0.25, 3, 7, 50, 0.2), (3, 0.05, 2, 10, 60, 0.2)]):
+        m = rand_matrix(rng, L, perr)
+        seed = 2000 + i
+        code = tm.Toric_code(L); code.qubit_matrix = m.copy()
+        s = Stream(seed); install(s, tm)
+        ld = mc.Ladder(p, code, Nc, 0.5)
+        tops_hist = []
+        for _ in range(nstep):
+            ld.step(iters)
+            tops_hist.append(ld.tops0)
+        restore(tm)
+        tag = f"ladder{i}"
+        out[f"{tag}_init"] = m
+        out[f"{tag}_states"] = np.array([c.code.qubit_matrix for c in ld.chains], dtype=np.uint8)
+        out[f"{tag}_flags"] = np.array([c.flag for c in ld.chains], dtype=np.uint8)
+        out[f"{tag}_tops_hist"] = np.array(tops_hist, dtype=np.int64)
+        out[f"{tag}_p_ladder"] = np.asarray(ld.p_ladder, dtype=np.float64)
+        out[f"{tag}_p_diff"] = np.asarray(ld.p_diff, dtype=np.float64)
+        out[f"{tag}_par"] = np.array([L, p, Nc, iters, nstep, seed, s.n], dtype=np.float64)
+        cases.append(tag)
+    # decoders.PTEQ (decoders.py:25-89), fixed steps and the error_based criterion
+    for i, (L, p, Nc, iters, steps, tops_burn, conv, perr, SEQ, TOPS, eps) in enumerate([
+            (3, 0.10, 3, 10, 400, 2, None, 0.15, 2, 10, 0.1), (3, 0.10, 3, 10, 400, 0, None, 0.15, 2, 10, 0.1),
+            (5, 0.10, 5, 10, 300, 1, None, 0.10, 2, 10, 0.1), (9, 0.15, 8, 10, 60, 0, None, 0.15, 2, 10, 0.1),
+            (3, 0.10, 3, 10, 4000, 2, "error_based", 0.15, 2, 10, 0.1),
+            (3, 0.05, 3, 5, 6000, 2, "error_based", 0.1, 2, 10, 0.3),
+            (3, 0.10, 3, 10, 6000, 1, "error_based", 0.1, 1, 4, 0.5),
+            (5, 0.05, 4, 10, 6000, 2, "error_based", 0.05, 2, 6, 0.4),
+            (5, 0.10, 5, 10, 8000, 2, "error_based", 0.10, 2, 10, 0.25)]):
+        m = rand_matrix(rng, L, perr)
+        seed = 3000 + i
+        code = tm.Toric_code(L); code.qubit_matrix = m.copy()
+        s = Stream(seed); install(s, tm)
+        pct = dec.PTEQ(code, p, Nc=Nc, SEQ=SEQ, TOPS=TOPS, eps=eps, steps=steps, iters=iters,
+                       tops_burn=tops_burn, conv_criteria=conv)
+        restore(tm)
+        tag = f"pteq{i}"
+        out[f"{tag}_init"] = m
+        out[f"{tag}_percent"] = np.asarray(pct, dtype=np.uint8)
+        out[f"{tag}_par"] = np.array([L, p, Nc, iters, steps, tops_burn, 1 if conv else 0, seed, s.n,
+                                      SEQ, TOPS, eps], dtype=np.float64)
+        cases.append(tag)
+    out["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(HERE, "f2_toric.npz"), **out)
+    print("f2_toric.npz", cases)
+
+
+# --------------------------------------------------------------------------- F3
+def _f3_worker(args):
+    (L, p, Nc, iters, steps, burn, m, seed) = args
+    tm, mc, dec = import_reference()
+    random.seed(seed)
+    code = tm.Toric_code(L); code.qubit_matrix = m.copy()
+    ld = mc.Ladder(p, code, Nc, 0.5)
+    hist = np.zeros(16, dtype=np.int64)
+    nerr = np.zeros(Nc)
+    for t in range(steps):
+        ld.step(iters)
+        if t >= burn:
+            hist[ld.chains[0].code.define_equivalence_class()] += 1
+            nerr += [c.code.count_errors() for c in ld.chains]
+    return hist, nerr / (steps - burn), ld.tops0
+
+
+def gen_f3(tm):
+    """Raw class counts of the bottom chain after a fixed burn-in (the 10-line
+    histogram loop around Ladder.step, decoders.py:55-68 with a fixed burn-in),
+    R replicas per syndrome, plus per-rung mean error counts (F5)."""
+    import multiprocessing as mp
+    rng = np.random.default_rng(11)
+    out = {}
+    configs = [("L5", 5, 0.10, 5, 10, 6000, 1000, 3, 16), ("L3", 3, 0.10, 3, 10, 6000, 1000, 2, 16)]
+    with mp.get_context("spawn").Pool(8) as pool:
+        for name, L, p, Nc, iters, steps, burn, nsyn, R in configs:
+            ms = [rand_matrix(rng, L, p) for _ in range(nsyn)]
+            jobs = [(L, p, Nc, iters, steps, burn, ms[s], 5000 + 100 * s + r)
+                    for s in range(nsyn) for r in range(R)]
+            res = pool.map(_f3_worker, jobs)
+            out[f"{name}_init"] = np.array(ms, dtype=np.uint8)
+            out[f"{name}_hist"] = np.array([h for h, _, _ in res]).reshape(nsyn, R, 16)
+            out[f"{name}_nerr"] = np.array([n for _, n, _ in res]).reshape(nsyn, R, Nc)
+            out[f"{name}_tops0"] = np.array([t for _, _, t in res]).reshape(nsyn, R)
+            out[f"{name}_par"] = np.array([L, p, Nc, iters, steps, burn], dtype=np.float64)
+            print(name, "done")
+    np.savez_compressed(os.path.join(HERE, "f3_toric.npz"), **out)
+
+
+# --------------------------------------------------------------------------- F4
+def gen_f4(tm, mc):
+    random.seed(1); np.random.seed(1)
+    code = tm.Toric_code(5)
+    code.generate_random_error(0.10)
+    init = code.qubit_matrix.copy()
+    ch = mc.Chain(0.10, code)
+    s = Stream(1); install(s, tm)       # random.Random(1) == the stream after random.seed(1)
+    ch.update_chain(10000)
+    restore(tm)
+    np.savez_compressed(os.path.join(HERE, "f4_config1.npz"), init=init,
+                        final=ch.code.qubit_matrix.astype(np.uint8),
+                        count=np.int64(ch.code.count_errors()),
+                        cls=np.int64(ch.code.define_equivalence_class()),
+                        draws=np.int64(s.n), defects=np.asarray(code.defect_matrix, dtype=np.uint8))
+    print("f4_config1.npz count", ch.code.count_errors(), "class", ch.code.define_equivalence_class())
+
+
+def main():
+    if not os.path.isdir(REF):
+        print("reference not present; nothing to do")
+        return
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="f1,f2,f3,f4")
+    only = set(ap.parse_args().only.split(","))
+    tm, mc, dec = import_reference()
+    if "f1" in only: gen_f1(tm)
+    if "f2" in only: gen_f2(tm, mc, dec)
+    if "f4" in only: gen_f4(tm, mc)
+    if "f3" in only: gen_f3(tm)
+
+
+if __name__ == "__main__":
+    main()
