@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- MCMC sweeps/s of the PTEQ hot path on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one batch: qecmc_pteq_launch_dev on
+65 536 toric L=9 syndromes (p=0.15, Nc=8 temperatures, iters=10) for
+`--ladder-steps` ladder steps, inputs already resident in HBM.  With N GPUs
+every rank processes its own 65 536-syndrome shard (weak scaling; Philox keyed
+by the global syndrome index) and the per-class counts are gathered to rank 0
+over RCCL inside the timed region.
+
+Prints ONE JSON line (rank 0).  `value` = chain-sweeps/s over all ranks, a sweep
+being 2*L*L = 162 Metropolis proposals on one chain.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "mcmc-qec-toric-rl_amd"))
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+ALGO_BYTES_PER_PROPOSAL = 8  # 4 one-byte qubit reads + 4 writes (toric_model.py:275-278), SURVEY.md §8d
+
+
+def synth_batch(N, L, p, seed):
+    """Toric_code.generate_random_error(p) (toric_model.py:15-23) followed by one
+    apply_random_logical (generate_data.py:131), vectorised over N syndromes."""
+    rng = np.random.default_rng(seed)
+    m = np.zeros((N, 2, L, L), dtype=np.uint8)
+    err = rng.random(m.shape) < p
+    m[err] = rng.integers(1, 4, size=int(err.sum()), dtype=np.uint8)
+    ops = rng.integers(0, 4, size=(N, 2))
+    xpos = rng.integers(0, L, size=(N, 2))
+    zpos = rng.integers(0, L, size=(N, 2))
+    idx = np.arange(N)
+    for layer in range(2):
+        do_x = np.isin(ops[:, layer], (1, 2))
+        do_z = np.isin(ops[:, layer], (3, 2))
+        for i in range(L):
+            if layer == 0:
+                m[idx[do_x], 0, xpos[do_x, 0], i] ^= 1
+                m[idx[do_z], 0, i, zpos[do_z, 0]] ^= 3
+            else:
+                m[idx[do_x], 1, i, xpos[do_x, 1]] ^= 1
+                m[idx[do_z], 1, zpos[do_z, 1], i] ^= 3
+    return m
+
+
+def cpu_baseline(init, p, Nc, iters, seed, target_s=12.0):
+    """The oracle (CPU restatement with the reference's random-scan semantics) timed on this
+    box's host cores on a bounded sample of the same workload."""
+    from oracle import oracle as orc
+    cores = os.cpu_count() or 1
+    L = init.shape[2]
+    n_syn = min(init.shape[0], 4 * cores)
+    t0 = time.perf_counter()
+    orc.toric_pteq_batch(init[:n_syn], p, Nc, 50, iters=iters, tops_burn=2, seed=seed, n_threads=cores)
+    dt = max(time.perf_counter() - t0, 1e-4)
+    steps = int(max(50, min(20000, 50 * target_s / dt)))
+    t0 = time.perf_counter()
+    orc.toric_pteq_batch(init[:n_syn], p, Nc, steps, iters=iters, tops_burn=2, seed=seed, n_threads=cores)
+    dt = time.perf_counter() - t0
+    proposals = n_syn * Nc * iters * steps
+    return {"value": proposals / (2 * L * L) / dt, "unit": "chain-sweeps/s", "cores": cores, "kind": "port",
+            "sample": f"{n_syn} syndromes x {steps} ladder steps ({proposals:.3g} proposals, {dt:.1f} s, "
+                      f"OpenMP over syndromes)",
+            "proposals_per_s": proposals / dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--ladder-steps", type=int, default=2000, help="ladder steps per pass (decoders.py `steps`)")
+    ap.add_argument("--syndromes", type=int, default=65536, help="syndromes per GPU")
+    ap.add_argument("--L", type=int, default=9)
+    ap.add_argument("--p", type=float, default=0.15)
+    ap.add_argument("--Nc", type=int, default=8)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--seed", type=int, default=20200915)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from qecmc import _lib as L_
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs a GPU: the product has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)   # RCCL
+
+    N, L, Nc = args.syndromes, args.L, args.Nc
+    nq, ncls = 2 * L * L, 16
+    first = rank * N                                    # global syndrome index of this shard
+    init_h = synth_batch(N, L, args.p, args.seed + rank)
+    d_init = torch.from_numpy(init_h.reshape(N, nq)).to(dev)
+    d_counts = torch.zeros((N, ncls), dtype=torch.int32, device=dev)
+    d_samples = torch.zeros(N, dtype=torch.int32, device=dev)
+    d_tops0 = torch.zeros(N, dtype=torch.int32, device=dev)
+    gathered = [torch.zeros_like(d_counts) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    pr = L_.make_params(code=L_.TORIC, L=L, Nc=Nc, p=args.p, p_logical=0.5, iters=args.iters,
+                        steps=args.ladder_steps, tops_burn=2, seed=args.seed, device=local_rank)
+    plan = C.c_void_p()
+    L_.check(L_.lib().qecmc_plan_create(pr, C.byref(plan)))
+    lds, threads, spb = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    L_.check(L_.lib().qecmc_plan_info(plan, lds, threads, spb))
+    stream = torch.cuda.current_stream()
+
+    def one_pass():
+        L_.check(L_.lib().qecmc_pteq_launch_dev(plan, d_init.data_ptr(), N, first, d_counts.data_ptr(),
+                                                d_samples.data_ptr(), d_tops0.data_ptr(), None,
+                                                C.c_void_p(stream.cuda_stream)))
+
+    def exchange():
+        if world > 1:                                   # the path's one exchange step: per-class counts -> rank 0
+            dist.gather(d_counts, gathered, dst=0)
+
+    for _ in range(args.warmup):
+        one_pass(); exchange()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record(stream); one_pass(); b.record(stream)
+        exchange()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = [a.elapsed_time(b) for a, b in ev]
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    proposals_per_pass = N * Nc * args.iters * args.ladder_steps      # per GPU
+    total_proposals = proposals_per_pass * args.steps * world
+    sweeps_per_s = total_proposals / nq / elapsed
+
+    if rank == 0:
+        samples = d_samples.cpu().numpy()
+        tops0 = d_tops0.cpu().numpy()
+        k_ms = float(np.mean(kernel_ms))
+        algo_bytes = proposals_per_pass * ALGO_BYTES_PER_PROPOSAL + N * (nq + 4 * ncls)
+        achieved = algo_bytes / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "MCMC sweeps/sec (whole node), L=9 toric p=0.15",
+            "value": sweeps_per_s,
+            "unit": "chain-sweeps/s (1 sweep = 2*L*L = %d Metropolis proposals on one chain)" % nq,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "configs[1]: toric L=%d p=%g, %d syndromes per GPU, Nc=%d parallel tempering, "
+                                   "iters=%d, %d ladder steps per pass, scan=random (reference chain)"
+                                   % (L, args.p, N, Nc, args.iters, args.ladder_steps),
+                       "syndromes_per_gpu": N, "L": L, "p": args.p, "Nc": Nc, "iters": args.iters,
+                       "ladder_steps": args.ladder_steps, "tops_burn": 2, "seed": args.seed,
+                       "lds_bytes_per_workgroup": lds.value, "threads_per_workgroup": threads.value,
+                       "parallelism": "syndrome shards x%d, RCCL gather of class counts" % world},
+            "proposals_per_s": total_proposals / elapsed,
+            "ladder_sweeps_per_s": sweeps_per_s / Nc,
+            "kernel_ms_per_launch": k_ms,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "note": "algorithmic bytes = 8 B/proposal + N*(nq+4*ncls) (SURVEY.md 8d); the state is "
+                                 "LDS-resident so real HBM traffic is ~N*(nq+4*ncls+8) B per launch and the binding "
+                                 "resource is VALU issue (Philox), see DESIGN.md"},
+            "mixing": {"frac_syndromes_past_burn_in": float(np.mean(samples > 0)),
+                       "mean_tops0": float(np.mean(tops0))},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(init_h, args.p, Nc, args.iters, args.seed)
+        print(json.dumps(out))
+    L_.lib().qecmc_plan_destroy(plan)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,150 @@
+/*
+ * qecmc.h -- C-ABI of the MI355X-native MCMC equivalence-class sampler.
+ *
+ * This is the drop-in boundary for ONE hot path of
+ * QEC-project-2020/MCMC-QEC-toric-RL: the Metropolis / parallel-tempering
+ * sampler of src/mcmc.py, the code-model stencils it calls
+ * (src/toric_model.py ...) and its caller decoders.PTEQ.  The reference has no
+ * FFI of its own (it is pure Python + numba); the boundary below is what a
+ * `ctypes.CDLL` binding on the reference side would load (INTEGRATION.md shows
+ * that binding).  Every entry point cites the reference interface it replaces
+ * (file:line relative to the reference tree).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; the caller owns every buffer and the
+ *     library keeps no pointer after a call returns (plans excepted);
+ *   - return 0 on success, a negative qecmc_status on error with a message in
+ *     qecmc_last_error() (thread-local); no C++ exception crosses the ABI;
+ *   - Pauli encoding 0=I 1=X 2=Y 3=Z, composition = XOR (toric_model.py:277);
+ *     toric state = uint8[2][L][L] C-order (toric_model.py:12), nq = 2*L*L;
+ *   - every compute entry point runs on the GPU (HIP, gfx950).  There is no
+ *     CPU fallback: without a device the call fails with QECMC_ERR_NO_DEVICE.
+ *   - `_dev` entry points take DEVICE pointers and a hipStream_t (as void*),
+ *     enqueue asynchronously and allocate nothing; the others take HOST
+ *     pointers and do H2D + kernel + D2H + synchronise themselves.
+ */
+#ifndef QECMC_H
+#define QECMC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QECMC_ABI_VERSION 1
+
+typedef enum qecmc_status {
+    QECMC_OK = 0,
+    QECMC_ERR_INVALID = -1,     /* bad argument (message says which) */
+    QECMC_ERR_NO_DEVICE = -2,   /* no HIP device / device index out of range */
+    QECMC_ERR_HIP = -3,         /* a HIP runtime call failed */
+    QECMC_ERR_UNSUPPORTED = -4  /* valid request this build has no kernel for */
+} qecmc_status;
+
+typedef enum qecmc_code { QECMC_TORIC = 0, QECMC_XZZX = 1, QECMC_ROTATED = 2 } qecmc_code;
+typedef enum qecmc_scan { QECMC_SCAN_RANDOM = 0, QECMC_SCAN_CHECKERBOARD = 1 } qecmc_scan;
+typedef enum qecmc_noise { QECMC_NOISE_DEPOLARIZING = 0, QECMC_NOISE_BIASED = 1 } qecmc_noise;
+typedef enum qecmc_conv { QECMC_CONV_NONE = 0, QECMC_CONV_ERROR_BASED = 1 } qecmc_conv;
+
+/* Mirrors the keyword arguments of decoders.PTEQ (decoders.py:25) plus what the
+ * batched GPU call needs.  Set abi_size = sizeof(qecmc_params). */
+typedef struct qecmc_params {
+    uint32_t abi_size;
+    int32_t  code;          /* qecmc_code */
+    int32_t  L;             /* system_size (toric_model.py:10) */
+    int32_t  Nc;            /* number of chains in the ladder (decoders.py:30; Q7: default L) */
+    int32_t  noise;         /* qecmc_noise */
+    int32_t  scan;          /* qecmc_scan: RANDOM = the reference's chain (src/mcmc.py:19-43) */
+    int32_t  conv_mode;     /* qecmc_conv (decoders.py:74) */
+    int32_t  device;        /* HIP device ordinal */
+    uint64_t iters;         /* proposals per chain between swap sweeps (decoders.py:25 iters=10) */
+    uint64_t steps;         /* ladder steps (decoders.py:25 steps) */
+    int32_t  tops_burn;     /* decoders.py:63 */
+    int32_t  TOPS;          /* decoders.py:74 */
+    int32_t  SEQ;           /* decoders.py:78 */
+    int32_t  reserved0;
+    double   eps;           /* decoders.py:102 */
+    double   p;             /* bottom-chain error rate (mcmc.py:50 p_bottom) */
+    double   eta;           /* bias (mcmc_biased.py:11); unused for depolarizing */
+    double   p_logical;     /* top-chain logical proposal rate (decoders.py:52 passes 0.5) */
+    uint64_t seed;          /* Philox key */
+    uint32_t first_syndrome;/* global index of syndrome 0 of this call: results do not
+                               depend on how a batch is sharded over GPUs */
+    uint32_t flags;         /* reserved, 0 */
+} qecmc_params;
+
+typedef struct qecmc_stats {
+    uint64_t proposals;     /* Metropolis trials executed (all chains, all syndromes) */
+    uint64_t swap_tests;
+    double   kernel_ms;     /* HIP-event time of the sampler kernel(s) */
+    double   total_ms;      /* wall time incl. H2D/D2H for host-pointer calls */
+} qecmc_stats;
+
+int         qecmc_abi_version(void);
+const char *qecmc_last_error(void);
+int         qecmc_device_count(void);      /* 0 when no GPU is visible */
+
+/* ---- stencil primitives (batched; N states per call, host pointers) -------
+ * Each runs the same __device__ stencil code the sampler kernels use. */
+
+/* Toric_code.apply_stabilizer -> _apply_stabilizer, toric_model.py:40-41,256-284.
+ * out[i] = in[i] with stabilizer (rows[i], cols[i], ops[i]) applied; dE[i] = error-count change. */
+int qecmc_apply_stabilizer(int code, int L, uint64_t N, const uint8_t *in, uint8_t *out,
+                           const int32_t *rows, const int32_t *cols, const int32_t *ops, int32_t *dE);
+/* _apply_logical, toric_model.py:179-225 (layer is ignored by non-toric codes). */
+int qecmc_apply_logical(int code, int L, uint64_t N, const uint8_t *in, uint8_t *out,
+                        const int32_t *ops, const int32_t *layers, const int32_t *xpos,
+                        const int32_t *zpos, int32_t *dE);
+/* Toric_code.count_errors -> _count_errors, toric_model.py:33-34,174-176. */
+int qecmc_count_errors(int code, int L, uint64_t N, const uint8_t *in, int64_t *n);
+/* define_equivalence_class, toric_model.py:52-53,317-351. */
+int qecmc_eq_class(int code, int L, uint64_t N, const uint8_t *in, int32_t *cls);
+/* to_class, toric_model.py:55-56,354-377. */
+int qecmc_to_class(int code, int L, uint64_t N, const uint8_t *in, uint8_t *out, const int32_t *eq);
+/* Toric_code.syndrom, toric_model.py:58-101: defects_out uint8[N][2][L][L]. */
+int qecmc_syndrome(int code, int L, uint64_t N, const uint8_t *in, uint8_t *defects_out);
+
+/* ---- chain / ladder on caller-owned state (host pointers) ----------------- */
+
+/* Chain.update_chain(iters), src/mcmc.py:19-43, on N independent chains.
+ * Chain i draws from Philox stream (syndrome = first_syndrome+i, slot, proposals
+ * k0 .. k0+iters-1).  p_logical != 0 selects the top-chain branch (mcmc.py:20). */
+int qecmc_chain_update(int code, int L, uint64_t N, uint8_t *states_inout, double p, double p_logical,
+                       uint64_t iters, uint64_t seed, uint32_t first_syndrome, uint32_t slot, uint64_t k0);
+
+/* Ladder.step(iters) x nsteps, src/mcmc.py:94-103, on N ladders in slot order.
+ * states uint8[N][Nc][nq], flags uint8[N][Nc], tops0 uint32[N]; step0 / prop0 =
+ * ladder steps / proposals per slot already done (Philox addressing).  Uses
+ * params->{code,L,Nc,p,p_logical,seed,first_syndrome,device}. */
+int qecmc_ladder_step(const qecmc_params *params, uint64_t N, uint8_t *states_inout, uint8_t *flags_inout,
+                      uint32_t *tops0_inout, uint64_t iters, uint64_t nsteps, uint64_t step0, uint64_t prop0);
+
+/* ---- the batched hot path: decoders.PTEQ (decoders.py:25-89) on N syndromes */
+
+/* Host-pointer form.  init uint8[N][nq] (one seed configuration per syndrome,
+ * generate_data.py:131-138); counts_out uint32[N][ncls] = eq[since_burn]
+ * (decoders.py:66-67); samples_out uint32[N] = since_burn+1 or 0 when the burn-in
+ * never ended (A10 "burn-in trap"); tops0_out uint32[N] (nullable);
+ * final_states_out uint8[N][Nc][nq] in slot order (nullable); stats nullable. */
+int qecmc_pteq_batch(const qecmc_params *params, const uint8_t *init, uint64_t N, uint32_t *counts_out,
+                     uint32_t *samples_out, uint32_t *tops0_out, uint8_t *final_states_out,
+                     qecmc_stats *stats_out);
+
+/* Plan + device-pointer form: build once (validates, uploads threshold tables),
+ * then launch asynchronously on a caller stream with buffers already in HBM. */
+typedef struct qecmc_plan qecmc_plan;
+int qecmc_plan_create(const qecmc_params *params, qecmc_plan **plan_out);
+int qecmc_plan_destroy(qecmc_plan *plan);
+int qecmc_pteq_launch_dev(qecmc_plan *plan, const void *d_init, uint64_t N, uint32_t first_syndrome,
+                          void *d_counts, void *d_samples, void *d_tops0 /*nullable*/,
+                          void *d_final_states /*nullable*/, void *hip_stream);
+/* Bytes of dynamic LDS and threads per workgroup the plan's kernel uses (for reports). */
+int qecmc_plan_info(const qecmc_plan *plan, uint32_t *lds_bytes, uint32_t *block_threads,
+                    uint32_t *syndromes_per_block);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

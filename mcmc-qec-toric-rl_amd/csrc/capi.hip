@@ -1,0 +1,441 @@
+// C-ABI of libqecmc (include/qecmc.h): argument checking, host-side threshold
+// tables, device buffers and kernel launches.  No CPU compute fallback: every
+// entry point that computes needs a HIP device.
+#include "../../include/qecmc.h"
+
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+
+using namespace qecmc;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return fail(QECMC_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+int use_device(int dev)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(QECMC_ERR_NO_DEVICE, "no HIP device visible: libqecmc has no CPU fallback");
+    if (dev < 0 || dev >= n) return fail(QECMC_ERR_NO_DEVICE, "device %d out of range (0..%d)", dev, n - 1);
+    HIP_TRY(hipSetDevice(dev));
+    return 0;
+}
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+int check_code_L(int code, int L)
+{
+    if (code != QECMC_TORIC) return fail(QECMC_ERR_UNSUPPORTED, "code %d: only the toric code (0) has kernels in this build", code);
+    if (L < 2 || L > 64) return fail(QECMC_ERR_INVALID, "L=%d out of range [2,64]", L);
+    return 0;
+}
+
+// ceil(v * 2^32) as used by every integer acceptance test: u < v  <=>  x < ceil(v*2^32) for u = x*2^-32
+uint64_t thr64(double v)
+{
+    if (!(v < 1.0)) return 1ull << 32;
+    if (!(v > 0.0)) return 0;
+    return (uint64_t)std::ceil(v * 4294967296.0);
+}
+uint32_t thr32(double v)
+{
+    const uint64_t t = thr64(v);
+    return t > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)t;
+}
+
+// np.linspace(p_bottom, p_top, Nc) and Ladder.p_diff (src/mcmc.py:65,69)
+void ladder_probabilities(double p_bottom, double p_top, int Nc, std::vector<double> &pl, std::vector<double> &pd)
+{
+    pl.assign(Nc, p_bottom);
+    pd.assign(Nc > 1 ? Nc - 1 : 0, 1.0);
+    if (Nc > 1) {
+        const double step = (p_top - p_bottom) / (double)(Nc - 1);
+        for (int i = 0; i < Nc; ++i) pl[i] = (double)i * step + p_bottom;
+        pl[Nc - 1] = p_top;
+    }
+    for (int i = 0; i + 1 < Nc; ++i) pd[i] = (pl[i] * (1 - pl[i + 1])) / (pl[i + 1] * (1 - pl[i]));
+}
+
+inline double chain_factor(double p) { return (p / 3.0) / (1.0 - p); }   // src/mcmc.py:16
+
+// XOR masks of the toric logical operators on the 2-bit packed state
+// (toric_model.py:192-223): kind 0 = X on layer-0 row, 1 = Z on layer-0 column,
+// 2 = X on layer-1 column, 3 = Z on layer-1 row; position L = identity.
+std::vector<uint32_t> toric_logical_masks(int L, int W)
+{
+    const int LL = L * L;
+    std::vector<uint32_t> m((size_t)4 * (L + 1) * W, 0u);
+    auto set = [&](int kind, int pos, int q, uint32_t op) { m[((size_t)kind * (L + 1) + pos) * W + (q >> 4)] ^= op << ((q & 15) * 2); };
+    for (int pos = 0; pos < L; ++pos)
+        for (int i = 0; i < L; ++i) {
+            set(0, pos, pos * L + i, 1);
+            set(1, pos, i * L + pos, 3);
+            set(2, pos, LL + i * L + pos, 1);
+            set(3, pos, LL + pos * L + i, 3);
+        }
+    return m;
+}
+
+}  // namespace
+
+struct qecmc_plan {
+    qecmc_params prm;
+    LadderArgs args;
+    DevBuf swap_thr, lmask, acc_top;
+    size_t lds_bytes;
+};
+
+namespace {
+
+int validate_params(const qecmc_params *p)
+{
+    if (!p) return fail(QECMC_ERR_INVALID, "params is NULL");
+    if (p->abi_size != sizeof(qecmc_params))
+        return fail(QECMC_ERR_INVALID, "params->abi_size=%u, this library expects %zu", p->abi_size, sizeof(qecmc_params));
+    if (int rc = check_code_L(p->code, p->L)) return rc;
+    if (p->Nc < 1 || p->Nc > kMaxNc) return fail(QECMC_ERR_INVALID, "Nc=%d out of range [1,%d]", p->Nc, kMaxNc);
+    if (!(p->p > 0.0) || !(p->p <= 0.75)) return fail(QECMC_ERR_INVALID, "p=%g must be in (0, 0.75]", p->p);
+    if (!(p->p_logical >= 0.0) || !(p->p_logical <= 1.0)) return fail(QECMC_ERR_INVALID, "p_logical=%g must be in [0,1]", p->p_logical);
+    if (p->noise != QECMC_NOISE_DEPOLARIZING) return fail(QECMC_ERR_UNSUPPORTED, "noise model %d not built yet", p->noise);
+    if (p->scan != QECMC_SCAN_RANDOM) return fail(QECMC_ERR_UNSUPPORTED, "scan mode %d not built yet", p->scan);
+    if (p->conv_mode != QECMC_CONV_NONE) return fail(QECMC_ERR_UNSUPPORTED, "conv_mode %d not built yet (use fixed steps)", p->conv_mode);
+    if (p->iters == 0 || p->iters > 0xFFFFFFFFull) return fail(QECMC_ERR_INVALID, "iters out of range");
+    if (p->tops_burn < 0) return fail(QECMC_ERR_INVALID, "tops_burn must be >= 0");
+    return 0;
+}
+
+int build_plan(const qecmc_params *p, qecmc_plan *pl)
+{
+    pl->prm = *p;
+    LadderArgs &a = pl->args;
+    std::memset(&a, 0, sizeof a);
+    const int L = p->L, Nc = p->Nc, nq = 2 * L * L, W = (nq + 15) / 16, ncls = 16;
+    a.L = L; a.Nc = Nc; a.W = W; a.nq = nq; a.ncls = ncls;
+    a.iters = (uint32_t)p->iters;
+    a.seed_lo = (uint32_t)p->seed; a.seed_hi = (uint32_t)(p->seed >> 32);
+    a.tops_burn = (uint32_t)p->tops_burn;
+    a.thr_logical = p->p_logical > 0 ? thr64(p->p_logical) : 0;
+    pl->lds_bytes = ladder_lds_bytes(L, Nc, W, ncls);
+    if (pl->lds_bytes > 160 * 1024)
+        return fail(QECMC_ERR_UNSUPPORTED, "L=%d Nc=%d needs %zu B of LDS per workgroup (> 160 KiB)", L, Nc, pl->lds_bytes);
+
+    std::vector<double> pladder, pdiff;
+    ladder_probabilities(p->p, 0.75, Nc, pladder, pdiff);                  // mcmc.py:62-69
+    for (int c = 0; c < Nc; ++c) {
+        const double f = chain_factor(pladder[c]);
+        if (f >= 1.0) a.acc_all_mask |= 1u << c;
+        for (int d = 1; d <= 4; ++d) a.acc_thr[c][d - 1] = thr32(std::pow(f, (double)d));   // mcmc.py:42
+    }
+    std::vector<uint32_t> top_tbl(nq + 1, 0u);                             // mcmc.py:34 for a top chain below p = 0.75
+    for (int d = 1; d <= nq; ++d) top_tbl[d] = thr32(std::pow(chain_factor(pladder[Nc - 1]), (double)d));
+    std::vector<uint64_t> sw((size_t)(Nc > 1 ? Nc - 1 : 1) * (nq + 1), 0);
+    for (int i = 0; i + 1 < Nc; ++i)
+        for (int d = 0; d <= nq; ++d) sw[(size_t)i * (nq + 1) + d] = thr64(std::pow(pdiff[i], (double)d));   // mcmc.py:149
+    const std::vector<uint32_t> lm = toric_logical_masks(L, W);
+    HIP_TRY(pl->swap_thr.alloc(sw.size() * sizeof(uint64_t)));
+    HIP_TRY(pl->lmask.alloc(lm.size() * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpy(pl->swap_thr.p, sw.data(), sw.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(pl->lmask.p, lm.data(), lm.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(pl->acc_top.alloc(top_tbl.size() * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpy(pl->acc_top.p, top_tbl.data(), top_tbl.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    a.acc_tbl_top = pl->acc_top.as<uint32_t>();
+    a.swap_thr = pl->swap_thr.as<uint64_t>();
+    a.lmask = pl->lmask.as<uint32_t>();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int qecmc_abi_version(void) { return QECMC_ABI_VERSION; }
+const char *qecmc_last_error(void) { return g_err.c_str(); }
+int qecmc_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ---------------------------------------------------------------- primitives
+#define PRIM_PROLOGUE()                                   \
+    if (int rc = check_code_L(code, L)) return rc;        \
+    if (int rc = use_device(0)) return rc;                \
+    const size_t nq = (size_t)2 * L * L;                  \
+    (void)nq;                                             \
+    if (N == 0) return 0
+
+int qecmc_apply_stabilizer(int code, int L, uint64_t N, const uint8_t *in, uint8_t *out, const int32_t *rows,
+                           const int32_t *cols, const int32_t *ops, int32_t *dE)
+{
+    PRIM_PROLOGUE();
+    if (!in || !out || !rows || !cols || !ops || !dE) return fail(QECMC_ERR_INVALID, "NULL buffer");
+    for (uint64_t i = 0; i < N; ++i) {
+        if (rows[i] < 0 || rows[i] >= L || cols[i] < 0 || cols[i] >= L) return fail(QECMC_ERR_INVALID, "stabilizer %llu: (row,col)=(%d,%d) outside [0,%d)", (unsigned long long)i, rows[i], cols[i], L);
+        if (ops[i] != 1 && ops[i] != 3) return fail(QECMC_ERR_INVALID, "stabilizer %llu: operator %d is not 1 (X) or 3 (Z)", (unsigned long long)i, ops[i]);
+    }
+    DevBuf din, dout, dr, dc, dop, dd;
+    HIP_TRY(din.alloc(N * nq)); HIP_TRY(dout.alloc(N * nq));
+    HIP_TRY(dr.alloc(N * 4)); HIP_TRY(dc.alloc(N * 4)); HIP_TRY(dop.alloc(N * 4)); HIP_TRY(dd.alloc(N * 4));
+    HIP_TRY(hipMemcpy(din.p, in, N * nq, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dr.p, rows, N * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dc.p, cols, N * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dop.p, ops, N * 4, hipMemcpyHostToDevice));
+    HIP_TRY(launch_apply_stabilizer(L, N, din.as<uint8_t>(), dout.as<uint8_t>(), dr.as<int32_t>(), dc.as<int32_t>(), dop.as<int32_t>(), dd.as<int32_t>(), 0));
+    HIP_TRY(hipMemcpy(out, dout.p, N * nq, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(dE, dd.p, N * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int qecmc_apply_logical(int code, int L, uint64_t N, const uint8_t *in, uint8_t *out, const int32_t *ops,
+                        const int32_t *layers, const int32_t *xpos, const int32_t *zpos, int32_t *dE)
+{
+    PRIM_PROLOGUE();
+    if (!in || !out || !ops || !layers || !xpos || !zpos || !dE) return fail(QECMC_ERR_INVALID, "NULL buffer");
+    for (uint64_t i = 0; i < N; ++i) {
+        if (ops[i] < 0 || ops[i] > 3) return fail(QECMC_ERR_INVALID, "logical %llu: operator %d outside [0,3]", (unsigned long long)i, ops[i]);
+        if (layers[i] != 0 && layers[i] != 1) return fail(QECMC_ERR_INVALID, "logical %llu: layer %d is not 0 or 1", (unsigned long long)i, layers[i]);
+        if (xpos[i] < 0 || xpos[i] >= L || zpos[i] < 0 || zpos[i] >= L) return fail(QECMC_ERR_INVALID, "logical %llu: position outside [0,%d)", (unsigned long long)i, L);
+    }
+    DevBuf din, dout, d0, d1, d2, d3, dd;
+    HIP_TRY(din.alloc(N * nq)); HIP_TRY(dout.alloc(N * nq));
+    HIP_TRY(d0.alloc(N * 4)); HIP_TRY(d1.alloc(N * 4)); HIP_TRY(d2.alloc(N * 4)); HIP_TRY(d3.alloc(N * 4)); HIP_TRY(dd.alloc(N * 4));
+    HIP_TRY(hipMemcpy(din.p, in, N * nq, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d0.p, ops, N * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d1.p, layers, N * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d2.p, xpos, N * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d3.p, zpos, N * 4, hipMemcpyHostToDevice));
+    HIP_TRY(launch_apply_logical(L, N, din.as<uint8_t>(), dout.as<uint8_t>(), d0.as<int32_t>(), d1.as<int32_t>(), d2.as<int32_t>(), d3.as<int32_t>(), dd.as<int32_t>(), 0));
+    HIP_TRY(hipMemcpy(out, dout.p, N * nq, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(dE, dd.p, N * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int qecmc_count_errors(int code, int L, uint64_t N, const uint8_t *in, int64_t *n)
+{
+    PRIM_PROLOGUE();
+    if (!in || !n) return fail(QECMC_ERR_INVALID, "NULL buffer");
+    DevBuf din, dn;
+    HIP_TRY(din.alloc(N * nq)); HIP_TRY(dn.alloc(N * 8));
+    HIP_TRY(hipMemcpy(din.p, in, N * nq, hipMemcpyHostToDevice));
+    HIP_TRY(launch_count_errors((int)nq, N, din.as<uint8_t>(), dn.as<int64_t>(), 0));
+    HIP_TRY(hipMemcpy(n, dn.p, N * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int qecmc_eq_class(int code, int L, uint64_t N, const uint8_t *in, int32_t *cls)
+{
+    PRIM_PROLOGUE();
+    if (!in || !cls) return fail(QECMC_ERR_INVALID, "NULL buffer");
+    DevBuf din, dc;
+    HIP_TRY(din.alloc(N * nq)); HIP_TRY(dc.alloc(N * 4));
+    HIP_TRY(hipMemcpy(din.p, in, N * nq, hipMemcpyHostToDevice));
+    HIP_TRY(launch_eq_class(L, N, din.as<uint8_t>(), dc.as<int32_t>(), 0));
+    HIP_TRY(hipMemcpy(cls, dc.p, N * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int qecmc_to_class(int code, int L, uint64_t N, const uint8_t *in, uint8_t *out, const int32_t *eq)
+{
+    PRIM_PROLOGUE();
+    if (!in || !out || !eq) return fail(QECMC_ERR_INVALID, "NULL buffer");
+    for (uint64_t i = 0; i < N; ++i)
+        if (eq[i] < 0 || eq[i] > 15) return fail(QECMC_ERR_INVALID, "to_class %llu: class %d outside [0,16)", (unsigned long long)i, eq[i]);
+    DevBuf din, dout, de;
+    HIP_TRY(din.alloc(N * nq)); HIP_TRY(dout.alloc(N * nq)); HIP_TRY(de.alloc(N * 4));
+    HIP_TRY(hipMemcpy(din.p, in, N * nq, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(de.p, eq, N * 4, hipMemcpyHostToDevice));
+    HIP_TRY(launch_to_class(L, N, din.as<uint8_t>(), dout.as<uint8_t>(), de.as<int32_t>(), 0));
+    HIP_TRY(hipMemcpy(out, dout.p, N * nq, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int qecmc_syndrome(int code, int L, uint64_t N, const uint8_t *in, uint8_t *defects_out)
+{
+    PRIM_PROLOGUE();
+    if (!in || !defects_out) return fail(QECMC_ERR_INVALID, "NULL buffer");
+    DevBuf din, dout;
+    HIP_TRY(din.alloc(N * nq)); HIP_TRY(dout.alloc(N * nq));
+    HIP_TRY(hipMemcpy(din.p, in, N * nq, hipMemcpyHostToDevice));
+    HIP_TRY(launch_syndrome(L, N, din.as<uint8_t>(), dout.as<uint8_t>(), 0));
+    HIP_TRY(hipMemcpy(defects_out, dout.p, N * nq, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---------------------------------------------------------------- chain / ladder
+int qecmc_chain_update(int code, int L, uint64_t N, uint8_t *states_inout, double p, double p_logical,
+                       uint64_t iters, uint64_t seed, uint32_t first_syndrome, uint32_t slot, uint64_t k0)
+{
+    PRIM_PROLOGUE();
+    if (!states_inout) return fail(QECMC_ERR_INVALID, "NULL buffer");
+    if (!(p > 0.0) || !(p <= 0.75)) return fail(QECMC_ERR_INVALID, "p=%g must be in (0, 0.75]", p);
+    if (!(p_logical >= 0.0) || !(p_logical <= 1.0)) return fail(QECMC_ERR_INVALID, "p_logical=%g must be in [0,1]", p_logical);
+    if (slot >= 0x100u) return fail(QECMC_ERR_INVALID, "slot %u collides with the swap stream id", slot);
+    ChainArgs a;
+    std::memset(&a, 0, sizeof a);
+    const double f = chain_factor(p);
+    std::vector<uint32_t> tbl(nq + 1, 0u);
+    for (size_t d = 1; d <= nq; ++d) tbl[d] = thr32(std::pow(f, (double)d));
+    DevBuf ds, dt;
+    HIP_TRY(ds.alloc(N * nq)); HIP_TRY(dt.alloc(tbl.size() * 4));
+    HIP_TRY(hipMemcpy(ds.p, states_inout, N * nq, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dt.p, tbl.data(), tbl.size() * 4, hipMemcpyHostToDevice));
+    a.states = ds.as<uint8_t>(); a.N = N; a.iters = iters; a.k0 = k0;
+    a.thr_logical = p_logical > 0 ? thr64(p_logical) : 0;
+    a.acc_tbl = dt.as<uint32_t>(); a.acc_all = f >= 1.0;
+    a.first_syndrome = first_syndrome; a.slot = slot;
+    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.L = L;
+    HIP_TRY(launch_chain_update(a, 0));
+    HIP_TRY(hipMemcpy(states_inout, ds.p, N * nq, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int qecmc_ladder_step(const qecmc_params *params, uint64_t N, uint8_t *states_inout, uint8_t *flags_inout,
+                      uint32_t *tops0_inout, uint64_t iters, uint64_t nsteps, uint64_t step0, uint64_t prop0)
+{
+    if (!params) return fail(QECMC_ERR_INVALID, "params is NULL");
+    qecmc_params p = *params;
+    p.iters = iters;
+    p.conv_mode = QECMC_CONV_NONE;
+    if (int rc = validate_params(&p)) return rc;
+    if (!states_inout || !flags_inout || !tops0_inout) return fail(QECMC_ERR_INVALID, "NULL buffer");
+    if (int rc = use_device(p.device)) return rc;
+    if (N == 0) return 0;
+    qecmc_plan pl;
+    if (int rc = build_plan(&p, &pl)) return rc;
+    const size_t nq = pl.args.nq, Nc = pl.args.Nc;
+    DevBuf ds, df, dt;
+    HIP_TRY(ds.alloc(N * Nc * nq)); HIP_TRY(df.alloc(N * Nc)); HIP_TRY(dt.alloc(N * 4));
+    HIP_TRY(hipMemcpy(ds.p, states_inout, N * Nc * nq, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(df.p, flags_inout, N * Nc, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dt.p, tops0_inout, N * 4, hipMemcpyHostToDevice));
+    LadderArgs a = pl.args;
+    a.states = ds.as<uint8_t>(); a.flags = df.as<uint8_t>(); a.tops0 = dt.as<uint32_t>();
+    a.N = N; a.first_syndrome = p.first_syndrome; a.step0 = step0; a.prop0 = prop0; a.nsteps = nsteps;
+    a.resume = 1; a.write_states = 1;
+    HIP_TRY(launch_ladder_rs_toric(a, 0));
+    HIP_TRY(hipMemcpy(states_inout, ds.p, N * Nc * nq, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(flags_inout, df.p, N * Nc, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(tops0_inout, dt.p, N * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---------------------------------------------------------------- PTEQ batch
+int qecmc_plan_create(const qecmc_params *params, qecmc_plan **plan_out)
+{
+    if (!plan_out) return fail(QECMC_ERR_INVALID, "plan_out is NULL");
+    *plan_out = nullptr;
+    if (int rc = validate_params(params)) return rc;
+    if (int rc = use_device(params->device)) return rc;
+    qecmc_plan *pl = new (std::nothrow) qecmc_plan();
+    if (!pl) return fail(QECMC_ERR_INVALID, "out of host memory");
+    if (int rc = build_plan(params, pl)) { delete pl; return rc; }
+    *plan_out = pl;
+    return 0;
+}
+
+int qecmc_plan_destroy(qecmc_plan *plan)
+{
+    delete plan;
+    return 0;
+}
+
+int qecmc_plan_info(const qecmc_plan *plan, uint32_t *lds_bytes, uint32_t *block_threads, uint32_t *syndromes_per_block)
+{
+    if (!plan) return fail(QECMC_ERR_INVALID, "plan is NULL");
+    if (lds_bytes) *lds_bytes = (uint32_t)plan->lds_bytes;
+    if (block_threads) *block_threads = (uint32_t)plan->args.Nc * 64u;
+    if (syndromes_per_block) *syndromes_per_block = kSynPerBlock;
+    return 0;
+}
+
+int qecmc_pteq_launch_dev(qecmc_plan *plan, const void *d_init, uint64_t N, uint32_t first_syndrome, void *d_counts,
+                          void *d_samples, void *d_tops0, void *d_final_states, void *hip_stream)
+{
+    if (!plan) return fail(QECMC_ERR_INVALID, "plan is NULL");
+    if (N == 0) return 0;
+    if (!d_init || !d_counts || !d_samples) return fail(QECMC_ERR_INVALID, "NULL device buffer");
+    if (N + first_syndrome > 0xFFFFFFFFull) return fail(QECMC_ERR_INVALID, "global syndrome index exceeds 32 bits");
+    LadderArgs a = plan->args;
+    a.init = static_cast<const uint8_t *>(d_init);
+    a.counts = static_cast<uint32_t *>(d_counts);
+    a.samples = static_cast<uint32_t *>(d_samples);
+    a.tops0 = static_cast<uint32_t *>(d_tops0);
+    a.states = static_cast<uint8_t *>(d_final_states);
+    a.write_states = d_final_states != nullptr;
+    a.N = N; a.first_syndrome = first_syndrome;
+    a.step0 = 0; a.prop0 = 0; a.nsteps = plan->prm.steps; a.resume = 0;
+    HIP_TRY(launch_ladder_rs_toric(a, static_cast<hipStream_t>(hip_stream)));
+    return 0;
+}
+
+int qecmc_pteq_batch(const qecmc_params *params, const uint8_t *init, uint64_t N, uint32_t *counts_out,
+                     uint32_t *samples_out, uint32_t *tops0_out, uint8_t *final_states_out, qecmc_stats *stats_out)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    qecmc_plan *pl = nullptr;
+    if (int rc = qecmc_plan_create(params, &pl)) return rc;
+    struct Guard { qecmc_plan *p; ~Guard() { delete p; } } guard{pl};
+    if (N == 0) return 0;
+    if (!init || !counts_out || !samples_out) return fail(QECMC_ERR_INVALID, "NULL buffer");
+    const size_t nq = pl->args.nq, Nc = pl->args.Nc, ncls = pl->args.ncls;
+    DevBuf di, dc, ds, dt, df;
+    HIP_TRY(di.alloc(N * nq)); HIP_TRY(dc.alloc(N * ncls * 4)); HIP_TRY(ds.alloc(N * 4)); HIP_TRY(dt.alloc(N * 4));
+    if (final_states_out) HIP_TRY(df.alloc(N * Nc * nq));
+    HIP_TRY(hipMemcpy(di.p, init, N * nq, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, 0));
+    int rc = qecmc_pteq_launch_dev(pl, di.p, N, params->first_syndrome, dc.p, ds.p, dt.p, final_states_out ? df.p : nullptr, nullptr);
+    if (rc) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
+    HIP_TRY(hipEventRecord(e1, 0));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    HIP_TRY(hipMemcpy(counts_out, dc.p, N * ncls * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(samples_out, ds.p, N * 4, hipMemcpyDeviceToHost));
+    if (tops0_out) HIP_TRY(hipMemcpy(tops0_out, dt.p, N * 4, hipMemcpyDeviceToHost));
+    if (final_states_out) HIP_TRY(hipMemcpy(final_states_out, df.p, N * Nc * nq, hipMemcpyDeviceToHost));
+    if (stats_out) {
+        stats_out->proposals = N * Nc * params->iters * params->steps;
+        stats_out->swap_tests = N * (Nc - 1) * params->steps;
+        stats_out->kernel_ms = ms;
+        stats_out->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,62 @@
+// Internal interface between the C-ABI layer (capi.hip) and the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace qecmc {
+
+constexpr int kMaxNc = 16;          // one wavefront per ladder slot, <= 1024 threads per workgroup
+constexpr int kSynPerBlock = 64;    // one lane per syndrome
+
+// Arguments of the random-scan ladder kernel (passed by value; fits the kernarg segment).
+struct LadderArgs {
+    // inputs / outputs (device pointers)
+    const uint8_t *init;      // [N][nq]           fresh start (resume == 0)
+    uint8_t *states;          // [N][Nc][nq]       resume input and/or final-state output (nullable)
+    uint8_t *flags;           // [N][Nc]           resume in/out (nullable)
+    uint32_t *tops0;          // [N]               resume in / out (nullable)
+    uint32_t *counts;         // [N][ncls]         out (nullable)
+    uint32_t *samples;        // [N]               out (nullable)
+    const uint64_t *swap_thr; // [Nc-1][nq+1]      ceil(p_diff[i]^d * 2^32)
+    const uint32_t *lmask;    // [4][L+1][W]       logical-operator XOR masks (row L = identity)
+    const uint32_t *acc_tbl_top; // [nq+1]          ceil(f_top^dE * 2^32): top slot below p = 0.75 (Nc == 1 only)
+    uint64_t N;
+    uint64_t step0, prop0, nsteps;
+    uint64_t thr_logical;     // ceil(p_logical * 2^32)
+    uint32_t iters;
+    uint32_t first_syndrome;
+    uint32_t seed_lo, seed_hi;
+    uint32_t tops_burn;
+    uint32_t acc_all_mask;    // bit c: slot c accepts every proposal (f >= 1, mcmc.py:30)
+    uint32_t acc_thr[kMaxNc][4];   // ceil(f_c^dE * 2^32), dE = 1..4
+    int L, Nc, W, nq, ncls;
+    int resume;               // 0: replicate init into every slot (mcmc.py:72); 1: load states/flags/tops0
+    int write_states;
+};
+
+size_t ladder_lds_bytes(int L, int Nc, int W, int ncls);
+hipError_t launch_ladder_rs_toric(const LadderArgs &a, hipStream_t stream);
+
+// byte-state primitive kernels (primitives.hip); all pointers are device pointers
+hipError_t launch_apply_stabilizer(int L, uint64_t N, const uint8_t *in, uint8_t *out, const int32_t *rows,
+                                   const int32_t *cols, const int32_t *ops, int32_t *dE, hipStream_t s);
+hipError_t launch_apply_logical(int L, uint64_t N, const uint8_t *in, uint8_t *out, const int32_t *ops,
+                                const int32_t *layers, const int32_t *xpos, const int32_t *zpos, int32_t *dE,
+                                hipStream_t s);
+hipError_t launch_count_errors(int nq, uint64_t N, const uint8_t *in, int64_t *n, hipStream_t s);
+hipError_t launch_eq_class(int L, uint64_t N, const uint8_t *in, int32_t *cls, hipStream_t s);
+hipError_t launch_to_class(int L, uint64_t N, const uint8_t *in, uint8_t *out, const int32_t *eq, hipStream_t s);
+hipError_t launch_syndrome(int L, uint64_t N, const uint8_t *in, uint8_t *defects, hipStream_t s);
+
+struct ChainArgs {
+    uint8_t *states;          // [N][nq] in/out
+    uint64_t N, iters, k0;
+    uint64_t thr_logical;     // 0 => p_logical == 0 (non-top branch, mcmc.py:37)
+    const uint32_t *acc_tbl;  // [nq+1] ceil(f^dE * 2^32) for dE >= 1 (entry 0 unused)
+    uint32_t acc_all;         // f >= 1: every proposal is accepted (mcmc.py:30)
+    uint32_t first_syndrome, slot, seed_lo, seed_hi;
+    int L;
+};
+hipError_t launch_chain_update(const ChainArgs &a, hipStream_t s);
+
+}  // namespace qecmc

@@ -1,0 +1,50 @@
+// Philox4x32-10 counter-based RNG (Salmon et al., SC'11) for gfx950.
+// One call = one 128-bit block = the four uniforms of one Metropolis proposal
+// (row, col, op, accept; src/mcmc.py:38-42 draws exactly four per proposal).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace qecmc {
+
+struct u32x4 { uint32_t x, y, z, w; };
+
+// Counter layout (DESIGN.md "RNG addressing"):
+//   c0 = k[31:0], c1 = k[47:32] | sub<<16, c2 = global syndrome index, c3 = stream id
+//   key = 64-bit seed.  k = proposal index of the slot (or ladder-step index for the
+//   swap stream), sub = block number within one proposal / swap sweep.
+constexpr uint32_t kSwapStream = 0x100u;
+
+__host__ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                        uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1;
+        c3 = (uint32_t)p0;
+        c0 = n0;
+        c2 = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return u32x4{c0, c1, c2, c3};
+}
+
+__host__ __device__ __forceinline__ u32x4 philox_block(uint64_t k, uint32_t sub, uint32_t syndrome,
+                                                       uint32_t stream, uint32_t seed_lo, uint32_t seed_hi)
+{
+    return philox4x32_10((uint32_t)k, (uint32_t)((k >> 32) & 0xFFFFu) | (sub << 16), syndrome, stream,
+                         seed_lo, seed_hi);
+}
+
+// int(u * n) for u = x * 2^-32, exactly (toric_model.py:291 `int(random() * size)`)
+__host__ __device__ __forceinline__ uint32_t scale_u32(uint32_t x, uint32_t n)
+{
+    return (uint32_t)(((uint64_t)x * n) >> 32);
+}
+
+}  // namespace qecmc

@@ -1,0 +1,128 @@
+"""ctypes binding of libqecmc.so (C-ABI: include/qecmc.h).
+
+The library is the product: there is no Python/NumPy compute fallback.  If the
+shared object is missing, or no MI355X is visible when a compute entry point
+is called, the call raises -- loudly -- instead of degrading.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libqecmc.so")
+
+TORIC, XZZX, ROTATED = 0, 1, 2
+SCAN_RANDOM, SCAN_CHECKERBOARD = 0, 1
+NOISE_DEPOLARIZING, NOISE_BIASED = 0, 1
+CONV_NONE, CONV_ERROR_BASED = 0, 1
+
+
+class QecmcError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    """struct qecmc_params (include/qecmc.h)."""
+    _fields_ = [("abi_size", C.c_uint32), ("code", C.c_int32), ("L", C.c_int32), ("Nc", C.c_int32),
+                ("noise", C.c_int32), ("scan", C.c_int32), ("conv_mode", C.c_int32), ("device", C.c_int32),
+                ("iters", C.c_uint64), ("steps", C.c_uint64), ("tops_burn", C.c_int32), ("TOPS", C.c_int32),
+                ("SEQ", C.c_int32), ("reserved0", C.c_int32), ("eps", C.c_double), ("p", C.c_double),
+                ("eta", C.c_double), ("p_logical", C.c_double), ("seed", C.c_uint64),
+                ("first_syndrome", C.c_uint32), ("flags", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("proposals", C.c_uint64), ("swap_tests", C.c_uint64), ("kernel_ms", C.c_double),
+                ("total_ms", C.c_double)]
+
+
+_u8p = C.POINTER(C.c_uint8)
+_i32p = C.POINTER(C.c_int32)
+_u32p = C.POINTER(C.c_uint32)
+_i64p = C.POINTER(C.c_int64)
+
+# every symbol include/qecmc.h declares, with its signature
+SIGNATURES = {
+    "qecmc_abi_version": (C.c_int, []),
+    "qecmc_last_error": (C.c_char_p, []),
+    "qecmc_device_count": (C.c_int, []),
+    "qecmc_apply_stabilizer": (C.c_int, [C.c_int, C.c_int, C.c_uint64, _u8p, _u8p, _i32p, _i32p, _i32p, _i32p]),
+    "qecmc_apply_logical": (C.c_int, [C.c_int, C.c_int, C.c_uint64, _u8p, _u8p, _i32p, _i32p, _i32p, _i32p, _i32p]),
+    "qecmc_count_errors": (C.c_int, [C.c_int, C.c_int, C.c_uint64, _u8p, _i64p]),
+    "qecmc_eq_class": (C.c_int, [C.c_int, C.c_int, C.c_uint64, _u8p, _i32p]),
+    "qecmc_to_class": (C.c_int, [C.c_int, C.c_int, C.c_uint64, _u8p, _u8p, _i32p]),
+    "qecmc_syndrome": (C.c_int, [C.c_int, C.c_int, C.c_uint64, _u8p, _u8p]),
+    "qecmc_chain_update": (C.c_int, [C.c_int, C.c_int, C.c_uint64, _u8p, C.c_double, C.c_double, C.c_uint64,
+                                     C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64]),
+    "qecmc_ladder_step": (C.c_int, [C.POINTER(Params), C.c_uint64, _u8p, _u8p, _u32p, C.c_uint64, C.c_uint64,
+                                    C.c_uint64, C.c_uint64]),
+    "qecmc_pteq_batch": (C.c_int, [C.POINTER(Params), _u8p, C.c_uint64, _u32p, _u32p, _u32p, _u8p,
+                                   C.POINTER(Stats)]),
+    "qecmc_plan_create": (C.c_int, [C.POINTER(Params), C.POINTER(C.c_void_p)]),
+    "qecmc_plan_destroy": (C.c_int, [C.c_void_p]),
+    "qecmc_plan_info": (C.c_int, [C.c_void_p, _u32p, _u32p, _u32p]),
+    "qecmc_pteq_launch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise QecmcError(f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` "
+                             "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        if L.qecmc_abi_version() != 1:
+            raise QecmcError("libqecmc ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise QecmcError(f"libqecmc error {rc}: {lib().qecmc_last_error().decode()}")
+
+
+def device_count():
+    return lib().qecmc_device_count()
+
+
+def u8(a):
+    return a.ctypes.data_as(_u8p)
+
+
+def i32(a):
+    return a.ctypes.data_as(_i32p)
+
+
+def u32(a):
+    return a.ctypes.data_as(_u32p)
+
+
+def as_states(m, ndim_state):
+    """C-contiguous uint8 array with a leading batch axis; returns (array, batched?)."""
+    a = np.ascontiguousarray(m, dtype=np.uint8)
+    if a.ndim == ndim_state:
+        return a[None], False
+    if a.ndim == ndim_state + 1:
+        return a, True
+    raise ValueError(f"expected a uint8 array of {ndim_state} or {ndim_state + 1} dimensions, got shape {a.shape}")
+
+
+def make_params(code=TORIC, L=0, Nc=1, p=0.1, p_logical=0.0, iters=10, steps=0, tops_burn=2, TOPS=10, SEQ=2,
+                eps=0.1, seed=0, first_syndrome=0, conv_mode=CONV_NONE, scan=SCAN_RANDOM,
+                noise=NOISE_DEPOLARIZING, eta=0.0, device=0):
+    pr = Params()
+    pr.abi_size = C.sizeof(Params)
+    pr.code, pr.L, pr.Nc, pr.noise, pr.scan, pr.conv_mode, pr.device = code, L, Nc, noise, scan, conv_mode, device
+    pr.iters, pr.steps, pr.tops_burn, pr.TOPS, pr.SEQ = iters, steps, tops_burn, TOPS, SEQ
+    pr.eps, pr.p, pr.eta, pr.p_logical = eps, p, eta, p_logical
+    pr.seed, pr.first_syndrome, pr.flags = seed & 0xFFFFFFFFFFFFFFFF, first_syndrome, 0
+    return pr

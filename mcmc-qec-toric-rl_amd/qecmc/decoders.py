@@ -1,0 +1,60 @@
+"""Host-side mirror of the reference's `PTEQ` (decoders.py:25-89) and the new
+batched call `pteq_batch` that the hot path is built around."""
+import numpy as np
+
+from . import _lib as L_
+from .mcmc import _code_id, _fresh_seed
+
+
+def percent_from_counts(counts, samples):
+    """decoders.py:89: (eq[since_burn] / (since_burn + 1) * 100).astype(uint8) --
+    truncating, in float64, with an all-zero row when nothing was recorded (A10)."""
+    counts = np.asarray(counts)
+    den = np.maximum(np.asarray(samples, dtype=np.float64), 1.0)
+    return (np.divide(counts, den[..., None] if counts.ndim > 1 else den) * 100).astype(np.uint8)
+
+
+def pteq_batch(init, p, Nc=None, steps=1000, iters=10, tops_burn=2, p_logical=0.5, seed=0, first_syndrome=0,
+               device=0, return_states=False, return_stats=False):
+    """decoders.PTEQ with conv_criteria=None on N syndromes at once.
+
+    init: uint8[N, 2, L, L] seed configurations (one per syndrome).
+    Returns dict(counts uint32[N,16], samples uint32[N], tops0 uint32[N], percent uint8[N,16]
+    [, states uint8[N,Nc,2,L,L]] [, stats]).
+    """
+    a, _ = L_.as_states(init, 3)
+    N, size = a.shape[0], a.shape[2]
+    Nc = Nc or size
+    pr = L_.make_params(code=L_.TORIC, L=size, Nc=Nc, p=float(p), p_logical=float(p_logical), iters=int(iters),
+                        steps=int(steps), tops_burn=int(tops_burn), seed=seed, first_syndrome=first_syndrome,
+                        device=device)
+    counts = np.zeros((N, 16), dtype=np.uint32)
+    samples = np.zeros(N, dtype=np.uint32)
+    tops0 = np.zeros(N, dtype=np.uint32)
+    states = np.empty((N, Nc, 2, size, size), dtype=np.uint8) if return_states else None
+    stats = L_.Stats()
+    L_.check(L_.lib().qecmc_pteq_batch(pr, L_.u8(a), N, L_.u32(counts), L_.u32(samples), L_.u32(tops0),
+                                       L_.u8(states) if return_states else None, stats))
+    out = dict(counts=counts, samples=samples, tops0=tops0, percent=percent_from_counts(counts, samples))
+    if return_states:
+        out["states"] = states
+    if return_stats:
+        out["stats"] = dict(proposals=int(stats.proposals), swap_tests=int(stats.swap_tests),
+                            kernel_ms=float(stats.kernel_ms), total_ms=float(stats.total_ms))
+    return out
+
+
+def PTEQ(init_code, p, Nc=None, SEQ=2, TOPS=10, tops_burn=2, eps=0.1, steps=50000000, iters=10,
+         conv_criteria='error_based', seed=None):
+    """Drop-in for decoders.PTEQ (decoders.py:25): same arguments, returns the uint8
+    percent vector of the equivalence classes."""
+    if tops_burn >= TOPS:
+        print('tops_burn has to be smaller than TOPS')
+    _code_id(init_code)
+    if conv_criteria is not None:
+        raise NotImplementedError("conv_criteria='error_based' is not built yet: pass conv_criteria=None and a "
+                                  "fixed `steps`")
+    seed = _fresh_seed() if seed is None else seed
+    res = pteq_batch(init_code.qubit_matrix, p, Nc=Nc or init_code.system_size, steps=steps, iters=iters,
+                     tops_burn=tops_burn, p_logical=0.5, seed=seed)
+    return res["percent"][0]

@@ -1,0 +1,105 @@
+"""Host-side mirror of the reference's `Chain` / `Ladder` (src/mcmc.py:10-103).
+
+Same constructor arguments and attributes (`code`, `p`, `p_logical`, `flag`,
+`factor`; `chains`, `tops0`, `Nc`, `p_ladder`, `p_diff`).  The Metropolis loop
+itself runs on the GPU: `Chain.update_chain(iters)` and `Ladder.step(iters)`
+are each ONE call through the C-ABI (qecmc_chain_update / qecmc_ladder_step),
+drawing from counter-based Philox streams instead of CPython's global MT19937
+(the reference is unseeded, quirk Q8: only the distribution is defined).
+"""
+import copy
+import random as rand
+
+import numpy as np
+
+from . import _lib as L_
+
+
+def _fresh_seed():
+    # follows `random.seed(...)`, so a seeded caller gets reproducible runs
+    return rand.getrandbits(64)
+
+
+def _code_id(code):
+    name = type(code).__name__
+    if name == "Toric_code":
+        return L_.TORIC
+    raise NotImplementedError(f"no GPU kernels for code model {name} in this build")
+
+
+class Chain:
+    def __init__(self, p, code, seed=None, stream=0):
+        self.code = code
+        self.p = p
+        self.p_logical = 0
+        self.flag = 0
+        self.factor = ((self.p / 3.0) / (1.0 - self.p))
+        self.seed = _fresh_seed() if seed is None else seed
+        self.stream = stream          # Philox syndrome index of this chain
+        self.slot = 0                 # Philox stream id (ladder slot)
+        self.proposals_done = 0
+
+    def update_chain(self, iters):
+        """`iters` Metropolis proposals (src/mcmc.py:19-43) in one kernel launch."""
+        m, _ = L_.as_states(self.code.qubit_matrix, self.code.qubit_matrix.ndim)
+        m = m.copy()
+        L_.check(L_.lib().qecmc_chain_update(_code_id(self.code), self.code.system_size, 1, L_.u8(m), float(self.p),
+                                             float(self.p_logical), int(iters), self.seed, self.stream, self.slot,
+                                             self.proposals_done))
+        self.proposals_done += int(iters)
+        self.code.qubit_matrix = m[0]
+
+    def update_chain_fast(self, iters):
+        # the reference's jitted loop is hard-wired to the planar stencil (quirk Q1); for the
+        # codes built here it must be the same chain as update_chain
+        self.update_chain(iters)
+
+
+class Ladder:
+    def __init__(self, p_bottom, init_code, Nc, p_logical=0, seed=None, stream=0):
+        self.p_bottom = p_bottom
+        self.init_code = init_code
+        self.Nc = Nc
+        self.p_logical = p_logical
+        p_top = 0.75
+        p_ladder = np.linspace(p_bottom, p_top, Nc)
+        self.p_ladder = p_ladder
+        self.p_diff = (p_ladder[:-1] * (1 - p_ladder[1:])) / (p_ladder[1:] * (1 - p_ladder[:-1]))
+        self.seed = _fresh_seed() if seed is None else seed
+        self.stream = stream
+        self.chains = [Chain(p, copy.deepcopy(init_code), seed=self.seed, stream=stream) for p in p_ladder]
+        for slot, ch in enumerate(self.chains):
+            ch.slot = slot
+        self.chains[-1].flag = 1
+        self.chains[-1].p_logical = p_logical
+        self.tops0 = 0
+        self.steps_done = 0
+        self.proposals_done = 0
+
+    def _params(self, iters):
+        code = self.chains[0].code
+        return L_.make_params(code=_code_id(code), L=code.system_size, Nc=self.Nc, p=float(self.p_bottom),
+                              p_logical=float(self.p_logical), iters=int(iters), seed=self.seed,
+                              first_syndrome=self.stream)
+
+    def update_ladder(self, iters):
+        for ch in self.chains:
+            ch.proposals_done = self.proposals_done
+            ch.update_chain(iters)
+        self.proposals_done += int(iters)
+
+    def step(self, iters, nsteps=1):
+        """`nsteps` x Ladder.step(iters) (src/mcmc.py:94-103) in one kernel launch."""
+        states = np.ascontiguousarray(np.stack([ch.code.qubit_matrix for ch in self.chains])[None], dtype=np.uint8)
+        flags = np.array([[ch.flag for ch in self.chains]], dtype=np.uint8)
+        tops0 = np.array([self.tops0], dtype=np.uint32)
+        pr = self._params(iters)
+        L_.check(L_.lib().qecmc_ladder_step(pr, 1, L_.u8(states), L_.u8(flags), L_.u32(tops0), int(iters), int(nsteps),
+                                            self.steps_done, self.proposals_done))
+        self.steps_done += int(nsteps)
+        self.proposals_done += int(iters) * int(nsteps)
+        for c, ch in enumerate(self.chains):
+            ch.code.qubit_matrix = states[0, c].copy()
+            ch.flag = int(flags[0, c])
+            ch.proposals_done = self.proposals_done
+        self.tops0 = int(tops0[0])

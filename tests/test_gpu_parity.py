@@ -1,0 +1,182 @@
+"""GPU parity tests proper: the HIP path, called through the C-ABI, against the
+golden fixtures and against the CPU oracle on the same seeded inputs.  Integer /
+byte work: the bar is bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def q():
+    import qecmc
+    assert qecmc.device_count() >= 1, "no MI355X visible: the product has no CPU fallback"
+    return qecmc
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+def rand_states(rng, N, L, p):
+    m = np.zeros((N, 2, L, L), dtype=np.uint8)
+    err = rng.random(m.shape) < p
+    m[err] = rng.integers(1, 4, size=int(err.sum()), dtype=np.uint8)
+    return m
+
+
+# ------------------------------------------------------------------ F1: stencils vs the reference's vectors
+@pytest.mark.parametrize("L", [3, 5, 9])
+@pytest.mark.parametrize("rep", [0, 1])
+def test_f1_stencils_on_device(q, L, rep):
+    from qecmc import toric_model as tm
+    g = np.load(os.path.join(GOLDEN, "f1_toric.npz"))
+    t = f"L{L}_{rep}"
+    m = g[f"{t}_m"]
+    code = q.Toric_code(L)
+    code.qubit_matrix = m.copy()
+    assert code.count_errors() == int(g[f"{t}_count"])
+    assert code.define_equivalence_class() == int(g[f"{t}_class"])
+    code.syndrom()
+    assert np.array_equal(code.defect_matrix, g[f"{t}_defects"])
+    # all stabilizers in one batched call
+    ops, rows, cols = np.meshgrid([1, 3], np.arange(L), np.arange(L), indexing="ij")
+    n = ops.size
+    new, dE = tm.apply_stabilizer(np.broadcast_to(m, (n,) + m.shape), rows.ravel(), cols.ravel(), ops.ravel())
+    assert np.array_equal(new, g[f"{t}_stab_new"]) and np.array_equal(dE, g[f"{t}_stab_dE"])
+    assert np.array_equal(code.qubit_matrix, m)          # apply_* never mutate the input
+    a = g[f"{t}_log_arg"]
+    new, dE = tm.apply_logical(np.broadcast_to(m, (len(a),) + m.shape), a[:, 0], a[:, 1], a[:, 2], a[:, 3])
+    assert np.array_equal(new, g[f"{t}_log_new"]) and np.array_equal(dE, g[f"{t}_log_dE"])
+    out = tm.to_class(np.broadcast_to(m, (16,) + m.shape), np.arange(16))
+    assert np.array_equal(out, g[f"{t}_to_class"])
+    assert np.array_equal(tm.eq_class(out), np.arange(16))
+    # single-call forms used by the drop-in API
+    one, d1 = code.apply_stabilizer(L - 1, 0, 1)
+    assert np.array_equal(one, g[f"{t}_stab_new"][(L - 1) * L]) and d1 == int(g[f"{t}_stab_dE"][(L - 1) * L])
+
+
+def test_stencil_argument_errors(q):
+    code = q.Toric_code(3)
+    with pytest.raises(q.QecmcError):
+        code.apply_stabilizer(3, 0, 1)
+    with pytest.raises(q.QecmcError):
+        code.apply_stabilizer(0, 0, 2)
+    with pytest.raises(q.QecmcError):
+        code.to_class(16)
+
+
+# ------------------------------------------------------------------ Chain.update_chain vs oracle (same Philox stream)
+@pytest.mark.parametrize("L,p,p_logical,iters", [(3, 0.5, 0.0, 50), (5, 0.10, 0.0, 1000), (9, 0.15, 0.0, 2000),
+                                                 (9, 0.75, 0.5, 1000), (5, 0.30, 0.5, 1000), (9, 0.20, 0.25, 800),
+                                                 (15, 0.18, 0.0, 500), (4, 0.6, 1.0, 300)])
+def test_chain_update_bit_exact(q, orc, L, p, p_logical, iters):
+    rng = np.random.default_rng(L * 100 + iters)
+    m = rand_states(rng, 1, L, 0.15)[0]
+    seed, stream, slot, k0 = 0xDEADBEEFCAFE, 7, 3, 12345
+    code = q.Toric_code(L)
+    code.qubit_matrix = m.copy()
+    ch = q.Chain(p, code, seed=seed, stream=stream)
+    ch.p_logical, ch.slot, ch.proposals_done = p_logical, slot, k0
+    ch.update_chain(iters)
+    ref = orc.toric_chain_update(m, p, p_logical, iters, orc.Rng.philox(seed, stream), slot=slot, k0=k0)
+    assert np.array_equal(ch.code.qubit_matrix, ref)
+    assert np.array_equal(q.toric_model.syndrome(ref), q.toric_model.syndrome(m))
+
+
+# ------------------------------------------------------------------ Ladder.step vs oracle
+@pytest.mark.parametrize("L,p,Nc,iters,nstep", [(3, 0.3, 4, 5, 60), (5, 0.10, 5, 10, 80), (9, 0.15, 8, 10, 60),
+                                                (5, 0.25, 3, 7, 70), (3, 0.05, 2, 10, 90), (7, 0.12, 16, 3, 40)])
+def test_ladder_step_bit_exact(q, orc, L, p, Nc, iters, nstep):
+    rng = np.random.default_rng(L + Nc)
+    m = rand_states(rng, 1, L, 0.15)[0]
+    seed, stream = 99, 5
+    code = q.Toric_code(L)
+    code.qubit_matrix = m.copy()
+    ld = q.Ladder(p, code, Nc, 0.5, seed=seed, stream=stream)
+    ref = orc.ToricLadder(m, p, Nc, 0.5)
+    r = orc.Rng.philox(seed, stream)
+    assert np.array_equal(ld.p_ladder, ref.p_ladder) and np.array_equal(ld.p_diff, ref.p_diff)
+    done = 0
+    for chunk in (1, 1, 3, nstep - 5):                   # resumable: any chunking gives the same trajectory
+        ld.step(iters, nsteps=chunk)
+        for _ in range(chunk):
+            ref.step(iters, r)
+        done += chunk
+        got = np.stack([c.code.qubit_matrix for c in ld.chains])
+        assert np.array_equal(got, ref.states), f"states differ after {done} steps"
+        assert [c.flag for c in ld.chains] == ref.flags.tolist()
+        assert ld.tops0 == ref.tops0
+
+
+# ------------------------------------------------------------------ PTEQ batch vs oracle
+@pytest.mark.parametrize("L,p,Nc,N,steps,tops_burn", [
+    (3, 0.10, 3, 1, 300, 2), (3, 0.10, 2, 63, 200, 0), (5, 0.10, 5, 65, 200, 1), (5, 0.10, 5, 130, 150, 2),
+    (9, 0.15, 8, 96, 100, 0), (9, 0.15, 8, 64, 120, 2), (7, 0.12, 16, 20, 60, 0), (15, 0.18, 8, 70, 40, 0),
+    (5, 0.2, 1, 10, 50, 0)])
+def test_pteq_batch_bit_exact(q, orc, L, p, Nc, N, steps, tops_burn):
+    rng = np.random.default_rng(N * 7 + L)
+    init = rand_states(rng, N, L, p)
+    got = q.pteq_batch(init, p, Nc=Nc, steps=steps, iters=10, tops_burn=tops_burn, seed=2020, first_syndrome=11,
+                       return_states=True)
+    ref = orc.toric_pteq_batch(init, p, Nc, steps, iters=10, tops_burn=tops_burn, seed=2020, first_syndrome=11,
+                               return_states=True)
+    assert np.array_equal(got["tops0"], ref["tops0"].astype(np.uint32))
+    assert np.array_equal(got["samples"], ref["samples"].astype(np.uint32))
+    assert np.array_equal(got["counts"], ref["counts"])
+    assert np.array_equal(got["states"], ref["states"])
+    assert np.array_equal(got["counts"].sum(axis=1), got["samples"])
+
+
+def test_sharding_invariance(q):
+    """Philox is keyed by the GLOBAL syndrome index: a batch split across calls (GPUs) gives the same answer."""
+    rng = np.random.default_rng(3)
+    init = rand_states(rng, 200, 5, 0.1)
+    full = q.pteq_batch(init, 0.1, Nc=5, steps=100, tops_burn=0, seed=5)
+    a = q.pteq_batch(init[:77], 0.1, Nc=5, steps=100, tops_burn=0, seed=5, first_syndrome=0)
+    b = q.pteq_batch(init[77:], 0.1, Nc=5, steps=100, tops_burn=0, seed=5, first_syndrome=77)
+    assert np.array_equal(full["counts"], np.concatenate([a["counts"], b["counts"]]))
+    assert np.array_equal(full["tops0"], np.concatenate([a["tops0"], b["tops0"]]))
+
+
+def test_pteq_dropin_signature(q, orc):
+    rng = np.random.default_rng(1)
+    code = q.Toric_code(5)
+    code.qubit_matrix = rand_states(rng, 1, 5, 0.1)[0]
+    pct = q.PTEQ(code, 0.1, Nc=5, steps=400, iters=10, tops_burn=1, conv_criteria=None, seed=77)
+    ref = orc.toric_pteq(code.qubit_matrix, 0.1, Nc=5, steps=400, iters=10, tops_burn=1, rng=orc.Rng.philox(77, 0))
+    assert pct.dtype == np.uint8 and pct.shape == (16,)
+    assert np.array_equal(pct, ref["percent"])
+
+
+def test_empty_batch(q):
+    out = q.pteq_batch(np.zeros((0, 2, 5, 5), dtype=np.uint8), 0.1, Nc=5, steps=10)
+    assert out["counts"].shape == (0, 16)
+
+
+# ------------------------------------------------------------------ size-independent properties at BASELINE size
+def test_full_size_properties(q, orc):
+    """cfg 2 shape: 65 536 toric L=9 syndromes, Nc=8 (shortened run).  Checks that need no oracle at this size:
+    the syndrome of every chain is conserved, counts add up to the sample count, and a random
+    subset of syndromes is bit-identical to the oracle."""
+    from qecmc import toric_model as tm
+    rng = np.random.default_rng(2020)
+    N, L, Nc, steps = 65536, 9, 8, 50
+    init = rand_states(rng, N, L, 0.15)
+    got = q.pteq_batch(init, 0.15, Nc=Nc, steps=steps, iters=10, tops_burn=0, seed=9, return_states=True)
+    assert np.array_equal(got["counts"].sum(axis=1), got["samples"]) and np.all(got["samples"] == steps)
+    syn0 = tm.syndrome(init)
+    for c in range(Nc):
+        assert np.array_equal(tm.syndrome(np.ascontiguousarray(got["states"][:, c])), syn0)
+    pick = rng.choice(N, size=48, replace=False)
+    for s in pick:
+        ref = orc.toric_pteq_batch(init[s:s + 1], 0.15, Nc, steps, iters=10, tops_burn=0, seed=9, first_syndrome=int(s),
+                                   return_states=True)
+        assert np.array_equal(got["counts"][s], ref["counts"][0])
+        assert np.array_equal(got["states"][s], ref["states"][0])
