@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--Nc", type=int, default=8)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--seed", type=int, default=20200915)
+    ap.add_argument("--p-logical", type=float, default=0.5, help="top-chain logical rate (decoders.py:52 uses 0.5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -113,7 +114,7 @@ def main():
     d_tops0 = torch.zeros(N, dtype=torch.int32, device=dev)
     gathered = [torch.zeros_like(d_counts) for _ in range(world)] if (world > 1 and rank == 0) else None
 
-    pr = L_.make_params(code=L_.TORIC, L=L, Nc=Nc, p=args.p, p_logical=0.5, iters=args.iters,
+    pr = L_.make_params(code=L_.TORIC, L=L, Nc=Nc, p=args.p, p_logical=args.p_logical, iters=args.iters,
                         steps=args.ladder_steps, tops_burn=2, seed=args.seed, device=local_rank)
     plan = C.c_void_p()
     L_.check(L_.lib().qecmc_plan_create(pr, C.byref(plan)))

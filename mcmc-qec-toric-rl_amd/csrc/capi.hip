@@ -163,6 +163,9 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
     std::vector<uint64_t> sw((size_t)(Nc > 1 ? Nc - 1 : 1) * (nq + 1), 0);
     for (int i = 0; i + 1 < Nc; ++i)
         for (int d = 0; d <= nq; ++d) sw[(size_t)i * (nq + 1) + d] = thr64(std::pow(pdiff[i], (double)d));   // mcmc.py:149
+    a.swap_fast_ok = 1;
+    for (int i = 0; i + 1 < Nc; ++i)
+        if (nq >= 1 && sw[(size_t)i * (nq + 1) + 1] > 0xFFFFFFFFull) a.swap_fast_ok = 0;
     const std::vector<uint32_t> lm = toric_logical_masks(L, W);
     HIP_TRY(pl->swap_thr.alloc(sw.size() * sizeof(uint64_t)));
     HIP_TRY(pl->lmask.alloc(lm.size() * sizeof(uint32_t)));

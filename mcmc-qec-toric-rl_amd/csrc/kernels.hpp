@@ -7,6 +7,7 @@ namespace qecmc {
 
 constexpr int kMaxNc = 16;          // one wavefront per ladder slot, <= 1024 threads per workgroup
 constexpr int kSynPerBlock = 64;    // one lane per syndrome
+constexpr int kSwapFast = 64;       // swap-threshold entries per rung pair kept in LDS (d < kSwapFast)
 
 // Arguments of the random-scan ladder kernel (passed by value; fits the kernarg segment).
 struct LadderArgs {
@@ -29,6 +30,7 @@ struct LadderArgs {
     uint32_t tops_burn;
     uint32_t acc_all_mask;    // bit c: slot c accepts every proposal (f >= 1, mcmc.py:30)
     uint32_t acc_thr[kMaxNc][4];   // ceil(f_c^dE * 2^32), dE = 1..4
+    int32_t swap_fast_ok;          // every swap threshold with d >= 1 fits 32 bits (false only if two rungs coincide)
     int L, Nc, W, nq, ncls;
     int resume;               // 0: replicate init into every slot (mcmc.py:72); 1: load states/flags/tops0
     int write_states;

@@ -23,6 +23,11 @@
 //   * swaps (mcmc.py:96-103) move slot->state indices, not data; error counts and
 //     equivalence classes are carried incrementally per state (n += dE; class ^=
 //     logical delta) instead of recounted (mcmc.py:88-89, toric_model.py:317).
+//   * one barrier per ladder step: every wave publishes its slot record (error
+//     count, state id, class, flag) and then replays the whole top-down swap
+//     cascade (mcmc.py:96-103) itself from those records to learn which state
+//     lands in its own slot -- a few integer ops per rung, no serial section
+//     that leaves seven waves idle, no second barrier.
 //   * HBM traffic is compulsory only: nq bytes in, ncls counters out per syndrome.
 #include "kernels.hpp"
 #include "philox.hpp"
@@ -32,8 +37,9 @@ namespace qecmc {
 // LDS carve-up in dwords (keep in sync with the kernel)
 size_t ladder_lds_bytes(int L, int Nc, int W, int ncls)
 {
-    return sizeof(uint32_t) * ((size_t)Nc * W * 64 + 3 * (size_t)Nc * 64 + (size_t)ncls * 64 + (size_t)Nc * 9 +
-                               4 * (size_t)(L + 1) * W);
+    (void)L;
+    return sizeof(uint32_t) * ((size_t)Nc * W * 64 + 4 * (size_t)Nc * 64 + (size_t)ncls * 64 + (size_t)Nc * 9 +
+                               (size_t)Nc * kSwapFast);   // st + info[2] + swx[2] + hist + thrT + swapT
 }
 
 __device__ __forceinline__ uint32_t nnz2(uint32_t x) { return __popc((x | (x >> 1)) & 0x55555555u); }
@@ -82,6 +88,13 @@ __device__ __forceinline__ uint32_t toric_class_packed(const uint32_t *sb, int W
     return x1 + 2u * z1 + 4u * x2 + 8u * z2;
 }
 
+// slot record published once per ladder step: error count | state id << 16 | class << 24 | flag << 31
+// (flag = "has been at the top since it last reached the bottom", Chain.flag, mcmc.py:75,99-103)
+__device__ __forceinline__ uint32_t pack_info(uint32_t n, uint32_t sid, uint32_t cls, uint32_t flag)
+{
+    return n | (sid << 16) | (cls << 24) | (flag << 31);
+}
+
 template <int MAXT, int MINW>
 __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const LadderArgs a)
 {
@@ -90,13 +103,12 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
     const int tid = threadIdx.x, lane = tid & 63, slot = tid >> 6;
     const int nthreads = NC * 64;
 
-    uint32_t *st = lds;                           // [NC][W][64]  packed states
-    uint32_t *nerr = st + (size_t)NC * W * 64;    // [NC][64]     error count of state s
-    uint32_t *scls = nerr + NC * 64;              // [NC][64]     equivalence class of state s
-    uint32_t *perm = scls + NC * 64;              // [NC][64]     state held by slot c
-    uint32_t *hist = perm + NC * 64;              // [ncls][64]
-    uint32_t *thrT = hist + ncls * 64;            // [NC][9]      accept iff x <= thrT[slot][dE+4]
-    uint32_t *lmask = thrT + NC * 9;              // [4][L+1][W]
+    uint32_t *st = lds;                           // [NC][W][64]   packed states
+    uint32_t *info = st + (size_t)NC * W * 64;    // [2][NC][64]   slot records, double-buffered by step parity
+    uint32_t *swx = info + 2 * NC * 64;           // [2][NC][64]   swap uniform of rung pair i, same parity
+    uint32_t *hist = swx + 2 * NC * 64;           // [ncls][64]
+    uint32_t *thrT = hist + ncls * 64;            // [NC][9]       accept iff x <= thrT[slot][dE+4]
+    uint32_t *swapT = thrT + NC * 9;              // [NC][kSwapFast]  swap iff x <= swapT[i][d]
 
     const uint64_t s0 = (uint64_t)blockIdx.x * 64u;
     const int cnt = (int)((a.N - s0) < 64u ? (a.N - s0) : 64u);
@@ -104,7 +116,11 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
 
     for (int i = tid; i < NC * W * 64; i += nthreads) st[i] = 0;
     for (int i = tid; i < ncls * 64; i += nthreads) hist[i] = 0;
-    for (int i = tid; i < 4 * (L + 1) * W; i += nthreads) lmask[i] = a.lmask[i];
+    for (int i = tid; i < (NC - 1) * kSwapFast; i += nthreads) {
+        // u < p_diff^d  <=>  x < thr; d = 0 always swaps and is never looked up (mcmc.py:146-149)
+        const int pr = i / kSwapFast, d = i - pr * kSwapFast;
+        swapT[i] = (d >= 1 && d <= nq) ? (uint32_t)a.swap_thr[(size_t)pr * (nq + 1) + d] : 0u;
+    }
     if (tid < NC * 9) {
         // u < f^dE  <=>  x < thr  <=>  x <= thr-1;  dE <= 0 (f^dE >= 1) and f >= 1 always accept (mcmc.py:30,42)
         const int c = tid / 9, d = tid - c * 9 - 4;
@@ -139,23 +155,20 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
         }
     }
     __syncthreads();
+
+    // every wave carries its slot's current state id, error count, class and flag in registers
+    uint32_t sid = (uint32_t)slot, n, cls, flag = (slot == NC - 1);   // chains[-1].flag = 1 (mcmc.py:75)
     {
         const uint32_t *sb = st + slot * W * 64 + lane;
-        uint32_t n = 0;
+        n = 0;
         for (int w = 0; w < W; ++w) n += nnz2(sb[w * 64]);
-        nerr[slot * 64 + lane] = n;
-        scls[slot * 64 + lane] = toric_class_packed(sb, W, LL);
-        perm[slot * 64 + lane] = (uint32_t)slot;
+        cls = toric_class_packed(sb, W, LL);
     }
-    // per-syndrome ladder bookkeeping lives in the registers of wave 0
-    uint32_t flagbits = 1u << (NC - 1);           // chains[-1].flag = 1 (mcmc.py:75)
-    uint32_t tops0 = 0, samples = 0;
-    if (a.resume && slot == 0 && lane < cnt) {
-        flagbits = 0;
-        for (int c = 0; c < NC; ++c) flagbits |= (uint32_t)(a.flags[(s0 + lane) * NC + c] != 0) << c;
-        tops0 = a.tops0[s0 + lane];
+    uint32_t tops0 = 0, samples = 0;              // per-syndrome counters live in wave 0
+    if (a.resume && lane < cnt) {
+        flag = a.flags[(s0 + lane) * NC + slot] != 0;
+        if (slot == 0) tops0 = a.tops0[s0 + lane];
     }
-    __syncthreads();
 
     const uint32_t slot_u = __builtin_amdgcn_readfirstlane(slot);
     const bool acc_all = (a.acc_all_mask >> slot_u) & 1u;
@@ -164,15 +177,16 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
     const uint32_t thrL1 = (uint32_t)(a.thr_logical - 1);      // x < thr_logical <=> x <= thr_logical-1 (thr in [1, 2^32])
     const uint32_t *myT = thrT + slot_u * 9 + 4;
     const uint32_t Lodd = L & 1;                                // a row/column operator flips L parities
-    const int wb = LL >> 4;
+    const uint32_t rowbits = 2u * (uint32_t)L;                  // bits of one lattice row in the packed stream
+    const uint32_t rowmask = rowbits >= 32 ? 0xFFFFFFFFu : (1u << rowbits) - 1u;
+    const bool swap_fast = a.swap_fast_ok != 0;
 
     for (uint64_t t = 0; t < a.nsteps; ++t) {
         // ---------------- Chain.update_chain(iters) on every slot (mcmc.py:81-83) -----------
-        const uint32_t sid = perm[slot * 64 + lane];
         uint32_t *stw = st + sid * W * 64 + lane;
         const uint64_t kbase = a.prop0 + t * iters;
         if (!top_logical) {
-            int n = (int)nerr[sid * 64 + lane];
+            int ni = (int)n;
             for (uint32_t j = 0; j < iters; ++j) {
                 const u32x4 x = philox_block(kbase + j, 0, syn, slot_u, a.seed_lo, a.seed_hi);
                 const uint32_t row = scale_u32(x.x, L), col = scale_u32(x.y, L);   // toric_model.py:291-292
@@ -193,32 +207,28 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 if (x.w <= myT[dE]) {                                               // mcmc.py:42
 #pragma unroll
                     for (int i = 0; i < 4; ++i) lds_xor(ad[i], op << sh[i]);
-                    n += dE;
+                    ni += dE;
                 }
             }
-            nerr[sid * 64 + lane] = (uint32_t)n;
-        } else if (acc_all) {
-            // top chain at p = 0.75: every proposal is accepted (mcmc.py:30) -> blind XORs
-            uint32_t cdelta = 0;
+            n = (uint32_t)ni;
+        } else if (acc_all && L <= 16) {
+            // Top chain at p = 0.75: every proposal is accepted (mcmc.py:30), so moves are blind
+            // XORs and commute.  Stabilizers go straight to LDS; logical operators are collected
+            // in a per-lane frame (which rows / columns carry an operator) and flushed once.
+            //   fr0: bit r      = X on row r of layer 0      bit 16+c = Z on column c of layer 0
+            //   fr1: bit c      = X on column c of layer 1   bit 16+r = Z on row r of layer 1
+            uint32_t fr0 = 0, fr1 = 0, cdelta = 0;
             for (uint32_t j = 0; j < iters; ++j) {
-                const uint64_t k = kbase + j;
-                const u32x4 x = philox_block(k, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                const u32x4 x = philox_block(kbase + j, 0, syn, slot_u, a.seed_lo, a.seed_hi);
                 if (x.x <= thrL1) {                                                 // mcmc.py:23
                     // _apply_random_logical, toric_model.py:228-253
                     const uint32_t op0 = x.y >> 30, op1 = x.z >> 30;
-                    const u32x4 b = philox_block(k, 1, syn, slot_u, a.seed_lo, a.seed_hi);
-                    const uint32_t dx0 = (op0 == 1) | (op0 == 2), dz0 = op0 >> 1, dx1 = (op1 == 1) | (op1 == 2), dz1 = op1 >> 1;
-                    int nb = 0;
-                    uint32_t ix0 = L, iz0 = L, ix1 = L, iz1 = L;                   // row L of each table = identity
-                    if (dx0) ix0 = scale_u32(sel4(b, nb++), L);
-                    if (dz0) iz0 = scale_u32(sel4(b, nb++), L);
-                    if (dx1) ix1 = scale_u32(sel4(b, nb++), L);
-                    if (dz1) iz1 = scale_u32(sel4(b, nb++), L);
-                    const int LW = (L + 1) * W;
-                    const uint32_t *m0 = lmask + ix0 * W, *m1 = lmask + LW + iz0 * W, *m2 = lmask + 2 * LW + ix1 * W,
-                                   *m3 = lmask + 3 * LW + iz1 * W;
-                    for (int w = 0; w <= wb; ++w) lds_xor(stw + w * 64, m0[w] ^ m1[w]);    // layer 0 words
-                    for (int w = wb; w < W; ++w) lds_xor(stw + w * 64, m2[w] ^ m3[w]);     // layer 1 words
+                    const uint32_t dx0 = (op0 ^ (op0 >> 1)) & 1u, dz0 = op0 >> 1;   // X iff op in {1,2}; Z iff op in {2,3}
+                    const uint32_t dx1 = (op1 ^ (op1 >> 1)) & 1u, dz1 = op1 >> 1;
+                    const uint32_t x0 = scale_low30(x.y, L), z0 = scale_u16(x.w >> 16, L);
+                    const uint32_t x1 = scale_low30(x.z, L), z1 = scale_u16(x.w & 0xFFFFu, L);
+                    fr0 ^= (dx0 << x0) | (dz0 << (16 + z0));
+                    fr1 ^= (dx1 << x1) | (dz1 << (16 + z1));
                     cdelta ^= dx0 | (dz0 << 1) | (dx1 << 2) | (dz1 << 3);
                 } else {
                     const uint32_t row = scale_u32(x.y, L), col = scale_u32(x.z, L), isX = x.w >> 31;
@@ -229,27 +239,46 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                     for (int i = 0; i < 4; ++i) lds_xor(stw + (q[i] >> 4) * 64, op << ((q[i] & 15u) * 2u));
                 }
             }
-            uint32_t n = 0;
+            // flush the frame: lattice row r of layer l is the 2L-bit span at bit 2*(l*LL + r*L)
+            {
+                uint32_t c0 = fr0 >> 16, c1 = fr1 & 0xFFFFu;       // column sets -> one 2-bit field per column
+                c0 = (c0 | (c0 << 8)) & 0x00FF00FFu; c0 = (c0 | (c0 << 4)) & 0x0F0F0F0Fu;
+                c0 = (c0 | (c0 << 2)) & 0x33333333u; c0 = (c0 | (c0 << 1)) & 0x55555555u;
+                c1 = (c1 | (c1 << 8)) & 0x00FF00FFu; c1 = (c1 | (c1 << 4)) & 0x0F0F0F0Fu;
+                c1 = (c1 | (c1 << 2)) & 0x33333333u; c1 = (c1 | (c1 << 1)) & 0x55555555u;
+                const uint32_t colpat0 = c0 * 3u;                   // Z (11) on the chosen columns of layer 0
+                const uint32_t colpat1 = c1;                        // X (01) on the chosen columns of layer 1
+                uint32_t off = 0;
+                for (int r = 0; r < L; ++r, off += rowbits) {      // layer 0: X (01) along chosen rows
+                    const uint32_t m = colpat0 ^ (((fr0 >> r) & 1u) ? (0x55555555u & rowmask) : 0u);
+                    const uint32_t wd = off >> 5, shb = off & 31u;
+                    lds_xor(stw + wd * 64, m << shb);
+                    if (shb + rowbits > 32) lds_xor(stw + (wd + 1) * 64, m >> (32 - shb));
+                }
+                for (int r = 0; r < L; ++r, off += rowbits) {      // layer 1: Z (11) along chosen rows
+                    const uint32_t m = colpat1 ^ (((fr1 >> (16 + r)) & 1u) ? rowmask : 0u);
+                    const uint32_t wd = off >> 5, shb = off & 31u;
+                    lds_xor(stw + wd * 64, m << shb);
+                    if (shb + rowbits > 32) lds_xor(stw + (wd + 1) * 64, m >> (32 - shb));
+                }
+            }
+            n = 0;
             for (int w = 0; w < W; ++w) n += nnz2(stw[w * 64]);
-            nerr[sid * 64 + lane] = n;
-            if (Lodd) scls[sid * 64 + lane] ^= cdelta;
+            if (Lodd) cls ^= cdelta;
         } else {
-            // top chain below p = 0.75 (only a 1-chain ladder): full Metropolis test, mcmc.py:30-34
-            int n = (int)nerr[sid * 64 + lane];
+            // general top chain (L > 16, or a 1-chain ladder whose top sits below p = 0.75):
+            // table-driven logical operators and the full Metropolis test, mcmc.py:20-35
+            int ni = (int)n;
             uint32_t cdelta = 0;
+            const uint32_t *lmask = a.lmask;
             for (uint32_t j = 0; j < iters; ++j) {
                 const uint64_t k = kbase + j;
                 const u32x4 x = philox_block(k, 0, syn, slot_u, a.seed_lo, a.seed_hi);
                 if (x.x <= thrL1) {
                     const uint32_t op0 = x.y >> 30, op1 = x.z >> 30;
-                    const u32x4 b = philox_block(k, 1, syn, slot_u, a.seed_lo, a.seed_hi);
-                    const uint32_t dx0 = (op0 == 1) | (op0 == 2), dz0 = op0 >> 1, dx1 = (op1 == 1) | (op1 == 2), dz1 = op1 >> 1;
-                    int nb = 0;
-                    uint32_t ix0 = L, iz0 = L, ix1 = L, iz1 = L;
-                    if (dx0) ix0 = scale_u32(sel4(b, nb++), L);
-                    if (dz0) iz0 = scale_u32(sel4(b, nb++), L);
-                    if (dx1) ix1 = scale_u32(sel4(b, nb++), L);
-                    if (dz1) iz1 = scale_u32(sel4(b, nb++), L);
+                    const uint32_t dx0 = (op0 ^ (op0 >> 1)) & 1u, dz0 = op0 >> 1, dx1 = (op1 ^ (op1 >> 1)) & 1u, dz1 = op1 >> 1;
+                    const uint32_t ix0 = dx0 ? scale_low30(x.y, L) : L, iz0 = dz0 ? scale_u16(x.w >> 16, L) : L;   // row L = identity
+                    const uint32_t ix1 = dx1 ? scale_low30(x.z, L) : L, iz1 = dz1 ? scale_u16(x.w & 0xFFFFu, L) : L;
                     const int LW = (L + 1) * W;
                     const uint32_t *m0 = lmask + ix0 * W, *m1 = lmask + LW + iz0 * W, *m2 = lmask + 2 * LW + ix1 * W,
                                    *m3 = lmask + 3 * LW + iz1 * W;
@@ -259,10 +288,10 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                         dE += (int)nnz2(old ^ m0[w] ^ m1[w] ^ m2[w] ^ m3[w]) - (int)nnz2(old);
                     }
                     bool acc = true;
-                    if (dE > 0) acc = philox_block(k, 2, syn, slot_u, a.seed_lo, a.seed_hi).x < a.acc_tbl_top[dE];
+                    if (!acc_all && dE > 0) acc = philox_block(k, 2, syn, slot_u, a.seed_lo, a.seed_hi).x < a.acc_tbl_top[dE];
                     if (acc) {
                         for (int w = 0; w < W; ++w) lds_xor(stw + w * 64, m0[w] ^ m1[w] ^ m2[w] ^ m3[w]);
-                        n += dE;
+                        ni += dE;
                         cdelta ^= dx0 | (dz0 << 1) | (dx1 << 2) | (dz1 << 3);
                     }
                 } else {
@@ -276,60 +305,63 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                         dE += (int)(f == 0u) - (int)(f == op);
                     }
                     bool acc = true;
-                    if (dE > 0) acc = philox_block(k, 2, syn, slot_u, a.seed_lo, a.seed_hi).x < a.acc_tbl_top[dE];
+                    if (!acc_all && dE > 0) acc = philox_block(k, 2, syn, slot_u, a.seed_lo, a.seed_hi).x < a.acc_tbl_top[dE];
                     if (acc) {
                         for (int i = 0; i < 4; ++i) lds_xor(stw + (q[i] >> 4) * 64, op << ((q[i] & 15u) * 2u));
-                        n += dE;
+                        ni += dE;
                     }
                 }
             }
-            nerr[sid * 64 + lane] = (uint32_t)n;
-            if (Lodd) scls[sid * 64 + lane] ^= cdelta;
+            n = (uint32_t)ni;
+            if (Lodd) cls ^= cdelta;
         }
 
-        // swap uniforms do not depend on the state: draw them while the slower waves finish
-        u32x4 sw0{0, 0, 0, 0}, sw1{0, 0, 0, 0}, sw2{0, 0, 0, 0}, sw3{0, 0, 0, 0};
-        if (slot_u == 0) {
-            const uint64_t tstep = a.step0 + t;
-            if (NC > 1) sw0 = philox_block(tstep, 0, syn, kSwapStream, a.seed_lo, a.seed_hi);
-            if (NC > 5) sw1 = philox_block(tstep, 1, syn, kSwapStream, a.seed_lo, a.seed_hi);
-            if (NC > 9) sw2 = philox_block(tstep, 2, syn, kSwapStream, a.seed_lo, a.seed_hi);
-            if (NC > 13) sw3 = philox_block(tstep, 3, syn, kSwapStream, a.seed_lo, a.seed_hi);
+        // ---------------- swap sweep, Ladder.step mcmc.py:96-103 --------------------------------
+        // (double-buffered by step parity: a fast wave may publish step t+1 while a slow one still reads step t)
+        uint32_t *cur = info + (t & 1) * NC * 64 + lane, *sx = swx + (t & 1) * NC * 64 + lane;
+        cur[slot * 64] = pack_info(n, sid, cls, flag);
+        if (slot_u < 4 && (int)slot_u * 4 < NC - 1) {
+            // the sweep's uniforms do not depend on the state: waves 0..3 draw one Philox block each
+            const u32x4 b = philox_block(a.step0 + t, slot_u, syn, kSwapStream, a.seed_lo, a.seed_hi);
+            uint32_t *p = sx + slot_u * 4 * 64;                    // rows 4b .. 4b+3 = rung pairs, NC-1 of them exist
+            const int left = NC - 1 - (int)slot_u * 4;
+            p[0] = b.x;
+            if (left > 1) p[64] = b.y;
+            if (left > 2) p[128] = b.z;
+            if (left > 3) p[192] = b.w;
         }
         __syncthreads();
-
-        // ---------------- swap sweep + PTEQ bookkeeping, one lane per syndrome ---------------
-        if (slot_u == 0) {
-            uint32_t hi = perm[(NC - 1) * 64 + lane];
-            uint32_t nhi = nerr[hi * 64 + lane];
+        {
+            // every wave replays the top-down cascade on the published records; `car` is the record
+            // being carried down, `mine` the one that ends in this wave's slot
+            uint32_t car = cur[(NC - 1) * 64], mine = car;
             for (int i = NC - 2; i >= 0; --i) {                                    // mcmc.py:96
-                const int sub = i >> 2;
-                const u32x4 &blk = sub == 0 ? sw0 : sub == 1 ? sw1 : sub == 2 ? sw2 : sw3;
-                const uint32_t lo = perm[i * 64 + lane];
-                const uint32_t nlo = nerr[lo * 64 + lane];
-                const int d = (int)nhi - (int)nlo;                                  // ne_hi - ne_lo
-                bool flip = d < 0;                                                  // _r_flip, mcmc.py:146
-                if (!flip) flip = (uint64_t)sel4(blk, i & 3) < a.swap_thr[(size_t)i * (nq + 1) + d];   // :149
-                if (flip) {                                                          // :98-99
-                    perm[i * 64 + lane] = hi;
-                    perm[(i + 1) * 64 + lane] = lo;
-                    const uint32_t fl = (flagbits >> i) & 1u, fh = (flagbits >> (i + 1)) & 1u;
-                    flagbits = (flagbits & ~(3u << i)) | (fh << i) | (fl << (i + 1));
-                } else {
-                    hi = lo;
-                    nhi = nlo;
+                const uint32_t lo = cur[i * 64], xi = sx[i * 64];
+                const int d = (int)(car & 0xFFFFu) - (int)(lo & 0xFFFFu);          // ne_hi - ne_lo
+                bool flip = d <= 0;                                                 // _r_flip :146, and u < rel_p**0 = 1
+                if (!flip) {                                                        // :149
+                    if (swap_fast && d < kSwapFast) flip = xi < swapT[i * kSwapFast + d];
+                    else flip = (uint64_t)xi < a.swap_thr[(size_t)i * (nq + 1) + d];
+                }
+                const uint32_t into = flip ? lo : car;                              // what slot i+1 now holds (:98-99)
+                car = flip ? car : lo;
+                if ((int)slot_u == i + 1) mine = into;
+            }
+            if (slot_u == 0) mine = car;
+            n = mine & 0xFFFFu; sid = (mine >> 16) & 0xFFu; cls = (mine >> 24) & 0x3Fu; flag = mine >> 31;
+            if ((int)slot_u == NC - 1) flag = 1;                                    // chains[-1].flag = 1, mcmc.py:100
+            if (slot_u == 0) {                                                      // ladder + PTEQ bookkeeping
+                if (flag) { tops0++; flag = 0; }                                    // :101-103
+                if (a.counts != nullptr && tops0 >= a.tops_burn) {                  // decoders.py:60-67
+                    hist[cls * 64 + lane] += 1;
+                    samples++;
                 }
             }
-            flagbits |= 1u << (NC - 1);                                             // mcmc.py:100
-            if (flagbits & 1u) { tops0++; flagbits &= ~1u; }                        // :101-103
-            if (a.counts != nullptr && tops0 >= a.tops_burn) {                      // decoders.py:60-67
-                const uint32_t cls = scls[hi * 64 + lane];                          // `hi` is now the state in slot 0
-                hist[cls * 64 + lane] += 1;
-                samples++;
-            }
         }
-        __syncthreads();
     }
+    uint32_t *fin = info + (a.nsteps & 1) * NC * 64;
+    fin[slot * 64 + lane] = pack_info(n, sid, cls, flag);
+    __syncthreads();
 
     // ---- results: coalesced stores ---------------------------------------------------
     if (a.counts != nullptr)
@@ -341,14 +373,14 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
         if (a.samples != nullptr) a.samples[s0 + lane] = samples;
         if (a.tops0 != nullptr) a.tops0[s0 + lane] = tops0;
         if (a.flags != nullptr)
-            for (int c = 0; c < NC; ++c) a.flags[(s0 + lane) * NC + c] = (flagbits >> c) & 1u;
+            for (int c = 0; c < NC; ++c) a.flags[(s0 + lane) * NC + c] = (uint8_t)(fin[c * 64 + lane] >> 31);
     }
     if (a.write_states && a.states != nullptr) {
         uint8_t *dst = a.states + s0 * (uint64_t)NC * nq;
         const int per = NC * nq, total = cnt * per;
         for (int o = tid; o < total; o += nthreads) {
             const int j = o / per, rem = o - j * per, c = rem / nq, q = rem - c * nq;
-            const uint32_t sidc = perm[c * 64 + j];
+            const uint32_t sidc = (fin[c * 64 + j] >> 16) & 0xFFu;
             dst[o] = (uint8_t)((st[(sidc * W + (q >> 4)) * 64 + j] >> ((q & 15) * 2)) & 3u);
         }
     }

@@ -15,6 +15,15 @@ struct u32x4 { uint32_t x, y, z, w; };
 //   swap stream), sub = block number within one proposal / swap sweep.
 constexpr uint32_t kSwapStream = 0x100u;
 
+__host__ __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);   // one v_bitop3_b32 instead of two v_xor_b32
+#else
+    return a ^ b ^ c;
+#endif
+}
+
 __host__ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                                         uint32_t k0, uint32_t k1)
 {
@@ -22,8 +31,8 @@ __host__ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1
     for (int r = 0; r < 10; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n0 = xor3((uint32_t)(p1 >> 32), c1, k0);
+        const uint32_t n2 = xor3((uint32_t)(p0 >> 32), c3, k1);
         c1 = (uint32_t)p1;
         c3 = (uint32_t)p0;
         c0 = n0;
@@ -40,6 +49,12 @@ __host__ __device__ __forceinline__ u32x4 philox_block(uint64_t k, uint32_t sub,
     return philox4x32_10((uint32_t)k, (uint32_t)((k >> 32) & 0xFFFFu) | (sub << 16), syndrome, stream,
                          seed_lo, seed_hi);
 }
+
+// Logical-operator positions of a top-chain proposal share its block (k,0) with the
+// operator draws (DESIGN.md "RNG addressing"): X_pos of layer 0 / 1 = low 30 bits of
+// word 1 / 2, Z_pos of layer 0 / 1 = high / low half of word 3.
+__host__ __device__ __forceinline__ uint32_t scale_low30(uint32_t w, uint32_t n) { return (uint32_t)(((uint64_t)(w << 2) * n) >> 32); }
+__host__ __device__ __forceinline__ uint32_t scale_u16(uint32_t h, uint32_t n) { return (h * n) >> 16; }
 
 // int(u * n) for u = x * 2^-32, exactly (toric_model.py:291 `int(random() * size)`)
 __host__ __device__ __forceinline__ uint32_t scale_u32(uint32_t x, uint32_t n)

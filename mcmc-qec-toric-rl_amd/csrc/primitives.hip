@@ -92,14 +92,11 @@ __global__ void k_chain_update(const ChainArgs a)
             int row = 0, col = 0, op = 0, op0 = 0, op1 = 0, x0 = 0, z0 = 0, x1 = 0, z1 = 0;
             const bool logical = (uint64_t)x.x < a.thr_logical;
             if (logical) {
-                op0 = x.y >> 30; op1 = x.z >> 30;
-                const u32x4 b = philox_block(k, 1, syn, a.slot, a.seed_lo, a.seed_hi);
-                const uint32_t bw[4] = {b.x, b.y, b.z, b.w};
-                int nb = 0;
-                if (op0 == 1 || op0 == 2) x0 = scale_u32(bw[nb++], L);
-                if (op0 == 3 || op0 == 2) z0 = scale_u32(bw[nb++], L);
-                if (op1 == 1 || op1 == 2) x1 = scale_u32(bw[nb++], L);
-                if (op1 == 3 || op1 == 2) z1 = scale_u32(bw[nb++], L);
+                op0 = x.y >> 30; op1 = x.z >> 30;                       // toric_model.py:234
+                if (op0 == 1 || op0 == 2) x0 = scale_low30(x.y, L);     // :241-248 (positions share block (k,0))
+                if (op0 == 3 || op0 == 2) z0 = scale_u16(x.w >> 16, L);
+                if (op1 == 1 || op1 == 2) x1 = scale_low30(x.z, L);
+                if (op1 == 3 || op1 == 2) z1 = scale_u16(x.w & 0xFFFFu, L);
                 dE = toric_apply_logical_b(L, m, op0, 0, x0, z0) + toric_apply_logical_b(L, m, op1, 1, x1, z1);
             } else {
                 row = scale_u32(x.y, L); col = scale_u32(x.z, L); op = (x.w >> 31) ? 1 : 3;

@@ -54,8 +54,10 @@ void orc_rng_init_philox(orc_rng *r, uint64_t seed, uint32_t syndrome)
 
 /* One uniform in [0,1).  Stream mode ignores the address and just takes the
  * next injected double (the reference has a single global `random` stream).
- * Philox mode: u = word `w` of block (k, sub) of `stream_id`, times 2^-32. */
-static double orc_draw(orc_rng *r, uint32_t stream_id, uint64_t k, uint32_t sub, int w)
+ * Philox mode: word `w` of block (k, sub) of `stream_id`; the uniform is the
+ * `nbits`-bit field that starts `shl` bits below the top of the word, scaled by
+ * 2^-nbits (shl = 0, nbits = 32: the whole word). */
+static double orc_draw_field(orc_rng *r, uint32_t stream_id, uint64_t k, uint32_t sub, int w, int shl, int nbits)
 {
     r->consumed++;
     if (r->mode == 0) {
@@ -73,7 +75,13 @@ static double orc_draw(orc_rng *r, uint32_t stream_id, uint64_t k, uint32_t sub,
         orc_philox4x32_10(ctr, key, r->c_w);
         r->c_stream = stream_id; r->c_k = k; r->c_sub = sub; r->c_valid = 1;
     }
-    return (double)r->c_w[w] * (1.0 / 4294967296.0);
+    uint32_t field = (uint32_t)(r->c_w[w] << shl) >> (32 - nbits);
+    return (double)field / (double)(1ull << nbits);
+}
+
+static double orc_draw(orc_rng *r, uint32_t stream_id, uint64_t k, uint32_t sub, int w)
+{
+    return orc_draw_field(r, stream_id, k, sub, w, 0, 32);
 }
 
 #define ORC_SWAP_STREAM 0x100u
@@ -217,19 +225,22 @@ static int toric_random_stabilizer(int L, const uint8_t *in, uint8_t *out, orc_r
 }
 
 /* _apply_random_logical, src/toric_model.py:228-253: op0, op1 first, then per
- * layer X_pos iff op in {1,2}, Z_pos iff op in {3,2}. */
+ * layer X_pos iff op in {1,2}, Z_pos iff op in {3,2}.  Philox addressing keeps the
+ * whole proposal in block (k,0): op0 / op1 = top two bits of words 1 / 2; X_pos of
+ * layer 0 / 1 = the low 30 bits of words 1 / 2; Z_pos of layer 0 / 1 = the high /
+ * low half of word 3 (disjoint bit fields of one block are independent uniforms). */
 static int toric_random_logical(int L, const uint8_t *in, uint8_t *out, orc_rng *rng,
                                 uint32_t slot, uint64_t k)
 {
     int ops[2];
     ops[0] = (int)(orc_draw(rng, slot, k, 0, 1) * 4);
     ops[1] = (int)(orc_draw(rng, slot, k, 0, 2) * 4);
-    int nb = 0, dE = 0;
+    int dE = 0;
     if (out != in) memcpy(out, in, (size_t)2 * L * L);
     for (int layer = 0; layer < 2; ++layer) {
         int op = ops[layer], xpos = 0, zpos = 0;
-        if (op == 1 || op == 2) xpos = (int)(orc_draw(rng, slot, k, 1, nb++) * L);
-        if (op == 3 || op == 2) zpos = (int)(orc_draw(rng, slot, k, 1, nb++) * L);
+        if (op == 1 || op == 2) xpos = (int)(orc_draw_field(rng, slot, k, 0, 1 + layer, 2, 30) * L);
+        if (op == 3 || op == 2) zpos = (int)(orc_draw_field(rng, slot, k, 0, 3, 16 * layer, 16) * L);
         dE += orc_toric_apply_logical(L, out, out, op, layer, xpos, zpos);
     }
     return dE;
