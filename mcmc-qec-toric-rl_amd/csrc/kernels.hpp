@@ -32,6 +32,9 @@ struct LadderArgs {
     uint32_t acc_thr[kMaxNc][4];   // ceil(f_c^dE * 2^32), dE = 1..4
     int32_t swap_fast_ok;          // every swap threshold with d >= 1 fits 32 bits (false only if two rungs coincide)
     int L, Nc, W, nq, ncls;
+#ifdef QECMC_TIMELINE
+    uint64_t *dbg;            // [grid][4] diagnostic stamps (tools/timeline.hip only)
+#endif
     int resume;               // 0: replicate init into every slot (mcmc.py:72); 1: load states/flags/tops0
     int write_states;
 };

@@ -110,6 +110,13 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
     uint32_t *thrT = hist + ncls * 64;            // [NC][9]       accept iff x <= thrT[slot][dE+4]
     uint32_t *swapT = thrT + NC * 9;              // [NC][kSwapFast]  swap iff x <= swapT[i][d]
 
+#ifdef QECMC_TIMELINE   // diagnostic build only (tools/timeline.hip): per-workgroup start/end stamps and placement
+    if (a.dbg && threadIdx.x == 0) {
+        a.dbg[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+        a.dbg[blockIdx.x * 4 + 1] = ((uint64_t)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) |   // XCC_ID
+                                    __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));                       // HW_ID
+    }
+#endif
     const uint64_t s0 = (uint64_t)blockIdx.x * 64u;
     const int cnt = (int)((a.N - s0) < 64u ? (a.N - s0) : 64u);
     const uint32_t syn = a.first_syndrome + (uint32_t)s0 + (uint32_t)lane;   // Philox ctr[2]
@@ -170,25 +177,38 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
         if (slot == 0) tops0 = a.tops0[s0 + lane];
     }
 
-    const uint32_t slot_u = __builtin_amdgcn_readfirstlane(slot);
-    const bool acc_all = (a.acc_all_mask >> slot_u) & 1u;
-    const bool top_logical = (slot_u == (uint32_t)(NC - 1)) && a.thr_logical != 0;
+    // Roles rotate: at every ladder step each wave moves on to the next slot, so the heavier top
+    // slot (frame flush + recount) visits every SIMD in turn instead of loading one of them for
+    // the whole run.  Results do not depend on which wave computes a slot.
+    const uint32_t wave_u = __builtin_amdgcn_readfirstlane(slot);
+    uint32_t slot_u = wave_u;                                   // the slot this wave works on in the current step
     const uint32_t iters = a.iters;
     const uint32_t thrL1 = (uint32_t)(a.thr_logical - 1);      // x < thr_logical <=> x <= thr_logical-1 (thr in [1, 2^32])
-    const uint32_t *myT = thrT + slot_u * 9 + 4;
     const uint32_t Lodd = L & 1;                                // a row/column operator flips L parities
     const uint32_t rowbits = 2u * (uint32_t)L;                  // bits of one lattice row in the packed stream
     const uint32_t rowmask = rowbits >= 32 ? 0xFFFFFFFFu : (1u << rowbits) - 1u;
     const bool swap_fast = a.swap_fast_ok != 0;
 
     for (uint64_t t = 0; t < a.nsteps; ++t) {
+        // Issue arbitration between co-resident workgroups is oldest-first, which lets the first one
+        // race ahead and leaves the last one alone (latency-bound, 2 waves per SIMD) at the end of a
+        // launch.  Lowering a workgroup's priority as it advances (cyclically, every 8 steps) narrows
+        // that spread: +6 % on a one-round grid (measured), neutral otherwise.
+        switch (3u - (uint32_t)((t >> 3) & 3)) {    // s_setprio takes an immediate
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+        }
         // ---------------- Chain.update_chain(iters) on every slot (mcmc.py:81-83) -----------
         uint32_t *stw = st + sid * W * 64 + lane;
         const uint64_t kbase = a.prop0 + t * iters;
+        const bool acc_all = (a.acc_all_mask >> slot_u) & 1u;
+        const bool top_logical = (slot_u == (uint32_t)(NC - 1)) && a.thr_logical != 0;
+        const uint32_t *myT = thrT + slot_u * 9 + 4;
         if (!top_logical) {
             int ni = (int)n;
-            for (uint32_t j = 0; j < iters; ++j) {
-                const u32x4 x = philox_block(kbase + j, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+            auto propose = [&](const u32x4 &x) {
                 const uint32_t row = scale_u32(x.x, L), col = scale_u32(x.y, L);   // toric_model.py:291-292
                 const uint32_t isX = x.z >> 31;                                    // :293-295
                 uint32_t q[4];
@@ -209,7 +229,17 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                     for (int i = 0; i < 4; ++i) lds_xor(ad[i], op << sh[i]);
                     ni += dE;
                 }
+            };
+            // the uniforms of a proposal do not depend on the state: draw two proposals' Philox blocks
+            // together so their serial 10-round chains overlap, then apply the proposals in order
+            uint32_t j = 0;
+            for (; j + 1 < iters; j += 2) {
+                const u32x4 xa = philox_block(kbase + j, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                const u32x4 xb = philox_block(kbase + j + 1, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                propose(xa);
+                propose(xb);
             }
+            if (j < iters) propose(philox_block(kbase + j, 0, syn, slot_u, a.seed_lo, a.seed_hi));
             n = (uint32_t)ni;
         } else if (acc_all && L <= 16) {
             // Top chain at p = 0.75: every proposal is accepted (mcmc.py:30), so moves are blind
@@ -319,12 +349,12 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
         // ---------------- swap sweep, Ladder.step mcmc.py:96-103 --------------------------------
         // (double-buffered by step parity: a fast wave may publish step t+1 while a slow one still reads step t)
         uint32_t *cur = info + (t & 1) * NC * 64 + lane, *sx = swx + (t & 1) * NC * 64 + lane;
-        cur[slot * 64] = pack_info(n, sid, cls, flag);
-        if (slot_u < 4 && (int)slot_u * 4 < NC - 1) {
+        cur[slot_u * 64] = pack_info(n, sid, cls, flag);
+        if (wave_u < 4 && (int)wave_u * 4 < NC - 1) {
             // the sweep's uniforms do not depend on the state: waves 0..3 draw one Philox block each
-            const u32x4 b = philox_block(a.step0 + t, slot_u, syn, kSwapStream, a.seed_lo, a.seed_hi);
-            uint32_t *p = sx + slot_u * 4 * 64;                    // rows 4b .. 4b+3 = rung pairs, NC-1 of them exist
-            const int left = NC - 1 - (int)slot_u * 4;
+            const u32x4 b = philox_block(a.step0 + t, wave_u, syn, kSwapStream, a.seed_lo, a.seed_hi);
+            uint32_t *p = sx + wave_u * 4 * 64;                    // rows 4b .. 4b+3 = rung pairs, NC-1 of them exist
+            const int left = NC - 1 - (int)wave_u * 4;
             p[0] = b.x;
             if (left > 1) p[64] = b.y;
             if (left > 2) p[128] = b.z;
@@ -333,7 +363,8 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
         __syncthreads();
         {
             // every wave replays the top-down cascade on the published records; `car` is the record
-            // being carried down, `mine` the one that ends in this wave's slot
+            // being carried down, `mine` the one that ends in the slot this wave takes over next
+            slot_u = slot_u + 1 == (uint32_t)NC ? 0u : slot_u + 1;
             uint32_t car = cur[(NC - 1) * 64], mine = car;
             for (int i = NC - 2; i >= 0; --i) {                                    // mcmc.py:96
                 const uint32_t lo = cur[i * 64], xi = sx[i * 64];
@@ -350,17 +381,21 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             if (slot_u == 0) mine = car;
             n = mine & 0xFFFFu; sid = (mine >> 16) & 0xFFu; cls = (mine >> 24) & 0x3Fu; flag = mine >> 31;
             if ((int)slot_u == NC - 1) flag = 1;                                    // chains[-1].flag = 1, mcmc.py:100
-            if (slot_u == 0) {                                                      // ladder + PTEQ bookkeeping
-                if (flag) { tops0++; flag = 0; }                                    // :101-103
+            if (wave_u == 0) {                                                      // ladder + PTEQ bookkeeping on slot 0's new state
+                tops0 += (NC == 1) | (car >> 31);                                   // chains[0].flag == 1, :101-102
                 if (a.counts != nullptr && tops0 >= a.tops_burn) {                  // decoders.py:60-67
-                    hist[cls * 64 + lane] += 1;
+                    hist[((car >> 24) & 0x3Fu) * 64 + lane] += 1;
                     samples++;
                 }
             }
+            if (slot_u == 0) flag = 0;                                              // :103
         }
     }
+#ifdef QECMC_TIMELINE
+    if (a.dbg && threadIdx.x == 0) a.dbg[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+#endif
     uint32_t *fin = info + (a.nsteps & 1) * NC * 64;
-    fin[slot * 64 + lane] = pack_info(n, sid, cls, flag);
+    fin[slot_u * 64 + lane] = pack_info(n, sid, cls, flag);
     __syncthreads();
 
     // ---- results: coalesced stores ---------------------------------------------------
