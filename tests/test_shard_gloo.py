@@ -1,0 +1,73 @@
+"""The N>1 path on CPU: world_size-2 (and 3) gloo process groups exercise shard bounds and the
+gather of per-class counts; the per-shard compute is the oracle (tests may use it as a stand-in
+for the GPU call), and the sharded answer must equal the unsharded one bit for bit."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _oracle_compute(init, p, first_syndrome=0, Nc=None, steps=100, iters=10, tops_burn=2, seed=0, **_):
+    from oracle import oracle as orc
+    r = orc.toric_pteq_batch(init, p, Nc, steps, iters=iters, tops_burn=tops_burn, seed=seed,
+                             first_syndrome=first_syndrome, n_threads=1)
+    return dict(counts=r["counts"], samples=r["samples"], tops0=r["tops0"])
+
+
+def _worker(rank, world, port, n_total, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "mcmc-qec-toric-rl_amd"))
+    import torch.distributed as dist
+    from qecmc.sharding import pteq_batch_sharded
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    rng = np.random.default_rng(5)
+    init = np.zeros((n_total, 2, 3, 3), dtype=np.uint8)
+    err = rng.random(init.shape) < 0.15
+    init[err] = rng.integers(1, 4, size=int(err.sum()), dtype=np.uint8)
+    out = pteq_batch_sharded(init, 0.1, compute=_oracle_compute, Nc=3, steps=60, tops_burn=0, seed=7)
+    if rank == 0:
+        full = _oracle_compute(init, 0.1, Nc=3, steps=60, tops_burn=0, seed=7)
+        ok = all(np.array_equal(out[k], full[k].astype(np.uint32)) for k in ("counts", "samples", "tops0"))
+        q.put(bool(ok))
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_total", [(2, 11), (2, 8), (3, 10)])
+def test_sharded_equals_unsharded(world, n_total):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
+def test_shard_bounds_cover_everything():
+    sys.path.insert(0, os.path.join(ROOT, "mcmc-qec-toric-rl_amd"))
+    from qecmc.sharding import shard_bounds
+    for n in (0, 1, 7, 8, 65536, 1048576 + 3):
+        for w in (1, 2, 3, 8):
+            b = [shard_bounds(n, w, r) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1

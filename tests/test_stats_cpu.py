@@ -1,0 +1,75 @@
+"""Statistical pins of the oracle in Philox mode (the mode the GPU is compared with bit for bit):
+exact enumeration at L=3, and the reference's own replica-averaged histograms (fixture F3)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from conftest import GOLDEN
+from util_exact import toric_class_probabilities
+
+
+def _rand_state(seed, L, p):
+    rng = np.random.default_rng(seed)
+    m = np.zeros((2, L, L), dtype=np.uint8)
+    err = rng.random(m.shape) < p
+    m[err] = rng.integers(1, 4, size=int(err.sum()), dtype=np.uint8)
+    return m
+
+
+def test_exact_enumeration_is_representative_independent():
+    M = np.array([[[0, 2, 0], [0, 0, 1], [3, 0, 0]], [[1, 0, 0], [0, 3, 0], [0, 0, 2]]], dtype=np.uint8)
+    P = toric_class_probabilities(M, 0.1, orc.toric_apply_stabilizer, orc.toric_to_class)
+    assert abs(P.sum() - 1) < 1e-12 and (P > 0).all()
+    # any other chain with the same syndrome (a stabilizer or a logical operator away) gives the same answer
+    M2, _ = orc.toric_apply_stabilizer(M, 1, 2, 3)
+    M3 = orc.toric_to_class(M2, 9)
+    for other in (M2, M3):
+        assert np.allclose(P, toric_class_probabilities(other, 0.1, orc.toric_apply_stabilizer, orc.toric_to_class), rtol=1e-12)
+
+
+@pytest.mark.parametrize("seed,p,Nc", [(1, 0.10, 3), (2, 0.15, 4)])
+def test_oracle_philox_matches_exact_enumeration_L3(seed, p, Nc):
+    init = _rand_state(seed, 3, 0.15)
+    P = toric_class_probabilities(init, p, orc.toric_apply_stabilizer, orc.toric_to_class)
+    R, steps = 96, 6000
+    res = orc.toric_pteq_batch(np.broadcast_to(init, (R,) + init.shape).copy(), p, Nc, steps, iters=10, tops_burn=5,
+                               seed=100 + seed, n_threads=8)
+    assert (res["samples"] > steps // 2).all()
+    frac = res["counts"] / res["samples"][:, None].astype(np.float64)
+    mean, sem = frac.mean(axis=0), frac.std(axis=0, ddof=1) / np.sqrt(R)
+    assert np.all(np.abs(mean - P) <= 5 * sem + 2e-4), (mean, P, sem)
+
+
+def _f3_protocol_oracle(init, p, Nc, iters, steps, burn, seed, syndrome):
+    ld = orc.ToricLadder(init, p, Nc, 0.5)
+    rng = orc.Rng.philox(seed, syndrome)
+    hist = np.zeros(16)
+    nerr = np.zeros(Nc)
+    for t in range(steps):
+        ld.step(iters, rng)
+        if t >= burn:
+            st = ld.states
+            hist[orc.toric_eq_class(st[0])] += 1
+            nerr += [orc.count_errors(s) for s in st]
+    return hist / (steps - burn), nerr / (steps - burn)
+
+
+@pytest.mark.parametrize("name", ["L3", "L5"])
+def test_oracle_philox_matches_reference_histograms(name):
+    """Same protocol as the fixture (fixed burn-in, R replicas): replica means of the bottom-chain class
+    histogram and of the per-rung error counts agree with the reference within the combined standard error."""
+    g = np.load(os.path.join(GOLDEN, "f3_toric.npz"))
+    L, p, Nc, iters, steps, burn = g[f"{name}_par"]
+    L, Nc, iters = int(L), int(Nc), int(iters)
+    steps_o, burn_o, R = 3000, 500, 12                    # shorter oracle runs keep the CPU suite fast
+    for s in range(g[f"{name}_init"].shape[0]):
+        ref_h = g[f"{name}_hist"][s] / (steps - burn)
+        ref_n = g[f"{name}_nerr"][s]
+        runs = [_f3_protocol_oracle(g[f"{name}_init"][s], float(p), Nc, iters, steps_o, burn_o, 900 + s, r) for r in range(R)]
+        oh = np.array([h for h, _ in runs]); on = np.array([n for _, n in runs])
+        se_h = np.sqrt(ref_h.var(axis=0, ddof=1) / ref_h.shape[0] + oh.var(axis=0, ddof=1) / R)
+        se_n = np.sqrt(ref_n.var(axis=0, ddof=1) / ref_n.shape[0] + on.var(axis=0, ddof=1) / R)
+        assert np.all(np.abs(ref_h.mean(axis=0) - oh.mean(axis=0)) <= 4.5 * se_h + 5e-3), (s, ref_h.mean(0), oh.mean(0))
+        assert np.all(np.abs(ref_n.mean(axis=0) - on.mean(axis=0)) <= 4.5 * se_n + 0.05), (s, ref_n.mean(0), on.mean(0))
