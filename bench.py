@@ -141,7 +141,7 @@ def main():
 
     def one_pass():
         L_.check(L_.lib().qecmc_pteq_launch_dev(plan, d_init.data_ptr(), N, first, d_counts.data_ptr(),
-                                                d_samples.data_ptr(), d_tops0.data_ptr(), None,
+                                                d_samples.data_ptr(), d_tops0.data_ptr(), None, None, None, None,
                                                 C.c_void_p(stream.cuda_stream)))
 
     def exchange():

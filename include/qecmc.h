@@ -127,19 +127,27 @@ int qecmc_ladder_step(const qecmc_params *params, uint64_t N, uint8_t *states_in
  * generate_data.py:131-138); counts_out uint32[N][ncls] = eq[since_burn]
  * (decoders.py:66-67); samples_out uint32[N] = since_burn+1 or 0 when the burn-in
  * never ended (A10 "burn-in trap"); tops0_out uint32[N] (nullable);
- * final_states_out uint8[N][Nc][nq] in slot order (nullable); stats nullable. */
+ * steps_done_out uint32[N] (nullable) = ladder steps run until the convergence
+ * criterion fired (decoders.py:74-82), or params->steps; converged_out uint8[N]
+ * (nullable); final_states_out uint8[N][Nc][nq] in slot order (nullable; only
+ * meaningful with conv_mode NONE); stats nullable.
+ * conv_mode ERROR_BASED needs 2*N*steps bytes of device workspace (the per-step
+ * bottom-chain error counts the criterion averages, decoders.py:68,93-105). */
 int qecmc_pteq_batch(const qecmc_params *params, const uint8_t *init, uint64_t N, uint32_t *counts_out,
-                     uint32_t *samples_out, uint32_t *tops0_out, uint8_t *final_states_out,
-                     qecmc_stats *stats_out);
+                     uint32_t *samples_out, uint32_t *tops0_out, uint32_t *steps_done_out,
+                     uint8_t *converged_out, uint8_t *final_states_out, qecmc_stats *stats_out);
 
 /* Plan + device-pointer form: build once (validates, uploads threshold tables),
- * then launch asynchronously on a caller stream with buffers already in HBM. */
+ * then launch asynchronously on a caller stream with buffers already in HBM.
+ * d_workspace: qecmc_plan_workspace_bytes() bytes (0 for conv_mode NONE, then NULL is fine). */
 typedef struct qecmc_plan qecmc_plan;
 int qecmc_plan_create(const qecmc_params *params, qecmc_plan **plan_out);
 int qecmc_plan_destroy(qecmc_plan *plan);
+int qecmc_plan_workspace_bytes(const qecmc_plan *plan, uint64_t N, uint64_t *bytes_out);
 int qecmc_pteq_launch_dev(qecmc_plan *plan, const void *d_init, uint64_t N, uint32_t first_syndrome,
                           void *d_counts, void *d_samples, void *d_tops0 /*nullable*/,
-                          void *d_final_states /*nullable*/, void *hip_stream);
+                          void *d_steps_done /*nullable*/, void *d_converged /*nullable*/,
+                          void *d_final_states /*nullable*/, void *d_workspace /*nullable*/, void *hip_stream);
 /* Bytes of dynamic LDS and threads per workgroup the plan's kernel uses (for reports). */
 int qecmc_plan_info(const qecmc_plan *plan, uint32_t *lds_bytes, uint32_t *block_threads,
                     uint32_t *syndromes_per_block);

@@ -131,7 +131,8 @@ int validate_params(const qecmc_params *p)
     if (!(p->p_logical >= 0.0) || !(p->p_logical <= 1.0)) return fail(QECMC_ERR_INVALID, "p_logical=%g must be in [0,1]", p->p_logical);
     if (p->noise != QECMC_NOISE_DEPOLARIZING) return fail(QECMC_ERR_UNSUPPORTED, "noise model %d not built yet", p->noise);
     if (p->scan != QECMC_SCAN_RANDOM) return fail(QECMC_ERR_UNSUPPORTED, "scan mode %d not built yet", p->scan);
-    if (p->conv_mode != QECMC_CONV_NONE) return fail(QECMC_ERR_UNSUPPORTED, "conv_mode %d not built yet (use fixed steps)", p->conv_mode);
+    if (p->conv_mode != QECMC_CONV_NONE && p->conv_mode != QECMC_CONV_ERROR_BASED) return fail(QECMC_ERR_INVALID, "conv_mode %d unknown", p->conv_mode);
+    if (p->conv_mode == QECMC_CONV_ERROR_BASED && (p->TOPS < 0 || p->SEQ < 0 || !(p->eps >= 0))) return fail(QECMC_ERR_INVALID, "TOPS, SEQ and eps must be non-negative");
     if (p->iters == 0 || p->iters > 0xFFFFFFFFull) return fail(QECMC_ERR_INVALID, "iters out of range");
     if (p->tops_burn < 0) return fail(QECMC_ERR_INVALID, "tops_burn must be >= 0");
     return 0;
@@ -147,6 +148,7 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
     a.iters = (uint32_t)p->iters;
     a.seed_lo = (uint32_t)p->seed; a.seed_hi = (uint32_t)(p->seed >> 32);
     a.tops_burn = (uint32_t)p->tops_burn;
+    a.conv_mode = p->conv_mode; a.TOPS = (uint32_t)p->TOPS; a.SEQ = (uint32_t)p->SEQ; a.eps = p->eps;
     a.thr_logical = p->p_logical > 0 ? thr64(p->p_logical) : 0;
     pl->lds_bytes = ladder_lds_bytes(L, Nc, W, ncls);
     if (pl->lds_bytes > 160 * 1024)
@@ -385,18 +387,31 @@ int qecmc_plan_info(const qecmc_plan *plan, uint32_t *lds_bytes, uint32_t *block
     return 0;
 }
 
+int qecmc_plan_workspace_bytes(const qecmc_plan *plan, uint64_t N, uint64_t *bytes_out)
+{
+    if (!plan || !bytes_out) return fail(QECMC_ERR_INVALID, "NULL argument");
+    *bytes_out = plan->prm.conv_mode == QECMC_CONV_ERROR_BASED ? 2ull * N * plan->prm.steps : 0ull;
+    return 0;
+}
+
 int qecmc_pteq_launch_dev(qecmc_plan *plan, const void *d_init, uint64_t N, uint32_t first_syndrome, void *d_counts,
-                          void *d_samples, void *d_tops0, void *d_final_states, void *hip_stream)
+                          void *d_samples, void *d_tops0, void *d_steps_done, void *d_converged, void *d_final_states,
+                          void *d_workspace, void *hip_stream)
 {
     if (!plan) return fail(QECMC_ERR_INVALID, "plan is NULL");
     if (N == 0) return 0;
     if (!d_init || !d_counts || !d_samples) return fail(QECMC_ERR_INVALID, "NULL device buffer");
     if (N + first_syndrome > 0xFFFFFFFFull) return fail(QECMC_ERR_INVALID, "global syndrome index exceeds 32 bits");
+    if (plan->prm.conv_mode == QECMC_CONV_ERROR_BASED && !d_workspace)
+        return fail(QECMC_ERR_INVALID, "conv_mode error_based needs the workspace of qecmc_plan_workspace_bytes()");
     LadderArgs a = plan->args;
     a.init = static_cast<const uint8_t *>(d_init);
     a.counts = static_cast<uint32_t *>(d_counts);
     a.samples = static_cast<uint32_t *>(d_samples);
     a.tops0 = static_cast<uint32_t *>(d_tops0);
+    a.steps_done = static_cast<uint32_t *>(d_steps_done);
+    a.converged = static_cast<uint8_t *>(d_converged);
+    a.nlog = static_cast<uint16_t *>(d_workspace);
     a.states = static_cast<uint8_t *>(d_final_states);
     a.write_states = d_final_states != nullptr;
     a.N = N; a.first_syndrome = first_syndrome;
@@ -406,7 +421,8 @@ int qecmc_pteq_launch_dev(qecmc_plan *plan, const void *d_init, uint64_t N, uint
 }
 
 int qecmc_pteq_batch(const qecmc_params *params, const uint8_t *init, uint64_t N, uint32_t *counts_out,
-                     uint32_t *samples_out, uint32_t *tops0_out, uint8_t *final_states_out, qecmc_stats *stats_out)
+                     uint32_t *samples_out, uint32_t *tops0_out, uint32_t *steps_done_out, uint8_t *converged_out,
+                     uint8_t *final_states_out, qecmc_stats *stats_out)
 {
     const auto t0 = std::chrono::steady_clock::now();
     qecmc_plan *pl = nullptr;
@@ -415,14 +431,24 @@ int qecmc_pteq_batch(const qecmc_params *params, const uint8_t *init, uint64_t N
     if (N == 0) return 0;
     if (!init || !counts_out || !samples_out) return fail(QECMC_ERR_INVALID, "NULL buffer");
     const size_t nq = pl->args.nq, Nc = pl->args.Nc, ncls = pl->args.ncls;
-    DevBuf di, dc, ds, dt, df;
+    uint64_t ws_bytes = 0;
+    qecmc_plan_workspace_bytes(pl, N, &ws_bytes);
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    if (ws_bytes > free_b / 2)
+        return fail(QECMC_ERR_INVALID, "conv_mode error_based needs %llu bytes of workspace (2*N*steps), %zu free: lower "
+                    "`steps` or the batch size", (unsigned long long)ws_bytes, free_b);
+    DevBuf di, dc, ds, dt, dsd, dcv, df, dw;
     HIP_TRY(di.alloc(N * nq)); HIP_TRY(dc.alloc(N * ncls * 4)); HIP_TRY(ds.alloc(N * 4)); HIP_TRY(dt.alloc(N * 4));
+    HIP_TRY(dsd.alloc(N * 4)); HIP_TRY(dcv.alloc(N));
+    if (ws_bytes) HIP_TRY(dw.alloc(ws_bytes));
     if (final_states_out) HIP_TRY(df.alloc(N * Nc * nq));
     HIP_TRY(hipMemcpy(di.p, init, N * nq, hipMemcpyHostToDevice));
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, 0));
-    int rc = qecmc_pteq_launch_dev(pl, di.p, N, params->first_syndrome, dc.p, ds.p, dt.p, final_states_out ? df.p : nullptr, nullptr);
+    int rc = qecmc_pteq_launch_dev(pl, di.p, N, params->first_syndrome, dc.p, ds.p, dt.p, dsd.p, dcv.p,
+                                   final_states_out ? df.p : nullptr, ws_bytes ? dw.p : nullptr, nullptr);
     if (rc) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
     HIP_TRY(hipEventRecord(e1, 0));
     HIP_TRY(hipEventSynchronize(e1));
@@ -432,9 +458,11 @@ int qecmc_pteq_batch(const qecmc_params *params, const uint8_t *init, uint64_t N
     HIP_TRY(hipMemcpy(counts_out, dc.p, N * ncls * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(samples_out, ds.p, N * 4, hipMemcpyDeviceToHost));
     if (tops0_out) HIP_TRY(hipMemcpy(tops0_out, dt.p, N * 4, hipMemcpyDeviceToHost));
+    if (steps_done_out) HIP_TRY(hipMemcpy(steps_done_out, dsd.p, N * 4, hipMemcpyDeviceToHost));
+    if (converged_out) HIP_TRY(hipMemcpy(converged_out, dcv.p, N, hipMemcpyDeviceToHost));
     if (final_states_out) HIP_TRY(hipMemcpy(final_states_out, df.p, N * Nc * nq, hipMemcpyDeviceToHost));
     if (stats_out) {
-        stats_out->proposals = N * Nc * params->iters * params->steps;
+        stats_out->proposals = N * Nc * params->iters * params->steps;   // upper bound when the criterion stops early
         stats_out->swap_tests = N * (Nc - 1) * params->steps;
         stats_out->kernel_ms = ms;
         stats_out->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -18,6 +18,9 @@ struct LadderArgs {
     uint32_t *tops0;          // [N]               resume in / out (nullable)
     uint32_t *counts;         // [N][ncls]         out (nullable)
     uint32_t *samples;        // [N]               out (nullable)
+    uint32_t *steps_done;     // [N]               out (nullable): ladder steps until convergence (or nsteps)
+    uint8_t *converged;       // [N]               out (nullable)
+    uint16_t *nlog;           // [nsteps][N]       bottom-chain error counts (conv_mode workspace)
     const uint64_t *swap_thr; // [Nc-1][nq+1]      ceil(p_diff[i]^d * 2^32)
     const uint32_t *lmask;    // [4][L+1][W]       logical-operator XOR masks (row L = identity)
     const uint32_t *acc_tbl_top; // [nq+1]          ceil(f_top^dE * 2^32): top slot below p = 0.75 (Nc == 1 only)
@@ -28,6 +31,9 @@ struct LadderArgs {
     uint32_t first_syndrome;
     uint32_t seed_lo, seed_hi;
     uint32_t tops_burn;
+    uint32_t TOPS, SEQ;       // decoders.py:74,78
+    double eps;               // decoders.py:102
+    int conv_mode;            // 0 = fixed steps, 1 = error_based
     uint32_t acc_all_mask;    // bit c: slot c accepts every proposal (f >= 1, mcmc.py:30)
     uint32_t acc_thr[kMaxNc][4];   // ceil(f_c^dE * 2^32), dE = 1..4
     int32_t swap_fast_ok;          // every swap threshold with d >= 1 fits 32 bits (false only if two rungs coincide)

@@ -39,7 +39,7 @@ size_t ladder_lds_bytes(int L, int Nc, int W, int ncls)
 {
     (void)L;
     return sizeof(uint32_t) * ((size_t)Nc * W * 64 + 4 * (size_t)Nc * 64 + (size_t)ncls * 64 + (size_t)Nc * 9 +
-                               (size_t)Nc * kSwapFast);   // st + info[2] + swx[2] + hist + thrT + swapT
+                               (size_t)Nc * kSwapFast + 16);   // st + info[2] + swx[2] + hist + thrT + swapT + stop flag
 }
 
 __device__ __forceinline__ uint32_t nnz2(uint32_t x) { return __popc((x | (x >> 1)) & 0x55555555u); }
@@ -108,7 +108,8 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
     uint32_t *swx = info + 2 * NC * 64;           // [2][NC][64]   swap uniform of rung pair i, same parity
     uint32_t *hist = swx + 2 * NC * 64;           // [ncls][64]
     uint32_t *thrT = hist + ncls * 64;            // [NC][9]       accept iff x <= thrT[slot][dE+4]
-    uint32_t *swapT = thrT + NC * 9;              // [NC][kSwapFast]  swap iff x <= swapT[i][d]
+    uint32_t *swapT = thrT + NC * 9;              // [NC][kSwapFast]  swap iff x < swapT[i][d]
+    volatile uint32_t *stopf = swapT + NC * kSwapFast;   // [1]  every syndrome of the workgroup has converged
 
 #ifdef QECMC_TIMELINE   // diagnostic build only (tools/timeline.hip): per-workgroup start/end stamps and placement
     if (a.dbg && threadIdx.x == 0) {
@@ -123,6 +124,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
 
     for (int i = tid; i < NC * W * 64; i += nthreads) st[i] = 0;
     for (int i = tid; i < ncls * 64; i += nthreads) hist[i] = 0;
+    if (tid == 0) *stopf = 0;
     for (int i = tid; i < (NC - 1) * kSwapFast; i += nthreads) {
         // u < p_diff^d  <=>  x < thr; d = 0 always swaps and is never looked up (mcmc.py:146-149)
         const int pr = i / kSwapFast, d = i - pr * kSwapFast;
@@ -172,6 +174,10 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
         cls = toric_class_packed(sb, W, LL);
     }
     uint32_t tops0 = 0, samples = 0;              // per-syndrome counters live in wave 0
+    // convergence criterion of decoders.py:74-82,93-105 (wave 0 only): window sums over the logged
+    // bottom-chain error counts, Q2 = series[l/4 : l/2], Q4 = series[3l/4 : l]
+    uint32_t burn = 0, conv_start = 0, conv_streak = 0, done = 0, steps_done = 0, conv_ok = 0;
+    uint64_t sumA = 0, sumB = 0;
     if (a.resume && lane < cnt) {
         flag = a.flags[(s0 + lane) * NC + slot] != 0;
         if (slot == 0) tops0 = a.tops0[s0 + lane];
@@ -361,6 +367,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             if (left > 3) p[192] = b.w;
         }
         __syncthreads();
+        if (a.conv_mode && *stopf) break;                   // set by wave 0 one step earlier: uniform for the workgroup
         {
             // every wave replays the top-down cascade on the published records; `car` is the record
             // being carried down, `mine` the one that ends in the slot this wave takes over next
@@ -381,13 +388,42 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             if (slot_u == 0) mine = car;
             n = mine & 0xFFFFu; sid = (mine >> 16) & 0xFFu; cls = (mine >> 24) & 0x3Fu; flag = mine >> 31;
             if ((int)slot_u == NC - 1) flag = 1;                                    // chains[-1].flag = 1, mcmc.py:100
-            if (wave_u == 0) {                                                      // ladder + PTEQ bookkeeping on slot 0's new state
+            if (wave_u == 0 && !done) {                                             // ladder + PTEQ bookkeeping on slot 0's new state
                 tops0 += (NC == 1) | (car >> 31);                                   // chains[0].flag == 1, :101-102
+                const uint32_t n0 = car & 0xFFFFu;
                 if (a.counts != nullptr && tops0 >= a.tops_burn) {                  // decoders.py:60-67
                     hist[((car >> 24) & 0x3Fu) * 64 + lane] += 1;
                     samples++;
+                    if (a.conv_mode && lane < cnt) {
+                        // nbr_errors_bottom_chain[since_burn] = count_errors (:68); series index i lives in log row burn+i
+                        uint16_t *mylog = a.nlog + (s0 + lane);
+                        mylog[(size_t)t * a.N] = (uint16_t)n0;
+                        const uint32_t l = samples, lo1 = l - 1;
+                        const uint32_t a0 = lo1 >> 2, b0 = lo1 >> 1, c0 = (3u * lo1) >> 2, a1 = l >> 2, b1 = l >> 1, c1 = (3u * l) >> 2;
+                        sumB += n0;
+                        if (c1 != c0) sumB -= mylog[(size_t)(burn + c0) * a.N];
+                        if (b1 != b0) sumA += mylog[(size_t)(burn + b0) * a.N];
+                        if (a1 != a0) sumA -= mylog[(size_t)(burn + a0) * a.N];
+                    }
+                } else {
+                    burn++;                                                         // resulting_burn_in, :71
+                }
+                if (a.conv_mode && tops0 >= a.TOPS) {                               // :74
+                    const uint32_t l = samples ? samples : 1u;
+                    const uint32_t den2 = (l >> 1) - (l >> 2), den4 = l - ((3u * l) >> 2);
+                    bool accept = false;                                            // empty slice -> nan -> not accepted
+                    if (samples && den2 && den4)
+                        accept = fabs((double)sumA / (double)den2 - (double)sumB / (double)den4) < a.eps;   // :96-102
+                    if (accept) {
+                        if (conv_streak >= a.SEQ) { done = 1; conv_ok = 1; steps_done = (uint32_t)t + 1; }   // :77-78
+                        else conv_streak = tops0 - conv_start;                      // :79
+                    } else {
+                        conv_streak = 0;                                            // :81-82
+                        conv_start = tops0;
+                    }
                 }
             }
+            if (wave_u == 0 && a.conv_mode && __all(done || lane >= cnt)) *stopf = 1;
             if (slot_u == 0) flag = 0;                                              // :103
         }
     }
@@ -406,6 +442,8 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
         }
     if (slot == 0 && lane < cnt) {
         if (a.samples != nullptr) a.samples[s0 + lane] = samples;
+        if (a.steps_done != nullptr) a.steps_done[s0 + lane] = done ? steps_done : (uint32_t)a.nsteps;
+        if (a.converged != nullptr) a.converged[s0 + lane] = (uint8_t)conv_ok;
         if (a.tops0 != nullptr) a.tops0[s0 + lane] = tops0;
         if (a.flags != nullptr)
             for (int c = 0; c < NC; ++c) a.flags[(s0 + lane) * NC + c] = (uint8_t)(fin[c * 64 + lane] >> 31);

@@ -57,13 +57,14 @@ SIGNATURES = {
                                      C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64]),
     "qecmc_ladder_step": (C.c_int, [C.POINTER(Params), C.c_uint64, _u8p, _u8p, _u32p, C.c_uint64, C.c_uint64,
                                     C.c_uint64, C.c_uint64]),
-    "qecmc_pteq_batch": (C.c_int, [C.POINTER(Params), _u8p, C.c_uint64, _u32p, _u32p, _u32p, _u8p,
+    "qecmc_pteq_batch": (C.c_int, [C.POINTER(Params), _u8p, C.c_uint64, _u32p, _u32p, _u32p, _u32p, _u8p, _u8p,
                                    C.POINTER(Stats)]),
+    "qecmc_plan_workspace_bytes": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "qecmc_plan_create": (C.c_int, [C.POINTER(Params), C.POINTER(C.c_void_p)]),
     "qecmc_plan_destroy": (C.c_int, [C.c_void_p]),
     "qecmc_plan_info": (C.c_int, [C.c_void_p, _u32p, _u32p, _u32p]),
     "qecmc_pteq_launch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
-                                        C.c_void_p, C.c_void_p, C.c_void_p]),
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

@@ -15,27 +15,35 @@ def percent_from_counts(counts, samples):
 
 
 def pteq_batch(init, p, Nc=None, steps=1000, iters=10, tops_burn=2, p_logical=0.5, seed=0, first_syndrome=0,
-               device=0, return_states=False, return_stats=False):
-    """decoders.PTEQ with conv_criteria=None on N syndromes at once.
+               device=0, return_states=False, return_stats=False, conv_criteria=None, SEQ=2, TOPS=10, eps=0.1):
+    """decoders.PTEQ (decoders.py:25-89) on N syndromes at once.
 
-    init: uint8[N, 2, L, L] seed configurations (one per syndrome).
-    Returns dict(counts uint32[N,16], samples uint32[N], tops0 uint32[N], percent uint8[N,16]
-    [, states uint8[N,Nc,2,L,L]] [, stats]).
+    init: uint8[N, 2, L, L] seed configurations (one per syndrome).  conv_criteria None runs exactly
+    `steps` ladder steps; 'error_based' stops each syndrome by the reference's criterion (:74-105).
+    Returns dict(counts uint32[N,16], samples uint32[N], tops0 uint32[N], steps_done uint32[N],
+    converged bool[N], percent uint8[N,16] [, states uint8[N,Nc,2,L,L]] [, stats]).
     """
+    if conv_criteria not in (None, 'error_based'):
+        raise ValueError(f"conv_criteria={conv_criteria!r}: only None and 'error_based' exist for PTEQ")
     a, _ = L_.as_states(init, 3)
     N, size = a.shape[0], a.shape[2]
     Nc = Nc or size
     pr = L_.make_params(code=L_.TORIC, L=size, Nc=Nc, p=float(p), p_logical=float(p_logical), iters=int(iters),
-                        steps=int(steps), tops_burn=int(tops_burn), seed=seed, first_syndrome=first_syndrome,
-                        device=device)
+                        steps=int(steps), tops_burn=int(tops_burn), TOPS=int(TOPS), SEQ=int(SEQ), eps=float(eps),
+                        seed=seed, first_syndrome=first_syndrome, device=device,
+                        conv_mode=L_.CONV_ERROR_BASED if conv_criteria else L_.CONV_NONE)
     counts = np.zeros((N, 16), dtype=np.uint32)
     samples = np.zeros(N, dtype=np.uint32)
     tops0 = np.zeros(N, dtype=np.uint32)
+    steps_done = np.zeros(N, dtype=np.uint32)
+    converged = np.zeros(N, dtype=np.uint8)
     states = np.empty((N, Nc, 2, size, size), dtype=np.uint8) if return_states else None
     stats = L_.Stats()
     L_.check(L_.lib().qecmc_pteq_batch(pr, L_.u8(a), N, L_.u32(counts), L_.u32(samples), L_.u32(tops0),
+                                       L_.u32(steps_done), L_.u8(converged),
                                        L_.u8(states) if return_states else None, stats))
-    out = dict(counts=counts, samples=samples, tops0=tops0, percent=percent_from_counts(counts, samples))
+    out = dict(counts=counts, samples=samples, tops0=tops0, steps_done=steps_done, converged=converged.astype(bool),
+               percent=percent_from_counts(counts, samples))
     if return_states:
         out["states"] = states
     if return_stats:
@@ -46,15 +54,25 @@ def pteq_batch(init, p, Nc=None, steps=1000, iters=10, tops_burn=2, p_logical=0.
 
 def PTEQ(init_code, p, Nc=None, SEQ=2, TOPS=10, tops_burn=2, eps=0.1, steps=50000000, iters=10,
          conv_criteria='error_based', seed=None):
-    """Drop-in for decoders.PTEQ (decoders.py:25): same arguments, returns the uint8
-    percent vector of the equivalence classes."""
+    """Drop-in for decoders.PTEQ (decoders.py:25): same arguments, returns the uint8 percent vector of
+    the equivalence classes.  With the convergence criterion the run is issued with a growing horizon (65 536
+    ladder steps, x4 until it converges or `steps` is reached) so that the default `steps = 5e7` never allocates
+    a 5e7-entry error-count log up front.  Philox is counter-based, so a longer horizon replays the same
+    trajectory: the answer equals that of a single run with the full `steps`."""
     if tops_burn >= TOPS:
         print('tops_burn has to be smaller than TOPS')
     _code_id(init_code)
-    if conv_criteria is not None:
-        raise NotImplementedError("conv_criteria='error_based' is not built yet: pass conv_criteria=None and a "
-                                  "fixed `steps`")
     seed = _fresh_seed() if seed is None else seed
-    res = pteq_batch(init_code.qubit_matrix, p, Nc=Nc or init_code.system_size, steps=steps, iters=iters,
-                     tops_burn=tops_burn, p_logical=0.5, seed=seed)
+    kw = dict(Nc=Nc or init_code.system_size, iters=iters, tops_burn=tops_burn, p_logical=0.5, seed=seed)
+    if conv_criteria is None:
+        return pteq_batch(init_code.qubit_matrix, p, steps=steps, **kw)["percent"][0]
+    horizon = min(int(steps), 1 << 16)
+    while True:
+        res = pteq_batch(init_code.qubit_matrix, p, steps=horizon, conv_criteria=conv_criteria, SEQ=SEQ, TOPS=TOPS,
+                         eps=eps, **kw)
+        if res["converged"][0] or horizon >= int(steps):
+            break
+        horizon = min(int(steps), horizon * 4)
+    if not res["converged"][0]:
+        print('\n\nWARNING: PTEQ hit max number of steps before convergence:\t', horizon, '\n\n')
     return res["percent"][0]

@@ -77,6 +77,11 @@ def lib():
                                               C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
                                               C.POINTER(C.c_uint64), u8p]
         _LIB.orc_toric_pteq_batch.restype = None
+        _LIB.orc_toric_pteq_batch_conv.argtypes = [C.c_int, u8p, C.c_uint64, C.c_uint32, C.c_double, C.c_int, C.c_int,
+                                                   C.c_int, C.c_int, C.c_double, C.c_uint64, C.c_uint64, C.c_int,
+                                                   C.c_uint64, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
+                                                   C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), u8p, u8p]
+        _LIB.orc_toric_pteq_batch_conv.restype = None
     return _LIB
 
 
@@ -217,18 +222,22 @@ def toric_pteq(init, p, Nc=None, SEQ=2, TOPS=10, tops_burn=2, eps=0.1, steps=100
 
 
 def toric_pteq_batch(init, p, Nc, steps, iters=10, tops_burn=2, seed=0, first_syndrome=0, n_threads=0,
-                     return_states=False):
+                     return_states=False, conv_criteria=None, SEQ=2, TOPS=10, eps=0.1):
     init = _m(init); N = init.shape[0]; L = init.shape[2]
     counts = np.zeros((N, 16), dtype=np.uint32)
     samples = np.zeros(N, dtype=np.uint64)
     tops0 = np.zeros(N, dtype=np.uint64)
+    steps_done = np.zeros(N, dtype=np.uint64)
+    converged = np.zeros(N, dtype=np.uint8)
     fin = np.empty((N, Nc) + init.shape[1:], dtype=np.uint8) if return_states else None
-    lib().orc_toric_pteq_batch(L, _u8(init), N, first_syndrome, p, Nc, tops_burn, steps, iters, seed, n_threads,
-                               counts.ctypes.data_as(C.POINTER(C.c_uint32)),
-                               samples.ctypes.data_as(C.POINTER(C.c_uint64)),
-                               tops0.ctypes.data_as(C.POINTER(C.c_uint64)),
-                               _u8(fin) if fin is not None else None)
-    out = dict(counts=counts, samples=samples, tops0=tops0)
+    lib().orc_toric_pteq_batch_conv(L, _u8(init), N, first_syndrome, p, Nc, SEQ, TOPS, tops_burn, eps, steps, iters,
+                                    1 if conv_criteria == "error_based" else 0, seed, n_threads,
+                                    counts.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                    samples.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                    tops0.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                    steps_done.ctypes.data_as(C.POINTER(C.c_uint64)), _u8(converged),
+                                    _u8(fin) if fin is not None else None)
+    out = dict(counts=counts, samples=samples, tops0=tops0, steps_done=steps_done, converged=converged.astype(bool))
     if return_states:
         out["states"] = fin
     return out

@@ -410,6 +410,16 @@ void orc_toric_pteq_batch(int L, const uint8_t *init, uint64_t N, uint32_t first
                           int n_threads, uint32_t *counts_out, uint64_t *samples_out,
                           uint64_t *tops0_out, uint8_t *final_states)
 {
+    orc_toric_pteq_batch_conv(L, init, N, first_syndrome, p, Nc, 2, 10, tops_burn, 0.1, steps, iters, 0, seed,
+                              n_threads, counts_out, samples_out, tops0_out, NULL, NULL, final_states);
+}
+
+void orc_toric_pteq_batch_conv(int L, const uint8_t *init, uint64_t N, uint32_t first_syndrome, double p,
+                               int Nc, int SEQ, int TOPS, int tops_burn, double eps, uint64_t steps,
+                               uint64_t iters, int conv_mode, uint64_t seed, int n_threads,
+                               uint32_t *counts_out, uint64_t *samples_out, uint64_t *tops0_out,
+                               uint64_t *steps_done_out, uint8_t *converged_out, uint8_t *final_states)
+{
     const size_t nq = (size_t)2 * L * L;
 #ifdef _OPENMP
     if (n_threads > 0) omp_set_num_threads(n_threads);
@@ -421,10 +431,12 @@ void orc_toric_pteq_batch(int L, const uint8_t *init, uint64_t N, uint32_t first
         orc_rng rng;
         orc_rng_init_philox(&rng, seed, first_syndrome + (uint32_t)s);
         orc_pteq_result res;
-        orc_toric_pteq(L, init + (size_t)s * nq, p, Nc, 2, 10, tops_burn, 0.1, steps, iters, 0, &rng,
+        orc_toric_pteq(L, init + (size_t)s * nq, p, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, conv_mode, &rng,
                        &res, final_states ? final_states + (size_t)s * Nc * nq : NULL);
         memcpy(counts_out + (size_t)s * 16, res.counts, sizeof res.counts);
         samples_out[s] = res.samples;
         tops0_out[s] = res.tops0;
+        if (steps_done_out) steps_done_out[s] = res.steps_done;
+        if (converged_out) converged_out[s] = (uint8_t)res.converged;
     }
 }

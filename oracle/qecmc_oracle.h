@@ -106,6 +106,14 @@ void orc_toric_pteq_batch(int L, const uint8_t *init /*[N][nq]*/, uint64_t N, ui
                           uint32_t *counts_out /*[N][16]*/, uint64_t *samples_out /*[N]*/,
                           uint64_t *tops0_out /*[N]*/, uint8_t *final_states /*nullable [N][Nc][nq]*/);
 
+/* As above with the convergence criterion of decoders.py:74-82,93-105 (conv_mode 1). */
+void orc_toric_pteq_batch_conv(int L, const uint8_t *init, uint64_t N, uint32_t first_syndrome, double p,
+                               int Nc, int SEQ, int TOPS, int tops_burn, double eps, uint64_t steps,
+                               uint64_t iters, int conv_mode, uint64_t seed, int n_threads,
+                               uint32_t *counts_out, uint64_t *samples_out, uint64_t *tops0_out,
+                               uint64_t *steps_done_out /*nullable*/, uint8_t *converged_out /*nullable*/,
+                               uint8_t *final_states /*nullable*/);
+
 #ifdef __cplusplus
 }
 #endif

@@ -180,3 +180,34 @@ def test_full_size_properties(q, orc):
                                    return_states=True)
         assert np.array_equal(got["counts"][s], ref["counts"][0])
         assert np.array_equal(got["states"][s], ref["states"][0])
+
+
+# ------------------------------------------------------------------ convergence criterion (decoders.py:74-105)
+@pytest.mark.parametrize("L,p,Nc,N,steps,tops_burn,SEQ,TOPS,eps", [
+    (3, 0.10, 3, 70, 3000, 1, 1, 4, 0.5), (3, 0.10, 3, 64, 6000, 2, 2, 10, 0.25), (5, 0.10, 5, 40, 4000, 2, 2, 6, 0.4),
+    (5, 0.12, 4, 33, 6000, 1, 1, 4, 0.6), (3, 0.2, 2, 10, 500, 0, 0, 1, 1.0)])
+def test_pteq_error_based_bit_exact(q, orc, L, p, Nc, N, steps, tops_burn, SEQ, TOPS, eps):
+    rng = np.random.default_rng(L * 31 + N)
+    init = rand_states(rng, N, L, p)
+    kw = dict(steps=steps, iters=10, tops_burn=tops_burn, seed=77, first_syndrome=3, conv_criteria="error_based",
+              SEQ=SEQ, TOPS=TOPS, eps=eps)
+    got = q.pteq_batch(init, p, Nc=Nc, **kw)
+    ref = orc.toric_pteq_batch(init, p, Nc, kw.pop("steps"), **kw)
+    assert np.array_equal(got["converged"], ref["converged"])
+    assert np.array_equal(got["steps_done"], ref["steps_done"].astype(np.uint32))
+    assert np.array_equal(got["samples"], ref["samples"].astype(np.uint32))
+    assert np.array_equal(got["tops0"], ref["tops0"].astype(np.uint32))
+    assert np.array_equal(got["counts"], ref["counts"])
+    assert 0 < got["converged"].sum()                       # the early-exit path really ran
+
+
+def test_pteq_dropin_default_criterion(q, orc):
+    """PTEQ(code, p) with the reference's defaults (error_based, SEQ=2, TOPS=10, eps=0.1, steps=5e7)."""
+    rng = np.random.default_rng(8)
+    code = q.Toric_code(3)
+    code.qubit_matrix = rand_states(rng, 1, 3, 0.1)[0]
+    pct = q.PTEQ(code, 0.1, seed=5)
+    ref = orc.toric_pteq_batch(code.qubit_matrix[None], 0.1, 3, 1 << 22, seed=5, conv_criteria="error_based")
+    assert ref["converged"][0]
+    exp = (np.divide(ref["counts"][0], ref["samples"][0]) * 100).astype(np.uint8)
+    assert np.array_equal(pct, exp) and 96 <= int(pct.sum()) <= 100
