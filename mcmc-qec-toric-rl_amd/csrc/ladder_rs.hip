@@ -37,7 +37,7 @@ namespace qecmc {
 // LDS carve-up in dwords (keep in sync with the kernel)
 size_t ladder_lds_bytes(int L, int Nc, int W, int ncls)
 {
-    (void)L;
+    (void)L;   // per group of 64 syndromes
     return sizeof(uint32_t) * ((size_t)Nc * W * 64 + 4 * (size_t)Nc * 64 + (size_t)ncls * 64 + (size_t)Nc * 9 +
                                (size_t)Nc * kSwapFast + 16);   // st + info[2] + swx[2] + hist + thrT + swapT + stop flag
 }
@@ -95,13 +95,21 @@ __device__ __forceinline__ uint32_t pack_info(uint32_t n, uint32_t sid, uint32_t
     return n | (sid << 16) | (cls << 24) | (flag << 31);
 }
 
-template <int MAXT, int MINW>
+// CONV: build with the error_based convergence criterion (its per-lane window sums cost ~10 VGPRs,
+// so fixed-step runs use the instantiation without it)
+// GROUPS: independent 64-syndrome ladders per workgroup (they share only the barrier).  Two groups
+// (16 waves at Nc = 8, two workgroups per CU) keep 4 waves per SIMD busy even when a workgroup is
+// alone on its CU at the end of a launch, where one group (2 waves per SIMD) is latency-bound.
+template <int MAXT, int MINW, bool CONV, int GROUPS>
 __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const LadderArgs a)
 {
-    extern __shared__ uint32_t lds[];
+    extern __shared__ uint32_t lds_all[];
     const int NC = a.Nc, W = a.W, L = a.L, LL = L * L, nq = a.nq, ncls = a.ncls;
-    const int tid = threadIdx.x, lane = tid & 63, slot = tid >> 6;
-    const int nthreads = NC * 64;
+    const int nthreads = NC * 64;                 // threads of one group
+    const int grp = (GROUPS == 1) ? 0 : ((int)threadIdx.x >= nthreads);
+    const int tid = (int)threadIdx.x - grp * nthreads, lane = tid & 63, slot = tid >> 6;
+    const int gdw = NC * W * 64 + 4 * NC * 64 + ncls * 64 + NC * 9 + NC * kSwapFast + 16;   // dwords per group (ladder_lds_bytes)
+    uint32_t *lds = lds_all + grp * gdw;
 
     uint32_t *st = lds;                           // [NC][W][64]   packed states
     uint32_t *info = st + (size_t)NC * W * 64;    // [2][NC][64]   slot records, double-buffered by step parity
@@ -118,8 +126,8 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                                     __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));                       // HW_ID
     }
 #endif
-    const uint64_t s0 = (uint64_t)blockIdx.x * 64u;
-    const int cnt = (int)((a.N - s0) < 64u ? (a.N - s0) : 64u);
+    const uint64_t s0 = ((uint64_t)blockIdx.x * GROUPS + grp) * 64u;
+    const int cnt = a.N > s0 ? (int)((a.N - s0) < 64u ? (a.N - s0) : 64u) : 0;   // 0: a group past the end of the batch
     const uint32_t syn = a.first_syndrome + (uint32_t)s0 + (uint32_t)lane;   // Philox ctr[2]
 
     for (int i = tid; i < NC * W * 64; i += nthreads) st[i] = 0;
@@ -367,7 +375,10 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             if (left > 3) p[192] = b.w;
         }
         __syncthreads();
-        if (a.conv_mode && *stopf) break;                   // set by wave 0 one step earlier: uniform for the workgroup
+        if (CONV) {                                         // flags set one step earlier: uniform for the workgroup
+            volatile uint32_t *f0 = lds_all + gdw - 16;
+            if (f0[0] && (GROUPS == 1 || f0[gdw])) break;
+        }
         {
             // every wave replays the top-down cascade on the published records; `car` is the record
             // being carried down, `mine` the one that ends in the slot this wave takes over next
@@ -394,7 +405,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 if (a.counts != nullptr && tops0 >= a.tops_burn) {                  // decoders.py:60-67
                     hist[((car >> 24) & 0x3Fu) * 64 + lane] += 1;
                     samples++;
-                    if (a.conv_mode && lane < cnt) {
+                    if (CONV && lane < cnt) {
                         // nbr_errors_bottom_chain[since_burn] = count_errors (:68); series index i lives in log row burn+i
                         uint16_t *mylog = a.nlog + (s0 + lane);
                         mylog[(size_t)t * a.N] = (uint16_t)n0;
@@ -408,7 +419,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 } else {
                     burn++;                                                         // resulting_burn_in, :71
                 }
-                if (a.conv_mode && tops0 >= a.TOPS) {                               // :74
+                if (CONV && tops0 >= a.TOPS) {                               // :74
                     const uint32_t l = samples ? samples : 1u;
                     const uint32_t den2 = (l >> 1) - (l >> 2), den4 = l - ((3u * l) >> 2);
                     bool accept = false;                                            // empty slice -> nan -> not accepted
@@ -423,7 +434,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                     }
                 }
             }
-            if (wave_u == 0 && a.conv_mode && __all(done || lane >= cnt)) *stopf = 1;
+            if (CONV && wave_u == 0 && __all(done || lane >= cnt)) *stopf = 1;
             if (slot_u == 0) flag = 0;                                              // :103
         }
     }
@@ -461,20 +472,37 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
 
 hipError_t launch_ladder_rs_toric(const LadderArgs &a, hipStream_t stream)
 {
-    const unsigned grid = (unsigned)((a.N + 63) / 64);
-    const unsigned block = (unsigned)a.Nc * 64u;
-    const size_t lds = ladder_lds_bytes(a.L, a.Nc, a.W, a.ncls);
+    unsigned grid = (unsigned)((a.N + 63) / 64);
+    unsigned block = (unsigned)a.Nc * 64u;
+    size_t lds = ladder_lds_bytes(a.L, a.Nc, a.W, a.ncls);
     if (grid == 0) return hipSuccess;
-    // <=512 threads: ask for 8 waves/SIMD (4 workgroups of 8 waves per CU); 1024 threads: 4 waves/SIMD
-    const void *fn = block <= 512 ? (const void *)ladder_rs_toric_kernel<512, 8> : (const void *)ladder_rs_toric_kernel<1024, 4>;
+    // Nc <= 8: two 64-syndrome groups per workgroup (<= 1024 threads, 2 workgroups = 32 waves per CU);
+    // Nc > 8: one group (<= 1024 threads)
+    const bool conv = a.conv_mode != 0;
+    // two groups pay off when the whole grid is resident at once or nearly so (the end-of-launch tail);
+    // on many-round grids the smaller 8-wave workgroups synchronise more cheaply (measured +3.5 %)
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int groups = (a.Nc <= 8 && a.N > 64 && grid <= 8u * (unsigned)n_cu) ? 2 : 1;
+    grid = (grid + groups - 1) / groups;
+    block *= groups;
+    lds *= groups;
+    const void *fn;
+    if (groups == 2) fn = conv ? (const void *)ladder_rs_toric_kernel<1024, 8, true, 2> : (const void *)ladder_rs_toric_kernel<1024, 8, false, 2>;
+    else if (block <= 512) fn = conv ? (const void *)ladder_rs_toric_kernel<512, 8, true, 1> : (const void *)ladder_rs_toric_kernel<512, 8, false, 1>;
+    else fn = conv ? (const void *)ladder_rs_toric_kernel<1024, 4, true, 1> : (const void *)ladder_rs_toric_kernel<1024, 4, false, 1>;
     if (lds > 64 * 1024) {   // beyond the default dynamic-LDS window (160 KiB per CU on gfx950)
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    if (block <= 512)
-        hipLaunchKernelGGL((ladder_rs_toric_kernel<512, 8>), dim3(grid), dim3(block), lds, stream, a);
-    else
-        hipLaunchKernelGGL((ladder_rs_toric_kernel<1024, 4>), dim3(grid), dim3(block), lds, stream, a);
+    void *kargs[] = {const_cast<LadderArgs *>(&a)};
+    hipError_t e = hipLaunchKernel(fn, dim3(grid), dim3(block), kargs, lds, stream);
+    if (e != hipSuccess) return e;
     return hipGetLastError();
 }
 
