@@ -15,7 +15,7 @@ _LIB = None
 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
-    src = [os.path.join(_HERE, f) for f in ("qecmc_oracle.c", "qecmc_oracle.h")]
+    src = [os.path.join(_HERE, f) for f in ("qecmc_oracle.c", "qecmc_oracle_surf.c", "qecmc_oracle.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "liboracle.so"])
     return so
@@ -28,8 +28,16 @@ class _Rng(C.Structure):
                 ("c_k", C.c_uint64), ("c_valid", C.c_int), ("c_w", C.c_uint32 * 4)]
 
 
+class Model(C.Structure):
+    _fields_ = [("code", C.c_int), ("L", C.c_int), ("noise", C.c_int), ("eta", C.c_double)]
+
+
+TORIC, XZZX, ROTATED = 0, 1, 2
+DEPOLARIZING, BIASED = 0, 1
+
+
 class _Ladder(C.Structure):
-    _fields_ = [("L", C.c_int), ("Nc", C.c_int), ("nq", C.c_int), ("p_logical", C.c_double),
+    _fields_ = [("model", Model), ("L", C.c_int), ("Nc", C.c_int), ("nq", C.c_int), ("p_logical", C.c_double),
                 ("p_ladder", C.POINTER(C.c_double)), ("p_diff", C.POINTER(C.c_double)),
                 ("states", C.POINTER(C.c_uint8)), ("flags", C.POINTER(C.c_uint8)),
                 ("tops0", C.c_uint64), ("step_index", C.c_uint64), ("scratch", C.POINTER(C.c_uint8))]
@@ -82,6 +90,29 @@ def lib():
                                                    C.c_uint64, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
                                                    C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), u8p, u8p]
         _LIB.orc_toric_pteq_batch_conv.restype = None
+        mp = C.POINTER(Model)
+        _LIB.orc_surf_apply_stabilizer.argtypes = [C.c_int, C.c_int, u8p, u8p, C.c_int, C.c_int, C.c_int]
+        _LIB.orc_surf_apply_stabilizer.restype = C.c_int
+        _LIB.orc_surf_apply_logical.argtypes = [C.c_int, C.c_int, u8p, u8p, C.c_int, C.c_int, C.c_int]
+        _LIB.orc_surf_apply_logical.restype = C.c_int
+        _LIB.orc_surf_eq_class.argtypes = [C.c_int, C.c_int, u8p]
+        _LIB.orc_surf_eq_class.restype = C.c_int
+        _LIB.orc_surf_syndrome.argtypes = [C.c_int, C.c_int, u8p, u8p]
+        _LIB.orc_surf_syndrome.restype = None
+        _LIB.orc_chain_update.argtypes = [mp, u8p, C.c_double, C.c_double, C.c_uint64, C.POINTER(_Rng), C.c_uint32,
+                                          C.c_uint64, u8p]
+        _LIB.orc_chain_update.restype = None
+        _LIB.orc_ladder_new.argtypes = [mp, u8p, C.c_double, C.c_int, C.c_double]
+        _LIB.orc_ladder_new.restype = C.POINTER(_Ladder)
+        _LIB.orc_ladder_step.argtypes = [C.POINTER(_Ladder), C.c_uint64, C.POINTER(_Rng)]
+        _LIB.orc_pteq.argtypes = [mp, u8p, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_uint64,
+                                  C.c_uint64, C.c_int, C.POINTER(_Rng), C.POINTER(PteqResult), u8p]
+        _LIB.orc_pteq.restype = None
+        _LIB.orc_pteq_batch.argtypes = [mp, u8p, C.c_uint64, C.c_uint32, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_double, C.c_uint64, C.c_uint64, C.c_int, C.c_uint64, C.c_int,
+                                        C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                        C.POINTER(C.c_uint64), u8p, u8p]
+        _LIB.orc_pteq_batch.restype = None
     return _LIB
 
 
@@ -238,6 +269,122 @@ def toric_pteq_batch(init, p, Nc, steps, iters=10, tops_burn=2, seed=0, first_sy
                                     steps_done.ctypes.data_as(C.POINTER(C.c_uint64)), _u8(converged),
                                     _u8(fin) if fin is not None else None)
     out = dict(counts=counts, samples=samples, tops0=tops0, steps_done=steps_done, converged=converged.astype(bool))
+    if return_states:
+        out["states"] = fin
+    return out
+
+
+# ---- XZZX / rotated surface code (uint8[L,L]) and the code/noise-generic chain, ladder, PTEQ --------
+def _model(code, L, noise=DEPOLARIZING, eta=0.0):
+    return Model(code, L, noise, float(eta))
+
+
+def _size(code, m):
+    return m.shape[-1]
+
+
+def surf_apply_stabilizer(code, m, row, col, op):
+    m = _m(m); out = np.empty_like(m)
+    dE = lib().orc_surf_apply_stabilizer(code, m.shape[0], _u8(m), _u8(out), row, col, op)
+    return out, dE
+
+
+def surf_apply_logical(code, m, op, xpos=0, zpos=0):
+    m = _m(m); out = np.empty_like(m)
+    dE = lib().orc_surf_apply_logical(code, m.shape[0], _u8(m), _u8(out), op, xpos, zpos)
+    return out, dE
+
+
+def surf_eq_class(code, m):
+    m = _m(m)
+    return int(lib().orc_surf_eq_class(code, m.shape[0], _u8(m)))
+
+
+def surf_syndrome(code, m):
+    m = _m(m); L = m.shape[0]
+    out = np.zeros((L + 1, L + 1), dtype=np.uint8)
+    lib().orc_surf_syndrome(code, L, _u8(m), _u8(out))
+    return out
+
+
+def chain_update(code, m, p, p_logical, iters, rng, slot=0, k0=0, noise=DEPOLARIZING, eta=0.0):
+    m = _m(m).copy()
+    scratch = np.empty_like(m)
+    mod = _model(code, _size(code, m), noise, eta)
+    lib().orc_chain_update(C.byref(mod), _u8(m), p, p_logical, iters, C.byref(rng.c), slot, k0, _u8(scratch))
+    return m
+
+
+class Ladder:
+    """Ladder / Ladder_biased of any code model (states in slot order)."""
+
+    def __init__(self, code, init, p_bottom, Nc, p_logical=0.0, noise=DEPOLARIZING, eta=0.0):
+        init = _m(init)
+        self.shape = init.shape
+        self.Nc = Nc; self.nq = init.size
+        mod = _model(code, _size(code, init), noise, eta)
+        self._p = lib().orc_ladder_new(C.byref(mod), _u8(init), p_bottom, Nc, p_logical)
+
+    def __del__(self):
+        if getattr(self, "_p", None):
+            lib().orc_ladder_free(self._p)
+            self._p = None
+
+    def step(self, iters, rng):
+        lib().orc_ladder_step(self._p, iters, C.byref(rng.c))
+
+    @property
+    def states(self):
+        a = np.ctypeslib.as_array(self._p.contents.states, shape=(self.Nc * self.nq,))
+        return a.reshape((self.Nc,) + self.shape).copy()
+
+    @property
+    def flags(self):
+        return np.ctypeslib.as_array(self._p.contents.flags, shape=(self.Nc,)).copy()
+
+    @property
+    def tops0(self):
+        return int(self._p.contents.tops0)
+
+    @property
+    def p_ladder(self):
+        return np.ctypeslib.as_array(self._p.contents.p_ladder, shape=(self.Nc,)).copy()
+
+    @property
+    def p_diff(self):
+        return np.ctypeslib.as_array(self._p.contents.p_diff, shape=(self.Nc - 1,)).copy()
+
+
+def pteq(code, init, p, Nc=None, SEQ=2, TOPS=10, tops_burn=2, eps=0.1, steps=1000, iters=10, conv_criteria=None,
+         rng=None, noise=DEPOLARIZING, eta=0.0):
+    init = _m(init); Nc = Nc or _size(code, init)
+    mod = _model(code, _size(code, init), noise, eta)
+    res = PteqResult()
+    fin = np.empty((Nc,) + init.shape, dtype=np.uint8)
+    lib().orc_pteq(C.byref(mod), _u8(init), p, Nc, SEQ, TOPS, tops_burn, eps, steps, iters,
+                   1 if conv_criteria == "error_based" else 0, C.byref(rng.c), C.byref(res), _u8(fin))
+    ncls = 16 if code == TORIC else 4
+    return dict(counts=np.array(res.counts[:ncls], dtype=np.uint32), samples=int(res.samples), tops0=int(res.tops0),
+                steps_done=int(res.steps_done), converged=bool(res.converged),
+                percent=np.array(res.percent[:ncls], dtype=np.uint8), states=fin)
+
+
+def pteq_batch(code, init, p, Nc, steps, iters=10, tops_burn=2, seed=0, first_syndrome=0, n_threads=0,
+               return_states=False, conv_criteria=None, SEQ=2, TOPS=10, eps=0.1, noise=DEPOLARIZING, eta=0.0):
+    init = _m(init); N = init.shape[0]
+    mod = _model(code, init.shape[-1], noise, eta)
+    counts = np.zeros((N, 16), dtype=np.uint32)
+    samples = np.zeros(N, dtype=np.uint64); tops0 = np.zeros(N, dtype=np.uint64)
+    steps_done = np.zeros(N, dtype=np.uint64); converged = np.zeros(N, dtype=np.uint8)
+    fin = np.empty((N, Nc) + init.shape[1:], dtype=np.uint8) if return_states else None
+    lib().orc_pteq_batch(C.byref(mod), _u8(init), N, first_syndrome, p, Nc, SEQ, TOPS, tops_burn, eps, steps, iters,
+                         1 if conv_criteria == "error_based" else 0, seed, n_threads,
+                         counts.ctypes.data_as(C.POINTER(C.c_uint32)), samples.ctypes.data_as(C.POINTER(C.c_uint64)),
+                         tops0.ctypes.data_as(C.POINTER(C.c_uint64)), steps_done.ctypes.data_as(C.POINTER(C.c_uint64)),
+                         _u8(converged), _u8(fin) if fin is not None else None)
+    ncls = 16 if code == TORIC else 4
+    out = dict(counts=counts[:, :ncls].copy(), samples=samples, tops0=tops0, steps_done=steps_done,
+               converged=converged.astype(bool))
     if return_states:
         out["states"] = fin
     return out

@@ -210,55 +210,118 @@ void orc_toric_syndrome(int L, const uint8_t *in, uint8_t *defects_out)
 }
 
 /* ------------------------------------------------------------------------ */
-/* Chain.update_chain, src/mcmc.py:19-43                                      */
+/* Chain.update_chain, src/mcmc.py:19-43 (and Chain_biased, mcmc_biased.py:20-59) */
 /* ------------------------------------------------------------------------ */
+int orc_nq(int code, int L) { return code == ORC_TORIC ? 2 * L * L : L * L; }
+int orc_ncls(int code) { return code == ORC_TORIC ? 16 : 4; }
 
-/* _apply_random_stabilizer, src/toric_model.py:287-296: three draws row, col, op */
-static int toric_random_stabilizer(int L, const uint8_t *in, uint8_t *out, orc_rng *rng,
-                                   uint32_t slot, uint64_t k, int w_row, int w_col, int w_op)
+int orc_eq_class(int code, int L, const uint8_t *m)
 {
-    int row = (int)(orc_draw(rng, slot, k, 0, w_row) * L);
-    int col = (int)(orc_draw(rng, slot, k, 0, w_col) * L);
-    int op = (int)(orc_draw(rng, slot, k, 0, w_op) * 2);
-    if (op == 0) op = 3;
-    return orc_toric_apply_stabilizer(L, in, out, row, col, op);
+    return code == ORC_TORIC ? orc_toric_eq_class(L, m) : orc_surf_eq_class(code, L, m);
 }
 
-/* _apply_random_logical, src/toric_model.py:228-253: op0, op1 first, then per
- * layer X_pos iff op in {1,2}, Z_pos iff op in {3,2}.  Philox addressing keeps the
- * whole proposal in block (k,0): op0 / op1 = top two bits of words 1 / 2; X_pos of
- * layer 0 / 1 = the low 30 bits of words 1 / 2; Z_pos of layer 0 / 1 = the high /
- * low half of word 3 (disjoint bit fields of one block are independent uniforms). */
-static int toric_random_logical(int L, const uint8_t *in, uint8_t *out, orc_rng *rng,
+/* _apply_random_stabilizer.
+ * toric (toric_model.py:287-296): three draws row, col, op -> words w0, w0+1, w0+2 of block (k,0).
+ * xzzx / rotated (xzzx_model.py:439-452, rotated_surface_model.py:395-408): FIVE draws, always:
+ * rows, cols in [0,L-1), rows2 in [0,(L-1)/2), cols2 in [0,4), then `u > phalf` picks the full
+ * plaquette.  Philox addressing: rows / cols = high / low half of word w0, rows2 = high half of
+ * word w0+1, cols2 = next two bits, selector = word w0+2 (non-top w0 = 0, top w0 = 1). */
+static int model_random_stabilizer(const orc_model *m, const uint8_t *in, uint8_t *out, orc_rng *rng,
+                                   uint32_t slot, uint64_t k, int w0)
+{
+    const int L = m->L;
+    if (m->code == ORC_TORIC) {
+        int row = (int)(orc_draw(rng, slot, k, 0, w0) * L);
+        int col = (int)(orc_draw(rng, slot, k, 0, w0 + 1) * L);
+        int op = (int)(orc_draw(rng, slot, k, 0, w0 + 2) * 2);
+        if (op == 0) op = 3;
+        return orc_toric_apply_stabilizer(L, in, out, row, col, op);
+    }
+    int rows = (int)((L - 1) * orc_draw_field(rng, slot, k, 0, w0, 0, 16));
+    int cols = (int)((L - 1) * orc_draw_field(rng, slot, k, 0, w0, 16, 16));
+    int rows2 = (int)(((L - 1) / 2.0) * orc_draw_field(rng, slot, k, 0, w0 + 1, 0, 16));
+    int cols2 = (int)(4 * orc_draw_field(rng, slot, k, 0, w0 + 1, 16, 2));
+    double phalf = (double)(L * L - (L - 1) * (L - 1) - 1) / (double)(L * L - 1);
+    if (orc_draw(rng, slot, k, 0, w0 + 2) > phalf)
+        return orc_surf_apply_stabilizer(m->code, L, in, out, rows, cols, 1);
+    return orc_surf_apply_stabilizer(m->code, L, in, out, rows2, cols2, 3);
+}
+
+/* _apply_random_logical.  toric (toric_model.py:228-253): op0, op1 first, then per layer X_pos iff
+ * op in {1,2}, Z_pos iff op in {3,2}; Philox addressing keeps the proposal in block (k,0): op0 / op1 =
+ * top two bits of words 1 / 2, X_pos of layer 0 / 1 = the low 30 bits of words 1 / 2, Z_pos of layer
+ * 0 / 1 = the high / low half of word 3.  xzzx / rotated (xzzx_model.py:340-357,
+ * rotated_surface_model.py:331-346): one operator (top two bits of word 1), X_pos iff op in {1,2} (low 30
+ * bits of word 1), Z_pos iff op in {3,2} (high half of word 3). */
+static int model_random_logical(const orc_model *m, const uint8_t *in, uint8_t *out, orc_rng *rng,
                                 uint32_t slot, uint64_t k)
 {
-    int ops[2];
-    ops[0] = (int)(orc_draw(rng, slot, k, 0, 1) * 4);
-    ops[1] = (int)(orc_draw(rng, slot, k, 0, 2) * 4);
-    int dE = 0;
-    if (out != in) memcpy(out, in, (size_t)2 * L * L);
-    for (int layer = 0; layer < 2; ++layer) {
-        int op = ops[layer], xpos = 0, zpos = 0;
-        if (op == 1 || op == 2) xpos = (int)(orc_draw_field(rng, slot, k, 0, 1 + layer, 2, 30) * L);
-        if (op == 3 || op == 2) zpos = (int)(orc_draw_field(rng, slot, k, 0, 3, 16 * layer, 16) * L);
-        dE += orc_toric_apply_logical(L, out, out, op, layer, xpos, zpos);
+    const int L = m->L;
+    if (m->code == ORC_TORIC) {
+        int ops[2];
+        ops[0] = (int)(orc_draw(rng, slot, k, 0, 1) * 4);
+        ops[1] = (int)(orc_draw(rng, slot, k, 0, 2) * 4);
+        int dE = 0;
+        if (out != in) memcpy(out, in, (size_t)2 * L * L);
+        for (int layer = 0; layer < 2; ++layer) {
+            int op = ops[layer], xpos = 0, zpos = 0;
+            if (op == 1 || op == 2) xpos = (int)(orc_draw_field(rng, slot, k, 0, 1 + layer, 2, 30) * L);
+            if (op == 3 || op == 2) zpos = (int)(orc_draw_field(rng, slot, k, 0, 3, 16 * layer, 16) * L);
+            dE += orc_toric_apply_logical(L, out, out, op, layer, xpos, zpos);
+        }
+        return dE;
     }
-    return dE;
+    int op = (int)(orc_draw(rng, slot, k, 0, 1) * 4), xpos = 0, zpos = 0;
+    if (op == 1 || op == 2) xpos = (int)(orc_draw_field(rng, slot, k, 0, 1, 2, 30) * L);
+    if (op == 3 || op == 2) zpos = (int)(orc_draw_field(rng, slot, k, 0, 3, 0, 16) * L);
+    return orc_surf_apply_logical(m->code, L, in, out, op, xpos, zpos);
 }
 
-void orc_toric_chain_update(int L, uint8_t *state, double p, double p_logical, uint64_t iters,
-                            orc_rng *rng, uint32_t slot, uint64_t k0, uint8_t *scratch)
+/* p_x^nx p_y^ny p_z^nz p_I^(num-nx-ny-nz), mcmc_biased.py:31,43 (left-to-right products of pow()) */
+static double biased_weight(const uint8_t *s, int nq, double px, double py, double pz)
 {
-    const size_t nq = (size_t)2 * L * L;
+    int nx = 0, ny = 0, nz = 0;
+    for (int i = 0; i < nq; ++i) { nx += s[i] == 1; ny += s[i] == 2; nz += s[i] == 3; }
+    return pow(px, (double)nx) * pow(py, (double)ny) * pow(pz, (double)nz) * pow(1 - px - py - pz, (double)(nq - nx - ny - nz));
+}
+
+void orc_chain_update(const orc_model *m, uint8_t *state, double p, double p_logical, uint64_t iters,
+                      orc_rng *rng, uint32_t slot, uint64_t k0, uint8_t *scratch)
+{
+    const size_t nq = (size_t)orc_nq(m->code, m->L);
+    if (m->noise == ORC_NOISE_BIASED) {
+        /* Chain_biased.update_chain, mcmc_biased.py:20-59.  pb is computed ONCE before the loop and never
+         * refreshed after an accept (reference quirk Q3, reproduced). */
+        const double eta = m->eta;
+        const double pz = p * eta / (eta + 1), px = p / (2 * (eta + 1)), py = px;      /* :25-27 */
+        const double pb = biased_weight(state, (int)nq, px, py, pz);                    /* :28-31 */
+        for (uint64_t j = 0; j < iters; ++j) {
+            uint64_t k = k0 + j;
+            double u;
+            if (p_logical != 0) {                                                       /* :32-46 */
+                if (orc_draw(rng, slot, k, 0, 0) < p_logical) model_random_logical(m, state, scratch, rng, slot, k);
+                else model_random_stabilizer(m, state, scratch, rng, slot, k, 1);
+                const double pn = biased_weight(scratch, (int)nq, px, py, pz);
+                u = orc_draw(rng, slot, k, 2, 0);
+                if (u < pn / pb) memcpy(state, scratch, nq);
+            } else {                                                                    /* :49-59 */
+                model_random_stabilizer(m, state, scratch, rng, slot, k, 0);
+                const double pn = biased_weight(scratch, (int)nq, px, py, pz);
+                u = orc_draw(rng, slot, k, 0, 3);
+                if (u < pn / pb) memcpy(state, scratch, nq);
+            }
+        }
+        return;
+    }
     const double factor = (p / 3.0) / (1.0 - p);                  /* mcmc.py:16 */
     if (p_logical != 0) {                                          /* mcmc.py:20 */
         for (uint64_t j = 0; j < iters; ++j) {
             uint64_t k = k0 + j;
             int dE;
             if (orc_draw(rng, slot, k, 0, 0) < p_logical)          /* mcmc.py:23 */
-                dE = toric_random_logical(L, state, scratch, rng, slot, k);
+                dE = model_random_logical(m, state, scratch, rng, slot, k);
             else
-                dE = toric_random_stabilizer(L, state, scratch, rng, slot, k, 1, 2, 3);
+                dE = model_random_stabilizer(m, state, scratch, rng, slot, k, 1);
             if (p >= 0.75 || dE <= 0) {                            /* mcmc.py:30 */
                 memcpy(state, scratch, nq);
                 continue;
@@ -269,15 +332,22 @@ void orc_toric_chain_update(int L, uint8_t *state, double p, double p_logical, u
     } else {
         for (uint64_t j = 0; j < iters; ++j) {                     /* mcmc.py:38 */
             uint64_t k = k0 + j;
-            int dE = toric_random_stabilizer(L, state, scratch, rng, slot, k, 0, 1, 2);
+            int dE = model_random_stabilizer(m, state, scratch, rng, slot, k, 0);
             if (orc_draw(rng, slot, k, 0, 3) < pow(factor, (double)dE))   /* mcmc.py:42 */
                 memcpy(state, scratch, nq);
         }
     }
 }
 
+void orc_toric_chain_update(int L, uint8_t *state, double p, double p_logical, uint64_t iters,
+                            orc_rng *rng, uint32_t slot, uint64_t k0, uint8_t *scratch)
+{
+    orc_model m = {ORC_TORIC, L, ORC_NOISE_DEPOLARIZING, 0.0};
+    orc_chain_update(&m, state, p, p_logical, iters, rng, slot, k0, scratch);
+}
+
 /* ------------------------------------------------------------------------ */
-/* Ladder, src/mcmc.py:49-103                                                 */
+/* Ladder, src/mcmc.py:49-103 (Ladder_biased, mcmc_biased.py:66-124)          */
 /* ------------------------------------------------------------------------ */
 static void fill_ladder_p(double p_bottom, double p_top, int Nc, double *p_ladder, double *p_diff)
 {
@@ -293,19 +363,28 @@ static void fill_ladder_p(double p_bottom, double p_top, int Nc, double *p_ladde
         p_diff[i] = (p_ladder[i] * (1 - p_ladder[i + 1])) / (p_ladder[i + 1] * (1 - p_ladder[i]));
 }
 
-orc_ladder *orc_toric_ladder_new(int L, const uint8_t *init, double p_bottom, int Nc, double p_logical)
+orc_ladder *orc_ladder_new(const orc_model *m, const uint8_t *init, double p_bottom, int Nc, double p_logical)
 {
     orc_ladder *ld = (orc_ladder *)calloc(1, sizeof *ld);
-    ld->L = L; ld->Nc = Nc; ld->nq = 2 * L * L; ld->p_logical = p_logical;
+    ld->model = *m;
+    ld->L = m->L; ld->Nc = Nc; ld->nq = orc_nq(m->code, m->L); ld->p_logical = p_logical;
     ld->p_ladder = (double *)calloc((size_t)Nc, sizeof(double));
     ld->p_diff = (double *)calloc((size_t)(Nc > 1 ? Nc - 1 : 1), sizeof(double));
     ld->states = (uint8_t *)malloc((size_t)Nc * ld->nq);
     ld->flags = (uint8_t *)calloc((size_t)Nc, 1);
     ld->scratch = (uint8_t *)malloc((size_t)ld->nq);
-    fill_ladder_p(p_bottom, 0.75, Nc, ld->p_ladder, ld->p_diff);    /* mcmc.py:62-69 */
+    /* p_top = 0.75 (mcmc.py:62) or (eta+1)/(2 eta+1) (mcmc_biased.py:81) */
+    const double p_top = m->noise == ORC_NOISE_BIASED ? (m->eta + 1) / (2 * m->eta + 1) : 0.75;
+    fill_ladder_p(p_bottom, p_top, Nc, ld->p_ladder, ld->p_diff);    /* mcmc.py:62-69 */
     for (int c = 0; c < Nc; ++c) memcpy(ld->states + (size_t)c * ld->nq, init, (size_t)ld->nq); /* :72 */
     ld->flags[Nc - 1] = 1;                                          /* mcmc.py:75 */
     return ld;
+}
+
+orc_ladder *orc_toric_ladder_new(int L, const uint8_t *init, double p_bottom, int Nc, double p_logical)
+{
+    orc_model m = {ORC_TORIC, L, ORC_NOISE_DEPOLARIZING, 0.0};
+    return orc_ladder_new(&m, init, p_bottom, Nc, p_logical);
 }
 
 void orc_ladder_free(orc_ladder *ld)
@@ -315,20 +394,21 @@ void orc_ladder_free(orc_ladder *ld)
     free(ld);
 }
 
-/* Ladder.step(iters), src/mcmc.py:94-103 */
-void orc_toric_ladder_step(orc_ladder *ld, uint64_t iters, orc_rng *rng)
+/* Ladder.step(iters), src/mcmc.py:94-103 (mcmc_biased.py:115-124) */
+void orc_ladder_step(orc_ladder *ld, uint64_t iters, orc_rng *rng)
 {
     const int Nc = ld->Nc, nq = ld->nq;
     const uint64_t k0 = ld->step_index * iters;
     for (int c = 0; c < Nc; ++c)                                    /* update_ladder :81-83 */
-        orc_toric_chain_update(ld->L, ld->states + (size_t)c * nq, ld->p_ladder[c],
-                               c == Nc - 1 ? ld->p_logical : 0.0, iters, rng, (uint32_t)c, k0,
-                               ld->scratch);
+        orc_chain_update(&ld->model, ld->states + (size_t)c * nq, ld->p_ladder[c],
+                         c == Nc - 1 ? ld->p_logical : 0.0, iters, rng, (uint32_t)c, k0, ld->scratch);
     for (int i = Nc - 2; i >= 0; --i) {                             /* :96 */
         int64_t ne_lo = orc_count_errors((size_t)nq, ld->states + (size_t)i * nq);
         int64_t ne_hi = orc_count_errors((size_t)nq, ld->states + (size_t)(i + 1) * nq);
         int flip;
-        if (ne_hi < ne_lo) flip = 1;                                /* _r_flip :146 */
+        /* _r_flip: mcmc.py:146 skips the draw when ne_hi < ne_lo; mcmc_biased.py:154-156 always draws
+         * (rel_p ** negative > 1, so the outcome is the same; only the stream position differs) */
+        if (ld->model.noise != ORC_NOISE_BIASED && ne_hi < ne_lo) flip = 1;
         else flip = orc_draw(rng, ORC_SWAP_STREAM, ld->step_index, (uint32_t)i >> 2, i & 3)
                     < pow(ld->p_diff[i], (double)(ne_hi - ne_lo));  /* :149 */
         if (flip) {                                                 /* :98-99 */
@@ -343,8 +423,12 @@ void orc_toric_ladder_step(orc_ladder *ld, uint64_t iters, orc_rng *rng)
     ld->step_index++;
 }
 
+void orc_toric_ladder_step(orc_ladder *ld, uint64_t iters, orc_rng *rng) { orc_ladder_step(ld, iters, rng); }
+
 /* ------------------------------------------------------------------------ */
 /* decoders.PTEQ, decoders.py:25-89, and conv_crit_error_based_PT :93-105     */
+/* (PTEQ_biased, decoders_biasednoise.py:28-90, is the same loop around       */
+/*  Ladder_biased)                                                            */
 /* ------------------------------------------------------------------------ */
 static double mean_range(const double *a, uint64_t lo, uint64_t hi)
 {
@@ -356,11 +440,12 @@ static double mean_range(const double *a, uint64_t lo, uint64_t hi)
     return s / (double)(hi - lo);
 }
 
-void orc_toric_pteq(int L, const uint8_t *init, double p, int Nc, int SEQ, int TOPS, int tops_burn,
-                    double eps, uint64_t steps, uint64_t iters, int conv_mode, orc_rng *rng,
-                    orc_pteq_result *res, uint8_t *final_states)
+void orc_pteq(const orc_model *m, const uint8_t *init, double p, int Nc, int SEQ, int TOPS, int tops_burn,
+              double eps, uint64_t steps, uint64_t iters, int conv_mode, orc_rng *rng,
+              orc_pteq_result *res, uint8_t *final_states)
 {
-    orc_ladder *ld = orc_toric_ladder_new(L, init, p, Nc, 0.5);     /* decoders.py:52 */
+    orc_ladder *ld = orc_ladder_new(m, init, p, Nc, 0.5);           /* decoders.py:52 */
+    const int ncls = orc_ncls(m->code);
     uint64_t since_burn = 0, resulting_burn_in = 0, recorded = 0;
     uint64_t conv_start = 0, conv_streak = 0;
     uint32_t eq[16];
@@ -369,8 +454,8 @@ void orc_toric_pteq(int L, const uint8_t *init, double p, int Nc, int SEQ, int T
     int converged = 0;
     uint64_t step;
     for (step = 0; step < steps; ++step) {                          /* :55 */
-        orc_toric_ladder_step(ld, iters, rng);                      /* :57 */
-        int cur = orc_toric_eq_class(L, ld->states);                /* :60 */
+        orc_ladder_step(ld, iters, rng);                            /* :57 */
+        int cur = orc_eq_class(m->code, m->L, ld->states);          /* :60 */
         if (ld->tops0 >= (uint64_t)tops_burn) {                     /* :63 */
             since_burn = step - resulting_burn_in;
             eq[cur] += 1;                                           /* :66-67 (running row) */
@@ -398,11 +483,20 @@ void orc_toric_pteq(int L, const uint8_t *init, double p, int Nc, int SEQ, int T
     res->tops0 = ld->tops0;
     res->steps_done = step;
     res->converged = converged;
-    for (int i = 0; i < 16; ++i)                                    /* :89 */
+    memset(res->percent, 0, sizeof res->percent);
+    for (int i = 0; i < ncls; ++i)                                  /* :89 */
         res->percent[i] = (uint8_t)((double)eq[i] / (double)(since_burn + 1) * 100.0);
     if (final_states) memcpy(final_states, ld->states, (size_t)Nc * ld->nq);
     free(series);
     orc_ladder_free(ld);
+}
+
+void orc_toric_pteq(int L, const uint8_t *init, double p, int Nc, int SEQ, int TOPS, int tops_burn,
+                    double eps, uint64_t steps, uint64_t iters, int conv_mode, orc_rng *rng,
+                    orc_pteq_result *res, uint8_t *final_states)
+{
+    orc_model m = {ORC_TORIC, L, ORC_NOISE_DEPOLARIZING, 0.0};
+    orc_pteq(&m, init, p, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, conv_mode, rng, res, final_states);
 }
 
 void orc_toric_pteq_batch(int L, const uint8_t *init, uint64_t N, uint32_t first_syndrome, double p,
@@ -410,8 +504,9 @@ void orc_toric_pteq_batch(int L, const uint8_t *init, uint64_t N, uint32_t first
                           int n_threads, uint32_t *counts_out, uint64_t *samples_out,
                           uint64_t *tops0_out, uint8_t *final_states)
 {
-    orc_toric_pteq_batch_conv(L, init, N, first_syndrome, p, Nc, 2, 10, tops_burn, 0.1, steps, iters, 0, seed,
-                              n_threads, counts_out, samples_out, tops0_out, NULL, NULL, final_states);
+    orc_model m = {ORC_TORIC, L, ORC_NOISE_DEPOLARIZING, 0.0};
+    orc_pteq_batch(&m, init, N, first_syndrome, p, Nc, 2, 10, tops_burn, 0.1, steps, iters, 0, seed,
+                   n_threads, counts_out, samples_out, tops0_out, NULL, NULL, final_states);
 }
 
 void orc_toric_pteq_batch_conv(int L, const uint8_t *init, uint64_t N, uint32_t first_syndrome, double p,
@@ -420,7 +515,19 @@ void orc_toric_pteq_batch_conv(int L, const uint8_t *init, uint64_t N, uint32_t 
                                uint32_t *counts_out, uint64_t *samples_out, uint64_t *tops0_out,
                                uint64_t *steps_done_out, uint8_t *converged_out, uint8_t *final_states)
 {
-    const size_t nq = (size_t)2 * L * L;
+    orc_model m = {ORC_TORIC, L, ORC_NOISE_DEPOLARIZING, 0.0};
+    orc_pteq_batch(&m, init, N, first_syndrome, p, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, conv_mode, seed,
+                   n_threads, counts_out, samples_out, tops0_out, steps_done_out, converged_out, final_states);
+}
+
+/* counts_out is [N][16] for every code (4-class codes use the first four entries) */
+void orc_pteq_batch(const orc_model *m, const uint8_t *init, uint64_t N, uint32_t first_syndrome, double p,
+                    int Nc, int SEQ, int TOPS, int tops_burn, double eps, uint64_t steps,
+                    uint64_t iters, int conv_mode, uint64_t seed, int n_threads,
+                    uint32_t *counts_out, uint64_t *samples_out, uint64_t *tops0_out,
+                    uint64_t *steps_done_out, uint8_t *converged_out, uint8_t *final_states)
+{
+    const size_t nq = (size_t)orc_nq(m->code, m->L);
 #ifdef _OPENMP
     if (n_threads > 0) omp_set_num_threads(n_threads);
 #else
@@ -431,8 +538,8 @@ void orc_toric_pteq_batch_conv(int L, const uint8_t *init, uint64_t N, uint32_t 
         orc_rng rng;
         orc_rng_init_philox(&rng, seed, first_syndrome + (uint32_t)s);
         orc_pteq_result res;
-        orc_toric_pteq(L, init + (size_t)s * nq, p, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, conv_mode, &rng,
-                       &res, final_states ? final_states + (size_t)s * Nc * nq : NULL);
+        orc_pteq(m, init + (size_t)s * nq, p, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, conv_mode, &rng,
+                 &res, final_states ? final_states + (size_t)s * Nc * nq : NULL);
         memcpy(counts_out + (size_t)s * 16, res.counts, sizeof res.counts);
         samples_out[s] = res.samples;
         tops0_out[s] = res.tops0;

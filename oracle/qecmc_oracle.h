@@ -52,6 +52,28 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 void orc_rng_init_stream(orc_rng *r, const double *stream, uint64_t len);
 void orc_rng_init_philox(orc_rng *r, uint64_t seed, uint32_t syndrome);
 
+enum { ORC_TORIC = 0, ORC_XZZX = 1, ORC_ROTATED = 2 };
+enum { ORC_NOISE_DEPOLARIZING = 0, ORC_NOISE_BIASED = 1 };
+
+/* which code model / acceptance rule a chain uses (duck typing in the reference) */
+typedef struct orc_model {
+    int code;      /* ORC_TORIC: uint8[2][L][L], 16 classes; ORC_XZZX / ORC_ROTATED: uint8[L][L], 4 classes */
+    int L;
+    int noise;     /* ORC_NOISE_DEPOLARIZING: src/mcmc.py; ORC_NOISE_BIASED: src/mcmc_biased.py */
+    double eta;    /* bias, mcmc_biased.py:11 */
+} orc_model;
+
+int orc_nq(int code, int L);
+int orc_ncls(int code);
+int orc_eq_class(int code, int L, const uint8_t *m);
+
+/* ---- XZZX / rotated stencils (src/xzzx_model.py, src/rotated_surface_model.py) ---- */
+int  orc_surf_generator(int code, int L, int row, int col, int op, int sites[4], int paulis[4]);
+int  orc_surf_apply_stabilizer(int code, int L, const uint8_t *in, uint8_t *out, int row, int col, int op);
+int  orc_surf_apply_logical(int code, int L, const uint8_t *in, uint8_t *out, int op, int xpos, int zpos);
+int  orc_surf_eq_class(int code, int L, const uint8_t *m);
+void orc_surf_syndrome(int code, int L, const uint8_t *in, uint8_t *defects /*[L+1][L+1]*/);
+
 /* ---- toric stencils (src/toric_model.py) -------------------------------- */
 int     orc_toric_apply_stabilizer(int L, const uint8_t *in, uint8_t *out, int row, int col, int op);
 int     orc_toric_apply_logical(int L, const uint8_t *in, uint8_t *out, int op, int layer, int xpos, int zpos);
@@ -62,6 +84,7 @@ void    orc_toric_syndrome(int L, const uint8_t *in, uint8_t *defects_out);
 
 /* ---- chain / ladder / PTEQ (src/mcmc.py, decoders.py) -------------------- */
 typedef struct orc_ladder {
+    orc_model model;
     int L, Nc, nq;
     double p_logical;
     double *p_ladder;    /* [Nc]   */
@@ -97,6 +120,21 @@ typedef struct orc_pteq_result {
 void orc_toric_pteq(int L, const uint8_t *init, double p, int Nc, int SEQ, int TOPS, int tops_burn,
                     double eps, uint64_t steps, uint64_t iters, int conv_mode, orc_rng *rng,
                     orc_pteq_result *res, uint8_t *final_states);
+
+/* code / noise generic forms of the above */
+void orc_chain_update(const orc_model *m, uint8_t *state, double p, double p_logical, uint64_t iters,
+                      orc_rng *rng, uint32_t slot, uint64_t k0, uint8_t *scratch);
+orc_ladder *orc_ladder_new(const orc_model *m, const uint8_t *init, double p_bottom, int Nc, double p_logical);
+void orc_ladder_step(orc_ladder *ld, uint64_t iters, orc_rng *rng);
+void orc_pteq(const orc_model *m, const uint8_t *init, double p, int Nc, int SEQ, int TOPS, int tops_burn,
+              double eps, uint64_t steps, uint64_t iters, int conv_mode, orc_rng *rng,
+              orc_pteq_result *res, uint8_t *final_states);
+void orc_pteq_batch(const orc_model *m, const uint8_t *init, uint64_t N, uint32_t first_syndrome, double p,
+                    int Nc, int SEQ, int TOPS, int tops_burn, double eps, uint64_t steps,
+                    uint64_t iters, int conv_mode, uint64_t seed, int n_threads,
+                    uint32_t *counts_out /*[N][16]*/, uint64_t *samples_out, uint64_t *tops0_out,
+                    uint64_t *steps_done_out /*nullable*/, uint8_t *converged_out /*nullable*/,
+                    uint8_t *final_states /*nullable*/);
 
 /* N independent PTEQ runs (one per syndrome, Philox keyed by first_syndrome+i),
  * spread over `n_threads` OpenMP threads.  This is the timed CPU baseline. */

@@ -17,6 +17,7 @@ Fixtures
                   seed is stored
   f3_toric.npz    replica-averaged PTEQ class histograms (statistical)
   f4_config1.npz  BASELINE config-1 plumbing vector
+  f1_surf.npz / f2_surf.npz   the same for the XZZX and rotated codes, incl. the biased chain
 """
 import argparse
 import os
@@ -50,6 +51,14 @@ def import_reference():
     return tm, mc, dec
 
 
+def import_reference_surf():
+    import src.xzzx_model as xm
+    import src.rotated_surface_model as rm
+    import src.mcmc_biased as mb
+    import decoders_biasednoise as decb
+    return xm, rm, mb, decb
+
+
 class Stream:
     """random.Random(seed).random with a draw counter; installed over the
     reference's two aliases of `random`."""
@@ -63,17 +72,19 @@ class Stream:
         return self.r.random()
 
 
-def install(stream, tm):
-    random.random = stream          # `rand.random()` in src/mcmc.py
-    tm.random = stream              # `from random import random` in src/toric_model.py
+def install(stream, *models):
+    random.random = stream          # `rand.random()` in src/mcmc*.py and the models
+    for m in models:
+        m.random = stream           # `from random import random` in the model modules
 
 
 _ORIG_RANDOM = random.random
 
 
-def restore(tm):
+def restore(*models):
     random.random = _ORIG_RANDOM
-    tm.random = _ORIG_RANDOM
+    for m in models:
+        m.random = _ORIG_RANDOM
 
 
 def rand_matrix(rng, L, p):
@@ -193,6 +204,153 @@ def gen_f2(tm, mc, dec):
     print("f2_toric.npz", cases)
 
 
+# --------------------------------------------------------------------------- F1/F2 for xzzx + rotated
+def rand_matrix2(rng, L, p):
+    m = np.zeros((L, L), dtype=np.uint8)
+    err = rng.random((L, L)) < p
+    m[err] = rng.integers(1, 4, size=int(err.sum()), dtype=np.uint8)
+    return m
+
+
+def _surf_defects(mod, m):
+    """the loops of xzzx_code.syndrome / RotSurCode.syndrome (without the plot call)"""
+    L = m.shape[0]
+    d = np.zeros((L + 1, L + 1), dtype=np.uint8)
+    for i in range(L - 1):
+        for j in range(L - 1):
+            d[i + 1, j + 1] = mod._find_syndrome(m, i, j, 1)
+    for i in range(int((L - 1) / 2)):
+        for j, (r, c) in enumerate([(0, 2 * i + 2), (2 * i + 2, L), (L, 2 * i + 1), (2 * i + 1, 0)]):
+            d[r, c] = mod._find_syndrome(m, i, j, 3)
+    return d
+
+
+def gen_f1_surf(xm, rm):
+    rng = np.random.default_rng(424242)
+    out = {}
+    for name, mod, cls in (("xzzx", xm, xm.xzzx_code), ("rot", rm, rm.RotSurCode)):
+        for L in (3, 5, 9):
+            for rep, p in enumerate((0.15, 0.45)):
+                t = f"{name}_L{L}_{rep}"
+                m = rand_matrix2(rng, L, p)
+                code = cls(L); code.qubit_matrix = m.copy()
+                out[f"{t}_m"] = m
+                out[f"{t}_count"] = np.int64(code.count_errors())
+                out[f"{t}_class"] = np.int64(code.define_equivalence_class())
+                out[f"{t}_defects"] = _surf_defects(mod, m)
+                arg, new, dE = [], [], []
+                for r in range(L - 1):
+                    for c in range(L - 1):
+                        n, d = code.apply_stabilizer(r, c, 1); arg.append((r, c, 1)); new.append(n); dE.append(d)
+                for r in range((L - 1) // 2):
+                    for c in range(4):
+                        n, d = code.apply_stabilizer(r, c, 3); arg.append((r, c, 3)); new.append(n); dE.append(d)
+                out[f"{t}_stab_arg"] = np.array(arg, dtype=np.int64)
+                out[f"{t}_stab_new"] = np.array(new, dtype=np.uint8)
+                out[f"{t}_stab_dE"] = np.array(dE, dtype=np.int64)
+                arg, new, dE, cl = [], [], [], []
+                for op in range(4):
+                    for xp in range(L):
+                        for zp in range(L):
+                            n, d = code.apply_logical(op, xp, zp)
+                            arg.append((op, xp, zp)); new.append(n); dE.append(d)
+                            c2 = cls(L); c2.qubit_matrix = n; cl.append(c2.define_equivalence_class())
+                out[f"{t}_log_arg"] = np.array(arg, dtype=np.int64)
+                out[f"{t}_log_new"] = np.array(new, dtype=np.uint8)
+                out[f"{t}_log_dE"] = np.array(dE, dtype=np.int64)
+                out[f"{t}_log_class"] = np.array(cl, dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, "f1_surf.npz"), **out)
+    print("f1_surf.npz", len(out), "arrays")
+
+
+def gen_f2_surf(xm, rm, mc, mb, dec, decb):
+    rng = np.random.default_rng(99)
+    out = {}
+    cases = []
+    mods = (xm, rm)
+    codes = {"xzzx": xm.xzzx_code, "rot": rm.RotSurCode}
+    # depolarizing Chain (src/mcmc.py) on both codes
+    for i, (name, L, p, p_logical, iters, perr) in enumerate([
+            ("rot", 3, 0.5, 0.0, 40, 0.3), ("rot", 5, 0.17, 0.0, 400, 0.15), ("rot", 9, 0.17, 0.0, 500, 0.15),
+            ("rot", 5, 0.75, 0.5, 300, 0.15), ("rot", 9, 0.3, 0.5, 300, 0.15), ("xzzx", 5, 0.15, 0.0, 400, 0.15),
+            ("xzzx", 9, 0.75, 0.5, 300, 0.15), ("xzzx", 7, 0.2, 0.5, 200, 0.2), ("rot", 7, 0.1, 0.0, 200, 0.2)]):
+        m = rand_matrix2(rng, L, perr)
+        seed = 5000 + i
+        code = codes[name](L); code.qubit_matrix = m.copy()
+        ch = mc.Chain(p, code); ch.p_logical = p_logical
+        s = Stream(seed); install(s, *mods)
+        ch.update_chain(iters)
+        restore(*mods)
+        tag = f"chain{i}"
+        out[f"{tag}_init"] = m; out[f"{tag}_final"] = ch.code.qubit_matrix.astype(np.uint8)
+        out[f"{tag}_par"] = np.array([0 if name == "xzzx" else 1, L, p, p_logical, iters, seed, s.n, 0, 0], dtype=np.float64)
+        cases.append(tag)
+    # Chain_biased (src/mcmc_biased.py)
+    for i, (name, L, p, eta, p_logical, iters, perr) in enumerate([
+            ("xzzx", 3, 0.3, 10, 0.0, 60, 0.3), ("xzzx", 5, 0.15, 100, 0.0, 300, 0.15), ("xzzx", 9, 0.15, 100, 0.0, 300, 0.15),
+            ("xzzx", 5, 0.4, 10, 0.5, 300, 0.15), ("xzzx", 9, 0.5, 100, 0.5, 200, 0.15), ("rot", 5, 0.2, 3, 0.5, 200, 0.15)]):
+        m = rand_matrix2(rng, L, perr)
+        seed = 5100 + i
+        code = codes[name](L); code.qubit_matrix = m.copy()
+        ch = mb.Chain_biased(p, eta, code); ch.p_logical = p_logical
+        s = Stream(seed); install(s, *mods)
+        ch.update_chain(iters)
+        restore(*mods)
+        tag = f"bchain{i}"
+        out[f"{tag}_init"] = m; out[f"{tag}_final"] = ch.code.qubit_matrix.astype(np.uint8)
+        out[f"{tag}_par"] = np.array([0 if name == "xzzx" else 1, L, p, p_logical, iters, seed, s.n, 1, eta], dtype=np.float64)
+        cases.append(tag)
+    # Ladder / Ladder_biased
+    for i, (name, biased, L, p, eta, Nc, iters, nstep, perr) in enumerate([
+            ("rot", 0, 3, 0.3, 0, 4, 5, 40, 0.3), ("rot", 0, 5, 0.17, 0, 5, 10, 50, 0.15), ("rot", 0, 9, 0.17, 0, 8, 10, 30, 0.15),
+            ("xzzx", 0, 5, 0.15, 0, 4, 10, 40, 0.15), ("xzzx", 1, 3, 0.3, 10, 3, 5, 40, 0.3), ("xzzx", 1, 5, 0.15, 100, 5, 10, 40, 0.15),
+            ("xzzx", 1, 9, 0.15, 100, 8, 10, 20, 0.15)]):
+        m = rand_matrix2(rng, L, perr)
+        seed = 5200 + i
+        code = codes[name](L); code.qubit_matrix = m.copy()
+        s = Stream(seed); install(s, *mods)
+        ld = mb.Ladder_biased(p, code, eta, Nc, 0.5) if biased else mc.Ladder(p, code, Nc, 0.5)
+        tops = []
+        for _ in range(nstep):
+            ld.step(iters); tops.append(ld.tops0)
+        restore(*mods)
+        tag = f"ladder{i}"
+        out[f"{tag}_init"] = m
+        out[f"{tag}_states"] = np.array([c.code.qubit_matrix for c in ld.chains], dtype=np.uint8)
+        out[f"{tag}_flags"] = np.array([c.flag for c in ld.chains], dtype=np.uint8)
+        out[f"{tag}_tops_hist"] = np.array(tops, dtype=np.int64)
+        out[f"{tag}_p_ladder"] = np.asarray(ld.p_ladder, dtype=np.float64)
+        out[f"{tag}_p_diff"] = np.asarray(ld.p_diff, dtype=np.float64)
+        out[f"{tag}_par"] = np.array([0 if name == "xzzx" else 1, L, p, Nc, iters, nstep, seed, s.n, biased, eta], dtype=np.float64)
+        cases.append(tag)
+    # PTEQ (rotated, depolarizing) and PTEQ_biased (xzzx)
+    for i, (name, biased, L, p, eta, Nc, iters, steps, tops_burn, conv, perr, SEQ, TOPS, eps) in enumerate([
+            ("rot", 0, 3, 0.17, 0, 3, 10, 300, 2, None, 0.15, 2, 10, 0.1), ("rot", 0, 5, 0.17, 0, 5, 10, 200, 0, None, 0.15, 2, 10, 0.1),
+            ("rot", 0, 3, 0.17, 0, 3, 10, 6000, 1, "error_based", 0.15, 1, 4, 0.5),
+            ("xzzx", 1, 3, 0.3, 10, 3, 10, 300, 2, None, 0.3, 2, 10, 0.1), ("xzzx", 1, 5, 0.15, 100, 5, 10, 150, 0, None, 0.15, 2, 10, 0.1),
+            ("xzzx", 1, 5, 0.15, 100, 5, 10, 4000, 2, "error_based", 0.15, 2, 10, 0.1)]):
+        m = rand_matrix2(rng, L, perr)
+        seed = 5300 + i
+        code = codes[name](L); code.qubit_matrix = m.copy()
+        s = Stream(seed); install(s, *mods)
+        if biased:
+            pct = decb.PTEQ_biased(code, p, eta=eta, Nc=Nc, SEQ=SEQ, TOPS=TOPS, eps=eps, steps=steps, iters=iters,
+                                   tops_burn=tops_burn, conv_criteria=conv)
+        else:
+            pct = dec.PTEQ(code, p, Nc=Nc, SEQ=SEQ, TOPS=TOPS, eps=eps, steps=steps, iters=iters, tops_burn=tops_burn,
+                           conv_criteria=conv)
+        restore(*mods)
+        tag = f"pteq{i}"
+        out[f"{tag}_init"] = m
+        out[f"{tag}_percent"] = np.asarray(pct, dtype=np.uint8)
+        out[f"{tag}_par"] = np.array([0 if name == "xzzx" else 1, L, p, Nc, iters, steps, tops_burn, 1 if conv else 0, seed, s.n,
+                                      SEQ, TOPS, eps, biased, eta], dtype=np.float64)
+        cases.append(tag)
+    out["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(HERE, "f2_surf.npz"), **out)
+    print("f2_surf.npz", cases)
+
+
 # --------------------------------------------------------------------------- F3
 def _f3_worker(args):
     (L, p, Nc, iters, steps, burn, m, seed) = args
@@ -256,12 +414,16 @@ def main():
         print("reference not present; nothing to do")
         return
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="f1,f2,f3,f4")
+    ap.add_argument("--only", default="f1,f2,f3,f4,f1s,f2s")
     only = set(ap.parse_args().only.split(","))
     tm, mc, dec = import_reference()
     if "f1" in only: gen_f1(tm)
     if "f2" in only: gen_f2(tm, mc, dec)
     if "f4" in only: gen_f4(tm, mc)
+    if "f1s" in only or "f2s" in only:
+        xm, rm, mb, decb = import_reference_surf()
+        if "f1s" in only: gen_f1_surf(xm, rm)
+        if "f2s" in only: gen_f2_surf(xm, rm, mc, mb, dec, decb)
     if "f3" in only: gen_f3(tm)
 
 
