@@ -89,7 +89,8 @@ int         qecmc_device_count(void);      /* 0 when no GPU is visible */
 /* ---- stencil primitives (batched; N states per call, host pointers) -------
  * Each runs the same __device__ stencil code the sampler kernels use. */
 
-/* Toric_code.apply_stabilizer -> _apply_stabilizer, toric_model.py:40-41,256-284.
+/* Toric_code.apply_stabilizer -> _apply_stabilizer, toric_model.py:40-41,256-284 (xzzx_model.py:360-436,
+ * rotated_surface_model.py:349-392: operator 1 = plaquette (row,col), 3 = half plaquette `row` on side `col`).
  * out[i] = in[i] with stabilizer (rows[i], cols[i], ops[i]) applied; dE[i] = error-count change. */
 int qecmc_apply_stabilizer(int code, int L, uint64_t N, const uint8_t *in, uint8_t *out,
                            const int32_t *rows, const int32_t *cols, const int32_t *ops, int32_t *dE);
@@ -103,7 +104,8 @@ int qecmc_count_errors(int code, int L, uint64_t N, const uint8_t *in, int64_t *
 int qecmc_eq_class(int code, int L, uint64_t N, const uint8_t *in, int32_t *cls);
 /* to_class, toric_model.py:55-56,354-377. */
 int qecmc_to_class(int code, int L, uint64_t N, const uint8_t *in, uint8_t *out, const int32_t *eq);
-/* Toric_code.syndrom, toric_model.py:58-101: defects_out uint8[N][2][L][L]. */
+/* Toric_code.syndrom, toric_model.py:58-101: defects_out uint8[N][2][L][L]; xzzx_code.syndrome /
+ * RotSurCode.syndrome (xzzx_model.py:60-83): defects_out uint8[N][L+1][L+1] (plaquette_defects). */
 int qecmc_syndrome(int code, int L, uint64_t N, const uint8_t *in, uint8_t *defects_out);
 
 /* ---- chain / ladder on caller-owned state (host pointers) ----------------- */
@@ -113,6 +115,12 @@ int qecmc_syndrome(int code, int L, uint64_t N, const uint8_t *in, uint8_t *defe
  * k0 .. k0+iters-1).  p_logical != 0 selects the top-chain branch (mcmc.py:20). */
 int qecmc_chain_update(int code, int L, uint64_t N, uint8_t *states_inout, double p, double p_logical,
                        uint64_t iters, uint64_t seed, uint32_t first_syndrome, uint32_t slot, uint64_t k0);
+
+/* Chain_biased.update_chain(iters), src/mcmc_biased.py:20-59 (acceptance pn/pb from the full
+ * (nx,ny,nz) counts, pb frozen at loop entry as in the reference, quirk Q3). */
+int qecmc_chain_update_biased(int code, int L, uint64_t N, uint8_t *states_inout, double p, double eta,
+                              double p_logical, uint64_t iters, uint64_t seed, uint32_t first_syndrome,
+                              uint32_t slot, uint64_t k0);
 
 /* Ladder.step(iters) x nsteps, src/mcmc.py:94-103, on N ladders in slot order.
  * states uint8[N][Nc][nq], flags uint8[N][Nc], tops0 uint32[N]; step0 / prop0 =

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "kernels.hpp"
+#include "stencil_bytes.hpp"
 
 using namespace qecmc;
 
@@ -58,9 +59,35 @@ struct DevBuf {
 
 int check_code_L(int code, int L)
 {
-    if (code != QECMC_TORIC) return fail(QECMC_ERR_UNSUPPORTED, "code %d: only the toric code (0) has kernels in this build", code);
+    if (code != QECMC_TORIC && code != QECMC_XZZX && code != QECMC_ROTATED)
+        return fail(QECMC_ERR_INVALID, "code %d unknown (0 toric, 1 xzzx, 2 rotated)", code);
     if (L < 2 || L > 64) return fail(QECMC_ERR_INVALID, "L=%d out of range [2,64]", L);
+    if (code != QECMC_TORIC && (L < 3 || L % 2 == 0))
+        return fail(QECMC_ERR_INVALID, "L=%d: the xzzx / rotated models need odd L >= 3 (their half-plaquette indexing, xzzx_model.py:444)", L);
     return 0;
+}
+
+inline size_t code_nq(int code, int L) { return code == QECMC_TORIC ? (size_t)2 * L * L : (size_t)L * L; }
+
+// px^n, py^n, pz^n, pI^n for n = 0..nq (mcmc_biased.py:25-31): the same libm pow() the reference calls
+std::vector<double> bias_tables(double p, double eta, size_t nq)
+{
+    const double pz = p * eta / (eta + 1), px = p / (2 * (eta + 1)), py = px, pi = 1 - px - py - pz;
+    std::vector<double> t(4 * (nq + 1));
+    for (size_t n = 0; n <= nq; ++n) {
+        t[n] = std::pow(px, (double)n);
+        t[(nq + 1) + n] = std::pow(py, (double)n);
+        t[2 * (nq + 1) + n] = std::pow(pz, (double)n);
+        t[3 * (nq + 1) + n] = std::pow(pi, (double)n);
+    }
+    return t;
+}
+
+// floor(phalf * 2^32), phalf = (L^2 - (L-1)^2 - 1)/(L^2 - 1) (xzzx_model.py:444): u > phalf <=> x > this
+uint64_t half_threshold(int L)
+{
+    const double phalf = (double)(L * L - (L - 1) * (L - 1) - 1) / (double)(L * L - 1);
+    return (uint64_t)std::floor(phalf * 4294967296.0);
 }
 
 // ceil(v * 2^32) as used by every integer acceptance test: u < v  <=>  x < ceil(v*2^32) for u = x*2^-32
@@ -109,12 +136,47 @@ std::vector<uint32_t> toric_logical_masks(int L, int W)
     return m;
 }
 
+// XOR masks of the xzzx / rotated logical operators, same [4][L+1][W] layout as the toric table
+// (kinds 2, 3 unused): kind 0 = X (xzzx: anti-diagonal for every position; rotated: column `pos`),
+// kind 1 = Z (xzzx: diagonal; rotated: row `pos`); xzzx_model.py:291-311, rotated_surface_model.py:260-280
+std::vector<uint32_t> surf_logical_masks(int code, int L, int W)
+{
+    std::vector<uint32_t> m((size_t)4 * (L + 1) * W, 0u);
+    auto set = [&](int kind, int pos, int q, uint32_t op) { m[((size_t)kind * (L + 1) + pos) * W + (q >> 4)] ^= op << ((q & 15) * 2); };
+    for (int pos = 0; pos < L; ++pos)
+        for (int i = 0; i < L; ++i) {
+            if (code == QECMC_XZZX) { set(0, pos, i * L + (L - 1 - i), 1); set(1, pos, i * L + i, 3); }
+            else { set(0, pos, i * L + pos, 1); set(1, pos, pos * L + i, 3); }
+        }
+    return m;
+}
+
+// generator table of the plaquette codes: entry g = 4 x u16 (site << 2 | pauli), two u32 per generator
+std::vector<uint32_t> surf_generator_table(int code, int L)
+{
+    const int nfull = (L - 1) * (L - 1), nhalf = 2 * (L - 1);
+    std::vector<uint32_t> t((size_t)2 * (nfull + nhalf), 0u);
+    auto put = [&](int g, int row, int col, int op) {
+        int sites[4], paulis[4];
+        const int n = surf_generator(code, L, row, col, op, sites, paulis);
+        uint32_t e[4] = {0, 0, 0, 0};
+        for (int i = 0; i < n; ++i) e[i] = ((uint32_t)sites[i] << 2) | (uint32_t)paulis[i];
+        t[2 * g] = e[0] | (e[1] << 16);
+        t[2 * g + 1] = e[2] | (e[3] << 16);
+    };
+    for (int r = 0; r < L - 1; ++r)
+        for (int c = 0; c < L - 1; ++c) put(r * (L - 1) + c, r, c, 1);
+    for (int i = 0; i < (L - 1) / 2; ++i)
+        for (int side = 0; side < 4; ++side) put(nfull + i * 4 + side, i, side, 3);
+    return t;
+}
+
 }  // namespace
 
 struct qecmc_plan {
     qecmc_params prm;
     LadderArgs args;
-    DevBuf swap_thr, lmask, acc_top;
+    DevBuf swap_thr, lmask, acc_top, gen, bias;
     size_t lds_bytes;
 };
 
@@ -127,9 +189,13 @@ int validate_params(const qecmc_params *p)
         return fail(QECMC_ERR_INVALID, "params->abi_size=%u, this library expects %zu", p->abi_size, sizeof(qecmc_params));
     if (int rc = check_code_L(p->code, p->L)) return rc;
     if (p->Nc < 1 || p->Nc > kMaxNc) return fail(QECMC_ERR_INVALID, "Nc=%d out of range [1,%d]", p->Nc, kMaxNc);
-    if (!(p->p > 0.0) || !(p->p <= 0.75)) return fail(QECMC_ERR_INVALID, "p=%g must be in (0, 0.75]", p->p);
+    if (p->noise != QECMC_NOISE_DEPOLARIZING && p->noise != QECMC_NOISE_BIASED) return fail(QECMC_ERR_INVALID, "noise model %d unknown", p->noise);
+    if (p->noise == QECMC_NOISE_BIASED) {
+        if (!(p->eta > 0.0)) return fail(QECMC_ERR_INVALID, "eta=%g must be positive", p->eta);
+        if (!(p->p > 0.0) || !(p->p < (p->eta + 1) / (2 * p->eta + 1))) return fail(QECMC_ERR_INVALID, "p=%g must be in (0, (eta+1)/(2 eta+1))", p->p);
+        if (p->code == QECMC_TORIC) return fail(QECMC_ERR_UNSUPPORTED, "biased noise is built for the xzzx and rotated codes (BASELINE config 4)");
+    } else if (!(p->p > 0.0) || !(p->p <= 0.75)) return fail(QECMC_ERR_INVALID, "p=%g must be in (0, 0.75]", p->p);
     if (!(p->p_logical >= 0.0) || !(p->p_logical <= 1.0)) return fail(QECMC_ERR_INVALID, "p_logical=%g must be in [0,1]", p->p_logical);
-    if (p->noise != QECMC_NOISE_DEPOLARIZING) return fail(QECMC_ERR_UNSUPPORTED, "noise model %d not built yet", p->noise);
     if (p->scan != QECMC_SCAN_RANDOM) return fail(QECMC_ERR_UNSUPPORTED, "scan mode %d not built yet", p->scan);
     if (p->conv_mode != QECMC_CONV_NONE && p->conv_mode != QECMC_CONV_ERROR_BASED) return fail(QECMC_ERR_INVALID, "conv_mode %d unknown", p->conv_mode);
     if (p->conv_mode == QECMC_CONV_ERROR_BASED && (p->TOPS < 0 || p->SEQ < 0 || !(p->eps >= 0))) return fail(QECMC_ERR_INVALID, "TOPS, SEQ and eps must be non-negative");
@@ -143,7 +209,9 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
     pl->prm = *p;
     LadderArgs &a = pl->args;
     std::memset(&a, 0, sizeof a);
-    const int L = p->L, Nc = p->Nc, nq = 2 * L * L, W = (nq + 15) / 16, ncls = 16;
+    const int L = p->L, Nc = p->Nc, nq = (int)code_nq(p->code, L), W = (nq + 15) / 16, ncls = p->code == QECMC_TORIC ? 16 : 4;
+    const bool biased = p->noise == QECMC_NOISE_BIASED;
+    a.code = p->code; a.noise = p->noise;
     a.L = L; a.Nc = Nc; a.W = W; a.nq = nq; a.ncls = ncls;
     a.iters = (uint32_t)p->iters;
     a.seed_lo = (uint32_t)p->seed; a.seed_hi = (uint32_t)(p->seed >> 32);
@@ -155,10 +223,11 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
         return fail(QECMC_ERR_UNSUPPORTED, "L=%d Nc=%d needs %zu B of LDS per workgroup (> 160 KiB)", L, Nc, pl->lds_bytes);
 
     std::vector<double> pladder, pdiff;
-    ladder_probabilities(p->p, 0.75, Nc, pladder, pdiff);                  // mcmc.py:62-69
+    // p_top = 0.75 (mcmc.py:62) or (eta+1)/(2 eta+1) (mcmc_biased.py:81)
+    ladder_probabilities(p->p, biased ? (p->eta + 1) / (2 * p->eta + 1) : 0.75, Nc, pladder, pdiff);   // mcmc.py:62-69
     for (int c = 0; c < Nc; ++c) {
         const double f = chain_factor(pladder[c]);
-        if (f >= 1.0) a.acc_all_mask |= 1u << c;
+        if (f >= 1.0 && !biased) a.acc_all_mask |= 1u << c;
         for (int d = 1; d <= 4; ++d) a.acc_thr[c][d - 1] = thr32(std::pow(f, (double)d));   // mcmc.py:42
     }
     std::vector<uint32_t> top_tbl(nq + 1, 0u);                             // mcmc.py:34 for a top chain below p = 0.75
@@ -169,7 +238,24 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
     a.swap_fast_ok = 1;
     for (int i = 0; i + 1 < Nc; ++i)
         if (nq >= 1 && sw[(size_t)i * (nq + 1) + 1] > 0xFFFFFFFFull) a.swap_fast_ok = 0;
-    const std::vector<uint32_t> lm = toric_logical_masks(L, W);
+    const std::vector<uint32_t> lm = p->code == QECMC_TORIC ? toric_logical_masks(L, W) : surf_logical_masks(p->code, L, W);
+    if (p->code != QECMC_TORIC) {
+        const std::vector<uint32_t> gt = surf_generator_table(p->code, L);
+        HIP_TRY(pl->gen.alloc(gt.size() * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpy(pl->gen.p, gt.data(), gt.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        a.gen = pl->gen.as<uint2>();
+        a.thr_half = half_threshold(L);
+    }
+    if (biased) {
+        std::vector<double> bt;
+        for (int c = 0; c < Nc; ++c) {
+            const std::vector<double> t = bias_tables(pladder[c], p->eta, (size_t)nq);
+            bt.insert(bt.end(), t.begin(), t.end());
+        }
+        HIP_TRY(pl->bias.alloc(bt.size() * sizeof(double)));
+        HIP_TRY(hipMemcpy(pl->bias.p, bt.data(), bt.size() * sizeof(double), hipMemcpyHostToDevice));
+        a.bias_tbl = pl->bias.as<double>();
+    }
     HIP_TRY(pl->swap_thr.alloc(sw.size() * sizeof(uint64_t)));
     HIP_TRY(pl->lmask.alloc(lm.size() * sizeof(uint32_t)));
     HIP_TRY(hipMemcpy(pl->swap_thr.p, sw.data(), sw.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
@@ -199,7 +285,7 @@ int qecmc_device_count(void)
 #define PRIM_PROLOGUE()                                   \
     if (int rc = check_code_L(code, L)) return rc;        \
     if (int rc = use_device(0)) return rc;                \
-    const size_t nq = (size_t)2 * L * L;                  \
+    const size_t nq = code_nq(code, L);                   \
     (void)nq;                                             \
     if (N == 0) return 0
 
@@ -209,8 +295,10 @@ int qecmc_apply_stabilizer(int code, int L, uint64_t N, const uint8_t *in, uint8
     PRIM_PROLOGUE();
     if (!in || !out || !rows || !cols || !ops || !dE) return fail(QECMC_ERR_INVALID, "NULL buffer");
     for (uint64_t i = 0; i < N; ++i) {
-        if (rows[i] < 0 || rows[i] >= L || cols[i] < 0 || cols[i] >= L) return fail(QECMC_ERR_INVALID, "stabilizer %llu: (row,col)=(%d,%d) outside [0,%d)", (unsigned long long)i, rows[i], cols[i], L);
-        if (ops[i] != 1 && ops[i] != 3) return fail(QECMC_ERR_INVALID, "stabilizer %llu: operator %d is not 1 (X) or 3 (Z)", (unsigned long long)i, ops[i]);
+        if (ops[i] != 1 && ops[i] != 3) return fail(QECMC_ERR_INVALID, "stabilizer %llu: operator %d is not 1 or 3", (unsigned long long)i, ops[i]);
+        const int rmax = code == QECMC_TORIC ? L : (ops[i] == 1 ? L - 1 : (L - 1) / 2);
+        const int cmax = code == QECMC_TORIC ? L : (ops[i] == 1 ? L - 1 : 4);
+        if (rows[i] < 0 || rows[i] >= rmax || cols[i] < 0 || cols[i] >= cmax) return fail(QECMC_ERR_INVALID, "stabilizer %llu: (row,col)=(%d,%d) outside [0,%d)x[0,%d)", (unsigned long long)i, rows[i], cols[i], rmax, cmax);
     }
     DevBuf din, dout, dr, dc, dop, dd;
     HIP_TRY(din.alloc(N * nq)); HIP_TRY(dout.alloc(N * nq));
@@ -219,7 +307,7 @@ int qecmc_apply_stabilizer(int code, int L, uint64_t N, const uint8_t *in, uint8
     HIP_TRY(hipMemcpy(dr.p, rows, N * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dc.p, cols, N * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dop.p, ops, N * 4, hipMemcpyHostToDevice));
-    HIP_TRY(launch_apply_stabilizer(L, N, din.as<uint8_t>(), dout.as<uint8_t>(), dr.as<int32_t>(), dc.as<int32_t>(), dop.as<int32_t>(), dd.as<int32_t>(), 0));
+    HIP_TRY(launch_apply_stabilizer(code, L, N, din.as<uint8_t>(), dout.as<uint8_t>(), dr.as<int32_t>(), dc.as<int32_t>(), dop.as<int32_t>(), dd.as<int32_t>(), 0));
     HIP_TRY(hipMemcpy(out, dout.p, N * nq, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(dE, dd.p, N * 4, hipMemcpyDeviceToHost));
     return 0;
@@ -243,7 +331,7 @@ int qecmc_apply_logical(int code, int L, uint64_t N, const uint8_t *in, uint8_t 
     HIP_TRY(hipMemcpy(d1.p, layers, N * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d2.p, xpos, N * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d3.p, zpos, N * 4, hipMemcpyHostToDevice));
-    HIP_TRY(launch_apply_logical(L, N, din.as<uint8_t>(), dout.as<uint8_t>(), d0.as<int32_t>(), d1.as<int32_t>(), d2.as<int32_t>(), d3.as<int32_t>(), dd.as<int32_t>(), 0));
+    HIP_TRY(launch_apply_logical(code, L, N, din.as<uint8_t>(), dout.as<uint8_t>(), d0.as<int32_t>(), d1.as<int32_t>(), d2.as<int32_t>(), d3.as<int32_t>(), dd.as<int32_t>(), 0));
     HIP_TRY(hipMemcpy(out, dout.p, N * nq, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(dE, dd.p, N * 4, hipMemcpyDeviceToHost));
     return 0;
@@ -268,7 +356,7 @@ int qecmc_eq_class(int code, int L, uint64_t N, const uint8_t *in, int32_t *cls)
     DevBuf din, dc;
     HIP_TRY(din.alloc(N * nq)); HIP_TRY(dc.alloc(N * 4));
     HIP_TRY(hipMemcpy(din.p, in, N * nq, hipMemcpyHostToDevice));
-    HIP_TRY(launch_eq_class(L, N, din.as<uint8_t>(), dc.as<int32_t>(), 0));
+    HIP_TRY(launch_eq_class(code, L, N, din.as<uint8_t>(), dc.as<int32_t>(), 0));
     HIP_TRY(hipMemcpy(cls, dc.p, N * 4, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -277,6 +365,7 @@ int qecmc_to_class(int code, int L, uint64_t N, const uint8_t *in, uint8_t *out,
 {
     PRIM_PROLOGUE();
     if (!in || !out || !eq) return fail(QECMC_ERR_INVALID, "NULL buffer");
+    if (code != QECMC_TORIC) return fail(QECMC_ERR_UNSUPPORTED, "to_class exists for the toric code only (toric_model.py:354)");
     for (uint64_t i = 0; i < N; ++i)
         if (eq[i] < 0 || eq[i] > 15) return fail(QECMC_ERR_INVALID, "to_class %llu: class %d outside [0,16)", (unsigned long long)i, eq[i]);
     DevBuf din, dout, de;
@@ -292,21 +381,24 @@ int qecmc_syndrome(int code, int L, uint64_t N, const uint8_t *in, uint8_t *defe
 {
     PRIM_PROLOGUE();
     if (!in || !defects_out) return fail(QECMC_ERR_INVALID, "NULL buffer");
+    const size_t nd = code == QECMC_TORIC ? nq : (size_t)(L + 1) * (L + 1);
     DevBuf din, dout;
-    HIP_TRY(din.alloc(N * nq)); HIP_TRY(dout.alloc(N * nq));
+    HIP_TRY(din.alloc(N * nq)); HIP_TRY(dout.alloc(N * nd));
     HIP_TRY(hipMemcpy(din.p, in, N * nq, hipMemcpyHostToDevice));
-    HIP_TRY(launch_syndrome(L, N, din.as<uint8_t>(), dout.as<uint8_t>(), 0));
-    HIP_TRY(hipMemcpy(defects_out, dout.p, N * nq, hipMemcpyDeviceToHost));
+    HIP_TRY(launch_syndrome(code, L, N, din.as<uint8_t>(), dout.as<uint8_t>(), 0));
+    HIP_TRY(hipMemcpy(defects_out, dout.p, N * nd, hipMemcpyDeviceToHost));
     return 0;
 }
 
 // ---------------------------------------------------------------- chain / ladder
-int qecmc_chain_update(int code, int L, uint64_t N, uint8_t *states_inout, double p, double p_logical,
-                       uint64_t iters, uint64_t seed, uint32_t first_syndrome, uint32_t slot, uint64_t k0)
+static int chain_update_impl(int code, int L, uint64_t N, uint8_t *states_inout, double p, double eta, int noise,
+                             double p_logical, uint64_t iters, uint64_t seed, uint32_t first_syndrome, uint32_t slot, uint64_t k0)
 {
     PRIM_PROLOGUE();
     if (!states_inout) return fail(QECMC_ERR_INVALID, "NULL buffer");
-    if (!(p > 0.0) || !(p <= 0.75)) return fail(QECMC_ERR_INVALID, "p=%g must be in (0, 0.75]", p);
+    if (noise) {
+        if (!(p > 0.0) || !(p < 1.0) || !(eta > 0.0)) return fail(QECMC_ERR_INVALID, "biased noise needs p in (0,1) and eta > 0 (p=%g eta=%g)", p, eta);
+    } else if (!(p > 0.0) || !(p <= 0.75)) return fail(QECMC_ERR_INVALID, "p=%g must be in (0, 0.75]", p);
     if (!(p_logical >= 0.0) || !(p_logical <= 1.0)) return fail(QECMC_ERR_INVALID, "p_logical=%g must be in [0,1]", p_logical);
     if (slot >= 0x100u) return fail(QECMC_ERR_INVALID, "slot %u collides with the swap stream id", slot);
     ChainArgs a;
@@ -314,18 +406,33 @@ int qecmc_chain_update(int code, int L, uint64_t N, uint8_t *states_inout, doubl
     const double f = chain_factor(p);
     std::vector<uint32_t> tbl(nq + 1, 0u);
     for (size_t d = 1; d <= nq; ++d) tbl[d] = thr32(std::pow(f, (double)d));
-    DevBuf ds, dt;
-    HIP_TRY(ds.alloc(N * nq)); HIP_TRY(dt.alloc(tbl.size() * 4));
+    const std::vector<double> bt = bias_tables(p, noise ? eta : 1.0, nq);
+    DevBuf ds, dt, db;
+    HIP_TRY(ds.alloc(N * nq)); HIP_TRY(dt.alloc(tbl.size() * 4)); HIP_TRY(db.alloc(bt.size() * 8));
     HIP_TRY(hipMemcpy(ds.p, states_inout, N * nq, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dt.p, tbl.data(), tbl.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(db.p, bt.data(), bt.size() * 8, hipMemcpyHostToDevice));
     a.states = ds.as<uint8_t>(); a.N = N; a.iters = iters; a.k0 = k0;
     a.thr_logical = p_logical > 0 ? thr64(p_logical) : 0;
-    a.acc_tbl = dt.as<uint32_t>(); a.acc_all = f >= 1.0;
+    a.acc_tbl = dt.as<uint32_t>(); a.acc_all = !noise && f >= 1.0;
     a.first_syndrome = first_syndrome; a.slot = slot;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.L = L;
+    a.code = code; a.noise = noise; a.thr_half = half_threshold(L); a.bias_tbl = db.as<double>();
     HIP_TRY(launch_chain_update(a, 0));
     HIP_TRY(hipMemcpy(states_inout, ds.p, N * nq, hipMemcpyDeviceToHost));
     return 0;
+}
+
+int qecmc_chain_update(int code, int L, uint64_t N, uint8_t *states_inout, double p, double p_logical,
+                       uint64_t iters, uint64_t seed, uint32_t first_syndrome, uint32_t slot, uint64_t k0)
+{
+    return chain_update_impl(code, L, N, states_inout, p, 0.0, 0, p_logical, iters, seed, first_syndrome, slot, k0);
+}
+
+int qecmc_chain_update_biased(int code, int L, uint64_t N, uint8_t *states_inout, double p, double eta, double p_logical,
+                              uint64_t iters, uint64_t seed, uint32_t first_syndrome, uint32_t slot, uint64_t k0)
+{
+    return chain_update_impl(code, L, N, states_inout, p, eta, 1, p_logical, iters, seed, first_syndrome, slot, k0);
 }
 
 int qecmc_ladder_step(const qecmc_params *params, uint64_t N, uint8_t *states_inout, uint8_t *flags_inout,

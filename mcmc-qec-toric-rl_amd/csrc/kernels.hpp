@@ -23,6 +23,10 @@ struct LadderArgs {
     uint16_t *nlog;           // [nsteps][N]       bottom-chain error counts (conv_mode workspace)
     const uint64_t *swap_thr; // [Nc-1][nq+1]      ceil(p_diff[i]^d * 2^32)
     const uint32_t *lmask;    // [4][L+1][W]       logical-operator XOR masks (row L = identity)
+    const uint2 *gen;         // [(L-1)^2 + 2(L-1)]  xzzx / rotated generators: 4 x u16 (site << 2 | pauli), 0 = unused
+    const double *bias_tbl;   // [Nc][4][nq+1]      px^n, py^n, pz^n, pI^n per rung (biased noise)
+    uint64_t thr_half;        // floor(phalf * 2^32) (xzzx_model.py:444)
+    int code, noise;          // qecmc_code, qecmc_noise
     const uint32_t *acc_tbl_top; // [nq+1]          ceil(f_top^dE * 2^32): top slot below p = 0.75 (Nc == 1 only)
     uint64_t N;
     uint64_t step0, prop0, nsteps;
@@ -49,15 +53,15 @@ size_t ladder_lds_bytes(int L, int Nc, int W, int ncls);
 hipError_t launch_ladder_rs_toric(const LadderArgs &a, hipStream_t stream);
 
 // byte-state primitive kernels (primitives.hip); all pointers are device pointers
-hipError_t launch_apply_stabilizer(int L, uint64_t N, const uint8_t *in, uint8_t *out, const int32_t *rows,
+hipError_t launch_apply_stabilizer(int code, int L, uint64_t N, const uint8_t *in, uint8_t *out, const int32_t *rows,
                                    const int32_t *cols, const int32_t *ops, int32_t *dE, hipStream_t s);
-hipError_t launch_apply_logical(int L, uint64_t N, const uint8_t *in, uint8_t *out, const int32_t *ops,
+hipError_t launch_apply_logical(int code, int L, uint64_t N, const uint8_t *in, uint8_t *out, const int32_t *ops,
                                 const int32_t *layers, const int32_t *xpos, const int32_t *zpos, int32_t *dE,
                                 hipStream_t s);
 hipError_t launch_count_errors(int nq, uint64_t N, const uint8_t *in, int64_t *n, hipStream_t s);
-hipError_t launch_eq_class(int L, uint64_t N, const uint8_t *in, int32_t *cls, hipStream_t s);
+hipError_t launch_eq_class(int code, int L, uint64_t N, const uint8_t *in, int32_t *cls, hipStream_t s);
 hipError_t launch_to_class(int L, uint64_t N, const uint8_t *in, uint8_t *out, const int32_t *eq, hipStream_t s);
-hipError_t launch_syndrome(int L, uint64_t N, const uint8_t *in, uint8_t *defects, hipStream_t s);
+hipError_t launch_syndrome(int code, int L, uint64_t N, const uint8_t *in, uint8_t *defects, hipStream_t s);
 
 struct ChainArgs {
     uint8_t *states;          // [N][nq] in/out
@@ -67,6 +71,10 @@ struct ChainArgs {
     uint32_t acc_all;         // f >= 1: every proposal is accepted (mcmc.py:30)
     uint32_t first_syndrome, slot, seed_lo, seed_hi;
     int L;
+    int code;                 // 0 toric, 1 xzzx, 2 rotated
+    int noise;                // 0 depolarizing (mcmc.py), 1 biased (mcmc_biased.py)
+    uint64_t thr_half;        // floor(phalf * 2^32): xzzx / rotated pick the full plaquette iff x > thr_half
+    const double *bias_tbl;   // [4][nq+1] px^n, py^n, pz^n, pI^n (biased noise)
 };
 hipError_t launch_chain_update(const ChainArgs &a, hipStream_t s);
 

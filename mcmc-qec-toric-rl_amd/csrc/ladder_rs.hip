@@ -31,6 +31,7 @@
 //   * HBM traffic is compulsory only: nq bytes in, ncls counters out per syndrome.
 #include "kernels.hpp"
 #include "philox.hpp"
+#include "stencil_bytes.hpp"   // kCode* constants
 
 namespace qecmc {
 
@@ -88,6 +89,45 @@ __device__ __forceinline__ uint32_t toric_class_packed(const uint32_t *sb, int W
     return x1 + 2u * z1 + 4u * x2 + 8u * z2;
 }
 
+// ---- XZZX / rotated codes on the packed state (one L x L layer) ---------------------------------
+// internal class value v = xparity | zparity << 1; rotated class = v (rotated_surface_model.py:411-420),
+// XZZX class = v ^ (v >> 1) (xzzx_model.py:474-486 maps (1,0)->1, (1,1)->2, (0,1)->3)
+__device__ __forceinline__ uint32_t surf_class_packed(int code, const uint32_t *sb, int L)
+{
+    uint32_t x = 0, z = 0;
+    for (int i = 0; i < L; ++i) {
+        const uint32_t qa = (uint32_t)i, qb = (uint32_t)(i * L);
+        const uint32_t fa = (sb[(qa >> 4) * 64] >> ((qa & 15u) * 2u)) & 3u;    // row 0
+        const uint32_t fb = (sb[(qb >> 4) * 64] >> ((qb & 15u) * 2u)) & 3u;    // column 0
+        const uint32_t xa = (fa ^ (fa >> 1)) & 1u, za = fa >> 1, xb = (fb ^ (fb >> 1)) & 1u, zb = fb >> 1;   // X / Z components
+        if (code == kCodeXzzx) {            // row 0 counts Y, X at even i, Z at odd i; column 0 the other way round
+            x ^= (i & 1) ? za : xa;
+            z ^= (i & 1) ? xb : zb;
+        } else {
+            x ^= xa;
+            z ^= zb;
+        }
+    }
+    return x | (z << 1);
+}
+
+// counts of X, Y, Z fields in one packed word
+__device__ __forceinline__ void count_xyz(uint32_t w, int &nx, int &ny, int &nz)
+{
+    const uint32_t b0 = w & 0x55555555u, b1 = (w >> 1) & 0x55555555u;
+    nx += __popc(b0 & ~b1); ny += __popc(b1 & ~b0); nz += __popc(b0 & b1);
+}
+
+// rows / cols / rows2 / cols2 / selector of _apply_random_stabilizer (xzzx_model.py:439-452) -> generator index
+// into the plan's table: [0, (L-1)^2) full plaquettes row-major, then 4 per half-plaquette index
+__device__ __forceinline__ uint32_t surf_generator_index(uint32_t L, uint32_t wa, uint32_t wb, uint32_t wsel, uint64_t thr_half)
+{
+    const uint32_t Lm = L - 1;
+    const uint32_t full = (((wa >> 16) * Lm) >> 16) * Lm + (((wa & 0xFFFFu) * Lm) >> 16);
+    const uint32_t half = Lm * Lm + (((wb >> 16) * Lm) >> 17) * 4u + ((wb >> 14) & 3u);
+    return (uint64_t)wsel > thr_half ? full : half;
+}
+
 // slot record published once per ladder step: error count | state id << 16 | class << 24 | flag << 31
 // (flag = "has been at the top since it last reached the bottom", Chain.flag, mcmc.py:75,99-103)
 __device__ __forceinline__ uint32_t pack_info(uint32_t n, uint32_t sid, uint32_t cls, uint32_t flag)
@@ -100,7 +140,9 @@ __device__ __forceinline__ uint32_t pack_info(uint32_t n, uint32_t sid, uint32_t
 // GROUPS: independent 64-syndrome ladders per workgroup (they share only the barrier).  Two groups
 // (16 waves at Nc = 8, two workgroups per CU) keep 4 waves per SIMD busy even when a workgroup is
 // alone on its CU at the end of a launch, where one group (2 waves per SIMD) is latency-bound.
-template <int MAXT, int MINW, bool CONV, int GROUPS>
+// CODE / BIASED: code model (toric, xzzx, rotated) and acceptance rule (src/mcmc.py or src/mcmc_biased.py).
+// The tuned paths are toric + depolarizing; the other combinations share the staging, cascade and bookkeeping.
+template <int MAXT, int MINW, bool CONV, int GROUPS, int CODE, bool BIASED>
 __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const LadderArgs a)
 {
     extern __shared__ uint32_t lds_all[];
@@ -179,7 +221,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
         const uint32_t *sb = st + slot * W * 64 + lane;
         n = 0;
         for (int w = 0; w < W; ++w) n += nnz2(sb[w * 64]);
-        cls = toric_class_packed(sb, W, LL);
+        cls = CODE == kCodeToric ? toric_class_packed(sb, W, LL) : surf_class_packed(CODE, sb, L);
     }
     uint32_t tops0 = 0, samples = 0;              // per-syndrome counters live in wave 0
     // convergence criterion of decoders.py:74-82,93-105 (wave 0 only): window sums over the logged
@@ -220,6 +262,127 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
         const bool acc_all = (a.acc_all_mask >> slot_u) & 1u;
         const bool top_logical = (slot_u == (uint32_t)(NC - 1)) && a.thr_logical != 0;
         const uint32_t *myT = thrT + slot_u * 9 + 4;
+        if constexpr (CODE != kCodeToric || BIASED) {
+            // ---------- XZZX / rotated codes and the biased acceptance rule ----------------------------
+            const bool top = top_logical;
+            if (!top && !BIASED && CODE != kCodeToric) {
+                // depolarizing Metropolis on a plaquette code: generator table lookup, 2 or 4 sites
+                int ni = (int)n;
+                for (uint32_t j = 0; j < iters; ++j) {
+                    const u32x4 x = philox_block(kbase + j, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                    const uint32_t g = surf_generator_index(L, x.x, x.y, x.z, a.thr_half);
+                    const uint2 e = a.gen[g];                                      // 4 x (site << 2 | pauli), 0 = no site
+                    const uint32_t ent[4] = {e.x & 0xFFFFu, e.x >> 16, e.y & 0xFFFFu, e.y >> 16};
+                    uint32_t *ad[4];
+                    uint32_t sh[4], F = 0, OPS = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const uint32_t q = ent[i] >> 2;
+                        ad[i] = stw + (q >> 4) * 64;
+                        sh[i] = (q & 15u) * 2u;
+                        F |= ((*ad[i] >> sh[i]) & 3u) << (2 * i);
+                        OPS |= (ent[i] & 3u) << (2 * i);
+                    }
+                    const uint32_t G = F ^ OPS;
+                    const int dE = __popc((G | (G >> 1)) & 0x55u) - __popc((F | (F >> 1)) & 0x55u);
+                    if (x.w <= myT[dE]) {                                           // mcmc.py:42
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) lds_xor(ad[i], (ent[i] & 3u) << sh[i]);
+                        ni += dE;
+                    }
+                }
+                n = (uint32_t)ni;
+            } else {
+                // general path: top chains (logical proposals, mcmc.py:20-35) and every biased chain
+                // (mcmc_biased.py:20-59: accept iff u < pn/pb with pb frozen at loop entry, quirk Q3)
+                int nx = 0, ny = 0, nz = 0;
+                for (int w = 0; w < W; ++w) count_xyz(stw[w * 64], nx, ny, nz);
+                const int T1 = nq + 1;
+                const double *bt = BIASED ? a.bias_tbl + (size_t)slot_u * 4 * T1 : nullptr;
+                double pb = 1.0;
+                if constexpr (BIASED) pb = bt[nx] * bt[T1 + ny] * bt[2 * T1 + nz] * bt[3 * T1 + (nq - nx - ny - nz)];
+                uint32_t cdelta = 0;
+                const uint32_t *lmask = a.lmask;
+                const int LW = (L + 1) * W;
+                for (uint32_t j = 0; j < iters; ++j) {
+                    const uint64_t k = kbase + j;
+                    const u32x4 x = philox_block(k, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                    const bool logical = top && x.x <= thrL1;                       // mcmc.py:23
+                    int dx = 0, dy = 0, dz = 0;                                    // change of the X / Y / Z counts
+                    uint32_t ent[4] = {0, 0, 0, 0}, cd = 0;
+                    const uint32_t *m0 = lmask + L * W, *m1 = m0, *m2 = m0, *m3 = m0;   // identity rows
+                    if (logical) {
+                        if (CODE == kCodeToric) {
+                            const uint32_t op0 = x.y >> 30, op1 = x.z >> 30;
+                            const uint32_t dx0 = (op0 ^ (op0 >> 1)) & 1u, dz0 = op0 >> 1, dx1 = (op1 ^ (op1 >> 1)) & 1u, dz1 = op1 >> 1;
+                            if (dx0) m0 = lmask + scale_low30(x.y, L) * W;
+                            if (dz0) m1 = lmask + LW + scale_u16(x.w >> 16, L) * W;
+                            if (dx1) m2 = lmask + 2 * LW + scale_low30(x.z, L) * W;
+                            if (dz1) m3 = lmask + 3 * LW + scale_u16(x.w & 0xFFFFu, L) * W;
+                            cd = Lodd ? (dx0 | (dz0 << 1) | (dx1 << 2) | (dz1 << 3)) : 0u;
+                        } else {
+                            const uint32_t op = x.y >> 30;                          // xzzx_model.py:346 / rotated_surface_model.py:334
+                            const uint32_t xp = ((op ^ (op >> 1)) & 1u) ? scale_low30(x.y, L) : 0u;   // drawn iff op in {1,2}
+                            const uint32_t zp = (op >> 1) ? scale_u16(x.w >> 16, L) : 0u;             // drawn iff op in {3,2}
+                            // applied operators: xzzx X iff op in {1,2}, Z iff op in {3,2}; rotated X iff op in {1,3}, Z iff op in {2,3}
+                            const uint32_t ax = CODE == kCodeXzzx ? ((op ^ (op >> 1)) & 1u) : (op & 1u);
+                            const uint32_t az = op >> 1;
+                            if (ax) m0 = lmask + xp * W;                            // kind 0: X (xzzx: anti-diagonal at every pos)
+                            if (az) m1 = lmask + LW + zp * W;                       // kind 1: Z
+                            cd = ax | (az << 1);
+                        }
+                        for (int w = 0; w < W; ++w) {
+                            const uint32_t old = stw[w * 64], neu = old ^ m0[w] ^ m1[w] ^ m2[w] ^ m3[w];
+                            int ox = 0, oy = 0, oz = 0;
+                            count_xyz(old, ox, oy, oz);
+                            count_xyz(neu, dx, dy, dz);
+                            dx -= ox; dy -= oy; dz -= oz;
+                        }
+                    } else {
+                        const uint32_t wa = top ? x.y : x.x, wb = top ? x.z : x.y, wc = top ? x.w : x.z;
+                        if (CODE == kCodeToric) {
+                            uint32_t q[4];
+                            const uint32_t isX = wc >> 31;
+                            toric_sites(L, LL, scale_u32(wa, L), scale_u32(wb, L), isX, q);
+                            for (int i = 0; i < 4; ++i) ent[i] = (q[i] << 2) | (isX ? 1u : 3u);
+                        } else {
+                            const uint2 e = a.gen[surf_generator_index(L, wa, wb, wc, a.thr_half)];
+                            ent[0] = e.x & 0xFFFFu; ent[1] = e.x >> 16; ent[2] = e.y & 0xFFFFu; ent[3] = e.y >> 16;
+                        }
+                        for (int i = 0; i < 4; ++i) {
+                            const uint32_t q = ent[i] >> 2, f = (stw[(q >> 4) * 64] >> ((q & 15u) * 2u)) & 3u, g = f ^ (ent[i] & 3u);
+                            dx += (int)(g == 1u) - (int)(f == 1u);
+                            dy += (int)(g == 2u) - (int)(f == 2u);
+                            dz += (int)(g == 3u) - (int)(f == 3u);
+                        }
+                    }
+                    const int dE = dx + dy + dz;
+                    bool acc;
+                    if constexpr (BIASED) {
+                        const uint32_t xa = top ? philox_block(k, 2, syn, slot_u, a.seed_lo, a.seed_hi).x : x.w;
+                        const int mx = nx + dx, my = ny + dy, mz = nz + dz;
+                        const double pn = bt[mx] * bt[T1 + my] * bt[2 * T1 + mz] * bt[3 * T1 + (nq - mx - my - mz)];
+                        acc = (double)xa * (1.0 / 4294967296.0) < pn / pb;          // mcmc_biased.py:44-46
+                    } else if (top) {
+                        acc = acc_all || dE <= 0;                                   // mcmc.py:30
+                        if (!acc) acc = philox_block(k, 2, syn, slot_u, a.seed_lo, a.seed_hi).x < a.acc_tbl_top[dE];   // :34
+                    } else {
+                        acc = x.w <= myT[dE < -4 ? -4 : dE];                        // mcmc.py:42 (stabilizers only: |dE| <= 4)
+                    }
+                    if (acc) {
+                        if (logical) {
+                            for (int w = 0; w < W; ++w) lds_xor(stw + w * 64, m0[w] ^ m1[w] ^ m2[w] ^ m3[w]);
+                            cdelta ^= cd;
+                        } else {
+                            for (int i = 0; i < 4; ++i) lds_xor(stw + (ent[i] >> 6) * 64, (ent[i] & 3u) << (((ent[i] >> 2) & 15u) * 2u));
+                        }
+                        nx += dx; ny += dy; nz += dz;
+                    }
+                }
+                n = (uint32_t)(nx + ny + nz);
+                cls ^= cdelta;
+            }
+        } else
         if (!top_logical) {
             int ni = (int)n;
             auto propose = [&](const u32x4 &x) {
@@ -403,7 +566,8 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 tops0 += (NC == 1) | (car >> 31);                                   // chains[0].flag == 1, :101-102
                 const uint32_t n0 = car & 0xFFFFu;
                 if (a.counts != nullptr && tops0 >= a.tops_burn) {                  // decoders.py:60-67
-                    hist[((car >> 24) & 0x3Fu) * 64 + lane] += 1;
+                    const uint32_t v = (car >> 24) & 0x3Fu;
+                    hist[(CODE == kCodeXzzx ? (v ^ (v >> 1)) : v) * 64 + lane] += 1;
                     samples++;
                     if (CONV && lane < cnt) {
                         // nbr_errors_bottom_chain[since_burn] = count_errors (:68); series index i lives in log row burn+i
@@ -493,9 +657,20 @@ hipError_t launch_ladder_rs_toric(const LadderArgs &a, hipStream_t stream)
     block *= groups;
     lds *= groups;
     const void *fn;
-    if (groups == 2) fn = conv ? (const void *)ladder_rs_toric_kernel<1024, 8, true, 2> : (const void *)ladder_rs_toric_kernel<1024, 8, false, 2>;
-    else if (block <= 512) fn = conv ? (const void *)ladder_rs_toric_kernel<512, 8, true, 1> : (const void *)ladder_rs_toric_kernel<512, 8, false, 1>;
-    else fn = conv ? (const void *)ladder_rs_toric_kernel<1024, 4, true, 1> : (const void *)ladder_rs_toric_kernel<1024, 4, false, 1>;
+    constexpr int T = kCodeToric, X = kCodeXzzx, R = kCodeRotated;
+    if (a.code == T && !a.noise) {
+        if (groups == 2) fn = conv ? (const void *)ladder_rs_toric_kernel<1024, 8, true, 2, T, false> : (const void *)ladder_rs_toric_kernel<1024, 8, false, 2, T, false>;
+        else if (block <= 512) fn = conv ? (const void *)ladder_rs_toric_kernel<512, 8, true, 1, T, false> : (const void *)ladder_rs_toric_kernel<512, 8, false, 1, T, false>;
+        else fn = conv ? (const void *)ladder_rs_toric_kernel<1024, 4, true, 1, T, false> : (const void *)ladder_rs_toric_kernel<1024, 4, false, 1, T, false>;
+    } else {
+        // the other code / noise combinations run one group per workgroup (any Nc <= 16)
+        grid *= groups; block /= groups; lds /= groups;
+        if (a.code == X && !a.noise) fn = conv ? (const void *)ladder_rs_toric_kernel<1024, 4, true, 1, X, false> : (const void *)ladder_rs_toric_kernel<1024, 4, false, 1, X, false>;
+        else if (a.code == R && !a.noise) fn = conv ? (const void *)ladder_rs_toric_kernel<1024, 4, true, 1, R, false> : (const void *)ladder_rs_toric_kernel<1024, 4, false, 1, R, false>;
+        else if (a.code == X) fn = conv ? (const void *)ladder_rs_toric_kernel<1024, 4, true, 1, X, true> : (const void *)ladder_rs_toric_kernel<1024, 4, false, 1, X, true>;
+        else if (a.code == R) fn = conv ? (const void *)ladder_rs_toric_kernel<1024, 4, true, 1, R, true> : (const void *)ladder_rs_toric_kernel<1024, 4, false, 1, R, true>;
+        else return hipErrorInvalidValue;
+    }
     if (lds > 64 * 1024) {   // beyond the default dynamic-LDS window (160 KiB per CU on gfx950)
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;

@@ -18,24 +18,28 @@ __device__ __forceinline__ void copy_state(uint8_t *dst, const uint8_t *src, int
 }
 }  // namespace
 
-__global__ void k_apply_stabilizer(int L, uint64_t N, const uint8_t *in, uint8_t *out, const int32_t *rows,
+__device__ __forceinline__ int code_nq(int code, int L) { return code == kCodeToric ? 2 * L * L : L * L; }
+
+__global__ void k_apply_stabilizer(int code, int L, uint64_t N, const uint8_t *in, uint8_t *out, const int32_t *rows,
                                    const int32_t *cols, const int32_t *ops, int32_t *dE)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
-    const int nq = 2 * L * L;
+    const int nq = code_nq(code, L);
     copy_state(out + i * nq, in + i * nq, nq);
-    dE[i] = toric_apply_stabilizer_b(L, out + i * nq, rows[i], cols[i], ops[i]);
+    dE[i] = code == kCodeToric ? toric_apply_stabilizer_b(L, out + i * nq, rows[i], cols[i], ops[i])
+                               : surf_apply_stabilizer_b(code, L, out + i * nq, rows[i], cols[i], ops[i]);
 }
 
-__global__ void k_apply_logical(int L, uint64_t N, const uint8_t *in, uint8_t *out, const int32_t *ops,
+__global__ void k_apply_logical(int code, int L, uint64_t N, const uint8_t *in, uint8_t *out, const int32_t *ops,
                                 const int32_t *layers, const int32_t *xpos, const int32_t *zpos, int32_t *dE)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
-    const int nq = 2 * L * L;
+    const int nq = code_nq(code, L);
     copy_state(out + i * nq, in + i * nq, nq);
-    dE[i] = toric_apply_logical_b(L, out + i * nq, ops[i], layers[i], xpos[i], zpos[i]);
+    dE[i] = code == kCodeToric ? toric_apply_logical_b(L, out + i * nq, ops[i], layers[i], xpos[i], zpos[i])
+                               : surf_apply_logical_b(code, L, out + i * nq, ops[i], xpos[i], zpos[i]);
 }
 
 __global__ void k_count_errors(int nq, uint64_t N, const uint8_t *in, int64_t *n)
@@ -45,11 +49,12 @@ __global__ void k_count_errors(int nq, uint64_t N, const uint8_t *in, int64_t *n
     n[i] = count_errors_b(nq, in + i * nq);
 }
 
-__global__ void k_eq_class(int L, uint64_t N, const uint8_t *in, int32_t *cls)
+__global__ void k_eq_class(int code, int L, uint64_t N, const uint8_t *in, int32_t *cls)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
-    cls[i] = toric_eq_class_b(L, in + i * (uint64_t)(2 * L * L));
+    const uint8_t *m = in + i * (uint64_t)code_nq(code, L);
+    cls[i] = code == kCodeToric ? toric_eq_class_b(L, m) : surf_eq_class_b(code, L, m);
 }
 
 __global__ void k_to_class(int L, uint64_t N, const uint8_t *in, uint8_t *out, const int32_t *eq)
@@ -61,56 +66,95 @@ __global__ void k_to_class(int L, uint64_t N, const uint8_t *in, uint8_t *out, c
     toric_to_class_b(L, out + i * nq, eq[i]);
 }
 
-__global__ void k_syndrome(int L, uint64_t N, const uint8_t *in, uint8_t *defects)
+__global__ void k_syndrome(int code, int L, uint64_t N, const uint8_t *in, uint8_t *defects)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
-    const int nq = 2 * L * L;
-    toric_syndrome_b(L, in + i * nq, defects + i * nq);
+    if (code == kCodeToric) toric_syndrome_b(L, in + i * (uint64_t)(2 * L * L), defects + i * (uint64_t)(2 * L * L));
+    else surf_syndrome_b(code, L, in + i * (uint64_t)(L * L), defects + i * (uint64_t)((L + 1) * (L + 1)));
 }
 
-// Chain.update_chain(iters), src/mcmc.py:19-43, one thread per chain, state in HBM.
-// Draw addressing is the oracle's (DESIGN.md "RNG addressing").
+// x.w of a surf-code proposal block: rows / cols from the halves of word a, rows2 / cols2 from word b
+__device__ __forceinline__ void surf_pick(int L, uint32_t wa, uint32_t wb, uint32_t wsel, uint64_t thr_half, int &row, int &col, int &op)
+{
+    if ((uint64_t)wsel > thr_half) {                 // `u > phalf`: full plaquette (xzzx_model.py:446-449)
+        row = (int)(((wa >> 16) * (uint32_t)(L - 1)) >> 16);
+        col = (int)(((wa & 0xFFFFu) * (uint32_t)(L - 1)) >> 16);
+        op = 1;
+    } else {                                         // half plaquette: rows2 = int(((L-1)/2) u), cols2 = int(4 u)
+        row = (int)(((wb >> 16) * (uint32_t)(L - 1)) >> 17);
+        col = (int)((wb >> 14) & 3u);
+        op = 3;
+    }
+}
+
+// p_x^nx p_y^ny p_z^nz p_I^nI from the host-built power tables (mcmc_biased.py:31,43): IEEE products in the
+// reference's left-to-right order, so the value is bit-identical to the CPU's
+__device__ __forceinline__ double biased_weight_b(const double *tbl, int nq, const uint8_t *m)
+{
+    int nx = 0, ny = 0, nz = 0;
+    for (int i = 0; i < nq; ++i) { nx += m[i] == 1; ny += m[i] == 2; nz += m[i] == 3; }
+    const int T = nq + 1;
+    return tbl[nx] * tbl[T + ny] * tbl[2 * T + nz] * tbl[3 * T + (nq - nx - ny - nz)];
+}
+
+// Chain.update_chain(iters), src/mcmc.py:19-43, and Chain_biased.update_chain, src/mcmc_biased.py:20-59,
+// one thread per chain, state in HBM.  Draw addressing is the oracle's (DESIGN.md "RNG addressing").
 __global__ void k_chain_update(const ChainArgs a)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.N) return;
-    const int L = a.L, nq = 2 * L * L;
+    const int L = a.L, code = a.code, nq = code_nq(code, L);
     uint8_t *m = a.states + i * nq;
     const uint32_t syn = a.first_syndrome + (uint32_t)i;
     auto thr = [&](int dE) { return a.acc_tbl[dE]; };       // ceil(f^dE * 2^32), dE in [1, nq]
+    const bool top = a.thr_logical != 0;
+    const double pb = a.noise ? biased_weight_b(a.bias_tbl, nq, m) : 0.0;       // mcmc_biased.py:28-31 (never refreshed: Q3)
     for (uint64_t j = 0; j < a.iters; ++j) {
         const uint64_t k = a.k0 + j;
         const u32x4 x = philox_block(k, 0, syn, a.slot, a.seed_lo, a.seed_hi);
-        if (a.thr_logical == 0) {                                  // mcmc.py:37-43
-            const int row = scale_u32(x.x, L), col = scale_u32(x.y, L), op = (x.z >> 31) ? 1 : 3;
-            const int dE = toric_apply_stabilizer_b(L, m, row, col, op);
-            const bool acc = dE <= 0 || a.acc_all || x.w < thr(dE);
-            if (!acc) toric_apply_stabilizer_b(L, m, row, col, op);   // undo (XOR is an involution)
-        } else {                                                    // mcmc.py:20-35
-            int dE;
-            int row = 0, col = 0, op = 0, op0 = 0, op1 = 0, x0 = 0, z0 = 0, x1 = 0, z1 = 0;
-            const bool logical = (uint64_t)x.x < a.thr_logical;
-            if (logical) {
-                op0 = x.y >> 30; op1 = x.z >> 30;                       // toric_model.py:234
-                if (op0 == 1 || op0 == 2) x0 = scale_low30(x.y, L);     // :241-248 (positions share block (k,0))
+        // ---- propose (in place; XOR moves are involutions, so a rejected move is undone by re-applying it)
+        int dE, row = 0, col = 0, op = 0, op0 = 0, op1 = 0, x0 = 0, z0 = 0, x1 = 0, z1 = 0;
+        const bool logical = top && (uint64_t)x.x < a.thr_logical;                 // mcmc.py:23
+        if (logical) {
+            if (code == kCodeToric) {
+                op0 = x.y >> 30; op1 = x.z >> 30;                                   // toric_model.py:234
+                if (op0 == 1 || op0 == 2) x0 = scale_low30(x.y, L);                 // :241-248 (positions share block (k,0))
                 if (op0 == 3 || op0 == 2) z0 = scale_u16(x.w >> 16, L);
                 if (op1 == 1 || op1 == 2) x1 = scale_low30(x.z, L);
                 if (op1 == 3 || op1 == 2) z1 = scale_u16(x.w & 0xFFFFu, L);
                 dE = toric_apply_logical_b(L, m, op0, 0, x0, z0) + toric_apply_logical_b(L, m, op1, 1, x1, z1);
             } else {
-                row = scale_u32(x.y, L); col = scale_u32(x.z, L); op = (x.w >> 31) ? 1 : 3;
-                dE = toric_apply_stabilizer_b(L, m, row, col, op);
+                op0 = x.y >> 30;                                                    // xzzx_model.py:346-355
+                if (op0 == 1 || op0 == 2) x0 = scale_low30(x.y, L);
+                if (op0 == 3 || op0 == 2) z0 = scale_u16(x.w >> 16, L);
+                dE = surf_apply_logical_b(code, L, m, op0, x0, z0);
             }
-            bool acc = a.acc_all || dE <= 0;                         // mcmc.py:30
-            if (!acc) {
-                const u32x4 c = philox_block(k, 2, syn, a.slot, a.seed_lo, a.seed_hi);
-                acc = c.x < thr(dE);                                 // mcmc.py:34
-            }
-            if (!acc) {
-                if (logical) { toric_apply_logical_b(L, m, op1, 1, x1, z1); toric_apply_logical_b(L, m, op0, 0, x0, z0); }
-                else toric_apply_stabilizer_b(L, m, row, col, op);
-            }
+        } else if (code == kCodeToric) {
+            const uint32_t wr = top ? x.y : x.x, wc = top ? x.z : x.y, wo = top ? x.w : x.z;
+            row = scale_u32(wr, L); col = scale_u32(wc, L); op = (wo >> 31) ? 1 : 3;
+            dE = toric_apply_stabilizer_b(L, m, row, col, op);
+        } else {
+            surf_pick(L, top ? x.y : x.x, top ? x.z : x.y, top ? x.w : x.z, a.thr_half, row, col, op);
+            dE = surf_apply_stabilizer_b(code, L, m, row, col, op);
+        }
+        // ---- accept?
+        bool acc;
+        if (a.noise) {                                                              // mcmc_biased.py:40-46 / :53-59
+            const uint32_t xa = top ? philox_block(k, 2, syn, a.slot, a.seed_lo, a.seed_hi).x : x.w;
+            acc = (double)xa * (1.0 / 4294967296.0) < biased_weight_b(a.bias_tbl, nq, m) / pb;
+        } else if (top) {                                                           // mcmc.py:30-34
+            acc = a.acc_all || dE <= 0;
+            if (!acc) acc = philox_block(k, 2, syn, a.slot, a.seed_lo, a.seed_hi).x < thr(dE);
+        } else {
+            acc = dE <= 0 || a.acc_all || x.w < thr(dE);                            // mcmc.py:42
+        }
+        if (!acc) {
+            if (logical) {
+                if (code == kCodeToric) { toric_apply_logical_b(L, m, op1, 1, x1, z1); toric_apply_logical_b(L, m, op0, 0, x0, z0); }
+                else surf_apply_logical_b(code, L, m, op0, x0, z0);
+            } else if (code == kCodeToric) toric_apply_stabilizer_b(L, m, row, col, op);
+            else surf_apply_stabilizer_b(code, L, m, row, col, op);
         }
     }
 }
@@ -122,32 +166,32 @@ __global__ void k_chain_update(const ChainArgs a)
         return hipGetLastError();                                                        \
     } while (0)
 
-hipError_t launch_apply_stabilizer(int L, uint64_t N, const uint8_t *in, uint8_t *out, const int32_t *rows,
+hipError_t launch_apply_stabilizer(int code, int L, uint64_t N, const uint8_t *in, uint8_t *out, const int32_t *rows,
                                    const int32_t *cols, const int32_t *ops, int32_t *dE, hipStream_t s)
 {
-    QECMC_LAUNCH(k_apply_stabilizer, N, s, L, N, in, out, rows, cols, ops, dE);
+    QECMC_LAUNCH(k_apply_stabilizer, N, s, code, L, N, in, out, rows, cols, ops, dE);
 }
-hipError_t launch_apply_logical(int L, uint64_t N, const uint8_t *in, uint8_t *out, const int32_t *ops,
+hipError_t launch_apply_logical(int code, int L, uint64_t N, const uint8_t *in, uint8_t *out, const int32_t *ops,
                                 const int32_t *layers, const int32_t *xpos, const int32_t *zpos, int32_t *dE,
                                 hipStream_t s)
 {
-    QECMC_LAUNCH(k_apply_logical, N, s, L, N, in, out, ops, layers, xpos, zpos, dE);
+    QECMC_LAUNCH(k_apply_logical, N, s, code, L, N, in, out, ops, layers, xpos, zpos, dE);
 }
 hipError_t launch_count_errors(int nq, uint64_t N, const uint8_t *in, int64_t *n, hipStream_t s)
 {
     QECMC_LAUNCH(k_count_errors, N, s, nq, N, in, n);
 }
-hipError_t launch_eq_class(int L, uint64_t N, const uint8_t *in, int32_t *cls, hipStream_t s)
+hipError_t launch_eq_class(int code, int L, uint64_t N, const uint8_t *in, int32_t *cls, hipStream_t s)
 {
-    QECMC_LAUNCH(k_eq_class, N, s, L, N, in, cls);
+    QECMC_LAUNCH(k_eq_class, N, s, code, L, N, in, cls);
 }
 hipError_t launch_to_class(int L, uint64_t N, const uint8_t *in, uint8_t *out, const int32_t *eq, hipStream_t s)
 {
     QECMC_LAUNCH(k_to_class, N, s, L, N, in, out, eq);
 }
-hipError_t launch_syndrome(int L, uint64_t N, const uint8_t *in, uint8_t *defects, hipStream_t s)
+hipError_t launch_syndrome(int code, int L, uint64_t N, const uint8_t *in, uint8_t *defects, hipStream_t s)
 {
-    QECMC_LAUNCH(k_syndrome, N, s, L, N, in, defects);
+    QECMC_LAUNCH(k_syndrome, N, s, code, L, N, in, defects);
 }
 hipError_t launch_chain_update(const ChainArgs &a, hipStream_t s)
 {

@@ -93,3 +93,110 @@ __device__ inline void toric_syndrome_b(int L, const uint8_t *m, uint8_t *d)
 }
 
 }  // namespace qecmc
+
+// ---------------------------------------------------------------------------------------------
+// XZZX code (src/xzzx_model.py) and rotated surface code (src/rotated_surface_model.py): L x L
+// qubits, (L-1)^2 four-qubit plaquettes + 2(L-1) two-qubit boundary half-plaquettes.
+// ---------------------------------------------------------------------------------------------
+namespace qecmc {
+
+constexpr int kCodeToric = 0, kCodeXzzx = 1, kCodeRotated = 2;
+
+// generator (row, col, operator) -> up to 4 (flat site, Pauli) pairs; operator 1 = full plaquette,
+// 3 = half plaquette `row` on side `col` (xzzx_model.py:369-434, rotated_surface_model.py:357-381)
+__host__ __device__ inline int surf_generator(int code, int L, int row, int col, int op, int sites[4], int paulis[4])
+{
+    if (op == 1) {
+        if (code == kCodeXzzx) {
+            sites[0] = row * L + col;           paulis[0] = 1;
+            sites[1] = (row + 1) * L + col;     paulis[1] = 3;
+            sites[2] = row * L + col + 1;       paulis[2] = 3;
+            sites[3] = (row + 1) * L + col + 1; paulis[3] = 1;
+        } else {
+            const int p = (row % 2 == col % 2) ? 1 : 3;
+            sites[0] = row * L + col;       sites[1] = row * L + col + 1;
+            sites[2] = (row + 1) * L + col; sites[3] = (row + 1) * L + col + 1;
+            paulis[0] = paulis[1] = paulis[2] = paulis[3] = p;
+        }
+        return 4;
+    }
+    switch (col) {
+        case 0: sites[0] = 2 * row + 1;               sites[1] = 2 * row + 2; break;
+        case 1: sites[0] = (2 * row + 1) * L + L - 1; sites[1] = (2 * row + 2) * L + L - 1; break;
+        case 2: sites[0] = (L - 1) * L + 2 * row;     sites[1] = (L - 1) * L + 2 * row + 1; break;
+        default: sites[0] = (2 * row) * L;            sites[1] = (2 * row + 1) * L; break;
+    }
+    if (code == kCodeXzzx) {
+        paulis[0] = (col == 0 || col == 3) ? 3 : 1;
+        paulis[1] = (col == 0 || col == 3) ? 1 : 3;
+    } else {
+        paulis[0] = paulis[1] = (col == 0 || col == 2) ? 1 : 3;
+    }
+    return 2;
+}
+
+__device__ inline int surf_apply_stabilizer_b(int code, int L, uint8_t *m, int row, int col, int op)
+{
+    int sites[4], paulis[4], dE = 0;
+    const int n = surf_generator(code, L, row, col, op, sites, paulis);
+    for (int i = 0; i < n; ++i) dE += flip_b(&m[sites[i]], paulis[i]);
+    return dE;
+}
+
+// _apply_logical: xzzx_model.py:279-313 (anti-diagonal X, diagonal Z, positions ignored);
+// rotated_surface_model.py:251-282 (X on column X_pos iff op in {1,3}, Z on row Z_pos iff op in {2,3})
+__device__ inline int surf_apply_logical_b(int code, int L, uint8_t *m, int op, int xpos, int zpos)
+{
+    if (op == 0) return 0;
+    int dE = 0;
+    if (code == kCodeXzzx) {
+        if (op == 1 || op == 2) for (int i = 0; i < L; ++i) dE += flip_b(&m[i * L + (L - 1 - i)], 1);
+        if (op == 3 || op == 2) for (int i = 0; i < L; ++i) dE += flip_b(&m[i * L + i], 3);
+    } else {
+        if (op == 1 || op == 3) for (int i = 0; i < L; ++i) dE += flip_b(&m[i * L + xpos], 1);
+        if (op == 2 || op == 3) for (int i = 0; i < L; ++i) dE += flip_b(&m[zpos * L + i], 3);
+    }
+    return dE;
+}
+
+// _define_equivalence_class: xzzx_model.py:455-486, rotated_surface_model.py:411-420
+__device__ inline int surf_eq_class_b(int code, int L, const uint8_t *m)
+{
+    int x = 0, z = 0;
+    if (code == kCodeXzzx) {
+        for (int i = 0; i < L; ++i) {
+            const int a = m[i], b = m[i * L];
+            x ^= (a == 2) ^ ((i & 1) ? (a == 3) : (a == 1));
+            z ^= (b == 2) ^ ((i & 1) ? (b == 1) : (b == 3));
+        }
+        return x ? (z ? 2 : 1) : (z ? 3 : 0);
+    }
+    for (int i = 0; i < L; ++i) {
+        x ^= (m[i] == 1) | (m[i] == 2);
+        z ^= (m[i * L] == 3) | (m[i * L] == 2);
+    }
+    return x + 2 * z;
+}
+
+// xzzx_code.syndrome / RotSurCode.syndrome: d = uint8[L+1][L+1]
+__device__ inline void surf_syndrome_b(int code, int L, const uint8_t *m, uint8_t *d)
+{
+    const int S = L + 1;
+    for (int i = 0; i < S * S; ++i) d[i] = 0;
+    auto defect = [&](int row, int col, int op) {
+        int sites[4], paulis[4], v = 0;
+        const int n = surf_generator(code, L, row, col, op, sites, paulis);
+        for (int i = 0; i < n; ++i) v ^= (m[sites[i]] != 0 && m[sites[i]] != paulis[i]);
+        return (uint8_t)v;
+    };
+    for (int i = 0; i < L - 1; ++i)
+        for (int j = 0; j < L - 1; ++j) d[(i + 1) * S + j + 1] = defect(i, j, 1);
+    for (int i = 0; i < (L - 1) / 2; ++i) {
+        d[2 * i + 2] = defect(i, 0, 3);
+        d[(2 * i + 2) * S + L] = defect(i, 1, 3);
+        d[L * S + 2 * i + 1] = defect(i, 2, 3);
+        d[(2 * i + 1) * S] = defect(i, 3, 3);
+    }
+}
+
+}  // namespace qecmc

@@ -1,9 +1,14 @@
 """qecmc -- MI355X-native MCMC equivalence-class sampler (host-side mirror of the
 reference's Toric_code / Chain / Ladder / PTEQ API over the libqecmc C-ABI)."""
 from ._lib import QecmcError, device_count, lib
+from ._lib import TORIC, XZZX, ROTATED
 from .toric_model import Toric_code
+from .xzzx_model import xzzx_code
+from .rotated_surface_model import RotSurCode
 from .mcmc import Chain, Ladder
+from .mcmc_biased import Chain_biased, Ladder_biased
 from .decoders import PTEQ, pteq_batch, percent_from_counts
+from .decoders_biasednoise import PTEQ_biased
 
-__all__ = ["QecmcError", "device_count", "lib", "Toric_code", "Chain", "Ladder", "PTEQ", "pteq_batch",
-           "percent_from_counts"]
+__all__ = ["QecmcError", "device_count", "lib", "TORIC", "XZZX", "ROTATED", "Toric_code", "xzzx_code", "RotSurCode",
+           "Chain", "Ladder", "Chain_biased", "Ladder_biased", "PTEQ", "PTEQ_biased", "pteq_batch", "percent_from_counts"]

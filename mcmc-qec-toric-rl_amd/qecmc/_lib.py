@@ -55,6 +55,8 @@ SIGNATURES = {
     "qecmc_syndrome": (C.c_int, [C.c_int, C.c_int, C.c_uint64, _u8p, _u8p]),
     "qecmc_chain_update": (C.c_int, [C.c_int, C.c_int, C.c_uint64, _u8p, C.c_double, C.c_double, C.c_uint64,
                                      C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64]),
+    "qecmc_chain_update_biased": (C.c_int, [C.c_int, C.c_int, C.c_uint64, _u8p, C.c_double, C.c_double, C.c_double,
+                                            C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64]),
     "qecmc_ladder_step": (C.c_int, [C.POINTER(Params), C.c_uint64, _u8p, _u8p, _u32p, C.c_uint64, C.c_uint64,
                                     C.c_uint64, C.c_uint64]),
     "qecmc_pteq_batch": (C.c_int, [C.POINTER(Params), _u8p, C.c_uint64, _u32p, _u32p, _u32p, _u32p, _u8p, _u8p,

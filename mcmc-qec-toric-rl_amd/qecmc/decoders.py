@@ -15,29 +15,33 @@ def percent_from_counts(counts, samples):
 
 
 def pteq_batch(init, p, Nc=None, steps=1000, iters=10, tops_burn=2, p_logical=0.5, seed=0, first_syndrome=0,
-               device=0, return_states=False, return_stats=False, conv_criteria=None, SEQ=2, TOPS=10, eps=0.1):
+               device=0, return_states=False, return_stats=False, conv_criteria=None, SEQ=2, TOPS=10, eps=0.1,
+               code=L_.TORIC, eta=None):
     """decoders.PTEQ (decoders.py:25-89) on N syndromes at once.
 
-    init: uint8[N, 2, L, L] seed configurations (one per syndrome).  conv_criteria None runs exactly
+    init: uint8[N, 2, L, L] (toric) or uint8[N, L, L] (code=XZZX / ROTATED) seed configurations, one per
+    syndrome; eta selects the biased chain of src/mcmc_biased.py (PTEQ_biased).  conv_criteria None runs exactly
     `steps` ladder steps; 'error_based' stops each syndrome by the reference's criterion (:74-105).
     Returns dict(counts uint32[N,16], samples uint32[N], tops0 uint32[N], steps_done uint32[N],
     converged bool[N], percent uint8[N,16] [, states uint8[N,Nc,2,L,L]] [, stats]).
     """
     if conv_criteria not in (None, 'error_based'):
         raise ValueError(f"conv_criteria={conv_criteria!r}: only None and 'error_based' exist for PTEQ")
-    a, _ = L_.as_states(init, 3)
-    N, size = a.shape[0], a.shape[2]
+    a, _ = L_.as_states(init, 3 if code == L_.TORIC else 2)
+    N, size = a.shape[0], a.shape[-1]
     Nc = Nc or size
-    pr = L_.make_params(code=L_.TORIC, L=size, Nc=Nc, p=float(p), p_logical=float(p_logical), iters=int(iters),
+    ncls = 16 if code == L_.TORIC else 4
+    pr = L_.make_params(code=code, L=size, Nc=Nc, p=float(p), p_logical=float(p_logical), iters=int(iters),
                         steps=int(steps), tops_burn=int(tops_burn), TOPS=int(TOPS), SEQ=int(SEQ), eps=float(eps),
                         seed=seed, first_syndrome=first_syndrome, device=device,
-                        conv_mode=L_.CONV_ERROR_BASED if conv_criteria else L_.CONV_NONE)
-    counts = np.zeros((N, 16), dtype=np.uint32)
+                        conv_mode=L_.CONV_ERROR_BASED if conv_criteria else L_.CONV_NONE,
+                        noise=L_.NOISE_DEPOLARIZING if eta is None else L_.NOISE_BIASED, eta=0.0 if eta is None else float(eta))
+    counts = np.zeros((N, ncls), dtype=np.uint32)
     samples = np.zeros(N, dtype=np.uint32)
     tops0 = np.zeros(N, dtype=np.uint32)
     steps_done = np.zeros(N, dtype=np.uint32)
     converged = np.zeros(N, dtype=np.uint8)
-    states = np.empty((N, Nc, 2, size, size), dtype=np.uint8) if return_states else None
+    states = np.empty((N, Nc) + a.shape[1:], dtype=np.uint8) if return_states else None
     stats = L_.Stats()
     L_.check(L_.lib().qecmc_pteq_batch(pr, L_.u8(a), N, L_.u32(counts), L_.u32(samples), L_.u32(tops0),
                                        L_.u32(steps_done), L_.u8(converged),
@@ -59,11 +63,15 @@ def PTEQ(init_code, p, Nc=None, SEQ=2, TOPS=10, tops_burn=2, eps=0.1, steps=5000
     ladder steps, x4 until it converges or `steps` is reached) so that the default `steps = 5e7` never allocates
     a 5e7-entry error-count log up front.  Philox is counter-based, so a longer horizon replays the same
     trajectory: the answer equals that of a single run with the full `steps`."""
+    return _pteq(init_code, p, None, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, conv_criteria, seed)
+
+
+def _pteq(init_code, p, eta, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, conv_criteria, seed):
     if tops_burn >= TOPS:
         print('tops_burn has to be smaller than TOPS')
-    _code_id(init_code)
     seed = _fresh_seed() if seed is None else seed
-    kw = dict(Nc=Nc or init_code.system_size, iters=iters, tops_burn=tops_burn, p_logical=0.5, seed=seed)
+    kw = dict(Nc=Nc or init_code.system_size, iters=iters, tops_burn=tops_burn, p_logical=0.5, seed=seed,
+              code=_code_id(init_code), eta=eta)
     if conv_criteria is None:
         return pteq_batch(init_code.qubit_matrix, p, steps=steps, **kw)["percent"][0]
     horizon = min(int(steps), 1 << 16)

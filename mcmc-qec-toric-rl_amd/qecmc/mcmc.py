@@ -22,12 +22,15 @@ def _fresh_seed():
 
 def _code_id(code):
     name = type(code).__name__
-    if name == "Toric_code":
-        return L_.TORIC
-    raise NotImplementedError(f"no GPU kernels for code model {name} in this build")
+    ids = {"Toric_code": L_.TORIC, "xzzx_code": L_.XZZX, "RotSurCode": L_.ROTATED}
+    if name not in ids:
+        raise NotImplementedError(f"no GPU kernels for code model {name} in this build")
+    return ids[name]
 
 
 class Chain:
+    _eta = None           # Chain_biased sets the bias
+
     def __init__(self, p, code, seed=None, stream=0):
         self.code = code
         self.p = p
@@ -43,9 +46,14 @@ class Chain:
         """`iters` Metropolis proposals (src/mcmc.py:19-43) in one kernel launch."""
         m, _ = L_.as_states(self.code.qubit_matrix, self.code.qubit_matrix.ndim)
         m = m.copy()
-        L_.check(L_.lib().qecmc_chain_update(_code_id(self.code), self.code.system_size, 1, L_.u8(m), float(self.p),
-                                             float(self.p_logical), int(iters), self.seed, self.stream, self.slot,
-                                             self.proposals_done))
+        if self._eta is None:
+            L_.check(L_.lib().qecmc_chain_update(_code_id(self.code), self.code.system_size, 1, L_.u8(m), float(self.p),
+                                                 float(self.p_logical), int(iters), self.seed, self.stream, self.slot,
+                                                 self.proposals_done))
+        else:
+            L_.check(L_.lib().qecmc_chain_update_biased(_code_id(self.code), self.code.system_size, 1, L_.u8(m),
+                                                        float(self.p), float(self._eta), float(self.p_logical), int(iters),
+                                                        self.seed, self.stream, self.slot, self.proposals_done))
         self.proposals_done += int(iters)
         self.code.qubit_matrix = m[0]
 
@@ -56,18 +64,21 @@ class Chain:
 
 
 class Ladder:
+    _eta = None           # Ladder_biased sets the bias
+    _chain_cls = None
+
     def __init__(self, p_bottom, init_code, Nc, p_logical=0, seed=None, stream=0):
         self.p_bottom = p_bottom
         self.init_code = init_code
         self.Nc = Nc
         self.p_logical = p_logical
-        p_top = 0.75
+        p_top = 0.75 if self._eta is None else (self._eta + 1) / (2 * self._eta + 1)
         p_ladder = np.linspace(p_bottom, p_top, Nc)
         self.p_ladder = p_ladder
         self.p_diff = (p_ladder[:-1] * (1 - p_ladder[1:])) / (p_ladder[1:] * (1 - p_ladder[:-1]))
         self.seed = _fresh_seed() if seed is None else seed
         self.stream = stream
-        self.chains = [Chain(p, copy.deepcopy(init_code), seed=self.seed, stream=stream) for p in p_ladder]
+        self.chains = [self._make_chain(p, copy.deepcopy(init_code), stream) for p in p_ladder]
         for slot, ch in enumerate(self.chains):
             ch.slot = slot
         self.chains[-1].flag = 1
@@ -76,11 +87,15 @@ class Ladder:
         self.steps_done = 0
         self.proposals_done = 0
 
+    def _make_chain(self, p, code, stream):
+        return Chain(p, code, seed=self.seed, stream=stream)
+
     def _params(self, iters):
         code = self.chains[0].code
         return L_.make_params(code=_code_id(code), L=code.system_size, Nc=self.Nc, p=float(self.p_bottom),
                               p_logical=float(self.p_logical), iters=int(iters), seed=self.seed,
-                              first_syndrome=self.stream)
+                              first_syndrome=self.stream, noise=L_.NOISE_DEPOLARIZING if self._eta is None else L_.NOISE_BIASED,
+                              eta=0.0 if self._eta is None else float(self._eta))
 
     def update_ladder(self, iters):
         for ch in self.chains:

@@ -46,7 +46,9 @@ def test_params_struct_matches_the_c_layout():
 
 
 @pytest.mark.parametrize("kw,frag", [(dict(L=1), b"L=1"), (dict(L=5, Nc=17), b"Nc=17"), (dict(L=5, Nc=3, p=0.9), b"p=0.9"),
-                                     (dict(L=5, Nc=3, code=1), b"code 1"), (dict(L=5, Nc=3, iters=0), b"iters"),
+                                     (dict(L=5, Nc=3, code=5), b"code 5"), (dict(L=4, Nc=3, code=1), b"odd L"),
+                                     (dict(L=5, Nc=3, noise=1, eta=10.0), b"biased noise is built for"),
+                                     (dict(L=5, Nc=3, code=1, noise=1, eta=0.0), b"eta"), (dict(L=5, Nc=3, iters=0), b"iters"),
                                      (dict(L=5, Nc=3, scan=1), b"scan"), (dict(L=5, Nc=3, p_logical=1.5), b"p_logical")])
 def test_argument_validation_precedes_everything(kw, frag):
     base = dict(L=5, Nc=5, p=0.1, p_logical=0.5, steps=10)
