@@ -52,12 +52,24 @@ def synth_batch(N, L, p, seed):
     return m
 
 
+def synth_batch_plaquette(N, L, px, py, pz, seed):
+    """xzzx_code / RotSurCode.generate_random_error(p_x, p_y, p_z) (xzzx_model.py:16-30), vectorised;
+    no logical is applied on top (the class of a raw error chain is what generate_data.py:121-122 records)."""
+    rng = np.random.default_rng(seed)
+    r = rng.random((N, L, L))
+    m = np.zeros((N, L, L), dtype=np.uint8)
+    m[r < pz] = 3
+    m[(r > pz) & (r < pz + px)] = 1
+    m[(r > pz + px) & (r < pz + px + py)] = 2
+    return m
+
+
 def measured_hbm_traffic(args):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN_pmc_summary.json:
     FETCH_SIZE and WRITE_SIZE collected in separate passes around this same default bench command),
     or None when the workload differs from the profiled one."""
     import glob
-    if (args.syndromes, args.L, args.Nc, args.iters, args.ladder_steps, args.p_logical) != (65536, 9, 8, 10, 2000, 0.5):
+    if (args.code, args.syndromes, args.L, args.Nc, args.iters, args.ladder_steps, args.p_logical) != ("toric", 65536, 9, 8, 10, 2000, 0.5):
         return None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
     if not files:
@@ -103,6 +115,8 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--seed", type=int, default=20200915)
     ap.add_argument("--p-logical", type=float, default=0.5, help="top-chain logical rate (decoders.py:52 uses 0.5)")
+    ap.add_argument("--code", default="toric", choices=["toric", "xzzx", "rotated"], help="other codes: parity-test configs 4, 5")
+    ap.add_argument("--eta", type=float, default=None, help="bias: selects the mcmc_biased chain (config 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -122,17 +136,26 @@ def main():
         dist.init_process_group("nccl", device_id=dev)   # RCCL
 
     N, L, Nc = args.syndromes, args.L, args.Nc
-    nq, ncls = 2 * L * L, 16
+    toric = args.code == "toric"
+    code_id = {"toric": L_.TORIC, "xzzx": L_.XZZX, "rotated": L_.ROTATED}[args.code]
+    nq, ncls = (2 * L * L, 16) if toric else (L * L, 4)
     first = rank * N                                    # global syndrome index of this shard
-    init_h = synth_batch(N, L, args.p, args.seed + rank)
+    if toric:
+        init_h = synth_batch(N, L, args.p, args.seed + rank)
+    elif args.eta is None:
+        init_h = synth_batch_plaquette(N, L, args.p / 3, args.p / 3, args.p / 3, args.seed + rank)
+    else:
+        init_h = synth_batch_plaquette(N, L, args.p / (2 * (args.eta + 1)), args.p / (2 * (args.eta + 1)),
+                                       args.p * args.eta / (args.eta + 1), args.seed + rank)
     d_init = torch.from_numpy(init_h.reshape(N, nq)).to(dev)
     d_counts = torch.zeros((N, ncls), dtype=torch.int32, device=dev)
     d_samples = torch.zeros(N, dtype=torch.int32, device=dev)
     d_tops0 = torch.zeros(N, dtype=torch.int32, device=dev)
     gathered = [torch.zeros_like(d_counts) for _ in range(world)] if (world > 1 and rank == 0) else None
 
-    pr = L_.make_params(code=L_.TORIC, L=L, Nc=Nc, p=args.p, p_logical=args.p_logical, iters=args.iters,
-                        steps=args.ladder_steps, tops_burn=2, seed=args.seed, device=local_rank)
+    pr = L_.make_params(code=code_id, L=L, Nc=Nc, p=args.p, p_logical=args.p_logical, iters=args.iters,
+                        steps=args.ladder_steps, tops_burn=2, seed=args.seed, device=local_rank,
+                        noise=L_.NOISE_DEPOLARIZING if args.eta is None else L_.NOISE_BIASED, eta=args.eta or 0.0)
     plan = C.c_void_p()
     L_.check(L_.lib().qecmc_plan_create(pr, C.byref(plan)))
     lds, threads, spb = C.c_uint32(), C.c_uint32(), C.c_uint32()
@@ -189,9 +212,10 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "configs[1]: toric L=%d p=%g, %d syndromes per GPU, Nc=%d parallel tempering, "
+            "config": {"workload": "%s: %s L=%d p=%g%s, %d syndromes per GPU, Nc=%d parallel tempering, "
                                    "iters=%d, %d ladder steps per pass, scan=random (reference chain)"
-                                   % (L, args.p, N, Nc, args.iters, args.ladder_steps),
+                                   % ("configs[1]" if (toric and L == 9) else "parity-test configuration", args.code, L, args.p,
+                                      "" if args.eta is None else " eta=%g" % args.eta, N, Nc, args.iters, args.ladder_steps),
                        "syndromes_per_gpu": N, "L": L, "p": args.p, "Nc": Nc, "iters": args.iters,
                        "ladder_steps": args.ladder_steps, "tops_burn": 2, "seed": args.seed,
                        "lds_bytes_per_workgroup": lds.value, "threads_per_workgroup": threads.value,
@@ -209,7 +233,7 @@ def main():
             "mixing": {"frac_syndromes_past_burn_in": float(np.mean(samples > 0)),
                        "mean_tops0": float(np.mean(tops0))},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and toric:
             out["cpu_baseline"] = cpu_baseline(init_h, args.p, Nc, args.iters, args.seed)
         print(json.dumps(out))
     L_.lib().qecmc_plan_destroy(plan)

@@ -1,0 +1,86 @@
+"""Batched counterpart of the reference's data-generation harness (`generate_data.generate`,
+generate_data.py:20-269).
+
+The reference makes one random error, hides its class with a random logical operator, decodes it
+with one `PTEQ` call and appends (qubit_matrix, distribution) to a pandas pickle, one syndrome at a
+time.  Here the seed configurations of a whole batch are drawn on the host (NumPy, the recipe of
+toric_model.py:15-24 / xzzx_model.py:16-30 and generate_data.py:121-131), decoded in ONE batched
+GPU call, and returned / saved as plain arrays (npz instead of the MultiIndex pickle).
+"""
+import numpy as np
+
+from . import _lib as L_
+from .decoders import pteq_batch
+
+_CODES = {"toric": L_.TORIC, "xzzx": L_.XZZX, "rotated": L_.ROTATED}
+
+
+def _class_of(code, m):
+    from . import _surf, toric_model
+    return toric_model.eq_class(m) if code == L_.TORIC else _surf.eq_class(code, m)
+
+
+def draw_errors(code, size, n, p_error, rng, eta=None):
+    """n random error chains: toric -- each qubit errs w.p. p_error, Pauli uniform (toric_model.py:15-23);
+    xzzx / rotated -- one uniform per qubit against (p_z, p_x, p_y) (xzzx_model.py:16-30), with
+    p_x = p_y = p_z = p/3 (generate_data.py:116-118) or the Z-biased split p_z = p eta/(eta+1),
+    p_x = p_y = p/(2(eta+1)) (generate_data.py:78-83)."""
+    code = _CODES.get(code, code)
+    if code == L_.TORIC:
+        m = np.zeros((n, 2, size, size), dtype=np.uint8)
+        err = rng.random(m.shape) < p_error
+        m[err] = rng.integers(1, 4, size=int(err.sum()), dtype=np.uint8)
+        return m
+    if eta is None:
+        px = py = pz = p_error / 3
+    else:
+        pz, px = p_error * eta / (eta + 1), p_error / (2 * (eta + 1))
+        py = px
+    r = rng.random((n, size, size))
+    m = np.zeros((n, size, size), dtype=np.uint8)
+    m[r < pz] = 3
+    m[(r > pz) & (r < pz + px)] = 1
+    m[(r > pz + px) & (r < pz + px + py)] = 2
+    return m
+
+
+def hide_class(code, m, rng):
+    """`init_code.qubit_matrix, _ = init_code.apply_random_logical()` (generate_data.py:131) on a batch:
+    the operator draws of toric_model.py:234-248 / xzzx_model.py:346-355, applied by the device stencil."""
+    from . import _surf, toric_model
+    code = _CODES.get(code, code)
+    n, size = m.shape[0], m.shape[-1]
+    if code == L_.TORIC:
+        for layer in range(2):
+            ops = rng.integers(0, 4, size=n)
+            xpos = np.where(np.isin(ops, (1, 2)), rng.integers(0, size, size=n), 0)
+            zpos = np.where(np.isin(ops, (3, 2)), rng.integers(0, size, size=n), 0)
+            m, _ = toric_model.apply_logical(m, ops, layer, xpos, zpos)
+        return m
+    ops = rng.integers(0, 4, size=n)
+    xpos = np.where(np.isin(ops, (1, 2)), rng.integers(0, size, size=n), 0)
+    zpos = np.where(np.isin(ops, (3, 2)), rng.integers(0, size, size=n), 0)
+    m, _ = _surf.apply_logical(code, m, ops, xpos, zpos)
+    return m
+
+
+def generate(params, nbr_datapoints, seed=0, file_path=None, steps=100000, conv_criteria="error_based", **pteq_kw):
+    """params: dict like generate_data.py:276-296 ({'code','size','p_error','noise'[,'eta']}), method PTEQ.
+    Returns (and optionally saves as npz) qubit_matrix uint8[n,...] (the raw errors, generate_data.py:120),
+    eq_true int32[n], counts uint32[n,ncls], distr uint8[n,ncls] (what PTEQ returns), success bool[n]
+    (argmax(distr) == eq_true, generate_data.py:139), steps_done, converged."""
+    code = _CODES[params["code"]]
+    size, p = params["size"], params["p_error"]
+    eta = params.get("eta") if params.get("noise", "depolarizing") == "biased" else None
+    rng = np.random.default_rng(seed)
+    raw = draw_errors(code, size, nbr_datapoints, p, rng, eta)
+    eq_true = np.asarray(_class_of(code, raw), dtype=np.int32)
+    init = hide_class(code, raw, rng)
+    res = pteq_batch(init, p, Nc=params.get("Nc"), steps=steps, conv_criteria=conv_criteria, seed=seed, code=code, eta=eta,
+                     **pteq_kw)
+    out = dict(qubit_matrix=raw, eq_true=eq_true, counts=res["counts"], distr=res["percent"],
+               success=np.argmax(res["percent"], axis=1) == eq_true, steps_done=res["steps_done"],
+               converged=res["converged"], samples=res["samples"])
+    if file_path is not None:
+        np.savez_compressed(file_path, params=np.array([repr(params)]), **out)
+    return out
