@@ -69,7 +69,7 @@ def measured_hbm_traffic(args):
     FETCH_SIZE and WRITE_SIZE collected in separate passes around this same default bench command),
     or None when the workload differs from the profiled one."""
     import glob
-    if (args.code, args.syndromes, args.L, args.Nc, args.iters, args.ladder_steps, args.p_logical) != ("toric", 65536, 9, 8, 10, 2000, 0.5):
+    if (args.scan, args.code, args.syndromes, args.L, args.Nc, args.iters, args.ladder_steps, args.p_logical) != ("random", "toric", 65536, 9, 8, 10, 2000, 0.5):
         return None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
     if not files:
@@ -117,6 +117,8 @@ def main():
     ap.add_argument("--p-logical", type=float, default=0.5, help="top-chain logical rate (decoders.py:52 uses 0.5)")
     ap.add_argument("--code", default="toric", choices=["toric", "xzzx", "rotated"], help="other codes: parity-test configs 4, 5")
     ap.add_argument("--eta", type=float, default=None, help="bias: selects the mcmc_biased chain (config 4)")
+    ap.add_argument("--scan", default="random", choices=["random", "sweep"],
+                    help="random = the reference's random-scan chain; sweep = systematic generator sweep (scan=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -155,7 +157,8 @@ def main():
 
     pr = L_.make_params(code=code_id, L=L, Nc=Nc, p=args.p, p_logical=args.p_logical, iters=args.iters,
                         steps=args.ladder_steps, tops_burn=2, seed=args.seed, device=local_rank,
-                        noise=L_.NOISE_DEPOLARIZING if args.eta is None else L_.NOISE_BIASED, eta=args.eta or 0.0)
+                        noise=L_.NOISE_DEPOLARIZING if args.eta is None else L_.NOISE_BIASED, eta=args.eta or 0.0,
+                        scan=L_.SCAN_RANDOM if args.scan == "random" else L_.SCAN_CHECKERBOARD)
     plan = C.c_void_p()
     L_.check(L_.lib().qecmc_plan_create(pr, C.byref(plan)))
     lds, threads, spb = C.c_uint32(), C.c_uint32(), C.c_uint32()
@@ -213,9 +216,10 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%s: %s L=%d p=%g%s, %d syndromes per GPU, Nc=%d parallel tempering, "
-                                   "iters=%d, %d ladder steps per pass, scan=random (reference chain)"
+                                   "iters=%d, %d ladder steps per pass, scan=%s"
                                    % ("configs[1]" if (toric and L == 9) else "parity-test configuration", args.code, L, args.p,
-                                      "" if args.eta is None else " eta=%g" % args.eta, N, Nc, args.iters, args.ladder_steps),
+                                      "" if args.eta is None else " eta=%g" % args.eta, N, Nc, args.iters, args.ladder_steps,
+                                      "random (the reference's chain)" if args.scan == "random" else "sweep (systematic generator sweep)"),
                        "syndromes_per_gpu": N, "L": L, "p": args.p, "Nc": Nc, "iters": args.iters,
                        "ladder_steps": args.ladder_steps, "tops_burn": 2, "seed": args.seed,
                        "lds_bytes_per_workgroup": lds.value, "threads_per_workgroup": threads.value,
@@ -233,7 +237,7 @@ def main():
             "mixing": {"frac_syndromes_past_burn_in": float(np.mean(samples > 0)),
                        "mean_tops0": float(np.mean(tops0))},
         }
-        if world == 1 and not args.no_cpu_baseline and toric:
+        if world == 1 and not args.no_cpu_baseline and toric and args.scan == "random":
             out["cpu_baseline"] = cpu_baseline(init_h, args.p, Nc, args.iters, args.seed)
         print(json.dumps(out))
     L_.lib().qecmc_plan_destroy(plan)

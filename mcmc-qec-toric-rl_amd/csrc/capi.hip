@@ -151,6 +151,28 @@ std::vector<uint32_t> surf_logical_masks(int code, int L, int W)
     return m;
 }
 
+// generator table of the toric code in sweep order: all X-type (row-major), then all Z-type; the four sites of
+// toric_model.py:261-269, each as u16 (flat site << 2 | pauli)
+std::vector<uint32_t> toric_generator_table(int L)
+{
+    const int LL = L * L;
+    std::vector<uint32_t> t((size_t)4 * LL, 0u);
+    for (int op = 0; op < 2; ++op)
+        for (int r = 0; r < L; ++r)
+            for (int c = 0; c < L; ++c) {
+                const int rm = (r + L - 1) % L, rp = (r + 1) % L, cm = (c + L - 1) % L, cp = (c + 1) % L;
+                const uint32_t pauli = op == 0 ? 1u : 3u;
+                uint32_t q[4];
+                q[0] = LL + r * L + c; q[1] = r * L + c;
+                if (op == 0) { q[2] = LL + r * L + cm; q[3] = rm * L + c; }
+                else { q[2] = r * L + cp; q[3] = LL + rp * L + c; }
+                const int g = op * LL + r * L + c;
+                t[2 * g] = ((q[0] << 2) | pauli) | (((q[1] << 2) | pauli) << 16);
+                t[2 * g + 1] = ((q[2] << 2) | pauli) | (((q[3] << 2) | pauli) << 16);
+            }
+    return t;
+}
+
 // generator table of the plaquette codes: entry g = 4 x u16 (site << 2 | pauli), two u32 per generator
 std::vector<uint32_t> surf_generator_table(int code, int L)
 {
@@ -196,7 +218,8 @@ int validate_params(const qecmc_params *p)
         if (p->code == QECMC_TORIC) return fail(QECMC_ERR_UNSUPPORTED, "biased noise is built for the xzzx and rotated codes (BASELINE config 4)");
     } else if (!(p->p > 0.0) || !(p->p <= 0.75)) return fail(QECMC_ERR_INVALID, "p=%g must be in (0, 0.75]", p->p);
     if (!(p->p_logical >= 0.0) || !(p->p_logical <= 1.0)) return fail(QECMC_ERR_INVALID, "p_logical=%g must be in [0,1]", p->p_logical);
-    if (p->scan != QECMC_SCAN_RANDOM) return fail(QECMC_ERR_UNSUPPORTED, "scan mode %d not built yet", p->scan);
+    if (p->scan != QECMC_SCAN_RANDOM && p->scan != QECMC_SCAN_CHECKERBOARD) return fail(QECMC_ERR_INVALID, "scan mode %d unknown", p->scan);
+    if (p->scan == QECMC_SCAN_CHECKERBOARD && p->noise != QECMC_NOISE_DEPOLARIZING) return fail(QECMC_ERR_UNSUPPORTED, "the systematic sweep is built for the depolarizing rule only");
     if (p->conv_mode != QECMC_CONV_NONE && p->conv_mode != QECMC_CONV_ERROR_BASED) return fail(QECMC_ERR_INVALID, "conv_mode %d unknown", p->conv_mode);
     if (p->conv_mode == QECMC_CONV_ERROR_BASED && (p->TOPS < 0 || p->SEQ < 0 || !(p->eps >= 0))) return fail(QECMC_ERR_INVALID, "TOPS, SEQ and eps must be non-negative");
     if (p->iters == 0 || p->iters > 0xFFFFFFFFull) return fail(QECMC_ERR_INVALID, "iters out of range");
@@ -239,8 +262,10 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
     for (int i = 0; i + 1 < Nc; ++i)
         if (nq >= 1 && sw[(size_t)i * (nq + 1) + 1] > 0xFFFFFFFFull) a.swap_fast_ok = 0;
     const std::vector<uint32_t> lm = p->code == QECMC_TORIC ? toric_logical_masks(L, W) : surf_logical_masks(p->code, L, W);
-    if (p->code != QECMC_TORIC) {
-        const std::vector<uint32_t> gt = surf_generator_table(p->code, L);
+    a.scan = p->scan;
+    {
+        const std::vector<uint32_t> gt = p->code == QECMC_TORIC ? toric_generator_table(L) : surf_generator_table(p->code, L);
+        a.n_gen = (uint32_t)(gt.size() / 2);
         HIP_TRY(pl->gen.alloc(gt.size() * sizeof(uint32_t)));
         HIP_TRY(hipMemcpy(pl->gen.p, gt.data(), gt.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         a.gen = pl->gen.as<uint2>();

@@ -27,6 +27,8 @@ struct LadderArgs {
     const double *bias_tbl;   // [Nc][4][nq+1]      px^n, py^n, pz^n, pI^n per rung (biased noise)
     uint64_t thr_half;        // floor(phalf * 2^32) (xzzx_model.py:444)
     int code, noise;          // qecmc_code, qecmc_noise
+    int scan;                 // qecmc_scan
+    uint32_t n_gen;           // number of stabilizer generators G (sweep order = table order)
     const uint32_t *acc_tbl_top; // [nq+1]          ceil(f_top^dE * 2^32): top slot below p = 0.75 (Nc == 1 only)
     uint64_t N;
     uint64_t step0, prop0, nsteps;

@@ -142,7 +142,9 @@ __device__ __forceinline__ uint32_t pack_info(uint32_t n, uint32_t sid, uint32_t
 // alone on its CU at the end of a launch, where one group (2 waves per SIMD) is latency-bound.
 // CODE / BIASED: code model (toric, xzzx, rotated) and acceptance rule (src/mcmc.py or src/mcmc_biased.py).
 // The tuned paths are toric + depolarizing; the other combinations share the staging, cascade and bookkeeping.
-template <int MAXT, int MINW, bool CONV, int GROUPS, int CODE, bool BIASED>
+// SCAN: false = the reference's random scan; true = systematic sweep (proposal k tests generator k mod G):
+// sites are wave-uniform scalars and one Philox block feeds four proposals.
+template <int MAXT, int MINW, bool CONV, int GROUPS, int CODE, bool BIASED, bool SCAN>
 __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const LadderArgs a)
 {
     extern __shared__ uint32_t lds_all[];
@@ -268,9 +270,22 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             if (!top && !BIASED && CODE != kCodeToric) {
                 // depolarizing Metropolis on a plaquette code: generator table lookup, 2 or 4 sites
                 int ni = (int)n;
+                uint32_t gs = SCAN ? (uint32_t)(kbase % a.n_gen) : 0u;
+                u32x4 blk{0, 0, 0, 0};
+                uint64_t kb_cur = ~0ull;
                 for (uint32_t j = 0; j < iters; ++j) {
-                    const u32x4 x = philox_block(kbase + j, 0, syn, slot_u, a.seed_lo, a.seed_hi);
-                    const uint32_t g = surf_generator_index(L, x.x, x.y, x.z, a.thr_half);
+                    u32x4 x;
+                    uint32_t g;
+                    if constexpr (SCAN) {                                          // generator k mod G, accept word k&3 of block k>>2
+                        const uint64_t k = kbase + j;
+                        if ((k >> 2) != kb_cur) { kb_cur = k >> 2; blk = philox_block(kb_cur, 3, syn, slot_u, a.seed_lo, a.seed_hi); }
+                        x.w = sel4(blk, (int)(k & 3));
+                        g = gs;
+                        gs = gs + 1 == a.n_gen ? 0u : gs + 1;
+                    } else {
+                        x = philox_block(kbase + j, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                        g = surf_generator_index(L, x.x, x.y, x.z, a.thr_half);
+                    }
                     const uint2 e = a.gen[g];                                      // 4 x (site << 2 | pauli), 0 = no site
                     const uint32_t ent[4] = {e.x & 0xFFFFu, e.x >> 16, e.y & 0xFFFFu, e.y >> 16};
                     uint32_t *ad[4];
@@ -304,7 +319,8 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 uint32_t cdelta = 0;
                 const uint32_t *lmask = a.lmask;
                 const int LW = (L + 1) * W;
-                for (uint32_t j = 0; j < iters; ++j) {
+                uint32_t gs = SCAN ? (uint32_t)(kbase % a.n_gen) : 0u;
+                for (uint32_t j = 0; j < iters; ++j, gs = gs + 1 == a.n_gen ? 0u : gs + 1) {
                     const uint64_t k = kbase + j;
                     const u32x4 x = philox_block(k, 0, syn, slot_u, a.seed_lo, a.seed_hi);
                     const bool logical = top && x.x <= thrL1;                       // mcmc.py:23
@@ -340,7 +356,10 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                         }
                     } else {
                         const uint32_t wa = top ? x.y : x.x, wb = top ? x.z : x.y, wc = top ? x.w : x.z;
-                        if (CODE == kCodeToric) {
+                        if constexpr (SCAN) {
+                            const uint2 e = a.gen[gs];
+                            ent[0] = e.x & 0xFFFFu; ent[1] = e.x >> 16; ent[2] = e.y & 0xFFFFu; ent[3] = e.y >> 16;
+                        } else if (CODE == kCodeToric) {
                             uint32_t q[4];
                             const uint32_t isX = wc >> 31;
                             toric_sites(L, LL, scale_u32(wa, L), scale_u32(wb, L), isX, q);
@@ -363,6 +382,8 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                         const int mx = nx + dx, my = ny + dy, mz = nz + dz;
                         const double pn = bt[mx] * bt[T1 + my] * bt[2 * T1 + mz] * bt[3 * T1 + (nq - mx - my - mz)];
                         acc = (double)xa * (1.0 / 4294967296.0) < pn / pb;          // mcmc_biased.py:44-46
+                    } else if (SCAN && top && acc_all && !logical) {
+                        acc = x.w >> 31;                                            // sweep at f = 1: apply with probability 1/2
                     } else if (top) {
                         acc = acc_all || dE <= 0;                                   // mcmc.py:30
                         if (!acc) acc = philox_block(k, 2, syn, slot_u, a.seed_lo, a.seed_hi).x < a.acc_tbl_top[dE];   // :34
@@ -407,9 +428,41 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                     ni += dE;
                 }
             };
+            uint32_t j = 0;
+            if constexpr (SCAN) {
+                // systematic sweep: generator k mod G (wave-uniform sites from the plan's table), one Philox
+                // block per four proposals
+                uint32_t gs = (uint32_t)(kbase % a.n_gen);
+                u32x4 blk{0, 0, 0, 0};
+                uint64_t kb_cur = ~0ull;
+                for (; j < iters; ++j) {
+                    const uint64_t k = kbase + j;
+                    if ((k >> 2) != kb_cur) { kb_cur = k >> 2; blk = philox_block(kb_cur, 3, syn, slot_u, a.seed_lo, a.seed_hi); }
+                    const uint32_t xw = sel4(blk, (int)(k & 3));
+                    const uint2 e = a.gen[gs];
+                    gs = gs + 1 == a.n_gen ? 0u : gs + 1;
+                    const uint32_t ent[4] = {e.x & 0xFFFFu, e.x >> 16, e.y & 0xFFFFu, e.y >> 16};
+                    const uint32_t op = ent[0] & 3u;
+                    uint32_t *ad[4];
+                    uint32_t sh[4], F = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const uint32_t q = ent[i] >> 2;
+                        ad[i] = stw + (q >> 4) * 64;
+                        sh[i] = (q & 15u) * 2u;
+                        F |= ((*ad[i] >> sh[i]) & 3u) << (2 * i);
+                    }
+                    const uint32_t G = F ^ (op * 0x55u);
+                    const int dE = __popc((G | (G >> 1)) & 0x55u) - __popc((F | (F >> 1)) & 0x55u);
+                    if (xw <= myT[dE]) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) lds_xor(ad[i], op << sh[i]);
+                        ni += dE;
+                    }
+                }
+            }
             // the uniforms of a proposal do not depend on the state: draw two proposals' Philox blocks
             // together so their serial 10-round chains overlap, then apply the proposals in order
-            uint32_t j = 0;
             for (; j + 1 < iters; j += 2) {
                 const u32x4 xa = philox_block(kbase + j, 0, syn, slot_u, a.seed_lo, a.seed_hi);
                 const u32x4 xb = philox_block(kbase + j + 1, 0, syn, slot_u, a.seed_lo, a.seed_hi);
@@ -437,6 +490,14 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                     fr0 ^= (dx0 << x0) | (dz0 << (16 + z0));
                     fr1 ^= (dx1 << x1) | (dz1 << (16 + z1));
                     cdelta ^= dx0 | (dz0 << 1) | (dx1 << 2) | (dz1 << 3);
+                } else if constexpr (SCAN) {
+                    // sweep at f = 1: generator k mod G with probability 1/2 (a coin-less sweep composes to the identity)
+                    const uint2 e = a.gen[(uint32_t)((kbase + j) % a.n_gen)];
+                    const uint32_t ent[4] = {e.x & 0xFFFFu, e.x >> 16, e.y & 0xFFFFu, e.y >> 16};
+                    if (x.w >> 31) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) lds_xor(stw + (ent[i] >> 6) * 64, (ent[i] & 3u) << (((ent[i] >> 2) & 15u) * 2u));
+                    }
                 } else {
                     const uint32_t row = scale_u32(x.y, L), col = scale_u32(x.z, L), isX = x.w >> 31;
                     uint32_t q[4];
@@ -502,17 +563,24 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                         cdelta ^= dx0 | (dz0 << 1) | (dx1 << 2) | (dz1 << 3);
                     }
                 } else {
-                    const uint32_t row = scale_u32(x.y, L), col = scale_u32(x.z, L), isX = x.w >> 31;
-                    uint32_t q[4];
-                    toric_sites(L, LL, row, col, isX, q);
-                    const uint32_t op = isX ? 1u : 3u;
+                    uint32_t q[4], op;
+                    if constexpr (SCAN) {                                          // generator k mod G from the plan's table
+                        const uint2 e = a.gen[(uint32_t)(k % a.n_gen)];
+                        q[0] = (e.x & 0xFFFFu) >> 2; q[1] = e.x >> 18; q[2] = (e.y & 0xFFFFu) >> 2; q[3] = e.y >> 18;
+                        op = e.x & 3u;
+                    } else {
+                        const uint32_t isX = x.w >> 31;
+                        toric_sites(L, LL, scale_u32(x.y, L), scale_u32(x.z, L), isX, q);
+                        op = isX ? 1u : 3u;
+                    }
                     int dE = 0;
                     for (int i = 0; i < 4; ++i) {
                         const uint32_t f = (stw[(q[i] >> 4) * 64] >> ((q[i] & 15u) * 2u)) & 3u;
                         dE += (int)(f == 0u) - (int)(f == op);
                     }
                     bool acc = true;
-                    if (!acc_all && dE > 0) acc = philox_block(k, 2, syn, slot_u, a.seed_lo, a.seed_hi).x < a.acc_tbl_top[dE];
+                    if (SCAN && acc_all) acc = x.w >> 31;                           // sweep at f = 1: probability 1/2
+                    else if (!acc_all && dE > 0) acc = philox_block(k, 2, syn, slot_u, a.seed_lo, a.seed_hi).x < a.acc_tbl_top[dE];
                     if (acc) {
                         for (int i = 0; i < 4; ++i) lds_xor(stw + (q[i] >> 4) * 64, op << ((q[i] & 15u) * 2u));
                         ni += dE;
@@ -658,19 +726,24 @@ hipError_t launch_ladder_rs_toric(const LadderArgs &a, hipStream_t stream)
     lds *= groups;
     const void *fn;
     constexpr int T = kCodeToric, X = kCodeXzzx, R = kCodeRotated;
+#define QECMC_K(maxt, minw, g, code, biased) \
+    (a.scan ? (conv ? (const void *)ladder_rs_toric_kernel<maxt, minw, true, g, code, biased, true> : (const void *)ladder_rs_toric_kernel<maxt, minw, false, g, code, biased, true>) \
+            : (conv ? (const void *)ladder_rs_toric_kernel<maxt, minw, true, g, code, biased, false> : (const void *)ladder_rs_toric_kernel<maxt, minw, false, g, code, biased, false>))
     if (a.code == T && !a.noise) {
-        if (groups == 2) fn = conv ? (const void *)ladder_rs_toric_kernel<1024, 8, true, 2, T, false> : (const void *)ladder_rs_toric_kernel<1024, 8, false, 2, T, false>;
-        else if (block <= 512) fn = conv ? (const void *)ladder_rs_toric_kernel<512, 8, true, 1, T, false> : (const void *)ladder_rs_toric_kernel<512, 8, false, 1, T, false>;
-        else fn = conv ? (const void *)ladder_rs_toric_kernel<1024, 4, true, 1, T, false> : (const void *)ladder_rs_toric_kernel<1024, 4, false, 1, T, false>;
+        if (groups == 2) fn = QECMC_K(1024, 8, 2, T, false);
+        else if (block <= 512) fn = QECMC_K(512, 8, 1, T, false);
+        else fn = QECMC_K(1024, 4, 1, T, false);
     } else {
         // the other code / noise combinations run one group per workgroup (any Nc <= 16)
         grid *= groups; block /= groups; lds /= groups;
-        if (a.code == X && !a.noise) fn = conv ? (const void *)ladder_rs_toric_kernel<1024, 4, true, 1, X, false> : (const void *)ladder_rs_toric_kernel<1024, 4, false, 1, X, false>;
-        else if (a.code == R && !a.noise) fn = conv ? (const void *)ladder_rs_toric_kernel<1024, 4, true, 1, R, false> : (const void *)ladder_rs_toric_kernel<1024, 4, false, 1, R, false>;
-        else if (a.code == X) fn = conv ? (const void *)ladder_rs_toric_kernel<1024, 4, true, 1, X, true> : (const void *)ladder_rs_toric_kernel<1024, 4, false, 1, X, true>;
-        else if (a.code == R) fn = conv ? (const void *)ladder_rs_toric_kernel<1024, 4, true, 1, R, true> : (const void *)ladder_rs_toric_kernel<1024, 4, false, 1, R, true>;
+        if (a.code == X && !a.noise) fn = QECMC_K(1024, 4, 1, X, false);
+        else if (a.code == R && !a.noise) fn = QECMC_K(1024, 4, 1, R, false);
+        else if (a.scan) return hipErrorInvalidValue;          // the sweep is built for the depolarizing rule only
+        else if (a.code == X) fn = conv ? (const void *)ladder_rs_toric_kernel<1024, 4, true, 1, X, true, false> : (const void *)ladder_rs_toric_kernel<1024, 4, false, 1, X, true, false>;
+        else if (a.code == R) fn = conv ? (const void *)ladder_rs_toric_kernel<1024, 4, true, 1, R, true, false> : (const void *)ladder_rs_toric_kernel<1024, 4, false, 1, R, true, false>;
         else return hipErrorInvalidValue;
     }
+#undef QECMC_K
     if (lds > 64 * 1024) {   // beyond the default dynamic-LDS window (160 KiB per CU on gfx950)
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;

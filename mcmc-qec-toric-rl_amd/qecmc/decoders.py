@@ -16,11 +16,12 @@ def percent_from_counts(counts, samples):
 
 def pteq_batch(init, p, Nc=None, steps=1000, iters=10, tops_burn=2, p_logical=0.5, seed=0, first_syndrome=0,
                device=0, return_states=False, return_stats=False, conv_criteria=None, SEQ=2, TOPS=10, eps=0.1,
-               code=L_.TORIC, eta=None):
+               code=L_.TORIC, eta=None, scan="random"):
     """decoders.PTEQ (decoders.py:25-89) on N syndromes at once.
 
     init: uint8[N, 2, L, L] (toric) or uint8[N, L, L] (code=XZZX / ROTATED) seed configurations, one per
-    syndrome; eta selects the biased chain of src/mcmc_biased.py (PTEQ_biased).  conv_criteria None runs exactly
+    syndrome; eta selects the biased chain of src/mcmc_biased.py (PTEQ_biased); scan="random" is the reference's
+    chain, scan="sweep" the systematic generator sweep (same stationary law, faster).  conv_criteria None runs exactly
     `steps` ladder steps; 'error_based' stops each syndrome by the reference's criterion (:74-105).
     Returns dict(counts uint32[N,16], samples uint32[N], tops0 uint32[N], steps_done uint32[N],
     converged bool[N], percent uint8[N,16] [, states uint8[N,Nc,2,L,L]] [, stats]).
@@ -35,7 +36,8 @@ def pteq_batch(init, p, Nc=None, steps=1000, iters=10, tops_burn=2, p_logical=0.
                         steps=int(steps), tops_burn=int(tops_burn), TOPS=int(TOPS), SEQ=int(SEQ), eps=float(eps),
                         seed=seed, first_syndrome=first_syndrome, device=device,
                         conv_mode=L_.CONV_ERROR_BASED if conv_criteria else L_.CONV_NONE,
-                        noise=L_.NOISE_DEPOLARIZING if eta is None else L_.NOISE_BIASED, eta=0.0 if eta is None else float(eta))
+                        noise=L_.NOISE_DEPOLARIZING if eta is None else L_.NOISE_BIASED, eta=0.0 if eta is None else float(eta),
+                        scan={"random": L_.SCAN_RANDOM, "sweep": L_.SCAN_CHECKERBOARD}[scan])
     counts = np.zeros((N, ncls), dtype=np.uint32)
     samples = np.zeros(N, dtype=np.uint32)
     tops0 = np.zeros(N, dtype=np.uint32)

@@ -29,7 +29,7 @@ class _Rng(C.Structure):
 
 
 class Model(C.Structure):
-    _fields_ = [("code", C.c_int), ("L", C.c_int), ("noise", C.c_int), ("eta", C.c_double)]
+    _fields_ = [("code", C.c_int), ("L", C.c_int), ("noise", C.c_int), ("eta", C.c_double), ("scan", C.c_int)]
 
 
 TORIC, XZZX, ROTATED = 0, 1, 2
@@ -275,8 +275,8 @@ def toric_pteq_batch(init, p, Nc, steps, iters=10, tops_burn=2, seed=0, first_sy
 
 
 # ---- XZZX / rotated surface code (uint8[L,L]) and the code/noise-generic chain, ladder, PTEQ --------
-def _model(code, L, noise=DEPOLARIZING, eta=0.0):
-    return Model(code, L, noise, float(eta))
+def _model(code, L, noise=DEPOLARIZING, eta=0.0, scan=0):
+    return Model(code, L, noise, float(eta), scan)
 
 
 def _size(code, m):
@@ -307,10 +307,10 @@ def surf_syndrome(code, m):
     return out
 
 
-def chain_update(code, m, p, p_logical, iters, rng, slot=0, k0=0, noise=DEPOLARIZING, eta=0.0):
+def chain_update(code, m, p, p_logical, iters, rng, slot=0, k0=0, noise=DEPOLARIZING, eta=0.0, scan=0):
     m = _m(m).copy()
     scratch = np.empty_like(m)
-    mod = _model(code, _size(code, m), noise, eta)
+    mod = _model(code, _size(code, m), noise, eta, scan)
     lib().orc_chain_update(C.byref(mod), _u8(m), p, p_logical, iters, C.byref(rng.c), slot, k0, _u8(scratch))
     return m
 
@@ -318,11 +318,11 @@ def chain_update(code, m, p, p_logical, iters, rng, slot=0, k0=0, noise=DEPOLARI
 class Ladder:
     """Ladder / Ladder_biased of any code model (states in slot order)."""
 
-    def __init__(self, code, init, p_bottom, Nc, p_logical=0.0, noise=DEPOLARIZING, eta=0.0):
+    def __init__(self, code, init, p_bottom, Nc, p_logical=0.0, noise=DEPOLARIZING, eta=0.0, scan=0):
         init = _m(init)
         self.shape = init.shape
         self.Nc = Nc; self.nq = init.size
-        mod = _model(code, _size(code, init), noise, eta)
+        mod = _model(code, _size(code, init), noise, eta, scan)
         self._p = lib().orc_ladder_new(C.byref(mod), _u8(init), p_bottom, Nc, p_logical)
 
     def __del__(self):
@@ -370,9 +370,9 @@ def pteq(code, init, p, Nc=None, SEQ=2, TOPS=10, tops_burn=2, eps=0.1, steps=100
 
 
 def pteq_batch(code, init, p, Nc, steps, iters=10, tops_burn=2, seed=0, first_syndrome=0, n_threads=0,
-               return_states=False, conv_criteria=None, SEQ=2, TOPS=10, eps=0.1, noise=DEPOLARIZING, eta=0.0):
+               return_states=False, conv_criteria=None, SEQ=2, TOPS=10, eps=0.1, noise=DEPOLARIZING, eta=0.0, scan=0):
     init = _m(init); N = init.shape[0]
-    mod = _model(code, init.shape[-1], noise, eta)
+    mod = _model(code, init.shape[-1], noise, eta, scan)
     counts = np.zeros((N, 16), dtype=np.uint32)
     samples = np.zeros(N, dtype=np.uint64); tops0 = np.zeros(N, dtype=np.uint64)
     steps_done = np.zeros(N, dtype=np.uint64); converged = np.zeros(N, dtype=np.uint8)

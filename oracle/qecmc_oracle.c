@@ -277,6 +277,54 @@ static int model_random_logical(const orc_model *m, const uint8_t *in, uint8_t *
     return orc_surf_apply_logical(m->code, L, in, out, op, xpos, zpos);
 }
 
+/* scan = 1: proposal k of a chain tests generator k mod G, in the fixed order "all X-type (row-major), then all
+ * Z-type" (toric) / "all plaquettes (row-major), then the half plaquettes" (xzzx, rotated) */
+static int model_sweep_stabilizer(const orc_model *m, const uint8_t *in, uint8_t *out, uint64_t k)
+{
+    const int L = m->L;
+    if (m->code == ORC_TORIC) {
+        const int LL = L * L;
+        int g = (int)(k % (uint64_t)(2 * LL)), op = 1;
+        if (g >= LL) { op = 3; g -= LL; }
+        return orc_toric_apply_stabilizer(L, in, out, g / L, g % L, op);
+    }
+    const int nf = (L - 1) * (L - 1);
+    int g = (int)(k % (uint64_t)(nf + 2 * (L - 1)));
+    if (g < nf) return orc_surf_apply_stabilizer(m->code, L, in, out, g / (L - 1), g % (L - 1), 1);
+    g -= nf;
+    return orc_surf_apply_stabilizer(m->code, L, in, out, g / 4, g % 4, 3);
+}
+
+/* Systematic-sweep Metropolis (scan = 1).  Non-top chains: generator k mod G, accepted iff u < f^dE with u = word
+ * k&3 of Philox block (k>>2, sub 3).  Top chain: block (k,0) as in random scan -- word 0 selects a logical proposal;
+ * otherwise generator k mod G is applied with probability 1/2 when p >= 0.75 (top bit of word 3: without the coin a
+ * full sweep at f = 1 would compose to the identity), or by the Metropolis rule below p = 0.75. */
+static void chain_update_sweep(const orc_model *m, uint8_t *state, double p, double p_logical, uint64_t iters,
+                               orc_rng *rng, uint32_t slot, uint64_t k0, uint8_t *scratch)
+{
+    const size_t nq = (size_t)orc_nq(m->code, m->L);
+    const double factor = (p / 3.0) / (1.0 - p);
+    for (uint64_t j = 0; j < iters; ++j) {
+        const uint64_t k = k0 + j;
+        if (p_logical != 0) {
+            int dE;
+            if (orc_draw(rng, slot, k, 0, 0) < p_logical) {
+                dE = model_random_logical(m, state, scratch, rng, slot, k);
+            } else {
+                dE = model_sweep_stabilizer(m, state, scratch, k);
+                if (p >= 0.75) {
+                    if (orc_draw(rng, slot, k, 0, 3) >= 0.5) memcpy(state, scratch, nq);
+                    continue;
+                }
+            }
+            if (p >= 0.75 || dE <= 0 || orc_draw(rng, slot, k, 2, 0) < pow(factor, (double)dE)) memcpy(state, scratch, nq);
+        } else {
+            const int dE = model_sweep_stabilizer(m, state, scratch, k);
+            if (orc_draw(rng, slot, k >> 2, 3, (int)(k & 3)) < pow(factor, (double)dE)) memcpy(state, scratch, nq);
+        }
+    }
+}
+
 /* p_x^nx p_y^ny p_z^nz p_I^(num-nx-ny-nz), mcmc_biased.py:31,43 (left-to-right products of pow()) */
 static double biased_weight(const uint8_t *s, int nq, double px, double py, double pz)
 {
@@ -289,6 +337,10 @@ void orc_chain_update(const orc_model *m, uint8_t *state, double p, double p_log
                       orc_rng *rng, uint32_t slot, uint64_t k0, uint8_t *scratch)
 {
     const size_t nq = (size_t)orc_nq(m->code, m->L);
+    if (m->scan == 1 && m->noise == ORC_NOISE_DEPOLARIZING) {
+        chain_update_sweep(m, state, p, p_logical, iters, rng, slot, k0, scratch);
+        return;
+    }
     if (m->noise == ORC_NOISE_BIASED) {
         /* Chain_biased.update_chain, mcmc_biased.py:20-59.  pb is computed ONCE before the loop and never
          * refreshed after an accept (reference quirk Q3, reproduced). */
@@ -342,7 +394,7 @@ void orc_chain_update(const orc_model *m, uint8_t *state, double p, double p_log
 void orc_toric_chain_update(int L, uint8_t *state, double p, double p_logical, uint64_t iters,
                             orc_rng *rng, uint32_t slot, uint64_t k0, uint8_t *scratch)
 {
-    orc_model m = {ORC_TORIC, L, ORC_NOISE_DEPOLARIZING, 0.0};
+    orc_model m = {ORC_TORIC, L, ORC_NOISE_DEPOLARIZING, 0.0, 0};
     orc_chain_update(&m, state, p, p_logical, iters, rng, slot, k0, scratch);
 }
 
@@ -383,7 +435,7 @@ orc_ladder *orc_ladder_new(const orc_model *m, const uint8_t *init, double p_bot
 
 orc_ladder *orc_toric_ladder_new(int L, const uint8_t *init, double p_bottom, int Nc, double p_logical)
 {
-    orc_model m = {ORC_TORIC, L, ORC_NOISE_DEPOLARIZING, 0.0};
+    orc_model m = {ORC_TORIC, L, ORC_NOISE_DEPOLARIZING, 0.0, 0};
     return orc_ladder_new(&m, init, p_bottom, Nc, p_logical);
 }
 
@@ -495,7 +547,7 @@ void orc_toric_pteq(int L, const uint8_t *init, double p, int Nc, int SEQ, int T
                     double eps, uint64_t steps, uint64_t iters, int conv_mode, orc_rng *rng,
                     orc_pteq_result *res, uint8_t *final_states)
 {
-    orc_model m = {ORC_TORIC, L, ORC_NOISE_DEPOLARIZING, 0.0};
+    orc_model m = {ORC_TORIC, L, ORC_NOISE_DEPOLARIZING, 0.0, 0};
     orc_pteq(&m, init, p, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, conv_mode, rng, res, final_states);
 }
 
@@ -504,7 +556,7 @@ void orc_toric_pteq_batch(int L, const uint8_t *init, uint64_t N, uint32_t first
                           int n_threads, uint32_t *counts_out, uint64_t *samples_out,
                           uint64_t *tops0_out, uint8_t *final_states)
 {
-    orc_model m = {ORC_TORIC, L, ORC_NOISE_DEPOLARIZING, 0.0};
+    orc_model m = {ORC_TORIC, L, ORC_NOISE_DEPOLARIZING, 0.0, 0};
     orc_pteq_batch(&m, init, N, first_syndrome, p, Nc, 2, 10, tops_burn, 0.1, steps, iters, 0, seed,
                    n_threads, counts_out, samples_out, tops0_out, NULL, NULL, final_states);
 }
@@ -515,7 +567,7 @@ void orc_toric_pteq_batch_conv(int L, const uint8_t *init, uint64_t N, uint32_t 
                                uint32_t *counts_out, uint64_t *samples_out, uint64_t *tops0_out,
                                uint64_t *steps_done_out, uint8_t *converged_out, uint8_t *final_states)
 {
-    orc_model m = {ORC_TORIC, L, ORC_NOISE_DEPOLARIZING, 0.0};
+    orc_model m = {ORC_TORIC, L, ORC_NOISE_DEPOLARIZING, 0.0, 0};
     orc_pteq_batch(&m, init, N, first_syndrome, p, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, conv_mode, seed,
                    n_threads, counts_out, samples_out, tops0_out, steps_done_out, converged_out, final_states);
 }

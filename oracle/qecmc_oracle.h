@@ -61,6 +61,8 @@ typedef struct orc_model {
     int L;
     int noise;     /* ORC_NOISE_DEPOLARIZING: src/mcmc.py; ORC_NOISE_BIASED: src/mcmc_biased.py */
     double eta;    /* bias, mcmc_biased.py:11 */
+    int scan;      /* 0: the reference's random scan; 1: systematic sweep over the generators (NOT the reference's
+                      chain: the deterministic-scan variant the GPU offers as scan=1, same stationary law) */
 } orc_model;
 
 int orc_nq(int code, int L);

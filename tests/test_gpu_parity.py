@@ -211,3 +211,29 @@ def test_pteq_dropin_default_criterion(q, orc):
     assert ref["converged"][0]
     exp = (np.divide(ref["counts"][0], ref["samples"][0]) * 100).astype(np.uint8)
     assert np.array_equal(pct, exp) and 96 <= int(pct.sum()) <= 100
+
+
+# ------------------------------------------------------------------ scan = sweep (systematic generator sweep)
+@pytest.mark.parametrize("code,L,p,Nc,N,steps,tops_burn,iters", [
+    ("toric", 3, 0.10, 3, 70, 200, 1, 10), ("toric", 5, 0.10, 5, 65, 150, 0, 10), ("toric", 9, 0.15, 8, 130, 100, 0, 10),
+    ("toric", 9, 0.15, 8, 64, 60, 0, 7), ("toric", 5, 0.2, 1, 20, 80, 0, 10), ("rotated", 5, 0.17, 5, 40, 150, 0, 10),
+    ("xzzx", 9, 0.15, 8, 64, 80, 0, 10), ("toric", 15, 0.18, 16, 30, 20, 0, 13)])
+def test_sweep_scan_bit_exact(q, orc, code, L, p, Nc, N, steps, tops_burn, iters):
+    """scan=sweep is not the reference's chain; the oracle restates the same sweep rule and the GPU must
+    reproduce it bit for bit (its physics is checked against exact enumeration in test_gpu_stats.py)."""
+    cid = {"toric": q.TORIC, "xzzx": q.XZZX, "rotated": q.ROTATED}[code]
+    rng = np.random.default_rng(N + L)
+    if code == "toric":
+        init = rand_states(rng, N, L, p)
+    else:
+        init = np.zeros((N, L, L), dtype=np.uint8)
+        err = rng.random(init.shape) < p
+        init[err] = rng.integers(1, 4, size=int(err.sum()), dtype=np.uint8)
+    got = q.pteq_batch(init, p, Nc=Nc, steps=steps, iters=iters, tops_burn=tops_burn, seed=99, first_syndrome=2, code=cid,
+                       scan="sweep", return_states=True)
+    ref = orc.pteq_batch(cid, init, p, Nc, steps, iters=iters, tops_burn=tops_burn, seed=99, first_syndrome=2, scan=1,
+                         return_states=True)
+    assert np.array_equal(got["tops0"], ref["tops0"].astype(np.uint32))
+    assert np.array_equal(got["samples"], ref["samples"].astype(np.uint32))
+    assert np.array_equal(got["counts"], ref["counts"])
+    assert np.array_equal(got["states"], ref["states"])

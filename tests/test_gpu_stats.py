@@ -28,14 +28,15 @@ def _rand_state(seed, L, p):
     return m
 
 
+@pytest.mark.parametrize("scan", ["random", "sweep"])
 @pytest.mark.parametrize("seed,p,Nc", [(1, 0.10, 3), (2, 0.15, 4), (3, 0.12, 4), (4, 0.20, 5)])
-def test_exact_enumeration_L3(q, seed, p, Nc):
+def test_exact_enumeration_L3(q, seed, p, Nc, scan):
     from qecmc import toric_model as tm
     init = _rand_state(seed, 3, 0.15)
     P = toric_class_probabilities(init, p, tm.apply_stabilizer, tm.to_class)      # device stencils build the group
     R, steps = 4096, 4000
     res = q.pteq_batch(np.broadcast_to(init, (R,) + init.shape).copy(), p, Nc=Nc, steps=steps, iters=10, tops_burn=5,
-                       seed=1000 + seed)
+                       seed=1000 + seed, scan=scan)
     ok = res["samples"] > steps // 2
     assert ok.mean() > 0.99
     frac = res["counts"][ok] / res["samples"][ok, None].astype(np.float64)
