@@ -51,7 +51,8 @@ struct LadderArgs {
     int write_states;
 };
 
-size_t ladder_lds_bytes(int L, int Nc, int W, int ncls);
+size_t ladder_lds_bytes(int L, int Nc, int W, int ncls, int gen_dwords);
+constexpr uint32_t kMaxGenLds = 2048;   // generator tables up to this many entries are staged in LDS
 hipError_t launch_ladder_rs_toric(const LadderArgs &a, hipStream_t stream);
 
 // byte-state primitive kernels (primitives.hip); all pointers are device pointers

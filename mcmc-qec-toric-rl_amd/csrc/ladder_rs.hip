@@ -36,11 +36,19 @@
 namespace qecmc {
 
 // LDS carve-up in dwords (keep in sync with the kernel)
-size_t ladder_lds_bytes(int L, int Nc, int W, int ncls)
+__host__ __device__ inline int ladder_group_dwords(int Nc, int W, int ncls, int gen_dwords)
+{
+    // st + info[2] + swx[2] + hist + thrT + swapT + stop flag (16) [+ generator table]; kept even so the
+    // generator table (uint2 entries) is 8-byte aligned
+    int d = Nc * W * 64 + 4 * Nc * 64 + ncls * 64 + Nc * 9 + Nc * kSwapFast + 16;
+    d += d & 1;
+    return d + gen_dwords;
+}
+
+size_t ladder_lds_bytes(int L, int Nc, int W, int ncls, int gen_dwords)
 {
     (void)L;   // per group of 64 syndromes
-    return sizeof(uint32_t) * ((size_t)Nc * W * 64 + 4 * (size_t)Nc * 64 + (size_t)ncls * 64 + (size_t)Nc * 9 +
-                               (size_t)Nc * kSwapFast + 16);   // st + info[2] + swx[2] + hist + thrT + swapT + stop flag
+    return sizeof(uint32_t) * (size_t)ladder_group_dwords(Nc, W, ncls, gen_dwords);
 }
 
 __device__ __forceinline__ uint32_t nnz2(uint32_t x) { return __popc((x | (x >> 1)) & 0x55555555u); }
@@ -152,7 +160,9 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
     const int nthreads = NC * 64;                 // threads of one group
     const int grp = (GROUPS == 1) ? 0 : ((int)threadIdx.x >= nthreads);
     const int tid = (int)threadIdx.x - grp * nthreads, lane = tid & 63, slot = tid >> 6;
-    const int gdw = NC * W * 64 + 4 * NC * 64 + ncls * 64 + NC * 9 + NC * kSwapFast + 16;   // dwords per group (ladder_lds_bytes)
+    constexpr bool kUsesGen = SCAN || CODE != kCodeToric;      // paths that look generators up in the plan's table
+    const int gen_dw = kUsesGen ? 2 * (int)a.n_gen : 0;
+    const int gdw = ladder_group_dwords(NC, W, ncls, gen_dw);   // dwords per group
     uint32_t *lds = lds_all + grp * gdw;
 
     uint32_t *st = lds;                           // [NC][W][64]   packed states
@@ -162,6 +172,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
     uint32_t *thrT = hist + ncls * 64;            // [NC][9]       accept iff x <= thrT[slot][dE+4]
     uint32_t *swapT = thrT + NC * 9;              // [NC][kSwapFast]  swap iff x < swapT[i][d]
     volatile uint32_t *stopf = swapT + NC * kSwapFast;   // [1]  every syndrome of the workgroup has converged
+    const uint2 *gtab = reinterpret_cast<const uint2 *>(lds + gdw - gen_dw);   // [n_gen] generator table (LDS copy)
 
 #ifdef QECMC_TIMELINE   // diagnostic build only (tools/timeline.hip): per-workgroup start/end stamps and placement
     if (a.dbg && threadIdx.x == 0) {
@@ -177,6 +188,8 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
     for (int i = tid; i < NC * W * 64; i += nthreads) st[i] = 0;
     for (int i = tid; i < ncls * 64; i += nthreads) hist[i] = 0;
     if (tid == 0) *stopf = 0;
+    if constexpr (kUsesGen)
+        for (int i = tid; i < gen_dw; i += nthreads) (lds + gdw - gen_dw)[i] = reinterpret_cast<const uint32_t *>(a.gen)[i];
     for (int i = tid; i < (NC - 1) * kSwapFast; i += nthreads) {
         // u < p_diff^d  <=>  x < thr; d = 0 always swaps and is never looked up (mcmc.py:146-149)
         const int pr = i / kSwapFast, d = i - pr * kSwapFast;
@@ -264,6 +277,51 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
         const bool acc_all = (a.acc_all_mask >> slot_u) & 1u;
         const bool top_logical = (slot_u == (uint32_t)(NC - 1)) && a.thr_logical != 0;
         const uint32_t *myT = thrT + slot_u * 9 + 4;
+        // sweep (scan = 1) of a top chain at f = 1 with table-driven logical masks: used by the plaquette codes and by
+        // toric L > 16 (the L <= 16 toric top chain has the frame-based fast path below)
+        auto blind_sweep_tables = [&]() {
+            const uint32_t *lmask = a.lmask;
+            const int LW = (L + 1) * W;
+            uint32_t gs = (uint32_t)(kbase % a.n_gen), cdelta = 0;
+            u32x4 coins{0, 0, 0, 0};
+            uint64_t cb_cur = ~0ull;
+            for (uint32_t j = 0; j < iters; ++j) {
+                const uint64_t k = kbase + j;
+                if ((k & 7) == 0) {                                                 // one random logical operator
+                    const u32x4 x = philox_block(k, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                    const uint32_t *m0 = lmask + L * W, *m1 = m0, *m2 = m0, *m3 = m0;   // identity rows
+                    if (CODE == kCodeToric) {
+                        const uint32_t op0 = x.y >> 30, op1 = x.z >> 30;
+                        const uint32_t dx0 = (op0 ^ (op0 >> 1)) & 1u, dz0 = op0 >> 1, dx1 = (op1 ^ (op1 >> 1)) & 1u, dz1 = op1 >> 1;
+                        if (dx0) m0 = lmask + scale_low30(x.y, L) * W;
+                        if (dz0) m1 = lmask + LW + scale_u16(x.w >> 16, L) * W;
+                        if (dx1) m2 = lmask + 2 * LW + scale_low30(x.z, L) * W;
+                        if (dz1) m3 = lmask + 3 * LW + scale_u16(x.w & 0xFFFFu, L) * W;
+                        cdelta ^= (L & 1) ? (dx0 | (dz0 << 1) | (dx1 << 2) | (dz1 << 3)) : 0u;
+                    } else {
+                        const uint32_t op = x.y >> 30;
+                        const uint32_t xp = ((op ^ (op >> 1)) & 1u) ? scale_low30(x.y, L) : 0u, zp = (op >> 1) ? scale_u16(x.w >> 16, L) : 0u;
+                        const uint32_t ax = CODE == kCodeXzzx ? ((op ^ (op >> 1)) & 1u) : (op & 1u), az = op >> 1;
+                        if (ax) m0 = lmask + xp * W;
+                        if (az) m1 = lmask + LW + zp * W;
+                        cdelta ^= ax | (az << 1);
+                    }
+                    for (int w = 0; w < W; ++w) lds_xor(stw + w * 64, m0[w] ^ m1[w] ^ m2[w] ^ m3[w]);
+                }
+                if ((k >> 7) != cb_cur) { cb_cur = k >> 7; coins = philox_block(cb_cur, 3, syn, slot_u, a.seed_lo, a.seed_hi); }
+                const uint2 ev = gtab[gs];
+                gs = gs + 1 == a.n_gen ? 0u : gs + 1;
+                if ((sel4(coins, (int)((k >> 5) & 3)) >> (k & 31)) & 1u) {
+                    const uint32_t ent[4] = {ev.x & 0xFFFFu, ev.x >> 16, ev.y & 0xFFFFu, ev.y >> 16};
+                    for (int i = 0; i < 4; ++i) lds_xor(stw + (ent[i] >> 6) * 64, (ent[i] & 3u) << (((ent[i] >> 2) & 15u) * 2u));
+                }
+            }
+            uint32_t cnt_n = 0;
+            for (int w = 0; w < W; ++w) cnt_n += nnz2(stw[w * 64]);
+            n = cnt_n;
+            cls ^= cdelta;
+        };
+
         if constexpr (CODE != kCodeToric || BIASED) {
             // ---------- XZZX / rotated codes and the biased acceptance rule ----------------------------
             const bool top = top_logical;
@@ -286,7 +344,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                         x = philox_block(kbase + j, 0, syn, slot_u, a.seed_lo, a.seed_hi);
                         g = surf_generator_index(L, x.x, x.y, x.z, a.thr_half);
                     }
-                    const uint2 e = a.gen[g];                                      // 4 x (site << 2 | pauli), 0 = no site
+                    const uint2 e = gtab[g];                                      // 4 x (site << 2 | pauli), 0 = no site
                     const uint32_t ent[4] = {e.x & 0xFFFFu, e.x >> 16, e.y & 0xFFFFu, e.y >> 16};
                     uint32_t *ad[4];
                     uint32_t sh[4], F = 0, OPS = 0;
@@ -307,6 +365,8 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                     }
                 }
                 n = (uint32_t)ni;
+            } else if (SCAN && top && acc_all) {
+                blind_sweep_tables();
             } else {
                 // general path: top chains (logical proposals, mcmc.py:20-35) and every biased chain
                 // (mcmc_biased.py:20-59: accept iff u < pn/pb with pb frozen at loop entry, quirk Q3)
@@ -357,7 +417,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                     } else {
                         const uint32_t wa = top ? x.y : x.x, wb = top ? x.z : x.y, wc = top ? x.w : x.z;
                         if constexpr (SCAN) {
-                            const uint2 e = a.gen[gs];
+                            const uint2 e = gtab[gs];
                             ent[0] = e.x & 0xFFFFu; ent[1] = e.x >> 16; ent[2] = e.y & 0xFFFFu; ent[3] = e.y >> 16;
                         } else if (CODE == kCodeToric) {
                             uint32_t q[4];
@@ -365,7 +425,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                             toric_sites(L, LL, scale_u32(wa, L), scale_u32(wb, L), isX, q);
                             for (int i = 0; i < 4; ++i) ent[i] = (q[i] << 2) | (isX ? 1u : 3u);
                         } else {
-                            const uint2 e = a.gen[surf_generator_index(L, wa, wb, wc, a.thr_half)];
+                            const uint2 e = gtab[surf_generator_index(L, wa, wb, wc, a.thr_half)];
                             ent[0] = e.x & 0xFFFFu; ent[1] = e.x >> 16; ent[2] = e.y & 0xFFFFu; ent[3] = e.y >> 16;
                         }
                         for (int i = 0; i < 4; ++i) {
@@ -382,8 +442,6 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                         const int mx = nx + dx, my = ny + dy, mz = nz + dz;
                         const double pn = bt[mx] * bt[T1 + my] * bt[2 * T1 + mz] * bt[3 * T1 + (nq - mx - my - mz)];
                         acc = (double)xa * (1.0 / 4294967296.0) < pn / pb;          // mcmc_biased.py:44-46
-                    } else if (SCAN && top && acc_all && !logical) {
-                        acc = x.w >> 31;                                            // sweep at f = 1: apply with probability 1/2
                     } else if (top) {
                         acc = acc_all || dE <= 0;                                   // mcmc.py:30
                         if (!acc) acc = philox_block(k, 2, syn, slot_u, a.seed_lo, a.seed_hi).x < a.acc_tbl_top[dE];   // :34
@@ -430,36 +488,41 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             };
             uint32_t j = 0;
             if constexpr (SCAN) {
-                // systematic sweep: generator k mod G (wave-uniform sites from the plan's table), one Philox
-                // block per four proposals
+                // systematic sweep: generator k mod G -- its sites are wave-uniform scalars from the plan's table --
+                // and one Philox block per four proposals (word k&3 of block k>>2): walk the blocks that overlap
+                // [kbase, kbase+iters) with a static word index
+                const uint64_t kend = kbase + iters;
                 uint32_t gs = (uint32_t)(kbase % a.n_gen);
-                u32x4 blk{0, 0, 0, 0};
-                uint64_t kb_cur = ~0ull;
-                for (; j < iters; ++j) {
-                    const uint64_t k = kbase + j;
-                    if ((k >> 2) != kb_cur) { kb_cur = k >> 2; blk = philox_block(kb_cur, 3, syn, slot_u, a.seed_lo, a.seed_hi); }
-                    const uint32_t xw = sel4(blk, (int)(k & 3));
-                    const uint2 e = a.gen[gs];
-                    gs = gs + 1 == a.n_gen ? 0u : gs + 1;
-                    const uint32_t ent[4] = {e.x & 0xFFFFu, e.x >> 16, e.y & 0xFFFFu, e.y >> 16};
-                    const uint32_t op = ent[0] & 3u;
-                    uint32_t *ad[4];
-                    uint32_t sh[4], F = 0;
+                for (uint64_t kb = kbase >> 2; (kb << 2) < kend; ++kb) {
+                    const u32x4 blk = philox_block(kb, 3, syn, slot_u, a.seed_lo, a.seed_hi);
+                    const uint32_t xs[4] = {blk.x, blk.y, blk.z, blk.w};
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const uint32_t q = ent[i] >> 2;
-                        ad[i] = stw + (q >> 4) * 64;
-                        sh[i] = (q & 15u) * 2u;
-                        F |= ((*ad[i] >> sh[i]) & 3u) << (2 * i);
-                    }
-                    const uint32_t G = F ^ (op * 0x55u);
-                    const int dE = __popc((G | (G >> 1)) & 0x55u) - __popc((F | (F >> 1)) & 0x55u);
-                    if (xw <= myT[dE]) {
+                    for (int wi = 0; wi < 4; ++wi) {
+                        const uint64_t k = (kb << 2) + wi;
+                        if (k < kbase || k >= kend) continue;                       // uniform
+                        const uint2 ev = gtab[gs];
+                        const uint32_t e0 = __builtin_amdgcn_readfirstlane(ev.x), e1 = __builtin_amdgcn_readfirstlane(ev.y);
+                        gs = gs + 1 == a.n_gen ? 0u : gs + 1;
+                        const uint32_t ent[4] = {e0 & 0xFFFFu, e0 >> 16, e1 & 0xFFFFu, e1 >> 16};
+                        const uint32_t op = e0 & 3u;
+                        uint32_t *ad[4];
+                        uint32_t sh[4], F = 0;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) lds_xor(ad[i], op << sh[i]);
-                        ni += dE;
+                        for (int i = 0; i < 4; ++i) {
+                            ad[i] = stw + (ent[i] >> 6) * 64;                      // scalar offsets
+                            sh[i] = ((ent[i] >> 2) & 15u) * 2u;
+                            F |= ((*ad[i] >> sh[i]) & 3u) << (2 * i);
+                        }
+                        const uint32_t G = F ^ (op * 0x55u);
+                        const int dE = __popc((G | (G >> 1)) & 0x55u) - __popc((F | (F >> 1)) & 0x55u);
+                        if (xs[wi] <= myT[dE]) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) lds_xor(ad[i], op << sh[i]);
+                            ni += dE;
+                        }
                     }
                 }
+                j = iters;
             }
             // the uniforms of a proposal do not depend on the state: draw two proposals' Philox blocks
             // together so their serial 10-round chains overlap, then apply the proposals in order
@@ -478,26 +541,40 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             //   fr0: bit r      = X on row r of layer 0      bit 16+c = Z on column c of layer 0
             //   fr1: bit c      = X on column c of layer 1   bit 16+r = Z on row r of layer 1
             uint32_t fr0 = 0, fr1 = 0, cdelta = 0;
-            for (uint32_t j = 0; j < iters; ++j) {
-                const u32x4 x = philox_block(kbase + j, 0, syn, slot_u, a.seed_lo, a.seed_hi);
-                if (x.x <= thrL1) {                                                 // mcmc.py:23
-                    // _apply_random_logical, toric_model.py:228-253
-                    const uint32_t op0 = x.y >> 30, op1 = x.z >> 30;
-                    const uint32_t dx0 = (op0 ^ (op0 >> 1)) & 1u, dz0 = op0 >> 1;   // X iff op in {1,2}; Z iff op in {2,3}
-                    const uint32_t dx1 = (op1 ^ (op1 >> 1)) & 1u, dz1 = op1 >> 1;
-                    const uint32_t x0 = scale_low30(x.y, L), z0 = scale_u16(x.w >> 16, L);
-                    const uint32_t x1 = scale_low30(x.z, L), z1 = scale_u16(x.w & 0xFFFFu, L);
-                    fr0 ^= (dx0 << x0) | (dz0 << (16 + z0));
-                    fr1 ^= (dx1 << x1) | (dz1 << (16 + z1));
-                    cdelta ^= dx0 | (dz0 << 1) | (dx1 << 2) | (dz1 << 3);
-                } else if constexpr (SCAN) {
-                    // sweep at f = 1: generator k mod G with probability 1/2 (a coin-less sweep composes to the identity)
-                    const uint2 e = a.gen[(uint32_t)((kbase + j) % a.n_gen)];
-                    const uint32_t ent[4] = {e.x & 0xFFFFu, e.x >> 16, e.y & 0xFFFFu, e.y >> 16};
-                    if (x.w >> 31) {
+            auto add_logical = [&](const u32x4 &x) {                                // _apply_random_logical, toric_model.py:228-253
+                const uint32_t op0 = x.y >> 30, op1 = x.z >> 30;
+                const uint32_t dx0 = (op0 ^ (op0 >> 1)) & 1u, dz0 = op0 >> 1;       // X iff op in {1,2}; Z iff op in {2,3}
+                const uint32_t dx1 = (op1 ^ (op1 >> 1)) & 1u, dz1 = op1 >> 1;
+                const uint32_t x0 = scale_low30(x.y, L), z0 = scale_u16(x.w >> 16, L);
+                const uint32_t x1 = scale_low30(x.z, L), z1 = scale_u16(x.w & 0xFFFFu, L);
+                fr0 ^= (dx0 << x0) | (dz0 << (16 + z0));
+                fr1 ^= (dx1 << x1) | (dz1 << (16 + z1));
+                cdelta ^= dx0 | (dz0 << 1) | (dx1 << 2) | (dz1 << 3);
+            };
+            if constexpr (SCAN) {
+                // sweep at f = 1: generator k mod G with probability 1/2 (coin bit k&31 of word (k>>5)&3 of block
+                // k>>7; a coin-less sweep composes to the identity) and one random logical every 8th proposal
+                uint32_t gs = (uint32_t)(kbase % a.n_gen);
+                u32x4 coins{0, 0, 0, 0};
+                uint64_t cb_cur = ~0ull;
+                for (uint32_t j = 0; j < iters; ++j) {
+                    const uint64_t k = kbase + j;
+                    if ((k & 7) == 0) add_logical(philox_block(k, 0, syn, slot_u, a.seed_lo, a.seed_hi));
+                    if ((k >> 7) != cb_cur) { cb_cur = k >> 7; coins = philox_block(cb_cur, 3, syn, slot_u, a.seed_lo, a.seed_hi); }
+                    const uint2 ev = gtab[gs];
+                    const uint32_t e0 = __builtin_amdgcn_readfirstlane(ev.x), e1 = __builtin_amdgcn_readfirstlane(ev.y);
+                    gs = gs + 1 == a.n_gen ? 0u : gs + 1;
+                    if ((sel4(coins, (int)((k >> 5) & 3)) >> (k & 31)) & 1u) {
+                        const uint32_t ent[4] = {e0 & 0xFFFFu, e0 >> 16, e1 & 0xFFFFu, e1 >> 16};
 #pragma unroll
                         for (int i = 0; i < 4; ++i) lds_xor(stw + (ent[i] >> 6) * 64, (ent[i] & 3u) << (((ent[i] >> 2) & 15u) * 2u));
                     }
+                }
+            } else
+            for (uint32_t j = 0; j < iters; ++j) {
+                const u32x4 x = philox_block(kbase + j, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                if (x.x <= thrL1) {                                                 // mcmc.py:23
+                    add_logical(x);
                 } else {
                     const uint32_t row = scale_u32(x.y, L), col = scale_u32(x.z, L), isX = x.w >> 31;
                     uint32_t q[4];
@@ -533,6 +610,8 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             n = 0;
             for (int w = 0; w < W; ++w) n += nnz2(stw[w * 64]);
             if (Lodd) cls ^= cdelta;
+        } else if (SCAN && acc_all) {
+            if constexpr (SCAN) blind_sweep_tables();                               // toric L > 16 at f = 1
         } else {
             // general top chain (L > 16, or a 1-chain ladder whose top sits below p = 0.75):
             // table-driven logical operators and the full Metropolis test, mcmc.py:20-35
@@ -565,7 +644,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 } else {
                     uint32_t q[4], op;
                     if constexpr (SCAN) {                                          // generator k mod G from the plan's table
-                        const uint2 e = a.gen[(uint32_t)(k % a.n_gen)];
+                        const uint2 e = gtab[(uint32_t)(k % a.n_gen)];
                         q[0] = (e.x & 0xFFFFu) >> 2; q[1] = e.x >> 18; q[2] = (e.y & 0xFFFFu) >> 2; q[3] = e.y >> 18;
                         op = e.x & 3u;
                     } else {
@@ -579,8 +658,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                         dE += (int)(f == 0u) - (int)(f == op);
                     }
                     bool acc = true;
-                    if (SCAN && acc_all) acc = x.w >> 31;                           // sweep at f = 1: probability 1/2
-                    else if (!acc_all && dE > 0) acc = philox_block(k, 2, syn, slot_u, a.seed_lo, a.seed_hi).x < a.acc_tbl_top[dE];
+                    if (!acc_all && dE > 0) acc = philox_block(k, 2, syn, slot_u, a.seed_lo, a.seed_hi).x < a.acc_tbl_top[dE];
                     if (acc) {
                         for (int i = 0; i < 4; ++i) lds_xor(stw + (q[i] >> 4) * 64, op << ((q[i] & 15u) * 2u));
                         ni += dE;
@@ -607,7 +685,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
         }
         __syncthreads();
         if (CONV) {                                         // flags set one step earlier: uniform for the workgroup
-            volatile uint32_t *f0 = lds_all + gdw - 16;
+            volatile uint32_t *f0 = lds_all + (NC * W * 64 + 4 * NC * 64 + ncls * 64 + NC * 9 + NC * kSwapFast);
             if (f0[0] && (GROUPS == 1 || f0[gdw])) break;
         }
         {
@@ -615,7 +693,11 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             // being carried down, `mine` the one that ends in the slot this wave takes over next
             slot_u = slot_u + 1 == (uint32_t)NC ? 0u : slot_u + 1;
             uint32_t car = cur[(NC - 1) * 64], mine = car;
+            // a wave only needs the cascade down to the rung that fills its own next slot (wave 0 also does the
+            // slot-0 bookkeeping and runs it to the bottom)
+            const int i_stop = (wave_u == 0 || slot_u == 0) ? 0 : (int)slot_u - 1;
             for (int i = NC - 2; i >= 0; --i) {                                    // mcmc.py:96
+                if (i < i_stop) continue;
                 const uint32_t lo = cur[i * 64], xi = sx[i * 64];
                 const int d = (int)(car & 0xFFFFu) - (int)(lo & 0xFFFFu);          // ne_hi - ne_lo
                 bool flip = d <= 0;                                                 // _r_flip :146, and u < rel_p**0 = 1
@@ -706,7 +788,8 @@ hipError_t launch_ladder_rs_toric(const LadderArgs &a, hipStream_t stream)
 {
     unsigned grid = (unsigned)((a.N + 63) / 64);
     unsigned block = (unsigned)a.Nc * 64u;
-    size_t lds = ladder_lds_bytes(a.L, a.Nc, a.W, a.ncls);
+    const bool uses_gen = a.scan || a.code != kCodeToric;
+    size_t lds = ladder_lds_bytes(a.L, a.Nc, a.W, a.ncls, uses_gen ? 2 * (int)a.n_gen : 0);
     if (grid == 0) return hipSuccess;
     // Nc <= 8: two 64-syndrome groups per workgroup (<= 1024 threads, 2 workgroups = 32 waves per CU);
     // Nc > 8: one group (<= 1024 threads)

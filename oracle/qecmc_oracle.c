@@ -296,9 +296,12 @@ static int model_sweep_stabilizer(const orc_model *m, const uint8_t *in, uint8_t
 }
 
 /* Systematic-sweep Metropolis (scan = 1).  Non-top chains: generator k mod G, accepted iff u < f^dE with u = word
- * k&3 of Philox block (k>>2, sub 3).  Top chain: block (k,0) as in random scan -- word 0 selects a logical proposal;
- * otherwise generator k mod G is applied with probability 1/2 when p >= 0.75 (top bit of word 3: without the coin a
- * full sweep at f = 1 would compose to the identity), or by the Metropolis rule below p = 0.75. */
+ * k&3 of Philox block (k>>2, sub 3).  Top chain at p >= 0.75 (every move is accepted): generator k mod G is applied
+ * with probability 1/2 (coin = bit k&31 of word (k>>5)&3 of block (k>>7, sub 3); without the coin a full sweep at
+ * f = 1 would compose to the identity), and every 8th proposal (k mod 8 == 0) also applies one uniformly random
+ * logical operator drawn as in random scan from block (k, 0) -- a single one already randomises the class.  A top
+ * chain below p = 0.75 (1-chain ladder) keeps the per-proposal rule: word 0 of block (k,0) selects a logical
+ * proposal, otherwise generator k mod G, Metropolis test with block (k,2). */
 static void chain_update_sweep(const orc_model *m, uint8_t *state, double p, double p_logical, uint64_t iters,
                                orc_rng *rng, uint32_t slot, uint64_t k0, uint8_t *scratch)
 {
@@ -306,18 +309,18 @@ static void chain_update_sweep(const orc_model *m, uint8_t *state, double p, dou
     const double factor = (p / 3.0) / (1.0 - p);
     for (uint64_t j = 0; j < iters; ++j) {
         const uint64_t k = k0 + j;
-        if (p_logical != 0) {
-            int dE;
-            if (orc_draw(rng, slot, k, 0, 0) < p_logical) {
-                dE = model_random_logical(m, state, scratch, rng, slot, k);
-            } else {
-                dE = model_sweep_stabilizer(m, state, scratch, k);
-                if (p >= 0.75) {
-                    if (orc_draw(rng, slot, k, 0, 3) >= 0.5) memcpy(state, scratch, nq);
-                    continue;
-                }
+        if (p_logical != 0 && p >= 0.75) {
+            if ((k & 7) == 0) {
+                model_random_logical(m, state, scratch, rng, slot, k);
+                memcpy(state, scratch, nq);
             }
-            if (p >= 0.75 || dE <= 0 || orc_draw(rng, slot, k, 2, 0) < pow(factor, (double)dE)) memcpy(state, scratch, nq);
+            model_sweep_stabilizer(m, state, scratch, k);
+            if (orc_draw_field(rng, slot, k >> 7, 3, (int)((k >> 5) & 3), 31 - (int)(k & 31), 1) >= 0.5) memcpy(state, scratch, nq);
+        } else if (p_logical != 0) {
+            int dE;
+            if (orc_draw(rng, slot, k, 0, 0) < p_logical) dE = model_random_logical(m, state, scratch, rng, slot, k);
+            else dE = model_sweep_stabilizer(m, state, scratch, k);
+            if (dE <= 0 || orc_draw(rng, slot, k, 2, 0) < pow(factor, (double)dE)) memcpy(state, scratch, nq);
         } else {
             const int dE = model_sweep_stabilizer(m, state, scratch, k);
             if (orc_draw(rng, slot, k >> 2, 3, (int)(k & 3)) < pow(factor, (double)dE)) memcpy(state, scratch, nq);
