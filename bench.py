@@ -239,6 +239,27 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline and toric and args.scan == "random":
             out["cpu_baseline"] = cpu_baseline(init_h, args.p, Nc, args.iters, args.seed)
+        if world == 1 and toric and args.scan == "random" and args.eta is None:
+            # the library's second scan mode on the same batch, for the record (`value` above is the reference's chain)
+            pr2 = L_.make_params(code=code_id, L=L, Nc=Nc, p=args.p, p_logical=args.p_logical, iters=args.iters,
+                                 steps=args.ladder_steps, tops_burn=2, seed=args.seed, device=local_rank,
+                                 scan=L_.SCAN_CHECKERBOARD)
+            plan2 = C.c_void_p()
+            L_.check(L_.lib().qecmc_plan_create(pr2, C.byref(plan2)))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for rep in range(2):
+                e0.record(stream)
+                L_.check(L_.lib().qecmc_pteq_launch_dev(plan2, d_init.data_ptr(), N, first, d_counts.data_ptr(),
+                                                        d_samples.data_ptr(), d_tops0.data_ptr(), None, None, None, None,
+                                                        C.c_void_p(stream.cuda_stream)))
+                e1.record(stream)
+                torch.cuda.synchronize()
+            ms2 = e0.elapsed_time(e1)
+            out["sweep_scan"] = {"note": "scan=1: systematic generator sweep (not the reference's chain; same stationary law, "
+                                         "validated against exact enumeration), same batch and ladder steps",
+                                 "kernel_ms_per_launch": ms2, "proposals_per_s": proposals_per_pass / (ms2 * 1e-3),
+                                 "chain_sweeps_per_s": proposals_per_pass / nq / (ms2 * 1e-3)}
+            L_.lib().qecmc_plan_destroy(plan2)
         print(json.dumps(out))
     L_.lib().qecmc_plan_destroy(plan)
     if world > 1:

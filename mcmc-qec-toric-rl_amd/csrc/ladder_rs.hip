@@ -493,6 +493,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 // [kbase, kbase+iters) with a static word index
                 const uint64_t kend = kbase + iters;
                 uint32_t gs = (uint32_t)(kbase % a.n_gen);
+                uint2 ev = gtab[gs];                                               // entry of the next proposal, fetched one ahead
                 for (uint64_t kb = kbase >> 2; (kb << 2) < kend; ++kb) {
                     const u32x4 blk = philox_block(kb, 3, syn, slot_u, a.seed_lo, a.seed_hi);
                     const uint32_t xs[4] = {blk.x, blk.y, blk.z, blk.w};
@@ -500,19 +501,21 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                     for (int wi = 0; wi < 4; ++wi) {
                         const uint64_t k = (kb << 2) + wi;
                         if (k < kbase || k >= kend) continue;                       // uniform
-                        const uint2 ev = gtab[gs];
                         const uint32_t e0 = __builtin_amdgcn_readfirstlane(ev.x), e1 = __builtin_amdgcn_readfirstlane(ev.y);
                         gs = gs + 1 == a.n_gen ? 0u : gs + 1;
+                        ev = gtab[gs];
                         const uint32_t ent[4] = {e0 & 0xFFFFu, e0 >> 16, e1 & 0xFFFFu, e1 >> 16};
                         const uint32_t op = e0 & 3u;
                         uint32_t *ad[4];
-                        uint32_t sh[4], F = 0;
+                        uint32_t sh[4], wv[4], F = 0;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             ad[i] = stw + (ent[i] >> 6) * 64;                      // scalar offsets
                             sh[i] = ((ent[i] >> 2) & 15u) * 2u;
-                            F |= ((*ad[i] >> sh[i]) & 3u) << (2 * i);
+                            wv[i] = *ad[i];                                        // all four reads in flight before the first use
                         }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) F |= ((wv[i] >> sh[i]) & 3u) << (2 * i);
                         const uint32_t G = F ^ (op * 0x55u);
                         const int dE = __popc((G | (G >> 1)) & 0x55u) - __popc((F | (F >> 1)) & 0x55u);
                         if (xs[wi] <= myT[dE]) {
