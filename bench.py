@@ -133,7 +133,8 @@ def main():
         raise RuntimeError("bench.py needs a GPU: the product has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)   # launched by torch.distributed.run
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)   # RCCL
 
@@ -153,7 +154,7 @@ def main():
     d_counts = torch.zeros((N, ncls), dtype=torch.int32, device=dev)
     d_samples = torch.zeros(N, dtype=torch.int32, device=dev)
     d_tops0 = torch.zeros(N, dtype=torch.int32, device=dev)
-    gathered = [torch.zeros_like(d_counts) for _ in range(world)] if (world > 1 and rank == 0) else None
+    gathered = [torch.zeros_like(d_counts) for _ in range(world)] if (use_dist and rank == 0) else None
 
     pr = L_.make_params(code=code_id, L=L, Nc=Nc, p=args.p, p_logical=args.p_logical, iters=args.iters,
                         steps=args.ladder_steps, tops_burn=2, seed=args.seed, device=local_rank,
@@ -171,13 +172,13 @@ def main():
                                                 C.c_void_p(stream.cuda_stream)))
 
     def exchange():
-        if world > 1:                                   # the path's one exchange step: per-class counts -> rank 0
+        if use_dist:                                    # the path's one exchange step: per-class counts -> rank 0
             dist.gather(d_counts, gathered, dst=0)
 
     for _ in range(args.warmup):
         one_pass(); exchange()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -186,14 +187,14 @@ def main():
         a.record(stream); one_pass(); b.record(stream)
         exchange()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -262,7 +263,7 @@ def main():
             L_.lib().qecmc_plan_destroy(plan2)
         print(json.dumps(out))
     L_.lib().qecmc_plan_destroy(plan)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
