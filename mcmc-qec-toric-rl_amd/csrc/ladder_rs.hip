@@ -160,7 +160,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
     const int nthreads = NC * 64;                 // threads of one group
     const int grp = (GROUPS == 1) ? 0 : ((int)threadIdx.x >= nthreads);
     const int tid = (int)threadIdx.x - grp * nthreads, lane = tid & 63, slot = tid >> 6;
-    constexpr bool kUsesGen = SCAN || CODE != kCodeToric;      // paths that look generators up in the plan's table
+    constexpr bool kUsesGen = true;                             // every path looks generators up in the plan's table
     const int gen_dw = kUsesGen ? 2 * (int)a.n_gen : 0;
     const int gdw = ladder_group_dwords(NC, W, ncls, gen_dw);   // dwords per group
     uint32_t *lds = lds_all + grp * gdw;
@@ -467,14 +467,14 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             auto propose = [&](const u32x4 &x) {
                 const uint32_t row = scale_u32(x.x, L), col = scale_u32(x.y, L);   // toric_model.py:291-292
                 const uint32_t isX = x.z >> 31;                                    // :293-295
-                uint32_t q[4];
-                toric_sites(L, LL, row, col, isX, q);
+                const uint2 ev = gtab[(isX ? 0u : (uint32_t)LL) + row * L + col];  // the four sites (toric_model.py:261-269)
+                const uint32_t ent[4] = {ev.x & 0xFFFFu, ev.x >> 16, ev.y & 0xFFFFu, ev.y >> 16};
                 uint32_t *ad[4];
                 uint32_t sh[4], F = 0;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    ad[i] = stw + (q[i] >> 4) * 64;
-                    sh[i] = (q[i] & 15u) * 2u;
+                    ad[i] = stw + (ent[i] >> 6) * 64;
+                    sh[i] = ((ent[i] >> 2) & 15u) * 2u;
                     F |= ((*ad[i] >> sh[i]) & 3u) << (2 * i);
                 }
                 const uint32_t op = isX ? 1u : 3u;
@@ -580,11 +580,10 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                     add_logical(x);
                 } else {
                     const uint32_t row = scale_u32(x.y, L), col = scale_u32(x.z, L), isX = x.w >> 31;
-                    uint32_t q[4];
-                    toric_sites(L, LL, row, col, isX, q);
-                    const uint32_t op = isX ? 1u : 3u;
+                    const uint2 ev = gtab[(isX ? 0u : (uint32_t)LL) + row * L + col];
+                    const uint32_t ent[4] = {ev.x & 0xFFFFu, ev.x >> 16, ev.y & 0xFFFFu, ev.y >> 16};
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) lds_xor(stw + (q[i] >> 4) * 64, op << ((q[i] & 15u) * 2u));
+                    for (int i = 0; i < 4; ++i) lds_xor(stw + (ent[i] >> 6) * 64, (ent[i] & 3u) << (((ent[i] >> 2) & 15u) * 2u));
                 }
             }
             // flush the frame: lattice row r of layer l is the 2L-bit span at bit 2*(l*LL + r*L)
@@ -791,7 +790,7 @@ hipError_t launch_ladder_rs_toric(const LadderArgs &a, hipStream_t stream)
 {
     unsigned grid = (unsigned)((a.N + 63) / 64);
     unsigned block = (unsigned)a.Nc * 64u;
-    const bool uses_gen = a.scan || a.code != kCodeToric;
+    const bool uses_gen = true;
     size_t lds = ladder_lds_bytes(a.L, a.Nc, a.W, a.ncls, uses_gen ? 2 * (int)a.n_gen : 0);
     if (grid == 0) return hipSuccess;
     // Nc <= 8: two 64-syndrome groups per workgroup (<= 1024 threads, 2 workgroups = 32 waves per CU);
