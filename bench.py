@@ -120,6 +120,7 @@ def main():
     ap.add_argument("--scan", default="random", choices=["random", "sweep"],
                     help="random = the reference's random-scan chain; sweep = systematic generator sweep (scan=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the extra scan=1 measurement (profiling runs)")
     args = ap.parse_args()
 
     import torch
@@ -240,7 +241,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline and toric and args.scan == "random":
             out["cpu_baseline"] = cpu_baseline(init_h, args.p, Nc, args.iters, args.seed)
-        if world == 1 and toric and args.scan == "random" and args.eta is None:
+        if world == 1 and toric and args.scan == "random" and args.eta is None and not args.no_sweep:
             # the library's second scan mode on the same batch, for the record (`value` above is the reference's chain)
             pr2 = L_.make_params(code=code_id, L=L, Nc=Nc, p=args.p, p_logical=args.p_logical, iters=args.iters,
                                  steps=args.ladder_steps, tops_burn=2, seed=args.seed, device=local_rank,

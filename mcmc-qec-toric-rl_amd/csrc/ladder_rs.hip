@@ -152,7 +152,10 @@ __device__ __forceinline__ uint32_t pack_info(uint32_t n, uint32_t sid, uint32_t
 // The tuned paths are toric + depolarizing; the other combinations share the staging, cascade and bookkeeping.
 // SCAN: false = the reference's random scan; true = systematic sweep (proposal k tests generator k mod G):
 // sites are wave-uniform scalars and one Philox block feeds four proposals.
-template <int MAXT, int MINW, bool CONV, int GROUPS, int CODE, bool BIASED, bool SCAN>
+// GENTOP: keep the table-driven general top-chain path (toric L > 16, or a 1-chain ladder whose top sits below
+// p = 0.75; always needed by the plaquette codes and the biased rule).  The common toric configurations compile it out,
+// which keeps its registers out of the hot loop.
+template <int MAXT, int MINW, bool CONV, int GROUPS, int CODE, bool BIASED, bool SCAN, bool GENTOP>
 __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const LadderArgs a)
 {
     extern __shared__ uint32_t lds_all[];
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
         const uint32_t *myT = thrT + slot_u * 9 + 4;
         // sweep (scan = 1) of a top chain at f = 1 with table-driven logical masks: used by the plaquette codes and by
         // toric L > 16 (the L <= 16 toric top chain has the frame-based fast path below)
-        auto blind_sweep_tables = [&]() {
+        [[maybe_unused]] auto blind_sweep_tables = [&]() {
             const uint32_t *lmask = a.lmask;
             const int LW = (L + 1) * W;
             uint32_t gs = (uint32_t)(kbase % a.n_gen), cdelta = 0;
@@ -613,8 +616,8 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             for (int w = 0; w < W; ++w) n += nnz2(stw[w * 64]);
             if (Lodd) cls ^= cdelta;
         } else if (SCAN && acc_all) {
-            if constexpr (SCAN) blind_sweep_tables();                               // toric L > 16 at f = 1
-        } else {
+            if constexpr (SCAN && GENTOP) blind_sweep_tables();                     // toric L > 16 at f = 1
+        } else if constexpr (GENTOP) {
             // general top chain (L > 16, or a 1-chain ladder whose top sits below p = 0.75):
             // table-driven logical operators and the full Metropolis test, mcmc.py:20-35
             int ni = (int)n;
@@ -811,23 +814,33 @@ hipError_t launch_ladder_rs_toric(const LadderArgs &a, hipStream_t stream)
     lds *= groups;
     const void *fn;
     constexpr int T = kCodeToric, X = kCodeXzzx, R = kCodeRotated;
-#define QECMC_K(maxt, minw, g, code, biased) \
-    (a.scan ? (conv ? (const void *)ladder_rs_toric_kernel<maxt, minw, true, g, code, biased, true> : (const void *)ladder_rs_toric_kernel<maxt, minw, false, g, code, biased, true>) \
-            : (conv ? (const void *)ladder_rs_toric_kernel<maxt, minw, true, g, code, biased, false> : (const void *)ladder_rs_toric_kernel<maxt, minw, false, g, code, biased, false>))
+#define QECMC_K2(maxt, minw, g, code, biased, gentop) \
+    (a.scan ? (conv ? (const void *)ladder_rs_toric_kernel<maxt, minw, true, g, code, biased, true, gentop> : (const void *)ladder_rs_toric_kernel<maxt, minw, false, g, code, biased, true, gentop>) \
+            : (conv ? (const void *)ladder_rs_toric_kernel<maxt, minw, true, g, code, biased, false, gentop> : (const void *)ladder_rs_toric_kernel<maxt, minw, false, g, code, biased, false, gentop>))
+#define QECMC_K(maxt, minw, g, code, biased) QECMC_K2(maxt, minw, g, code, biased, true)
     if (a.code == T && !a.noise) {
-        if (groups == 2) fn = QECMC_K(1024, 8, 2, T, false);
-        else if (block <= 512) fn = QECMC_K(512, 8, 1, T, false);
-        else fn = QECMC_K(1024, 4, 1, T, false);
+        // the general top-chain path is needed only for L > 16 or a top chain below p = 0.75 (1-chain ladder)
+        const bool gentop = a.thr_logical != 0 && (a.L > 16 || !((a.acc_all_mask >> (a.Nc - 1)) & 1u));
+        if (gentop) {
+            if (groups == 2) fn = QECMC_K2(1024, 8, 2, T, false, true);
+            else if (block <= 512) fn = QECMC_K2(512, 8, 1, T, false, true);
+            else fn = QECMC_K2(1024, 4, 1, T, false, true);
+        } else {
+            if (groups == 2) fn = QECMC_K2(1024, 8, 2, T, false, false);
+            else if (block <= 512) fn = QECMC_K2(512, 8, 1, T, false, false);
+            else fn = QECMC_K2(1024, 4, 1, T, false, false);
+        }
     } else {
         // the other code / noise combinations run one group per workgroup (any Nc <= 16)
         grid *= groups; block /= groups; lds /= groups;
         if (a.code == X && !a.noise) fn = QECMC_K(1024, 4, 1, X, false);
         else if (a.code == R && !a.noise) fn = QECMC_K(1024, 4, 1, R, false);
         else if (a.scan) return hipErrorInvalidValue;          // the sweep is built for the depolarizing rule only
-        else if (a.code == X) fn = conv ? (const void *)ladder_rs_toric_kernel<1024, 4, true, 1, X, true, false> : (const void *)ladder_rs_toric_kernel<1024, 4, false, 1, X, true, false>;
-        else if (a.code == R) fn = conv ? (const void *)ladder_rs_toric_kernel<1024, 4, true, 1, R, true, false> : (const void *)ladder_rs_toric_kernel<1024, 4, false, 1, R, true, false>;
+        else if (a.code == X) fn = conv ? (const void *)ladder_rs_toric_kernel<1024, 4, true, 1, X, true, false, true> : (const void *)ladder_rs_toric_kernel<1024, 4, false, 1, X, true, false, true>;
+        else if (a.code == R) fn = conv ? (const void *)ladder_rs_toric_kernel<1024, 4, true, 1, R, true, false, true> : (const void *)ladder_rs_toric_kernel<1024, 4, false, 1, R, true, false, true>;
         else return hipErrorInvalidValue;
     }
+#undef QECMC_K2
 #undef QECMC_K
     if (lds > 64 * 1024) {   // beyond the default dynamic-LDS window (160 KiB per CU on gfx950)
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -4,7 +4,7 @@ tag=${1:-r00}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/profiles_$tag
 mkdir -p $out
-BENCH="bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+BENCH="bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-sweep"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 $BENCH > $out/bench_under_kernel_trace.json 2> $out/kt.log
 cp $out/kt/*/*_kernel_stats.csv $out/kernel_stats.csv
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 $BENCH > /dev/null 2> $out/pmc_fetch.log
