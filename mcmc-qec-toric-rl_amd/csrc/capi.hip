@@ -242,10 +242,9 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
     a.conv_mode = p->conv_mode; a.TOPS = (uint32_t)p->TOPS; a.SEQ = (uint32_t)p->SEQ; a.eps = p->eps;
     a.thr_logical = p->p_logical > 0 ? thr64(p->p_logical) : 0;
     const uint32_t n_gen = p->code == QECMC_TORIC ? 2u * L * L : (uint32_t)((L - 1) * (L - 1) + 2 * (L - 1));
-    const bool uses_gen = true;   // every kernel path stages the generator table in LDS
-    if (uses_gen && n_gen > kMaxGenLds)
+    if (n_gen > kMaxGenLds)   // every kernel path stages the generator table in LDS
         return fail(QECMC_ERR_UNSUPPORTED, "L=%d: %u generators exceed the LDS table of %u (needed by scan=1 and by the xzzx / rotated codes)", L, n_gen, kMaxGenLds);
-    pl->lds_bytes = ladder_lds_bytes(L, Nc, W, ncls, uses_gen ? 2 * (int)n_gen : 0);
+    pl->lds_bytes = ladder_lds_bytes(L, Nc, W, ncls, ladder_gen_dwords(p->code, p->noise, p->scan, n_gen));
     if (pl->lds_bytes > 160 * 1024)
         return fail(QECMC_ERR_UNSUPPORTED, "L=%d Nc=%d needs %zu B of LDS per workgroup (> 160 KiB)", L, Nc, pl->lds_bytes);
 

@@ -38,11 +38,10 @@ namespace qecmc {
 // LDS carve-up in dwords (keep in sync with the kernel)
 __host__ __device__ inline int ladder_group_dwords(int Nc, int W, int ncls, int gen_dwords)
 {
-    // st + info[2] + swx[2] + hist + thrT + swapT + stop flag (16) [+ generator table]; kept even so the
-    // generator table (uint2 entries) is 8-byte aligned
+    // st + info[2] + swx[2] + hist + thrT + swapT + stop flag (16) + generator table
     int d = Nc * W * 64 + 4 * Nc * 64 + ncls * 64 + Nc * 9 + Nc * kSwapFast + 16;
-    d += d & 1;
-    return d + gen_dwords;
+    d = (d + 3) & ~3;          // 16-byte aligned generator table (ds_read_b128 entries)
+    return d + ((gen_dwords + 3) & ~3);
 }
 
 size_t ladder_lds_bytes(int L, int Nc, int W, int ncls, int gen_dwords)
@@ -163,9 +162,12 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
     const int nthreads = NC * 64;                 // threads of one group
     const int grp = (GROUPS == 1) ? 0 : ((int)threadIdx.x >= nthreads);
     const int tid = (int)threadIdx.x - grp * nthreads, lane = tid & 63, slot = tid >> 6;
-    constexpr bool kUsesGen = true;                             // every path looks generators up in the plan's table
-    const int gen_dw = kUsesGen ? 2 * (int)a.n_gen : 0;
+    // generator table in LDS: 4 x u16 per generator as the plan stores it, or -- for the toric random-scan hot path --
+    // expanded to 4 x u32 (dword offset << 8 | pauli << 5 | bit shift) so a site costs a shift, an add and a bfe
+    constexpr bool kWideGen = CODE == kCodeToric && !BIASED && !SCAN;
+    const int gen_dw = (kWideGen ? 4 : 2) * (int)a.n_gen;
     const int gdw = ladder_group_dwords(NC, W, ncls, gen_dw);   // dwords per group
+    const int gen_off = gdw - ((gen_dw + 3) & ~3);               // start of the generator table
     uint32_t *lds = lds_all + grp * gdw;
 
     uint32_t *st = lds;                           // [NC][W][64]   packed states
@@ -175,7 +177,8 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
     uint32_t *thrT = hist + ncls * 64;            // [NC][9]       accept iff x <= thrT[slot][dE+4]
     uint32_t *swapT = thrT + NC * 9;              // [NC][kSwapFast]  swap iff x < swapT[i][d]
     volatile uint32_t *stopf = swapT + NC * kSwapFast;   // [1]  every syndrome of the workgroup has converged
-    const uint2 *gtab = reinterpret_cast<const uint2 *>(lds + gdw - gen_dw);   // [n_gen] generator table (LDS copy)
+    [[maybe_unused]] const uint2 *gtab = reinterpret_cast<const uint2 *>(lds + gen_off);   // [n_gen] generator table (LDS copy)
+    [[maybe_unused]] const uint4 *gtab4 = reinterpret_cast<const uint4 *>(lds + gen_off);  // wide form (kWideGen)
 
 #ifdef QECMC_TIMELINE   // diagnostic build only (tools/timeline.hip): per-workgroup start/end stamps and placement
     if (a.dbg && threadIdx.x == 0) {
@@ -191,8 +194,14 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
     for (int i = tid; i < NC * W * 64; i += nthreads) st[i] = 0;
     for (int i = tid; i < ncls * 64; i += nthreads) hist[i] = 0;
     if (tid == 0) *stopf = 0;
-    if constexpr (kUsesGen)
-        for (int i = tid; i < gen_dw; i += nthreads) (lds + gdw - gen_dw)[i] = reinterpret_cast<const uint32_t *>(a.gen)[i];
+    if constexpr (kWideGen) {
+        for (int i = tid; i < gen_dw; i += nthreads) {
+            const uint32_t e = reinterpret_cast<const uint16_t *>(a.gen)[i], q = e >> 2;
+            (lds + gen_off)[i] = (((q >> 4) * 64u) << 8) | ((e & 3u) << 5) | ((q & 15u) * 2u);
+        }
+    } else {
+        for (int i = tid; i < gen_dw; i += nthreads) (lds + gen_off)[i] = reinterpret_cast<const uint32_t *>(a.gen)[i];
+    }
     for (int i = tid; i < (NC - 1) * kSwapFast; i += nthreads) {
         // u < p_diff^d  <=>  x < thr; d = 0 always swaps and is never looked up (mcmc.py:146-149)
         const int pr = i / kSwapFast, d = i - pr * kSwapFast;
@@ -470,22 +479,21 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             auto propose = [&](const u32x4 &x) {
                 const uint32_t row = scale_u32(x.x, L), col = scale_u32(x.y, L);   // toric_model.py:291-292
                 const uint32_t isX = x.z >> 31;                                    // :293-295
-                const uint2 ev = gtab[(isX ? 0u : (uint32_t)LL) + row * L + col];  // the four sites (toric_model.py:261-269)
-                const uint32_t ent[4] = {ev.x & 0xFFFFu, ev.x >> 16, ev.y & 0xFFFFu, ev.y >> 16};
+                const uint4 ev = gtab4[(isX ? 0u : (uint32_t)LL) + row * L + col];   // the four sites (toric_model.py:261-269)
+                const uint32_t sh[4] = {ev.x, ev.y, ev.z, ev.w};                    // bit shift in [4:0] (shifts use only those)
                 uint32_t *ad[4];
-                uint32_t sh[4], F = 0;
+                uint32_t F = 0;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    ad[i] = stw + (ent[i] >> 6) * 64;
-                    sh[i] = ((ent[i] >> 2) & 15u) * 2u;
-                    F |= ((*ad[i] >> sh[i]) & 3u) << (2 * i);
+                    ad[i] = stw + (sh[i] >> 8);
+                    F |= ((*ad[i] >> (sh[i] & 31u)) & 3u) << (2 * i);
                 }
                 const uint32_t op = isX ? 1u : 3u;
                 const uint32_t G = F ^ (op * 0x55u);                               // the four new values
                 const int dE = __popc((G | (G >> 1)) & 0x55u) - __popc((F | (F >> 1)) & 0x55u);   // :275-282
                 if (x.w <= myT[dE]) {                                               // mcmc.py:42
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) lds_xor(ad[i], op << sh[i]);
+                    for (int i = 0; i < 4; ++i) lds_xor(ad[i], op << (sh[i] & 31u));
                     ni += dE;
                 }
             };
@@ -583,10 +591,11 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                     add_logical(x);
                 } else {
                     const uint32_t row = scale_u32(x.y, L), col = scale_u32(x.z, L), isX = x.w >> 31;
-                    const uint2 ev = gtab[(isX ? 0u : (uint32_t)LL) + row * L + col];
-                    const uint32_t ent[4] = {ev.x & 0xFFFFu, ev.x >> 16, ev.y & 0xFFFFu, ev.y >> 16};
+                    const uint4 ev = gtab4[(isX ? 0u : (uint32_t)LL) + row * L + col];
+                    const uint32_t e4[4] = {ev.x, ev.y, ev.z, ev.w};
+                    const uint32_t op = isX ? 1u : 3u;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) lds_xor(stw + (ent[i] >> 6) * 64, (ent[i] & 3u) << (((ent[i] >> 2) & 15u) * 2u));
+                    for (int i = 0; i < 4; ++i) lds_xor(stw + (e4[i] >> 8), op << (e4[i] & 31u));
                 }
             }
             // flush the frame: lattice row r of layer l is the 2L-bit span at bit 2*(l*LL + r*L)
@@ -793,8 +802,7 @@ hipError_t launch_ladder_rs_toric(const LadderArgs &a, hipStream_t stream)
 {
     unsigned grid = (unsigned)((a.N + 63) / 64);
     unsigned block = (unsigned)a.Nc * 64u;
-    const bool uses_gen = true;
-    size_t lds = ladder_lds_bytes(a.L, a.Nc, a.W, a.ncls, uses_gen ? 2 * (int)a.n_gen : 0);
+    size_t lds = ladder_lds_bytes(a.L, a.Nc, a.W, a.ncls, ladder_gen_dwords(a.code, a.noise, a.scan, a.n_gen));
     if (grid == 0) return hipSuccess;
     // Nc <= 8: two 64-syndrome groups per workgroup (<= 1024 threads, 2 workgroups = 32 waves per CU);
     // Nc > 8: one group (<= 1024 threads)
@@ -808,7 +816,7 @@ hipError_t launch_ladder_rs_toric(const LadderArgs &a, hipStream_t stream)
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    const int groups = (a.Nc <= 8 && a.N > 64 && grid <= 8u * (unsigned)n_cu) ? 2 : 1;
+    const int groups = (a.Nc <= 8 && a.N > 64 && grid <= 8u * (unsigned)n_cu && 2 * lds <= 160 * 1024) ? 2 : 1;
     grid = (grid + groups - 1) / groups;
     block *= groups;
     lds *= groups;
