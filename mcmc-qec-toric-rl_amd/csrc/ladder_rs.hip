@@ -379,6 +379,31 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 n = (uint32_t)ni;
             } else if (SCAN && top && acc_all) {
                 blind_sweep_tables();
+            } else if (!BIASED && top && acc_all) {
+                // random scan, top chain at f = 1 (mcmc.py:30): every proposal is applied blindly, n recounted once
+                const uint32_t *lmask = a.lmask;
+                const int LW = (L + 1) * W;
+                uint32_t cdelta = 0;
+                for (uint32_t j = 0; j < iters; ++j) {
+                    const u32x4 x = philox_block(kbase + j, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                    if (x.x <= thrL1) {                                             // logical (xzzx_model.py:340-357)
+                        const uint32_t op = x.y >> 30;
+                        const uint32_t xp = ((op ^ (op >> 1)) & 1u) ? scale_low30(x.y, L) : 0u, zp = (op >> 1) ? scale_u16(x.w >> 16, L) : 0u;
+                        const uint32_t ax = CODE == kCodeXzzx ? ((op ^ (op >> 1)) & 1u) : (op & 1u), az = op >> 1;
+                        const uint32_t *m0 = ax ? lmask + xp * W : lmask + L * W, *m1 = az ? lmask + LW + zp * W : lmask + L * W;
+                        for (int w = 0; w < W; ++w) lds_xor(stw + w * 64, m0[w] ^ m1[w]);
+                        cdelta ^= ax | (az << 1);
+                    } else {
+                        const uint2 e = gtab[surf_generator_index(L, x.y, x.z, x.w, a.thr_half)];
+                        const uint32_t ent[4] = {e.x & 0xFFFFu, e.x >> 16, e.y & 0xFFFFu, e.y >> 16};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) lds_xor(stw + (ent[i] >> 6) * 64, (ent[i] & 3u) << (((ent[i] >> 2) & 15u) * 2u));
+                    }
+                }
+                uint32_t cnt_n = 0;
+                for (int w = 0; w < W; ++w) cnt_n += nnz2(stw[w * 64]);
+                n = cnt_n;
+                cls ^= cdelta;
             } else {
                 // general path: top chains (logical proposals, mcmc.py:20-35) and every biased chain
                 // (mcmc_biased.py:20-59: accept iff u < pn/pb with pb frozen at loop entry, quirk Q3)
@@ -839,14 +864,25 @@ hipError_t launch_ladder_rs_toric(const LadderArgs &a, hipStream_t stream)
             else fn = QECMC_K2(1024, 4, 1, T, false, false);
         }
     } else {
-        // the other code / noise combinations run one group per workgroup (any Nc <= 16)
+        if (!a.noise && (a.code == X || a.code == R)) {
+            if (a.code == X) {
+                if (groups == 2) fn = QECMC_K(1024, 8, 2, X, false);
+                else if (block <= 512) fn = QECMC_K(512, 8, 1, X, false);
+                else fn = QECMC_K(1024, 4, 1, X, false);
+            } else {
+                if (groups == 2) fn = QECMC_K(1024, 8, 2, R, false);
+                else if (block <= 512) fn = QECMC_K(512, 8, 1, R, false);
+                else fn = QECMC_K(1024, 4, 1, R, false);
+            }
+        } else {
+        // the biased rule runs one group per workgroup (any Nc <= 16)
         grid *= groups; block /= groups; lds /= groups;
-        if (a.code == X && !a.noise) fn = QECMC_K(1024, 4, 1, X, false);
-        else if (a.code == R && !a.noise) fn = QECMC_K(1024, 4, 1, R, false);
+        if (false) {}
         else if (a.scan) return hipErrorInvalidValue;          // the sweep is built for the depolarizing rule only
         else if (a.code == X) fn = conv ? (const void *)ladder_rs_toric_kernel<1024, 4, true, 1, X, true, false, true> : (const void *)ladder_rs_toric_kernel<1024, 4, false, 1, X, true, false, true>;
         else if (a.code == R) fn = conv ? (const void *)ladder_rs_toric_kernel<1024, 4, true, 1, R, true, false, true> : (const void *)ladder_rs_toric_kernel<1024, 4, false, 1, R, true, false, true>;
         else return hipErrorInvalidValue;
+        }
     }
 #undef QECMC_K2
 #undef QECMC_K
