@@ -712,11 +712,13 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
         // (double-buffered by step parity: a fast wave may publish step t+1 while a slow one still reads step t)
         uint32_t *cur = info + (t & 1) * NC * 64 + lane, *sx = swx + (t & 1) * NC * 64 + lane;
         cur[slot_u * 64] = pack_info(n, sid, cls, flag);
-        if (wave_u < 4 && (int)wave_u * 4 < NC - 1) {
-            // the sweep's uniforms do not depend on the state: waves 0..3 draw one Philox block each
-            const u32x4 b = philox_block(a.step0 + t, wave_u, syn, kSwapStream, a.seed_lo, a.seed_hi);
-            uint32_t *p = sx + wave_u * 4 * 64;                    // rows 4b .. 4b+3 = rung pairs, NC-1 of them exist
-            const int left = NC - 1 - (int)wave_u * 4;
+        const int swb = NC - 2 - (int)slot_u;                     // Philox block of swap uniforms this wave draws (if any)
+        if (swb >= 0 && swb < 4 && swb * 4 < NC - 1) {
+            // the sweep's uniforms do not depend on the state: the slots just below the top (never the
+            // heavier top slot itself) draw one Philox block each
+            const u32x4 b = philox_block(a.step0 + t, (uint32_t)swb, syn, kSwapStream, a.seed_lo, a.seed_hi);
+            uint32_t *p = sx + swb * 4 * 64;                       // rows 4b .. 4b+3 = rung pairs, NC-1 of them exist
+            const int left = NC - 1 - swb * 4;
             p[0] = b.x;
             if (left > 1) p[64] = b.y;
             if (left > 2) p[128] = b.z;
@@ -730,7 +732,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
         {
             // every wave replays the top-down cascade on the published records; `car` is the record
             // being carried down, `mine` the one that ends in the slot this wave takes over next
-            slot_u = slot_u + 1 == (uint32_t)NC ? 0u : slot_u + 1;
+            slot_u = slot_u == 0 ? (uint32_t)(NC - 1) : slot_u - 1;   // downwards: the wave leaving the top slot needs one rung only
             uint32_t car = cur[(NC - 1) * 64], mine = car;
             // a wave only needs the cascade down to the rung that fills its own next slot (wave 0 also does the
             // slot-0 bookkeeping and runs it to the bottom)
