@@ -54,7 +54,7 @@ struct LadderArgs {
 size_t ladder_lds_bytes(int L, int Nc, int W, int ncls, int gen_dwords);
 constexpr uint32_t kMaxGenLds = 2048;   // generator tables up to this many entries are staged in LDS
 // dwords of the LDS generator table: the toric random-scan kernels expand each generator to 4 x u32
-// (dword offset << 8 | pauli << 5 | bit shift), the other paths keep the plan's 4 x u16 form
+// (dword offset << 10 | pauli << 5 | bit shift), the other paths keep the plan's 4 x u16 form
 inline int ladder_gen_dwords(int code, int noise, int scan, uint32_t n_gen) { return (code == 0 && !noise && !scan ? 4 : 2) * (int)n_gen; }
 hipError_t launch_ladder_rs_toric(const LadderArgs &a, hipStream_t stream);
 

@@ -57,6 +57,21 @@ __device__ __forceinline__ uint32_t sel4(const u32x4 &b, int i)
     return i == 0 ? b.x : i == 1 ? b.y : i == 2 ? b.z : b.w;
 }
 
+// single-instruction forms that rely on the hardware using only bits [4:0] of a shift / field offset (the compiler
+// otherwise materialises the `& 31`)
+__device__ __forceinline__ uint32_t bfe2_lo5(uint32_t w, uint32_t e)
+{
+    uint32_t r;
+    asm("v_bfe_u32 %0, %1, %2, 2" : "=v"(r) : "v"(w), "v"(e));
+    return r;
+}
+__device__ __forceinline__ uint32_t shl_lo5(uint32_t v, uint32_t e)
+{
+    uint32_t r;
+    asm("v_lshlrev_b32 %0, %1, %2" : "=v"(r) : "v"(e), "v"(v));
+    return r;
+}
+
 __device__ __forceinline__ void lds_xor(uint32_t *p, uint32_t v)
 {
     __hip_atomic_fetch_xor(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_xor_b32, no return
@@ -163,7 +178,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
     const int grp = (GROUPS == 1) ? 0 : ((int)threadIdx.x >= nthreads);
     const int tid = (int)threadIdx.x - grp * nthreads, lane = tid & 63, slot = tid >> 6;
     // generator table in LDS: 4 x u16 per generator as the plan stores it, or -- for the toric random-scan hot path --
-    // expanded to 4 x u32 (dword offset << 8 | pauli << 5 | bit shift) so a site costs a shift, an add and a bfe
+    // expanded to 4 x u32 (dword offset << 10 | pauli << 5 | bit shift) so a site costs a shift, a shift-add and a bfe
     constexpr bool kWideGen = CODE == kCodeToric && !BIASED && !SCAN;
     const int gen_dw = (kWideGen ? 4 : 2) * (int)a.n_gen;
     const int gdw = ladder_group_dwords(NC, W, ncls, gen_dw);   // dwords per group
@@ -197,7 +212,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
     if constexpr (kWideGen) {
         for (int i = tid; i < gen_dw; i += nthreads) {
             const uint32_t e = reinterpret_cast<const uint16_t *>(a.gen)[i], q = e >> 2;
-            (lds + gen_off)[i] = (((q >> 4) * 64u) << 8) | ((e & 3u) << 5) | ((q & 15u) * 2u);
+            (lds + gen_off)[i] = (((q >> 4) * 64u) << 10) | ((e & 3u) << 5) | ((q & 15u) * 2u);   // dword offset << 10
         }
     } else {
         for (int i = tid; i < gen_dw; i += nthreads) (lds + gen_off)[i] = reinterpret_cast<const uint32_t *>(a.gen)[i];
@@ -505,20 +520,20 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 const uint32_t row = scale_u32(x.x, L), col = scale_u32(x.y, L);   // toric_model.py:291-292
                 const uint32_t isX = x.z >> 31;                                    // :293-295
                 const uint4 ev = gtab4[(isX ? 0u : (uint32_t)LL) + row * L + col];   // the four sites (toric_model.py:261-269)
-                const uint32_t sh[4] = {ev.x, ev.y, ev.z, ev.w};                    // bit shift in [4:0] (shifts use only those)
+                const uint32_t sh[4] = {ev.x, ev.y, ev.z, ev.w};                    // dword offset << 10 | bit shift in [4:0]
                 uint32_t *ad[4];
                 uint32_t F = 0;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    ad[i] = stw + (sh[i] >> 8);
-                    F |= ((*ad[i] >> (sh[i] & 31u)) & 3u) << (2 * i);
+                    ad[i] = stw + (sh[i] >> 10);
+                    F |= bfe2_lo5(*ad[i], sh[i]) << (2 * i);
                 }
                 const uint32_t op = isX ? 1u : 3u;
                 const uint32_t G = F ^ (op * 0x55u);                               // the four new values
                 const int dE = __popc((G | (G >> 1)) & 0x55u) - __popc((F | (F >> 1)) & 0x55u);   // :275-282
                 if (x.w <= myT[dE]) {                                               // mcmc.py:42
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) lds_xor(ad[i], op << (sh[i] & 31u));
+                    for (int i = 0; i < 4; ++i) lds_xor(ad[i], shl_lo5(op, sh[i]));
                     ni += dE;
                 }
             };
@@ -620,7 +635,8 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                     const uint32_t e4[4] = {ev.x, ev.y, ev.z, ev.w};
                     const uint32_t op = isX ? 1u : 3u;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) lds_xor(stw + (e4[i] >> 8), op << (e4[i] & 31u));
+                    for (int i = 0; i < 4; ++i)
+                        lds_xor(stw + (e4[i] >> 10), shl_lo5(op, e4[i]));
                 }
             }
             // flush the frame: lattice row r of layer l is the 2L-bit span at bit 2*(l*LL + r*L)
