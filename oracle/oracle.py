@@ -29,17 +29,18 @@ class _Rng(C.Structure):
 
 
 class Model(C.Structure):
-    _fields_ = [("code", C.c_int), ("L", C.c_int), ("noise", C.c_int), ("eta", C.c_double), ("scan", C.c_int)]
+    _fields_ = [("code", C.c_int), ("L", C.c_int), ("noise", C.c_int), ("eta", C.c_double), ("alpha", C.c_double),
+                ("det_pow", C.c_int), ("scan", C.c_int)]
 
 
 TORIC, XZZX, ROTATED = 0, 1, 2
-DEPOLARIZING, BIASED = 0, 1
+DEPOLARIZING, BIASED, ALPHA = 0, 1, 2
 
 
 class _Ladder(C.Structure):
     _fields_ = [("model", Model), ("L", C.c_int), ("Nc", C.c_int), ("nq", C.c_int), ("p_logical", C.c_double),
                 ("p_ladder", C.POINTER(C.c_double)), ("p_diff", C.POINTER(C.c_double)),
-                ("states", C.POINTER(C.c_uint8)), ("flags", C.POINTER(C.c_uint8)),
+                ("states", C.POINTER(C.c_uint8)), ("flags", C.POINTER(C.c_uint8)), ("n_eff", C.POINTER(C.c_double)),
                 ("tops0", C.c_uint64), ("step_index", C.c_uint64), ("scratch", C.POINTER(C.c_uint8))]
 
 
@@ -102,6 +103,10 @@ def lib():
         _LIB.orc_chain_update.argtypes = [mp, u8p, C.c_double, C.c_double, C.c_uint64, C.POINTER(_Rng), C.c_uint32,
                                           C.c_uint64, u8p]
         _LIB.orc_chain_update.restype = None
+        _LIB.orc_chain_update_alpha.argtypes = [mp, u8p, C.c_double, C.c_double, C.c_uint64, C.POINTER(_Rng), C.c_uint32,
+                                                C.c_uint64, u8p, C.POINTER(C.c_double)]
+        _LIB.orc_chain_update_alpha.restype = None
+        _LIB.orc_det_exp.argtypes = [C.c_double]; _LIB.orc_det_exp.restype = C.c_double
         _LIB.orc_ladder_new.argtypes = [mp, u8p, C.c_double, C.c_int, C.c_double]
         _LIB.orc_ladder_new.restype = C.POINTER(_Ladder)
         _LIB.orc_ladder_step.argtypes = [C.POINTER(_Ladder), C.c_uint64, C.POINTER(_Rng)]
@@ -275,8 +280,8 @@ def toric_pteq_batch(init, p, Nc, steps, iters=10, tops_burn=2, seed=0, first_sy
 
 
 # ---- XZZX / rotated surface code (uint8[L,L]) and the code/noise-generic chain, ladder, PTEQ --------
-def _model(code, L, noise=DEPOLARIZING, eta=0.0, scan=0):
-    return Model(code, L, noise, float(eta), scan)
+def _model(code, L, noise=DEPOLARIZING, eta=0.0, scan=0, alpha=0.0, det_pow=0):
+    return Model(code, L, noise, float(eta), float(alpha), det_pow, scan)
 
 
 def _size(code, m):
@@ -315,14 +320,25 @@ def chain_update(code, m, p, p_logical, iters, rng, slot=0, k0=0, noise=DEPOLARI
     return m
 
 
-class Ladder:
-    """Ladder / Ladder_biased of any code model (states in slot order)."""
+def chain_update_alpha(code, m, pz_tilde, alpha, p_logical, iters, rng, slot=0, k0=0):
+    """Chain_alpha.update_chain; returns (final matrix, n_eff attribute)."""
+    m = _m(m).copy()
+    scratch = np.empty_like(m)
+    mod = _model(code, _size(code, m), ALPHA, 0.0, 0, alpha)
+    n_eff = C.c_double(float(np.sum(m == 3) + alpha * (np.sum(m == 1) + np.sum(m == 2))))
+    lib().orc_chain_update_alpha(C.byref(mod), _u8(m), pz_tilde, p_logical, iters, C.byref(rng.c), slot, k0, _u8(scratch),
+                                 C.byref(n_eff))
+    return m, n_eff.value
 
-    def __init__(self, code, init, p_bottom, Nc, p_logical=0.0, noise=DEPOLARIZING, eta=0.0, scan=0):
+
+class Ladder:
+    """Ladder / Ladder_biased / Ladder_alpha of any code model (states in slot order)."""
+
+    def __init__(self, code, init, p_bottom, Nc, p_logical=0.0, noise=DEPOLARIZING, eta=0.0, scan=0, alpha=0.0, det_pow=0):
         init = _m(init)
         self.shape = init.shape
         self.Nc = Nc; self.nq = init.size
-        mod = _model(code, _size(code, init), noise, eta, scan)
+        mod = _model(code, _size(code, init), noise, eta, scan, alpha, det_pow)
         self._p = lib().orc_ladder_new(C.byref(mod), _u8(init), p_bottom, Nc, p_logical)
 
     def __del__(self):
@@ -354,11 +370,15 @@ class Ladder:
     def p_diff(self):
         return np.ctypeslib.as_array(self._p.contents.p_diff, shape=(self.Nc - 1,)).copy()
 
+    @property
+    def n_eff(self):
+        return np.ctypeslib.as_array(self._p.contents.n_eff, shape=(self.Nc,)).copy()
+
 
 def pteq(code, init, p, Nc=None, SEQ=2, TOPS=10, tops_burn=2, eps=0.1, steps=1000, iters=10, conv_criteria=None,
-         rng=None, noise=DEPOLARIZING, eta=0.0):
+         rng=None, noise=DEPOLARIZING, eta=0.0, alpha=0.0, det_pow=0):
     init = _m(init); Nc = Nc or _size(code, init)
-    mod = _model(code, _size(code, init), noise, eta)
+    mod = _model(code, _size(code, init), noise, eta, 0, alpha, det_pow)
     res = PteqResult()
     fin = np.empty((Nc,) + init.shape, dtype=np.uint8)
     lib().orc_pteq(C.byref(mod), _u8(init), p, Nc, SEQ, TOPS, tops_burn, eps, steps, iters,
@@ -370,9 +390,10 @@ def pteq(code, init, p, Nc=None, SEQ=2, TOPS=10, tops_burn=2, eps=0.1, steps=100
 
 
 def pteq_batch(code, init, p, Nc, steps, iters=10, tops_burn=2, seed=0, first_syndrome=0, n_threads=0,
-               return_states=False, conv_criteria=None, SEQ=2, TOPS=10, eps=0.1, noise=DEPOLARIZING, eta=0.0, scan=0):
+               return_states=False, conv_criteria=None, SEQ=2, TOPS=10, eps=0.1, noise=DEPOLARIZING, eta=0.0, scan=0,
+               alpha=0.0, det_pow=0):
     init = _m(init); N = init.shape[0]
-    mod = _model(code, init.shape[-1], noise, eta, scan)
+    mod = _model(code, init.shape[-1], noise, eta, scan, alpha, det_pow)
     counts = np.zeros((N, 16), dtype=np.uint32)
     samples = np.zeros(N, dtype=np.uint64); tops0 = np.zeros(N, dtype=np.uint64)
     steps_done = np.zeros(N, dtype=np.uint64); converged = np.zeros(N, dtype=np.uint8)

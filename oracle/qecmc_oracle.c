@@ -336,6 +336,67 @@ static double biased_weight(const uint8_t *s, int nq, double px, double py, doub
     return pow(px, (double)nx) * pow(py, (double)ny) * pow(pz, (double)nz) * pow(1 - px - py - pz, (double)(nq - nx - ny - nz));
 }
 
+/* exp(y) for y <= 0 from IEEE add / multiply / fma only, so the GPU (same operation sequence) returns the same bits.
+ * y >= 0 returns 1 (the callers only need to know the value is >= 1); results below 2^-1022 flush to 0. */
+double orc_det_exp(double y)
+{
+    if (!(y < 0.0)) return 1.0;
+    if (y < -745.0) return 0.0;
+    const double t = y * 1.4426950408889634;                 /* 1/ln 2 */
+    const long long k = (long long)(t - 0.5);                /* round to nearest (t < 0), truncating cast */
+    double r = fma(-(double)k, 6.93147180369123816490e-01, y);      /* ln2 high part */
+    r = fma(-(double)k, 1.90821492927058770002e-10, r);              /* ln2 low part */
+    double q = 1.0 / 6227020800.0;                           /* Horner, 1/13! ... 1/0! */
+    q = fma(q, r, 1.0 / 479001600.0);
+    q = fma(q, r, 1.0 / 39916800.0);
+    q = fma(q, r, 1.0 / 3628800.0);
+    q = fma(q, r, 1.0 / 362880.0);
+    q = fma(q, r, 1.0 / 40320.0);
+    q = fma(q, r, 1.0 / 5040.0);
+    q = fma(q, r, 1.0 / 720.0);
+    q = fma(q, r, 1.0 / 120.0);
+    q = fma(q, r, 1.0 / 24.0);
+    q = fma(q, r, 1.0 / 6.0);
+    q = fma(q, r, 0.5);
+    q = fma(q, r, 1.0);
+    q = fma(q, r, 1.0);
+    if (k < -1022) return 0.0;
+    union { uint64_t u; double d; } sc;
+    sc.u = (uint64_t)(k + 1023) << 52;                       /* 2^k */
+    return q * sc.d;
+}
+
+/* Chain_alpha.update_chain, mcmc_alpha.py:27-70: the biased rule with (p_x, p_y, p_z) derived from (pz_tilde, alpha),
+ * p_b frozen at loop entry (Q3), and n_eff = n_z + alpha (n_x + n_y) refreshed on every accepted move (:58,:70). */
+void orc_chain_update_alpha(const orc_model *m, uint8_t *state, double pz_tilde, double p_logical, uint64_t iters,
+                               orc_rng *rng, uint32_t slot, uint64_t k0, uint8_t *scratch, double *n_eff)
+{
+    const size_t nq = (size_t)orc_nq(m->code, m->L);
+    const double alpha = m->alpha;
+    const double p_tilde = pz_tilde + 2 * pow(pz_tilde, alpha);                         /* :32 */
+    const double p = p_tilde / (1 + p_tilde);                                           /* :34 */
+    const double pz = pz_tilde * (1 - p), px = pow(pz_tilde, alpha) * (1 - p), py = px; /* :35-36 */
+    const double pb = biased_weight(state, (int)nq, px, py, pz);                        /* :38-41 */
+    for (uint64_t j = 0; j < iters; ++j) {
+        const uint64_t k = k0 + j;
+        double u;
+        if (p_logical != 0) {
+            if (orc_draw(rng, slot, k, 0, 0) < p_logical) model_random_logical(m, state, scratch, rng, slot, k);
+            else model_random_stabilizer(m, state, scratch, rng, slot, k, 1);
+            u = orc_draw(rng, slot, k, 2, 0);
+        } else {
+            model_random_stabilizer(m, state, scratch, rng, slot, k, 0);
+            u = orc_draw(rng, slot, k, 0, 3);
+        }
+        if (u < biased_weight(scratch, (int)nq, px, py, pz) / pb) {
+            memcpy(state, scratch, nq);
+            int nx = 0, ny = 0, nz = 0;
+            for (size_t i = 0; i < nq; ++i) { nx += state[i] == 1; ny += state[i] == 2; nz += state[i] == 3; }
+            *n_eff = nz + alpha * (nx + ny);
+        }
+    }
+}
+
 void orc_chain_update(const orc_model *m, uint8_t *state, double p, double p_logical, uint64_t iters,
                       orc_rng *rng, uint32_t slot, uint64_t k0, uint8_t *scratch)
 {
@@ -397,7 +458,7 @@ void orc_chain_update(const orc_model *m, uint8_t *state, double p, double p_log
 void orc_toric_chain_update(int L, uint8_t *state, double p, double p_logical, uint64_t iters,
                             orc_rng *rng, uint32_t slot, uint64_t k0, uint8_t *scratch)
 {
-    orc_model m = {ORC_TORIC, L, ORC_NOISE_DEPOLARIZING, 0.0, 0};
+    orc_model m = {ORC_TORIC, L, ORC_NOISE_DEPOLARIZING, 0.0, 0.0, 0, 0};
     orc_chain_update(&m, state, p, p_logical, iters, rng, slot, k0, scratch);
 }
 
@@ -428,8 +489,14 @@ orc_ladder *orc_ladder_new(const orc_model *m, const uint8_t *init, double p_bot
     ld->states = (uint8_t *)malloc((size_t)Nc * ld->nq);
     ld->flags = (uint8_t *)calloc((size_t)Nc, 1);
     ld->scratch = (uint8_t *)malloc((size_t)ld->nq);
-    /* p_top = 0.75 (mcmc.py:62) or (eta+1)/(2 eta+1) (mcmc_biased.py:81) */
-    const double p_top = m->noise == ORC_NOISE_BIASED ? (m->eta + 1) / (2 * m->eta + 1) : 0.75;
+    ld->n_eff = (double *)calloc((size_t)Nc, sizeof(double));
+    {   /* Chain_alpha.__init__, mcmc_alpha.py:18-22 */
+        int nx = 0, ny = 0, nz = 0;
+        for (int i = 0; i < ld->nq; ++i) { nx += init[i] == 1; ny += init[i] == 2; nz += init[i] == 3; }
+        for (int c = 0; c < Nc; ++c) ld->n_eff[c] = nz + m->alpha * (nx + ny);
+    }
+    /* p_top = 0.75 (mcmc.py:62), (eta+1)/(2 eta+1) (mcmc_biased.py:81) or pz_tilde_top = 1 (mcmc_alpha.py:94) */
+    const double p_top = m->noise == ORC_NOISE_BIASED ? (m->eta + 1) / (2 * m->eta + 1) : m->noise == ORC_NOISE_ALPHA ? 1.0 : 0.75;
     fill_ladder_p(p_bottom, p_top, Nc, ld->p_ladder, ld->p_diff);    /* mcmc.py:62-69 */
     for (int c = 0; c < Nc; ++c) memcpy(ld->states + (size_t)c * ld->nq, init, (size_t)ld->nq); /* :72 */
     ld->flags[Nc - 1] = 1;                                          /* mcmc.py:75 */
@@ -438,14 +505,14 @@ orc_ladder *orc_ladder_new(const orc_model *m, const uint8_t *init, double p_bot
 
 orc_ladder *orc_toric_ladder_new(int L, const uint8_t *init, double p_bottom, int Nc, double p_logical)
 {
-    orc_model m = {ORC_TORIC, L, ORC_NOISE_DEPOLARIZING, 0.0, 0};
+    orc_model m = {ORC_TORIC, L, ORC_NOISE_DEPOLARIZING, 0.0, 0.0, 0, 0};
     return orc_ladder_new(&m, init, p_bottom, Nc, p_logical);
 }
 
 void orc_ladder_free(orc_ladder *ld)
 {
     if (!ld) return;
-    free(ld->p_ladder); free(ld->p_diff); free(ld->states); free(ld->flags); free(ld->scratch);
+    free(ld->p_ladder); free(ld->p_diff); free(ld->states); free(ld->flags); free(ld->scratch); free(ld->n_eff);
     free(ld);
 }
 
@@ -454,15 +521,28 @@ void orc_ladder_step(orc_ladder *ld, uint64_t iters, orc_rng *rng)
 {
     const int Nc = ld->Nc, nq = ld->nq;
     const uint64_t k0 = ld->step_index * iters;
-    for (int c = 0; c < Nc; ++c)                                    /* update_ladder :81-83 */
-        orc_chain_update(&ld->model, ld->states + (size_t)c * nq, ld->p_ladder[c],
-                         c == Nc - 1 ? ld->p_logical : 0.0, iters, rng, (uint32_t)c, k0, ld->scratch);
+    const int is_alpha = ld->model.noise == ORC_NOISE_ALPHA;
+    for (int c = 0; c < Nc; ++c) {                                  /* update_ladder :81-83 */
+        if (is_alpha)
+            orc_chain_update_alpha(&ld->model, ld->states + (size_t)c * nq, ld->p_ladder[c], c == Nc - 1 ? ld->p_logical : 0.0,
+                               iters, rng, (uint32_t)c, k0, ld->scratch, &ld->n_eff[c]);
+        else
+            orc_chain_update(&ld->model, ld->states + (size_t)c * nq, ld->p_ladder[c],
+                             c == Nc - 1 ? ld->p_logical : 0.0, iters, rng, (uint32_t)c, k0, ld->scratch);
+    }
     for (int i = Nc - 2; i >= 0; --i) {                             /* :96 */
         int64_t ne_lo = orc_count_errors((size_t)nq, ld->states + (size_t)i * nq);
         int64_t ne_hi = orc_count_errors((size_t)nq, ld->states + (size_t)(i + 1) * nq);
         int flip;
         /* _r_flip: mcmc.py:146 skips the draw when ne_hi < ne_lo; mcmc_biased.py:154-156 always draws
          * (rel_p ** negative > 1, so the outcome is the same; only the stream position differs) */
+        if (is_alpha) {
+            /* Ladder_alpha.r_flip, mcmc_alpha.py:118-123: the chains' n_eff attributes -- which do NOT travel with
+             * the codes when they are swapped (Q4) -- and the ratio of the two pz_tilde's; always draws */
+            const double u = orc_draw(rng, ORC_SWAP_STREAM, ld->step_index, (uint32_t)i >> 2, i & 3);
+            const double base = ld->p_ladder[i] / ld->p_ladder[i + 1], e = ld->n_eff[i + 1] - ld->n_eff[i];
+            flip = ld->model.det_pow ? u < orc_det_exp(e * log(base)) : u < pow(base, e);
+        } else
         if (ld->model.noise != ORC_NOISE_BIASED && ne_hi < ne_lo) flip = 1;
         else flip = orc_draw(rng, ORC_SWAP_STREAM, ld->step_index, (uint32_t)i >> 2, i & 3)
                     < pow(ld->p_diff[i], (double)(ne_hi - ne_lo));  /* :149 */
@@ -515,7 +595,8 @@ void orc_pteq(const orc_model *m, const uint8_t *init, double p, int Nc, int SEQ
             since_burn = step - resulting_burn_in;
             eq[cur] += 1;                                           /* :66-67 (running row) */
             recorded = since_burn + 1;
-            if (series) series[since_burn] = (double)orc_count_errors((size_t)ld->nq, ld->states);
+            if (series) series[since_burn] = m->noise == ORC_NOISE_ALPHA ? ld->n_eff[0]     /* decoders_biasednoise.py:204 */
+                                                                         : (double)orc_count_errors((size_t)ld->nq, ld->states);
         } else {
             resulting_burn_in += 1;                                 /* :71 */
         }
@@ -550,7 +631,7 @@ void orc_toric_pteq(int L, const uint8_t *init, double p, int Nc, int SEQ, int T
                     double eps, uint64_t steps, uint64_t iters, int conv_mode, orc_rng *rng,
                     orc_pteq_result *res, uint8_t *final_states)
 {
-    orc_model m = {ORC_TORIC, L, ORC_NOISE_DEPOLARIZING, 0.0, 0};
+    orc_model m = {ORC_TORIC, L, ORC_NOISE_DEPOLARIZING, 0.0, 0.0, 0, 0};
     orc_pteq(&m, init, p, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, conv_mode, rng, res, final_states);
 }
 
@@ -559,7 +640,7 @@ void orc_toric_pteq_batch(int L, const uint8_t *init, uint64_t N, uint32_t first
                           int n_threads, uint32_t *counts_out, uint64_t *samples_out,
                           uint64_t *tops0_out, uint8_t *final_states)
 {
-    orc_model m = {ORC_TORIC, L, ORC_NOISE_DEPOLARIZING, 0.0, 0};
+    orc_model m = {ORC_TORIC, L, ORC_NOISE_DEPOLARIZING, 0.0, 0.0, 0, 0};
     orc_pteq_batch(&m, init, N, first_syndrome, p, Nc, 2, 10, tops_burn, 0.1, steps, iters, 0, seed,
                    n_threads, counts_out, samples_out, tops0_out, NULL, NULL, final_states);
 }
@@ -570,7 +651,7 @@ void orc_toric_pteq_batch_conv(int L, const uint8_t *init, uint64_t N, uint32_t 
                                uint32_t *counts_out, uint64_t *samples_out, uint64_t *tops0_out,
                                uint64_t *steps_done_out, uint8_t *converged_out, uint8_t *final_states)
 {
-    orc_model m = {ORC_TORIC, L, ORC_NOISE_DEPOLARIZING, 0.0, 0};
+    orc_model m = {ORC_TORIC, L, ORC_NOISE_DEPOLARIZING, 0.0, 0.0, 0, 0};
     orc_pteq_batch(&m, init, N, first_syndrome, p, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, conv_mode, seed,
                    n_threads, counts_out, samples_out, tops0_out, steps_done_out, converged_out, final_states);
 }

@@ -53,7 +53,7 @@ void orc_rng_init_stream(orc_rng *r, const double *stream, uint64_t len);
 void orc_rng_init_philox(orc_rng *r, uint64_t seed, uint32_t syndrome);
 
 enum { ORC_TORIC = 0, ORC_XZZX = 1, ORC_ROTATED = 2 };
-enum { ORC_NOISE_DEPOLARIZING = 0, ORC_NOISE_BIASED = 1 };
+enum { ORC_NOISE_DEPOLARIZING = 0, ORC_NOISE_BIASED = 1, ORC_NOISE_ALPHA = 2 };
 
 /* which code model / acceptance rule a chain uses (duck typing in the reference) */
 typedef struct orc_model {
@@ -61,6 +61,9 @@ typedef struct orc_model {
     int L;
     int noise;     /* ORC_NOISE_DEPOLARIZING: src/mcmc.py; ORC_NOISE_BIASED: src/mcmc_biased.py */
     double eta;    /* bias, mcmc_biased.py:11 */
+    double alpha;  /* "alpha" noise exponent, mcmc_alpha.py:11 (noise = ORC_NOISE_ALPHA; the ladder variable is pz_tilde) */
+    int det_pow;   /* alpha swap test: 0 = libm pow as the reference (mcmc_alpha.py:123); 1 = the deterministic
+                      exp(e*ln(base)) the GPU uses (same decision unless u falls within ~1e-16 of the threshold) */
     int scan;      /* 0: the reference's random scan; 1: systematic sweep over the generators (NOT the reference's
                       chain: the deterministic-scan variant the GPU offers as scan=1, same stationary law) */
 } orc_model;
@@ -93,6 +96,7 @@ typedef struct orc_ladder {
     double *p_diff;      /* [Nc-1] */
     uint8_t *states;     /* [Nc][nq], slot order (chains[i].code.qubit_matrix) */
     uint8_t *flags;      /* [Nc] */
+    double *n_eff;       /* [Nc] Chain_alpha.n_eff: stays with the SLOT when codes are swapped (quirk Q4) */
     uint64_t tops0;
     uint64_t step_index; /* ladder steps done so far (Philox addressing) */
     uint8_t *scratch;    /* [nq] */
@@ -137,6 +141,11 @@ void orc_pteq_batch(const orc_model *m, const uint8_t *init, uint64_t N, uint32_
                     uint32_t *counts_out /*[N][16]*/, uint64_t *samples_out, uint64_t *tops0_out,
                     uint64_t *steps_done_out /*nullable*/, uint8_t *converged_out /*nullable*/,
                     uint8_t *final_states /*nullable*/);
+
+/* Chain_alpha.update_chain (mcmc_alpha.py:27-70); *n_eff is the chain's n_eff attribute (updated on accepted moves only) */
+void orc_chain_update_alpha(const orc_model *m, uint8_t *state, double pz_tilde, double p_logical, uint64_t iters,
+                            orc_rng *rng, uint32_t slot, uint64_t k0, uint8_t *scratch, double *n_eff);
+double orc_det_exp(double y);   /* deterministic exp for y <= 0 (IEEE +,*,fma only): bit-identical on CPU and GPU */
 
 /* N independent PTEQ runs (one per syndrome, Philox keyed by first_syndrome+i),
  * spread over `n_threads` OpenMP threads.  This is the timed CPU baseline. */

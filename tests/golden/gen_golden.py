@@ -18,6 +18,7 @@ Fixtures
   f3_toric.npz    replica-averaged PTEQ class histograms (statistical)
   f4_config1.npz  BASELINE config-1 plumbing vector
   f1_surf.npz / f2_surf.npz   the same for the XZZX and rotated codes, incl. the biased chain
+  f2_alpha.npz                Chain_alpha / Ladder_alpha / PTEQ_alpha trajectories (src/mcmc_alpha.py)
 """
 import argparse
 import os
@@ -352,6 +353,72 @@ def gen_f2_surf(xm, rm, mc, mb, dec, decb):
 
 
 # --------------------------------------------------------------------------- F3
+def gen_f2_alpha(xm, rm, ma, decb):
+    """Chain_alpha / Ladder_alpha (src/mcmc_alpha.py) and PTEQ_alpha (decoders_biasednoise.py:175) on the injected stream."""
+    rng = np.random.default_rng(177)
+    out = {}
+    cases = []
+    mods = (xm, rm)
+    codes = {"xzzx": xm.xzzx_code, "rot": rm.RotSurCode}
+    for i, (name, L, pzt, alpha, p_logical, iters, perr) in enumerate([
+            ("xzzx", 3, 0.2, 2.0, 0.0, 60, 0.3), ("xzzx", 5, 0.1, 1.7, 0.0, 300, 0.15), ("xzzx", 9, 0.08, 2.5, 0.0, 300, 0.15),
+            ("xzzx", 5, 1.0, 2.0, 0.5, 300, 0.15), ("xzzx", 9, 0.5, 1.3, 0.5, 200, 0.15), ("rot", 5, 0.15, 1.0, 0.5, 200, 0.15),
+            ("rot", 7, 0.12, 3.1, 0.0, 300, 0.15)]):
+        m = rand_matrix2(rng, L, perr)
+        seed = 6100 + i
+        code = codes[name](L); code.qubit_matrix = m.copy()
+        ch = ma.Chain_alpha(np.float64(pzt), alpha, code); ch.p_logical = p_logical
+        s = Stream(seed); install(s, *mods)
+        ch.update_chain(iters)
+        restore(*mods)
+        tag = f"achain{i}"
+        out[f"{tag}_init"] = m; out[f"{tag}_final"] = ch.code.qubit_matrix.astype(np.uint8)
+        out[f"{tag}_par"] = np.array([0 if name == "xzzx" else 1, L, pzt, p_logical, iters, seed, s.n, alpha, ch.n_eff], dtype=np.float64)
+        cases.append(tag)
+    for i, (name, L, pzt, alpha, Nc, iters, nstep, perr) in enumerate([
+            ("xzzx", 3, 0.2, 2.0, 3, 5, 60, 0.3), ("xzzx", 5, 0.1, 1.7, 5, 10, 60, 0.15), ("xzzx", 9, 0.08, 2.5, 8, 10, 30, 0.15),
+            ("rot", 5, 0.15, 1.0, 4, 10, 60, 0.15), ("rot", 7, 0.12, 3.1, 6, 10, 40, 0.15), ("xzzx", 7, 0.05, 1.4, 7, 10, 40, 0.1)]):
+        m = rand_matrix2(rng, L, perr)
+        seed = 6200 + i
+        code = codes[name](L); code.qubit_matrix = m.copy()
+        s = Stream(seed); install(s, *mods)
+        ld = ma.Ladder_alpha(pzt, code, alpha, Nc, 0.5)
+        tops = []; neff = []
+        for _ in range(nstep):
+            ld.step(iters); tops.append(ld.tops0); neff.append([c.n_eff for c in ld.chains])
+        restore(*mods)
+        tag = f"aladder{i}"
+        out[f"{tag}_init"] = m
+        out[f"{tag}_states"] = np.array([c.code.qubit_matrix for c in ld.chains], dtype=np.uint8)
+        out[f"{tag}_flags"] = np.array([c.flag for c in ld.chains], dtype=np.uint8)
+        out[f"{tag}_tops_hist"] = np.array(tops, dtype=np.int64)
+        out[f"{tag}_neff_hist"] = np.array(neff, dtype=np.float64)
+        out[f"{tag}_p_ladder"] = np.asarray(ld.pz_tilde_ladder, dtype=np.float64)
+        out[f"{tag}_par"] = np.array([0 if name == "xzzx" else 1, L, pzt, Nc, iters, nstep, seed, s.n, alpha], dtype=np.float64)
+        cases.append(tag)
+    for i, (name, L, pzt, alpha, Nc, iters, steps, tops_burn, conv, perr, SEQ, TOPS, eps) in enumerate([
+            ("xzzx", 3, 0.2, 2.0, 3, 10, 300, 2, None, 0.3, 2, 10, 0.1), ("xzzx", 5, 0.1, 1.7, 5, 10, 200, 0, None, 0.15, 2, 10, 0.1),
+            ("rot", 5, 0.15, 1.3, 5, 10, 200, 1, None, 0.15, 2, 10, 0.1),
+            ("xzzx", 3, 0.2, 2.0, 3, 10, 6000, 1, "error_based", 0.3, 1, 4, 0.5),
+            ("xzzx", 5, 0.1, 1.7, 5, 10, 4000, 2, "error_based", 0.15, 2, 10, 0.1)]):
+        m = rand_matrix2(rng, L, perr)
+        seed = 6300 + i
+        code = codes[name](L); code.qubit_matrix = m.copy()
+        s = Stream(seed); install(s, *mods)
+        pct = decb.PTEQ_alpha(code, pzt, alpha=alpha, Nc=Nc, SEQ=SEQ, TOPS=TOPS, eps=eps, steps=steps, iters=iters,
+                              tops_burn=tops_burn, conv_criteria=conv)
+        restore(*mods)
+        tag = f"apteq{i}"
+        out[f"{tag}_init"] = m
+        out[f"{tag}_percent"] = np.asarray(pct, dtype=np.uint8)
+        out[f"{tag}_par"] = np.array([0 if name == "xzzx" else 1, L, pzt, Nc, iters, steps, tops_burn, 1 if conv else 0, seed, s.n,
+                                      SEQ, TOPS, eps, alpha], dtype=np.float64)
+        cases.append(tag)
+    out["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(HERE, "f2_alpha.npz"), **out)
+    print("f2_alpha.npz", cases)
+
+
 def _f3_worker(args):
     (L, p, Nc, iters, steps, burn, m, seed) = args
     tm, mc, dec = import_reference()
@@ -414,14 +481,17 @@ def main():
         print("reference not present; nothing to do")
         return
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="f1,f2,f3,f4,f1s,f2s")
+    ap.add_argument("--only", default="f1,f2,f3,f4,f1s,f2s,f2a")
     only = set(ap.parse_args().only.split(","))
     tm, mc, dec = import_reference()
     if "f1" in only: gen_f1(tm)
     if "f2" in only: gen_f2(tm, mc, dec)
     if "f4" in only: gen_f4(tm, mc)
-    if "f1s" in only or "f2s" in only:
+    if "f1s" in only or "f2s" in only or "f2a" in only:
         xm, rm, mb, decb = import_reference_surf()
+        if "f2a" in only:
+            import src.mcmc_alpha as ma
+            gen_f2_alpha(xm, rm, ma, decb)
         if "f1s" in only: gen_f1_surf(xm, rm)
         if "f2s" in only: gen_f2_surf(xm, rm, mc, mb, dec, decb)
     if "f3" in only: gen_f3(tm)
