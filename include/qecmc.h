@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define QECMC_ABI_VERSION 1
+#define QECMC_ABI_VERSION 2
 
 typedef enum qecmc_status {
     QECMC_OK = 0,
@@ -45,7 +45,7 @@ typedef enum qecmc_status {
 
 typedef enum qecmc_code { QECMC_TORIC = 0, QECMC_XZZX = 1, QECMC_ROTATED = 2 } qecmc_code;
 typedef enum qecmc_scan { QECMC_SCAN_RANDOM = 0, QECMC_SCAN_CHECKERBOARD = 1 } qecmc_scan;
-typedef enum qecmc_noise { QECMC_NOISE_DEPOLARIZING = 0, QECMC_NOISE_BIASED = 1 } qecmc_noise;
+typedef enum qecmc_noise { QECMC_NOISE_DEPOLARIZING = 0, QECMC_NOISE_BIASED = 1, QECMC_NOISE_ALPHA = 2 } qecmc_noise;
 typedef enum qecmc_conv { QECMC_CONV_NONE = 0, QECMC_CONV_ERROR_BASED = 1 } qecmc_conv;
 
 /* Mirrors the keyword arguments of decoders.PTEQ (decoders.py:25) plus what the
@@ -66,8 +66,9 @@ typedef struct qecmc_params {
     int32_t  SEQ;           /* decoders.py:78 */
     int32_t  reserved0;
     double   eps;           /* decoders.py:102 */
-    double   p;             /* bottom-chain error rate (mcmc.py:50 p_bottom) */
-    double   eta;           /* bias (mcmc_biased.py:11); unused for depolarizing */
+    double   p;             /* bottom-chain error rate (mcmc.py:50 p_bottom); pz_tilde_bottom for alpha noise (mcmc_alpha.py:76) */
+    double   eta;           /* bias (mcmc_biased.py:11); unused otherwise */
+    double   alpha;         /* alpha noise exponent (mcmc_alpha.py:11, decoders_biasednoise.py:175); unused otherwise */
     double   p_logical;     /* top-chain logical proposal rate (decoders.py:52 passes 0.5) */
     uint64_t seed;          /* Philox key */
     uint32_t first_syndrome;/* global index of syndrome 0 of this call: results do not
@@ -122,12 +123,28 @@ int qecmc_chain_update_biased(int code, int L, uint64_t N, uint8_t *states_inout
                               double p_logical, uint64_t iters, uint64_t seed, uint32_t first_syndrome,
                               uint32_t slot, uint64_t k0);
 
+/* Chain_alpha.update_chain(iters), src/mcmc_alpha.py:27-70: the biased rule with (p_x, p_y, p_z) derived from
+ * (pz_tilde, alpha).  accepted_out uint8[N] (nullable) = 1 iff chain i accepted at least one proposal -- the
+ * reference refreshes the chain's n_eff attribute on accepted moves only (:58,:70). */
+int qecmc_chain_update_alpha(int code, int L, uint64_t N, uint8_t *states_inout, double pz_tilde, double alpha,
+                             double p_logical, uint64_t iters, uint64_t seed, uint32_t first_syndrome,
+                             uint32_t slot, uint64_t k0, uint8_t *accepted_out);
+
 /* Ladder.step(iters) x nsteps, src/mcmc.py:94-103, on N ladders in slot order.
  * states uint8[N][Nc][nq], flags uint8[N][Nc], tops0 uint32[N]; step0 / prop0 =
  * ladder steps / proposals per slot already done (Philox addressing).  Uses
  * params->{code,L,Nc,p,p_logical,seed,first_syndrome,device}. */
 int qecmc_ladder_step(const qecmc_params *params, uint64_t N, uint8_t *states_inout, uint8_t *flags_inout,
                       uint32_t *tops0_inout, uint64_t iters, uint64_t nsteps, uint64_t step0, uint64_t prop0);
+
+/* Ladder_alpha.step(iters) x nsteps, src/mcmc_alpha.py:127-137 (params->noise = QECMC_NOISE_ALPHA, params->p =
+ * pz_tilde_bottom, params->alpha).  neff_counts_inout uint16[N][Nc][2] carries each SLOT's n_eff attribute as the
+ * pair (n_z, n_x + n_y) it was last computed from (n_eff = n_z + alpha (n_x + n_y), :58): the reference swaps codes
+ * and flags but not n_eff, so the attribute can lag the slot's configuration and is state the
+ * caller must carry between calls. */
+int qecmc_ladder_step_alpha(const qecmc_params *params, uint64_t N, uint8_t *states_inout, uint8_t *flags_inout,
+                            uint32_t *tops0_inout, uint16_t *neff_counts_inout, uint64_t iters, uint64_t nsteps,
+                            uint64_t step0, uint64_t prop0);
 
 /* ---- the batched hot path: decoders.PTEQ (decoders.py:25-89) on N syndromes */
 

@@ -83,6 +83,23 @@ std::vector<double> bias_tables(double p, double eta, size_t nq)
     return t;
 }
 
+// The same table for the "alpha" noise model: (p_x, p_y, p_z) from (pz_tilde, alpha) exactly as Chain_alpha.update_chain
+// forms them (mcmc_alpha.py:31-36)
+std::vector<double> alpha_tables(double pz_tilde, double alpha, size_t nq)
+{
+    const double p_tilde = pz_tilde + 2 * std::pow(pz_tilde, alpha);
+    const double p = p_tilde / (1 + p_tilde);
+    const double pz = pz_tilde * (1 - p), px = std::pow(pz_tilde, alpha) * (1 - p), py = px, pi = 1 - px - py - pz;
+    std::vector<double> t(4 * (nq + 1));
+    for (size_t n = 0; n <= nq; ++n) {
+        t[n] = std::pow(px, (double)n);
+        t[(nq + 1) + n] = std::pow(py, (double)n);
+        t[2 * (nq + 1) + n] = std::pow(pz, (double)n);
+        t[3 * (nq + 1) + n] = std::pow(pi, (double)n);
+    }
+    return t;
+}
+
 // floor(phalf * 2^32), phalf = (L^2 - (L-1)^2 - 1)/(L^2 - 1) (xzzx_model.py:444): u > phalf <=> x > this
 uint64_t half_threshold(int L)
 {
@@ -198,7 +215,7 @@ std::vector<uint32_t> surf_generator_table(int code, int L)
 struct qecmc_plan {
     qecmc_params prm;
     LadderArgs args;
-    DevBuf swap_thr, lmask, acc_top, gen, bias;
+    DevBuf swap_thr, lmask, acc_top, gen, bias, lnb;
     size_t lds_bytes;
 };
 
@@ -211,7 +228,12 @@ int validate_params(const qecmc_params *p)
         return fail(QECMC_ERR_INVALID, "params->abi_size=%u, this library expects %zu", p->abi_size, sizeof(qecmc_params));
     if (int rc = check_code_L(p->code, p->L)) return rc;
     if (p->Nc < 1 || p->Nc > kMaxNc) return fail(QECMC_ERR_INVALID, "Nc=%d out of range [1,%d]", p->Nc, kMaxNc);
-    if (p->noise != QECMC_NOISE_DEPOLARIZING && p->noise != QECMC_NOISE_BIASED) return fail(QECMC_ERR_INVALID, "noise model %d unknown", p->noise);
+    if (p->noise != QECMC_NOISE_DEPOLARIZING && p->noise != QECMC_NOISE_BIASED && p->noise != QECMC_NOISE_ALPHA) return fail(QECMC_ERR_INVALID, "noise model %d unknown", p->noise);
+    if (p->noise == QECMC_NOISE_ALPHA) {
+        if (!(p->alpha > 0.0)) return fail(QECMC_ERR_INVALID, "alpha=%g must be positive", p->alpha);
+        if (!(p->p > 0.0) || !(p->p <= 1.0)) return fail(QECMC_ERR_INVALID, "pz_tilde=%g must be in (0, 1]", p->p);
+        if (p->code == QECMC_TORIC) return fail(QECMC_ERR_UNSUPPORTED, "alpha noise is built for the xzzx and rotated codes (the reference sizes its weights for L^2 qubits, mcmc_alpha.py:27)");
+    } else
     if (p->noise == QECMC_NOISE_BIASED) {
         if (!(p->eta > 0.0)) return fail(QECMC_ERR_INVALID, "eta=%g must be positive", p->eta);
         if (!(p->p > 0.0) || !(p->p < (p->eta + 1) / (2 * p->eta + 1))) return fail(QECMC_ERR_INVALID, "p=%g must be in (0, (eta+1)/(2 eta+1))", p->p);
@@ -233,8 +255,9 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
     LadderArgs &a = pl->args;
     std::memset(&a, 0, sizeof a);
     const int L = p->L, Nc = p->Nc, nq = (int)code_nq(p->code, L), W = (nq + 15) / 16, ncls = p->code == QECMC_TORIC ? 16 : 4;
-    const bool biased = p->noise == QECMC_NOISE_BIASED;
-    a.code = p->code; a.noise = p->noise;
+    const bool alpha = p->noise == QECMC_NOISE_ALPHA;
+    const bool biased = p->noise == QECMC_NOISE_BIASED || alpha;     // table-driven acceptance pn / pb
+    a.code = p->code; a.noise = p->noise; a.alpha = p->alpha;
     a.L = L; a.Nc = Nc; a.W = W; a.nq = nq; a.ncls = ncls;
     a.iters = (uint32_t)p->iters;
     a.seed_lo = (uint32_t)p->seed; a.seed_hi = (uint32_t)(p->seed >> 32);
@@ -244,20 +267,22 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
     const uint32_t n_gen = p->code == QECMC_TORIC ? 2u * L * L : (uint32_t)((L - 1) * (L - 1) + 2 * (L - 1));
     if (n_gen > kMaxGenLds)   // every kernel path stages the generator table in LDS
         return fail(QECMC_ERR_UNSUPPORTED, "L=%d: %u generators exceed the LDS table of %u (needed by scan=1 and by the xzzx / rotated codes)", L, n_gen, kMaxGenLds);
-    pl->lds_bytes = ladder_lds_bytes(L, Nc, W, ncls, ladder_gen_dwords(p->code, p->noise, p->scan, n_gen));
+    pl->lds_bytes = ladder_lds_bytes(L, Nc, W, ncls, ladder_gen_dwords(p->code, p->noise, p->scan, n_gen, Nc));
     if (pl->lds_bytes > 160 * 1024)
         return fail(QECMC_ERR_UNSUPPORTED, "L=%d Nc=%d needs %zu B of LDS per workgroup (> 160 KiB)", L, Nc, pl->lds_bytes);
 
     std::vector<double> pladder, pdiff;
     // p_top = 0.75 (mcmc.py:62) or (eta+1)/(2 eta+1) (mcmc_biased.py:81)
-    ladder_probabilities(p->p, biased ? (p->eta + 1) / (2 * p->eta + 1) : 0.75, Nc, pladder, pdiff);   // mcmc.py:62-69
-    for (int c = 0; c < Nc; ++c) {
+    // ... or pz_tilde_top = 1 (mcmc_alpha.py:94)
+    ladder_probabilities(p->p, alpha ? 1.0 : biased ? (p->eta + 1) / (2 * p->eta + 1) : 0.75, Nc, pladder, pdiff);   // mcmc.py:62-69
+    if (alpha) pdiff.assign(pdiff.size(), 0.0);      // the depolarizing tables below are unused by the table-driven rules
+    for (int c = 0; c < Nc && !biased; ++c) {
         const double f = chain_factor(pladder[c]);
         if (f >= 1.0 && !biased) a.acc_all_mask |= 1u << c;
         for (int d = 1; d <= 4; ++d) a.acc_thr[c][d - 1] = thr32(std::pow(f, (double)d));   // mcmc.py:42
     }
     std::vector<uint32_t> top_tbl(nq + 1, 0u);                             // mcmc.py:34 for a top chain below p = 0.75
-    for (int d = 1; d <= nq; ++d) top_tbl[d] = thr32(std::pow(chain_factor(pladder[Nc - 1]), (double)d));
+    for (int d = 1; d <= nq && !biased; ++d) top_tbl[d] = thr32(std::pow(chain_factor(pladder[Nc - 1]), (double)d));
     std::vector<uint64_t> sw((size_t)(Nc > 1 ? Nc - 1 : 1) * (nq + 1), 0);
     for (int i = 0; i + 1 < Nc; ++i)
         for (int d = 0; d <= nq; ++d) sw[(size_t)i * (nq + 1) + d] = thr64(std::pow(pdiff[i], (double)d));   // mcmc.py:149
@@ -277,12 +302,19 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
     if (biased) {
         std::vector<double> bt;
         for (int c = 0; c < Nc; ++c) {
-            const std::vector<double> t = bias_tables(pladder[c], p->eta, (size_t)nq);
+            const std::vector<double> t = alpha ? alpha_tables(pladder[c], p->alpha, (size_t)nq) : bias_tables(pladder[c], p->eta, (size_t)nq);
             bt.insert(bt.end(), t.begin(), t.end());
         }
         HIP_TRY(pl->bias.alloc(bt.size() * sizeof(double)));
         HIP_TRY(hipMemcpy(pl->bias.p, bt.data(), bt.size() * sizeof(double), hipMemcpyHostToDevice));
         a.bias_tbl = pl->bias.as<double>();
+    }
+    if (alpha) {
+        std::vector<double> lnb(Nc > 1 ? Nc - 1 : 1, 0.0);
+        for (int i = 0; i + 1 < Nc; ++i) lnb[i] = std::log(pladder[i] / pladder[i + 1]);   // mcmc_alpha.py:123
+        HIP_TRY(pl->lnb.alloc(lnb.size() * sizeof(double)));
+        HIP_TRY(hipMemcpy(pl->lnb.p, lnb.data(), lnb.size() * sizeof(double), hipMemcpyHostToDevice));
+        a.alpha_lnb = pl->lnb.as<double>();
     }
     HIP_TRY(pl->swap_thr.alloc(sw.size() * sizeof(uint64_t)));
     HIP_TRY(pl->lmask.alloc(lm.size() * sizeof(uint32_t)));
@@ -420,10 +452,15 @@ int qecmc_syndrome(int code, int L, uint64_t N, const uint8_t *in, uint8_t *defe
 
 // ---------------------------------------------------------------- chain / ladder
 static int chain_update_impl(int code, int L, uint64_t N, uint8_t *states_inout, double p, double eta, int noise,
-                             double p_logical, uint64_t iters, uint64_t seed, uint32_t first_syndrome, uint32_t slot, uint64_t k0)
+                             double p_logical, uint64_t iters, uint64_t seed, uint32_t first_syndrome, uint32_t slot, uint64_t k0,
+                             uint8_t *accepted_out = nullptr)
 {
     PRIM_PROLOGUE();
     if (!states_inout) return fail(QECMC_ERR_INVALID, "NULL buffer");
+    if (noise == QECMC_NOISE_ALPHA) {      // `eta` carries alpha here
+        if (!(p > 0.0) || !(p <= 1.0) || !(eta > 0.0)) return fail(QECMC_ERR_INVALID, "alpha noise needs pz_tilde in (0,1] and alpha > 0 (pz_tilde=%g alpha=%g)", p, eta);
+        if (code == QECMC_TORIC) return fail(QECMC_ERR_UNSUPPORTED, "alpha noise is built for the xzzx and rotated codes");
+    } else
     if (noise) {
         if (!(p > 0.0) || !(p < 1.0) || !(eta > 0.0)) return fail(QECMC_ERR_INVALID, "biased noise needs p in (0,1) and eta > 0 (p=%g eta=%g)", p, eta);
     } else if (!(p > 0.0) || !(p <= 0.75)) return fail(QECMC_ERR_INVALID, "p=%g must be in (0, 0.75]", p);
@@ -431,12 +468,13 @@ static int chain_update_impl(int code, int L, uint64_t N, uint8_t *states_inout,
     if (slot >= 0x100u) return fail(QECMC_ERR_INVALID, "slot %u collides with the swap stream id", slot);
     ChainArgs a;
     std::memset(&a, 0, sizeof a);
-    const double f = chain_factor(p);
+    const double f = noise ? 0.0 : chain_factor(p);
     std::vector<uint32_t> tbl(nq + 1, 0u);
-    for (size_t d = 1; d <= nq; ++d) tbl[d] = thr32(std::pow(f, (double)d));
-    const std::vector<double> bt = bias_tables(p, noise ? eta : 1.0, nq);
-    DevBuf ds, dt, db;
+    for (size_t d = 1; d <= nq && !noise; ++d) tbl[d] = thr32(std::pow(f, (double)d));
+    const std::vector<double> bt = noise == QECMC_NOISE_ALPHA ? alpha_tables(p, eta, nq) : bias_tables(p, noise ? eta : 1.0, nq);
+    DevBuf ds, dt, db, dacc;
     HIP_TRY(ds.alloc(N * nq)); HIP_TRY(dt.alloc(tbl.size() * 4)); HIP_TRY(db.alloc(bt.size() * 8));
+    if (accepted_out) { HIP_TRY(dacc.alloc(N)); a.accepted = dacc.as<uint8_t>(); }
     HIP_TRY(hipMemcpy(ds.p, states_inout, N * nq, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dt.p, tbl.data(), tbl.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(db.p, bt.data(), bt.size() * 8, hipMemcpyHostToDevice));
@@ -448,6 +486,7 @@ static int chain_update_impl(int code, int L, uint64_t N, uint8_t *states_inout,
     a.code = code; a.noise = noise; a.thr_half = half_threshold(L); a.bias_tbl = db.as<double>();
     HIP_TRY(launch_chain_update(a, 0));
     HIP_TRY(hipMemcpy(states_inout, ds.p, N * nq, hipMemcpyDeviceToHost));
+    if (accepted_out) HIP_TRY(hipMemcpy(accepted_out, dacc.p, N, hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -463,8 +502,14 @@ int qecmc_chain_update_biased(int code, int L, uint64_t N, uint8_t *states_inout
     return chain_update_impl(code, L, N, states_inout, p, eta, 1, p_logical, iters, seed, first_syndrome, slot, k0);
 }
 
-int qecmc_ladder_step(const qecmc_params *params, uint64_t N, uint8_t *states_inout, uint8_t *flags_inout,
-                      uint32_t *tops0_inout, uint64_t iters, uint64_t nsteps, uint64_t step0, uint64_t prop0)
+int qecmc_chain_update_alpha(int code, int L, uint64_t N, uint8_t *states_inout, double pz_tilde, double alpha, double p_logical,
+                             uint64_t iters, uint64_t seed, uint32_t first_syndrome, uint32_t slot, uint64_t k0, uint8_t *accepted_out)
+{
+    return chain_update_impl(code, L, N, states_inout, pz_tilde, alpha, QECMC_NOISE_ALPHA, p_logical, iters, seed, first_syndrome, slot, k0, accepted_out);
+}
+
+static int ladder_step_impl(const qecmc_params *params, uint64_t N, uint8_t *states_inout, uint8_t *flags_inout,
+                            uint32_t *tops0_inout, uint16_t *neff_inout, uint64_t iters, uint64_t nsteps, uint64_t step0, uint64_t prop0)
 {
     if (!params) return fail(QECMC_ERR_INVALID, "params is NULL");
     qecmc_params p = *params;
@@ -472,6 +517,8 @@ int qecmc_ladder_step(const qecmc_params *params, uint64_t N, uint8_t *states_in
     p.conv_mode = QECMC_CONV_NONE;
     if (int rc = validate_params(&p)) return rc;
     if (!states_inout || !flags_inout || !tops0_inout) return fail(QECMC_ERR_INVALID, "NULL buffer");
+    if ((p.noise == QECMC_NOISE_ALPHA) != (neff_inout != nullptr))
+        return fail(QECMC_ERR_INVALID, "alpha-noise ladders step through qecmc_ladder_step_alpha (which carries the slots' n_eff), the others through qecmc_ladder_step");
     if (int rc = use_device(p.device)) return rc;
     if (N == 0) return 0;
     qecmc_plan pl;
@@ -483,6 +530,12 @@ int qecmc_ladder_step(const qecmc_params *params, uint64_t N, uint8_t *states_in
     HIP_TRY(hipMemcpy(df.p, flags_inout, N * Nc, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dt.p, tops0_inout, N * 4, hipMemcpyHostToDevice));
     LadderArgs a = pl.args;
+    DevBuf dn;
+    if (neff_inout) {
+        HIP_TRY(dn.alloc(N * Nc * 4));
+        HIP_TRY(hipMemcpy(dn.p, neff_inout, N * Nc * 4, hipMemcpyHostToDevice));
+        a.neff = dn.as<uint32_t>();
+    }
     a.states = ds.as<uint8_t>(); a.flags = df.as<uint8_t>(); a.tops0 = dt.as<uint32_t>();
     a.N = N; a.first_syndrome = p.first_syndrome; a.step0 = step0; a.prop0 = prop0; a.nsteps = nsteps;
     a.resume = 1; a.write_states = 1;
@@ -490,7 +543,22 @@ int qecmc_ladder_step(const qecmc_params *params, uint64_t N, uint8_t *states_in
     HIP_TRY(hipMemcpy(states_inout, ds.p, N * Nc * nq, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(flags_inout, df.p, N * Nc, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(tops0_inout, dt.p, N * 4, hipMemcpyDeviceToHost));
+    if (neff_inout) HIP_TRY(hipMemcpy(neff_inout, dn.p, N * Nc * 4, hipMemcpyDeviceToHost));
     return 0;
+}
+
+int qecmc_ladder_step(const qecmc_params *params, uint64_t N, uint8_t *states_inout, uint8_t *flags_inout,
+                      uint32_t *tops0_inout, uint64_t iters, uint64_t nsteps, uint64_t step0, uint64_t prop0)
+{
+    return ladder_step_impl(params, N, states_inout, flags_inout, tops0_inout, nullptr, iters, nsteps, step0, prop0);
+}
+
+int qecmc_ladder_step_alpha(const qecmc_params *params, uint64_t N, uint8_t *states_inout, uint8_t *flags_inout,
+                            uint32_t *tops0_inout, uint16_t *neff_counts_inout, uint64_t iters, uint64_t nsteps,
+                            uint64_t step0, uint64_t prop0)
+{
+    if (!neff_counts_inout) return fail(QECMC_ERR_INVALID, "NULL buffer");
+    return ladder_step_impl(params, N, states_inout, flags_inout, tops0_inout, neff_counts_inout, iters, nsteps, step0, prop0);
 }
 
 // ---------------------------------------------------------------- PTEQ batch
@@ -525,7 +593,8 @@ int qecmc_plan_info(const qecmc_plan *plan, uint32_t *lds_bytes, uint32_t *block
 int qecmc_plan_workspace_bytes(const qecmc_plan *plan, uint64_t N, uint64_t *bytes_out)
 {
     if (!plan || !bytes_out) return fail(QECMC_ERR_INVALID, "NULL argument");
-    *bytes_out = plan->prm.conv_mode == QECMC_CONV_ERROR_BASED ? 2ull * N * plan->prm.steps : 0ull;
+    // one log entry per (ladder step, syndrome): the bottom chain's error count (u16), or for alpha noise the two counts behind n_eff (2 x u16)
+    *bytes_out = plan->prm.conv_mode == QECMC_CONV_ERROR_BASED ? (plan->prm.noise == QECMC_NOISE_ALPHA ? 4ull : 2ull) * N * plan->prm.steps : 0ull;
     return 0;
 }
 

@@ -24,7 +24,10 @@ struct LadderArgs {
     const uint64_t *swap_thr; // [Nc-1][nq+1]      ceil(p_diff[i]^d * 2^32)
     const uint32_t *lmask;    // [4][L+1][W]       logical-operator XOR masks (row L = identity)
     const uint2 *gen;         // [(L-1)^2 + 2(L-1)]  xzzx / rotated generators: 4 x u16 (site << 2 | pauli), 0 = unused
-    const double *bias_tbl;   // [Nc][4][nq+1]      px^n, py^n, pz^n, pI^n per rung (biased noise)
+    const double *bias_tbl;   // [Nc][4][nq+1]      px^n, py^n, pz^n, pI^n per rung (biased and alpha noise)
+    const double *alpha_lnb;  // [Nc-1]             ln(pz_tilde[i] / pz_tilde[i+1]) (alpha noise, mcmc_alpha.py:123)
+    double alpha;             //                    mcmc_alpha.py:11
+    uint32_t *neff;           // [N][Nc]            alpha noise: the slots' n_eff attributes as n_z | (n_x+n_y) << 16; resume in / out
     uint64_t thr_half;        // floor(phalf * 2^32) (xzzx_model.py:444)
     int code, noise;          // qecmc_code, qecmc_noise
     int scan;                 // qecmc_scan
@@ -55,7 +58,12 @@ size_t ladder_lds_bytes(int L, int Nc, int W, int ncls, int gen_dwords);
 constexpr uint32_t kMaxGenLds = 2048;   // generator tables up to this many entries are staged in LDS
 // dwords of the LDS generator table: the toric random-scan kernels expand each generator to 4 x u32
 // (dword offset << 10 | pauli << 5 | bit shift), the other paths keep the plan's 4 x u16 form
-inline int ladder_gen_dwords(int code, int noise, int scan, uint32_t n_gen) { return (code == 0 && !noise && !scan ? 4 : 2) * (int)n_gen; }
+// alpha noise appends the double-buffered n_eff records [2][Nc][64] to the region
+inline int ladder_gen_dwords(int code, int noise, int scan, uint32_t n_gen, int Nc)
+{
+    const int tab = (code == 0 && !noise && !scan ? 4 : 2) * (int)n_gen;
+    return noise == 2 ? ((tab + 3) & ~3) + 2 * Nc * 64 : tab;
+}
 hipError_t launch_ladder_rs_toric(const LadderArgs &a, hipStream_t stream);
 
 // byte-state primitive kernels (primitives.hip); all pointers are device pointers
@@ -78,7 +86,8 @@ struct ChainArgs {
     uint32_t first_syndrome, slot, seed_lo, seed_hi;
     int L;
     int code;                 // 0 toric, 1 xzzx, 2 rotated
-    int noise;                // 0 depolarizing (mcmc.py), 1 biased (mcmc_biased.py)
+    int noise;                // 0 depolarizing (mcmc.py), 1 biased (mcmc_biased.py), 2 alpha (mcmc_alpha.py; same rule, other table)
+    uint8_t *accepted;        // [N] out (nullable): 1 iff at least one proposal was accepted (Chain_alpha refreshes n_eff then)
     uint64_t thr_half;        // floor(phalf * 2^32): xzzx / rotated pick the full plaquette iff x > thr_half
     const double *bias_tbl;   // [4][nq+1] px^n, py^n, pz^n, pI^n (biased noise)
 };

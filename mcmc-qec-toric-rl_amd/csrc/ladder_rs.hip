@@ -162,6 +162,57 @@ __device__ __forceinline__ uint32_t pack_info(uint32_t n, uint32_t sid, uint32_t
 // GROUPS: independent 64-syndrome ladders per workgroup (they share only the barrier).  Two groups
 // (16 waves at Nc = 8, two workgroups per CU) keep 4 waves per SIMD busy even when a workgroup is
 // alone on its CU at the end of a launch, where one group (2 waves per SIMD) is latency-bound.
+// exp(y) for y <= 0 from IEEE multiply / add / fma only: the same operation sequence as the oracle's orc_det_exp, so the
+// swap decision of the alpha ladder is bit-identical on both sides.  y >= 0 returns 1; below 2^-1022 flushes to 0.
+__device__ inline double det_exp(double y)
+{
+#pragma clang fp contract(off)
+    if (!(y < 0.0)) return 1.0;
+    if (y < -745.0) return 0.0;
+    const double t = y * 1.4426950408889634;
+    const int k = (int)(t - 0.5);
+    double r = __builtin_fma(-(double)k, 6.93147180369123816490e-01, y);
+    r = __builtin_fma(-(double)k, 1.90821492927058770002e-10, r);
+    double q = 1.0 / 6227020800.0;
+    q = __builtin_fma(q, r, 1.0 / 479001600.0);
+    q = __builtin_fma(q, r, 1.0 / 39916800.0);
+    q = __builtin_fma(q, r, 1.0 / 3628800.0);
+    q = __builtin_fma(q, r, 1.0 / 362880.0);
+    q = __builtin_fma(q, r, 1.0 / 40320.0);
+    q = __builtin_fma(q, r, 1.0 / 5040.0);
+    q = __builtin_fma(q, r, 1.0 / 720.0);
+    q = __builtin_fma(q, r, 1.0 / 120.0);
+    q = __builtin_fma(q, r, 1.0 / 24.0);
+    q = __builtin_fma(q, r, 1.0 / 6.0);
+    q = __builtin_fma(q, r, 0.5);
+    q = __builtin_fma(q, r, 1.0);
+    q = __builtin_fma(q, r, 1.0);
+    if (k < -1022) return 0.0;
+    return q * __longlong_as_double((long long)(k + 1023) << 52);
+}
+
+// u < (pz_lo / pz_hi) ** (n_eff_hi - n_eff_lo), mcmc_alpha.py:118-123, with n_eff = n_z + alpha (n_x + n_y) rebuilt from the
+// packed counts exactly as the reference forms it (:58) and the power taken as det_exp(e * ln(base))
+__device__ inline bool alpha_flip(uint32_t x, uint32_t hi, uint32_t lo, double alpha, double lnb)
+{
+#pragma clang fp contract(off)
+    const double ne_hi = (double)(hi & 0xFFFFu) + alpha * (double)(hi >> 16);
+    const double ne_lo = (double)(lo & 0xFFFFu) + alpha * (double)(lo >> 16);
+    const double e = ne_hi - ne_lo;
+    return (double)x * (1.0 / 4294967296.0) < det_exp(e * lnb);
+}
+
+// conv_crit_error_based_PT_alpha, decoders_biasednoise.py:229-238: |mean Q2 - mean Q4| < eps on the n_eff series, each mean
+// formed as (sum n_z + alpha sum n_xy) / len from exact integer sums
+__device__ inline bool alpha_series_close(uint64_t z2, uint64_t xy2, uint32_t den2, uint64_t z4, uint64_t xy4, uint32_t den4,
+                                          double alpha, double eps)
+{
+#pragma clang fp contract(off)
+    const double q2 = ((double)z2 + alpha * (double)xy2) / (double)den2;
+    const double q4 = ((double)z4 + alpha * (double)xy4) / (double)den4;
+    return fabs(q2 - q4) < eps;
+}
+
 // CODE / BIASED: code model (toric, xzzx, rotated) and acceptance rule (src/mcmc.py or src/mcmc_biased.py).
 // The tuned paths are toric + depolarizing; the other combinations share the staging, cascade and bookkeeping.
 // SCAN: false = the reference's random scan; true = systematic sweep (proposal k tests generator k mod G):
@@ -181,9 +232,12 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
     // expanded to 4 x u32 (dword offset << 10 | pauli << 5 | bit shift) so a site costs a shift, a shift-add and a bfe
     constexpr bool kWideGen = CODE == kCodeToric && !BIASED && !SCAN;
     const int gen_dw = (kWideGen ? 4 : 2) * (int)a.n_gen;
-    const int gdw = ladder_group_dwords(NC, W, ncls, gen_dw);   // dwords per group
-    const int gen_off = gdw - ((gen_dw + 3) & ~3);               // start of the generator table
+    const bool alpha_noise = BIASED && a.noise == 2;            // mcmc_alpha.py: biased rule + slot-bound n_eff swap test
+    const int gen_region = alpha_noise ? ((gen_dw + 3) & ~3) + 2 * NC * 64 : gen_dw;
+    const int gdw = ladder_group_dwords(NC, W, ncls, gen_region);   // dwords per group
+    const int gen_off = gdw - ((gen_region + 3) & ~3);           // start of the generator table
     uint32_t *lds = lds_all + grp * gdw;
+    [[maybe_unused]] uint32_t *neffb = lds + gen_off + ((gen_dw + 3) & ~3);   // [2][NC][64] n_z | (n_x+n_y) << 16 per slot, by step parity
 
     uint32_t *st = lds;                           // [NC][W][64]   packed states
     uint32_t *info = st + (size_t)NC * W * 64;    // [2][NC][64]   slot records, double-buffered by step parity
@@ -270,9 +324,25 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
     // bottom-chain error counts, Q2 = series[l/4 : l/2], Q4 = series[3l/4 : l]
     uint32_t burn = 0, conv_start = 0, conv_streak = 0, done = 0, steps_done = 0, conv_ok = 0;
     uint64_t sumA = 0, sumB = 0;
+    [[maybe_unused]] uint64_t sumAxy = 0, sumBxy = 0;          // alpha noise: window sums of n_x + n_y (sumA / sumB hold n_z)
     if (a.resume && lane < cnt) {
         flag = a.flags[(s0 + lane) * NC + slot] != 0;
         if (slot == 0) tops0 = a.tops0[s0 + lane];
+    }
+    if constexpr (BIASED) {
+        if (alpha_noise) {
+            // Chain_alpha.__init__ (mcmc_alpha.py:18-22) on a fresh ladder; the carried attributes on resume.
+            // Parity 1 is "the step before step 0".
+            uint32_t v;
+            if (a.resume) v = lane < cnt ? a.neff[(s0 + lane) * NC + slot] : 0u;
+            else {
+                int nx = 0, ny = 0, nz = 0;
+                for (int w = 0; w < W; ++w) count_xyz(st[(slot * W + w) * 64 + lane], nx, ny, nz);
+                v = (uint32_t)nz | ((uint32_t)(nx + ny) << 16);
+            }
+            neffb[(NC + slot) * 64 + lane] = v;
+            __syncthreads();
+        }
     }
 
     // Roles rotate: at every ladder step each wave moves on to the next slot, so the heavier top
@@ -429,6 +499,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 double pb = 1.0;
                 if constexpr (BIASED) pb = bt[nx] * bt[T1 + ny] * bt[2 * T1 + nz] * bt[3 * T1 + (nq - nx - ny - nz)];
                 uint32_t cdelta = 0;
+                bool any_acc = false;
                 const uint32_t *lmask = a.lmask;
                 const int LW = (L + 1) * W;
                 uint32_t gs = SCAN ? (uint32_t)(kbase % a.n_gen) : 0u;
@@ -508,10 +579,18 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                             for (int i = 0; i < 4; ++i) lds_xor(stw + (ent[i] >> 6) * 64, (ent[i] & 3u) << (((ent[i] >> 2) & 15u) * 2u));
                         }
                         nx += dx; ny += dy; nz += dz;
+                        any_acc = true;
                     }
                 }
                 n = (uint32_t)(nx + ny + nz);
                 cls ^= cdelta;
+                if constexpr (BIASED) {
+                    // the slot's n_eff is refreshed by accepted moves only (mcmc_alpha.py:58,70); otherwise it keeps the
+                    // value it had, possibly that of a configuration since swapped away (quirk Q4)
+                    if (alpha_noise)
+                        neffb[((t & 1) * NC + slot_u) * 64 + lane] = any_acc ? ((uint32_t)nz | ((uint32_t)(nx + ny) << 16))
+                                                                             : neffb[(((t & 1) ^ 1) * NC + slot_u) * 64 + lane];
+                }
             }
         } else
         if (!top_logical) {
@@ -758,6 +837,11 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 const uint32_t lo = cur[i * 64], xi = sx[i * 64];
                 const int d = (int)(car & 0xFFFFu) - (int)(lo & 0xFFFFu);          // ne_hi - ne_lo
                 bool flip = d <= 0;                                                 // _r_flip :146, and u < rel_p**0 = 1
+                if (BIASED && alpha_noise) {
+                    // Ladder_alpha.r_flip, mcmc_alpha.py:118-123: slot-bound n_eff, always draws
+                    const uint32_t *ne = neffb + (t & 1) * NC * 64 + lane;
+                    flip = alpha_flip(xi, ne[(i + 1) * 64], ne[i * 64], a.alpha, a.alpha_lnb[i]);
+                } else
                 if (!flip) {                                                        // :149
                     if (swap_fast && d < kSwapFast) flip = xi < swapT[i * kSwapFast + d];
                     else flip = (uint64_t)xi < a.swap_thr[(size_t)i * (nq + 1) + d];
@@ -776,6 +860,21 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                     const uint32_t v = (car >> 24) & 0x3Fu;
                     hist[(CODE == kCodeXzzx ? (v ^ (v >> 1)) : v) * 64 + lane] += 1;
                     samples++;
+                    if (CONV && BIASED && alpha_noise) {
+                        // nbr_errors_bottom_chain[since_burn] = chains[0].n_eff (decoders_biasednoise.py:204): slot 0's
+                        // attribute, logged as its two counts; the window sums stay exact integers
+                        if (lane < cnt) {
+                            uint32_t *mylog = reinterpret_cast<uint32_t *>(a.nlog) + (s0 + lane);
+                            const uint32_t v0 = neffb[(t & 1) * NC * 64 + lane];
+                            mylog[(size_t)t * a.N] = v0;
+                            const uint32_t l = samples, lo1 = l - 1;
+                            const uint32_t a0 = lo1 >> 2, b0 = lo1 >> 1, c0 = (3u * lo1) >> 2, a1 = l >> 2, b1 = l >> 1, c1 = (3u * l) >> 2;
+                            sumB += v0 & 0xFFFFu; sumBxy += v0 >> 16;
+                            if (c1 != c0) { const uint32_t v = mylog[(size_t)(burn + c0) * a.N]; sumB -= v & 0xFFFFu; sumBxy -= v >> 16; }
+                            if (b1 != b0) { const uint32_t v = mylog[(size_t)(burn + b0) * a.N]; sumA += v & 0xFFFFu; sumAxy += v >> 16; }
+                            if (a1 != a0) { const uint32_t v = mylog[(size_t)(burn + a0) * a.N]; sumA -= v & 0xFFFFu; sumAxy -= v >> 16; }
+                        }
+                    } else
                     if (CONV && lane < cnt) {
                         // nbr_errors_bottom_chain[since_burn] = count_errors (:68); series index i lives in log row burn+i
                         uint16_t *mylog = a.nlog + (s0 + lane);
@@ -794,8 +893,12 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                     const uint32_t l = samples ? samples : 1u;
                     const uint32_t den2 = (l >> 1) - (l >> 2), den4 = l - ((3u * l) >> 2);
                     bool accept = false;                                            // empty slice -> nan -> not accepted
-                    if (samples && den2 && den4)
-                        accept = fabs((double)sumA / (double)den2 - (double)sumB / (double)den4) < a.eps;   // :96-102
+                    if (samples && den2 && den4) {
+                        if (BIASED && alpha_noise)
+                            accept = alpha_series_close(sumA, sumAxy, den2, sumB, sumBxy, den4, a.alpha, a.eps);
+                        else
+                            accept = fabs((double)sumA / (double)den2 - (double)sumB / (double)den4) < a.eps;   // :96-102
+                    }
                     if (accept) {
                         if (conv_streak >= a.SEQ) { done = 1; conv_ok = 1; steps_done = (uint32_t)t + 1; }   // :77-78
                         else conv_streak = tops0 - conv_start;                      // :79
@@ -830,6 +933,10 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
         if (a.flags != nullptr)
             for (int c = 0; c < NC; ++c) a.flags[(s0 + lane) * NC + c] = (uint8_t)(fin[c * 64 + lane] >> 31);
     }
+    if constexpr (BIASED) {
+        if (alpha_noise && a.neff != nullptr && lane < cnt)
+            a.neff[(s0 + lane) * NC + slot] = neffb[((((uint32_t)a.nsteps & 1u) ^ 1u) * NC + slot) * 64 + lane];
+    }
     if (a.write_states && a.states != nullptr) {
         uint8_t *dst = a.states + s0 * (uint64_t)NC * nq;
         const int per = NC * nq, total = cnt * per;
@@ -845,7 +952,7 @@ hipError_t launch_ladder_rs_toric(const LadderArgs &a, hipStream_t stream)
 {
     unsigned grid = (unsigned)((a.N + 63) / 64);
     unsigned block = (unsigned)a.Nc * 64u;
-    size_t lds = ladder_lds_bytes(a.L, a.Nc, a.W, a.ncls, ladder_gen_dwords(a.code, a.noise, a.scan, a.n_gen));
+    size_t lds = ladder_lds_bytes(a.L, a.Nc, a.W, a.ncls, ladder_gen_dwords(a.code, a.noise, a.scan, a.n_gen, a.Nc));
     if (grid == 0) return hipSuccess;
     // Nc <= 8: two 64-syndrome groups per workgroup (<= 1024 threads, 2 workgroups = 32 waves per CU);
     // Nc > 8: one group (<= 1024 threads)

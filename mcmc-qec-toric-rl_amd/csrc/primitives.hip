@@ -110,6 +110,7 @@ __global__ void k_chain_update(const ChainArgs a)
     auto thr = [&](int dE) { return a.acc_tbl[dE]; };       // ceil(f^dE * 2^32), dE in [1, nq]
     const bool top = a.thr_logical != 0;
     const double pb = a.noise ? biased_weight_b(a.bias_tbl, nq, m) : 0.0;       // mcmc_biased.py:28-31 (never refreshed: Q3)
+    bool any_acc = false;
     for (uint64_t j = 0; j < a.iters; ++j) {
         const uint64_t k = a.k0 + j;
         const u32x4 x = philox_block(k, 0, syn, a.slot, a.seed_lo, a.seed_hi);
@@ -149,6 +150,7 @@ __global__ void k_chain_update(const ChainArgs a)
         } else {
             acc = dE <= 0 || a.acc_all || x.w < thr(dE);                            // mcmc.py:42
         }
+        any_acc |= acc;
         if (!acc) {
             if (logical) {
                 if (code == kCodeToric) { toric_apply_logical_b(L, m, op1, 1, x1, z1); toric_apply_logical_b(L, m, op0, 0, x0, z0); }
@@ -157,6 +159,7 @@ __global__ void k_chain_update(const ChainArgs a)
             else surf_apply_stabilizer_b(code, L, m, row, col, op);
         }
     }
+    if (a.accepted != nullptr) a.accepted[i] = any_acc;
 }
 
 #define QECMC_LAUNCH(kern, N, s, ...)                                                    \

@@ -8,7 +8,8 @@ from .rotated_surface_model import RotSurCode
 from .mcmc import Chain, Ladder
 from .mcmc_biased import Chain_biased, Ladder_biased
 from .decoders import PTEQ, pteq_batch, percent_from_counts
-from .decoders_biasednoise import PTEQ_biased
+from .mcmc_alpha import Chain_alpha, Ladder_alpha
+from .decoders_biasednoise import PTEQ_biased, PTEQ_alpha
 
 __all__ = ["QecmcError", "device_count", "lib", "TORIC", "XZZX", "ROTATED", "Toric_code", "xzzx_code", "RotSurCode",
-           "Chain", "Ladder", "Chain_biased", "Ladder_biased", "PTEQ", "PTEQ_biased", "pteq_batch", "percent_from_counts"]
+           "Chain", "Ladder", "Chain_biased", "Ladder_biased", "Chain_alpha", "Ladder_alpha", "PTEQ", "PTEQ_biased", "PTEQ_alpha", "pteq_batch", "percent_from_counts"]

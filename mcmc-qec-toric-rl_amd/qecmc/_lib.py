@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libqecmc.so")
 
 TORIC, XZZX, ROTATED = 0, 1, 2
 SCAN_RANDOM, SCAN_CHECKERBOARD = 0, 1
-NOISE_DEPOLARIZING, NOISE_BIASED = 0, 1
+NOISE_DEPOLARIZING, NOISE_BIASED, NOISE_ALPHA = 0, 1, 2
 CONV_NONE, CONV_ERROR_BASED = 0, 1
 
 
@@ -28,7 +28,7 @@ class Params(C.Structure):
                 ("noise", C.c_int32), ("scan", C.c_int32), ("conv_mode", C.c_int32), ("device", C.c_int32),
                 ("iters", C.c_uint64), ("steps", C.c_uint64), ("tops_burn", C.c_int32), ("TOPS", C.c_int32),
                 ("SEQ", C.c_int32), ("reserved0", C.c_int32), ("eps", C.c_double), ("p", C.c_double),
-                ("eta", C.c_double), ("p_logical", C.c_double), ("seed", C.c_uint64),
+                ("eta", C.c_double), ("alpha", C.c_double), ("p_logical", C.c_double), ("seed", C.c_uint64),
                 ("first_syndrome", C.c_uint32), ("flags", C.c_uint32)]
 
 
@@ -41,6 +41,7 @@ _u8p = C.POINTER(C.c_uint8)
 _i32p = C.POINTER(C.c_int32)
 _u32p = C.POINTER(C.c_uint32)
 _i64p = C.POINTER(C.c_int64)
+_u16p = C.POINTER(C.c_uint16)
 
 # every symbol include/qecmc.h declares, with its signature
 SIGNATURES = {
@@ -57,8 +58,12 @@ SIGNATURES = {
                                      C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64]),
     "qecmc_chain_update_biased": (C.c_int, [C.c_int, C.c_int, C.c_uint64, _u8p, C.c_double, C.c_double, C.c_double,
                                             C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64]),
+    "qecmc_chain_update_alpha": (C.c_int, [C.c_int, C.c_int, C.c_uint64, _u8p, C.c_double, C.c_double, C.c_double,
+                                           C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, _u8p]),
     "qecmc_ladder_step": (C.c_int, [C.POINTER(Params), C.c_uint64, _u8p, _u8p, _u32p, C.c_uint64, C.c_uint64,
                                     C.c_uint64, C.c_uint64]),
+    "qecmc_ladder_step_alpha": (C.c_int, [C.POINTER(Params), C.c_uint64, _u8p, _u8p, _u32p, _u16p, C.c_uint64,
+                                          C.c_uint64, C.c_uint64, C.c_uint64]),
     "qecmc_pteq_batch": (C.c_int, [C.POINTER(Params), _u8p, C.c_uint64, _u32p, _u32p, _u32p, _u32p, _u8p, _u8p,
                                    C.POINTER(Stats)]),
     "qecmc_plan_workspace_bytes": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
@@ -82,7 +87,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
-        if L.qecmc_abi_version() != 1:
+        if L.qecmc_abi_version() != 2:
             raise QecmcError("libqecmc ABI version mismatch")
         _lib = L
     return _lib
@@ -109,6 +114,10 @@ def u32(a):
     return a.ctypes.data_as(_u32p)
 
 
+def u16(a):
+    return a.ctypes.data_as(_u16p)
+
+
 def as_states(m, ndim_state):
     """C-contiguous uint8 array with a leading batch axis; returns (array, batched?)."""
     a = np.ascontiguousarray(m, dtype=np.uint8)
@@ -121,11 +130,11 @@ def as_states(m, ndim_state):
 
 def make_params(code=TORIC, L=0, Nc=1, p=0.1, p_logical=0.0, iters=10, steps=0, tops_burn=2, TOPS=10, SEQ=2,
                 eps=0.1, seed=0, first_syndrome=0, conv_mode=CONV_NONE, scan=SCAN_RANDOM,
-                noise=NOISE_DEPOLARIZING, eta=0.0, device=0):
+                noise=NOISE_DEPOLARIZING, eta=0.0, alpha=0.0, device=0):
     pr = Params()
     pr.abi_size = C.sizeof(Params)
     pr.code, pr.L, pr.Nc, pr.noise, pr.scan, pr.conv_mode, pr.device = code, L, Nc, noise, scan, conv_mode, device
     pr.iters, pr.steps, pr.tops_burn, pr.TOPS, pr.SEQ = iters, steps, tops_burn, TOPS, SEQ
-    pr.eps, pr.p, pr.eta, pr.p_logical = eps, p, eta, p_logical
+    pr.eps, pr.p, pr.eta, pr.alpha, pr.p_logical = eps, p, eta, alpha, p_logical
     pr.seed, pr.first_syndrome, pr.flags = seed & 0xFFFFFFFFFFFFFFFF, first_syndrome, 0
     return pr

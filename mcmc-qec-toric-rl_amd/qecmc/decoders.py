@@ -16,11 +16,12 @@ def percent_from_counts(counts, samples):
 
 def pteq_batch(init, p, Nc=None, steps=1000, iters=10, tops_burn=2, p_logical=0.5, seed=0, first_syndrome=0,
                device=0, return_states=False, return_stats=False, conv_criteria=None, SEQ=2, TOPS=10, eps=0.1,
-               code=L_.TORIC, eta=None, scan="random"):
+               code=L_.TORIC, eta=None, scan="random", alpha=None):
     """decoders.PTEQ (decoders.py:25-89) on N syndromes at once.
 
     init: uint8[N, 2, L, L] (toric) or uint8[N, L, L] (code=XZZX / ROTATED) seed configurations, one per
-    syndrome; eta selects the biased chain of src/mcmc_biased.py (PTEQ_biased); scan="random" is the reference's
+    syndrome; eta selects the biased chain of src/mcmc_biased.py (PTEQ_biased), alpha the "alpha" noise ladder of
+    src/mcmc_alpha.py (PTEQ_alpha; `p` is then pz_tilde); scan="random" is the reference's
     chain, scan="sweep" the systematic generator sweep (same stationary law, faster).  conv_criteria None runs exactly
     `steps` ladder steps; 'error_based' stops each syndrome by the reference's criterion (:74-105).
     Returns dict(counts uint32[N,16], samples uint32[N], tops0 uint32[N], steps_done uint32[N],
@@ -36,7 +37,8 @@ def pteq_batch(init, p, Nc=None, steps=1000, iters=10, tops_burn=2, p_logical=0.
                         steps=int(steps), tops_burn=int(tops_burn), TOPS=int(TOPS), SEQ=int(SEQ), eps=float(eps),
                         seed=seed, first_syndrome=first_syndrome, device=device,
                         conv_mode=L_.CONV_ERROR_BASED if conv_criteria else L_.CONV_NONE,
-                        noise=L_.NOISE_DEPOLARIZING if eta is None else L_.NOISE_BIASED, eta=0.0 if eta is None else float(eta),
+                        noise=L_.NOISE_ALPHA if alpha is not None else L_.NOISE_DEPOLARIZING if eta is None else L_.NOISE_BIASED,
+                        eta=0.0 if eta is None else float(eta), alpha=0.0 if alpha is None else float(alpha),
                         scan={"random": L_.SCAN_RANDOM, "sweep": L_.SCAN_CHECKERBOARD}[scan])
     counts = np.zeros((N, ncls), dtype=np.uint32)
     samples = np.zeros(N, dtype=np.uint32)
@@ -68,12 +70,12 @@ def PTEQ(init_code, p, Nc=None, SEQ=2, TOPS=10, tops_burn=2, eps=0.1, steps=5000
     return _pteq(init_code, p, None, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, conv_criteria, seed)
 
 
-def _pteq(init_code, p, eta, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, conv_criteria, seed):
+def _pteq(init_code, p, eta, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, conv_criteria, seed, alpha=None):
     if tops_burn >= TOPS:
         print('tops_burn has to be smaller than TOPS')
     seed = _fresh_seed() if seed is None else seed
     kw = dict(Nc=Nc or init_code.system_size, iters=iters, tops_burn=tops_burn, p_logical=0.5, seed=seed,
-              code=_code_id(init_code), eta=eta)
+              code=_code_id(init_code), eta=eta, alpha=alpha)
     if conv_criteria is None:
         return pteq_batch(init_code.qubit_matrix, p, steps=steps, **kw)["percent"][0]
     horizon = min(int(steps), 1 << 16)

@@ -40,7 +40,7 @@ DEPOLARIZING, BIASED, ALPHA = 0, 1, 2
 class _Ladder(C.Structure):
     _fields_ = [("model", Model), ("L", C.c_int), ("Nc", C.c_int), ("nq", C.c_int), ("p_logical", C.c_double),
                 ("p_ladder", C.POINTER(C.c_double)), ("p_diff", C.POINTER(C.c_double)),
-                ("states", C.POINTER(C.c_uint8)), ("flags", C.POINTER(C.c_uint8)), ("n_eff", C.POINTER(C.c_double)),
+                ("states", C.POINTER(C.c_uint8)), ("flags", C.POINTER(C.c_uint8)), ("n_eff", C.POINTER(C.c_double)), ("n_eff_cnt", C.POINTER(C.c_uint32)),
                 ("tops0", C.c_uint64), ("step_index", C.c_uint64), ("scratch", C.POINTER(C.c_uint8))]
 
 
@@ -105,7 +105,7 @@ def lib():
         _LIB.orc_chain_update.restype = None
         _LIB.orc_chain_update_alpha.argtypes = [mp, u8p, C.c_double, C.c_double, C.c_uint64, C.POINTER(_Rng), C.c_uint32,
                                                 C.c_uint64, u8p, C.POINTER(C.c_double)]
-        _LIB.orc_chain_update_alpha.restype = None
+        _LIB.orc_chain_update_alpha.restype = C.c_int
         _LIB.orc_det_exp.argtypes = [C.c_double]; _LIB.orc_det_exp.restype = C.c_double
         _LIB.orc_ladder_new.argtypes = [mp, u8p, C.c_double, C.c_int, C.c_double]
         _LIB.orc_ladder_new.restype = C.POINTER(_Ladder)
@@ -373,6 +373,10 @@ class Ladder:
     @property
     def n_eff(self):
         return np.ctypeslib.as_array(self._p.contents.n_eff, shape=(self.Nc,)).copy()
+
+    @property
+    def n_eff_counts(self):
+        return np.ctypeslib.as_array(self._p.contents.n_eff_cnt, shape=(self.Nc, 2)).copy()
 
 
 def pteq(code, init, p, Nc=None, SEQ=2, TOPS=10, tops_burn=2, eps=0.1, steps=1000, iters=10, conv_criteria=None,

@@ -368,7 +368,7 @@ double orc_det_exp(double y)
 
 /* Chain_alpha.update_chain, mcmc_alpha.py:27-70: the biased rule with (p_x, p_y, p_z) derived from (pz_tilde, alpha),
  * p_b frozen at loop entry (Q3), and n_eff = n_z + alpha (n_x + n_y) refreshed on every accepted move (:58,:70). */
-void orc_chain_update_alpha(const orc_model *m, uint8_t *state, double pz_tilde, double p_logical, uint64_t iters,
+int orc_chain_update_alpha(const orc_model *m, uint8_t *state, double pz_tilde, double p_logical, uint64_t iters,
                                orc_rng *rng, uint32_t slot, uint64_t k0, uint8_t *scratch, double *n_eff)
 {
     const size_t nq = (size_t)orc_nq(m->code, m->L);
@@ -377,6 +377,7 @@ void orc_chain_update_alpha(const orc_model *m, uint8_t *state, double pz_tilde,
     const double p = p_tilde / (1 + p_tilde);                                           /* :34 */
     const double pz = pz_tilde * (1 - p), px = pow(pz_tilde, alpha) * (1 - p), py = px; /* :35-36 */
     const double pb = biased_weight(state, (int)nq, px, py, pz);                        /* :38-41 */
+    int accepted = 0;
     for (uint64_t j = 0; j < iters; ++j) {
         const uint64_t k = k0 + j;
         double u;
@@ -393,8 +394,10 @@ void orc_chain_update_alpha(const orc_model *m, uint8_t *state, double pz_tilde,
             int nx = 0, ny = 0, nz = 0;
             for (size_t i = 0; i < nq; ++i) { nx += state[i] == 1; ny += state[i] == 2; nz += state[i] == 3; }
             *n_eff = nz + alpha * (nx + ny);
+            accepted = 1;
         }
     }
+    return accepted;
 }
 
 void orc_chain_update(const orc_model *m, uint8_t *state, double p, double p_logical, uint64_t iters,
@@ -493,7 +496,11 @@ orc_ladder *orc_ladder_new(const orc_model *m, const uint8_t *init, double p_bot
     {   /* Chain_alpha.__init__, mcmc_alpha.py:18-22 */
         int nx = 0, ny = 0, nz = 0;
         for (int i = 0; i < ld->nq; ++i) { nx += init[i] == 1; ny += init[i] == 2; nz += init[i] == 3; }
-        for (int c = 0; c < Nc; ++c) ld->n_eff[c] = nz + m->alpha * (nx + ny);
+        ld->n_eff_cnt = (uint32_t *)calloc((size_t)Nc * 2, sizeof(uint32_t));
+        for (int c = 0; c < Nc; ++c) {
+            ld->n_eff[c] = nz + m->alpha * (nx + ny);
+            ld->n_eff_cnt[2 * c] = (uint32_t)nz; ld->n_eff_cnt[2 * c + 1] = (uint32_t)(nx + ny);
+        }
     }
     /* p_top = 0.75 (mcmc.py:62), (eta+1)/(2 eta+1) (mcmc_biased.py:81) or pz_tilde_top = 1 (mcmc_alpha.py:94) */
     const double p_top = m->noise == ORC_NOISE_BIASED ? (m->eta + 1) / (2 * m->eta + 1) : m->noise == ORC_NOISE_ALPHA ? 1.0 : 0.75;
@@ -512,7 +519,7 @@ orc_ladder *orc_toric_ladder_new(int L, const uint8_t *init, double p_bottom, in
 void orc_ladder_free(orc_ladder *ld)
 {
     if (!ld) return;
-    free(ld->p_ladder); free(ld->p_diff); free(ld->states); free(ld->flags); free(ld->scratch); free(ld->n_eff);
+    free(ld->p_ladder); free(ld->p_diff); free(ld->states); free(ld->flags); free(ld->scratch); free(ld->n_eff); free(ld->n_eff_cnt);
     free(ld);
 }
 
@@ -523,10 +530,15 @@ void orc_ladder_step(orc_ladder *ld, uint64_t iters, orc_rng *rng)
     const uint64_t k0 = ld->step_index * iters;
     const int is_alpha = ld->model.noise == ORC_NOISE_ALPHA;
     for (int c = 0; c < Nc; ++c) {                                  /* update_ladder :81-83 */
-        if (is_alpha)
-            orc_chain_update_alpha(&ld->model, ld->states + (size_t)c * nq, ld->p_ladder[c], c == Nc - 1 ? ld->p_logical : 0.0,
-                               iters, rng, (uint32_t)c, k0, ld->scratch, &ld->n_eff[c]);
-        else
+        if (is_alpha) {
+            if (orc_chain_update_alpha(&ld->model, ld->states + (size_t)c * nq, ld->p_ladder[c], c == Nc - 1 ? ld->p_logical : 0.0,
+                                       iters, rng, (uint32_t)c, k0, ld->scratch, &ld->n_eff[c])) {
+                const uint8_t *st = ld->states + (size_t)c * nq;         /* the counts n_eff was formed from */
+                uint32_t nz = 0, nxy = 0;
+                for (int q = 0; q < (int)nq; ++q) { nz += st[q] == 3; nxy += st[q] == 1 || st[q] == 2; }
+                ld->n_eff_cnt[2 * c] = nz; ld->n_eff_cnt[2 * c + 1] = nxy;
+            }
+        } else
             orc_chain_update(&ld->model, ld->states + (size_t)c * nq, ld->p_ladder[c],
                              c == Nc - 1 ? ld->p_logical : 0.0, iters, rng, (uint32_t)c, k0, ld->scratch);
     }
@@ -575,6 +587,13 @@ static double mean_range(const double *a, uint64_t lo, uint64_t hi)
     return s / (double)(hi - lo);
 }
 
+static double sum_range(const double *a, uint64_t lo, uint64_t hi)
+{
+    double s = 0;
+    for (uint64_t i = lo; i < hi; ++i) s += a[i];      /* integer-valued: exact */
+    return s;
+}
+
 void orc_pteq(const orc_model *m, const uint8_t *init, double p, int Nc, int SEQ, int TOPS, int tops_burn,
               double eps, uint64_t steps, uint64_t iters, int conv_mode, orc_rng *rng,
               orc_pteq_result *res, uint8_t *final_states)
@@ -586,6 +605,10 @@ void orc_pteq(const orc_model *m, const uint8_t *init, double p, int Nc, int SEQ
     uint32_t eq[16];
     memset(eq, 0, sizeof eq);
     double *series = conv_mode ? (double *)calloc((size_t)steps, sizeof(double)) : NULL;
+    /* det_pow: the GPU's form of the alpha series means, (sum n_z + alpha sum n_xy) / len from exact integer sums */
+    const int det_series = conv_mode && m->noise == ORC_NOISE_ALPHA && m->det_pow;
+    double *series_z = det_series ? (double *)calloc((size_t)steps, sizeof(double)) : NULL;
+    double *series_xy = det_series ? (double *)calloc((size_t)steps, sizeof(double)) : NULL;
     int converged = 0;
     uint64_t step;
     for (step = 0; step < steps; ++step) {                          /* :55 */
@@ -597,6 +620,7 @@ void orc_pteq(const orc_model *m, const uint8_t *init, double p, int Nc, int SEQ
             recorded = since_burn + 1;
             if (series) series[since_burn] = m->noise == ORC_NOISE_ALPHA ? ld->n_eff[0]     /* decoders_biasednoise.py:204 */
                                                                          : (double)orc_count_errors((size_t)ld->nq, ld->states);
+            if (det_series) { series_z[since_burn] = ld->n_eff_cnt[0]; series_xy[since_burn] = ld->n_eff_cnt[1]; }
         } else {
             resulting_burn_in += 1;                                 /* :71 */
         }
@@ -604,6 +628,11 @@ void orc_pteq(const orc_model *m, const uint8_t *init, double p, int Nc, int SEQ
             uint64_t l = since_burn + 1;
             double q2 = mean_range(series, l / 4, l / 2);
             double q4 = mean_range(series, 3 * l / 4, l);
+            if (det_series) {
+                const double n2 = (double)(l / 2 - l / 4), n4 = (double)(l - 3 * l / 4);
+                q2 = n2 > 0 ? (sum_range(series_z, l / 4, l / 2) + m->alpha * sum_range(series_xy, l / 4, l / 2)) / n2 : NAN;
+                q4 = n4 > 0 ? (sum_range(series_z, 3 * l / 4, l) + m->alpha * sum_range(series_xy, 3 * l / 4, l)) / n4 : NAN;
+            }
             double err = fabs(q2 - q4);
             if (err < eps) {                                        /* :102 */
                 if (conv_streak >= (uint64_t)SEQ) { converged = 1; step++; break; }
@@ -623,7 +652,7 @@ void orc_pteq(const orc_model *m, const uint8_t *init, double p, int Nc, int SEQ
     for (int i = 0; i < ncls; ++i)                                  /* :89 */
         res->percent[i] = (uint8_t)((double)eq[i] / (double)(since_burn + 1) * 100.0);
     if (final_states) memcpy(final_states, ld->states, (size_t)Nc * ld->nq);
-    free(series);
+    free(series); free(series_z); free(series_xy);
     orc_ladder_free(ld);
 }
 

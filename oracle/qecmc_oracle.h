@@ -97,6 +97,7 @@ typedef struct orc_ladder {
     uint8_t *states;     /* [Nc][nq], slot order (chains[i].code.qubit_matrix) */
     uint8_t *flags;      /* [Nc] */
     double *n_eff;       /* [Nc] Chain_alpha.n_eff: stays with the SLOT when codes are swapped (quirk Q4) */
+    uint32_t *n_eff_cnt; /* [Nc][2] the (n_z, n_x + n_y) each n_eff was formed from */
     uint64_t tops0;
     uint64_t step_index; /* ladder steps done so far (Philox addressing) */
     uint8_t *scratch;    /* [nq] */
@@ -143,7 +144,7 @@ void orc_pteq_batch(const orc_model *m, const uint8_t *init, uint64_t N, uint32_
                     uint8_t *final_states /*nullable*/);
 
 /* Chain_alpha.update_chain (mcmc_alpha.py:27-70); *n_eff is the chain's n_eff attribute (updated on accepted moves only) */
-void orc_chain_update_alpha(const orc_model *m, uint8_t *state, double pz_tilde, double p_logical, uint64_t iters,
+int orc_chain_update_alpha(const orc_model *m, uint8_t *state, double pz_tilde, double p_logical, uint64_t iters,
                             orc_rng *rng, uint32_t slot, uint64_t k0, uint8_t *scratch, double *n_eff);
 double orc_det_exp(double y);   /* deterministic exp for y <= 0 (IEEE +,*,fma only): bit-identical on CPU and GPU */
 

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/qecmc.h but not exported"
     assert set(names) == set(L_.SIGNATURES), "ctypes binding and header disagree"
-    assert lib.qecmc_abi_version() == 1
+    assert lib.qecmc_abi_version() == 2
 
 
 def test_params_struct_matches_the_c_layout():
@@ -49,7 +49,8 @@ def test_params_struct_matches_the_c_layout():
                                      (dict(L=5, Nc=3, code=5), b"code 5"), (dict(L=4, Nc=3, code=1), b"odd L"),
                                      (dict(L=5, Nc=3, noise=1, eta=10.0), b"biased noise is built for"),
                                      (dict(L=5, Nc=3, code=1, noise=1, eta=0.0), b"eta"), (dict(L=5, Nc=3, iters=0), b"iters"),
-                                     (dict(L=5, Nc=3, scan=1), b"scan"), (dict(L=5, Nc=3, p_logical=1.5), b"p_logical")])
+                                     (dict(L=5, Nc=3, scan=7), b"scan"), (dict(L=5, Nc=3, code=1, noise=2, alpha=0.0), b"alpha"),
+                                     (dict(L=5, Nc=3, noise=2, alpha=2.0), b"alpha noise is built for"), (dict(L=5, Nc=3, p_logical=1.5), b"p_logical")])
 def test_argument_validation_precedes_everything(kw, frag):
     base = dict(L=5, Nc=5, p=0.1, p_logical=0.5, steps=10)
     base.update(kw)
