@@ -20,7 +20,21 @@ def _class_of(code, m):
     return toric_model.eq_class(m) if code == L_.TORIC else _surf.eq_class(code, m)
 
 
-def draw_errors(code, size, n, p_error, rng, eta=None):
+def alpha_rates(pz_tilde, alpha):
+    """(p_x, p_y, p_z) of the alpha noise model (generate_data.py:84-91, mcmc_alpha.py:31-36)."""
+    p_tilde = pz_tilde + 2 * pz_tilde ** alpha
+    p = p_tilde / (1 + p_tilde)
+    px = pz_tilde ** alpha * (1 - p)
+    return px, px, pz_tilde * (1 - p)
+
+
+def biased_as_alpha(p, eta):
+    """generate_data.py:145-146: the (pz_tilde, alpha) that `generate` hands to PTEQ_alpha for noise = 'biased'."""
+    pz_tilde = (p / (1 + 1 / eta)) / (1 - p)
+    return pz_tilde, np.log(pz_tilde / (2 * eta)) / np.log(pz_tilde)
+
+
+def draw_errors(code, size, n, p_error, rng, eta=None, rates=None):
     """n random error chains: toric -- each qubit errs w.p. p_error, Pauli uniform (toric_model.py:15-23);
     xzzx / rotated -- one uniform per qubit against (p_z, p_x, p_y) (xzzx_model.py:16-30), with
     p_x = p_y = p_z = p/3 (generate_data.py:116-118) or the Z-biased split p_z = p eta/(eta+1),
@@ -31,7 +45,9 @@ def draw_errors(code, size, n, p_error, rng, eta=None):
         err = rng.random(m.shape) < p_error
         m[err] = rng.integers(1, 4, size=int(err.sum()), dtype=np.uint8)
         return m
-    if eta is None:
+    if rates is not None:
+        px, py, pz = rates
+    elif eta is None:
         px = py = pz = p_error / 3
     else:
         pz, px = p_error * eta / (eta + 1), p_error / (2 * (eta + 1))
@@ -64,19 +80,33 @@ def hide_class(code, m, rng):
     return m
 
 
-def generate(params, nbr_datapoints, seed=0, file_path=None, steps=100000, conv_criteria="error_based", **pteq_kw):
-    """params: dict like generate_data.py:276-296 ({'code','size','p_error','noise'[,'eta']}), method PTEQ.
+def generate(params, nbr_datapoints, seed=0, file_path=None, steps=100000, conv_criteria="error_based", biased_decoder="alpha",
+             **pteq_kw):
+    """params: dict like generate_data.py:276-296 ({'code','size','p_error','noise'[,'eta','alpha']}), method PTEQ.
+    noise 'depolarizing' -> PTEQ (:136); 'biased' -> errors from the eta split (:78-83) decoded by PTEQ_alpha with
+    (pz_tilde, alpha) derived from (p, eta) exactly as :142-150 does (biased_decoder="biased" decodes with PTEQ_biased
+    instead); 'alpha' -> p_error is pz_tilde, errors and decoder from (pz_tilde, alpha) (:84-91,:151-160).
     Returns (and optionally saves as npz) qubit_matrix uint8[n,...] (the raw errors, generate_data.py:120),
     eq_true int32[n], counts uint32[n,ncls], distr uint8[n,ncls] (what PTEQ returns), success bool[n]
     (argmax(distr) == eq_true, generate_data.py:139), steps_done, converged."""
     code = _CODES[params["code"]]
     size, p = params["size"], params["p_error"]
-    eta = params.get("eta") if params.get("noise", "depolarizing") == "biased" else None
+    noise = params.get("noise", "depolarizing")
+    if noise not in ("depolarizing", "biased", "alpha"):
+        raise ValueError(f"noise={noise!r}")
+    eta = params.get("eta") if noise == "biased" else None
     rng = np.random.default_rng(seed)
-    raw = draw_errors(code, size, nbr_datapoints, p, rng, eta)
+    raw = draw_errors(code, size, nbr_datapoints, p, rng, eta, rates=alpha_rates(p, params["alpha"]) if noise == "alpha" else None)
     eq_true = np.asarray(_class_of(code, raw), dtype=np.int32)
     init = hide_class(code, raw, rng)
-    res = pteq_batch(init, p, Nc=params.get("Nc"), steps=steps, conv_criteria=conv_criteria, seed=seed, code=code, eta=eta,
+    dec = dict(eta=eta)
+    p_dec = p
+    if noise == "alpha":
+        dec = dict(alpha=params["alpha"])
+    elif noise == "biased" and biased_decoder == "alpha":
+        p_dec, a = biased_as_alpha(p, eta)
+        dec = dict(alpha=float(a))
+    res = pteq_batch(init, p_dec, Nc=params.get("Nc"), steps=steps, conv_criteria=conv_criteria, seed=seed, code=code, **dec,
                      **pteq_kw)
     out = dict(qubit_matrix=raw, eq_true=eq_true, counts=res["counts"], distr=res["percent"],
                success=np.argmax(res["percent"], axis=1) == eq_true, steps_done=res["steps_done"],

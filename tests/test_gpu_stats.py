@@ -90,7 +90,11 @@ def test_harness_generate_decodes_low_noise(q, tmp_path):
                        ({"code": "rotated", "size": 5, "p_error": 0.05, "noise": "depolarizing"},
                         dict(steps=3000, conv_criteria=None, tops_burn=0)),
                        ({"code": "xzzx", "size": 5, "p_error": 0.05, "noise": "biased", "eta": 10},
-                        dict(steps=3000, conv_criteria=None, tops_burn=0))):
+                        dict(steps=3000, conv_criteria=None, tops_burn=0, biased_decoder="biased")),      # PTEQ_biased
+                       ({"code": "xzzx", "size": 5, "p_error": 0.05, "noise": "biased", "eta": 10},
+                        dict(steps=3000, conv_criteria=None, tops_burn=0)),     # PTEQ_alpha, as generate_data.py:142-150 routes it
+                       ({"code": "rotated", "size": 5, "p_error": 0.04, "noise": "alpha", "alpha": 2.0},
+                        dict(steps=200000))):                                   # PTEQ_alpha's default error_based criterion
         f = tmp_path / (params["code"] + ".npz")
         out = harness.generate(params, 256, seed=3, file_path=str(f), **kw)
         assert out["distr"].shape == (256, 16 if params["code"] == "toric" else 4)
