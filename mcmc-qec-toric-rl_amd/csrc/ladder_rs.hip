@@ -595,11 +595,12 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
         } else
         if (!top_logical) {
             int ni = (int)n;
-            auto propose = [&](const u32x4 &x) {
-                const uint32_t row = scale_u32(x.x, L), col = scale_u32(x.y, L);   // toric_model.py:291-292
-                const uint32_t isX = x.z >> 31;                                    // :293-295
-                const uint4 ev = gtab4[(isX ? 0u : (uint32_t)LL) + row * L + col];   // the four sites (toric_model.py:261-269)
-                const uint32_t sh[4] = {ev.x, ev.y, ev.z, ev.w};                    // dword offset << 10 | bit shift in [4:0]
+            // One Philox word picks the generator (g = floor(x * 2L^2 / 2^32): uniform over the 2L^2 generators as the
+            // reference's three draws are, toric_model.py:291-295), one is the acceptance uniform: a block feeds two proposals.
+            const uint32_t G2 = 2u * (uint32_t)LL;
+            auto propose = [&](uint32_t xp, uint32_t xa) {
+                const uint4 ev = gtab4[scale_u32(xp, G2)];                          // the four sites (toric_model.py:261-269)
+                const uint32_t sh[4] = {ev.x, ev.y, ev.z, ev.w};                    // dword offset << 10 | pauli << 5 | bit shift
                 uint32_t *ad[4];
                 uint32_t F = 0;
 #pragma unroll
@@ -607,10 +608,10 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                     ad[i] = stw + (sh[i] >> 10);
                     F |= bfe2_lo5(*ad[i], sh[i]) << (2 * i);
                 }
-                const uint32_t op = isX ? 1u : 3u;
+                const uint32_t op = (ev.x >> 5) & 3u;
                 const uint32_t G = F ^ (op * 0x55u);                               // the four new values
                 const int dE = __popc((G | (G >> 1)) & 0x55u) - __popc((F | (F >> 1)) & 0x55u);   // :275-282
-                if (x.w <= myT[dE]) {                                               // mcmc.py:42
+                if (xa <= myT[dE]) {                                                // mcmc.py:42
 #pragma unroll
                     for (int i = 0; i < 4; ++i) lds_xor(ad[i], shl_lo5(op, sh[i]));
                     ni += dE;
@@ -657,15 +658,27 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 }
                 j = iters;
             }
-            // the uniforms of a proposal do not depend on the state: draw two proposals' Philox blocks
-            // together so their serial 10-round chains overlap, then apply the proposals in order
-            for (; j + 1 < iters; j += 2) {
-                const u32x4 xa = philox_block(kbase + j, 0, syn, slot_u, a.seed_lo, a.seed_hi);
-                const u32x4 xb = philox_block(kbase + j + 1, 0, syn, slot_u, a.seed_lo, a.seed_hi);
-                propose(xa);
-                propose(xb);
+            // proposal k uses words 2(k&1), 2(k&1)+1 of block (k>>1, 0).  The uniforms do not depend on the state: draw two
+            // blocks together so their serial 10-round chains overlap, then apply the four proposals in order
+            if (!SCAN && j < iters && (kbase & 1)) {
+                const u32x4 xa = philox_block(kbase >> 1, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                propose(xa.z, xa.w);
+                j = 1;
             }
-            if (j < iters) propose(philox_block(kbase + j, 0, syn, slot_u, a.seed_lo, a.seed_hi));
+            for (; j + 3 < iters; j += 4) {
+                const uint64_t kb = (kbase + j) >> 1;
+                const u32x4 xa = philox_block(kb, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                const u32x4 xb = philox_block(kb + 1, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                propose(xa.x, xa.y);
+                propose(xa.z, xa.w);
+                propose(xb.x, xb.y);
+                propose(xb.z, xb.w);
+            }
+            for (; j < iters; j += 2) {
+                const u32x4 xa = philox_block((kbase + j) >> 1, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                propose(xa.x, xa.y);
+                if (j + 1 < iters) propose(xa.z, xa.w);
+            }
             n = (uint32_t)ni;
         } else if (acc_all && L <= 16) {
             // Top chain at p = 0.75: every proposal is accepted (mcmc.py:30), so moves are blind
@@ -709,10 +722,9 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 if (x.x <= thrL1) {                                                 // mcmc.py:23
                     add_logical(x);
                 } else {
-                    const uint32_t row = scale_u32(x.y, L), col = scale_u32(x.z, L), isX = x.w >> 31;
-                    const uint4 ev = gtab4[(isX ? 0u : (uint32_t)LL) + row * L + col];
+                    const uint4 ev = gtab4[scale_u32(x.y, 2u * (uint32_t)LL)];     // word 1 picks the generator
                     const uint32_t e4[4] = {ev.x, ev.y, ev.z, ev.w};
-                    const uint32_t op = isX ? 1u : 3u;
+                    const uint32_t op = (ev.x >> 5) & 3u;
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
                         lds_xor(stw + (e4[i] >> 10), shl_lo5(op, e4[i]));
@@ -782,8 +794,8 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                         q[0] = (e.x & 0xFFFFu) >> 2; q[1] = e.x >> 18; q[2] = (e.y & 0xFFFFu) >> 2; q[3] = e.y >> 18;
                         op = e.x & 3u;
                     } else {
-                        const uint32_t isX = x.w >> 31;
-                        toric_sites(L, LL, scale_u32(x.y, L), scale_u32(x.z, L), isX, q);
+                        const uint32_t g = scale_u32(x.y, 2u * (uint32_t)LL), isX = g < (uint32_t)LL, rc = isX ? g : g - (uint32_t)LL;
+                        toric_sites(L, LL, rc / (uint32_t)L, rc % (uint32_t)L, isX, q);
                         op = isX ? 1u : 3u;
                     }
                     int dE = 0;

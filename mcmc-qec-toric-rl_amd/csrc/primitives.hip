@@ -113,7 +113,13 @@ __global__ void k_chain_update(const ChainArgs a)
     bool any_acc = false;
     for (uint64_t j = 0; j < a.iters; ++j) {
         const uint64_t k = a.k0 + j;
-        const u32x4 x = philox_block(k, 0, syn, a.slot, a.seed_lo, a.seed_hi);
+        // toric non-top proposals share a block: words 2(k&1) (generator) and 2(k&1)+1 (acceptance) of block (k>>1, 0)
+        const bool paired = code == kCodeToric && !top;
+        u32x4 x = philox_block(paired ? k >> 1 : k, 0, syn, a.slot, a.seed_lo, a.seed_hi);
+        if (paired) {
+            if (k & 1) { x.x = x.z; x.y = x.w; }
+            x.w = x.y;                                                              // acceptance uniform
+        }
         // ---- propose (in place; XOR moves are involutions, so a rejected move is undone by re-applying it)
         int dE, row = 0, col = 0, op = 0, op0 = 0, op1 = 0, x0 = 0, z0 = 0, x1 = 0, z1 = 0;
         const bool logical = top && (uint64_t)x.x < a.thr_logical;                 // mcmc.py:23
@@ -132,8 +138,9 @@ __global__ void k_chain_update(const ChainArgs a)
                 dE = surf_apply_logical_b(code, L, m, op0, x0, z0);
             }
         } else if (code == kCodeToric) {
-            const uint32_t wr = top ? x.y : x.x, wc = top ? x.z : x.y, wo = top ? x.w : x.z;
-            row = scale_u32(wr, L); col = scale_u32(wc, L); op = (wo >> 31) ? 1 : 3;
+            // one word picks one of the 2L^2 generators (toric_model.py:291-295): X plaquettes first, row-major
+            const uint32_t g = scale_u32(top ? x.y : x.x, 2u * L * L), rc = g < (uint32_t)(L * L) ? g : g - L * L;
+            row = rc / L; col = rc % L; op = g < (uint32_t)(L * L) ? 1 : 3;
             dE = toric_apply_stabilizer_b(L, m, row, col, op);
         } else {
             surf_pick(L, top ? x.y : x.x, top ? x.z : x.y, top ? x.w : x.z, a.thr_half, row, col, op);

@@ -220,8 +220,25 @@ int orc_eq_class(int code, int L, const uint8_t *m)
     return code == ORC_TORIC ? orc_toric_eq_class(L, m) : orc_surf_eq_class(code, L, m);
 }
 
+/* Philox address of a toric proposal's draws.  Non-top chains (mcmc.py:38-43) need a generator and an acceptance
+ * uniform: proposal k uses words 2(k&1) (generator) and 2(k&1)+1 (acceptance) of block (k>>1, 0), so one block feeds
+ * two proposals.  Top chains (mcmc.py:21-35) keep block (k, 0): word 0 selects logical / stabilizer, word 1 picks the
+ * generator, words 1-3 carry a logical operator; the acceptance uniform is word 0 of block (k, 2). */
+static double toric_nontop_accept(orc_rng *rng, uint32_t slot, uint64_t k)
+{
+    return orc_draw(rng, slot, k >> 1, 0, 2 * (int)(k & 1) + 1);
+}
+
+/* acceptance uniform of a non-top proposal: toric see above; xzzx / rotated word 3 of block (k, 0) */
+static double nontop_accept(const orc_model *m, orc_rng *rng, uint32_t slot, uint64_t k)
+{
+    return m->code == ORC_TORIC ? toric_nontop_accept(rng, slot, k) : orc_draw(rng, slot, k, 0, 3);
+}
+
 /* _apply_random_stabilizer.
- * toric (toric_model.py:287-296): three draws row, col, op -> words w0, w0+1, w0+2 of block (k,0).
+ * toric (toric_model.py:287-296): three draws row, col, op, i.e. a uniform choice among the 2L^2 generators.  The
+ * injected-stream mode consumes them as the reference does; Philox mode spends ONE word on the same uniform choice:
+ * g = floor(x * 2L^2 / 2^32), op = 1 if g < L^2 else 3, (row, col) = divmod(g mod L^2, L).
  * xzzx / rotated (xzzx_model.py:439-452, rotated_surface_model.py:395-408): FIVE draws, always:
  * rows, cols in [0,L-1), rows2 in [0,(L-1)/2), cols2 in [0,4), then `u > phalf` picks the full
  * plaquette.  Philox addressing: rows / cols = high / low half of word w0, rows2 = high half of
@@ -231,10 +248,20 @@ static int model_random_stabilizer(const orc_model *m, const uint8_t *in, uint8_
 {
     const int L = m->L;
     if (m->code == ORC_TORIC) {
-        int row = (int)(orc_draw(rng, slot, k, 0, w0) * L);
-        int col = (int)(orc_draw(rng, slot, k, 0, w0 + 1) * L);
-        int op = (int)(orc_draw(rng, slot, k, 0, w0 + 2) * 2);
-        if (op == 0) op = 3;
+        int row, col, op;
+        if (rng->mode == 0) {
+            row = (int)(orc_draw(rng, slot, k, 0, w0) * L);           /* toric_model.py:291 */
+            col = (int)(orc_draw(rng, slot, k, 0, w0 + 1) * L);       /* :292 */
+            op = (int)(orc_draw(rng, slot, k, 0, w0 + 2) * 2);        /* :293 */
+            if (op == 0) op = 3;
+        } else {
+            const double u = w0 == 0 ? orc_draw(rng, slot, k >> 1, 0, 2 * (int)(k & 1)) : orc_draw(rng, slot, k, 0, 1);
+            const int g = (int)(u * (2 * L * L));
+            rng->consumed += 2;                                       /* counted like the reference's three draws */
+            op = g < L * L ? 1 : 3;
+            row = (g % (L * L)) / L;
+            col = g % L;
+        }
         return orc_toric_apply_stabilizer(L, in, out, row, col, op);
     }
     int rows = (int)((L - 1) * orc_draw_field(rng, slot, k, 0, w0, 0, 16));
@@ -387,7 +414,7 @@ int orc_chain_update_alpha(const orc_model *m, uint8_t *state, double pz_tilde, 
             u = orc_draw(rng, slot, k, 2, 0);
         } else {
             model_random_stabilizer(m, state, scratch, rng, slot, k, 0);
-            u = orc_draw(rng, slot, k, 0, 3);
+            u = nontop_accept(m, rng, slot, k);
         }
         if (u < biased_weight(scratch, (int)nq, px, py, pz) / pb) {
             memcpy(state, scratch, nq);
@@ -426,7 +453,7 @@ void orc_chain_update(const orc_model *m, uint8_t *state, double p, double p_log
             } else {                                                                    /* :49-59 */
                 model_random_stabilizer(m, state, scratch, rng, slot, k, 0);
                 const double pn = biased_weight(scratch, (int)nq, px, py, pz);
-                u = orc_draw(rng, slot, k, 0, 3);
+                u = nontop_accept(m, rng, slot, k);
                 if (u < pn / pb) memcpy(state, scratch, nq);
             }
         }
@@ -452,7 +479,7 @@ void orc_chain_update(const orc_model *m, uint8_t *state, double p, double p_log
         for (uint64_t j = 0; j < iters; ++j) {                     /* mcmc.py:38 */
             uint64_t k = k0 + j;
             int dE = model_random_stabilizer(m, state, scratch, rng, slot, k, 0);
-            if (orc_draw(rng, slot, k, 0, 3) < pow(factor, (double)dE))   /* mcmc.py:42 */
+            if (nontop_accept(m, rng, slot, k) < pow(factor, (double)dE))   /* mcmc.py:42 */
                 memcpy(state, scratch, nq);
         }
     }

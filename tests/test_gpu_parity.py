@@ -92,7 +92,8 @@ def test_chain_update_bit_exact(q, orc, L, p, p_logical, iters):
 
 # ------------------------------------------------------------------ Ladder.step vs oracle
 @pytest.mark.parametrize("L,p,Nc,iters,nstep", [(3, 0.3, 4, 5, 60), (5, 0.10, 5, 10, 80), (9, 0.15, 8, 10, 60),
-                                                (5, 0.25, 3, 7, 70), (3, 0.05, 2, 10, 90), (7, 0.12, 16, 3, 40)])
+                                                (5, 0.25, 3, 7, 70), (3, 0.05, 2, 10, 90), (7, 0.12, 16, 3, 40), (5, 0.12, 3, 1, 40),
+                                                (9, 0.15, 8, 13, 20)])
 def test_ladder_step_bit_exact(q, orc, L, p, Nc, iters, nstep):
     rng = np.random.default_rng(L + Nc)
     m = rand_states(rng, 1, L, 0.15)[0]

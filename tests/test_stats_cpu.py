@@ -73,3 +73,22 @@ def test_oracle_philox_matches_reference_histograms(name):
         se_n = np.sqrt(ref_n.var(axis=0, ddof=1) / ref_n.shape[0] + on.var(axis=0, ddof=1) / R)
         assert np.all(np.abs(ref_h.mean(axis=0) - oh.mean(axis=0)) <= 4.5 * se_h + 5e-3), (s, ref_h.mean(0), oh.mean(0))
         assert np.all(np.abs(ref_n.mean(axis=0) - on.mean(axis=0)) <= 4.5 * se_n + 0.05), (s, ref_n.mean(0), on.mean(0))
+
+
+@pytest.mark.parametrize("top", [False, True])
+def test_philox_generator_pick_is_uniform_over_generators(top):
+    """Philox mode spends one word on the reference's (row, col, op) choice (toric_model.py:291-295): every one of the
+    2 L^2 generators must come up, equally often.  At p = 0.75 each proposal is accepted, so one proposal from the empty
+    configuration shows which generator was picked."""
+    L, n = 4, 32 * 400
+    seen = {}
+    zero = np.zeros((2, L, L), np.uint8)
+    rng = orc.Rng.philox(77, 5)
+    for k in range(n):
+        m = orc.chain_update(orc.TORIC, zero, 0.75, 1e-300 if top else 0.0, 1, rng, slot=3, k0=k)   # tiny p_logical: top-branch addressing
+        assert np.count_nonzero(m) == 4
+        seen[m.tobytes()] = seen.get(m.tobytes(), 0) + 1
+    assert len(seen) == 2 * L * L
+    cnt = np.array(list(seen.values()), dtype=np.float64)
+    chi2 = np.sum((cnt - n / 32) ** 2 / (n / 32))
+    assert chi2 < 70                          # 31 degrees of freedom: P(chi2 > 70) ~ 1e-4
