@@ -233,11 +233,13 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
     constexpr bool kWideGen = CODE == kCodeToric && !BIASED && !SCAN;
     const int gen_dw = (kWideGen ? 4 : 2) * (int)a.n_gen;
     const bool alpha_noise = BIASED && a.noise == 2;            // mcmc_alpha.py: biased rule + slot-bound n_eff swap test
-    const int gen_region = alpha_noise ? ((gen_dw + 3) & ~3) + 2 * NC * 64 : gen_dw;
+    const int H = (CODE == kCodeToric && !BIASED && !SCAN) ? a.top_help : 0;   // top-chain Philox blocks drawn by the other waves
+    const int gen_region = alpha_noise ? ((gen_dw + 3) & ~3) + 2 * NC * 64 : H ? ((gen_dw + 3) & ~3) + 2 * H * 256 : gen_dw;
     const int gdw = ladder_group_dwords(NC, W, ncls, gen_region);   // dwords per group
     const int gen_off = gdw - ((gen_region + 3) & ~3);           // start of the generator table
     uint32_t *lds = lds_all + grp * gdw;
     [[maybe_unused]] uint32_t *neffb = lds + gen_off + ((gen_dw + 3) & ~3);   // [2][NC][64] n_z | (n_x+n_y) << 16 per slot, by step parity
+    [[maybe_unused]] uint32_t *topw = lds + gen_off + ((gen_dw + 3) & ~3);    // [2][H][4][64] top-chain Philox words, by step parity
 
     uint32_t *st = lds;                           // [NC][W][64]   packed states
     uint32_t *info = st + (size_t)NC * W * 64;    // [2][NC][64]   slot records, double-buffered by step parity
@@ -356,6 +358,19 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
     const uint32_t rowbits = 2u * (uint32_t)L;                  // bits of one lattice row in the packed stream
     const uint32_t rowmask = rowbits >= 32 ? 0xFFFFFFFFu : (1u << rowbits) - 1u;
     const bool swap_fast = a.swap_fast_ok != 0;
+
+    // Top-chain help: a top proposal's Philox block does not depend on the state, so the H lowest non-top slots draw one
+    // block each of the NEXT step's top chain and hand the words over through LDS (buffer = step parity).  The top wave's
+    // step (10 blocks + frame flush + recount) is otherwise ~1.5x a non-top wave's, and everyone waits for it at the barrier.
+    auto draw_top_block = [&](uint64_t k, int parity, uint32_t j) {
+        const u32x4 hb = philox_block(k, 0, syn, (uint32_t)(NC - 1), a.seed_lo, a.seed_hi);
+        uint32_t *tw = topw + ((parity * H + (int)j) * 4) * 64 + lane;
+        tw[0] = hb.x; tw[64] = hb.y; tw[128] = hb.z; tw[192] = hb.w;
+    };
+    if (H) {
+        if (slot < H) draw_top_block(a.prop0 + (uint64_t)slot, 0, (uint32_t)slot);
+        __syncthreads();
+    }
 
     for (uint64_t t = 0; t < a.nsteps; ++t) {
         // Issue arbitration between co-resident workgroups is oldest-first, which lets the first one
@@ -595,6 +610,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
         } else
         if (!top_logical) {
             int ni = (int)n;
+            if (H && slot_u < (uint32_t)H) draw_top_block(kbase + iters + slot_u, (int)((t + 1) & 1), slot_u);
             // One Philox word picks the generator (g = floor(x * 2L^2 / 2^32): uniform over the 2L^2 generators as the
             // reference's three draws are, toric_model.py:291-295), one is the acceptance uniform: a block feeds two proposals.
             const uint32_t G2 = 2u * (uint32_t)LL;
@@ -680,6 +696,9 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 if (j + 1 < iters) propose(xa.z, xa.w);
             }
             n = (uint32_t)ni;
+#ifdef QECMC_EXP_NOTOP
+        } else if (acc_all) {
+#endif
         } else if (acc_all && L <= 16) {
             // Top chain at p = 0.75: every proposal is accepted (mcmc.py:30), so moves are blind
             // XORs and commute.  Stabilizers go straight to LDS; logical operators are collected
@@ -718,7 +737,13 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 }
             } else
             for (uint32_t j = 0; j < iters; ++j) {
-                const u32x4 x = philox_block(kbase + j, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                u32x4 x;
+                if (j < (uint32_t)H) {                                              // drawn by another wave during the previous step
+                    const uint32_t *tw = topw + ((((int)(t & 1)) * H + (int)j) * 4) * 64 + lane;
+                    x.x = tw[0]; x.y = tw[64]; x.z = tw[128]; x.w = tw[192];
+                } else {
+                    x = philox_block(kbase + j, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                }
                 if (x.x <= thrL1) {                                                 // mcmc.py:23
                     add_logical(x);
                 } else {
@@ -826,12 +851,30 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             const u32x4 b = philox_block(a.step0 + t, (uint32_t)swb, syn, kSwapStream, a.seed_lo, a.seed_hi);
             uint32_t *p = sx + swb * 4 * 64;                       // rows 4b .. 4b+3 = rung pairs, NC-1 of them exist
             const int left = NC - 1 - swb * 4;
-            p[0] = b.x;
-            if (left > 1) p[64] = b.y;
-            if (left > 2) p[128] = b.z;
-            if (left > 3) p[192] = b.w;
+            // The swap test u < p_diff[i]^d (mcmc.py:149) does not need the records: thresholds fall with d, so it reads
+            // d <= dmax with dmax = the largest d whose threshold exceeds x.  dmax is found here, off the cascade's serial
+            // path: a log2 guess, then the exact table moves it up or down (so rounding in the guess cannot matter).
+            auto swap_dmax = [&](uint32_t x, int i) -> uint32_t {
+                if (BIASED && alpha_noise) return x;                // Ladder_alpha compares in floating point (below)
+                auto below = [&](int dd) -> bool {                  // x < ceil(p_diff[i]^dd * 2^32), dd in [1, nq]
+                    return (swap_fast && dd < kSwapFast) ? x < swapT[i * kSwapFast + dd]
+                                                         : (uint64_t)x < a.swap_thr[(size_t)i * (nq + 1) + dd];
+                };
+                const float inv = a.swap_inv_log2[i];               // 0: p_diff[i] >= 1 (coinciding rungs), every d passes
+                int d = inv == 0.0f ? nq : (int)((__log2f((float)x + 0.5f) - 32.0f) * inv);
+                d = d < 0 ? 0 : d > nq ? nq : d;
+                while (d < nq && below(d + 1)) ++d;
+                while (d > 0 && !below(d)) --d;
+                return (uint32_t)d;
+            };
+            p[0] = swap_dmax(b.x, swb * 4);
+            if (left > 1) p[64] = swap_dmax(b.y, swb * 4 + 1);
+            if (left > 2) p[128] = swap_dmax(b.z, swb * 4 + 2);
+            if (left > 3) p[192] = swap_dmax(b.w, swb * 4 + 3);
         }
+#ifndef QECMC_EXP_NOBARRIER   // QECMC_EXP_*: timing experiments only (tools/exp_build.sh), results are wrong
         __syncthreads();
+#endif
         if (CONV) {                                         // flags set one step earlier: uniform for the workgroup
             volatile uint32_t *f0 = lds_all + (NC * W * 64 + 4 * NC * 64 + ncls * 64 + NC * 9 + NC * kSwapFast);
             if (f0[0] && (GROUPS == 1 || f0[gdw])) break;
@@ -844,28 +887,45 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             // a wave only needs the cascade down to the rung that fills its own next slot (wave 0 also does the
             // slot-0 bookkeeping and runs it to the bottom)
             const int i_stop = (wave_u == 0 || slot_u == 0) ? 0 : (int)slot_u - 1;
-            for (int i = NC - 2; i >= 0; --i) {                                    // mcmc.py:96
-                if (i < i_stop) continue;
-                const uint32_t lo = cur[i * 64], xi = sx[i * 64];
-                const int d = (int)(car & 0xFFFFu) - (int)(lo & 0xFFFFu);          // ne_hi - ne_lo
-                bool flip = d <= 0;                                                 // _r_flip :146, and u < rel_p**0 = 1
-                if (BIASED && alpha_noise) {
-                    // Ladder_alpha.r_flip, mcmc_alpha.py:118-123: slot-bound n_eff, always draws
-                    const uint32_t *ne = neffb + (t & 1) * NC * 64 + lane;
-                    flip = alpha_flip(xi, ne[(i + 1) * 64], ne[i * 64], a.alpha, a.alpha_lnb[i]);
-                } else
-                if (!flip) {                                                        // :149
-                    if (swap_fast && d < kSwapFast) flip = xi < swapT[i * kSwapFast + d];
-                    else flip = (uint64_t)xi < a.swap_thr[(size_t)i * (nq + 1) + d];
+            // four rungs at a time: their records and swap bounds are fetched together, so a rung costs a few integer
+            // operations instead of an LDS round trip on the serial path
+#ifndef QECMC_EXP_NOCASCADE
+            for (int ib = NC - 2; ib >= i_stop; ib -= 4) {                          // mcmc.py:96
+                uint32_t lo4[4], x4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int ic = ib - u < 0 ? 0 : ib - u;
+                    lo4[u] = cur[ic * 64];
+                    x4[u] = sx[ic * 64];
                 }
-                const uint32_t into = flip ? lo : car;                              // what slot i+1 now holds (:98-99)
-                car = flip ? car : lo;
-                if ((int)slot_u == i + 1) mine = into;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = ib - u;
+                    const uint32_t lo = lo4[u], xi = x4[u];
+                    const int d = (int)(car & 0xFFFFu) - (int)(lo & 0xFFFFu);      // ne_hi - ne_lo
+                    bool flip = d <= (int)xi;                                       // _r_flip :146-149: d <= 0, or u < rel_p**d <=> d <= dmax
+                    if (BIASED && alpha_noise) {
+                        // Ladder_alpha.r_flip, mcmc_alpha.py:118-123: slot-bound n_eff, always draws
+                        const uint32_t *ne = neffb + (t & 1) * NC * 64 + lane;
+                        const int ic = i < 0 ? 0 : i;
+                        flip = alpha_flip(xi, ne[(ic + 1) * 64], ne[ic * 64], a.alpha, a.alpha_lnb[ic]);
+                    }
+                    if (i >= i_stop) {                                              // uniform
+                        const uint32_t into = flip ? lo : car;                      // what slot i+1 now holds (:98-99)
+                        car = flip ? car : lo;
+                        if ((int)slot_u == i + 1) mine = into;
+                    }
+                }
             }
+#endif
             if (slot_u == 0) mine = car;
             n = mine & 0xFFFFu; sid = (mine >> 16) & 0xFFu; cls = (mine >> 24) & 0x3Fu; flag = mine >> 31;
             if ((int)slot_u == NC - 1) flag = 1;                                    // chains[-1].flag = 1, mcmc.py:100
+#ifdef QECMC_EXP_NOBOOK
+            if (false) {
+#else
             if (wave_u == 0 && !done) {                                             // ladder + PTEQ bookkeeping on slot 0's new state
+#endif
                 tops0 += (NC == 1) | (car >> 31);                                   // chains[0].flag == 1, :101-102
                 const uint32_t n0 = car & 0xFFFFu;
                 if (a.counts != nullptr && tops0 >= a.tops_burn) {                  // decoders.py:60-67
@@ -964,7 +1024,7 @@ hipError_t launch_ladder_rs_toric(const LadderArgs &a, hipStream_t stream)
 {
     unsigned grid = (unsigned)((a.N + 63) / 64);
     unsigned block = (unsigned)a.Nc * 64u;
-    size_t lds = ladder_lds_bytes(a.L, a.Nc, a.W, a.ncls, ladder_gen_dwords(a.code, a.noise, a.scan, a.n_gen, a.Nc));
+    size_t lds = ladder_lds_bytes(a.L, a.Nc, a.W, a.ncls, ladder_gen_dwords(a.code, a.noise, a.scan, a.n_gen, a.Nc, a.top_help));
     if (grid == 0) return hipSuccess;
     // Nc <= 8: two 64-syndrome groups per workgroup (<= 1024 threads, 2 workgroups = 32 waves per CU);
     // Nc > 8: one group (<= 1024 threads)

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libqecmc.so")
+LIB_PATH = os.environ.get("QECMC_LIBRARY") or os.path.join(_HERE, "libqecmc.so")   # override: another build of the same ABI
 
 TORIC, XZZX, ROTATED = 0, 1, 2
 SCAN_RANDOM, SCAN_CHECKERBOARD = 0, 1
