@@ -267,7 +267,7 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
     const uint32_t n_gen = p->code == QECMC_TORIC ? 2u * L * L : (uint32_t)((L - 1) * (L - 1) + 2 * (L - 1));
     if (n_gen > kMaxGenLds)   // every kernel path stages the generator table in LDS
         return fail(QECMC_ERR_UNSUPPORTED, "L=%d: %u generators exceed the LDS table of %u (needed by scan=1 and by the xzzx / rotated codes)", L, n_gen, kMaxGenLds);
-    pl->lds_bytes = ladder_lds_bytes(L, Nc, W, ncls, ladder_gen_dwords(p->code, p->noise, p->scan, n_gen, Nc, 0));
+    pl->lds_bytes = ladder_lds_bytes(L, Nc, W, ncls, ladder_gen_dwords(p->code, p->noise, p->scan, n_gen, Nc));
     if (pl->lds_bytes > 160 * 1024)
         return fail(QECMC_ERR_UNSUPPORTED, "L=%d Nc=%d needs %zu B of LDS per workgroup (> 160 KiB)", L, Nc, pl->lds_bytes);
 
@@ -280,15 +280,6 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
         const double f = chain_factor(pladder[c]);
         if (f >= 1.0 && !biased) a.acc_all_mask |= 1u << c;
         for (int d = 1; d <= 4; ++d) a.acc_thr[c][d - 1] = thr32(std::pow(f, (double)d));   // mcmc.py:42
-    }
-    // top-chain help (kernels.hpp): the fast blind top path of the toric random-scan kernel, when the words fit in LDS
-    if (p->code == QECMC_TORIC && !biased && p->scan == QECMC_SCAN_RANDOM && a.thr_logical != 0 && Nc > 1 && L <= 16 &&
-        ((a.acc_all_mask >> (Nc - 1)) & 1u)) {
-        const int H = (int)std::min<uint64_t>((uint64_t)(Nc - 1), p->iters);
-        const size_t with = ladder_lds_bytes(L, Nc, W, ncls, ladder_gen_dwords(p->code, p->noise, p->scan, n_gen, Nc, H));
-        // only where it does not cost occupancy: 64-syndrome groups per CU by LDS stay >= what waves (32 per CU) or LDS allowed before
-        const size_t cu_lds = 160 * 1024, before = std::min<size_t>(32 / (size_t)Nc, cu_lds / pl->lds_bytes);
-        if (with <= cu_lds && cu_lds / with >= before) { a.top_help = H; pl->lds_bytes = with; }
     }
     std::vector<uint32_t> top_tbl(nq + 1, 0u);                             // mcmc.py:34 for a top chain below p = 0.75
     for (int d = 1; d <= nq && !biased; ++d) top_tbl[d] = thr32(std::pow(chain_factor(pladder[Nc - 1]), (double)d));

@@ -51,8 +51,6 @@ struct LadderArgs {
 #ifdef QECMC_TIMELINE
     uint64_t *dbg;            // [grid][4] diagnostic stamps (tools/timeline.hip only)
 #endif
-    int top_help;             // H > 0: the H lowest non-top slots each draw one Philox block of the NEXT step's top chain
-                              // (handed over through LDS), which evens out the top wave's longer step; 0 = off
     int resume;               // 0: replicate init into every slot (mcmc.py:72); 1: load states/flags/tops0
     int write_states;
 };
@@ -61,13 +59,11 @@ size_t ladder_lds_bytes(int L, int Nc, int W, int ncls, int gen_dwords);
 constexpr uint32_t kMaxGenLds = 2048;   // generator tables up to this many entries are staged in LDS
 // dwords of the LDS generator table: the toric random-scan kernels expand each generator to 4 x u32
 // (dword offset << 10 | pauli << 5 | bit shift), the other paths keep the plan's 4 x u16 form
-// alpha noise appends the double-buffered n_eff records [2][Nc][64] to the region, top_help the handed-over top-chain
-// Philox words [2][top_help][4][64]
-inline int ladder_gen_dwords(int code, int noise, int scan, uint32_t n_gen, int Nc, int top_help)
+// alpha noise appends the double-buffered n_eff records [2][Nc][64] to the region
+inline int ladder_gen_dwords(int code, int noise, int scan, uint32_t n_gen, int Nc)
 {
     const int tab = (code == 0 && !noise && !scan ? 4 : 2) * (int)n_gen;
-    if (noise == 2) return ((tab + 3) & ~3) + 2 * Nc * 64;
-    return top_help ? ((tab + 3) & ~3) + 2 * top_help * 256 : tab;
+    return noise == 2 ? ((tab + 3) & ~3) + 2 * Nc * 64 : tab;
 }
 hipError_t launch_ladder_rs_toric(const LadderArgs &a, hipStream_t stream);
 

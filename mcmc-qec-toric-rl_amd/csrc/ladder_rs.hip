@@ -233,13 +233,11 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
     constexpr bool kWideGen = CODE == kCodeToric && !BIASED && !SCAN;
     const int gen_dw = (kWideGen ? 4 : 2) * (int)a.n_gen;
     const bool alpha_noise = BIASED && a.noise == 2;            // mcmc_alpha.py: biased rule + slot-bound n_eff swap test
-    const int H = (CODE == kCodeToric && !BIASED && !SCAN) ? a.top_help : 0;   // top-chain Philox blocks drawn by the other waves
-    const int gen_region = alpha_noise ? ((gen_dw + 3) & ~3) + 2 * NC * 64 : H ? ((gen_dw + 3) & ~3) + 2 * H * 256 : gen_dw;
+    const int gen_region = alpha_noise ? ((gen_dw + 3) & ~3) + 2 * NC * 64 : gen_dw;
     const int gdw = ladder_group_dwords(NC, W, ncls, gen_region);   // dwords per group
     const int gen_off = gdw - ((gen_region + 3) & ~3);           // start of the generator table
     uint32_t *lds = lds_all + grp * gdw;
     [[maybe_unused]] uint32_t *neffb = lds + gen_off + ((gen_dw + 3) & ~3);   // [2][NC][64] n_z | (n_x+n_y) << 16 per slot, by step parity
-    [[maybe_unused]] uint32_t *topw = lds + gen_off + ((gen_dw + 3) & ~3);    // [2][H][4][64] top-chain Philox words, by step parity
 
     uint32_t *st = lds;                           // [NC][W][64]   packed states
     uint32_t *info = st + (size_t)NC * W * 64;    // [2][NC][64]   slot records, double-buffered by step parity
@@ -358,19 +356,6 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
     const uint32_t rowbits = 2u * (uint32_t)L;                  // bits of one lattice row in the packed stream
     const uint32_t rowmask = rowbits >= 32 ? 0xFFFFFFFFu : (1u << rowbits) - 1u;
     const bool swap_fast = a.swap_fast_ok != 0;
-
-    // Top-chain help: a top proposal's Philox block does not depend on the state, so the H lowest non-top slots draw one
-    // block each of the NEXT step's top chain and hand the words over through LDS (buffer = step parity).  The top wave's
-    // step (10 blocks + frame flush + recount) is otherwise ~1.5x a non-top wave's, and everyone waits for it at the barrier.
-    auto draw_top_block = [&](uint64_t k, int parity, uint32_t j) {
-        const u32x4 hb = philox_block(k, 0, syn, (uint32_t)(NC - 1), a.seed_lo, a.seed_hi);
-        uint32_t *tw = topw + ((parity * H + (int)j) * 4) * 64 + lane;
-        tw[0] = hb.x; tw[64] = hb.y; tw[128] = hb.z; tw[192] = hb.w;
-    };
-    if (H) {
-        if (slot < H) draw_top_block(a.prop0 + (uint64_t)slot, 0, (uint32_t)slot);
-        __syncthreads();
-    }
 
     for (uint64_t t = 0; t < a.nsteps; ++t) {
         // Issue arbitration between co-resident workgroups is oldest-first, which lets the first one
@@ -610,7 +595,6 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
         } else
         if (!top_logical) {
             int ni = (int)n;
-            if (H && slot_u < (uint32_t)H) draw_top_block(kbase + iters + slot_u, (int)((t + 1) & 1), slot_u);
             // One Philox word picks the generator (g = floor(x * 2L^2 / 2^32): uniform over the 2L^2 generators as the
             // reference's three draws are, toric_model.py:291-295), one is the acceptance uniform: a block feeds two proposals.
             const uint32_t G2 = 2u * (uint32_t)LL;
@@ -737,13 +721,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 }
             } else
             for (uint32_t j = 0; j < iters; ++j) {
-                u32x4 x;
-                if (j < (uint32_t)H) {                                              // drawn by another wave during the previous step
-                    const uint32_t *tw = topw + ((((int)(t & 1)) * H + (int)j) * 4) * 64 + lane;
-                    x.x = tw[0]; x.y = tw[64]; x.z = tw[128]; x.w = tw[192];
-                } else {
-                    x = philox_block(kbase + j, 0, syn, slot_u, a.seed_lo, a.seed_hi);
-                }
+                const u32x4 x = philox_block(kbase + j, 0, syn, slot_u, a.seed_lo, a.seed_hi);
                 if (x.x <= thrL1) {                                                 // mcmc.py:23
                     add_logical(x);
                 } else {
@@ -1024,7 +1002,7 @@ hipError_t launch_ladder_rs_toric(const LadderArgs &a, hipStream_t stream)
 {
     unsigned grid = (unsigned)((a.N + 63) / 64);
     unsigned block = (unsigned)a.Nc * 64u;
-    size_t lds = ladder_lds_bytes(a.L, a.Nc, a.W, a.ncls, ladder_gen_dwords(a.code, a.noise, a.scan, a.n_gen, a.Nc, a.top_help));
+    size_t lds = ladder_lds_bytes(a.L, a.Nc, a.W, a.ncls, ladder_gen_dwords(a.code, a.noise, a.scan, a.n_gen, a.Nc));
     if (grid == 0) return hipSuccess;
     // Nc <= 8: two 64-syndrome groups per workgroup (<= 1024 threads, 2 workgroups = 32 waves per CU);
     // Nc > 8: one group (<= 1024 threads)
