@@ -720,18 +720,28 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                     }
                 }
             } else
-            for (uint32_t j = 0; j < iters; ++j) {
-                const u32x4 x = philox_block(kbase + j, 0, syn, slot_u, a.seed_lo, a.seed_hi);
-                if (x.x <= thrL1) {                                                 // mcmc.py:23
-                    add_logical(x);
-                } else {
-                    const uint4 ev = gtab4[scale_u32(x.y, 2u * (uint32_t)LL)];     // word 1 picks the generator
-                    const uint32_t e4[4] = {ev.x, ev.y, ev.z, ev.w};
-                    const uint32_t op = (ev.x >> 5) & 3u;
+            {
+                auto blind = [&](const u32x4 &x) {
+                    if (x.x <= thrL1) {                                             // mcmc.py:23
+                        add_logical(x);
+                    } else {
+                        const uint4 ev = gtab4[scale_u32(x.y, 2u * (uint32_t)LL)]; // word 1 picks the generator
+                        const uint32_t e4[4] = {ev.x, ev.y, ev.z, ev.w};
+                        const uint32_t op = (ev.x >> 5) & 3u;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        lds_xor(stw + (e4[i] >> 10), shl_lo5(op, e4[i]));
+                        for (int i = 0; i < 4; ++i)
+                            lds_xor(stw + (e4[i] >> 10), shl_lo5(op, e4[i]));
+                    }
+                };
+                // two proposals' Philox chains in flight: this wave is the step's longest and often runs alone
+                uint32_t j = 0;
+                for (; j + 1 < iters; j += 2) {
+                    const u32x4 xa = philox_block(kbase + j, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                    const u32x4 xb = philox_block(kbase + j + 1, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                    blind(xa);
+                    blind(xb);
                 }
+                if (j < iters) blind(philox_block(kbase + j, 0, syn, slot_u, a.seed_lo, a.seed_hi));
             }
             // flush the frame: lattice row r of layer l is the 2L-bit span at bit 2*(l*LL + r*L)
             {
