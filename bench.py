@@ -88,11 +88,11 @@ def cpu_baseline(init, p, Nc, iters, seed, target_s=12.0):
     cores = os.cpu_count() or 1
     L = init.shape[2]
     n_syn = min(init.shape[0], 4 * cores)
-    orc.toric_pteq_batch(init[:n_syn], p, Nc, 20, iters=iters, tops_burn=2, seed=seed, n_threads=cores)   # spin the threads up
+    orc.toric_pteq_batch(init[:n_syn], p, Nc, 200, iters=iters, tops_burn=2, seed=seed, n_threads=cores)   # spin the threads up
     t0 = time.perf_counter()
-    orc.toric_pteq_batch(init[:n_syn], p, Nc, 200, iters=iters, tops_burn=2, seed=seed, n_threads=cores)
+    orc.toric_pteq_batch(init[:n_syn], p, Nc, 2000, iters=iters, tops_burn=2, seed=seed, n_threads=cores)   # calibration
     dt = max(time.perf_counter() - t0, 1e-4)
-    steps = int(max(200, min(100000, 200 * target_s / dt)))
+    steps = int(max(2000, min(200000, 2000 * target_s / dt)))
     t0 = time.perf_counter()
     orc.toric_pteq_batch(init[:n_syn], p, Nc, steps, iters=iters, tops_burn=2, seed=seed, n_threads=cores)
     dt = time.perf_counter() - t0
