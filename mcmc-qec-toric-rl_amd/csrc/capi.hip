@@ -100,13 +100,6 @@ std::vector<double> alpha_tables(double pz_tilde, double alpha, size_t nq)
     return t;
 }
 
-// floor(phalf * 2^32), phalf = (L^2 - (L-1)^2 - 1)/(L^2 - 1) (xzzx_model.py:444): u > phalf <=> x > this
-uint64_t half_threshold(int L)
-{
-    const double phalf = (double)(L * L - (L - 1) * (L - 1) - 1) / (double)(L * L - 1);
-    return (uint64_t)std::floor(phalf * 4294967296.0);
-}
-
 // ceil(v * 2^32) as used by every integer acceptance test: u < v  <=>  x < ceil(v*2^32) for u = x*2^-32
 uint64_t thr64(double v)
 {
@@ -301,7 +294,6 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
         HIP_TRY(pl->gen.alloc(gt.size() * sizeof(uint32_t)));
         HIP_TRY(hipMemcpy(pl->gen.p, gt.data(), gt.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         a.gen = pl->gen.as<uint2>();
-        a.thr_half = half_threshold(L);
     }
     if (biased) {
         std::vector<double> bt;
@@ -487,7 +479,7 @@ static int chain_update_impl(int code, int L, uint64_t N, uint8_t *states_inout,
     a.acc_tbl = dt.as<uint32_t>(); a.acc_all = !noise && f >= 1.0;
     a.first_syndrome = first_syndrome; a.slot = slot;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.L = L;
-    a.code = code; a.noise = noise; a.thr_half = half_threshold(L); a.bias_tbl = db.as<double>();
+    a.code = code; a.noise = noise; a.bias_tbl = db.as<double>();
     HIP_TRY(launch_chain_update(a, 0));
     HIP_TRY(hipMemcpy(states_inout, ds.p, N * nq, hipMemcpyDeviceToHost));
     if (accepted_out) HIP_TRY(hipMemcpy(accepted_out, dacc.p, N, hipMemcpyDeviceToHost));

@@ -28,7 +28,6 @@ struct LadderArgs {
     const double *alpha_lnb;  // [Nc-1]             ln(pz_tilde[i] / pz_tilde[i+1]) (alpha noise, mcmc_alpha.py:123)
     double alpha;             //                    mcmc_alpha.py:11
     uint32_t *neff;           // [N][Nc]            alpha noise: the slots' n_eff attributes as n_z | (n_x+n_y) << 16; resume in / out
-    uint64_t thr_half;        // floor(phalf * 2^32) (xzzx_model.py:444)
     int code, noise;          // qecmc_code, qecmc_noise
     int scan;                 // qecmc_scan
     uint32_t n_gen;           // number of stabilizer generators G (sweep order = table order)
@@ -89,7 +88,6 @@ struct ChainArgs {
     int code;                 // 0 toric, 1 xzzx, 2 rotated
     int noise;                // 0 depolarizing (mcmc.py), 1 biased (mcmc_biased.py), 2 alpha (mcmc_alpha.py; same rule, other table)
     uint8_t *accepted;        // [N] out (nullable): 1 iff at least one proposal was accepted (Chain_alpha refreshes n_eff then)
-    uint64_t thr_half;        // floor(phalf * 2^32): xzzx / rotated pick the full plaquette iff x > thr_half
     const double *bias_tbl;   // [4][nq+1] px^n, py^n, pz^n, pI^n (biased noise)
 };
 hipError_t launch_chain_update(const ChainArgs &a, hipStream_t s);

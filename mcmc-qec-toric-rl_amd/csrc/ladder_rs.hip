@@ -140,16 +140,6 @@ __device__ __forceinline__ void count_xyz(uint32_t w, int &nx, int &ny, int &nz)
     nx += __popc(b0 & ~b1); ny += __popc(b1 & ~b0); nz += __popc(b0 & b1);
 }
 
-// rows / cols / rows2 / cols2 / selector of _apply_random_stabilizer (xzzx_model.py:439-452) -> generator index
-// into the plan's table: [0, (L-1)^2) full plaquettes row-major, then 4 per half-plaquette index
-__device__ __forceinline__ uint32_t surf_generator_index(uint32_t L, uint32_t wa, uint32_t wb, uint32_t wsel, uint64_t thr_half)
-{
-    const uint32_t Lm = L - 1;
-    const uint32_t full = (((wa >> 16) * Lm) >> 16) * Lm + (((wa & 0xFFFFu) * Lm) >> 16);
-    const uint32_t half = Lm * Lm + (((wb >> 16) * Lm) >> 17) * 4u + ((wb >> 14) & 3u);
-    return (uint64_t)wsel > thr_half ? full : half;
-}
-
 // slot record published once per ladder step: error count | state id << 16 | class << 24 | flag << 31
 // (flag = "has been at the top since it last reached the bottom", Chain.flag, mcmc.py:75,99-103)
 __device__ __forceinline__ uint32_t pack_info(uint32_t n, uint32_t sid, uint32_t cls, uint32_t flag)
@@ -438,8 +428,11 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                         g = gs;
                         gs = gs + 1 == a.n_gen ? 0u : gs + 1;
                     } else {
-                        x = philox_block(kbase + j, 0, syn, slot_u, a.seed_lo, a.seed_hi);
-                        g = surf_generator_index(L, x.x, x.y, x.z, a.thr_half);
+                        // one block per two proposals: words 2(k&1) (generator, uniform over the L^2 - 1 of them) and 2(k&1)+1 (accept)
+                        const uint64_t k = kbase + j;
+                        if ((k >> 1) != kb_cur) { kb_cur = k >> 1; blk = philox_block(kb_cur, 0, syn, slot_u, a.seed_lo, a.seed_hi); }
+                        g = scale_u32((k & 1) ? blk.z : blk.x, a.n_gen);
+                        x.w = (k & 1) ? blk.w : blk.y;
                     }
                     const uint2 e = gtab[g];                                      // 4 x (site << 2 | pauli), 0 = no site
                     const uint32_t ent[4] = {e.x & 0xFFFFu, e.x >> 16, e.y & 0xFFFFu, e.y >> 16};
@@ -479,7 +472,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                         for (int w = 0; w < W; ++w) lds_xor(stw + w * 64, m0[w] ^ m1[w]);
                         cdelta ^= ax | (az << 1);
                     } else {
-                        const uint2 e = gtab[surf_generator_index(L, x.y, x.z, x.w, a.thr_half)];
+                        const uint2 e = gtab[scale_u32(x.y, a.n_gen)];              // word 1 picks the generator
                         const uint32_t ent[4] = {e.x & 0xFFFFu, e.x >> 16, e.y & 0xFFFFu, e.y >> 16};
 #pragma unroll
                         for (int i = 0; i < 4; ++i) lds_xor(stw + (ent[i] >> 6) * 64, (ent[i] & 3u) << (((ent[i] >> 2) & 15u) * 2u));
@@ -505,7 +498,12 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 uint32_t gs = SCAN ? (uint32_t)(kbase % a.n_gen) : 0u;
                 for (uint32_t j = 0; j < iters; ++j, gs = gs + 1 == a.n_gen ? 0u : gs + 1) {
                     const uint64_t k = kbase + j;
-                    const u32x4 x = philox_block(k, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                    // top: block (k, 0) = select, generator / logical fields; non-top: words 2(k&1), 2(k&1)+1 of block (k>>1, 0)
+                    u32x4 x = philox_block(top ? k : k >> 1, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                    if (!top) {
+                        if (k & 1) { x.x = x.z; x.y = x.w; }
+                        x.w = x.y;                                                  // acceptance uniform
+                    }
                     const bool logical = top && x.x <= thrL1;                       // mcmc.py:23
                     int dx = 0, dy = 0, dz = 0;                                    // change of the X / Y / Z counts
                     uint32_t ent[4] = {0, 0, 0, 0}, cd = 0;
@@ -538,17 +536,17 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                             dx -= ox; dy -= oy; dz -= oz;
                         }
                     } else {
-                        const uint32_t wa = top ? x.y : x.x, wb = top ? x.z : x.y, wc = top ? x.w : x.z;
+                        const uint32_t wa = top ? x.y : x.x;                        // the generator word
                         if constexpr (SCAN) {
                             const uint2 e = gtab[gs];
                             ent[0] = e.x & 0xFFFFu; ent[1] = e.x >> 16; ent[2] = e.y & 0xFFFFu; ent[3] = e.y >> 16;
                         } else if (CODE == kCodeToric) {
                             uint32_t q[4];
-                            const uint32_t isX = wc >> 31;
-                            toric_sites(L, LL, scale_u32(wa, L), scale_u32(wb, L), isX, q);
+                            const uint32_t g = scale_u32(wa, 2u * (uint32_t)LL), isX = g < (uint32_t)LL, rc = isX ? g : g - (uint32_t)LL;
+                            toric_sites(L, LL, rc / (uint32_t)L, rc % (uint32_t)L, isX, q);
                             for (int i = 0; i < 4; ++i) ent[i] = (q[i] << 2) | (isX ? 1u : 3u);
                         } else {
-                            const uint2 e = gtab[surf_generator_index(L, wa, wb, wc, a.thr_half)];
+                            const uint2 e = gtab[scale_u32(wa, a.n_gen)];
                             ent[0] = e.x & 0xFFFFu; ent[1] = e.x >> 16; ent[2] = e.y & 0xFFFFu; ent[3] = e.y >> 16;
                         }
                         for (int i = 0; i < 4; ++i) {

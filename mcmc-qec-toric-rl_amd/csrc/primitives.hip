@@ -74,18 +74,13 @@ __global__ void k_syndrome(int code, int L, uint64_t N, const uint8_t *in, uint8
     else surf_syndrome_b(code, L, in + i * (uint64_t)(L * L), defects + i * (uint64_t)((L + 1) * (L + 1)));
 }
 
-// x.w of a surf-code proposal block: rows / cols from the halves of word a, rows2 / cols2 from word b
-__device__ __forceinline__ void surf_pick(int L, uint32_t wa, uint32_t wb, uint32_t wsel, uint64_t thr_half, int &row, int &col, int &op)
+// one word picks one of the L^2 - 1 generators of the xzzx / rotated codes (xzzx_model.py:439-452 draws five uniforms for
+// the same uniform choice): full plaquettes row-major first, then half plaquette h/4 on side h%4
+__device__ __forceinline__ void surf_pick(int L, uint32_t w, int &row, int &col, int &op)
 {
-    if ((uint64_t)wsel > thr_half) {                 // `u > phalf`: full plaquette (xzzx_model.py:446-449)
-        row = (int)(((wa >> 16) * (uint32_t)(L - 1)) >> 16);
-        col = (int)(((wa & 0xFFFFu) * (uint32_t)(L - 1)) >> 16);
-        op = 1;
-    } else {                                         // half plaquette: rows2 = int(((L-1)/2) u), cols2 = int(4 u)
-        row = (int)(((wb >> 16) * (uint32_t)(L - 1)) >> 17);
-        col = (int)((wb >> 14) & 3u);
-        op = 3;
-    }
+    const uint32_t g = scale_u32(w, (uint32_t)(L * L - 1)), nfull = (uint32_t)((L - 1) * (L - 1));
+    if (g < nfull) { row = (int)(g / (uint32_t)(L - 1)); col = (int)(g % (uint32_t)(L - 1)); op = 1; }
+    else { row = (int)((g - nfull) >> 2); col = (int)((g - nfull) & 3u); op = 3; }
 }
 
 // p_x^nx p_y^ny p_z^nz p_I^nI from the host-built power tables (mcmc_biased.py:31,43): IEEE products in the
@@ -113,8 +108,8 @@ __global__ void k_chain_update(const ChainArgs a)
     bool any_acc = false;
     for (uint64_t j = 0; j < a.iters; ++j) {
         const uint64_t k = a.k0 + j;
-        // toric non-top proposals share a block: words 2(k&1) (generator) and 2(k&1)+1 (acceptance) of block (k>>1, 0)
-        const bool paired = code == kCodeToric && !top;
+        // non-top proposals share a block: words 2(k&1) (generator) and 2(k&1)+1 (acceptance) of block (k>>1, 0)
+        const bool paired = !top;
         u32x4 x = philox_block(paired ? k >> 1 : k, 0, syn, a.slot, a.seed_lo, a.seed_hi);
         if (paired) {
             if (k & 1) { x.x = x.z; x.y = x.w; }
@@ -143,7 +138,7 @@ __global__ void k_chain_update(const ChainArgs a)
             row = rc / L; col = rc % L; op = g < (uint32_t)(L * L) ? 1 : 3;
             dE = toric_apply_stabilizer_b(L, m, row, col, op);
         } else {
-            surf_pick(L, top ? x.y : x.x, top ? x.z : x.y, top ? x.w : x.z, a.thr_half, row, col, op);
+            surf_pick(L, top ? x.y : x.x, row, col, op);
             dE = surf_apply_stabilizer_b(code, L, m, row, col, op);
         }
         // ---- accept?

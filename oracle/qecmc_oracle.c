@@ -220,56 +220,60 @@ int orc_eq_class(int code, int L, const uint8_t *m)
     return code == ORC_TORIC ? orc_toric_eq_class(L, m) : orc_surf_eq_class(code, L, m);
 }
 
-/* Philox address of a toric proposal's draws.  Non-top chains (mcmc.py:38-43) need a generator and an acceptance
- * uniform: proposal k uses words 2(k&1) (generator) and 2(k&1)+1 (acceptance) of block (k>>1, 0), so one block feeds
- * two proposals.  Top chains (mcmc.py:21-35) keep block (k, 0): word 0 selects logical / stabilizer, word 1 picks the
- * generator, words 1-3 carry a logical operator; the acceptance uniform is word 0 of block (k, 2). */
-static double toric_nontop_accept(orc_rng *rng, uint32_t slot, uint64_t k)
+/* Philox address of a proposal's draws (every code model).  Non-top chains (mcmc.py:38-43) need a generator and an
+ * acceptance uniform: proposal k uses words 2(k&1) (generator) and 2(k&1)+1 (acceptance) of block (k>>1, 0), so one
+ * block feeds two proposals.  Top chains (mcmc.py:21-35) keep block (k, 0): word 0 selects logical / stabilizer, word 1
+ * picks the generator, words 1-3 carry a logical operator; the acceptance uniform is word 0 of block (k, 2). */
+static double nontop_accept(const orc_model *m, orc_rng *rng, uint32_t slot, uint64_t k)
 {
+    (void)m;
     return orc_draw(rng, slot, k >> 1, 0, 2 * (int)(k & 1) + 1);
 }
 
-/* acceptance uniform of a non-top proposal: toric see above; xzzx / rotated word 3 of block (k, 0) */
-static double nontop_accept(const orc_model *m, orc_rng *rng, uint32_t slot, uint64_t k)
-{
-    return m->code == ORC_TORIC ? toric_nontop_accept(rng, slot, k) : orc_draw(rng, slot, k, 0, 3);
-}
-
-/* _apply_random_stabilizer.
- * toric (toric_model.py:287-296): three draws row, col, op, i.e. a uniform choice among the 2L^2 generators.  The
- * injected-stream mode consumes them as the reference does; Philox mode spends ONE word on the same uniform choice:
- * g = floor(x * 2L^2 / 2^32), op = 1 if g < L^2 else 3, (row, col) = divmod(g mod L^2, L).
- * xzzx / rotated (xzzx_model.py:439-452, rotated_surface_model.py:395-408): FIVE draws, always:
- * rows, cols in [0,L-1), rows2 in [0,(L-1)/2), cols2 in [0,4), then `u > phalf` picks the full
- * plaquette.  Philox addressing: rows / cols = high / low half of word w0, rows2 = high half of
- * word w0+1, cols2 = next two bits, selector = word w0+2 (non-top w0 = 0, top w0 = 1). */
+/* _apply_random_stabilizer: a uniform choice among the stabilizer generators.
+ * toric (toric_model.py:287-296): three draws row, col, op -> uniform over the 2L^2 generators.
+ * xzzx / rotated (xzzx_model.py:439-452, rotated_surface_model.py:395-408): FIVE draws, always: rows, cols in [0,L-1),
+ * rows2 in [0,(L-1)/2), cols2 in [0,4), then `u > phalf` picks the full plaquette (rows, cols), else the half plaquette
+ * (rows2, cols2); phalf = 2/(L+1) makes that uniform over the (L-1)^2 + 2(L-1) = L^2 - 1 generators.
+ * The injected-stream mode consumes the draws as the reference does.  Philox mode spends ONE word on the same uniform
+ * choice, g = floor(x * G / 2^32): toric op = 1 if g < L^2 else 3, (row, col) = divmod(g mod L^2, L); xzzx / rotated
+ * g < (L-1)^2 is the full plaquette divmod(g, L-1), otherwise h = g - (L-1)^2 is half plaquette h/4 on side h%4. */
 static int model_random_stabilizer(const orc_model *m, const uint8_t *in, uint8_t *out, orc_rng *rng,
                                    uint32_t slot, uint64_t k, int w0)
 {
     const int L = m->L;
+    const int G = m->code == ORC_TORIC ? 2 * L * L : L * L - 1;
+    int g = -1;
+    if (rng->mode != 0) {
+        const double u = w0 == 0 ? orc_draw(rng, slot, k >> 1, 0, 2 * (int)(k & 1)) : orc_draw(rng, slot, k, 0, 1);
+        g = (int)(u * G);
+        rng->consumed += m->code == ORC_TORIC ? 2 : 4;              /* counted like the reference's three / five draws */
+    }
     if (m->code == ORC_TORIC) {
         int row, col, op;
-        if (rng->mode == 0) {
+        if (g < 0) {
             row = (int)(orc_draw(rng, slot, k, 0, w0) * L);           /* toric_model.py:291 */
             col = (int)(orc_draw(rng, slot, k, 0, w0 + 1) * L);       /* :292 */
             op = (int)(orc_draw(rng, slot, k, 0, w0 + 2) * 2);        /* :293 */
             if (op == 0) op = 3;
         } else {
-            const double u = w0 == 0 ? orc_draw(rng, slot, k >> 1, 0, 2 * (int)(k & 1)) : orc_draw(rng, slot, k, 0, 1);
-            const int g = (int)(u * (2 * L * L));
-            rng->consumed += 2;                                       /* counted like the reference's three draws */
             op = g < L * L ? 1 : 3;
             row = (g % (L * L)) / L;
             col = g % L;
         }
         return orc_toric_apply_stabilizer(L, in, out, row, col, op);
     }
-    int rows = (int)((L - 1) * orc_draw_field(rng, slot, k, 0, w0, 0, 16));
-    int cols = (int)((L - 1) * orc_draw_field(rng, slot, k, 0, w0, 16, 16));
-    int rows2 = (int)(((L - 1) / 2.0) * orc_draw_field(rng, slot, k, 0, w0 + 1, 0, 16));
-    int cols2 = (int)(4 * orc_draw_field(rng, slot, k, 0, w0 + 1, 16, 2));
+    if (g >= 0) {
+        const int nfull = (L - 1) * (L - 1);
+        if (g < nfull) return orc_surf_apply_stabilizer(m->code, L, in, out, g / (L - 1), g % (L - 1), 1);
+        return orc_surf_apply_stabilizer(m->code, L, in, out, (g - nfull) / 4, (g - nfull) % 4, 3);
+    }
+    int rows = (int)((L - 1) * orc_draw(rng, slot, k, 0, w0));                  /* xzzx_model.py:442-445 */
+    int cols = (int)((L - 1) * orc_draw(rng, slot, k, 0, w0));
+    int rows2 = (int)(((L - 1) / 2.0) * orc_draw(rng, slot, k, 0, w0));
+    int cols2 = (int)(4 * orc_draw(rng, slot, k, 0, w0));
     double phalf = (double)(L * L - (L - 1) * (L - 1) - 1) / (double)(L * L - 1);
-    if (orc_draw(rng, slot, k, 0, w0 + 2) > phalf)
+    if (orc_draw(rng, slot, k, 0, w0) > phalf)                                  /* :446 */
         return orc_surf_apply_stabilizer(m->code, L, in, out, rows, cols, 1);
     return orc_surf_apply_stabilizer(m->code, L, in, out, rows2, cols2, 3);
 }
