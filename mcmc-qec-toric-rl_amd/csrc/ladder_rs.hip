@@ -1012,19 +1012,12 @@ hipError_t launch_ladder_rs_toric(const LadderArgs &a, hipStream_t stream)
     unsigned block = (unsigned)a.Nc * 64u;
     size_t lds = ladder_lds_bytes(a.L, a.Nc, a.W, a.ncls, ladder_gen_dwords(a.code, a.noise, a.scan, a.n_gen, a.Nc));
     if (grid == 0) return hipSuccess;
-    // Nc <= 8: two 64-syndrome groups per workgroup (<= 1024 threads, 2 workgroups = 32 waves per CU);
-    // Nc > 8: one group (<= 1024 threads)
+    // One 64-syndrome group (Nc waves) per workgroup.  The kernel can also run two groups per workgroup (GROUPS = 2: they
+    // share only the barrier), which paid off while a one-round grid ended in a long tail; with the current proposal loop
+    // the 8-wave workgroups are faster at every batch size (+1.6 % at 65 536 syndromes, +5 % at 262 144), so only
+    // GROUPS = 1 is instantiated.
     const bool conv = a.conv_mode != 0;
-    // two groups pay off when the whole grid is resident at once or nearly so (the end-of-launch tail);
-    // on many-round grids the smaller 8-wave workgroups synchronise more cheaply (measured +3.5 %)
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    const int groups = (a.Nc <= 8 && a.N > 64 && grid <= 8u * (unsigned)n_cu && 2 * lds <= 160 * 1024) ? 2 : 1;
+    const int groups = 1;
     grid = (grid + groups - 1) / groups;
     block *= groups;
     lds *= groups;
@@ -1038,23 +1031,19 @@ hipError_t launch_ladder_rs_toric(const LadderArgs &a, hipStream_t stream)
         // the general top-chain path is needed only for L > 16 or a top chain below p = 0.75 (1-chain ladder)
         const bool gentop = a.thr_logical != 0 && (a.L > 16 || !((a.acc_all_mask >> (a.Nc - 1)) & 1u));
         if (gentop) {
-            if (groups == 2) fn = QECMC_K2(1024, 8, 2, T, false, true);
-            else if (block <= 512) fn = QECMC_K2(512, 8, 1, T, false, true);
+            if (block <= 512) fn = QECMC_K2(512, 8, 1, T, false, true);
             else fn = QECMC_K2(1024, 4, 1, T, false, true);
         } else {
-            if (groups == 2) fn = QECMC_K2(1024, 8, 2, T, false, false);
-            else if (block <= 512) fn = QECMC_K2(512, 8, 1, T, false, false);
+            if (block <= 512) fn = QECMC_K2(512, 8, 1, T, false, false);
             else fn = QECMC_K2(1024, 4, 1, T, false, false);
         }
     } else {
         if (!a.noise && (a.code == X || a.code == R)) {
             if (a.code == X) {
-                if (groups == 2) fn = QECMC_K(1024, 8, 2, X, false);
-                else if (block <= 512) fn = QECMC_K(512, 8, 1, X, false);
+                if (block <= 512) fn = QECMC_K(512, 8, 1, X, false);
                 else fn = QECMC_K(1024, 4, 1, X, false);
             } else {
-                if (groups == 2) fn = QECMC_K(1024, 8, 2, R, false);
-                else if (block <= 512) fn = QECMC_K(512, 8, 1, R, false);
+                if (block <= 512) fn = QECMC_K(512, 8, 1, R, false);
                 else fn = QECMC_K(1024, 4, 1, R, false);
             }
         } else {
