@@ -65,6 +65,14 @@ __device__ __forceinline__ uint32_t bfe2_lo5(uint32_t w, uint32_t e)
     asm("v_bfe_u32 %0, %1, %2, 2" : "=v"(r) : "v"(w), "v"(e));
     return r;
 }
+// (a << k) | b in one instruction
+__device__ __forceinline__ uint32_t lshl_or(uint32_t a, int k, uint32_t b)
+{
+    uint32_t r;
+    asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "n"(k), "v"(b));
+    return r;
+}
+
 __device__ __forceinline__ uint32_t shl_lo5(uint32_t v, uint32_t e)
 {
     uint32_t r;
@@ -219,7 +227,8 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
     const int grp = (GROUPS == 1) ? 0 : ((int)threadIdx.x >= nthreads);
     const int tid = (int)threadIdx.x - grp * nthreads, lane = tid & 63, slot = tid >> 6;
     // generator table in LDS: 4 x u16 per generator as the plan stores it, or -- for the toric random-scan hot path --
-    // expanded to 4 x u32 (dword offset << 10 | pauli << 5 | bit shift) so a site costs a shift, a shift-add and a bfe
+    // expanded to 4 x u32 (byte offset << 16 | Pauli x 0x55 << 8 | Pauli << 5 | bit shift) so a site costs one add (its high
+    // half, SDWA) and one bfe
     constexpr bool kWideGen = CODE == kCodeToric && !BIASED && !SCAN;
     const int gen_dw = (kWideGen ? 4 : 2) * (int)a.n_gen;
     const bool alpha_noise = BIASED && a.noise == 2;            // mcmc_alpha.py: biased rule + slot-bound n_eff swap test
@@ -256,7 +265,8 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
     if constexpr (kWideGen) {
         for (int i = tid; i < gen_dw; i += nthreads) {
             const uint32_t e = reinterpret_cast<const uint16_t *>(a.gen)[i], q = e >> 2;
-            (lds + gen_off)[i] = (((q >> 4) * 64u) << 10) | ((e & 3u) << 5) | ((q & 15u) * 2u);   // dword offset << 10
+            // byte offset of the state dword [31:16] | Pauli x 0x55 [15:8] | Pauli [6:5] | bit shift [4:0]
+            (lds + gen_off)[i] = (((q >> 4) * 256u) << 16) | (((e & 3u) * 0x55u) << 8) | ((e & 3u) << 5) | ((q & 15u) * 2u);
         }
     } else {
         for (int i = tid; i < gen_dw; i += nthreads) (lds + gen_off)[i] = reinterpret_cast<const uint32_t *>(a.gen)[i];
@@ -598,16 +608,17 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             const uint32_t G2 = 2u * (uint32_t)LL;
             auto propose = [&](uint32_t xp, uint32_t xa) {
                 const uint4 ev = gtab4[scale_u32(xp, G2)];                          // the four sites (toric_model.py:261-269)
-                const uint32_t sh[4] = {ev.x, ev.y, ev.z, ev.w};                    // dword offset << 10 | pauli << 5 | bit shift
+                const uint32_t sh[4] = {ev.x, ev.y, ev.z, ev.w};                    // byte offset << 16 | ... | bit shift
                 uint32_t *ad[4];
-                uint32_t F = 0;
+                uint32_t f[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    ad[i] = stw + (sh[i] >> 10);
-                    F |= bfe2_lo5(*ad[i], sh[i]) << (2 * i);
+                    ad[i] = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(stw) + (sh[i] >> 16));   // byte offset: one SDWA add
+                    f[i] = bfe2_lo5(*ad[i], sh[i]);
                 }
+                const uint32_t F = lshl_or(lshl_or(f[3], 2, f[2]), 4, lshl_or(f[1], 2, f[0]));
                 const uint32_t op = (ev.x >> 5) & 3u;
-                const uint32_t G = F ^ (op * 0x55u);                               // the four new values
+                const uint32_t G = F ^ ((ev.x >> 8) & 0xFFu);                      // the four new values (Pauli x 0x55)
                 const int dE = __popc((G | (G >> 1)) & 0x55u) - __popc((F | (F >> 1)) & 0x55u);   // :275-282
                 if (xa <= myT[dE]) {                                                // mcmc.py:42
 #pragma unroll
@@ -728,7 +739,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                         const uint32_t op = (ev.x >> 5) & 3u;
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
-                            lds_xor(stw + (e4[i] >> 10), shl_lo5(op, e4[i]));
+                            lds_xor(reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(stw) + (e4[i] >> 16)), shl_lo5(op, e4[i]));
                     }
                 };
                 // two proposals' Philox chains in flight: this wave is the step's longest and often runs alone
