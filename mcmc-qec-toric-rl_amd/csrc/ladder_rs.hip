@@ -619,11 +619,13 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 const uint32_t F = lshl_or(lshl_or(f[3], 2, f[2]), 4, lshl_or(f[1], 2, f[0]));
                 const uint32_t op = (ev.x >> 5) & 3u;
                 const uint32_t G = F ^ ((ev.x >> 8) & 0xFFu);                      // the four new values (Pauli x 0x55)
-                const int dE = __popc((G | (G >> 1)) & 0x55u) - __popc((F | (F >> 1)) & 0x55u);   // :275-282
-                if (xa <= myT[dE]) {                                                // mcmc.py:42
+                // dE + 4 = #(new != 0) + #(old == 0) (:275-282): two chained popcounts, no subtraction; the threshold row is
+                // indexed by dE + 4 anyway
+                const uint32_t dE4 = __popc((G | (G >> 1)) & 0x55u) + __popc(~(F | (F >> 1)) & 0x55u);
+                if (xa <= (myT - 4)[dE4]) {                                         // mcmc.py:42
 #pragma unroll
                     for (int i = 0; i < 4; ++i) lds_xor(ad[i], shl_lo5(op, sh[i]));
-                    ni += dE;
+                    ni += (int)dE4 - 4;
                 }
             };
             uint32_t j = 0;
