@@ -992,6 +992,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
 
     // ---- results: coalesced stores ---------------------------------------------------
     if (a.counts != nullptr)
+#pragma unroll 1
         for (int i = tid; i < cnt * ncls; i += nthreads) {
             const int j = i / ncls, c = i - j * ncls;
             a.counts[s0 * ncls + i] = hist[c * 64 + j];
@@ -1011,6 +1012,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
     if (a.write_states && a.states != nullptr) {
         uint8_t *dst = a.states + s0 * (uint64_t)NC * nq;
         const int per = NC * nq, total = cnt * per;
+#pragma unroll 1      // (unrolled, its index divisions spill a register of the whole kernel to scratch)
         for (int o = tid; o < total; o += nthreads) {
             const int j = o / per, rem = o - j * per, c = rem / nq, q = rem - c * nq;
             const uint32_t sidc = (fin[c * 64 + j] >> 16) & 0xFFu;
