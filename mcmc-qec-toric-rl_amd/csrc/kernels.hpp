@@ -57,11 +57,14 @@ struct LadderArgs {
 size_t ladder_lds_bytes(int L, int Nc, int W, int ncls, int gen_dwords);
 constexpr uint32_t kMaxGenLds = 2048;   // generator tables up to this many entries are staged in LDS
 // dwords of the LDS generator table: the toric random-scan kernels expand each generator to 4 x u32
-// (dword offset << 10 | pauli << 5 | bit shift), the other paths keep the plan's 4 x u16 form
+// (byte offset << 16 | pauli fields | bit shift), the other paths keep the plan's 4 x u16 form.  Up to kGenSplit
+// generators the expanded table is stored as two halves kGenSplit entries apart (sites 0,1 | sites 2,3).
 // alpha noise appends the double-buffered n_eff records [2][Nc][64] to the region
+constexpr int kGenSplit = 255;      // ds_read2_b64's second offset is an 8-bit count of 8-byte units
 inline int ladder_gen_dwords(int code, int noise, int scan, uint32_t n_gen, int Nc)
 {
-    const int tab = (code == 0 && !noise && !scan ? 4 : 2) * (int)n_gen;
+    const bool wide = code == 0 && !noise && !scan;
+    const int tab = wide ? ((int)n_gen <= kGenSplit ? 2 * (kGenSplit + (int)n_gen) : 4 * (int)n_gen) : 2 * (int)n_gen;
     return noise == 2 ? ((tab + 3) & ~3) + 2 * Nc * 64 : tab;
 }
 hipError_t launch_ladder_rs_toric(const LadderArgs &a, hipStream_t stream);

@@ -157,9 +157,9 @@ __device__ __forceinline__ uint32_t pack_info(uint32_t n, uint32_t sid, uint32_t
 
 // CONV: build with the error_based convergence criterion (its per-lane window sums cost ~10 VGPRs,
 // so fixed-step runs use the instantiation without it)
-// GROUPS: independent 64-syndrome ladders per workgroup (they share only the barrier).  Two groups
-// (16 waves at Nc = 8, two workgroups per CU) keep 4 waves per SIMD busy even when a workgroup is
-// alone on its CU at the end of a launch, where one group (2 waves per SIMD) is latency-bound.
+// GSPLIT: the expanded generator table of the toric random-scan path is stored as two halves kGenSplit entries apart
+// (sites 0,1 | sites 2,3): one ds_read2_b64 with a constant second offset costs ~15 LDS cycles for random entries,
+// 16 adjacent bytes ~21 (tools/ubench_lds.hip).  Needs n_gen <= kGenSplit (toric L <= 11).
 // exp(y) for y <= 0 from IEEE multiply / add / fma only: the same operation sequence as the oracle's orc_det_exp, so the
 // swap decision of the alpha ladder is bit-identical on both sides.  y >= 0 returns 1; below 2^-1022 flushes to 0.
 __device__ inline double det_exp(double y)
@@ -218,24 +218,24 @@ __device__ inline bool alpha_series_close(uint64_t z2, uint64_t xy2, uint32_t de
 // GENTOP: keep the table-driven general top-chain path (toric L > 16, or a 1-chain ladder whose top sits below
 // p = 0.75; always needed by the plaquette codes and the biased rule).  The common toric configurations compile it out,
 // which keeps its registers out of the hot loop.
-template <int MAXT, int MINW, bool CONV, int GROUPS, int CODE, bool BIASED, bool SCAN, bool GENTOP>
+template <int MAXT, int MINW, bool CONV, bool GSPLIT, int CODE, bool BIASED, bool SCAN, bool GENTOP>
 __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const LadderArgs a)
 {
     extern __shared__ uint32_t lds_all[];
     const int NC = a.Nc, W = a.W, L = a.L, LL = L * L, nq = a.nq, ncls = a.ncls;
     const int nthreads = NC * 64;                 // threads of one group
-    const int grp = (GROUPS == 1) ? 0 : ((int)threadIdx.x >= nthreads);
-    const int tid = (int)threadIdx.x - grp * nthreads, lane = tid & 63, slot = tid >> 6;
+    const int tid = (int)threadIdx.x, lane = tid & 63, slot = tid >> 6;
     // generator table in LDS: 4 x u16 per generator as the plan stores it, or -- for the toric random-scan hot path --
     // expanded to 4 x u32 (byte offset << 16 | Pauli x 0x55 << 8 | Pauli << 5 | bit shift) so a site costs one add (its high
     // half, SDWA) and one bfe
     constexpr bool kWideGen = CODE == kCodeToric && !BIASED && !SCAN;
-    const int gen_dw = (kWideGen ? 4 : 2) * (int)a.n_gen;
+    constexpr bool kSplitGen = kWideGen && GSPLIT;
+    const int gen_dw = kWideGen ? (kSplitGen ? 2 * (kGenSplit + (int)a.n_gen) : 4 * (int)a.n_gen) : 2 * (int)a.n_gen;
     const bool alpha_noise = BIASED && a.noise == 2;            // mcmc_alpha.py: biased rule + slot-bound n_eff swap test
     const int gen_region = alpha_noise ? ((gen_dw + 3) & ~3) + 2 * NC * 64 : gen_dw;
     const int gdw = ladder_group_dwords(NC, W, ncls, gen_region);   // dwords per group
     const int gen_off = gdw - ((gen_region + 3) & ~3);           // start of the generator table
-    uint32_t *lds = lds_all + grp * gdw;
+    uint32_t *lds = lds_all;
     [[maybe_unused]] uint32_t *neffb = lds + gen_off + ((gen_dw + 3) & ~3);   // [2][NC][64] n_z | (n_x+n_y) << 16 per slot, by step parity
 
     uint32_t *st = lds;                           // [NC][W][64]   packed states
@@ -247,6 +247,14 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
     volatile uint32_t *stopf = swapT + NC * kSwapFast;   // [1]  every syndrome of the workgroup has converged
     [[maybe_unused]] const uint2 *gtab = reinterpret_cast<const uint2 *>(lds + gen_off);   // [n_gen] generator table (LDS copy)
     [[maybe_unused]] const uint4 *gtab4 = reinterpret_cast<const uint4 *>(lds + gen_off);  // wide form (kWideGen)
+    [[maybe_unused]] auto gen_entry = [&](uint32_t g) -> uint4 {                          // one ds_read2_b64 either way
+        if constexpr (kSplitGen) {
+            const uint2 lo = gtab[g], hi = gtab[g + kGenSplit];
+            return uint4{lo.x, lo.y, hi.x, hi.y};
+        } else {
+            return gtab4[g];
+        }
+    };
 
 #ifdef QECMC_TIMELINE   // diagnostic build only (tools/timeline.hip): per-workgroup start/end stamps and placement
     if (a.dbg && threadIdx.x == 0) {
@@ -255,7 +263,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                                     __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));                       // HW_ID
     }
 #endif
-    const uint64_t s0 = ((uint64_t)blockIdx.x * GROUPS + grp) * 64u;
+    const uint64_t s0 = (uint64_t)blockIdx.x * 64u;
     const int cnt = a.N > s0 ? (int)((a.N - s0) < 64u ? (a.N - s0) : 64u) : 0;   // 0: a group past the end of the batch
     const uint32_t syn = a.first_syndrome + (uint32_t)s0 + (uint32_t)lane;   // Philox ctr[2]
 
@@ -263,10 +271,12 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
     for (int i = tid; i < ncls * 64; i += nthreads) hist[i] = 0;
     if (tid == 0) *stopf = 0;
     if constexpr (kWideGen) {
-        for (int i = tid; i < gen_dw; i += nthreads) {
+        for (int i = tid; i < 4 * (int)a.n_gen; i += nthreads) {
             const uint32_t e = reinterpret_cast<const uint16_t *>(a.gen)[i], q = e >> 2;
             // byte offset of the state dword [31:16] | Pauli x 0x55 [15:8] | Pauli [6:5] | bit shift [4:0]
-            (lds + gen_off)[i] = (((q >> 4) * 256u) << 16) | (((e & 3u) * 0x55u) << 8) | ((e & 3u) << 5) | ((q & 15u) * 2u);
+            const int g = i >> 2, k = i & 3;                                       // generator, site
+            (lds + gen_off)[kSplitGen ? 2 * (g + (k >> 1) * kGenSplit) + (k & 1) : i] =
+                (((q >> 4) * 256u) << 16) | (((e & 3u) * 0x55u) << 8) | ((e & 3u) << 5) | ((q & 15u) * 2u);
         }
     } else {
         for (int i = tid; i < gen_dw; i += nthreads) (lds + gen_off)[i] = reinterpret_cast<const uint32_t *>(a.gen)[i];
@@ -607,7 +617,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             // reference's three draws are, toric_model.py:291-295), one is the acceptance uniform: a block feeds two proposals.
             const uint32_t G2 = 2u * (uint32_t)LL;
             auto propose = [&](uint32_t xp, uint32_t xa) {
-                const uint4 ev = gtab4[scale_u32(xp, G2)];                          // the four sites (toric_model.py:261-269)
+                const uint4 ev = gen_entry(scale_u32(xp, G2));                      // the four sites (toric_model.py:261-269)
                 const uint32_t sh[4] = {ev.x, ev.y, ev.z, ev.w};                    // byte offset << 16 | ... | bit shift
                 uint32_t *ad[4];
                 uint32_t f[4];
@@ -736,7 +746,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                     if (x.x <= thrL1) {                                             // mcmc.py:23
                         add_logical(x);
                     } else {
-                        const uint4 ev = gtab4[scale_u32(x.y, 2u * (uint32_t)LL)]; // word 1 picks the generator
+                        const uint4 ev = gen_entry(scale_u32(x.y, 2u * (uint32_t)LL));   // word 1 picks the generator
                         const uint32_t e4[4] = {ev.x, ev.y, ev.z, ev.w};
                         const uint32_t op = (ev.x >> 5) & 3u;
 #pragma unroll
@@ -876,7 +886,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
 #endif
         if (CONV) {                                         // flags set one step earlier: uniform for the workgroup
             volatile uint32_t *f0 = lds_all + (NC * W * 64 + 4 * NC * 64 + ncls * 64 + NC * 9 + NC * kSwapFast);
-            if (f0[0] && (GROUPS == 1 || f0[gdw])) break;
+            if (f0[0]) break;
         }
         {
             // every wave replays the top-down cascade on the published records; `car` is the record
@@ -1027,15 +1037,10 @@ hipError_t launch_ladder_rs_toric(const LadderArgs &a, hipStream_t stream)
     unsigned block = (unsigned)a.Nc * 64u;
     size_t lds = ladder_lds_bytes(a.L, a.Nc, a.W, a.ncls, ladder_gen_dwords(a.code, a.noise, a.scan, a.n_gen, a.Nc));
     if (grid == 0) return hipSuccess;
-    // One 64-syndrome group (Nc waves) per workgroup.  The kernel can also run two groups per workgroup (GROUPS = 2: they
-    // share only the barrier), which paid off while a one-round grid ended in a long tail; with the current proposal loop
-    // the 8-wave workgroups are faster at every batch size (+1.6 % at 65 536 syndromes, +5 % at 262 144), so only
-    // GROUPS = 1 is instantiated.
+    // One 64-syndrome group (Nc waves) per workgroup.  (Two groups per workgroup, sharing only the barrier, paid off while a
+    // one-round grid ended in a long tail; with the current proposal loop the 8-wave workgroups are faster at every batch
+    // size: +1.6 % at 65 536 syndromes, +5 % at 262 144.)
     const bool conv = a.conv_mode != 0;
-    const int groups = 1;
-    grid = (grid + groups - 1) / groups;
-    block *= groups;
-    lds *= groups;
     const void *fn;
     constexpr int T = kCodeToric, X = kCodeXzzx, R = kCodeRotated;
 #define QECMC_K2(maxt, minw, g, code, biased, gentop) \
@@ -1045,29 +1050,29 @@ hipError_t launch_ladder_rs_toric(const LadderArgs &a, hipStream_t stream)
     if (a.code == T && !a.noise) {
         // the general top-chain path is needed only for L > 16 or a top chain below p = 0.75 (1-chain ladder)
         const bool gentop = a.thr_logical != 0 && (a.L > 16 || !((a.acc_all_mask >> (a.Nc - 1)) & 1u));
+        const bool gsplit = !a.scan && (int)a.n_gen <= kGenSplit;      // the table layout of ladder_gen_dwords()
         if (gentop) {
-            if (block <= 512) fn = QECMC_K2(512, 8, 1, T, false, true);
-            else fn = QECMC_K2(1024, 4, 1, T, false, true);
+            if (block <= 512) fn = gsplit ? QECMC_K2(512, 8, true, T, false, true) : QECMC_K2(512, 8, false, T, false, true);
+            else fn = gsplit ? QECMC_K2(1024, 4, true, T, false, true) : QECMC_K2(1024, 4, false, T, false, true);
         } else {
-            if (block <= 512) fn = QECMC_K2(512, 8, 1, T, false, false);
-            else fn = QECMC_K2(1024, 4, 1, T, false, false);
+            if (block <= 512) fn = gsplit ? QECMC_K2(512, 8, true, T, false, false) : QECMC_K2(512, 8, false, T, false, false);
+            else fn = gsplit ? QECMC_K2(1024, 4, true, T, false, false) : QECMC_K2(1024, 4, false, T, false, false);
         }
     } else {
         if (!a.noise && (a.code == X || a.code == R)) {
             if (a.code == X) {
-                if (block <= 512) fn = QECMC_K(512, 8, 1, X, false);
-                else fn = QECMC_K(1024, 4, 1, X, false);
+                if (block <= 512) fn = QECMC_K(512, 8, false, X, false);
+                else fn = QECMC_K(1024, 4, false, X, false);
             } else {
-                if (block <= 512) fn = QECMC_K(512, 8, 1, R, false);
-                else fn = QECMC_K(1024, 4, 1, R, false);
+                if (block <= 512) fn = QECMC_K(512, 8, false, R, false);
+                else fn = QECMC_K(1024, 4, false, R, false);
             }
         } else {
         // the biased rule runs one group per workgroup (any Nc <= 16)
-        grid *= groups; block /= groups; lds /= groups;
         if (false) {}
         else if (a.scan) return hipErrorInvalidValue;          // the sweep is built for the depolarizing rule only
-        else if (a.code == X) fn = conv ? (const void *)ladder_rs_toric_kernel<1024, 4, true, 1, X, true, false, true> : (const void *)ladder_rs_toric_kernel<1024, 4, false, 1, X, true, false, true>;
-        else if (a.code == R) fn = conv ? (const void *)ladder_rs_toric_kernel<1024, 4, true, 1, R, true, false, true> : (const void *)ladder_rs_toric_kernel<1024, 4, false, 1, R, true, false, true>;
+        else if (a.code == X) fn = conv ? (const void *)ladder_rs_toric_kernel<1024, 4, true, false, X, true, false, true> : (const void *)ladder_rs_toric_kernel<1024, 4, false, false, X, true, false, true>;
+        else if (a.code == R) fn = conv ? (const void *)ladder_rs_toric_kernel<1024, 4, true, false, R, true, false, true> : (const void *)ladder_rs_toric_kernel<1024, 4, false, false, R, true, false, true>;
         else return hipErrorInvalidValue;
         }
     }

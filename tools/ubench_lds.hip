@@ -24,6 +24,8 @@ __global__ __launch_bounds__(512) void k(uint32_t *out, int iters, uint32_t seed
             if (KIND == 0) acc += ((volatile uint32_t *)p)[u * 64];                           // ds_read_b32
             else if (KIND == 1) ((volatile uint32_t *)p)[u * 64] = acc + u;                   // ds_write_b32
             else if (KIND == 5) { r = r * 1664525u + 1013904223u; const uint2 e = tab2[(r >> 24) % 162u]; acc += e.x ^ e.y; }    // random ds_read_b64
+            else if (KIND == 7) { r = r * 1664525u + 1013904223u; const uint32_t g = (r >> 24) % 162u; const uint2 e0 = tab2[g], e1 = tab2[g + 81]; acc += e0.x ^ e1.y; }   // two 8-byte tables: ds_read2_b64 offset1:81
+            else if (KIND == 8) { r = r * 1664525u + 1013904223u; const uint32_t g = (r >> 24) % 81u; const uint2 e0 = tab2[2 * g], e1 = tab2[2 * g + 1]; acc += e0.x ^ e1.y; }   // adjacent pair: ds_read2_b64 offset1:1
             else if (KIND == 6) { r = r * 1664525u + 1013904223u; acc += tab1[(r >> 24) % 162u]; }                               // random ds_read_b32
             else if (KIND == 2) __hip_atomic_fetch_xor(p + u * 64, acc | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_xor_b32
             else if (KIND == 3) { r = r * 1664525u + 1013904223u; const uint4 e = tab[(r >> 24) % 162u]; acc += e.x ^ e.w; }     // random ds_read_b128
@@ -64,6 +66,8 @@ int main()
     run<3>("ds_read_b128 random/162");
     run<5>("ds_read_b64 random/162");
     run<6>("ds_read_b32 random/162");
+    run<7>("ds_read2_b64 split tables");
+    run<8>("ds_read2_b64 adjacent");
     run<4>("(index arithmetic only)");
     return 0;
 }
