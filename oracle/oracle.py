@@ -33,7 +33,7 @@ class Model(C.Structure):
                 ("det_pow", C.c_int), ("scan", C.c_int)]
 
 
-TORIC, XZZX, ROTATED = 0, 1, 2
+TORIC, XZZX, ROTATED, PLANAR = 0, 1, 2, 3
 DEPOLARIZING, BIASED, ALPHA = 0, 1, 2
 
 
@@ -100,6 +100,11 @@ def lib():
         _LIB.orc_surf_eq_class.restype = C.c_int
         _LIB.orc_surf_syndrome.argtypes = [C.c_int, C.c_int, u8p, u8p]
         _LIB.orc_surf_syndrome.restype = None
+        _LIB.orc_planar_syndrome.argtypes = [C.c_int, u8p, u8p, u8p]
+        _LIB.orc_planar_syndrome.restype = None
+        _LIB.orc_surf_ngen.argtypes = [C.c_int, C.c_int]; _LIB.orc_surf_ngen.restype = C.c_int
+        _LIB.orc_surf_gen_rco.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        _LIB.orc_surf_gen_rco.restype = None
         _LIB.orc_chain_update.argtypes = [mp, u8p, C.c_double, C.c_double, C.c_uint64, C.POINTER(_Rng), C.c_uint32,
                                           C.c_uint64, u8p]
         _LIB.orc_chain_update.restype = None
@@ -290,19 +295,37 @@ def _size(code, m):
 
 def surf_apply_stabilizer(code, m, row, col, op):
     m = _m(m); out = np.empty_like(m)
-    dE = lib().orc_surf_apply_stabilizer(code, m.shape[0], _u8(m), _u8(out), row, col, op)
+    dE = lib().orc_surf_apply_stabilizer(code, m.shape[-1], _u8(m), _u8(out), row, col, op)
     return out, dE
 
 
 def surf_apply_logical(code, m, op, xpos=0, zpos=0):
     m = _m(m); out = np.empty_like(m)
-    dE = lib().orc_surf_apply_logical(code, m.shape[0], _u8(m), _u8(out), op, xpos, zpos)
+    dE = lib().orc_surf_apply_logical(code, m.shape[-1], _u8(m), _u8(out), op, xpos, zpos)
     return out, dE
 
 
 def surf_eq_class(code, m):
     m = _m(m)
-    return int(lib().orc_surf_eq_class(code, m.shape[0], _u8(m)))
+    return int(lib().orc_surf_eq_class(code, m.shape[-1], _u8(m)))
+
+
+def planar_syndrome(m):
+    """(vertex_defects bool[L-1, L], plaquette_defects bool[L, L-1]) of Planar_code.syndrom (planar_model.py:134-153)."""
+    m = _m(m); L = m.shape[-1]
+    v = np.zeros((L - 1, L), dtype=np.uint8); q = np.zeros((L, L - 1), dtype=np.uint8)
+    lib().orc_planar_syndrome(L, _u8(m), _u8(v), _u8(q))
+    return v.astype(bool), q.astype(bool)
+
+
+def surf_ngen(code, L):
+    return int(lib().orc_surf_ngen(code, L))
+
+
+def surf_gen_rco(code, L, g):
+    r, c, o = C.c_int(), C.c_int(), C.c_int()
+    lib().orc_surf_gen_rco(code, L, g, C.byref(r), C.byref(c), C.byref(o))
+    return r.value, c.value, o.value
 
 
 def surf_syndrome(code, m):

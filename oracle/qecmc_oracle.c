@@ -212,7 +212,7 @@ void orc_toric_syndrome(int L, const uint8_t *in, uint8_t *defects_out)
 /* ------------------------------------------------------------------------ */
 /* Chain.update_chain, src/mcmc.py:19-43 (and Chain_biased, mcmc_biased.py:20-59) */
 /* ------------------------------------------------------------------------ */
-int orc_nq(int code, int L) { return code == ORC_TORIC ? 2 * L * L : L * L; }
+int orc_nq(int code, int L) { return (code == ORC_TORIC || code == ORC_PLANAR) ? 2 * L * L : L * L; }
 int orc_ncls(int code) { return code == ORC_TORIC ? 16 : 4; }
 
 int orc_eq_class(int code, int L, const uint8_t *m)
@@ -242,12 +242,12 @@ static int model_random_stabilizer(const orc_model *m, const uint8_t *in, uint8_
                                    uint32_t slot, uint64_t k, int w0)
 {
     const int L = m->L;
-    const int G = m->code == ORC_TORIC ? 2 * L * L : L * L - 1;
+    const int G = m->code == ORC_TORIC ? 2 * L * L : orc_surf_ngen(m->code, L);
     int g = -1;
     if (rng->mode != 0) {
         const double u = w0 == 0 ? orc_draw(rng, slot, k >> 1, 0, 2 * (int)(k & 1)) : orc_draw(rng, slot, k, 0, 1);
         g = (int)(u * G);
-        rng->consumed += m->code == ORC_TORIC ? 2 : 4;              /* counted like the reference's three / five draws */
+        rng->consumed += (m->code == ORC_TORIC || m->code == ORC_PLANAR) ? 2 : 4;   /* counted like the reference's three / five draws */
     }
     if (m->code == ORC_TORIC) {
         int row, col, op;
@@ -264,9 +264,15 @@ static int model_random_stabilizer(const orc_model *m, const uint8_t *in, uint8_
         return orc_toric_apply_stabilizer(L, in, out, row, col, op);
     }
     if (g >= 0) {
-        const int nfull = (L - 1) * (L - 1);
-        if (g < nfull) return orc_surf_apply_stabilizer(m->code, L, in, out, g / (L - 1), g % (L - 1), 1);
-        return orc_surf_apply_stabilizer(m->code, L, in, out, (g - nfull) / 4, (g - nfull) % 4, 3);
+        int row, col, op;
+        orc_surf_gen_rco(m->code, L, g, &row, &col, &op);
+        return orc_surf_apply_stabilizer(m->code, L, in, out, row, col, op);
+    }
+    if (m->code == ORC_PLANAR) {                                                /* planar_model.py:343-352 */
+        const int short_side = (int)((L - 1) * orc_draw(rng, slot, k, 0, w0));
+        const int long_side = (int)(L * orc_draw(rng, slot, k, 0, w0));
+        if (orc_draw(rng, slot, k, 0, w0) < 0.5) return orc_surf_apply_stabilizer(m->code, L, in, out, short_side, long_side, 1);
+        return orc_surf_apply_stabilizer(m->code, L, in, out, long_side, short_side, 3);
     }
     int rows = (int)((L - 1) * orc_draw(rng, slot, k, 0, w0));                  /* xzzx_model.py:442-445 */
     int cols = (int)((L - 1) * orc_draw(rng, slot, k, 0, w0));
@@ -319,11 +325,9 @@ static int model_sweep_stabilizer(const orc_model *m, const uint8_t *in, uint8_t
         if (g >= LL) { op = 3; g -= LL; }
         return orc_toric_apply_stabilizer(L, in, out, g / L, g % L, op);
     }
-    const int nf = (L - 1) * (L - 1);
-    int g = (int)(k % (uint64_t)(nf + 2 * (L - 1)));
-    if (g < nf) return orc_surf_apply_stabilizer(m->code, L, in, out, g / (L - 1), g % (L - 1), 1);
-    g -= nf;
-    return orc_surf_apply_stabilizer(m->code, L, in, out, g / 4, g % 4, 3);
+    int row, col, op;
+    orc_surf_gen_rco(m->code, L, (int)(k % (uint64_t)orc_surf_ngen(m->code, L)), &row, &col, &op);
+    return orc_surf_apply_stabilizer(m->code, L, in, out, row, col, op);
 }
 
 /* Systematic-sweep Metropolis (scan = 1).  Non-top chains: generator k mod G, accepted iff u < f^dE with u = word

@@ -52,12 +52,13 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 void orc_rng_init_stream(orc_rng *r, const double *stream, uint64_t len);
 void orc_rng_init_philox(orc_rng *r, uint64_t seed, uint32_t syndrome);
 
-enum { ORC_TORIC = 0, ORC_XZZX = 1, ORC_ROTATED = 2 };
+enum { ORC_TORIC = 0, ORC_XZZX = 1, ORC_ROTATED = 2, ORC_PLANAR = 3 };
 enum { ORC_NOISE_DEPOLARIZING = 0, ORC_NOISE_BIASED = 1, ORC_NOISE_ALPHA = 2 };
 
 /* which code model / acceptance rule a chain uses (duck typing in the reference) */
 typedef struct orc_model {
-    int code;      /* ORC_TORIC: uint8[2][L][L], 16 classes; ORC_XZZX / ORC_ROTATED: uint8[L][L], 4 classes */
+    int code;      /* ORC_TORIC: uint8[2][L][L], 16 classes; ORC_XZZX / ORC_ROTATED: uint8[L][L], 4 classes;
+                      ORC_PLANAR: uint8[2][L][L] (layer 1 uses its first L-1 rows / columns), 4 classes */
     int L;
     int noise;     /* ORC_NOISE_DEPOLARIZING: src/mcmc.py; ORC_NOISE_BIASED: src/mcmc_biased.py */
     double eta;    /* bias, mcmc_biased.py:11 */
@@ -78,6 +79,11 @@ int  orc_surf_apply_stabilizer(int code, int L, const uint8_t *in, uint8_t *out,
 int  orc_surf_apply_logical(int code, int L, const uint8_t *in, uint8_t *out, int op, int xpos, int zpos);
 int  orc_surf_eq_class(int code, int L, const uint8_t *m);
 void orc_surf_syndrome(int code, int L, const uint8_t *in, uint8_t *defects /*[L+1][L+1]*/);
+/* number of generators, and generator g in the order the sweep / the one-word pick use (-> row, col, op) */
+int  orc_surf_ngen(int code, int L);
+void orc_surf_gen_rco(int code, int L, int g, int *row, int *col, int *op);
+/* Planar_code.syndrom, planar_model.py:134-153: vertex_defects uint8[L-1][L] then plaquette_defects uint8[L][L-1] */
+void orc_planar_syndrome(int L, const uint8_t *in, uint8_t *vertex, uint8_t *plaquette);
 
 /* ---- toric stencils (src/toric_model.py) -------------------------------- */
 int     orc_toric_apply_stabilizer(int L, const uint8_t *in, uint8_t *out, int row, int col, int op);

@@ -4,7 +4,9 @@
  * (src/rotated_surface_model.py) stencils.  Both live on an L x L qubit matrix
  * (uint8, C order) with (L-1)^2 four-qubit plaquettes and 2(L-1) two-qubit
  * boundary half-plaquettes; they differ in the Pauli each site receives, in the
- * logical operators and in the class function.
+ * logical operators and in the class function.  Also the planar (unrotated) surface code of src/planar_model.py:
+ * uint8[2][L][L] with layer 1 living on its first L-1 rows / columns, L(L-1) X-type and L(L-1) Z-type generators of
+ * three (boundary) or four sites -- the model Chain.update_chain_fast is hard-wired to.
  *
  * Parity status: PINNED by tests/test_oracle_golden.py against f1_surf.npz /
  * f2_surf.npz (captured from the reference).
@@ -19,6 +21,28 @@
  * xzzx_model.py:369-434, rotated_surface_model.py:357-381. */
 int orc_surf_generator(int code, int L, int row, int col, int op, int sites[4], int paulis[4])
 {
+    if (code == ORC_PLANAR) {
+        /* planar_model.py:297-326.  site = layer*L*L + r*L + c.  op 1 at (row in [0,L-1), col in [0,L)):
+         * (0,row,col), (0,row+1,col) and the layer-1 qubits (1,row,col), (1,row,col-1) that exist;
+         * op 3 at (row in [0,L), col in [0,L-1)): (0,row,col), (0,row,col+1) and (1,row,col), (1,row-1,col) */
+        const int LL = L * L;
+        int n = 0;
+        if (op == 1) {
+            sites[n++] = row * L + col;
+            sites[n++] = (row + 1) * L + col;
+            if (col == 0) sites[n++] = LL + row * L;
+            else if (col == L - 1) sites[n++] = LL + row * L + col - 1;
+            else { sites[n++] = LL + row * L + col; sites[n++] = LL + row * L + col - 1; }
+        } else {
+            sites[n++] = row * L + col;
+            sites[n++] = row * L + col + 1;
+            if (row == 0) sites[n++] = LL + col;
+            else if (row == L - 1) sites[n++] = LL + (row - 1) * L + col;
+            else { sites[n++] = LL + row * L + col; sites[n++] = LL + (row - 1) * L + col; }
+        }
+        for (int i = 0; i < n; ++i) paulis[i] = op;
+        return n;
+    }
     if (op == 1) {
         if (code == ORC_XZZX) {
             sites[0] = row * L + col;       paulis[0] = 1;
@@ -62,7 +86,7 @@ static inline int flip_site(uint8_t *q, int op)
 int orc_surf_apply_stabilizer(int code, int L, const uint8_t *in, uint8_t *out, int row, int col, int op)
 {
     int sites[4], paulis[4];
-    if (out != in) memcpy(out, in, (size_t)L * L);
+    if (out != in) memcpy(out, in, (size_t)orc_nq(code, L));
     const int n = orc_surf_generator(code, L, row, col, op, sites, paulis);
     int dE = 0;
     for (int i = 0; i < n; ++i) dE += flip_site(&out[sites[i]], paulis[i]);
@@ -104,9 +128,18 @@ void orc_surf_syndrome(int code, int L, const uint8_t *in, uint8_t *defects)
  * column X_pos iff op in {1,3}, Z on row Z_pos iff op in {2,3}. */
 int orc_surf_apply_logical(int code, int L, const uint8_t *in, uint8_t *out, int op, int xpos, int zpos)
 {
-    if (out != in) memcpy(out, in, (size_t)L * L);
+    if (out != in) memcpy(out, in, (size_t)orc_nq(code, L));
     if (op == 0) return 0;
     int dE = 0;
+    if (code == ORC_PLANAR) {
+        /* planar_model.py:235-268: X along row X_pos of layer 0 iff op in {1,3}, Z along column Z_pos iff op in {2,3} */
+        const int do_x = (op == 1 || op == 3), do_z = (op == 2 || op == 3);
+        for (int i = 0; i < L; ++i) {
+            if (do_x) dE += flip_site(&out[xpos * L + i], 1);
+            if (do_z) dE += flip_site(&out[i * L + zpos], 3);
+        }
+        return dE;
+    }
     if (code == ORC_XZZX) {
         const int do_x = (op == 1 || op == 2), do_z = (op == 3 || op == 2);
         if (do_x) for (int i = 0; i < L; ++i) dE += flip_site(&out[i * L + (L - 1 - i)], 1);
@@ -123,6 +156,13 @@ int orc_surf_apply_logical(int code, int L, const uint8_t *in, uint8_t *out, int
 int orc_surf_eq_class(int code, int L, const uint8_t *m)
 {
     int x = 0, z = 0;
+    if (code == ORC_PLANAR) {                               /* planar_model.py:379-390 */
+        for (int i = 0; i < L; ++i) {
+            x += (m[i * L] == 1) || (m[i * L] == 2);          /* first column of layer 0 */
+            z += (m[i] == 3) || (m[i] == 2);                  /* first row of layer 0 */
+        }
+        return (x % 2) + 2 * (z % 2);
+    }
     if (code == ORC_XZZX) {
         for (int i = 0; i < L; ++i) {
             x += m[i] == 2;                                   /* row 0 */
@@ -138,4 +178,38 @@ int orc_surf_eq_class(int code, int L, const uint8_t *m)
         z += (m[i * L] == 3) || (m[i * L] == 2);
     }
     return (x % 2) + 2 * (z % 2);
+}
+
+/* generators in table order: xzzx / rotated -- full plaquettes row-major, then half plaquette h/4 on side h%4;
+ * planar -- the L(L-1) X-type generators row-major over (row in [0,L-1), col in [0,L)), then the Z-type ones
+ * row-major over (row in [0,L), col in [0,L-1)) */
+int orc_surf_ngen(int code, int L) { return code == ORC_PLANAR ? 2 * L * (L - 1) : L * L - 1; }
+
+void orc_surf_gen_rco(int code, int L, int g, int *row, int *col, int *op)
+{
+    if (code == ORC_PLANAR) {
+        const int nx = L * (L - 1);
+        if (g < nx) { *op = 1; *row = g / L; *col = g % L; }
+        else { *op = 3; *row = (g - nx) / (L - 1); *col = (g - nx) % (L - 1); }
+        return;
+    }
+    const int nf = (L - 1) * (L - 1);
+    if (g < nf) { *op = 1; *row = g / (L - 1); *col = g % (L - 1); }
+    else { *op = 3; *row = (g - nf) / 4; *col = (g - nf) % 4; }
+}
+
+/* Planar_code.syndrom, planar_model.py:134-153 */
+void orc_planar_syndrome(int L, const uint8_t *in, uint8_t *vertex, uint8_t *plaquette)
+{
+    const int LL = L * L;
+#define YZ(l, r, c) ((in[(l) * LL + (r) * L + (c)] == 2) || (in[(l) * LL + (r) * L + (c)] == 3))
+#define XY(l, r, c) ((in[(l) * LL + (r) * L + (c)] == 1) || (in[(l) * LL + (r) * L + (c)] == 2))
+    for (int r = 0; r < L - 1; ++r)                                         /* vertex_defects [L-1][L] */
+        for (int c = 0; c < L; ++c)
+            vertex[r * L + c] = (uint8_t)((YZ(0, r + 1, c) ^ YZ(0, r, c)) ^ (YZ(1, r, c) ^ YZ(1, r, (c + L - 1) % L)));
+    for (int r = 0; r < L; ++r)                                             /* plaquette_defects [L][L-1] */
+        for (int c = 0; c < L - 1; ++c)
+            plaquette[r * (L - 1) + c] = (uint8_t)((XY(0, r, c + 1) ^ XY(0, r, c)) ^ (XY(1, r, c) ^ XY(1, (r + L - 1) % L, c)));
+#undef YZ
+#undef XY
 }

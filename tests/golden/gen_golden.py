@@ -19,6 +19,7 @@ Fixtures
   f4_config1.npz  BASELINE config-1 plumbing vector
   f1_surf.npz / f2_surf.npz   the same for the XZZX and rotated codes, incl. the biased chain
   f2_alpha.npz                Chain_alpha / Ladder_alpha / PTEQ_alpha trajectories (src/mcmc_alpha.py)
+  f_planar.npz                Planar_code stencil KATs and Chain (incl. update_chain_fast) / Ladder / PTEQ trajectories
 """
 import argparse
 import os
@@ -419,6 +420,108 @@ def gen_f2_alpha(xm, rm, ma, decb):
     print("f2_alpha.npz", cases)
 
 
+def rand_planar(rng, L, p):
+    m = np.zeros((2, L, L), dtype=np.uint8)
+    err = rng.random((2, L, L)) < p
+    m[err] = rng.integers(1, 4, size=int(err.sum()), dtype=np.uint8)
+    m[1, -1, :] = 0                      # planar_model.py:38-39
+    m[1, :, -1] = 0
+    return m
+
+
+def gen_planar(pm, mc, dec):
+    """Planar_code (src/planar_model.py): every stabilizer / logical, class, syndrome (exact KATs) and Chain
+    (update_chain and update_chain_fast, which is hard-wired to this stencil, mcmc.py:6,152-160), Ladder and PTEQ
+    trajectories on the injected stream."""
+    rng = np.random.default_rng(404)
+    out = {}
+    kats = []
+    for L in (3, 4, 7):
+        for rep in range(2):
+            m = rand_planar(rng, L, 0.25)
+            code = pm.Planar_code(L); code.qubit_matrix = m.copy()
+            t = f"L{L}_{rep}"
+            out[f"{t}_m"] = m
+            out[f"{t}_count"] = np.int64(code.count_errors())
+            out[f"{t}_class"] = np.int64(code.define_equivalence_class())
+            code.syndrom()
+            out[f"{t}_vertex"] = np.asarray(code.vertex_defects, dtype=np.uint8)
+            out[f"{t}_plaquette"] = np.asarray(code.plaquette_defects, dtype=np.uint8)
+            args, news, dEs = [], [], []
+            for r in range(L - 1):
+                for c in range(L):
+                    for (rr, cc, op) in ((r, c, 1), (c, r, 3)):     # op 1: (short, long); op 3: (long, short), planar_model.py:347-352
+                        new, dE = code.apply_stabilizer(rr, cc, op)
+                        args.append((rr, cc, op)); news.append(new.copy()); dEs.append(dE)
+            out[f"{t}_stab_arg"] = np.array(args, dtype=np.int64); out[f"{t}_stab_new"] = np.array(news, dtype=np.uint8)
+            out[f"{t}_stab_dE"] = np.array(dEs, dtype=np.int64)
+            args, news, dEs, cls = [], [], [], []
+            for op in range(4):
+                for xp in range(L):
+                    for zp in range(L):
+                        new, dE = code.apply_logical(op, xp, zp)
+                        args.append((op, xp, zp)); news.append(new.copy()); dEs.append(dE)
+                        c2 = pm.Planar_code(L); c2.qubit_matrix = new
+                        cls.append(c2.define_equivalence_class())
+            out[f"{t}_log_arg"] = np.array(args, dtype=np.int64); out[f"{t}_log_new"] = np.array(news, dtype=np.uint8)
+            out[f"{t}_log_dE"] = np.array(dEs, dtype=np.int64); out[f"{t}_log_class"] = np.array(cls, dtype=np.int64)
+            kats.append(t)
+    out["kats"] = np.array(kats)
+    cases = []
+    for i, (L, p, p_logical, iters, perr, fast) in enumerate([
+            (3, 0.5, 0.0, 60, 0.3, 0), (5, 0.15, 0.0, 400, 0.15, 0), (7, 0.12, 0.0, 400, 0.12, 1), (5, 0.75, 0.5, 300, 0.15, 0),
+            (7, 0.3, 0.5, 300, 0.15, 0), (4, 0.2, 0.0, 200, 0.2, 1)]):
+        m = rand_planar(rng, L, perr)
+        seed = 7000 + i
+        code = pm.Planar_code(L); code.qubit_matrix = m.copy()
+        ch = mc.Chain(p, code); ch.p_logical = p_logical
+        s = Stream(seed); install(s, pm, mc)
+        if fast:
+            for _ in range(iters // 5):
+                ch.update_chain_fast(5)                 # STDC's inner call, decoders.py:250
+        else:
+            ch.update_chain(iters)
+        restore(pm, mc)
+        tag = f"chain{i}"
+        out[f"{tag}_init"] = m; out[f"{tag}_final"] = ch.code.qubit_matrix.astype(np.uint8)
+        out[f"{tag}_par"] = np.array([L, p, p_logical, iters, seed, s.n, fast], dtype=np.float64)
+        cases.append(tag)
+    for i, (L, p, Nc, iters, nstep, perr) in enumerate([(3, 0.3, 3, 5, 50, 0.3), (5, 0.15, 5, 10, 50, 0.15), (7, 0.12, 8, 10, 25, 0.12)]):
+        m = rand_planar(rng, L, perr)
+        seed = 7100 + i
+        code = pm.Planar_code(L); code.qubit_matrix = m.copy()
+        s = Stream(seed); install(s, pm, mc)
+        ld = mc.Ladder(p, code, Nc, 0.5)
+        tops = []
+        for _ in range(nstep):
+            ld.step(iters); tops.append(ld.tops0)
+        restore(pm, mc)
+        tag = f"ladder{i}"
+        out[f"{tag}_init"] = m
+        out[f"{tag}_states"] = np.array([c.code.qubit_matrix for c in ld.chains], dtype=np.uint8)
+        out[f"{tag}_flags"] = np.array([c.flag for c in ld.chains], dtype=np.uint8)
+        out[f"{tag}_tops_hist"] = np.array(tops, dtype=np.int64)
+        out[f"{tag}_par"] = np.array([L, p, Nc, iters, nstep, seed, s.n], dtype=np.float64)
+        cases.append(tag)
+    for i, (L, p, Nc, iters, steps, tops_burn, conv, perr, SEQ, TOPS, eps) in enumerate([
+            (3, 0.17, 3, 10, 300, 2, None, 0.15, 2, 10, 0.1), (5, 0.12, 5, 10, 200, 0, None, 0.12, 2, 10, 0.1),
+            (3, 0.17, 3, 10, 6000, 1, "error_based", 0.15, 1, 4, 0.5)]):
+        m = rand_planar(rng, L, perr)
+        seed = 7200 + i
+        code = pm.Planar_code(L); code.qubit_matrix = m.copy()
+        s = Stream(seed); install(s, pm, mc)
+        pct = dec.PTEQ(code, p, Nc=Nc, SEQ=SEQ, TOPS=TOPS, eps=eps, steps=steps, iters=iters, tops_burn=tops_burn, conv_criteria=conv)
+        restore(pm, mc)
+        tag = f"pteq{i}"
+        out[f"{tag}_init"] = m
+        out[f"{tag}_percent"] = np.asarray(pct, dtype=np.uint8)
+        out[f"{tag}_par"] = np.array([L, p, Nc, iters, steps, tops_burn, 1 if conv else 0, seed, s.n, SEQ, TOPS, eps], dtype=np.float64)
+        cases.append(tag)
+    out["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(HERE, "f_planar.npz"), **out)
+    print("f_planar.npz", kats, cases)
+
+
 def _f3_worker(args):
     (L, p, Nc, iters, steps, burn, m, seed) = args
     tm, mc, dec = import_reference()
@@ -481,12 +584,15 @@ def main():
         print("reference not present; nothing to do")
         return
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="f1,f2,f3,f4,f1s,f2s,f2a")
+    ap.add_argument("--only", default="f1,f2,f3,f4,f1s,f2s,f2a,fp")
     only = set(ap.parse_args().only.split(","))
     tm, mc, dec = import_reference()
     if "f1" in only: gen_f1(tm)
     if "f2" in only: gen_f2(tm, mc, dec)
     if "f4" in only: gen_f4(tm, mc)
+    if "fp" in only:
+        import src.planar_model as pm
+        gen_planar(pm, mc, dec)
     if "f1s" in only or "f2s" in only or "f2a" in only:
         xm, rm, mb, decb = import_reference_surf()
         if "f2a" in only:
