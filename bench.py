@@ -116,7 +116,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--seed", type=int, default=20200915)
     ap.add_argument("--p-logical", type=float, default=0.5, help="top-chain logical rate (decoders.py:52 uses 0.5)")
-    ap.add_argument("--code", default="toric", choices=["toric", "xzzx", "rotated"], help="other codes: parity-test configs 4, 5")
+    ap.add_argument("--code", default="toric", choices=["toric", "xzzx", "rotated", "planar"], help="other codes: parity-test configs 4, 5")
     ap.add_argument("--eta", type=float, default=None, help="bias: selects the mcmc_biased chain (config 4)")
     ap.add_argument("--scan", default="random", choices=["random", "sweep"],
                     help="random = the reference's random-scan chain; sweep = systematic generator sweep (scan=1)")
@@ -142,11 +142,15 @@ def main():
 
     N, L, Nc = args.syndromes, args.L, args.Nc
     toric = args.code == "toric"
-    code_id = {"toric": L_.TORIC, "xzzx": L_.XZZX, "rotated": L_.ROTATED}[args.code]
-    nq, ncls = (2 * L * L, 16) if toric else (L * L, 4)
+    code_id = {"toric": L_.TORIC, "xzzx": L_.XZZX, "rotated": L_.ROTATED, "planar": L_.PLANAR}[args.code]
+    nq, ncls = (2 * L * L, 16) if toric else (2 * L * L if args.code == "planar" else L * L, 4)
     first = rank * N                                    # global syndrome index of this shard
     if toric:
         init_h = synth_batch(N, L, args.p, args.seed + rank)
+    elif args.code == "planar":       # Planar_code.generate_random_error(p/3, p/3, p/3) (generate_data.py:66-68, planar_model.py:18-40)
+        init_h = np.stack([synth_batch_plaquette(N, L, args.p / 3, args.p / 3, args.p / 3, args.seed + rank + 7919 * l) for l in range(2)], axis=1)
+        init_h[:, 1, -1, :] = 0
+        init_h[:, 1, :, -1] = 0
     elif args.eta is None:
         init_h = synth_batch_plaquette(N, L, args.p / 3, args.p / 3, args.p / 3, args.seed + rank)
     else:

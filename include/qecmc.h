@@ -16,7 +16,8 @@
  *   - return 0 on success, a negative qecmc_status on error with a message in
  *     qecmc_last_error() (thread-local); no C++ exception crosses the ABI;
  *   - Pauli encoding 0=I 1=X 2=Y 3=Z, composition = XOR (toric_model.py:277);
- *     toric state = uint8[2][L][L] C-order (toric_model.py:12), nq = 2*L*L;
+ *     toric state = uint8[2][L][L] C-order (toric_model.py:12), nq = 2*L*L; xzzx / rotated state = uint8[L][L];
+ *     planar state = uint8[2][L][L] with layer 1 on its first L-1 rows / columns (planar_model.py:14,38-39);
  *   - every compute entry point runs on the GPU (HIP, gfx950).  There is no
  *     CPU fallback: without a device the call fails with QECMC_ERR_NO_DEVICE.
  *   - `_dev` entry points take DEVICE pointers and a hipStream_t (as void*),
@@ -43,7 +44,7 @@ typedef enum qecmc_status {
     QECMC_ERR_UNSUPPORTED = -4  /* valid request this build has no kernel for */
 } qecmc_status;
 
-typedef enum qecmc_code { QECMC_TORIC = 0, QECMC_XZZX = 1, QECMC_ROTATED = 2 } qecmc_code;
+typedef enum qecmc_code { QECMC_TORIC = 0, QECMC_XZZX = 1, QECMC_ROTATED = 2, QECMC_PLANAR = 3 } qecmc_code;
 typedef enum qecmc_scan { QECMC_SCAN_RANDOM = 0, QECMC_SCAN_CHECKERBOARD = 1 } qecmc_scan;
 typedef enum qecmc_noise { QECMC_NOISE_DEPOLARIZING = 0, QECMC_NOISE_BIASED = 1, QECMC_NOISE_ALPHA = 2 } qecmc_noise;
 typedef enum qecmc_conv { QECMC_CONV_NONE = 0, QECMC_CONV_ERROR_BASED = 1 } qecmc_conv;
@@ -91,7 +92,8 @@ int         qecmc_device_count(void);      /* 0 when no GPU is visible */
  * Each runs the same __device__ stencil code the sampler kernels use. */
 
 /* Toric_code.apply_stabilizer -> _apply_stabilizer, toric_model.py:40-41,256-284 (xzzx_model.py:360-436,
- * rotated_surface_model.py:349-392: operator 1 = plaquette (row,col), 3 = half plaquette `row` on side `col`).
+ * rotated_surface_model.py:349-392: operator 1 = plaquette (row,col), 3 = half plaquette `row` on side `col`;
+ * planar_model.py:292-339: operator 1 at (row < L-1, col < L), operator 3 at (row < L, col < L-1)).
  * out[i] = in[i] with stabilizer (rows[i], cols[i], ops[i]) applied; dE[i] = error-count change. */
 int qecmc_apply_stabilizer(int code, int L, uint64_t N, const uint8_t *in, uint8_t *out,
                            const int32_t *rows, const int32_t *cols, const int32_t *ops, int32_t *dE);
@@ -106,7 +108,8 @@ int qecmc_eq_class(int code, int L, uint64_t N, const uint8_t *in, int32_t *cls)
 /* to_class, toric_model.py:55-56,354-377. */
 int qecmc_to_class(int code, int L, uint64_t N, const uint8_t *in, uint8_t *out, const int32_t *eq);
 /* Toric_code.syndrom, toric_model.py:58-101: defects_out uint8[N][2][L][L]; xzzx_code.syndrome /
- * RotSurCode.syndrome (xzzx_model.py:60-83): defects_out uint8[N][L+1][L+1] (plaquette_defects). */
+ * RotSurCode.syndrome (xzzx_model.py:60-83): defects_out uint8[N][L+1][L+1] (plaquette_defects); Planar_code.syndrom
+ * (planar_model.py:134-153): defects_out uint8[N][2 L (L-1)] = vertex_defects [L-1][L] then plaquette_defects [L][L-1]. */
 int qecmc_syndrome(int code, int L, uint64_t N, const uint8_t *in, uint8_t *defects_out);
 
 /* ---- chain / ladder on caller-owned state (host pointers) ----------------- */

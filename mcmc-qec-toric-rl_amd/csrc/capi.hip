@@ -59,15 +59,15 @@ struct DevBuf {
 
 int check_code_L(int code, int L)
 {
-    if (code != QECMC_TORIC && code != QECMC_XZZX && code != QECMC_ROTATED)
-        return fail(QECMC_ERR_INVALID, "code %d unknown (0 toric, 1 xzzx, 2 rotated)", code);
+    if (code != QECMC_TORIC && code != QECMC_XZZX && code != QECMC_ROTATED && code != QECMC_PLANAR)
+        return fail(QECMC_ERR_INVALID, "code %d unknown (0 toric, 1 xzzx, 2 rotated, 3 planar)", code);
     if (L < 2 || L > 64) return fail(QECMC_ERR_INVALID, "L=%d out of range [2,64]", L);
-    if (code != QECMC_TORIC && (L < 3 || L % 2 == 0))
+    if ((code == QECMC_XZZX || code == QECMC_ROTATED) && (L < 3 || L % 2 == 0))
         return fail(QECMC_ERR_INVALID, "L=%d: the xzzx / rotated models need odd L >= 3 (their half-plaquette indexing, xzzx_model.py:444)", L);
     return 0;
 }
 
-inline size_t code_nq(int code, int L) { return code == QECMC_TORIC ? (size_t)2 * L * L : (size_t)L * L; }
+inline size_t code_nq(int code, int L) { return (size_t)code_nq_of(code, L); }
 
 // px^n, py^n, pz^n, pI^n for n = 0..nq (mcmc_biased.py:25-31): the same libm pow() the reference calls
 std::vector<double> bias_tables(double p, double eta, size_t nq)
@@ -156,6 +156,7 @@ std::vector<uint32_t> surf_logical_masks(int code, int L, int W)
     for (int pos = 0; pos < L; ++pos)
         for (int i = 0; i < L; ++i) {
             if (code == QECMC_XZZX) { set(0, pos, i * L + (L - 1 - i), 1); set(1, pos, i * L + i, 3); }
+            else if (code == QECMC_PLANAR) { set(0, pos, pos * L + i, 1); set(1, pos, i * L + pos, 3); }   // row X_pos / column Z_pos of layer 0
             else { set(0, pos, i * L + pos, 1); set(1, pos, pos * L + i, 3); }
         }
     return m;
@@ -186,20 +187,17 @@ std::vector<uint32_t> toric_generator_table(int L)
 // generator table of the plaquette codes: entry g = 4 x u16 (site << 2 | pauli), two u32 per generator
 std::vector<uint32_t> surf_generator_table(int code, int L)
 {
-    const int nfull = (L - 1) * (L - 1), nhalf = 2 * (L - 1);
-    std::vector<uint32_t> t((size_t)2 * (nfull + nhalf), 0u);
-    auto put = [&](int g, int row, int col, int op) {
-        int sites[4], paulis[4];
+    const int n_gen = surf_ngen(code, L);
+    std::vector<uint32_t> t((size_t)2 * n_gen, 0u);
+    for (int g = 0; g < n_gen; ++g) {
+        int row, col, op, sites[4], paulis[4];
+        surf_gen_rco(code, L, g, row, col, op);
         const int n = surf_generator(code, L, row, col, op, sites, paulis);
         uint32_t e[4] = {0, 0, 0, 0};
         for (int i = 0; i < n; ++i) e[i] = ((uint32_t)sites[i] << 2) | (uint32_t)paulis[i];
         t[2 * g] = e[0] | (e[1] << 16);
         t[2 * g + 1] = e[2] | (e[3] << 16);
-    };
-    for (int r = 0; r < L - 1; ++r)
-        for (int c = 0; c < L - 1; ++c) put(r * (L - 1) + c, r, c, 1);
-    for (int i = 0; i < (L - 1) / 2; ++i)
-        for (int side = 0; side < 4; ++side) put(nfull + i * 4 + side, i, side, 3);
+    }
     return t;
 }
 
@@ -225,12 +223,12 @@ int validate_params(const qecmc_params *p)
     if (p->noise == QECMC_NOISE_ALPHA) {
         if (!(p->alpha > 0.0)) return fail(QECMC_ERR_INVALID, "alpha=%g must be positive", p->alpha);
         if (!(p->p > 0.0) || !(p->p <= 1.0)) return fail(QECMC_ERR_INVALID, "pz_tilde=%g must be in (0, 1]", p->p);
-        if (p->code == QECMC_TORIC) return fail(QECMC_ERR_UNSUPPORTED, "alpha noise is built for the xzzx and rotated codes (the reference sizes its weights for L^2 qubits, mcmc_alpha.py:27)");
+        if (p->code == QECMC_TORIC || p->code == QECMC_PLANAR) return fail(QECMC_ERR_UNSUPPORTED, "alpha noise is built for the xzzx and rotated codes (the reference sizes its weights for L^2 qubits, mcmc_alpha.py:27)");
     } else
     if (p->noise == QECMC_NOISE_BIASED) {
         if (!(p->eta > 0.0)) return fail(QECMC_ERR_INVALID, "eta=%g must be positive", p->eta);
         if (!(p->p > 0.0) || !(p->p < (p->eta + 1) / (2 * p->eta + 1))) return fail(QECMC_ERR_INVALID, "p=%g must be in (0, (eta+1)/(2 eta+1))", p->p);
-        if (p->code == QECMC_TORIC) return fail(QECMC_ERR_UNSUPPORTED, "biased noise is built for the xzzx and rotated codes (BASELINE config 4)");
+        if (p->code == QECMC_TORIC || p->code == QECMC_PLANAR) return fail(QECMC_ERR_UNSUPPORTED, "biased noise is built for the xzzx and rotated codes (BASELINE config 4)");
     } else if (!(p->p > 0.0) || !(p->p <= 0.75)) return fail(QECMC_ERR_INVALID, "p=%g must be in (0, 0.75]", p->p);
     if (!(p->p_logical >= 0.0) || !(p->p_logical <= 1.0)) return fail(QECMC_ERR_INVALID, "p_logical=%g must be in [0,1]", p->p_logical);
     if (p->scan != QECMC_SCAN_RANDOM && p->scan != QECMC_SCAN_CHECKERBOARD) return fail(QECMC_ERR_INVALID, "scan mode %d unknown", p->scan);
@@ -257,7 +255,7 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
     a.tops_burn = (uint32_t)p->tops_burn;
     a.conv_mode = p->conv_mode; a.TOPS = (uint32_t)p->TOPS; a.SEQ = (uint32_t)p->SEQ; a.eps = p->eps;
     a.thr_logical = p->p_logical > 0 ? thr64(p->p_logical) : 0;
-    const uint32_t n_gen = p->code == QECMC_TORIC ? 2u * L * L : (uint32_t)((L - 1) * (L - 1) + 2 * (L - 1));
+    const uint32_t n_gen = p->code == QECMC_TORIC ? 2u * L * L : (uint32_t)surf_ngen(p->code, L);
     if (n_gen > kMaxGenLds)   // every kernel path stages the generator table in LDS
         return fail(QECMC_ERR_UNSUPPORTED, "L=%d: %u generators exceed the LDS table of %u (needed by scan=1 and by the xzzx / rotated codes)", L, n_gen, kMaxGenLds);
     pl->lds_bytes = ladder_lds_bytes(L, Nc, W, ncls, ladder_gen_dwords(p->code, p->noise, p->scan, n_gen, Nc));
@@ -352,8 +350,8 @@ int qecmc_apply_stabilizer(int code, int L, uint64_t N, const uint8_t *in, uint8
     if (!in || !out || !rows || !cols || !ops || !dE) return fail(QECMC_ERR_INVALID, "NULL buffer");
     for (uint64_t i = 0; i < N; ++i) {
         if (ops[i] != 1 && ops[i] != 3) return fail(QECMC_ERR_INVALID, "stabilizer %llu: operator %d is not 1 or 3", (unsigned long long)i, ops[i]);
-        const int rmax = code == QECMC_TORIC ? L : (ops[i] == 1 ? L - 1 : (L - 1) / 2);
-        const int cmax = code == QECMC_TORIC ? L : (ops[i] == 1 ? L - 1 : 4);
+        const int rmax = code == QECMC_TORIC ? L : code == QECMC_PLANAR ? (ops[i] == 1 ? L - 1 : L) : (ops[i] == 1 ? L - 1 : (L - 1) / 2);
+        const int cmax = code == QECMC_TORIC ? L : code == QECMC_PLANAR ? (ops[i] == 1 ? L : L - 1) : (ops[i] == 1 ? L - 1 : 4);
         if (rows[i] < 0 || rows[i] >= rmax || cols[i] < 0 || cols[i] >= cmax) return fail(QECMC_ERR_INVALID, "stabilizer %llu: (row,col)=(%d,%d) outside [0,%d)x[0,%d)", (unsigned long long)i, rows[i], cols[i], rmax, cmax);
     }
     DevBuf din, dout, dr, dc, dop, dd;
@@ -437,7 +435,7 @@ int qecmc_syndrome(int code, int L, uint64_t N, const uint8_t *in, uint8_t *defe
 {
     PRIM_PROLOGUE();
     if (!in || !defects_out) return fail(QECMC_ERR_INVALID, "NULL buffer");
-    const size_t nd = code == QECMC_TORIC ? nq : (size_t)(L + 1) * (L + 1);
+    const size_t nd = code == QECMC_TORIC ? nq : code == QECMC_PLANAR ? (size_t)2 * L * (L - 1) : (size_t)(L + 1) * (L + 1);
     DevBuf din, dout;
     HIP_TRY(din.alloc(N * nq)); HIP_TRY(dout.alloc(N * nd));
     HIP_TRY(hipMemcpy(din.p, in, N * nq, hipMemcpyHostToDevice));
@@ -455,7 +453,7 @@ static int chain_update_impl(int code, int L, uint64_t N, uint8_t *states_inout,
     if (!states_inout) return fail(QECMC_ERR_INVALID, "NULL buffer");
     if (noise == QECMC_NOISE_ALPHA) {      // `eta` carries alpha here
         if (!(p > 0.0) || !(p <= 1.0) || !(eta > 0.0)) return fail(QECMC_ERR_INVALID, "alpha noise needs pz_tilde in (0,1] and alpha > 0 (pz_tilde=%g alpha=%g)", p, eta);
-        if (code == QECMC_TORIC) return fail(QECMC_ERR_UNSUPPORTED, "alpha noise is built for the xzzx and rotated codes");
+        if (code == QECMC_TORIC || code == QECMC_PLANAR) return fail(QECMC_ERR_UNSUPPORTED, "alpha noise is built for the xzzx and rotated codes");
     } else
     if (noise) {
         if (!(p > 0.0) || !(p < 1.0) || !(eta > 0.0)) return fail(QECMC_ERR_INVALID, "biased noise needs p in (0,1) and eta > 0 (p=%g eta=%g)", p, eta);

@@ -133,6 +133,9 @@ __device__ __forceinline__ uint32_t surf_class_packed(int code, const uint32_t *
         if (code == kCodeXzzx) {            // row 0 counts Y, X at even i, Z at odd i; column 0 the other way round
             x ^= (i & 1) ? za : xa;
             z ^= (i & 1) ? xb : zb;
+        } else if (code == kCodePlanar) {   // X/Y parity of layer 0's first column, Z/Y parity of its first row (planar_model.py:379-390)
+            x ^= xb;
+            z ^= za;
         } else {
             x ^= xa;
             z ^= zb;
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                     } else {
                         // one block per two proposals: words 2(k&1) (generator, uniform over the L^2 - 1 of them) and 2(k&1)+1 (accept)
                         const uint64_t k = kbase + j;
-                        if ((k >> 1) != kb_cur) { kb_cur = k >> 1; blk = philox_block(kb_cur, 0, syn, slot_u, a.seed_lo, a.seed_hi); }
+                        if ((k >> 1) != kb_cur) { kb_cur = k >> 1; blk = philox_block(kb_cur, 1, syn, slot_u, a.seed_lo, a.seed_hi); }
                         g = scale_u32((k & 1) ? blk.z : blk.x, a.n_gen);
                         x.w = (k & 1) ? blk.w : blk.y;
                     }
@@ -518,8 +521,8 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 uint32_t gs = SCAN ? (uint32_t)(kbase % a.n_gen) : 0u;
                 for (uint32_t j = 0; j < iters; ++j, gs = gs + 1 == a.n_gen ? 0u : gs + 1) {
                     const uint64_t k = kbase + j;
-                    // top: block (k, 0) = select, generator / logical fields; non-top: words 2(k&1), 2(k&1)+1 of block (k>>1, 0)
-                    u32x4 x = philox_block(top ? k : k >> 1, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                    // top: block (k, 0) = select, generator / logical fields; non-top: words 2(k&1), 2(k&1)+1 of block (k>>1, 1)
+                    u32x4 x = philox_block(top ? k : k >> 1, top ? 0u : 1u, syn, slot_u, a.seed_lo, a.seed_hi);
                     if (!top) {
                         if (k & 1) { x.x = x.z; x.y = x.w; }
                         x.w = x.y;                                                  // acceptance uniform
@@ -679,24 +682,24 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 }
                 j = iters;
             }
-            // proposal k uses words 2(k&1), 2(k&1)+1 of block (k>>1, 0).  The uniforms do not depend on the state: draw two
+            // proposal k uses words 2(k&1), 2(k&1)+1 of block (k>>1, 1).  The uniforms do not depend on the state: draw two
             // blocks together so their serial 10-round chains overlap, then apply the four proposals in order
             if (!SCAN && j < iters && (kbase & 1)) {
-                const u32x4 xa = philox_block(kbase >> 1, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                const u32x4 xa = philox_block(kbase >> 1, 1, syn, slot_u, a.seed_lo, a.seed_hi);
                 propose(xa.z, xa.w);
                 j = 1;
             }
             for (; j + 3 < iters; j += 4) {
                 const uint64_t kb = (kbase + j) >> 1;
-                const u32x4 xa = philox_block(kb, 0, syn, slot_u, a.seed_lo, a.seed_hi);
-                const u32x4 xb = philox_block(kb + 1, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                const u32x4 xa = philox_block(kb, 1, syn, slot_u, a.seed_lo, a.seed_hi);
+                const u32x4 xb = philox_block(kb + 1, 1, syn, slot_u, a.seed_lo, a.seed_hi);
                 propose(xa.x, xa.y);
                 propose(xa.z, xa.w);
                 propose(xb.x, xb.y);
                 propose(xb.z, xb.w);
             }
             for (; j < iters; j += 2) {
-                const u32x4 xa = philox_block((kbase + j) >> 1, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                const u32x4 xa = philox_block((kbase + j) >> 1, 1, syn, slot_u, a.seed_lo, a.seed_hi);
                 propose(xa.x, xa.y);
                 if (j + 1 < iters) propose(xa.z, xa.w);
             }
@@ -1042,7 +1045,7 @@ hipError_t launch_ladder_rs_toric(const LadderArgs &a, hipStream_t stream)
     // size: +1.6 % at 65 536 syndromes, +5 % at 262 144.)
     const bool conv = a.conv_mode != 0;
     const void *fn;
-    constexpr int T = kCodeToric, X = kCodeXzzx, R = kCodeRotated;
+    constexpr int T = kCodeToric, X = kCodeXzzx, R = kCodeRotated, P = kCodePlanar;
 #define QECMC_K2(maxt, minw, g, code, biased, gentop) \
     (a.scan ? (conv ? (const void *)ladder_rs_toric_kernel<maxt, minw, true, g, code, biased, true, gentop> : (const void *)ladder_rs_toric_kernel<maxt, minw, false, g, code, biased, true, gentop>) \
             : (conv ? (const void *)ladder_rs_toric_kernel<maxt, minw, true, g, code, biased, false, gentop> : (const void *)ladder_rs_toric_kernel<maxt, minw, false, g, code, biased, false, gentop>))
@@ -1059,8 +1062,11 @@ hipError_t launch_ladder_rs_toric(const LadderArgs &a, hipStream_t stream)
             else fn = gsplit ? QECMC_K2(1024, 4, true, T, false, false) : QECMC_K2(1024, 4, false, T, false, false);
         }
     } else {
-        if (!a.noise && (a.code == X || a.code == R)) {
-            if (a.code == X) {
+        if (!a.noise && (a.code == X || a.code == R || a.code == P)) {
+            if (a.code == P) {
+                if (block <= 512) fn = QECMC_K(512, 8, false, P, false);
+                else fn = QECMC_K(1024, 4, false, P, false);
+            } else if (a.code == X) {
                 if (block <= 512) fn = QECMC_K(512, 8, false, X, false);
                 else fn = QECMC_K(1024, 4, false, X, false);
             } else {

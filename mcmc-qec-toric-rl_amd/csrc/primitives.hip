@@ -18,7 +18,7 @@ __device__ __forceinline__ void copy_state(uint8_t *dst, const uint8_t *src, int
 }
 }  // namespace
 
-__device__ __forceinline__ int code_nq(int code, int L) { return code == kCodeToric ? 2 * L * L : L * L; }
+__device__ __forceinline__ int code_nq(int code, int L) { return code_nq_of(code, L); }
 
 __global__ void k_apply_stabilizer(int code, int L, uint64_t N, const uint8_t *in, uint8_t *out, const int32_t *rows,
                                    const int32_t *cols, const int32_t *ops, int32_t *dE)
@@ -71,16 +71,15 @@ __global__ void k_syndrome(int code, int L, uint64_t N, const uint8_t *in, uint8
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     if (code == kCodeToric) toric_syndrome_b(L, in + i * (uint64_t)(2 * L * L), defects + i * (uint64_t)(2 * L * L));
+    else if (code == kCodePlanar) planar_syndrome_b(L, in + i * (uint64_t)(2 * L * L), defects + i * (uint64_t)(2 * L * (L - 1)));
     else surf_syndrome_b(code, L, in + i * (uint64_t)(L * L), defects + i * (uint64_t)((L + 1) * (L + 1)));
 }
 
-// one word picks one of the L^2 - 1 generators of the xzzx / rotated codes (xzzx_model.py:439-452 draws five uniforms for
-// the same uniform choice): full plaquettes row-major first, then half plaquette h/4 on side h%4
-__device__ __forceinline__ void surf_pick(int L, uint32_t w, int &row, int &col, int &op)
+// one word picks one of the generators of a plaquette code (xzzx_model.py:439-452 draws five uniforms, planar_model.py:343-352
+// three, for the same uniform choice), in table order (surf_gen_rco)
+__device__ __forceinline__ void surf_pick(int code, int L, uint32_t w, int &row, int &col, int &op)
 {
-    const uint32_t g = scale_u32(w, (uint32_t)(L * L - 1)), nfull = (uint32_t)((L - 1) * (L - 1));
-    if (g < nfull) { row = (int)(g / (uint32_t)(L - 1)); col = (int)(g % (uint32_t)(L - 1)); op = 1; }
-    else { row = (int)((g - nfull) >> 2); col = (int)((g - nfull) & 3u); op = 3; }
+    surf_gen_rco(code, L, (int)scale_u32(w, (uint32_t)surf_ngen(code, L)), row, col, op);
 }
 
 // p_x^nx p_y^ny p_z^nz p_I^nI from the host-built power tables (mcmc_biased.py:31,43): IEEE products in the
@@ -108,9 +107,9 @@ __global__ void k_chain_update(const ChainArgs a)
     bool any_acc = false;
     for (uint64_t j = 0; j < a.iters; ++j) {
         const uint64_t k = a.k0 + j;
-        // non-top proposals share a block: words 2(k&1) (generator) and 2(k&1)+1 (acceptance) of block (k>>1, 0)
+        // non-top proposals share a block: words 2(k&1) (generator) and 2(k&1)+1 (acceptance) of block (k>>1, 1)
         const bool paired = !top;
-        u32x4 x = philox_block(paired ? k >> 1 : k, 0, syn, a.slot, a.seed_lo, a.seed_hi);
+        u32x4 x = philox_block(paired ? k >> 1 : k, paired ? 1u : 0u, syn, a.slot, a.seed_lo, a.seed_hi);
         if (paired) {
             if (k & 1) { x.x = x.z; x.y = x.w; }
             x.w = x.y;                                                              // acceptance uniform
@@ -138,7 +137,7 @@ __global__ void k_chain_update(const ChainArgs a)
             row = rc / L; col = rc % L; op = g < (uint32_t)(L * L) ? 1 : 3;
             dE = toric_apply_stabilizer_b(L, m, row, col, op);
         } else {
-            surf_pick(L, top ? x.y : x.x, row, col, op);
+            surf_pick(code, L, top ? x.y : x.x, row, col, op);
             dE = surf_apply_stabilizer_b(code, L, m, row, col, op);
         }
         // ---- accept?

@@ -92,6 +92,7 @@ __device__ inline void toric_syndrome_b(int L, const uint8_t *m, uint8_t *d)
         }
 }
 
+
 }  // namespace qecmc
 
 // ---------------------------------------------------------------------------------------------
@@ -100,12 +101,52 @@ __device__ inline void toric_syndrome_b(int L, const uint8_t *m, uint8_t *d)
 // ---------------------------------------------------------------------------------------------
 namespace qecmc {
 
-constexpr int kCodeToric = 0, kCodeXzzx = 1, kCodeRotated = 2;
+constexpr int kCodeToric = 0, kCodeXzzx = 1, kCodeRotated = 2, kCodePlanar = 3;
+
+// qubits of a state, stabilizer generators of a code
+__host__ __device__ inline int code_nq_of(int code, int L) { return (code == kCodeToric || code == kCodePlanar) ? 2 * L * L : L * L; }
+__host__ __device__ inline int surf_ngen(int code, int L) { return code == kCodePlanar ? 2 * L * (L - 1) : L * L - 1; }
+
+// generator g in table order -> (row, col, operator): xzzx / rotated -- full plaquettes row-major, then half plaquette h/4 on
+// side h%4; planar -- the L(L-1) X-type generators over (row in [0,L-1), col in [0,L)), then the Z-type ones over
+// (row in [0,L), col in [0,L-1)) (planar_model.py:343-352)
+__host__ __device__ inline void surf_gen_rco(int code, int L, int g, int &row, int &col, int &op)
+{
+    if (code == kCodePlanar) {
+        const int nx = L * (L - 1);
+        if (g < nx) { op = 1; row = g / L; col = g % L; }
+        else { op = 3; row = (g - nx) / (L - 1); col = (g - nx) % (L - 1); }
+        return;
+    }
+    const int nf = (L - 1) * (L - 1);
+    if (g < nf) { op = 1; row = g / (L - 1); col = g % (L - 1); }
+    else { op = 3; row = (g - nf) >> 2; col = (g - nf) & 3; }
+}
 
 // generator (row, col, operator) -> up to 4 (flat site, Pauli) pairs; operator 1 = full plaquette,
 // 3 = half plaquette `row` on side `col` (xzzx_model.py:369-434, rotated_surface_model.py:357-381)
 __host__ __device__ inline int surf_generator(int code, int L, int row, int col, int op, int sites[4], int paulis[4])
 {
+    if (code == kCodePlanar) {
+        // planar_model.py:297-326: site = layer*L*L + r*L + c; boundary generators have three sites
+        const int LL = L * L;
+        int n = 0;
+        if (op == 1) {
+            sites[n++] = row * L + col;
+            sites[n++] = (row + 1) * L + col;
+            if (col == 0) sites[n++] = LL + row * L;
+            else if (col == L - 1) sites[n++] = LL + row * L + col - 1;
+            else { sites[n++] = LL + row * L + col; sites[n++] = LL + row * L + col - 1; }
+        } else {
+            sites[n++] = row * L + col;
+            sites[n++] = row * L + col + 1;
+            if (row == 0) sites[n++] = LL + col;
+            else if (row == L - 1) sites[n++] = LL + (row - 1) * L + col;
+            else { sites[n++] = LL + row * L + col; sites[n++] = LL + (row - 1) * L + col; }
+        }
+        for (int i = 0; i < n; ++i) paulis[i] = op;
+        return n;
+    }
     if (op == 1) {
         if (code == kCodeXzzx) {
             sites[0] = row * L + col;           paulis[0] = 1;
@@ -149,6 +190,13 @@ __device__ inline int surf_apply_logical_b(int code, int L, uint8_t *m, int op, 
 {
     if (op == 0) return 0;
     int dE = 0;
+    if (code == kCodePlanar) {      // planar_model.py:235-268: X along row X_pos of layer 0 iff op in {1,3}, Z along column Z_pos iff op in {2,3}
+        for (int i = 0; i < L; ++i) {
+            if (op == 1 || op == 3) dE += flip_b(&m[xpos * L + i], 1);
+            if (op == 2 || op == 3) dE += flip_b(&m[i * L + zpos], 3);
+        }
+        return dE;
+    }
     if (code == kCodeXzzx) {
         if (op == 1 || op == 2) for (int i = 0; i < L; ++i) dE += flip_b(&m[i * L + (L - 1 - i)], 1);
         if (op == 3 || op == 2) for (int i = 0; i < L; ++i) dE += flip_b(&m[i * L + i], 3);
@@ -163,6 +211,13 @@ __device__ inline int surf_apply_logical_b(int code, int L, uint8_t *m, int op, 
 __device__ inline int surf_eq_class_b(int code, int L, const uint8_t *m)
 {
     int x = 0, z = 0;
+    if (code == kCodePlanar) {      // planar_model.py:379-390: X/Y parity of layer 0's first column, Z/Y parity of its first row
+        for (int i = 0; i < L; ++i) {
+            x ^= (m[i * L] == 1) | (m[i * L] == 2);
+            z ^= (m[i] == 3) | (m[i] == 2);
+        }
+        return x + 2 * z;
+    }
     if (code == kCodeXzzx) {
         for (int i = 0; i < L; ++i) {
             const int a = m[i], b = m[i * L];
@@ -197,6 +252,22 @@ __device__ inline void surf_syndrome_b(int code, int L, const uint8_t *m, uint8_
         d[L * S + 2 * i + 1] = defect(i, 2, 3);
         d[(2 * i + 1) * S] = defect(i, 3, 3);
     }
+}
+
+
+// Planar_code.syndrom, planar_model.py:134-153: d = vertex_defects uint8[L-1][L] followed by plaquette_defects uint8[L][L-1]
+__device__ inline void planar_syndrome_b(int L, const uint8_t *m, uint8_t *d)
+{
+    const int LL = L * L;
+    auto yz = [&](int l, int r, int c) { const uint8_t q = m[l * LL + r * L + c]; return (int)(q == 2 || q == 3); };
+    auto xy = [&](int l, int r, int c) { const uint8_t q = m[l * LL + r * L + c]; return (int)(q == 1 || q == 2); };
+    for (int r = 0; r < L - 1; ++r)
+        for (int c = 0; c < L; ++c)
+            d[r * L + c] = (uint8_t)(yz(0, r + 1, c) ^ yz(0, r, c) ^ yz(1, r, c) ^ yz(1, r, (c + L - 1) % L));
+    uint8_t *q = d + (L - 1) * L;
+    for (int r = 0; r < L; ++r)
+        for (int c = 0; c < L - 1; ++c)
+            q[r * (L - 1) + c] = (uint8_t)(xy(0, r, c + 1) ^ xy(0, r, c) ^ xy(1, r, c) ^ xy(1, (r + L - 1) % L, c));
 }
 
 }  // namespace qecmc

@@ -1,15 +1,16 @@
 """qecmc -- MI355X-native MCMC equivalence-class sampler (host-side mirror of the
 reference's Toric_code / Chain / Ladder / PTEQ API over the libqecmc C-ABI)."""
 from ._lib import QecmcError, device_count, lib
-from ._lib import TORIC, XZZX, ROTATED
+from ._lib import TORIC, XZZX, ROTATED, PLANAR
 from .toric_model import Toric_code
 from .xzzx_model import xzzx_code
 from .rotated_surface_model import RotSurCode
+from .planar_model import Planar_code
 from .mcmc import Chain, Ladder
 from .mcmc_biased import Chain_biased, Ladder_biased
 from .decoders import PTEQ, pteq_batch, percent_from_counts
 from .mcmc_alpha import Chain_alpha, Ladder_alpha
 from .decoders_biasednoise import PTEQ_biased, PTEQ_alpha
 
-__all__ = ["QecmcError", "device_count", "lib", "TORIC", "XZZX", "ROTATED", "Toric_code", "xzzx_code", "RotSurCode",
+__all__ = ["QecmcError", "device_count", "lib", "TORIC", "XZZX", "ROTATED", "PLANAR", "Toric_code", "xzzx_code", "RotSurCode", "Planar_code",
            "Chain", "Ladder", "Chain_biased", "Ladder_biased", "Chain_alpha", "Ladder_alpha", "PTEQ", "PTEQ_biased", "PTEQ_alpha", "pteq_batch", "percent_from_counts"]

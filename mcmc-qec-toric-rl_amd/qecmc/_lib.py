@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("QECMC_LIBRARY") or os.path.join(_HERE, "libqecmc.so")   # override: another build of the same ABI
 
-TORIC, XZZX, ROTATED = 0, 1, 2
+TORIC, XZZX, ROTATED, PLANAR = 0, 1, 2, 3
 SCAN_RANDOM, SCAN_CHECKERBOARD = 0, 1
 NOISE_DEPOLARIZING, NOISE_BIASED, NOISE_ALPHA = 0, 1, 2
 CONV_NONE, CONV_ERROR_BASED = 0, 1

@@ -19,7 +19,7 @@ def pteq_batch(init, p, Nc=None, steps=1000, iters=10, tops_burn=2, p_logical=0.
                code=L_.TORIC, eta=None, scan="random", alpha=None):
     """decoders.PTEQ (decoders.py:25-89) on N syndromes at once.
 
-    init: uint8[N, 2, L, L] (toric) or uint8[N, L, L] (code=XZZX / ROTATED) seed configurations, one per
+    init: uint8[N, 2, L, L] (toric, code=PLANAR) or uint8[N, L, L] (code=XZZX / ROTATED) seed configurations, one per
     syndrome; eta selects the biased chain of src/mcmc_biased.py (PTEQ_biased), alpha the "alpha" noise ladder of
     src/mcmc_alpha.py (PTEQ_alpha; `p` is then pz_tilde); scan="random" is the reference's
     chain, scan="sweep" the systematic generator sweep (same stationary law, faster).  conv_criteria None runs exactly
@@ -29,7 +29,7 @@ def pteq_batch(init, p, Nc=None, steps=1000, iters=10, tops_burn=2, p_logical=0.
     """
     if conv_criteria not in (None, 'error_based'):
         raise ValueError(f"conv_criteria={conv_criteria!r}: only None and 'error_based' exist for PTEQ")
-    a, _ = L_.as_states(init, 3 if code == L_.TORIC else 2)
+    a, _ = L_.as_states(init, 3 if code in (L_.TORIC, L_.PLANAR) else 2)
     N, size = a.shape[0], a.shape[-1]
     Nc = Nc or size
     ncls = 16 if code == L_.TORIC else 4

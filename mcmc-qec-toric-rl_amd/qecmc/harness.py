@@ -12,11 +12,13 @@ import numpy as np
 from . import _lib as L_
 from .decoders import pteq_batch
 
-_CODES = {"toric": L_.TORIC, "xzzx": L_.XZZX, "rotated": L_.ROTATED}
+_CODES = {"toric": L_.TORIC, "xzzx": L_.XZZX, "rotated": L_.ROTATED, "planar": L_.PLANAR}
 
 
 def _class_of(code, m):
-    from . import _surf, toric_model
+    from . import _surf, planar_model, toric_model
+    if code == L_.PLANAR:
+        return planar_model.eq_class(m)
     return toric_model.eq_class(m) if code == L_.TORIC else _surf.eq_class(code, m)
 
 
@@ -52,11 +54,15 @@ def draw_errors(code, size, n, p_error, rng, eta=None, rates=None):
     else:
         pz, px = p_error * eta / (eta + 1), p_error / (2 * (eta + 1))
         py = px
-    r = rng.random((n, size, size))
-    m = np.zeros((n, size, size), dtype=np.uint8)
+    shape = (n, 2, size, size) if code == L_.PLANAR else (n, size, size)
+    r = rng.random(shape)
+    m = np.zeros(shape, dtype=np.uint8)
     m[r < pz] = 3
     m[(r > pz) & (r < pz + px)] = 1
     m[(r > pz + px) & (r < pz + px + py)] = 2
+    if code == L_.PLANAR:                 # layer 1 lives on its first L-1 rows / columns (planar_model.py:38-39)
+        m[:, 1, -1, :] = 0
+        m[:, 1, :, -1] = 0
     return m
 
 
@@ -76,6 +82,9 @@ def hide_class(code, m, rng):
     ops = rng.integers(0, 4, size=n)
     xpos = np.where(np.isin(ops, (1, 2)), rng.integers(0, size, size=n), 0)
     zpos = np.where(np.isin(ops, (3, 2)), rng.integers(0, size, size=n), 0)
+    if code == L_.PLANAR:
+        from . import planar_model
+        return planar_model.apply_logical(m, ops, xpos, zpos)[0]
     m, _ = _surf.apply_logical(code, m, ops, xpos, zpos)
     return m
 

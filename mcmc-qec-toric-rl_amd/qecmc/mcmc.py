@@ -22,7 +22,7 @@ def _fresh_seed():
 
 def _code_id(code):
     name = type(code).__name__
-    ids = {"Toric_code": L_.TORIC, "xzzx_code": L_.XZZX, "RotSurCode": L_.ROTATED}
+    ids = {"Toric_code": L_.TORIC, "xzzx_code": L_.XZZX, "RotSurCode": L_.ROTATED, "Planar_code": L_.PLANAR}
     if name not in ids:
         raise NotImplementedError(f"no GPU kernels for code model {name} in this build")
     return ids[name]
@@ -58,9 +58,14 @@ class Chain:
         self.code.qubit_matrix = m[0]
 
     def update_chain_fast(self, iters):
-        # the reference's jitted loop is hard-wired to the planar stencil (quirk Q1); for the
-        # codes built here it must be the same chain as update_chain
-        self.update_chain(iters)
+        # the reference's jitted loop (mcmc.py:152-160) is the non-top branch of update_chain, hard-wired to the planar
+        # stencil (quirk Q1): on a Planar_code it is that chain; on the other codes the reference would corrupt the
+        # state, and the only sensible reading is the same chain as update_chain on the code's own stencil
+        p_logical, self.p_logical = self.p_logical, 0
+        try:
+            self.update_chain(iters)
+        finally:
+            self.p_logical = p_logical
 
 
 class Ladder:

@@ -221,13 +221,13 @@ int orc_eq_class(int code, int L, const uint8_t *m)
 }
 
 /* Philox address of a proposal's draws (every code model).  Non-top chains (mcmc.py:38-43) need a generator and an
- * acceptance uniform: proposal k uses words 2(k&1) (generator) and 2(k&1)+1 (acceptance) of block (k>>1, 0), so one
+ * acceptance uniform: proposal k uses words 2(k&1) (generator) and 2(k&1)+1 (acceptance) of block (k>>1, sub 1), so one
  * block feeds two proposals.  Top chains (mcmc.py:21-35) keep block (k, 0): word 0 selects logical / stabilizer, word 1
  * picks the generator, words 1-3 carry a logical operator; the acceptance uniform is word 0 of block (k, 2). */
 static double nontop_accept(const orc_model *m, orc_rng *rng, uint32_t slot, uint64_t k)
 {
     (void)m;
-    return orc_draw(rng, slot, k >> 1, 0, 2 * (int)(k & 1) + 1);
+    return orc_draw(rng, slot, k >> 1, 1, 2 * (int)(k & 1) + 1);
 }
 
 /* _apply_random_stabilizer: a uniform choice among the stabilizer generators.
@@ -245,7 +245,7 @@ static int model_random_stabilizer(const orc_model *m, const uint8_t *in, uint8_
     const int G = m->code == ORC_TORIC ? 2 * L * L : orc_surf_ngen(m->code, L);
     int g = -1;
     if (rng->mode != 0) {
-        const double u = w0 == 0 ? orc_draw(rng, slot, k >> 1, 0, 2 * (int)(k & 1)) : orc_draw(rng, slot, k, 0, 1);
+        const double u = w0 == 0 ? orc_draw(rng, slot, k >> 1, 1, 2 * (int)(k & 1)) : orc_draw(rng, slot, k, 0, 1);
         g = (int)(u * G);
         rng->consumed += (m->code == ORC_TORIC || m->code == ORC_PLANAR) ? 2 : 4;   /* counted like the reference's three / five draws */
     }

@@ -37,8 +37,8 @@ def test_exact_enumeration_L3(q, seed, p, Nc, scan):
     R, steps = 4096, 4000
     res = q.pteq_batch(np.broadcast_to(init, (R,) + init.shape).copy(), p, Nc=Nc, steps=steps, iters=10, tops_burn=5,
                        seed=1000 + seed, scan=scan)
-    ok = res["samples"] > steps // 2
-    assert ok.mean() > 0.99
+    ok = res["samples"] > steps // 2                  # replicas whose burn-in (tops0 >= 5) ended in the first half
+    assert ok.mean() > 0.97
     frac = res["counts"][ok] / res["samples"][ok, None].astype(np.float64)
     mean, sem = frac.mean(axis=0), frac.std(axis=0, ddof=1) / np.sqrt(ok.sum())
     # within Monte-Carlo error of the exact answer (4096 replicas: sem ~ 1e-3); the 2e-4 floor absorbs the
@@ -93,6 +93,8 @@ def test_harness_generate_decodes_low_noise(q, tmp_path):
                         dict(steps=3000, conv_criteria=None, tops_burn=0, biased_decoder="biased")),      # PTEQ_biased
                        ({"code": "xzzx", "size": 5, "p_error": 0.05, "noise": "biased", "eta": 10},
                         dict(steps=3000, conv_criteria=None, tops_burn=0)),     # PTEQ_alpha, as generate_data.py:142-150 routes it
+                       ({"code": "planar", "size": 5, "p_error": 0.03, "noise": "depolarizing"},
+                        dict(steps=3000, conv_criteria=None, tops_burn=0)),
                        ({"code": "rotated", "size": 5, "p_error": 0.04, "noise": "alpha", "alpha": 2.0},
                         dict(steps=200000))):                                   # PTEQ_alpha's default error_based criterion
         f = tmp_path / (params["code"] + ".npz")
