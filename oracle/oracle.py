@@ -112,6 +112,13 @@ def lib():
                                                 C.c_uint64, u8p, C.POINTER(C.c_double)]
         _LIB.orc_chain_update_alpha.restype = C.c_int
         _LIB.orc_det_exp.argtypes = [C.c_double]; _LIB.orc_det_exp.restype = C.c_double
+        u64p = C.POINTER(C.c_uint64); u32p_ = C.POINTER(C.c_uint32)
+        _LIB.orc_ptdc_droplet.argtypes = [mp, u8p, C.c_double, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(_Rng), u64p, C.c_uint64, u32p_]
+        _LIB.orc_ptdc_droplet.restype = None
+        _LIB.orc_ptdc_batch.argtypes = [mp, u8p, C.c_uint64, C.c_int, C.c_int, C.c_uint32, C.c_double, C.c_int, C.c_uint64,
+                                        C.c_uint64, C.c_uint64, C.c_int, u32p_]
+        _LIB.orc_ptdc_batch.restype = None
+        _LIB.orc_state_key.argtypes = [u8p, C.c_size_t]; _LIB.orc_state_key.restype = C.c_uint64
         _LIB.orc_ladder_new.argtypes = [mp, u8p, C.c_double, C.c_int, C.c_double]
         _LIB.orc_ladder_new.restype = C.POINTER(_Ladder)
         _LIB.orc_ladder_step.argtypes = [C.POINTER(_Ladder), C.c_uint64, C.POINTER(_Rng)]
@@ -436,3 +443,38 @@ def pteq_batch(code, init, p, Nc, steps, iters=10, tops_burn=2, seed=0, first_sy
     if return_states:
         out["states"] = fin
     return out
+
+
+# ---- unique-chain estimators (decoders.py:138-233) ---------------------------------------------------------------
+def ptdc_droplet(code, init, p_sampling, Nc, steps, iters=10, rng=None, tab=None):
+    """PTDC_droplet (conv_mult = 0): returns (N(n) uint32[nq+1] of the chains that were new to `tab`, tab)."""
+    init = _m(init); nq = init.size
+    mod = _model(code, init.shape[-1])
+    if tab is None:
+        cap = 16
+        while cap < 2 * steps * Nc:
+            cap <<= 1
+        tab = np.zeros(cap, dtype=np.uint64)
+    hist = np.zeros(nq + 1, dtype=np.uint32)
+    lib().orc_ptdc_droplet(C.byref(mod), _u8(init), p_sampling, Nc, steps, iters, C.byref(rng.c),
+                           tab.ctypes.data_as(C.POINTER(C.c_uint64)), tab.size, hist.ctypes.data_as(C.POINTER(C.c_uint32)))
+    return hist, tab
+
+
+def ptdc_batch(code, init, p_sampling, Nc, steps, droplets=1, iters=10, seed=0, first_syndrome=0, n_threads=0):
+    """init uint8[N, ncls, ...] class representatives -> N(n) uint32[N, ncls, nq+1] (orc_ptdc_batch)."""
+    init = _m(init); N, ncls = init.shape[0], init.shape[1]
+    nq = int(np.prod(init.shape[2:]))
+    mod = _model(code, init.shape[-1])
+    hist = np.zeros((N, ncls, nq + 1), dtype=np.uint32)
+    lib().orc_ptdc_batch(C.byref(mod), _u8(init), N, ncls, droplets, first_syndrome, p_sampling, Nc, steps, iters, seed, n_threads,
+                         hist.ctypes.data_as(C.POINTER(C.c_uint32)))
+    return hist
+
+
+def ptdc_distribution(hist, p_error):
+    """eqdistr of decoders.py:208,229-233: Z_E = sum over unique chains of exp(-beta n), normalised, in percent."""
+    beta = -np.log((p_error / 3) / (1 - p_error))
+    n = np.arange(hist.shape[-1], dtype=np.float64)
+    Z = (hist.astype(np.float64) * np.exp(-beta * n)).sum(axis=-1)
+    return Z / Z.sum(axis=-1, keepdims=True) * 100

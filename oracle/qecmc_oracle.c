@@ -747,3 +747,65 @@ void orc_pteq_batch(const orc_model *m, const uint8_t *init, uint64_t N, uint32_
         if (converged_out) converged_out[s] = (uint8_t)res.converged;
     }
 }
+
+
+/* ------------------------------------------------------------------------ */
+/*  unique-chain estimators (decoders.py:138-233)                            */
+/* ------------------------------------------------------------------------ */
+uint64_t orc_state_key(const uint8_t *state, size_t nq)
+{
+    uint64_t h = 0xCBF29CE484222325ull;                 /* FNV-1a, 64 bit */
+    for (size_t i = 0; i < nq; ++i) { h ^= state[i]; h *= 0x100000001B3ull; }
+    h ^= h >> 32;                                      /* the low bits index the table: fold the high half in */
+    return h ? h : 1;
+}
+
+int orc_uset_insert(uint64_t *tab, uint64_t cap, uint64_t key)
+{
+    uint64_t i = (key * 0x9E3779B97F4A7C15ull) >> 20 & (cap - 1);
+    for (;;) {
+        if (tab[i] == 0) { tab[i] = key; return 1; }
+        if (tab[i] == key) return 0;
+        i = (i + 1) & (cap - 1);
+    }
+}
+
+void orc_ptdc_droplet(const orc_model *m, const uint8_t *init, double p_sampling, int Nc, uint64_t steps, uint64_t iters,
+                      orc_rng *rng, uint64_t *tab, uint64_t cap, uint32_t *hist)
+{
+    orc_ladder *ld = orc_ladder_new(m, init, p_sampling, Nc, 0.0);      /* decoders.py:182,196: no p_logical */
+    const size_t nq = (size_t)ld->nq;
+    for (uint64_t step = 0; step < steps; ++step) {                     /* :142 */
+        orc_ladder_step(ld, iters, rng);                                /* :144 */
+        for (int c = 0; c < Nc; ++c) {                                  /* :146-152 */
+            const uint8_t *st = ld->states + (size_t)c * nq;
+            if (orc_uset_insert(tab, cap, orc_state_key(st, nq))) hist[orc_count_errors(nq, st)]++;
+        }
+    }
+    orc_ladder_free(ld);
+}
+
+void orc_ptdc_batch(const orc_model *m, const uint8_t *init, uint64_t N, int ncls, int D, uint32_t first_syndrome,
+                    double p_sampling, int Nc, uint64_t steps, uint64_t iters, uint64_t seed, int n_threads, uint32_t *hist_out)
+{
+    const size_t nq = (size_t)orc_nq(m->code, m->L);
+    uint64_t cap = 16;
+    while (cap < 2 * steps * (uint64_t)Nc * (uint64_t)D) cap <<= 1;
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#else
+    (void)n_threads;
+#endif
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t sc = 0; sc < (int64_t)(N * (uint64_t)ncls); ++sc) {
+        uint64_t *tab = (uint64_t *)calloc(cap, sizeof(uint64_t));
+        uint32_t *hist = hist_out + (size_t)sc * (nq + 1);
+        memset(hist, 0, (nq + 1) * sizeof(uint32_t));
+        for (int d = 0; d < D; ++d) {
+            orc_rng rng;
+            orc_rng_init_philox(&rng, seed, first_syndrome + (uint32_t)(sc * D + d));
+            orc_ptdc_droplet(m, init + (size_t)sc * nq, p_sampling, Nc, steps, iters, &rng, tab, cap, hist);
+        }
+        free(tab);
+    }
+}

@@ -152,7 +152,23 @@ void orc_pteq_batch(const orc_model *m, const uint8_t *init, uint64_t N, uint32_
 /* Chain_alpha.update_chain (mcmc_alpha.py:27-70); *n_eff is the chain's n_eff attribute (updated on accepted moves only) */
 int orc_chain_update_alpha(const orc_model *m, uint8_t *state, double pz_tilde, double p_logical, uint64_t iters,
                             orc_rng *rng, uint32_t slot, uint64_t k0, uint8_t *scratch, double *n_eff);
-double orc_det_exp(double y);   /* deterministic exp for y <= 0 (IEEE +,*,fma only): bit-identical on CPU and GPU */
+double orc_det_exp(double y);
+
+/* ---- unique-chain estimators (decoders.py:138-233, PTDC) ----
+ * 64-bit key of a configuration (FNV-1a over the bytes, never 0) -- the role of hash(qubit_matrix.tobytes()), decoders.py:148 */
+uint64_t orc_state_key(const uint8_t *state, size_t nq);
+/* open-addressing set of keys: tab[cap] (cap a power of two, 0 = empty); returns 1 if the key was new */
+int orc_uset_insert(uint64_t *tab, uint64_t cap, uint64_t key);
+/* PTDC_droplet (decoders.py:138-164, conv_mult = 0): `steps` x Ladder.step(iters) on a ladder WITHOUT logical moves
+ * (PTDC builds Ladder(p_sampling, code, Nc), p_logical = 0), every rung's configuration recorded after every step;
+ * hist[n] += 1 for every configuration not seen before in `tab` (its length n = count_errors). */
+void orc_ptdc_droplet(const orc_model *m, const uint8_t *init, double p_sampling, int Nc, uint64_t steps, uint64_t iters,
+                      orc_rng *rng, uint64_t *tab, uint64_t cap, uint32_t *hist /*[nq+1]*/);
+/* N syndromes x ncls class representatives x D droplets; droplet ladders of one (syndrome, class) share a set (the dict
+ * merge of decoders.py:220-226).  Ladder l = (s * ncls + c) * D + d draws from Philox syndrome first_syndrome + l.
+ * init uint8[N][ncls][nq]; hist_out uint32[N][ncls][nq+1] = number of unique chains of each length, N(n). */
+void orc_ptdc_batch(const orc_model *m, const uint8_t *init, uint64_t N, int ncls, int D, uint32_t first_syndrome,
+                    double p_sampling, int Nc, uint64_t steps, uint64_t iters, uint64_t seed, int n_threads, uint32_t *hist_out);   /* deterministic exp for y <= 0 (IEEE +,*,fma only): bit-identical on CPU and GPU */
 
 /* N independent PTEQ runs (one per syndrome, Philox keyed by first_syndrome+i),
  * spread over `n_threads` OpenMP threads.  This is the timed CPU baseline. */

@@ -19,6 +19,7 @@ Fixtures
   f4_config1.npz  BASELINE config-1 plumbing vector
   f1_surf.npz / f2_surf.npz   the same for the XZZX and rotated codes, incl. the biased chain
   f2_alpha.npz                Chain_alpha / Ladder_alpha / PTEQ_alpha trajectories (src/mcmc_alpha.py)
+  f_ptdc.npz                  PTDC_droplet unique-chain length histograms N(n) and PTDC percent vectors (decoders.py:138-233)
   f_planar.npz                Planar_code stencil KATs and Chain (incl. update_chain_fast) / Ladder / PTEQ trajectories
 """
 import argparse
@@ -522,6 +523,48 @@ def gen_planar(pm, mc, dec):
     print("f_planar.npz", kats, cases)
 
 
+def gen_ptdc(tm, pm, mc, dec):
+    """PTDC_droplet (decoders.py:138-164): the unique-chain set of a class ladder -> N(n), the number of distinct chains of
+    each length; and PTDC's percent vector (droplets = 1) for a toric syndrome."""
+    rng = np.random.default_rng(808)
+    out = {}
+    cases = []
+    for i, (name, L, p, Nc, steps, perr) in enumerate([("toric", 3, 0.1, 3, 300, 0.15), ("toric", 5, 0.1, 5, 200, 0.1),
+                                                      ("planar", 3, 0.15, 3, 300, 0.15), ("planar", 5, 0.1, 4, 150, 0.1),
+                                                      ("toric", 4, 0.3, 2, 200, 0.2)]):
+        m = rand_matrix(rng, L, perr) if name == "toric" else rand_planar(rng, L, perr)
+        seed = 8000 + i
+        code = tm.Toric_code(L) if name == "toric" else pm.Planar_code(L)
+        code.qubit_matrix = m.copy()
+        s = Stream(seed); install(s, tm, pm, mc)
+        ld = mc.Ladder(p, code, Nc)                       # as PTDC builds it (decoders.py:182): no p_logical
+        samples = dec.PTDC_droplet(ld, steps, 10, 0)
+        restore(tm, pm, mc)
+        nq = m.size
+        tag = f"drop{i}"
+        out[f"{tag}_init"] = m
+        out[f"{tag}_hist"] = np.bincount(np.array(list(samples.values()), dtype=np.int64), minlength=nq + 1).astype(np.uint32)
+        out[f"{tag}_states"] = np.array([c.code.qubit_matrix for c in ld.chains], dtype=np.uint8)
+        out[f"{tag}_par"] = np.array([0 if name == "toric" else 3, L, p, Nc, steps, seed, s.n], dtype=np.float64)
+        cases.append(tag)
+    for i, (L, p_error, p_sampling, Nc, steps, perr) in enumerate([(3, 0.1, None, 3, 600, 0.15), (3, 0.08, 0.2, 2, 400, 0.1)]):
+        m = rand_matrix(rng, L, perr)
+        seed = 8100 + i
+        code = tm.Toric_code(L); code.qubit_matrix = m.copy()
+        s = Stream(seed); install(s, tm, pm, mc)
+        pct = dec.PTDC(code, p_error, p_sampling=p_sampling, droplets=1, Nc=Nc, steps=steps, conv_mult=0)
+        restore(tm, pm, mc)
+        tag = f"ptdc{i}"
+        out[f"{tag}_init"] = m
+        out[f"{tag}_percent"] = np.asarray(pct, dtype=np.uint8)
+        out[f"{tag}_classes"] = np.array([tm._to_class(eq, m.copy()) for eq in range(16)], dtype=np.uint8)   # toric_model.py:354
+        out[f"{tag}_par"] = np.array([L, p_error, p_sampling or p_error, Nc, steps, seed, s.n], dtype=np.float64)
+        cases.append(tag)
+    out["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(HERE, "f_ptdc.npz"), **out)
+    print("f_ptdc.npz", cases)
+
+
 def _f3_worker(args):
     (L, p, Nc, iters, steps, burn, m, seed) = args
     tm, mc, dec = import_reference()
@@ -584,15 +627,16 @@ def main():
         print("reference not present; nothing to do")
         return
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="f1,f2,f3,f4,f1s,f2s,f2a,fp")
+    ap.add_argument("--only", default="f1,f2,f3,f4,f1s,f2s,f2a,fp,fd")
     only = set(ap.parse_args().only.split(","))
     tm, mc, dec = import_reference()
     if "f1" in only: gen_f1(tm)
     if "f2" in only: gen_f2(tm, mc, dec)
     if "f4" in only: gen_f4(tm, mc)
-    if "fp" in only:
+    if "fp" in only or "fd" in only:
         import src.planar_model as pm
-        gen_planar(pm, mc, dec)
+        if "fp" in only: gen_planar(pm, mc, dec)
+        if "fd" in only: gen_ptdc(tm, pm, mc, dec)
     if "f1s" in only or "f2s" in only or "f2a" in only:
         xm, rm, mb, decb = import_reference_surf()
         if "f2a" in only:

@@ -1,0 +1,56 @@
+"""Pins the oracle's unique-chain estimator (PTDC_droplet / PTDC, decoders.py:138-233) against the reference on an
+injected stream (f_ptdc.npz): N(n) = number of distinct chains of each length found by a class ladder, and PTDC's
+percent vector."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from conftest import GOLDEN
+
+
+def _load():
+    return np.load(os.path.join(GOLDEN, "f_ptdc.npz"))
+
+
+def _stream(seed, n):
+    r = random.Random(seed)
+    return np.array([r.random() for _ in range(n)], dtype=np.float64)
+
+
+def _cases(prefix):
+    return [str(c) for c in _load()["cases"] if str(c).startswith(prefix)]
+
+
+@pytest.mark.parametrize("case", _cases("drop"))
+def test_ptdc_droplet_length_histogram(case):
+    g = _load()
+    code, L, p, Nc, steps, seed, ndraw = g[f"{case}_par"]
+    rng = orc.Rng.stream(_stream(int(seed), int(ndraw)))
+    hist, tab = orc.ptdc_droplet(int(code), g[f"{case}_init"], float(p), int(Nc), int(steps), rng=rng)
+    assert rng.consumed == int(ndraw)
+    assert np.array_equal(hist, g[f"{case}_hist"])
+    assert int((tab != 0).sum()) == int(hist.sum())
+
+
+@pytest.mark.parametrize("case", _cases("ptdc"))
+def test_ptdc_percent(case):
+    """PTDC with droplets = 1 runs the 16 class ladders one after the other on the same stream (decoders.py:217-219)."""
+    g = _load()
+    L, p_error, p_sampling, Nc, steps, seed, ndraw = g[f"{case}_par"]
+    rng = orc.Rng.stream(_stream(int(seed), int(ndraw)))
+    reps = g[f"{case}_classes"]
+    assert [orc.toric_eq_class(r) for r in reps] == list(range(16))
+    hist = np.stack([orc.ptdc_droplet(orc.TORIC, r, float(p_sampling), int(Nc), int(steps) // int(Nc), rng=rng)[0] for r in reps])
+    assert rng.consumed == int(ndraw)
+    pct = orc.ptdc_distribution(hist, float(p_error)).astype(np.uint8)
+    assert np.array_equal(pct, g[f"{case}_percent"])
+
+
+def test_state_key_and_set():
+    r = np.random.default_rng(0)
+    states = r.integers(0, 4, size=(2000, 50), dtype=np.uint8)
+    keys = {int(orc.lib().orc_state_key(orc._u8(s), s.size)) for s in states}
+    assert len(keys) == len({s.tobytes() for s in states}) and 0 not in keys
