@@ -165,6 +165,18 @@ int qecmc_pteq_batch(const qecmc_params *params, const uint8_t *init, uint64_t N
                      uint32_t *samples_out, uint32_t *tops0_out, uint32_t *steps_done_out,
                      uint8_t *converged_out, uint8_t *final_states_out, qecmc_stats *stats_out);
 
+/* PTDC (decoders.py:168-233, conv_mult = 0) on N syndromes: the direct-counting estimator.  For every syndrome and
+ * class, `droplets` independent ladders WITHOUT logical moves (decoders.py:182,196) run params->steps ladder steps of
+ * params->iters proposals at p = params->p (p_sampling); after every step every rung's configuration goes into the
+ * (syndrome, class) set of chains seen so far (PTDC_droplet, decoders.py:146-152; the droplets' sets are merged,
+ * :220-226).  init uint8[N][ncls][nq] = one representative per class (what the reference's list form of init_code /
+ * to_class provides); hist_out uint32[N][ncls][nq+1] = N(n), the number of distinct chains of each length found.
+ * The caller forms Z_E = sum_n N(n) exp(-beta n) with beta from p_error (:208,229-233).  PTDC itself passes
+ * steps // Nc (:201).  Ladder l = (s * ncls + c) * droplets + d draws from Philox syndrome first_syndrome + l.
+ * Uses params->{code,L,Nc,p,iters,steps,seed,first_syndrome,device}; p_logical is ignored (0). */
+int qecmc_ptdc_batch(const qecmc_params *params, const uint8_t *init, uint64_t N, int32_t droplets,
+                     uint32_t *hist_out, qecmc_stats *stats_out);
+
 /* Plan + device-pointer form: build once (validates, uploads threshold tables),
  * then launch asynchronously on a caller stream with buffers already in HBM.
  * d_workspace: qecmc_plan_workspace_bytes() bytes (0 for conv_mode NONE, then NULL is fine). */

@@ -88,3 +88,54 @@ def _pteq(init_code, p, eta, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, conv_c
     if not res["converged"][0]:
         print('\n\nWARNING: PTEQ hit max number of steps before convergence:\t', horizon, '\n\n')
     return res["percent"][0]
+
+
+def ptdc_batch(init, p_sampling, Nc=None, steps=2000, droplets=1, iters=10, seed=0, first_syndrome=0, device=0, code=L_.TORIC,
+               return_stats=False):
+    """The sampling half of PTDC (decoders.py:168-233, conv_mult = 0) on N syndromes at once.
+
+    init: uint8[N, ncls, ...] -- one representative per equivalence class for every syndrome (what `to_class` / the list
+    form of init_code provides).  For every (syndrome, class), `droplets` ladders without logical moves run `steps` ladder
+    steps; returns N(n) uint32[N, ncls, nq+1], the number of DISTINCT chains of each length seen by any rung of any droplet
+    (PTDC_droplet's dict, decoders.py:146-152,220-226).  `steps` is per ladder: PTDC passes steps // Nc (:201)."""
+    nd = 3 if code in (L_.TORIC, L_.PLANAR) else 2
+    a = np.ascontiguousarray(init, dtype=np.uint8)
+    if a.ndim != nd + 2:
+        raise ValueError(f"expected init of shape [N, classes, ...state], got {a.shape}")
+    N, ncls, size = a.shape[0], a.shape[1], a.shape[-1]
+    if ncls != (16 if code == L_.TORIC else 4):
+        raise ValueError("one representative per equivalence class is needed")
+    nq = int(np.prod(a.shape[2:]))
+    pr = L_.make_params(code=code, L=size, Nc=Nc or size, p=float(p_sampling), iters=int(iters), steps=int(steps), seed=seed,
+                        first_syndrome=first_syndrome, device=device)
+    hist = np.zeros((N, ncls, nq + 1), dtype=np.uint32)
+    stats = L_.Stats()
+    L_.check(L_.lib().qecmc_ptdc_batch(pr, L_.u8(a), N, int(droplets), L_.u32(hist), stats))
+    if return_stats:
+        return hist, dict(proposals=int(stats.proposals), kernel_ms=float(stats.kernel_ms), total_ms=float(stats.total_ms))
+    return hist
+
+
+def ptdc_distribution(hist, p_error):
+    """decoders.py:208,229-233: Z_E = sum over the unique chains of exp(-beta n), normalised over the classes, x 100."""
+    beta = -np.log((p_error / 3) / (1 - p_error))
+    n = np.arange(hist.shape[-1], dtype=np.float64)
+    Z = (hist.astype(np.float64) * np.exp(-beta * n)).sum(axis=-1)
+    return Z / Z.sum(axis=-1, keepdims=True) * 100
+
+
+def PTDC(init_code, p_error, p_sampling=None, droplets=4, Nc=None, steps=20000, conv_mult=0, seed=None):
+    """Drop-in for decoders.PTDC (decoders.py:168): same arguments, returns the uint8 percent vector.  init_code is a code
+    with `to_class` (toric) or a list with one code per class.  conv_mult (the early stop of :157-162) must be 0."""
+    if conv_mult:
+        raise NotImplementedError("PTDC's conv_mult early stop is not built; pass conv_mult=0 (the reference's default)")
+    p_sampling = p_sampling or p_error
+    if isinstance(init_code, list):
+        assert len(init_code) == init_code[0].nbr_eq_classes, 'if init_code is a list, it has to contain one code for each class'
+        code0, reps = init_code[0], [c.qubit_matrix for c in init_code]
+    else:
+        code0, reps = init_code, [init_code.to_class(eq) for eq in range(init_code.nbr_eq_classes)]
+    Nc = Nc or code0.system_size
+    hist = ptdc_batch(np.stack(reps)[None], p_sampling, Nc=Nc, steps=steps // Nc, droplets=droplets,
+                      seed=_fresh_seed() if seed is None else seed, code=_code_id(code0))
+    return ptdc_distribution(hist[0], p_error).astype(np.uint8)

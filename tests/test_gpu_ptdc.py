@@ -1,0 +1,80 @@
+"""GPU parity for the direct-counting estimator PTDC (decoders.py:138-233): the unique-chain length histograms N(n) of the
+GPU path (ladder kernel + hash-set insertion kernel) against the oracle, bit for bit, and the estimator against exact
+enumeration of the stabilizer group."""
+import numpy as np
+import pytest
+
+from util_exact import toric_class_probabilities
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def q():
+    import qecmc
+    assert qecmc.device_count() >= 1
+    return qecmc
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+def _toric_reps(q, m):
+    from qecmc import toric_model as tm
+    return np.stack([tm.to_class(m, eq) for eq in range(16)])
+
+
+def _rand_toric(rng, L, p):
+    m = np.zeros((2, L, L), dtype=np.uint8)
+    err = rng.random(m.shape) < p
+    m[err] = rng.integers(1, 4, size=int(err.sum()), dtype=np.uint8)
+    return m
+
+
+@pytest.mark.parametrize("L,p,Nc,steps,droplets,N", [(3, 0.1, 3, 120, 1, 3), (5, 0.1, 5, 60, 3, 2), (5, 0.3, 2, 100, 2, 2), (7, 0.15, 8, 25, 2, 1)])
+def test_ptdc_batch_toric_bit_exact(q, orc, L, p, Nc, steps, droplets, N):
+    rng = np.random.default_rng(L * 7 + steps)
+    init = np.stack([_toric_reps(q, _rand_toric(rng, L, 0.12)) for _ in range(N)])
+    assert [orc.toric_eq_class(r) for r in init[0]] == list(range(16))
+    got = q.ptdc_batch(init, p, Nc=Nc, steps=steps, droplets=droplets, seed=99, first_syndrome=4)
+    ref = orc.ptdc_batch(orc.TORIC, init, p, Nc, steps, droplets=droplets, seed=99, first_syndrome=4)
+    assert got.shape == (N, 16, 2 * L * L + 1) and got.sum() > 0
+    assert np.array_equal(got, ref)
+
+
+def test_ptdc_batch_planar_bit_exact(q, orc):
+    rng = np.random.default_rng(12)
+    L = 5
+    from qecmc import planar_model as pm
+    m = np.zeros((2, L, L), dtype=np.uint8)
+    err = rng.random(m.shape) < 0.1
+    m[err] = rng.integers(1, 4, size=int(err.sum()), dtype=np.uint8)
+    m[1, -1, :] = 0; m[1, :, -1] = 0
+    reps = [pm.apply_logical(m, op, 0, 0)[0] for op in range(4)]          # one representative per class
+    assert sorted(int(pm.eq_class(r)) for r in reps) == [0, 1, 2, 3]
+    init = np.stack(reps)[None]
+    got = q.ptdc_batch(init, 0.12, Nc=4, steps=80, droplets=2, seed=5, code=q.PLANAR)
+    ref = orc.ptdc_batch(orc.PLANAR, init, 0.12, 4, 80, droplets=2, seed=5)
+    assert np.array_equal(got, ref) and got.sum() > 0
+
+
+def test_ptdc_dropin_matches_exact_classes(q, orc):
+    """PTDC with the reference's signature; at L = 3 the sets it collects hold the chains that dominate Z_E, so the
+    estimate sits close to the exact class probabilities (and its argmax on the true class)."""
+    rng = np.random.default_rng(3)
+    m = _rand_toric(rng, 3, 0.12)
+    code = q.Toric_code(3)
+    code.qubit_matrix = m.copy()
+    p = 0.1
+    pct = q.PTDC(code, p, droplets=4, steps=6000, seed=17)
+    assert pct.dtype == np.uint8 and pct.shape == (16,)
+    P = toric_class_probabilities(m, p, orc.toric_apply_stabilizer, orc.toric_to_class) * 100
+    assert pct.argmax() == P.argmax() and 0.5 * np.abs(pct.astype(np.float64) - P).sum() < 6.0
+    with pytest.raises(NotImplementedError):
+        q.PTDC(code, p, conv_mult=2.0)
+    # the same ladders through the oracle
+    hist = orc.ptdc_batch(orc.TORIC, _toric_reps(q, m)[None], p, 3, 6000 // 3, droplets=4, seed=17)
+    assert np.array_equal(pct, orc.ptdc_distribution(hist[0], p).astype(np.uint8))
