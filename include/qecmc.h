@@ -173,9 +173,12 @@ int qecmc_pteq_batch(const qecmc_params *params, const uint8_t *init, uint64_t N
  * to_class provides); hist_out uint32[N][ncls][nq+1] = N(n), the number of distinct chains of each length found.
  * The caller forms Z_E = sum_n N(n) exp(-beta n) with beta from p_error (:208,229-233).  PTDC itself passes
  * steps // Nc (:201).  Ladder l = (s * ncls + c) * droplets + d draws from Philox syndrome first_syndrome + l.
- * Uses params->{code,L,Nc,p,iters,steps,seed,first_syndrome,device}; p_logical is ignored (0). */
+ * Uses params->{code,L,Nc,p,iters,steps,seed,first_syndrome,device}; p_logical is ignored (0).
+ * STDC / STDC_droplet (decoders.py:236-322) is the same computation on 1-chain ladders: Nc = 1, iters = 5
+ * (`chain.update_chain_fast(5)`, :250); its "rain" start (`apply_stabilizers_uniform` per droplet, :246-247) is passed in
+ * with init_per_droplet != 0, init then being uint8[N][ncls][droplets][nq]. */
 int qecmc_ptdc_batch(const qecmc_params *params, const uint8_t *init, uint64_t N, int32_t droplets,
-                     uint32_t *hist_out, qecmc_stats *stats_out);
+                     int32_t init_per_droplet, uint32_t *hist_out, qecmc_stats *stats_out);
 
 /* Plan + device-pointer form: build once (validates, uploads threshold tables),
  * then launch asynchronously on a caller stream with buffers already in HBM.

@@ -668,8 +668,8 @@ int qecmc_pteq_batch(const qecmc_params *params, const uint8_t *init, uint64_t N
     return 0;
 }
 
-int qecmc_ptdc_batch(const qecmc_params *params, const uint8_t *init, uint64_t N, int32_t droplets, uint32_t *hist_out,
-                     qecmc_stats *stats_out)
+int qecmc_ptdc_batch(const qecmc_params *params, const uint8_t *init, uint64_t N, int32_t droplets, int32_t init_per_droplet,
+                     uint32_t *hist_out, qecmc_stats *stats_out)
 {
     const auto t0 = std::chrono::steady_clock::now();
     if (!params) return fail(QECMC_ERR_INVALID, "params is NULL");
@@ -700,7 +700,8 @@ int qecmc_ptdc_batch(const qecmc_params *params, const uint8_t *init, uint64_t N
     for (uint64_t sc = 0; sc < sets; ++sc)
         for (size_t d = 0; d < D; ++d) {
             const uint64_t l = sc * D + d;
-            for (size_t c = 0; c < Nc; ++c) std::memcpy(&st[(l * Nc + c) * nq], init + sc * nq, nq);
+            const uint8_t *src = init + (init_per_droplet ? l : sc) * nq;
+            for (size_t c = 0; c < Nc; ++c) std::memcpy(&st[(l * Nc + c) * nq], src, nq);
             fl[l * Nc + Nc - 1] = 1;
         }
     DevBuf ds, df, dt, dtab, dh;

@@ -95,22 +95,25 @@ def ptdc_batch(init, p_sampling, Nc=None, steps=2000, droplets=1, iters=10, seed
     """The sampling half of PTDC (decoders.py:168-233, conv_mult = 0) on N syndromes at once.
 
     init: uint8[N, ncls, ...] -- one representative per equivalence class for every syndrome (what `to_class` / the list
-    form of init_code provides).  For every (syndrome, class), `droplets` ladders without logical moves run `steps` ladder
-    steps; returns N(n) uint32[N, ncls, nq+1], the number of DISTINCT chains of each length seen by any rung of any droplet
-    (PTDC_droplet's dict, decoders.py:146-152,220-226).  `steps` is per ladder: PTDC passes steps // Nc (:201)."""
+    form of init_code provides) -- or uint8[N, ncls, droplets, ...] with a start of its own for every droplet (STDC's rain).
+    For every (syndrome, class), `droplets` ladders without logical moves run `steps` ladder steps; returns N(n)
+    uint32[N, ncls, nq+1], the number of DISTINCT chains of each length seen by any rung of any droplet (PTDC_droplet's
+    dict, decoders.py:146-152,220-226).  `steps` is per ladder: PTDC passes steps // Nc (:201).  Nc = 1, iters = 5 is
+    STDC_droplet (:236-265)."""
     nd = 3 if code in (L_.TORIC, L_.PLANAR) else 2
     a = np.ascontiguousarray(init, dtype=np.uint8)
-    if a.ndim != nd + 2:
-        raise ValueError(f"expected init of shape [N, classes, ...state], got {a.shape}")
+    per_droplet = a.ndim == nd + 3
+    if a.ndim not in (nd + 2, nd + 3) or (per_droplet and a.shape[2] != droplets):
+        raise ValueError(f"expected init of shape [N, classes, (droplets,) ...state], got {a.shape}")
     N, ncls, size = a.shape[0], a.shape[1], a.shape[-1]
     if ncls != (16 if code == L_.TORIC else 4):
         raise ValueError("one representative per equivalence class is needed")
-    nq = int(np.prod(a.shape[2:]))
+    nq = int(np.prod(a.shape[-nd:]))
     pr = L_.make_params(code=code, L=size, Nc=Nc or size, p=float(p_sampling), iters=int(iters), steps=int(steps), seed=seed,
                         first_syndrome=first_syndrome, device=device)
     hist = np.zeros((N, ncls, nq + 1), dtype=np.uint32)
     stats = L_.Stats()
-    L_.check(L_.lib().qecmc_ptdc_batch(pr, L_.u8(a), N, int(droplets), L_.u32(hist), stats))
+    L_.check(L_.lib().qecmc_ptdc_batch(pr, L_.u8(a), N, int(droplets), int(per_droplet), L_.u32(hist), stats))
     if return_stats:
         return hist, dict(proposals=int(stats.proposals), kernel_ms=float(stats.kernel_ms), total_ms=float(stats.total_ms))
     return hist
@@ -139,3 +142,30 @@ def PTDC(init_code, p_error, p_sampling=None, droplets=4, Nc=None, steps=20000, 
     hist = ptdc_batch(np.stack(reps)[None], p_sampling, Nc=Nc, steps=steps // Nc, droplets=droplets,
                       seed=_fresh_seed() if seed is None else seed, code=_code_id(code0))
     return ptdc_distribution(hist[0], p_error).astype(np.uint8)
+
+
+def STDC(init_code, p_error, p_sampling=None, droplets=10, steps=20000, conv_mult=0, seed=None):
+    """Drop-in for decoders.STDC (decoders.py:268-322): single chains at p_sampling, `update_chain_fast(5)` per step,
+    Z_E from the distinct chains found; returns the float percent vector.  init_code: a list with one code per class
+    (no rain, :279), or a code with `to_class` (then every droplet starts from `apply_stabilizers_uniform()`, :246-247,
+    :292).  The reference's jitted loop is hard-wired to the planar stencil (quirk Q1), which is the only model it is
+    correct for; here the chain runs on the stencil of the code it is given.  conv_mult must be 0."""
+    if conv_mult:
+        raise NotImplementedError("STDC's conv_mult early stop is not built; pass conv_mult=0 (the reference's default)")
+    p_sampling = p_sampling or p_error
+    import copy
+    if isinstance(init_code, list):
+        assert len(init_code) == init_code[0].nbr_eq_classes, 'if init_code is a list, it has to contain one code for each class'
+        code0 = init_code[0]
+        init = np.stack([c.qubit_matrix for c in init_code])[None]
+    else:
+        code0 = init_code
+        reps = []
+        for eq in range(init_code.nbr_eq_classes):
+            c = copy.deepcopy(init_code)
+            c.qubit_matrix = c.to_class(eq)
+            reps.append(np.stack([c.apply_stabilizers_uniform() for _ in range(droplets)]))     # rain, one per droplet
+        init = np.stack(reps)[None]
+    hist = ptdc_batch(init, p_sampling, Nc=1, steps=steps, droplets=droplets, iters=5, seed=_fresh_seed() if seed is None else seed,
+                      code=_code_id(code0))
+    return ptdc_distribution(hist[0], p_error)

@@ -115,7 +115,7 @@ def lib():
         u64p = C.POINTER(C.c_uint64); u32p_ = C.POINTER(C.c_uint32)
         _LIB.orc_ptdc_droplet.argtypes = [mp, u8p, C.c_double, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(_Rng), u64p, C.c_uint64, u32p_]
         _LIB.orc_ptdc_droplet.restype = None
-        _LIB.orc_ptdc_batch.argtypes = [mp, u8p, C.c_uint64, C.c_int, C.c_int, C.c_uint32, C.c_double, C.c_int, C.c_uint64,
+        _LIB.orc_ptdc_batch.argtypes = [mp, u8p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_double, C.c_int, C.c_uint64,
                                         C.c_uint64, C.c_uint64, C.c_int, u32p_]
         _LIB.orc_ptdc_batch.restype = None
         _LIB.orc_state_key.argtypes = [u8p, C.c_size_t]; _LIB.orc_state_key.restype = C.c_uint64
@@ -446,7 +446,7 @@ def pteq_batch(code, init, p, Nc, steps, iters=10, tops_burn=2, seed=0, first_sy
 
 
 # ---- unique-chain estimators (decoders.py:138-233) ---------------------------------------------------------------
-def ptdc_droplet(code, init, p_sampling, Nc, steps, iters=10, rng=None, tab=None):
+def ptdc_droplet(code, init, p_sampling, Nc, steps, iters=10, rng=None, tab=None):  # Nc=1, iters=5: STDC_droplet
     """PTDC_droplet (conv_mult = 0): returns (N(n) uint32[nq+1] of the chains that were new to `tab`, tab)."""
     init = _m(init); nq = init.size
     mod = _model(code, init.shape[-1])
@@ -462,13 +462,15 @@ def ptdc_droplet(code, init, p_sampling, Nc, steps, iters=10, rng=None, tab=None
 
 
 def ptdc_batch(code, init, p_sampling, Nc, steps, droplets=1, iters=10, seed=0, first_syndrome=0, n_threads=0):
-    """init uint8[N, ncls, ...] class representatives -> N(n) uint32[N, ncls, nq+1] (orc_ptdc_batch)."""
+    """init uint8[N, ncls, ...] class representatives (or [N, ncls, droplets, ...]) -> N(n) uint32[N, ncls, nq+1]."""
     init = _m(init); N, ncls = init.shape[0], init.shape[1]
-    nq = int(np.prod(init.shape[2:]))
+    nd = 3 if code in (TORIC, PLANAR) else 2
+    per_droplet = init.ndim == nd + 3
+    nq = int(np.prod(init.shape[-nd:]))
     mod = _model(code, init.shape[-1])
     hist = np.zeros((N, ncls, nq + 1), dtype=np.uint32)
-    lib().orc_ptdc_batch(C.byref(mod), _u8(init), N, ncls, droplets, first_syndrome, p_sampling, Nc, steps, iters, seed, n_threads,
-                         hist.ctypes.data_as(C.POINTER(C.c_uint32)))
+    lib().orc_ptdc_batch(C.byref(mod), _u8(init), N, ncls, droplets, int(per_droplet), first_syndrome, p_sampling, Nc, steps, iters,
+                         seed, n_threads, hist.ctypes.data_as(C.POINTER(C.c_uint32)))
     return hist
 
 

@@ -785,8 +785,9 @@ void orc_ptdc_droplet(const orc_model *m, const uint8_t *init, double p_sampling
     orc_ladder_free(ld);
 }
 
-void orc_ptdc_batch(const orc_model *m, const uint8_t *init, uint64_t N, int ncls, int D, uint32_t first_syndrome,
-                    double p_sampling, int Nc, uint64_t steps, uint64_t iters, uint64_t seed, int n_threads, uint32_t *hist_out)
+void orc_ptdc_batch(const orc_model *m, const uint8_t *init, uint64_t N, int ncls, int D, int init_per_droplet,
+                    uint32_t first_syndrome, double p_sampling, int Nc, uint64_t steps, uint64_t iters, uint64_t seed,
+                    int n_threads, uint32_t *hist_out)
 {
     const size_t nq = (size_t)orc_nq(m->code, m->L);
     uint64_t cap = 16;
@@ -804,7 +805,7 @@ void orc_ptdc_batch(const orc_model *m, const uint8_t *init, uint64_t N, int ncl
         for (int d = 0; d < D; ++d) {
             orc_rng rng;
             orc_rng_init_philox(&rng, seed, first_syndrome + (uint32_t)(sc * D + d));
-            orc_ptdc_droplet(m, init + (size_t)sc * nq, p_sampling, Nc, steps, iters, &rng, tab, cap, hist);
+            orc_ptdc_droplet(m, init + (size_t)(init_per_droplet ? sc * D + d : sc) * nq, p_sampling, Nc, steps, iters, &rng, tab, cap, hist);
         }
         free(tab);
     }

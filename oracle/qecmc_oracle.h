@@ -167,8 +167,9 @@ void orc_ptdc_droplet(const orc_model *m, const uint8_t *init, double p_sampling
 /* N syndromes x ncls class representatives x D droplets; droplet ladders of one (syndrome, class) share a set (the dict
  * merge of decoders.py:220-226).  Ladder l = (s * ncls + c) * D + d draws from Philox syndrome first_syndrome + l.
  * init uint8[N][ncls][nq]; hist_out uint32[N][ncls][nq+1] = number of unique chains of each length, N(n). */
-void orc_ptdc_batch(const orc_model *m, const uint8_t *init, uint64_t N, int ncls, int D, uint32_t first_syndrome,
-                    double p_sampling, int Nc, uint64_t steps, uint64_t iters, uint64_t seed, int n_threads, uint32_t *hist_out);   /* deterministic exp for y <= 0 (IEEE +,*,fma only): bit-identical on CPU and GPU */
+void orc_ptdc_batch(const orc_model *m, const uint8_t *init, uint64_t N, int ncls, int D, int init_per_droplet,
+                    uint32_t first_syndrome, double p_sampling, int Nc, uint64_t steps, uint64_t iters, uint64_t seed,
+                    int n_threads, uint32_t *hist_out);   /* init_per_droplet: init is [N][ncls][D][nq] (STDC's rain) */   /* deterministic exp for y <= 0 (IEEE +,*,fma only): bit-identical on CPU and GPU */
 
 /* N independent PTEQ runs (one per syndrome, Philox keyed by first_syndrome+i),
  * spread over `n_threads` OpenMP threads.  This is the timed CPU baseline. */

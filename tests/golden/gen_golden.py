@@ -560,6 +560,37 @@ def gen_ptdc(tm, pm, mc, dec):
         out[f"{tag}_classes"] = np.array([tm._to_class(eq, m.copy()) for eq in range(16)], dtype=np.uint8)   # toric_model.py:354
         out[f"{tag}_par"] = np.array([L, p_error, p_sampling or p_error, Nc, steps, seed, s.n], dtype=np.float64)
         cases.append(tag)
+    # STDC_droplet / STDC (decoders.py:236-322) on the planar code: single chains, update_chain_fast(5) per step
+    for i, (L, p, steps, perr) in enumerate([(3, 0.15, 400, 0.15), (5, 0.1, 300, 0.1)]):
+        m = rand_planar(rng, L, perr)
+        seed = 8200 + i
+        code = pm.Planar_code(L); code.qubit_matrix = m.copy()
+        s = Stream(seed); install(s, tm, pm, mc)
+        ch = mc.Chain(p, code)
+        samples = dec.STDC_droplet(ch, steps, False, 0)
+        restore(tm, pm, mc)
+        tag = f"sdrop{i}"
+        out[f"{tag}_init"] = m
+        out[f"{tag}_hist"] = np.bincount(np.array(list(samples.values()), dtype=np.int64), minlength=m.size + 1).astype(np.uint32)
+        out[f"{tag}_final"] = ch.code.qubit_matrix.astype(np.uint8)
+        out[f"{tag}_par"] = np.array([L, p, steps, seed, s.n], dtype=np.float64)
+        cases.append(tag)
+    for i, (L, p_error, p_sampling, steps, perr) in enumerate([(3, 0.1, None, 500, 0.15), (4, 0.08, 0.2, 300, 0.1)]):
+        m = rand_planar(rng, L, perr)
+        seed = 8300 + i
+        inits = []
+        for op in range(4):                                   # one representative per class (the list form, :273-280)
+            c = pm.Planar_code(L); c.qubit_matrix, _ = pm._apply_logical(m.copy(), op, 0, 0)
+            inits.append(c)
+        inits.sort(key=lambda c: c.define_equivalence_class())
+        s = Stream(seed); install(s, tm, pm, mc)
+        dist = dec.STDC(inits, p_error, p_sampling=p_sampling, droplets=1, steps=steps, conv_mult=0)
+        restore(tm, pm, mc)
+        tag = f"stdc{i}"
+        out[f"{tag}_classes"] = np.array([c.qubit_matrix for c in inits], dtype=np.uint8)
+        out[f"{tag}_dist"] = np.asarray(dist, dtype=np.float64)
+        out[f"{tag}_par"] = np.array([L, p_error, p_sampling or p_error, steps, seed, s.n], dtype=np.float64)
+        cases.append(tag)
     out["cases"] = np.array(cases)
     np.savez_compressed(os.path.join(HERE, "f_ptdc.npz"), **out)
     print("f_ptdc.npz", cases)

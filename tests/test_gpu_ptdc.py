@@ -78,3 +78,52 @@ def test_ptdc_dropin_matches_exact_classes(q, orc):
     # the same ladders through the oracle
     hist = orc.ptdc_batch(orc.TORIC, _toric_reps(q, m)[None], p, 3, 6000 // 3, droplets=4, seed=17)
     assert np.array_equal(pct, orc.ptdc_distribution(hist[0], p).astype(np.uint8))
+
+
+def _planar_reps(rng, L, p):
+    from qecmc import planar_model as pm
+    m = np.zeros((2, L, L), dtype=np.uint8)
+    err = rng.random(m.shape) < p
+    m[err] = rng.integers(1, 4, size=int(err.sum()), dtype=np.uint8)
+    m[1, -1, :] = 0; m[1, :, -1] = 0
+    reps = sorted((pm.apply_logical(m, op, 0, 0)[0] for op in range(4)), key=lambda r: int(pm.eq_class(r)))
+    return m, np.stack(reps)
+
+
+def test_stdc_is_the_one_chain_case(q, orc):
+    """STDC_droplet (decoders.py:236-265): single chains, `update_chain_fast(5)` per step = Nc = 1, iters = 5."""
+    rng = np.random.default_rng(21)
+    init = np.stack([_planar_reps(rng, 5, 0.1)[1] for _ in range(3)])
+    got = q.ptdc_batch(init, 0.15, Nc=1, steps=400, droplets=3, iters=5, seed=8, first_syndrome=2, code=q.PLANAR)
+    ref = orc.ptdc_batch(orc.PLANAR, init, 0.15, 1, 400, droplets=3, iters=5, seed=8, first_syndrome=2)
+    assert np.array_equal(got, ref) and got.sum() > 1000
+    # the drop-in with the list form of init_code (no rain)
+    codes = []
+    for r in init[0]:
+        c = q.Planar_code(5); c.qubit_matrix = r.copy(); codes.append(c)
+    dist = q.STDC(codes, 0.1, p_sampling=0.15, droplets=3, steps=400, seed=8)
+    ref1 = orc.ptdc_batch(orc.PLANAR, init[:1], 0.15, 1, 400, droplets=3, iters=5, seed=8)
+    assert dist.dtype == np.float64 and np.allclose(dist, orc.ptdc_distribution(ref1[0], 0.1), rtol=1e-12)
+    assert abs(dist.sum() - 100) < 1e-9
+
+
+def test_stdc_rain_start(q, orc):
+    """A single toric init_code: every droplet starts from apply_stabilizers_uniform() of the class representative
+    (decoders.py:246-247,289-294); the per-droplet starts travel through init_per_droplet."""
+    rng = np.random.default_rng(4)
+    code = q.Toric_code(3)
+    code.qubit_matrix = _rand_toric(rng, 3, 0.12)
+    np.random.seed(11)
+    dist = q.STDC(code, 0.1, droplets=2, steps=500, seed=3)
+    np.random.seed(11)                                   # replay the rain on the host to rebuild the droplets' starts
+    import copy
+    starts = []
+    for eq in range(16):
+        c = copy.deepcopy(code); c.qubit_matrix = c.to_class(eq)
+        starts.append(np.stack([c.apply_stabilizers_uniform() for _ in range(2)]))
+    init = np.stack(starts)[None]
+    assert all(orc.toric_eq_class(init[0, eq, d]) == eq for eq in range(16) for d in range(2))
+    ref = orc.ptdc_batch(orc.TORIC, init, 0.1, 1, 500, droplets=2, iters=5, seed=3)
+    assert np.allclose(dist, orc.ptdc_distribution(ref[0], 0.1), rtol=1e-12)
+    P = toric_class_probabilities(code.qubit_matrix, 0.1, orc.toric_apply_stabilizer, orc.toric_to_class) * 100
+    assert dist.argmax() == P.argmax()

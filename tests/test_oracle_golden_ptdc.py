@@ -49,6 +49,29 @@ def test_ptdc_percent(case):
     assert np.array_equal(pct, g[f"{case}_percent"])
 
 
+@pytest.mark.parametrize("case", _cases("sdrop"))
+def test_stdc_droplet_length_histogram(case):
+    """STDC_droplet (decoders.py:236-265) = the 1-chain ladder, 5 proposals per step (`update_chain_fast(5)`, :250)."""
+    g = _load()
+    L, p, steps, seed, ndraw = g[f"{case}_par"]
+    rng = orc.Rng.stream(_stream(int(seed), int(ndraw)))
+    hist, _ = orc.ptdc_droplet(orc.PLANAR, g[f"{case}_init"], float(p), 1, int(steps), iters=5, rng=rng)
+    assert rng.consumed == int(ndraw)
+    assert np.array_equal(hist, g[f"{case}_hist"])
+
+
+@pytest.mark.parametrize("case", _cases("stdc"))
+def test_stdc_distribution(case):
+    g = _load()
+    L, p_error, p_sampling, steps, seed, ndraw = g[f"{case}_par"]
+    rng = orc.Rng.stream(_stream(int(seed), int(ndraw)))
+    reps = g[f"{case}_classes"]
+    assert [orc.surf_eq_class(orc.PLANAR, r) for r in reps] == [0, 1, 2, 3]
+    hist = np.stack([orc.ptdc_droplet(orc.PLANAR, r, float(p_sampling), 1, int(steps), iters=5, rng=rng)[0] for r in reps])
+    assert rng.consumed == int(ndraw)
+    assert np.allclose(orc.ptdc_distribution(hist, float(p_error)), g[f"{case}_dist"], rtol=1e-12, atol=0)
+
+
 def test_state_key_and_set():
     r = np.random.default_rng(0)
     states = r.integers(0, 4, size=(2000, 50), dtype=np.uint8)
