@@ -175,10 +175,16 @@ int qecmc_pteq_batch(const qecmc_params *params, const uint8_t *init, uint64_t N
  * steps // Nc (:201).  Ladder l = (s * ncls + c) * droplets + d draws from Philox syndrome first_syndrome + l.
  * Uses params->{code,L,Nc,p,iters,steps,seed,first_syndrome,device}; p_logical is ignored (0).
  * STDC / STDC_droplet (decoders.py:236-322) is the same computation on 1-chain ladders: Nc = 1, iters = 5
- * (`chain.update_chain_fast(5)`, :250); its "rain" start (`apply_stabilizers_uniform` per droplet, :246-247) is passed in
- * with init_per_droplet != 0, init then being uint8[N][ncls][droplets][nq]. */
+ * (`chain.update_chain_fast(5)`, :250).
+ * flags: QECMC_PTDC_INIT_PER_DROPLET -- init is uint8[N][ncls][droplets][nq], a start of its own for every droplet
+ *        (STDC's "rain", `apply_stabilizers_uniform` per droplet, :246-247);
+ *        QECMC_PTDC_SET_PER_RUNG -- one set per (ladder, rung) instead of per (syndrome, class): PTRC_droplet's
+ *        per-rung dictionaries (decoders.py:584-631); the outputs are then uint32[N][ncls][droplets][Nc][nq+1].
+ * m_out (nullable, shaped like hist_out): m(n), the number of OBSERVATIONS of chains of length n (the len_counts of
+ * PTRC_droplet :606-618 and STRC_droplet :768-776), from which the host forms the STRC / PTRC estimates. */
+enum { QECMC_PTDC_INIT_PER_DROPLET = 1, QECMC_PTDC_SET_PER_RUNG = 2 };
 int qecmc_ptdc_batch(const qecmc_params *params, const uint8_t *init, uint64_t N, int32_t droplets,
-                     int32_t init_per_droplet, uint32_t *hist_out, qecmc_stats *stats_out);
+                     uint32_t flags, uint32_t *hist_out, uint32_t *m_out, qecmc_stats *stats_out);
 
 /* Plan + device-pointer form: build once (validates, uploads threshold tables),
  * then launch asynchronously on a caller stream with buffers already in HBM.

@@ -668,8 +668,8 @@ int qecmc_pteq_batch(const qecmc_params *params, const uint8_t *init, uint64_t N
     return 0;
 }
 
-int qecmc_ptdc_batch(const qecmc_params *params, const uint8_t *init, uint64_t N, int32_t droplets, int32_t init_per_droplet,
-                     uint32_t *hist_out, qecmc_stats *stats_out)
+int qecmc_ptdc_batch(const qecmc_params *params, const uint8_t *init, uint64_t N, int32_t droplets, uint32_t flags,
+                     uint32_t *hist_out, uint32_t *m_out, qecmc_stats *stats_out)
 {
     const auto t0 = std::chrono::steady_clock::now();
     if (!params) return fail(QECMC_ERR_INVALID, "params is NULL");
@@ -679,17 +679,20 @@ int qecmc_ptdc_batch(const qecmc_params *params, const uint8_t *init, uint64_t N
     if (p.noise != QECMC_NOISE_DEPOLARIZING) return fail(QECMC_ERR_UNSUPPORTED, "PTDC is defined for the depolarizing ladder (decoders.py:168)");
     if (p.scan != QECMC_SCAN_RANDOM) return fail(QECMC_ERR_UNSUPPORTED, "PTDC runs the reference's random-scan ladder");
     if (droplets < 1) return fail(QECMC_ERR_INVALID, "droplets=%d must be >= 1", droplets);
+    if (flags & ~3u) return fail(QECMC_ERR_INVALID, "unknown flags 0x%x", flags);
+    const bool init_per_droplet = flags & QECMC_PTDC_INIT_PER_DROPLET, per_rung = flags & QECMC_PTDC_SET_PER_RUNG;
     qecmc_plan *pl = nullptr;
     if (int rc = qecmc_plan_create(&p, &pl)) return rc;
     struct Guard { qecmc_plan *p; ~Guard() { delete p; } } guard{pl};
     if (N == 0) return 0;
     if (!init || !hist_out) return fail(QECMC_ERR_INVALID, "NULL buffer");
     const size_t nq = pl->args.nq, Nc = pl->args.Nc, ncls = pl->args.ncls, D = (size_t)droplets;
-    const uint64_t sets = N * ncls, M = sets * D;                    // ladders
+    const uint64_t M = N * ncls * D;                                  // ladders
+    const uint64_t sets = per_rung ? M * Nc : N * ncls;               // PTRC: one per (ladder, rung); PTDC: one per (syndrome, class)
     if (M > 0xFFFFFFFFull) return fail(QECMC_ERR_INVALID, "N * classes * droplets = %llu ladders exceed the 32-bit syndrome index", (unsigned long long)M);
     uint64_t cap = 16;
-    while (cap < 2 * p.steps * Nc * D) cap <<= 1;                     // twice the insertions one set can see
-    const uint64_t need = sets * cap * 8 + M * Nc * nq + M * Nc + M * 4 + sets * (nq + 1) * 4;
+    while (cap < 2 * p.steps * (per_rung ? 1 : Nc * D)) cap <<= 1;    // twice the insertions one set can see
+    const uint64_t need = sets * cap * 8 + M * Nc * nq + M * Nc + M * 4 + sets * (nq + 1) * 8;
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     if (need > free_b - free_b / 8)
@@ -697,16 +700,17 @@ int qecmc_ptdc_batch(const qecmc_params *params, const uint8_t *init, uint64_t N
                     (unsigned long long)need, (unsigned long long)sets, (unsigned long long)cap, free_b);
     // every ladder starts as Nc copies of its class representative, top flag set (Ladder.__init__, mcmc.py:72-75)
     std::vector<uint8_t> st((size_t)M * Nc * nq), fl((size_t)M * Nc, 0);
-    for (uint64_t sc = 0; sc < sets; ++sc)
+    for (uint64_t sc = 0; sc < N * ncls; ++sc)
         for (size_t d = 0; d < D; ++d) {
             const uint64_t l = sc * D + d;
             const uint8_t *src = init + (init_per_droplet ? l : sc) * nq;
             for (size_t c = 0; c < Nc; ++c) std::memcpy(&st[(l * Nc + c) * nq], src, nq);
             fl[l * Nc + Nc - 1] = 1;
         }
-    DevBuf ds, df, dt, dtab, dh;
+    DevBuf ds, df, dt, dtab, dh, dm;
     HIP_TRY(ds.alloc(st.size())); HIP_TRY(df.alloc(fl.size())); HIP_TRY(dt.alloc(M * 4));
     HIP_TRY(dtab.alloc(sets * cap * 8)); HIP_TRY(dh.alloc(sets * (nq + 1) * 4));
+    if (m_out) { HIP_TRY(dm.alloc(sets * (nq + 1) * 4)); HIP_TRY(hipMemset(dm.p, 0, sets * (nq + 1) * 4)); }
     HIP_TRY(hipMemcpy(ds.p, st.data(), st.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(df.p, fl.data(), fl.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(dt.p, 0, M * 4)); HIP_TRY(hipMemset(dtab.p, 0, sets * cap * 8)); HIP_TRY(hipMemset(dh.p, 0, sets * (nq + 1) * 4));
@@ -719,7 +723,8 @@ int qecmc_ptdc_batch(const qecmc_params *params, const uint8_t *init, uint64_t N
     for (uint64_t t = 0; t < p.steps; ++t) {
         a.step0 = t; a.prop0 = t * p.iters;
         hipError_t e = launch_ladder_rs_toric(a, 0);                                              // Ladder.step(iters), decoders.py:144
-        if (e == hipSuccess) e = launch_uset_insert(ds.as<uint8_t>(), M * Nc, (int)nq, (uint32_t)(Nc * D), dtab.as<uint64_t>(), cap, dh.as<uint32_t>(), 0);
+        if (e == hipSuccess) e = launch_uset_insert(ds.as<uint8_t>(), M * Nc, (int)nq, per_rung ? 1u : (uint32_t)(Nc * D), dtab.as<uint64_t>(), cap, dh.as<uint32_t>(),
+                                                       m_out ? dm.as<uint32_t>() : nullptr, 0);
         if (e != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return fail(QECMC_ERR_HIP, "PTDC step %llu: %s", (unsigned long long)t, hipGetErrorString(e)); }
     }
     HIP_TRY(hipEventRecord(e1, 0));
@@ -728,6 +733,7 @@ int qecmc_ptdc_batch(const qecmc_params *params, const uint8_t *init, uint64_t N
     HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     HIP_TRY(hipMemcpy(hist_out, dh.p, sets * (nq + 1) * 4, hipMemcpyDeviceToHost));
+    if (m_out) HIP_TRY(hipMemcpy(m_out, dm.p, sets * (nq + 1) * 4, hipMemcpyDeviceToHost));
     if (stats_out) {
         stats_out->proposals = M * Nc * p.iters * p.steps;
         stats_out->swap_tests = M * (Nc - 1) * p.steps;

@@ -96,6 +96,6 @@ struct ChainArgs {
 hipError_t launch_chain_update(const ChainArgs &a, hipStream_t s);
 // unique-chain set insertion (PTDC_droplet, decoders.py:146-152): states [nchains][nq], set of chain i = i / chains_per_set
 hipError_t launch_uset_insert(const uint8_t *states, uint64_t nchains, int nq, uint32_t chains_per_set, uint64_t *tab,
-                              uint64_t cap, uint32_t *hist, hipStream_t s);
+                              uint64_t cap, uint32_t *hist, uint32_t *mhist /* nullable: m(n), every observation */, hipStream_t s);
 
 }  // namespace qecmc

@@ -167,7 +167,7 @@ __global__ void k_chain_update(const ChainArgs a)
 // key = FNV-1a over the state bytes (the role of hash(qubit_matrix.tobytes())); the set of chain i is table i / chains_per_set
 // (open addressing, 0 = empty); a configuration that was not there yet adds one to hist[set][its length].
 __global__ void k_uset_insert(const uint8_t *states, uint64_t nchains, int nq, uint32_t chains_per_set,
-                              unsigned long long *tab, uint64_t cap, uint32_t *hist)
+                              unsigned long long *tab, uint64_t cap, uint32_t *hist, uint32_t *mhist)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nchains) return;
@@ -182,6 +182,7 @@ __global__ void k_uset_insert(const uint8_t *states, uint64_t nchains, int nq, u
     h ^= h >> 32;
     const unsigned long long key = h ? h : 1ull;
     const uint64_t set = i / chains_per_set;
+    if (mhist != nullptr) atomicAdd(mhist + set * (uint64_t)(nq + 1) + n, 1u);       // m(n): every observation (decoders.py:606-618)
     unsigned long long *t = tab + set * cap;
     uint64_t idx = ((key * 0x9E3779B97F4A7C15ull) >> 20) & (cap - 1);
     for (uint64_t probes = 0; probes < cap; ++probes) {          // the table is sized at twice the number of insertions
@@ -227,9 +228,9 @@ hipError_t launch_syndrome(int code, int L, uint64_t N, const uint8_t *in, uint8
     QECMC_LAUNCH(k_syndrome, N, s, code, L, N, in, defects);
 }
 hipError_t launch_uset_insert(const uint8_t *states, uint64_t nchains, int nq, uint32_t chains_per_set, uint64_t *tab,
-                              uint64_t cap, uint32_t *hist, hipStream_t s)
+                              uint64_t cap, uint32_t *hist, uint32_t *mhist, hipStream_t s)
 {
-    QECMC_LAUNCH(k_uset_insert, nchains, s, states, nchains, nq, chains_per_set, reinterpret_cast<unsigned long long *>(tab), cap, hist);
+    QECMC_LAUNCH(k_uset_insert, nchains, s, states, nchains, nq, chains_per_set, reinterpret_cast<unsigned long long *>(tab), cap, hist, mhist);
 }
 hipError_t launch_chain_update(const ChainArgs &a, hipStream_t s)
 {

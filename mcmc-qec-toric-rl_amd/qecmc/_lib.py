@@ -16,6 +16,7 @@ TORIC, XZZX, ROTATED, PLANAR = 0, 1, 2, 3
 SCAN_RANDOM, SCAN_CHECKERBOARD = 0, 1
 NOISE_DEPOLARIZING, NOISE_BIASED, NOISE_ALPHA = 0, 1, 2
 CONV_NONE, CONV_ERROR_BASED = 0, 1
+PTDC_INIT_PER_DROPLET, PTDC_SET_PER_RUNG = 1, 2
 
 
 class QecmcError(RuntimeError):
@@ -66,7 +67,7 @@ SIGNATURES = {
                                           C.c_uint64, C.c_uint64, C.c_uint64]),
     "qecmc_pteq_batch": (C.c_int, [C.POINTER(Params), _u8p, C.c_uint64, _u32p, _u32p, _u32p, _u32p, _u8p, _u8p,
                                    C.POINTER(Stats)]),
-    "qecmc_ptdc_batch": (C.c_int, [C.POINTER(Params), _u8p, C.c_uint64, C.c_int32, C.c_int32, _u32p, C.POINTER(Stats)]),
+    "qecmc_ptdc_batch": (C.c_int, [C.POINTER(Params), _u8p, C.c_uint64, C.c_int32, C.c_uint32, _u32p, _u32p, C.POINTER(Stats)]),
     "qecmc_plan_workspace_bytes": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "qecmc_plan_create": (C.c_int, [C.POINTER(Params), C.POINTER(C.c_void_p)]),
     "qecmc_plan_destroy": (C.c_int, [C.c_void_p]),

@@ -91,7 +91,7 @@ def _pteq(init_code, p, eta, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, conv_c
 
 
 def ptdc_batch(init, p_sampling, Nc=None, steps=2000, droplets=1, iters=10, seed=0, first_syndrome=0, device=0, code=L_.TORIC,
-               return_stats=False):
+               return_stats=False, per_rung=False, with_m=False):
     """The sampling half of PTDC (decoders.py:168-233, conv_mult = 0) on N syndromes at once.
 
     init: uint8[N, ncls, ...] -- one representative per equivalence class for every syndrome (what `to_class` / the list
@@ -99,7 +99,8 @@ def ptdc_batch(init, p_sampling, Nc=None, steps=2000, droplets=1, iters=10, seed
     For every (syndrome, class), `droplets` ladders without logical moves run `steps` ladder steps; returns N(n)
     uint32[N, ncls, nq+1], the number of DISTINCT chains of each length seen by any rung of any droplet (PTDC_droplet's
     dict, decoders.py:146-152,220-226).  `steps` is per ladder: PTDC passes steps // Nc (:201).  Nc = 1, iters = 5 is
-    STDC_droplet (:236-265)."""
+    STDC_droplet / STRC_droplet (:236-265, :745-830).  per_rung=True keeps one set per (ladder, rung) as PTRC_droplet
+    does (:584-631): shape [N, ncls, droplets, Nc, nq+1].  with_m=True also returns m(n), all observations by length."""
     nd = 3 if code in (L_.TORIC, L_.PLANAR) else 2
     a = np.ascontiguousarray(init, dtype=np.uint8)
     per_droplet = a.ndim == nd + 3
@@ -109,14 +110,19 @@ def ptdc_batch(init, p_sampling, Nc=None, steps=2000, droplets=1, iters=10, seed
     if ncls != (16 if code == L_.TORIC else 4):
         raise ValueError("one representative per equivalence class is needed")
     nq = int(np.prod(a.shape[-nd:]))
-    pr = L_.make_params(code=code, L=size, Nc=Nc or size, p=float(p_sampling), iters=int(iters), steps=int(steps), seed=seed,
+    Nc = Nc or size
+    pr = L_.make_params(code=code, L=size, Nc=Nc, p=float(p_sampling), iters=int(iters), steps=int(steps), seed=seed,
                         first_syndrome=first_syndrome, device=device)
-    hist = np.zeros((N, ncls, nq + 1), dtype=np.uint32)
+    shape = (N, ncls, int(droplets), Nc, nq + 1) if per_rung else (N, ncls, nq + 1)
+    hist = np.zeros(shape, dtype=np.uint32)
+    mh = np.zeros(shape, dtype=np.uint32) if with_m else None
     stats = L_.Stats()
-    L_.check(L_.lib().qecmc_ptdc_batch(pr, L_.u8(a), N, int(droplets), int(per_droplet), L_.u32(hist), stats))
+    flags = (L_.PTDC_INIT_PER_DROPLET if per_droplet else 0) | (L_.PTDC_SET_PER_RUNG if per_rung else 0)
+    L_.check(L_.lib().qecmc_ptdc_batch(pr, L_.u8(a), N, int(droplets), flags, L_.u32(hist), L_.u32(mh) if with_m else None, stats))
+    out = (hist, mh) if with_m else hist
     if return_stats:
-        return hist, dict(proposals=int(stats.proposals), kernel_ms=float(stats.kernel_ms), total_ms=float(stats.total_ms))
-    return hist
+        return out, dict(proposals=int(stats.proposals), kernel_ms=float(stats.kernel_ms), total_ms=float(stats.total_ms))
+    return out
 
 
 def ptdc_distribution(hist, p_error):
@@ -169,3 +175,82 @@ def STDC(init_code, p_error, p_sampling=None, droplets=10, steps=20000, conv_mul
     hist = ptdc_batch(init, p_sampling, Nc=1, steps=steps, droplets=droplets, iters=5, seed=_fresh_seed() if seed is None else seed,
                       code=_code_id(code0))
     return ptdc_distribution(hist[0], p_error)
+
+
+def strc_distribution(n_unique, m_obs, p_error, p_sampling):
+    """STRC's estimate (decoders.py:863-949) from the counts of one syndrome: n_unique[c, n] = N(n), the distinct chains of
+    length n of class c (union over the droplets); m_obs[c, n] = m(n), all observations (summed over the droplets).
+    Z_e = sum_l m(l) exp(-beta_s n0 + d_beta l) x mean fraction of distinct chains at the two shortest lengths."""
+    from math import exp, log
+    beta_error = -log((p_error / 3) / (1 - p_error))
+    beta_sampling = -log((p_sampling / 3) / (1 - p_sampling))
+    d_beta = beta_sampling - beta_error
+    Z = np.zeros(n_unique.shape[0])
+    for c in range(n_unique.shape[0]):
+        lengths = np.flatnonzero(m_obs[c])
+        shortest = int(lengths[0])
+        fraction = n_unique[c, shortest] / m_obs[c, shortest]                                  # :925-926
+        if len(lengths) > 1:                                                                   # :931-933
+            nxt = int(lengths[1])
+            fraction = 0.5 * (fraction + n_unique[c, nxt] / m_obs[c, nxt] * exp(-beta_sampling * (nxt - shortest)))
+        Z[c] = sum(int(m_obs[c, l]) * exp(-beta_sampling * shortest + d_beta * int(l)) for l in lengths) * fraction   # :939
+    return Z / np.sum(Z) * 100
+
+
+def ptrc_distribution(n_unique, m_obs, p_error, p_sampling):
+    """PTRC's estimate (decoders.py:684-742) from the per-rung counts of one syndrome, n_unique / m_obs[c, droplet, rung, n]
+    (N(n) and m(n) are summed over the droplets, :705-717; the top rung is left out, :720)."""
+    from math import log
+    Nc = n_unique.shape[2]
+    p_ladder = np.linspace(p_sampling, 0.75, Nc)
+    beta_error = -log((p_error / 3) / (1 - p_error))
+    beta_ladder = -np.log((p_ladder[:-1] / 3) / (1 - p_ladder[:-1]))
+    d_beta = beta_ladder - beta_error
+    Nn, mn = n_unique.sum(axis=1).astype(np.float64), m_obs.sum(axis=1).astype(np.float64)
+    Z = np.zeros(n_unique.shape[0])
+    for c in range(n_unique.shape[0]):
+        for i in range(Nc - 1):
+            lengths = np.flatnonzero(mn[c, i])
+            counts = np.stack([Nn[c, i, lengths], mn[c, i, lengths]], axis=1)
+            C_mean = np.mean(counts[:2, 0] / counts[:2, 1] * np.exp(-beta_ladder[i] * (lengths[:2] - lengths[0])))     # :732
+            Z[c] += C_mean * (counts[:, 1] * np.exp(lengths * d_beta[i] - beta_ladder[i] * lengths[0])).sum()          # :735
+    return (Z / np.sum(Z) * 100).astype(np.uint8)
+
+
+def _class_starts(init_code, droplets, rain):
+    """[1, classes, (droplets,) ...] starts from a list with one code per class, or from a code with `to_class`
+    (then, with rain, every droplet starts from apply_stabilizers_uniform(), decoders.py:246-247)."""
+    import copy
+    if isinstance(init_code, list):
+        assert len(init_code) == init_code[0].nbr_eq_classes, 'if init_code is a list, it has to contain one code for each class'
+        return init_code[0], np.stack([c.qubit_matrix for c in init_code])[None]
+    reps = []
+    for eq in range(init_code.nbr_eq_classes):
+        c = copy.deepcopy(init_code)
+        c.qubit_matrix = c.to_class(eq)
+        reps.append(np.stack([c.apply_stabilizers_uniform() for _ in range(droplets)]) if rain else c.qubit_matrix)
+    return init_code, np.stack(reps)[None]
+
+
+def STRC(init_code, p_error, p_sampling=None, droplets=10, steps=20000, conv_mult=0, seed=None):
+    """Drop-in for decoders.STRC (decoders.py:835-949): single chains as in STDC; the estimate uses m(n) and the number of
+    distinct chains at the two shortest lengths.  Returns the float percent vector.  conv_mult must be 0."""
+    if conv_mult:
+        raise NotImplementedError("STRC's conv_mult early stop is not built; pass conv_mult=0 (the reference's default)")
+    p_sampling = p_sampling or p_error
+    code0, init = _class_starts(init_code, droplets, rain=True)
+    n_u, m_o = ptdc_batch(init, p_sampling, Nc=1, steps=steps, droplets=droplets, iters=5, with_m=True,
+                          seed=_fresh_seed() if seed is None else seed, code=_code_id(code0))
+    return strc_distribution(n_u[0], m_o[0], p_error, p_sampling)
+
+
+def PTRC(init_code, p_error, p_sampling=None, droplets=4, Nc=None, steps=20000, conv_mult=2.0, seed=None):
+    """Drop-in for decoders.PTRC (decoders.py:638-742): class ladders as in PTDC, per-rung N(n) and m(n), curve estimate
+    per rung.  Returns the uint8 percent vector.  (conv_mult is accepted and, as in the reference -- whose early stop is
+    commented out, :627-630 -- has no effect.)"""
+    p_sampling = p_sampling or p_error
+    code0, init = _class_starts(init_code, droplets, rain=False)
+    Nc = Nc or code0.system_size
+    n_u, m_o = ptdc_batch(init, p_sampling, Nc=Nc, steps=steps // Nc, droplets=droplets, per_rung=True, with_m=True,
+                          seed=_fresh_seed() if seed is None else seed, code=_code_id(code0))
+    return ptrc_distribution(n_u[0], m_o[0], p_error, p_sampling)

@@ -771,7 +771,7 @@ int orc_uset_insert(uint64_t *tab, uint64_t cap, uint64_t key)
 }
 
 void orc_ptdc_droplet(const orc_model *m, const uint8_t *init, double p_sampling, int Nc, uint64_t steps, uint64_t iters,
-                      orc_rng *rng, uint64_t *tab, uint64_t cap, uint32_t *hist)
+                      orc_rng *rng, uint64_t *tab, uint64_t cap, uint32_t *hist, int per_rung, uint32_t *mhist)
 {
     orc_ladder *ld = orc_ladder_new(m, init, p_sampling, Nc, 0.0);      /* decoders.py:182,196: no p_logical */
     const size_t nq = (size_t)ld->nq;
@@ -779,7 +779,10 @@ void orc_ptdc_droplet(const orc_model *m, const uint8_t *init, double p_sampling
         orc_ladder_step(ld, iters, rng);                                /* :144 */
         for (int c = 0; c < Nc; ++c) {                                  /* :146-152 */
             const uint8_t *st = ld->states + (size_t)c * nq;
-            if (orc_uset_insert(tab, cap, orc_state_key(st, nq))) hist[orc_count_errors(nq, st)]++;
+            const size_t set = per_rung ? (size_t)c : 0;
+            const uint64_t n = orc_count_errors(nq, st);
+            if (orc_uset_insert(tab + set * cap, cap, orc_state_key(st, nq))) hist[set * (nq + 1) + n]++;
+            if (mhist) mhist[set * (nq + 1) + n]++;
         }
     }
     orc_ladder_free(ld);
@@ -787,11 +790,11 @@ void orc_ptdc_droplet(const orc_model *m, const uint8_t *init, double p_sampling
 
 void orc_ptdc_batch(const orc_model *m, const uint8_t *init, uint64_t N, int ncls, int D, int init_per_droplet,
                     uint32_t first_syndrome, double p_sampling, int Nc, uint64_t steps, uint64_t iters, uint64_t seed,
-                    int n_threads, uint32_t *hist_out)
+                    int n_threads, uint32_t *hist_out, int per_rung, uint32_t *mhist_out)
 {
     const size_t nq = (size_t)orc_nq(m->code, m->L);
     uint64_t cap = 16;
-    while (cap < 2 * steps * (uint64_t)Nc * (uint64_t)D) cap <<= 1;
+    while (cap < 2 * steps * (per_rung ? 1u : (uint64_t)Nc * (uint64_t)D)) cap <<= 1;
 #ifdef _OPENMP
     if (n_threads > 0) omp_set_num_threads(n_threads);
 #else
@@ -799,13 +802,18 @@ void orc_ptdc_batch(const orc_model *m, const uint8_t *init, uint64_t N, int ncl
 #endif
 #pragma omp parallel for schedule(dynamic, 1)
     for (int64_t sc = 0; sc < (int64_t)(N * (uint64_t)ncls); ++sc) {
-        uint64_t *tab = (uint64_t *)calloc(cap, sizeof(uint64_t));
-        uint32_t *hist = hist_out + (size_t)sc * (nq + 1);
-        memset(hist, 0, (nq + 1) * sizeof(uint32_t));
+        uint64_t *tab = (uint64_t *)calloc(cap * (per_rung ? (size_t)Nc : 1), sizeof(uint64_t));
         for (int d = 0; d < D; ++d) {
+            const size_t out = per_rung ? ((size_t)sc * D + d) * Nc * (nq + 1) : (size_t)sc * (nq + 1);
+            if (per_rung || d == 0) {
+                memset(hist_out + out, 0, (per_rung ? Nc : 1) * (nq + 1) * sizeof(uint32_t));
+                if (mhist_out) memset(mhist_out + out, 0, (per_rung ? Nc : 1) * (nq + 1) * sizeof(uint32_t));
+            }
+            if (per_rung) memset(tab, 0, cap * (size_t)Nc * sizeof(uint64_t));
             orc_rng rng;
             orc_rng_init_philox(&rng, seed, first_syndrome + (uint32_t)(sc * D + d));
-            orc_ptdc_droplet(m, init + (size_t)(init_per_droplet ? sc * D + d : sc) * nq, p_sampling, Nc, steps, iters, &rng, tab, cap, hist);
+            orc_ptdc_droplet(m, init + (size_t)(init_per_droplet ? sc * D + d : sc) * nq, p_sampling, Nc, steps, iters, &rng, tab, cap,
+                             hist_out + out, per_rung, mhist_out ? mhist_out + out : NULL);
         }
         free(tab);
     }

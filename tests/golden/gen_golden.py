@@ -591,6 +591,37 @@ def gen_ptdc(tm, pm, mc, dec):
         out[f"{tag}_dist"] = np.asarray(dist, dtype=np.float64)
         out[f"{tag}_par"] = np.array([L, p_error, p_sampling or p_error, steps, seed, s.n], dtype=np.float64)
         cases.append(tag)
+    # STRC (decoders.py:745-949, planar list form) and PTRC (:584-742, toric list form): curve-fit estimators on N(n), m(n)
+    for i, (L, p_error, p_sampling, steps, perr) in enumerate([(3, 0.1, None, 500, 0.15), (4, 0.08, 0.25, 400, 0.1)]):
+        m = rand_planar(rng, L, perr)
+        seed = 8400 + i
+        inits = []
+        for op in range(4):
+            c = pm.Planar_code(L); c.qubit_matrix, _ = pm._apply_logical(m.copy(), op, 0, 0)
+            inits.append(c)
+        inits.sort(key=lambda c: c.define_equivalence_class())
+        s = Stream(seed); install(s, tm, pm, mc)
+        dist = dec.STRC(inits, p_error, p_sampling=p_sampling, droplets=1, steps=steps, conv_mult=0)
+        restore(tm, pm, mc)
+        tag = f"strc{i}"
+        out[f"{tag}_classes"] = np.array([c.qubit_matrix for c in inits], dtype=np.uint8)
+        out[f"{tag}_dist"] = np.asarray(dist, dtype=np.float64)
+        out[f"{tag}_par"] = np.array([L, p_error, p_sampling or p_error, steps, seed, s.n], dtype=np.float64)
+        cases.append(tag)
+    for i, (L, p_error, p_sampling, Nc, steps, perr) in enumerate([(3, 0.1, None, 3, 900, 0.15), (3, 0.08, 0.2, 4, 800, 0.1)]):
+        m = rand_matrix(rng, L, perr)
+        seed = 8500 + i
+        inits = []
+        for eq in range(16):
+            c = tm.Toric_code(L); c.qubit_matrix = tm._to_class(eq, m.copy()); inits.append(c)
+        s = Stream(seed); install(s, tm, pm, mc)
+        pct = dec.PTRC(inits, p_error, p_sampling=p_sampling, droplets=1, Nc=Nc, steps=steps)
+        restore(tm, pm, mc)
+        tag = f"ptrc{i}"
+        out[f"{tag}_classes"] = np.array([c.qubit_matrix for c in inits], dtype=np.uint8)
+        out[f"{tag}_percent"] = np.asarray(pct, dtype=np.uint8)
+        out[f"{tag}_par"] = np.array([L, p_error, p_sampling or p_error, Nc, steps, seed, s.n], dtype=np.float64)
+        cases.append(tag)
     out["cases"] = np.array(cases)
     np.savez_compressed(os.path.join(HERE, "f_ptdc.npz"), **out)
     print("f_ptdc.npz", cases)

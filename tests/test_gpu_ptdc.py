@@ -127,3 +127,39 @@ def test_stdc_rain_start(q, orc):
     assert np.allclose(dist, orc.ptdc_distribution(ref[0], 0.1), rtol=1e-12)
     P = toric_class_probabilities(code.qubit_matrix, 0.1, orc.toric_apply_stabilizer, orc.toric_to_class) * 100
     assert dist.argmax() == P.argmax()
+
+
+def test_per_rung_sets_and_observation_counts(q, orc):
+    """PTRC_droplet's bookkeeping (decoders.py:584-631): one set per (ladder, rung), N(n) and m(n)."""
+    rng = np.random.default_rng(31)
+    init = np.stack([_toric_reps(q, _rand_toric(rng, 3, 0.12)) for _ in range(2)])
+    got_n, got_m = q.ptdc_batch(init, 0.1, Nc=4, steps=150, droplets=2, seed=6, first_syndrome=1, per_rung=True, with_m=True)
+    ref_n, ref_m = orc.ptdc_batch(orc.TORIC, init, 0.1, 4, 150, droplets=2, seed=6, first_syndrome=1, per_rung=True, with_m=True)
+    assert got_n.shape == (2, 16, 2, 4, 19)
+    assert np.array_equal(got_n, ref_n) and np.array_equal(got_m, ref_m)
+    assert np.all(got_m.sum(axis=-1) == 150) and np.all(got_n <= got_m)
+    # shared sets with m(n): the single-chain form STRC uses
+    got_n, got_m = q.ptdc_batch(init, 0.2, Nc=1, steps=300, droplets=3, iters=5, seed=6, with_m=True)
+    ref_n, ref_m = orc.ptdc_batch(orc.TORIC, init, 0.2, 1, 300, droplets=3, iters=5, seed=6, with_m=True)
+    assert np.array_equal(got_n, ref_n) and np.array_equal(got_m, ref_m) and np.all(got_m.sum(axis=-1) == 900)
+
+
+def test_strc_ptrc_dropins(q, orc):
+    from qecmc.decoders import strc_distribution, ptrc_distribution
+    rng = np.random.default_rng(5)
+    m = _rand_toric(rng, 3, 0.12)
+    p = 0.1
+    P = toric_class_probabilities(m, p, orc.toric_apply_stabilizer, orc.toric_to_class) * 100
+    codes = []
+    for r in _toric_reps(q, m):
+        c = q.Toric_code(3); c.qubit_matrix = r.copy(); codes.append(c)
+    pct = q.PTRC(codes, p, droplets=3, Nc=3, steps=6000, seed=9)
+    n_u, m_o = orc.ptdc_batch(orc.TORIC, _toric_reps(q, m)[None], p, 3, 2000, droplets=3, seed=9, per_rung=True, with_m=True)
+    assert pct.dtype == np.uint8 and np.array_equal(pct, ptrc_distribution(n_u[0], m_o[0], p, p))
+    assert 0.5 * np.abs(pct.astype(np.float64) - P).sum() < 10.0     # (the two leading classes of this syndrome are degenerate: no argmax test)
+    dist = q.STRC(codes, p, p_sampling=0.2, droplets=3, steps=3000, seed=10)
+    n_u, m_o = orc.ptdc_batch(orc.TORIC, _toric_reps(q, m)[None], 0.2, 1, 3000, droplets=3, iters=5, seed=10, with_m=True)
+    assert np.allclose(dist, strc_distribution(n_u[0], m_o[0], p, 0.2), rtol=1e-12)
+    assert 0.5 * np.abs(dist - P).sum() < 10.0
+    with pytest.raises(NotImplementedError):
+        q.STRC(codes, p, conv_mult=2.0)

@@ -72,6 +72,34 @@ def test_stdc_distribution(case):
     assert np.allclose(orc.ptdc_distribution(hist, float(p_error)), g[f"{case}_dist"], rtol=1e-12, atol=0)
 
 
+@pytest.mark.parametrize("case", _cases("strc"))
+def test_strc_distribution(case):
+    """STRC (decoders.py:745-949): N(n) at the two shortest lengths and m(n) of the single chains, then the host formula
+    (qecmc.decoders.strc_distribution, pure NumPy)."""
+    from qecmc.decoders import strc_distribution
+    g = _load()
+    L, p_error, p_sampling, steps, seed, ndraw = g[f"{case}_par"]
+    rng = orc.Rng.stream(_stream(int(seed), int(ndraw)))
+    res = [orc.ptdc_droplet(orc.PLANAR, r, float(p_sampling), 1, int(steps), iters=5, rng=rng, with_m=True) for r in g[f"{case}_classes"]]
+    assert rng.consumed == int(ndraw)
+    dist = strc_distribution(np.stack([r[0] for r in res]), np.stack([r[1] for r in res]), float(p_error), float(p_sampling))
+    assert np.allclose(dist, g[f"{case}_dist"], rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("case", _cases("ptrc"))
+def test_ptrc_percent(case):
+    """PTRC (decoders.py:584-742): per-rung N(n) and m(n) of the class ladders, then qecmc.decoders.ptrc_distribution."""
+    from qecmc.decoders import ptrc_distribution
+    g = _load()
+    L, p_error, p_sampling, Nc, steps, seed, ndraw = g[f"{case}_par"]
+    rng = orc.Rng.stream(_stream(int(seed), int(ndraw)))
+    res = [orc.ptdc_droplet(orc.TORIC, r, float(p_sampling), int(Nc), int(steps) // int(Nc), rng=rng, per_rung=True, with_m=True)
+           for r in g[f"{case}_classes"]]
+    assert rng.consumed == int(ndraw)
+    pct = ptrc_distribution(np.stack([r[0] for r in res])[:, None], np.stack([r[1] for r in res])[:, None], float(p_error), float(p_sampling))
+    assert np.array_equal(pct, g[f"{case}_percent"])
+
+
 def test_state_key_and_set():
     r = np.random.default_rng(0)
     states = r.integers(0, 4, size=(2000, 50), dtype=np.uint8)
