@@ -254,3 +254,13 @@ def PTRC(init_code, p_error, p_sampling=None, droplets=4, Nc=None, steps=20000, 
     n_u, m_o = ptdc_batch(init, p_sampling, Nc=Nc, steps=steps // Nc, droplets=droplets, per_rung=True, with_m=True,
                           seed=_fresh_seed() if seed is None else seed, code=_code_id(code0))
     return ptrc_distribution(n_u[0], m_o[0], p_error, p_sampling)
+
+
+def single_temp(init_code, p, max_iters, seed=None):
+    """Drop-in for decoders.single_temp (decoders.py:108-135): one chain per class at p, `update_chain_fast(5)` per step; the
+    mean number of errors over the first max_iters - 1 steps (`np.average(nbr_errors_chain[eq, :j])` with j = max_iters - 1)."""
+    code0, init = _class_starts(init_code, 1, rain=False)
+    _, m_o = ptdc_batch(init, p, Nc=1, steps=max_iters - 1, droplets=1, iters=5, with_m=True,
+                        seed=_fresh_seed() if seed is None else seed, code=_code_id(code0))
+    n = np.arange(m_o.shape[-1], dtype=np.float64)
+    return (m_o[0] * n).sum(axis=-1) / (max_iters - 1)

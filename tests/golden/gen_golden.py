@@ -622,6 +622,23 @@ def gen_ptdc(tm, pm, mc, dec):
         out[f"{tag}_percent"] = np.asarray(pct, dtype=np.uint8)
         out[f"{tag}_par"] = np.array([L, p_error, p_sampling or p_error, Nc, steps, seed, s.n], dtype=np.float64)
         cases.append(tag)
+    # single_temp (decoders.py:108-135): mean chain length per class from single chains, update_chain_fast(5) per step
+    for i, (L, p, max_iters, perr) in enumerate([(3, 0.12, 300, 0.15), (5, 0.2, 200, 0.1)]):
+        m = rand_planar(rng, L, perr)
+        seed = 8600 + i
+        inits = []
+        for op in range(4):
+            c = pm.Planar_code(L); c.qubit_matrix, _ = pm._apply_logical(m.copy(), op, 0, 0)
+            inits.append(c)
+        inits.sort(key=lambda c: c.define_equivalence_class())
+        s = Stream(seed); install(s, tm, pm, mc)
+        means = dec.single_temp(inits, p, max_iters)
+        restore(tm, pm, mc)
+        tag = f"stemp{i}"
+        out[f"{tag}_classes"] = np.array([c.qubit_matrix for c in inits], dtype=np.uint8)
+        out[f"{tag}_means"] = np.asarray(means, dtype=np.float64)
+        out[f"{tag}_par"] = np.array([L, p, max_iters, seed, s.n], dtype=np.float64)
+        cases.append(tag)
     out["cases"] = np.array(cases)
     np.savez_compressed(os.path.join(HERE, "f_ptdc.npz"), **out)
     print("f_ptdc.npz", cases)

@@ -163,3 +163,14 @@ def test_strc_ptrc_dropins(q, orc):
     assert 0.5 * np.abs(dist - P).sum() < 10.0
     with pytest.raises(NotImplementedError):
         q.STRC(codes, p, conv_mult=2.0)
+
+
+def test_single_temp_dropin(q, orc):
+    rng = np.random.default_rng(41)
+    _, reps = _planar_reps(rng, 5, 0.1)
+    codes = []
+    for r in reps:
+        c = q.Planar_code(5); c.qubit_matrix = r.copy(); codes.append(c)
+    means = q.single_temp(codes, 0.2, 400, seed=2)
+    _, m_o = orc.ptdc_batch(orc.PLANAR, reps[None], 0.2, 1, 399, droplets=1, iters=5, seed=2, with_m=True)
+    assert np.allclose(means, (m_o[0] * np.arange(m_o.shape[-1])).sum(axis=-1) / 399, rtol=1e-12) and means.shape == (4,)

@@ -100,6 +100,22 @@ def test_ptrc_percent(case):
     assert np.array_equal(pct, g[f"{case}_percent"])
 
 
+@pytest.mark.parametrize("case", _cases("stemp"))
+def test_single_temp_means(case):
+    """single_temp (decoders.py:108-135): mean chain length over the first max_iters - 1 steps; the reference runs (and
+    draws for) max_iters steps per class."""
+    g = _load()
+    L, p, max_iters, seed, ndraw = g[f"{case}_par"]
+    rng = orc.Rng.stream(_stream(int(seed), int(ndraw)))
+    means = []
+    for r in g[f"{case}_classes"]:
+        _, m_o, _ = orc.ptdc_droplet(orc.PLANAR, r, float(p), 1, int(max_iters) - 1, iters=5, rng=rng, with_m=True)
+        orc.chain_update(orc.PLANAR, r, float(p), 0.0, 5, rng)      # the last step's draws (its length is not averaged)
+        means.append((m_o * np.arange(m_o.size)).sum() / (int(max_iters) - 1))
+    assert rng.consumed == int(ndraw)
+    assert np.allclose(means, g[f"{case}_means"], rtol=1e-12)
+
+
 def test_state_key_and_set():
     r = np.random.default_rng(0)
     states = r.integers(0, 4, size=(2000, 50), dtype=np.uint8)
