@@ -1,4 +1,5 @@
-// Random-scan parallel-tempering ladder kernel for the toric code (gfx950).
+// Random-scan parallel-tempering ladder kernel (gfx950): toric, XZZX, rotated and planar codes; depolarizing, biased and
+// alpha acceptance rules; the reference's random scan and the systematic sweep.
 //
 // This is the reference's Markov chain (src/mcmc.py:19-43 Chain.update_chain,
 // :94-103 Ladder.step, decoders.py:55-68 PTEQ bookkeeping) laid out for CDNA4:
@@ -12,10 +13,10 @@
 //     per qubit: word w of state s of lane l sits at dword (s*W + w)*64 + l, so a
 //     wave's ds_read_b32 / ds_xor_b32 hit bank (l mod 32) whatever (s, w) each
 //     lane picks: random-scan access with zero bank conflicts, and addresses
-//     need shifts only.
-//   * proposals: one Philox4x32-10 block = the four uniforms (row, col, op,
-//     accept) of one proposal; accept tests are integer compares against
-//     host-built thresholds ceil(f^dE * 2^32), so results are bit-identical to
+//     need one add only.
+//   * proposals: one Philox4x32-10 block feeds TWO non-top proposals (a word that picks one of the G generators,
+//     g = (x * G) >> 32, and the acceptance word, each); the generator's sites come from an LDS table; accept tests
+//     are integer compares against host-built thresholds ceil(f^dE * 2^32), so results are bit-identical to
 //     the CPU oracle fed the same Philox stream.
 //   * the top slot sits at p = 0.75 where every proposal is accepted
 //     (mcmc.py:30): its moves are fire-and-forget LDS XORs (no reads, no dE) and
@@ -26,7 +27,8 @@
 //   * one barrier per ladder step: every wave publishes its slot record (error
 //     count, state id, class, flag) and then replays the whole top-down swap
 //     cascade (mcmc.py:96-103) itself from those records to learn which state
-//     lands in its own slot -- a few integer ops per rung, no serial section
+//     lands in its own slot -- a few integer ops per rung (the swap uniform is turned into the largest accepted
+//     error-count difference before the barrier), no serial section
 //     that leaves seven waves idle, no second barrier.
 //   * HBM traffic is compulsory only: nq bytes in, ncls counters out per syndrome.
 #include "kernels.hpp"

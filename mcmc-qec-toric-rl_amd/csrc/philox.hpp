@@ -1,6 +1,6 @@
 // Philox4x32-10 counter-based RNG (Salmon et al., SC'11) for gfx950.
-// One call = one 128-bit block = the four uniforms of one Metropolis proposal
-// (row, col, op, accept; src/mcmc.py:38-42 draws exactly four per proposal).
+// One call = one 128-bit block: the draws of one top-chain proposal, or of two non-top proposals (a generator word and
+// an acceptance word each) -- DESIGN.md "RNG addressing".
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -11,8 +11,9 @@ struct u32x4 { uint32_t x, y, z, w; };
 
 // Counter layout (DESIGN.md "RNG addressing"):
 //   c0 = k[31:0], c1 = k[47:32] | sub<<16, c2 = global syndrome index, c3 = stream id
-//   key = 64-bit seed.  k = proposal index of the slot (or ladder-step index for the
-//   swap stream), sub = block number within one proposal / swap sweep.
+//   key = 64-bit seed.  k = proposal index of the slot (halved for the paired non-top blocks; ladder-step index for the
+//   swap stream), sub = 0 top-chain proposal, 1 paired non-top proposals, 2 top-chain acceptance, 3 sweep mode;
+//   for the swap stream the block number within one swap sweep.
 constexpr uint32_t kSwapStream = 0x100u;
 
 __host__ __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c)
