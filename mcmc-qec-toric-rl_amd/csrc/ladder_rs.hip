@@ -59,15 +59,13 @@ __device__ __forceinline__ uint32_t sel4(const u32x4 &b, int i)
     return i == 0 ? b.x : i == 1 ? b.y : i == 2 ? b.z : b.w;
 }
 
-// single-instruction forms that rely on the hardware using only bits [4:0] of a shift / field offset (the compiler
-// otherwise materialises the `& 31`)
+// single-instruction forms: the hardware uses only bits [4:0] of a shift amount / field offset, so the upper bits of the
+// table entry that supplies them need no masking
 __device__ __forceinline__ uint32_t bfe2_lo5(uint32_t w, uint32_t e)
 {
-    uint32_t r;
-    asm("v_bfe_u32 %0, %1, %2, 2" : "=v"(r) : "v"(w), "v"(e));
-    return r;
+    return __builtin_amdgcn_ubfe(w, e, 2u);                 // v_bfe_u32 w, e, 2
 }
-// (a << k) | b in one instruction
+// (a << k) | b in one instruction (left to itself the compiler merges three fields with three shifts and two ors)
 __device__ __forceinline__ uint32_t lshl_or(uint32_t a, int k, uint32_t b)
 {
     uint32_t r;
@@ -77,9 +75,7 @@ __device__ __forceinline__ uint32_t lshl_or(uint32_t a, int k, uint32_t b)
 
 __device__ __forceinline__ uint32_t shl_lo5(uint32_t v, uint32_t e)
 {
-    uint32_t r;
-    asm("v_lshlrev_b32 %0, %1, %2" : "=v"(r) : "v"(e), "v"(v));
-    return r;
+    return v << (e & 31u);                                  // v_lshlrev_b32: the mask folds away
 }
 
 __device__ __forceinline__ void lds_xor(uint32_t *p, uint32_t v)
