@@ -259,6 +259,10 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
     if (n_gen > kMaxGenLds)   // every kernel path stages the generator table in LDS
         return fail(QECMC_ERR_UNSUPPORTED, "L=%d: %u generators exceed the LDS table of %u (needed by scan=1 and by the xzzx / rotated codes)", L, n_gen, kMaxGenLds);
     pl->lds_bytes = ladder_lds_bytes(L, Nc, W, ncls, ladder_gen_dwords(p->code, p->noise, p->scan, n_gen, Nc));
+    if (biased) {   // the rule's power tables go to LDS when two workgroups still fit a CU (they are read per lane, per proposal)
+        const size_t with = ladder_lds_bytes(L, Nc, W, ncls, ladder_gen_dwords(p->code, p->noise, p->scan, n_gen, Nc, nq, 1));
+        if (with <= 80 * 1024) { a.bias_lds = 1; pl->lds_bytes = with; }
+    }
     if (pl->lds_bytes > 160 * 1024)
         return fail(QECMC_ERR_UNSUPPORTED, "L=%d Nc=%d needs %zu B of LDS per workgroup (> 160 KiB)", L, Nc, pl->lds_bytes);
 

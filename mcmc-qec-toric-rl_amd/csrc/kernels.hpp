@@ -25,6 +25,7 @@ struct LadderArgs {
     const uint32_t *lmask;    // [4][L+1][W]       logical-operator XOR masks (row L = identity)
     const uint2 *gen;         // [(L-1)^2 + 2(L-1)]  xzzx / rotated generators: 4 x u16 (site << 2 | pauli), 0 = unused
     const double *bias_tbl;   // [Nc][4][nq+1]      px^n, py^n, pz^n, pI^n per rung (biased and alpha noise)
+    int bias_lds;             //                    the kernel copies bias_tbl into LDS (fits: capi.hip decides)
     const double *alpha_lnb;  // [Nc-1]             ln(pz_tilde[i] / pz_tilde[i+1]) (alpha noise, mcmc_alpha.py:123)
     double alpha;             //                    mcmc_alpha.py:11
     uint32_t *neff;           // [N][Nc]            alpha noise: the slots' n_eff attributes as n_z | (n_x+n_y) << 16; resume in / out
@@ -61,11 +62,14 @@ constexpr uint32_t kMaxGenLds = 2048;   // generator tables up to this many entr
 // generators the expanded table is stored as two halves kGenSplit entries apart (sites 0,1 | sites 2,3).
 // alpha noise appends the double-buffered n_eff records [2][Nc][64] to the region
 constexpr int kGenSplit = 255;      // ds_read2_b64's second offset is an 8-bit count of 8-byte units
-inline int ladder_gen_dwords(int code, int noise, int scan, uint32_t n_gen, int Nc)
+// ... and, when the plan says so (LadderArgs::bias_lds), the biased / alpha rule's power tables double[Nc][4][nq+1]
+inline int ladder_gen_dwords(int code, int noise, int scan, uint32_t n_gen, int Nc, int nq = 0, int bias_lds = 0)
 {
     const bool wide = code == 0 && !noise && !scan;
-    const int tab = wide ? ((int)n_gen <= kGenSplit ? 2 * (kGenSplit + (int)n_gen) : 4 * (int)n_gen) : 2 * (int)n_gen;
-    return noise == 2 ? ((tab + 3) & ~3) + 2 * Nc * 64 : tab;
+    int d = wide ? ((int)n_gen <= kGenSplit ? 2 * (kGenSplit + (int)n_gen) : 4 * (int)n_gen) : 2 * (int)n_gen;
+    if (noise == 2) d = ((d + 3) & ~3) + 2 * Nc * 64;
+    if (noise && bias_lds) d = ((d + 3) & ~3) + 2 * Nc * 4 * (nq + 1);
+    return d;
 }
 hipError_t launch_ladder_rs_toric(const LadderArgs &a, hipStream_t stream);
 

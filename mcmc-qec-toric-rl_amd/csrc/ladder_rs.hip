@@ -160,7 +160,8 @@ __device__ __forceinline__ uint32_t pack_info(uint32_t n, uint32_t sid, uint32_t
 // so fixed-step runs use the instantiation without it)
 // GSPLIT: the expanded generator table of the toric random-scan path is stored as two halves kGenSplit entries apart
 // (sites 0,1 | sites 2,3): one ds_read2_b64 with a constant second offset costs ~15 LDS cycles for random entries,
-// 16 adjacent bytes ~21 (tools/ubench_lds.hip).  Needs n_gen <= kGenSplit (toric L <= 11).
+// 16 adjacent bytes ~21 (tools/ubench_lds.hip).  Needs n_gen <= kGenSplit (toric L <= 11).  In the BIASED instantiations
+// (which have no expanded table) the same flag says that the rule's power tables are read from an LDS copy.
 // exp(y) for y <= 0 from IEEE multiply / add / fma only: the same operation sequence as the oracle's orc_det_exp, so the
 // swap decision of the alpha ladder is bit-identical on both sides.  y >= 0 returns 1; below 2^-1022 flushes to 0.
 __device__ inline double det_exp(double y)
@@ -233,11 +234,14 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
     constexpr bool kSplitGen = kWideGen && GSPLIT;
     const int gen_dw = kWideGen ? (kSplitGen ? 2 * (kGenSplit + (int)a.n_gen) : 4 * (int)a.n_gen) : 2 * (int)a.n_gen;
     const bool alpha_noise = BIASED && a.noise == 2;            // mcmc_alpha.py: biased rule + slot-bound n_eff swap test
-    const int gen_region = alpha_noise ? ((gen_dw + 3) & ~3) + 2 * NC * 64 : gen_dw;
+    constexpr bool kBiasLds = BIASED && GSPLIT;                 // p_x^n ... p_I^n tables of every rung in LDS
+    const int neff_dw = alpha_noise ? 2 * NC * 64 : 0, bias_dw = kBiasLds ? 2 * NC * 4 * (nq + 1) : 0;
+    const int gen_region = (neff_dw || bias_dw) ? ((gen_dw + 3) & ~3) + neff_dw + bias_dw : gen_dw;
     const int gdw = ladder_group_dwords(NC, W, ncls, gen_region);   // dwords per group
     const int gen_off = gdw - ((gen_region + 3) & ~3);           // start of the generator table
     uint32_t *lds = lds_all;
     [[maybe_unused]] uint32_t *neffb = lds + gen_off + ((gen_dw + 3) & ~3);   // [2][NC][64] n_z | (n_x+n_y) << 16 per slot, by step parity
+    [[maybe_unused]] double *biasl = reinterpret_cast<double *>(lds + gen_off + ((gen_dw + 3) & ~3) + neff_dw);   // [NC][4][nq+1]
 
     uint32_t *st = lds;                           // [NC][W][64]   packed states
     uint32_t *info = st + (size_t)NC * W * 64;    // [2][NC][64]   slot records, double-buffered by step parity
@@ -286,6 +290,11 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
         // u < p_diff^d  <=>  x < thr; d = 0 always swaps and is never looked up (mcmc.py:146-149)
         const int pr = i / kSwapFast, d = i - pr * kSwapFast;
         swapT[i] = (d >= 1 && d <= nq) ? (uint32_t)a.swap_thr[(size_t)pr * (nq + 1) + d] : 0u;
+    }
+    if constexpr (kBiasLds) {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(a.bias_tbl);
+        uint32_t *dst = lds + gen_off + ((gen_dw + 3) & ~3) + neff_dw;
+        for (int i = tid; i < bias_dw; i += nthreads) dst[i] = src[i];
     }
     if (tid < NC * 9) {
         // u < f^dE  <=>  x < thr  <=>  x <= thr-1;  dE <= 0 (f^dE >= 1) and f >= 1 always accept (mcmc.py:30,42)
@@ -509,7 +518,9 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 int nx = 0, ny = 0, nz = 0;
                 for (int w = 0; w < W; ++w) count_xyz(stw[w * 64], nx, ny, nz);
                 const int T1 = nq + 1;
-                const double *bt = BIASED ? a.bias_tbl + (size_t)slot_u * 4 * T1 : nullptr;
+                const double *bt = nullptr;
+                if constexpr (kBiasLds) bt = biasl + (size_t)slot_u * 4 * T1;
+                else if constexpr (BIASED) bt = a.bias_tbl + (size_t)slot_u * 4 * T1;
                 double pb = 1.0;
                 if constexpr (BIASED) pb = bt[nx] * bt[T1 + ny] * bt[2 * T1 + nz] * bt[3 * T1 + (nq - nx - ny - nz)];
                 uint32_t cdelta = 0;
@@ -517,13 +528,19 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 const uint32_t *lmask = a.lmask;
                 const int LW = (L + 1) * W;
                 uint32_t gs = SCAN ? (uint32_t)(kbase % a.n_gen) : 0u;
+                u32x4 pair{0, 0, 0, 0};                                            // the block two non-top proposals share
+                uint64_t kb_pair = ~0ull;
                 for (uint32_t j = 0; j < iters; ++j, gs = gs + 1 == a.n_gen ? 0u : gs + 1) {
                     const uint64_t k = kbase + j;
                     // top: block (k, 0) = select, generator / logical fields; non-top: words 2(k&1), 2(k&1)+1 of block (k>>1, 1)
-                    u32x4 x = philox_block(top ? k : k >> 1, top ? 0u : 1u, syn, slot_u, a.seed_lo, a.seed_hi);
-                    if (!top) {
-                        if (k & 1) { x.x = x.z; x.y = x.w; }
-                        x.w = x.y;                                                  // acceptance uniform
+                    u32x4 x;
+                    if (top) {
+                        x = philox_block(k, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                    } else {
+                        if ((k >> 1) != kb_pair) { kb_pair = k >> 1; pair = philox_block(kb_pair, 1, syn, slot_u, a.seed_lo, a.seed_hi); }
+                        x.x = (k & 1) ? pair.z : pair.x;                            // generator word
+                        x.w = (k & 1) ? pair.w : pair.y;                            // acceptance uniform
+                        x.y = x.z = 0;
                     }
                     const bool logical = top && x.x <= thrL1;                       // mcmc.py:23
                     int dx = 0, dy = 0, dz = 0;                                    // change of the X / Y / Z counts
@@ -570,12 +587,19 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                             const uint2 e = gtab[scale_u32(wa, a.n_gen)];
                             ent[0] = e.x & 0xFFFFu; ent[1] = e.x >> 16; ent[2] = e.y & 0xFFFFu; ent[3] = e.y >> 16;
                         }
+                        // old and new values of the (up to) four sites as 2-bit fields; an unused entry reads site 0 into
+                        // both and cancels
+                        uint32_t F = 0, OPS = 0;
+#pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            const uint32_t q = ent[i] >> 2, f = (stw[(q >> 4) * 64] >> ((q & 15u) * 2u)) & 3u, g = f ^ (ent[i] & 3u);
-                            dx += (int)(g == 1u) - (int)(f == 1u);
-                            dy += (int)(g == 2u) - (int)(f == 2u);
-                            dz += (int)(g == 3u) - (int)(f == 3u);
+                            const uint32_t q = ent[i] >> 2;
+                            F |= ((stw[(q >> 4) * 64] >> ((q & 15u) * 2u)) & 3u) << (2 * i);
+                            OPS |= (ent[i] & 3u) << (2 * i);
                         }
+                        int ox = 0, oy = 0, oz = 0;
+                        count_xyz(F, ox, oy, oz);
+                        count_xyz(F ^ OPS, dx, dy, dz);
+                        dx -= ox; dy -= oy; dz -= oz;
                     }
                     const int dE = dx + dy + dz;
                     bool acc;
@@ -1036,7 +1060,7 @@ hipError_t launch_ladder_rs_toric(const LadderArgs &a, hipStream_t stream)
 {
     unsigned grid = (unsigned)((a.N + 63) / 64);
     unsigned block = (unsigned)a.Nc * 64u;
-    size_t lds = ladder_lds_bytes(a.L, a.Nc, a.W, a.ncls, ladder_gen_dwords(a.code, a.noise, a.scan, a.n_gen, a.Nc));
+    size_t lds = ladder_lds_bytes(a.L, a.Nc, a.W, a.ncls, ladder_gen_dwords(a.code, a.noise, a.scan, a.n_gen, a.Nc, a.nq, a.bias_lds));
     if (grid == 0) return hipSuccess;
     // One 64-syndrome group (Nc waves) per workgroup.  (Two groups per workgroup, sharing only the barrier, paid off while a
     // one-round grid ended in a long tail; with the current proposal loop the 8-wave workgroups are faster at every batch
@@ -1072,11 +1096,13 @@ hipError_t launch_ladder_rs_toric(const LadderArgs &a, hipStream_t stream)
                 else fn = QECMC_K(1024, 4, false, R, false);
             }
         } else {
-        // the biased rule runs one group per workgroup (any Nc <= 16)
         if (false) {}
         else if (a.scan) return hipErrorInvalidValue;          // the sweep is built for the depolarizing rule only
-        else if (a.code == X) fn = conv ? (const void *)ladder_rs_toric_kernel<1024, 4, true, false, X, true, false, true> : (const void *)ladder_rs_toric_kernel<1024, 4, false, false, X, true, false, true>;
-        else if (a.code == R) fn = conv ? (const void *)ladder_rs_toric_kernel<1024, 4, true, false, R, true, false, true> : (const void *)ladder_rs_toric_kernel<1024, 4, false, false, R, true, false, true>;
+#define QECMC_KB(maxt, minw, code, lds_tbl) (conv ? (const void *)ladder_rs_toric_kernel<maxt, minw, true, lds_tbl, code, true, false, true> \
+                                                  : (const void *)ladder_rs_toric_kernel<maxt, minw, false, lds_tbl, code, true, false, true>)
+        else if (a.code == X) fn = a.bias_lds ? QECMC_KB(1024, 4, X, true) : QECMC_KB(1024, 4, X, false);
+        else if (a.code == R) fn = a.bias_lds ? QECMC_KB(1024, 4, R, true) : QECMC_KB(1024, 4, R, false);
+#undef QECMC_KB
         else return hipErrorInvalidValue;
         }
     }
