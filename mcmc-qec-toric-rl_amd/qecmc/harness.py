@@ -123,3 +123,19 @@ def generate(params, nbr_datapoints, seed=0, file_path=None, steps=100000, conv_
     if file_path is not None:
         np.savez_compressed(file_path, params=np.array([repr(params)]), **out)
     return out
+
+
+def convergence_study(init, p, checkpoints, Nc=None, iters=10, tops_burn=0, seed=0, code=L_.TORIC, **pteq_kw):
+    """Class histograms of the same chains at increasing run lengths (BASELINE config 5: "long-chain convergence study").
+    Philox is counter-based, so a run of `s` ladder steps is the exact prefix of any longer run with the same seed: the
+    batch is simply re-run to every checkpoint (total cost < 2x the longest run for log-spaced checkpoints).
+    Returns dict(steps int64[k], counts uint32[k, N, ncls], samples uint32[k, N], percent uint8[k, N, ncls],
+    tv float64[k]) with tv = mean total-variation distance of each checkpoint's class distribution to the last one."""
+    cps = sorted(int(c) for c in checkpoints)
+    runs = [pteq_batch(init, p, Nc=Nc, steps=c, iters=iters, tops_burn=tops_burn, seed=seed, code=code, **pteq_kw) for c in cps]
+    counts = np.stack([r["counts"] for r in runs])
+    samples = np.stack([r["samples"] for r in runs])
+    frac = counts / np.maximum(samples, 1)[..., None].astype(np.float64)
+    tv = 0.5 * np.abs(frac - frac[-1]).sum(axis=-1).mean(axis=-1)
+    return dict(steps=np.array(cps, dtype=np.int64), counts=counts, samples=samples,
+                percent=np.stack([r["percent"] for r in runs]), tv=tv)

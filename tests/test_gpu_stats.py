@@ -105,3 +105,16 @@ def test_harness_generate_decodes_low_noise(q, tmp_path):
         assert out["success"].mean() > (0.75 if params["code"] == "toric" else 0.9), (params, out["success"].mean())
         back = np.load(f)
         assert np.array_equal(back["eq_true"], out["eq_true"]) and back["qubit_matrix"].dtype == np.uint8
+
+
+def test_convergence_study_prefix_property(q):
+    """A shorter run is the exact prefix of a longer one (counter-based RNG): with tops_burn = 0 every step is recorded, so
+    the counts are monotone in the run length, sample counts equal the step counts, and the distance to the longest
+    run's distribution shrinks."""
+    from qecmc import harness
+    rng = np.random.default_rng(9)
+    raw = harness.draw_errors("rotated", 7, 96, 0.12, rng)
+    out = harness.convergence_study(raw, 0.12, [100, 400, 1600, 6400], Nc=7, seed=4, code=q.ROTATED)
+    assert out["counts"].shape == (4, 96, 4) and np.array_equal(out["samples"], np.broadcast_to(out["steps"][:, None], (4, 96)))
+    assert np.all(np.diff(out["counts"].astype(np.int64), axis=0) >= 0)
+    assert out["tv"][0] > out["tv"][2] and out["tv"][-1] == 0
