@@ -230,9 +230,12 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
     // generator table in LDS: 4 x u16 per generator as the plan stores it, or -- for the toric random-scan hot path --
     // expanded to 4 x u32 (byte offset << 16 | Pauli x 0x55 << 8 | Pauli << 5 | bit shift) so a site costs one add (its high
     // half, SDWA) and one bfe
-    constexpr bool kWideGen = CODE == kCodeToric && !BIASED && !SCAN;
+    constexpr bool kWideGen = !BIASED && !SCAN;                // every code: the non-top random-scan loop reads the expanded table
     constexpr bool kSplitGen = kWideGen && GSPLIT;
-    const int gen_dw = kWideGen ? (kSplitGen ? 2 * (kGenSplit + (int)a.n_gen) : 4 * (int)a.n_gen) : 2 * (int)a.n_gen;
+    constexpr bool kNarrowGen = !kWideGen || CODE != kCodeToric;   // the plan's form: sweep, biased rule, plaquette-code top / general paths
+    const int narrow_dw = kNarrowGen ? (kWideGen ? (2 * (int)a.n_gen + 3) & ~3 : 2 * (int)a.n_gen) : 0;
+    const int wide_dw = kWideGen ? (kSplitGen ? 2 * (kGenSplit + (int)a.n_gen) : 4 * (int)a.n_gen) : 0;
+    const int gen_dw = narrow_dw + wide_dw;
     const bool alpha_noise = BIASED && a.noise == 2;            // mcmc_alpha.py: biased rule + slot-bound n_eff swap test
     constexpr bool kBiasLds = BIASED && GSPLIT;                 // p_x^n ... p_I^n tables of every rung in LDS
     const int neff_dw = alpha_noise ? 2 * NC * 64 : 0, bias_dw = kBiasLds ? 2 * NC * 4 * (nq + 1) : 0;
@@ -251,10 +254,11 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
     uint32_t *swapT = thrT + NC * 9;              // [NC][kSwapFast]  swap iff x < swapT[i][d]
     volatile uint32_t *stopf = swapT + NC * kSwapFast;   // [1]  every syndrome of the workgroup has converged
     [[maybe_unused]] const uint2 *gtab = reinterpret_cast<const uint2 *>(lds + gen_off);   // [n_gen] generator table (LDS copy)
-    [[maybe_unused]] const uint4 *gtab4 = reinterpret_cast<const uint4 *>(lds + gen_off);  // wide form (kWideGen)
+    [[maybe_unused]] const uint4 *gtab4 = reinterpret_cast<const uint4 *>(lds + gen_off + narrow_dw);  // wide form (kWideGen)
+    [[maybe_unused]] const uint2 *gtabw = reinterpret_cast<const uint2 *>(lds + gen_off + narrow_dw);  // ... as two halves
     [[maybe_unused]] auto gen_entry = [&](uint32_t g) -> uint4 {                          // one ds_read2_b64 either way
         if constexpr (kSplitGen) {
-            const uint2 lo = gtab[g], hi = gtab[g + kGenSplit];
+            const uint2 lo = gtabw[g], hi = gtabw[g + kGenSplit];
             return uint4{lo.x, lo.y, hi.x, hi.y};
         } else {
             return gtab4[g];
@@ -278,13 +282,17 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
     if constexpr (kWideGen) {
         for (int i = tid; i < 4 * (int)a.n_gen; i += nthreads) {
             const uint32_t e = reinterpret_cast<const uint16_t *>(a.gen)[i], q = e >> 2;
-            // byte offset of the state dword [31:16] | Pauli x 0x55 [15:8] | Pauli [6:5] | bit shift [4:0]
             const int g = i >> 2, k = i & 3;                                       // generator, site
-            (lds + gen_off)[kSplitGen ? 2 * (g + (k >> 1) * kGenSplit) + (k & 1) : i] =
-                (((q >> 4) * 256u) << 16) | (((e & 3u) * 0x55u) << 8) | ((e & 3u) << 5) | ((q & 15u) * 2u);
+            // byte offset of the state dword [31:16] | in site 0: the four Paulis as 2-bit fields [15:8] | Pauli [6:5] | bit shift [4:0]
+            uint32_t ops = 0;
+            if (k == 0)
+                for (int u = 0; u < 4; ++u) ops |= (uint32_t)(reinterpret_cast<const uint16_t *>(a.gen)[4 * g + u] & 3u) << (2 * u);
+            (lds + gen_off + narrow_dw)[kSplitGen ? 2 * (g + (k >> 1) * kGenSplit) + (k & 1) : i] =
+                (((q >> 4) * 256u) << 16) | (ops << 8) | ((e & 3u) << 5) | ((q & 15u) * 2u);
         }
-    } else {
-        for (int i = tid; i < gen_dw; i += nthreads) (lds + gen_off)[i] = reinterpret_cast<const uint32_t *>(a.gen)[i];
+    }
+    if constexpr (kNarrowGen) {
+        for (int i = tid; i < 2 * (int)a.n_gen; i += nthreads) (lds + gen_off)[i] = reinterpret_cast<const uint32_t *>(a.gen)[i];
     }
     for (int i = tid; i < (NC - 1) * kSwapFast; i += nthreads) {
         // u < p_diff^d  <=>  x < thr; d = 0 always swaps and is never looked up (mcmc.py:146-149)
@@ -439,11 +447,71 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             cls ^= cdelta;
         };
 
+        // ---------- the non-top random-scan loop (every code, depolarizing rule) -------------------------------------------
+        // One Philox word picks the generator (g = floor(x * G / 2^32): uniform over the G generators as the reference's
+        // three / five draws are, toric_model.py:291-295, xzzx_model.py:439-452), one is the acceptance uniform: a block feeds
+        // two proposals.
+        [[maybe_unused]] auto random_scan_loop = [&]() {
+            int ni = (int)n;
+            auto propose = [&](uint32_t xp, uint32_t xa) {
+                const uint4 ev = gen_entry(scale_u32(xp, a.n_gen));                 // the (up to) four sites; an unused entry is 0
+                const uint32_t sh[4] = {ev.x, ev.y, ev.z, ev.w};                    // byte offset << 16 | ... | Pauli << 5 | bit shift
+                uint32_t *ad[4];
+                uint32_t f[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ad[i] = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(stw) + (sh[i] >> 16));   // byte offset: one SDWA add
+                    f[i] = bfe2_lo5(*ad[i], sh[i]);
+                }
+                const uint32_t F = lshl_or(lshl_or(f[3], 2, f[2]), 4, lshl_or(f[1], 2, f[0]));
+                const uint32_t G = F ^ ((ev.x >> 8) & 0xFFu);                      // the four new values (the Paulis as 2-bit fields)
+                // dE + 4 = #(new != 0) + #(old == 0) (toric_model.py:275-282): two chained popcounts, no subtraction; the
+                // threshold row is indexed by dE + 4 anyway.  An unused entry reads site 0 into both and counts 1.
+                const uint32_t dE4 = __popc((G | (G >> 1)) & 0x55u) + __popc(~(F | (F >> 1)) & 0x55u);
+                if (xa <= (myT - 4)[dE4]) {                                         // mcmc.py:42
+                    if constexpr (CODE == kCodeToric) {                            // one Pauli for the whole generator
+                        const uint32_t op = (ev.x >> 5) & 3u;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) lds_xor(ad[i], shl_lo5(op, sh[i]));
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) lds_xor(ad[i], shl_lo5((sh[i] >> 5) & 3u, sh[i]));
+                    }
+                    ni += (int)dE4 - 4;
+                }
+            };
+            uint32_t j = 0;
+            // proposal k uses words 2(k&1), 2(k&1)+1 of block (k>>1, 1).  The uniforms do not depend on the state: draw two
+            // blocks together so their serial 10-round chains overlap, then apply the four proposals in order
+            if (j < iters && (kbase & 1)) {
+                const u32x4 xa = philox_block(kbase >> 1, 1, syn, slot_u, a.seed_lo, a.seed_hi);
+                propose(xa.z, xa.w);
+                j = 1;
+            }
+            for (; j + 3 < iters; j += 4) {
+                const uint64_t kb = (kbase + j) >> 1;
+                const u32x4 xa = philox_block(kb, 1, syn, slot_u, a.seed_lo, a.seed_hi);
+                const u32x4 xb = philox_block(kb + 1, 1, syn, slot_u, a.seed_lo, a.seed_hi);
+                propose(xa.x, xa.y);
+                propose(xa.z, xa.w);
+                propose(xb.x, xb.y);
+                propose(xb.z, xb.w);
+            }
+            for (; j < iters; j += 2) {
+                const u32x4 xa = philox_block((kbase + j) >> 1, 1, syn, slot_u, a.seed_lo, a.seed_hi);
+                propose(xa.x, xa.y);
+                if (j + 1 < iters) propose(xa.z, xa.w);
+            }
+            n = (uint32_t)ni;
+        };
+
         if constexpr (CODE != kCodeToric || BIASED) {
             // ---------- XZZX / rotated codes and the biased acceptance rule ----------------------------
             const bool top = top_logical;
-            if (!top && !BIASED && CODE != kCodeToric) {
-                // depolarizing Metropolis on a plaquette code: generator table lookup, 2 or 4 sites
+            if (!SCAN && !top && !BIASED && CODE != kCodeToric) {
+                if constexpr (kWideGen) random_scan_loop();
+            } else if (!top && !BIASED && CODE != kCodeToric) {
+                // sweep on a plaquette code: generator table lookup, 2 to 4 sites
                 int ni = (int)n;
                 uint32_t gs = SCAN ? (uint32_t)(kbase % a.n_gen) : 0u;
                 u32x4 blk{0, 0, 0, 0};
@@ -637,33 +705,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             }
         } else
         if (!top_logical) {
-            int ni = (int)n;
-            // One Philox word picks the generator (g = floor(x * 2L^2 / 2^32): uniform over the 2L^2 generators as the
-            // reference's three draws are, toric_model.py:291-295), one is the acceptance uniform: a block feeds two proposals.
-            const uint32_t G2 = 2u * (uint32_t)LL;
-            auto propose = [&](uint32_t xp, uint32_t xa) {
-                const uint4 ev = gen_entry(scale_u32(xp, G2));                      // the four sites (toric_model.py:261-269)
-                const uint32_t sh[4] = {ev.x, ev.y, ev.z, ev.w};                    // byte offset << 16 | ... | bit shift
-                uint32_t *ad[4];
-                uint32_t f[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    ad[i] = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(stw) + (sh[i] >> 16));   // byte offset: one SDWA add
-                    f[i] = bfe2_lo5(*ad[i], sh[i]);
-                }
-                const uint32_t F = lshl_or(lshl_or(f[3], 2, f[2]), 4, lshl_or(f[1], 2, f[0]));
-                const uint32_t op = (ev.x >> 5) & 3u;
-                const uint32_t G = F ^ ((ev.x >> 8) & 0xFFu);                      // the four new values (Pauli x 0x55)
-                // dE + 4 = #(new != 0) + #(old == 0) (:275-282): two chained popcounts, no subtraction; the threshold row is
-                // indexed by dE + 4 anyway
-                const uint32_t dE4 = __popc((G | (G >> 1)) & 0x55u) + __popc(~(F | (F >> 1)) & 0x55u);
-                if (xa <= (myT - 4)[dE4]) {                                         // mcmc.py:42
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) lds_xor(ad[i], shl_lo5(op, sh[i]));
-                    ni += (int)dE4 - 4;
-                }
-            };
-            uint32_t j = 0;
+            [[maybe_unused]] int ni = (int)n;
             if constexpr (SCAN) {
                 // systematic sweep: generator k mod G -- its sites are wave-uniform scalars from the plan's table --
                 // and one Philox block per four proposals (word k&3 of block k>>2): walk the blocks that overlap
@@ -702,33 +744,9 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                         }
                     }
                 }
-                j = iters;
             }
-            // proposal k uses words 2(k&1), 2(k&1)+1 of block (k>>1, 1).  The uniforms do not depend on the state: draw two
-            // blocks together so their serial 10-round chains overlap, then apply the four proposals in order
-            if (!SCAN && j < iters && (kbase & 1)) {
-                const u32x4 xa = philox_block(kbase >> 1, 1, syn, slot_u, a.seed_lo, a.seed_hi);
-                propose(xa.z, xa.w);
-                j = 1;
-            }
-            for (; j + 3 < iters; j += 4) {
-                const uint64_t kb = (kbase + j) >> 1;
-                const u32x4 xa = philox_block(kb, 1, syn, slot_u, a.seed_lo, a.seed_hi);
-                const u32x4 xb = philox_block(kb + 1, 1, syn, slot_u, a.seed_lo, a.seed_hi);
-                propose(xa.x, xa.y);
-                propose(xa.z, xa.w);
-                propose(xb.x, xb.y);
-                propose(xb.z, xb.w);
-            }
-            for (; j < iters; j += 2) {
-                const u32x4 xa = philox_block((kbase + j) >> 1, 1, syn, slot_u, a.seed_lo, a.seed_hi);
-                propose(xa.x, xa.y);
-                if (j + 1 < iters) propose(xa.z, xa.w);
-            }
-            n = (uint32_t)ni;
-#ifdef QECMC_EXP_NOTOP
-        } else if (acc_all) {
-#endif
+            if constexpr (SCAN) n = (uint32_t)ni;
+            else random_scan_loop();
         } else if (acc_all && L <= 16) {
             // Top chain at p = 0.75: every proposal is accepted (mcmc.py:30), so moves are blind
             // XORs and commute.  Stabilizers go straight to LDS; logical operators are collected
