@@ -557,8 +557,6 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 blind_sweep_tables();
             } else if (!BIASED && top && acc_all) {
                 // random scan, top chain at f = 1 (mcmc.py:30): every proposal is applied blindly, n recounted once
-                const uint32_t *lmask = a.lmask;
-                const int LW = (L + 1) * W;
                 uint32_t cdelta = 0;
                 for (uint32_t j = 0; j < iters; ++j) {
                     const u32x4 x = philox_block(kbase + j, 0, syn, slot_u, a.seed_lo, a.seed_hi);
@@ -566,8 +564,18 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                         const uint32_t op = x.y >> 30;
                         const uint32_t xp = ((op ^ (op >> 1)) & 1u) ? scale_low30(x.y, L) : 0u, zp = (op >> 1) ? scale_u16(x.w >> 16, L) : 0u;
                         const uint32_t ax = CODE == kCodeXzzx ? ((op ^ (op >> 1)) & 1u) : (op & 1u), az = op >> 1;
-                        const uint32_t *m0 = ax ? lmask + xp * W : lmask + L * W, *m1 = az ? lmask + LW + zp * W : lmask + L * W;
-                        for (int w = 0; w < W; ++w) lds_xor(stw + w * 64, m0[w] ^ m1[w]);
+                        // the operator's L + L sites, generated on the fly (per-lane positions would make the plan's mask rows
+                        // 2 W scattered global loads per proposal): xzzx -- X on the anti-diagonal, Z on the diagonal
+                        // (xzzx_model.py:291-311); rotated -- X on column X_pos, Z on row Z_pos (rotated_surface_model.py:260-280);
+                        // planar -- X on row X_pos, Z on column Z_pos of layer 0 (planar_model.py:264-268)
+                        for (uint32_t i = 0; i < (uint32_t)L; ++i) {
+                            uint32_t qx, qz;
+                            if (CODE == kCodeXzzx) { qx = i * L + ((uint32_t)L - 1u - i); qz = i * L + i; }
+                            else if (CODE == kCodeRotated) { qx = i * L + xp; qz = zp * L + i; }
+                            else { qx = xp * L + i; qz = i * L + zp; }
+                            lds_xor(stw + (qx >> 4) * 64, ax << ((qx & 15u) * 2u));
+                            lds_xor(stw + (qz >> 4) * 64, (az * 3u) << ((qz & 15u) * 2u));
+                        }
                         cdelta ^= ax | (az << 1);
                     } else {
                         const uint2 e = gtab[scale_u32(x.y, a.n_gen)];              // word 1 picks the generator
