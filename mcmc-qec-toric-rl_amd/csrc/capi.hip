@@ -696,40 +696,35 @@ int qecmc_ptdc_batch(const qecmc_params *params, const uint8_t *init, uint64_t N
     if (M > 0xFFFFFFFFull) return fail(QECMC_ERR_INVALID, "N * classes * droplets = %llu ladders exceed the 32-bit syndrome index", (unsigned long long)M);
     uint64_t cap = 16;
     while (cap < 2 * p.steps * (per_rung ? 1 : Nc * D)) cap <<= 1;    // twice the insertions one set can see
-    const uint64_t need = sets * cap * 8 + M * Nc * nq + M * Nc + M * 4 + sets * (nq + 1) * 8;
+    const uint64_t need = sets * cap * 8 + M * nq + sets * (nq + 1) * 8;
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     if (need > free_b - free_b / 8)
         return fail(QECMC_ERR_INVALID, "PTDC needs %llu bytes of device memory (%llu sets x %llu keys), %zu free: lower N, droplets or steps",
                     (unsigned long long)need, (unsigned long long)sets, (unsigned long long)cap, free_b);
-    // every ladder starts as Nc copies of its class representative, top flag set (Ladder.__init__, mcmc.py:72-75)
-    std::vector<uint8_t> st((size_t)M * Nc * nq), fl((size_t)M * Nc, 0);
+    // one start per ladder; the kernel copies it into every rung and sets the top flag (Ladder.__init__, mcmc.py:72-75)
+    std::vector<uint8_t> st((size_t)M * nq);
     for (uint64_t sc = 0; sc < N * ncls; ++sc)
-        for (size_t d = 0; d < D; ++d) {
-            const uint64_t l = sc * D + d;
-            const uint8_t *src = init + (init_per_droplet ? l : sc) * nq;
-            for (size_t c = 0; c < Nc; ++c) std::memcpy(&st[(l * Nc + c) * nq], src, nq);
-            fl[l * Nc + Nc - 1] = 1;
-        }
-    DevBuf ds, df, dt, dtab, dh, dm;
-    HIP_TRY(ds.alloc(st.size())); HIP_TRY(df.alloc(fl.size())); HIP_TRY(dt.alloc(M * 4));
+        for (size_t d = 0; d < D; ++d)
+            std::memcpy(&st[(sc * D + d) * nq], init + (init_per_droplet ? sc * D + d : sc) * nq, nq);
+    DevBuf ds, dtab, dh, dm;
+    HIP_TRY(ds.alloc(st.size()));
     HIP_TRY(dtab.alloc(sets * cap * 8)); HIP_TRY(dh.alloc(sets * (nq + 1) * 4));
     if (m_out) { HIP_TRY(dm.alloc(sets * (nq + 1) * 4)); HIP_TRY(hipMemset(dm.p, 0, sets * (nq + 1) * 4)); }
     HIP_TRY(hipMemcpy(ds.p, st.data(), st.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(df.p, fl.data(), fl.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(dt.p, 0, M * 4)); HIP_TRY(hipMemset(dtab.p, 0, sets * cap * 8)); HIP_TRY(hipMemset(dh.p, 0, sets * (nq + 1) * 4));
+    HIP_TRY(hipMemset(dtab.p, 0, sets * cap * 8)); HIP_TRY(hipMemset(dh.p, 0, sets * (nq + 1) * 4));
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, 0));
+    // ONE launch: the ladder kernel inserts every rung's configuration into its set after every step (USET instantiation)
     LadderArgs a = pl->args;
-    a.states = ds.as<uint8_t>(); a.flags = df.as<uint8_t>(); a.tops0 = dt.as<uint32_t>();
-    a.N = M; a.first_syndrome = p.first_syndrome; a.nsteps = 1; a.resume = 1; a.write_states = 1;
-    for (uint64_t t = 0; t < p.steps; ++t) {
-        a.step0 = t; a.prop0 = t * p.iters;
-        hipError_t e = launch_ladder_rs_toric(a, 0);                                              // Ladder.step(iters), decoders.py:144
-        if (e == hipSuccess) e = launch_uset_insert(ds.as<uint8_t>(), M * Nc, (int)nq, per_rung ? 1u : (uint32_t)(Nc * D), dtab.as<uint64_t>(), cap, dh.as<uint32_t>(),
-                                                       m_out ? dm.as<uint32_t>() : nullptr, 0);
-        if (e != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return fail(QECMC_ERR_HIP, "PTDC step %llu: %s", (unsigned long long)t, hipGetErrorString(e)); }
+    a.init = ds.as<uint8_t>();
+    a.N = M; a.first_syndrome = p.first_syndrome; a.nsteps = p.steps; a.step0 = 0; a.prop0 = 0; a.resume = 0; a.write_states = 0;
+    a.uset_tab = reinterpret_cast<unsigned long long *>(dtab.p); a.uset_cap = cap; a.uset_hist = dh.as<uint32_t>();
+    a.uset_mhist = m_out ? dm.as<uint32_t>() : nullptr; a.uset_D = (uint32_t)D; a.uset_per_rung = per_rung ? 1 : 0;
+    {
+        const hipError_t e = launch_ladder_rs_toric(a, 0);
+        if (e != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return fail(QECMC_ERR_HIP, "PTDC launch: %s", hipGetErrorString(e)); }
     }
     HIP_TRY(hipEventRecord(e1, 0));
     HIP_TRY(hipEventSynchronize(e1));

@@ -25,6 +25,14 @@ struct LadderArgs {
     const uint32_t *lmask;    // [4][L+1][W]       logical-operator XOR masks (row L = identity)
     const uint2 *gen;         // [(L-1)^2 + 2(L-1)]  xzzx / rotated generators: 4 x u16 (site << 2 | pauli), 0 = unused
     const double *bias_tbl;   // [Nc][4][nq+1]      px^n, py^n, pz^n, pI^n per rung (biased and alpha noise)
+    // unique-chain set of the direct-counting estimators (PTDC_droplet, decoders.py:146-152), filled in-kernel after every
+    // ladder step when uset_tab != nullptr: set of (ladder, rung) = ladder * Nc + rung if uset_per_rung, else ladder / uset_D
+    unsigned long long *uset_tab;   // [sets][uset_cap] keys, 0 = empty
+    uint64_t uset_cap;              // power of two
+    uint32_t *uset_hist;            // [sets][nq+1] N(n): distinct chains by length
+    uint32_t *uset_mhist;           // [sets][nq+1] m(n): observations by length (nullable)
+    uint32_t uset_D;                // droplets per set
+    int uset_per_rung;
     int bias_lds;             //                    the kernel copies bias_tbl into LDS (fits: capi.hip decides)
     const double *alpha_lnb;  // [Nc-1]             ln(pz_tilde[i] / pz_tilde[i+1]) (alpha noise, mcmc_alpha.py:123)
     double alpha;             //                    mcmc_alpha.py:11
@@ -101,8 +109,5 @@ struct ChainArgs {
     const double *bias_tbl;   // [4][nq+1] px^n, py^n, pz^n, pI^n (biased noise)
 };
 hipError_t launch_chain_update(const ChainArgs &a, hipStream_t s);
-// unique-chain set insertion (PTDC_droplet, decoders.py:146-152): states [nchains][nq], set of chain i = i / chains_per_set
-hipError_t launch_uset_insert(const uint8_t *states, uint64_t nchains, int nq, uint32_t chains_per_set, uint64_t *tab,
-                              uint64_t cap, uint32_t *hist, uint32_t *mhist /* nullable: m(n), every observation */, hipStream_t s);
 
 }  // namespace qecmc

@@ -220,7 +220,7 @@ __device__ inline bool alpha_series_close(uint64_t z2, uint64_t xy2, uint32_t de
 // GENTOP: keep the table-driven general top-chain path (toric L > 16, or a 1-chain ladder whose top sits below
 // p = 0.75; always needed by the plaquette codes and the biased rule).  The common toric configurations compile it out,
 // which keeps its registers out of the hot loop.
-template <int MAXT, int MINW, bool CONV, bool GSPLIT, int CODE, bool BIASED, bool SCAN, bool GENTOP>
+template <int MAXT, int MINW, bool CONV, bool GSPLIT, int CODE, bool BIASED, bool SCAN, bool GENTOP, bool USET = false>
 __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const LadderArgs a)
 {
     extern __shared__ uint32_t lds_all[];
@@ -1042,6 +1042,28 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             }
             if (CONV && wave_u == 0 && __all(done || lane >= cnt)) *stopf = 1;
             if (slot_u == 0) flag = 0;                                              // :103
+            if constexpr (USET) {
+                // PTDC_droplet / PTRC_droplet (decoders.py:146-152, :596-618): the configuration now in this wave's rung goes into
+                // the set of chains seen so far.  Key = FNV-1a over the packed words (any collision-free key gives the same N(n)).
+                if (lane < cnt) {
+                    const uint32_t *sw = st + sid * W * 64 + lane;
+                    uint64_t h = 0xCBF29CE484222325ull;
+                    for (int w = 0; w < W; ++w) h = (h ^ sw[w * 64]) * 0x100000001B3ull;
+                    h ^= h >> 32;
+                    const unsigned long long key = h ? h : 1ull;
+                    const uint64_t ladder = s0 + (uint64_t)lane;
+                    const uint64_t set = a.uset_per_rung ? ladder * (uint64_t)NC + slot_u : ladder / a.uset_D;
+                    if (a.uset_mhist != nullptr) atomicAdd(a.uset_mhist + set * (uint64_t)(nq + 1) + n, 1u);
+                    unsigned long long *tb = a.uset_tab + set * a.uset_cap;
+                    uint64_t idx = ((key * 0x9E3779B97F4A7C15ull) >> 20) & (a.uset_cap - 1);
+                    for (uint64_t probes = 0; probes < a.uset_cap; ++probes) {     // the table holds twice the insertions it can see
+                        const unsigned long long old = atomicCAS(tb + idx, 0ull, key);
+                        if (old == 0ull) { atomicAdd(a.uset_hist + set * (uint64_t)(nq + 1) + n, 1u); break; }
+                        if (old == key) break;
+                        idx = (idx + 1) & (a.uset_cap - 1);
+                    }
+                }
+            }
         }
     }
 #ifdef QECMC_TIMELINE
@@ -1098,6 +1120,17 @@ hipError_t launch_ladder_rs_toric(const LadderArgs &a, hipStream_t stream)
     (a.scan ? (conv ? (const void *)ladder_rs_toric_kernel<maxt, minw, true, g, code, biased, true, gentop> : (const void *)ladder_rs_toric_kernel<maxt, minw, false, g, code, biased, true, gentop>) \
             : (conv ? (const void *)ladder_rs_toric_kernel<maxt, minw, true, g, code, biased, false, gentop> : (const void *)ladder_rs_toric_kernel<maxt, minw, false, g, code, biased, false, gentop>))
 #define QECMC_K(maxt, minw, g, code, biased) QECMC_K2(maxt, minw, g, code, biased, true)
+    if (a.uset_tab != nullptr) {
+        // direct-counting runs: depolarizing random scan without logical moves (no general top path), fixed length
+        if (a.noise || a.scan || conv || a.thr_logical != 0) return hipErrorInvalidValue;
+        const bool gsplit = (int)a.n_gen <= kGenSplit;
+#define QECMC_KU(code) (block <= 512 ? (gsplit ? (const void *)ladder_rs_toric_kernel<512, 8, false, true, code, false, false, false, true>   \
+                                              : (const void *)ladder_rs_toric_kernel<512, 8, false, false, code, false, false, false, true>)  \
+                                     : (gsplit ? (const void *)ladder_rs_toric_kernel<1024, 4, false, true, code, false, false, false, true>  \
+                                              : (const void *)ladder_rs_toric_kernel<1024, 4, false, false, code, false, false, false, true>))
+        fn = a.code == T ? QECMC_KU(T) : a.code == X ? QECMC_KU(X) : a.code == R ? QECMC_KU(R) : QECMC_KU(P);
+#undef QECMC_KU
+    } else
     if (a.code == T && !a.noise) {
         // the general top-chain path is needed only for L > 16 or a top chain below p = 0.75 (1-chain ladder)
         const bool gentop = a.thr_logical != 0 && (a.L > 16 || !((a.acc_all_mask >> (a.Nc - 1)) & 1u));

@@ -163,36 +163,6 @@ __global__ void k_chain_update(const ChainArgs a)
     if (a.accepted != nullptr) a.accepted[i] = any_acc;
 }
 
-// Unique-chain set of the direct-counting estimators (PTDC_droplet, decoders.py:146-152): one thread per configuration.
-// key = FNV-1a over the state bytes (the role of hash(qubit_matrix.tobytes())); the set of chain i is table i / chains_per_set
-// (open addressing, 0 = empty); a configuration that was not there yet adds one to hist[set][its length].
-__global__ void k_uset_insert(const uint8_t *states, uint64_t nchains, int nq, uint32_t chains_per_set,
-                              unsigned long long *tab, uint64_t cap, uint32_t *hist, uint32_t *mhist)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nchains) return;
-    const uint8_t *st = states + i * (uint64_t)nq;
-    uint64_t h = 0xCBF29CE484222325ull;
-    uint32_t n = 0;
-    for (int q = 0; q < nq; ++q) {
-        const uint8_t v = st[q];
-        h = (h ^ v) * 0x100000001B3ull;
-        n += v != 0;
-    }
-    h ^= h >> 32;
-    const unsigned long long key = h ? h : 1ull;
-    const uint64_t set = i / chains_per_set;
-    if (mhist != nullptr) atomicAdd(mhist + set * (uint64_t)(nq + 1) + n, 1u);       // m(n): every observation (decoders.py:606-618)
-    unsigned long long *t = tab + set * cap;
-    uint64_t idx = ((key * 0x9E3779B97F4A7C15ull) >> 20) & (cap - 1);
-    for (uint64_t probes = 0; probes < cap; ++probes) {          // the table is sized at twice the number of insertions
-        const unsigned long long old = atomicCAS(t + idx, 0ull, key);
-        if (old == 0ull) { atomicAdd(hist + set * (uint64_t)(nq + 1) + n, 1u); return; }
-        if (old == key) return;
-        idx = (idx + 1) & (cap - 1);
-    }
-}
-
 #define QECMC_LAUNCH(kern, N, s, ...)                                                    \
     do {                                                                                 \
         if ((N) == 0) return hipSuccess;                                                 \
@@ -226,11 +196,6 @@ hipError_t launch_to_class(int L, uint64_t N, const uint8_t *in, uint8_t *out, c
 hipError_t launch_syndrome(int code, int L, uint64_t N, const uint8_t *in, uint8_t *defects, hipStream_t s)
 {
     QECMC_LAUNCH(k_syndrome, N, s, code, L, N, in, defects);
-}
-hipError_t launch_uset_insert(const uint8_t *states, uint64_t nchains, int nq, uint32_t chains_per_set, uint64_t *tab,
-                              uint64_t cap, uint32_t *hist, uint32_t *mhist, hipStream_t s)
-{
-    QECMC_LAUNCH(k_uset_insert, nchains, s, states, nchains, nq, chains_per_set, reinterpret_cast<unsigned long long *>(tab), cap, hist, mhist);
 }
 hipError_t launch_chain_update(const ChainArgs &a, hipStream_t s)
 {
