@@ -12,6 +12,19 @@ def _prep(m):
     return a, batched, a.shape[1], a.shape[0]
 
 
+def pauli_field(shape, p_x, p_y, p_z):
+    """One uniform per qubit from the `random` module in C order, mapped to a Pauli as the reference's generators do:
+    Z below p_z, X in (p_z, p_z + p_x), Y in (p_z + p_x, p_z + p_x + p_y) -- open intervals, xzzx_model.py:16-30 (elif chain),
+    rotated_surface_model.py:25-38 (independent ifs: the same outcome, the intervals are disjoint), planar_model.py:18-36."""
+    import random as rand
+    r = np.array([rand.random() for _ in range(int(np.prod(shape)))], dtype=np.float64).reshape(shape)
+    m = np.zeros(shape, dtype=np.uint8)
+    m[r < p_z] = 3
+    m[(p_z < r) & (r < p_z + p_x)] = 1
+    m[(p_z + p_x < r) & (r < p_z + p_x + p_y)] = 2
+    return m
+
+
 def _vec(v, n):
     return np.ascontiguousarray(np.broadcast_to(np.asarray(v, dtype=np.int32), (n,)))
 
@@ -70,20 +83,7 @@ class PlaquetteCode:
         self.plaquette_defects = np.zeros((size + 1, size + 1))
 
     def generate_random_error(self, p_x, p_y, p_z):
-        # one uniform per qubit from the `random` module, row-major (xzzx_model.py:16-30)
-        import random as rand
-        size = self.system_size
-        for i in range(size):
-            for j in range(size):
-                r = rand.random()
-                q = 0
-                if r < p_z:
-                    q = 3
-                elif p_z < r < (p_z + p_x):
-                    q = 1
-                elif (p_z + p_x) < r < (p_z + p_x + p_y):
-                    q = 2
-                self.qubit_matrix[i, j] = q
+        self.qubit_matrix = pauli_field((self.system_size, self.system_size), p_x, p_y, p_z)
         self.syndrome()
 
     def count_errors(self):

@@ -74,20 +74,10 @@ class Planar_code:
         self.vertex_defects = np.zeros((size - 1, size), dtype=bool)
 
     def generate_random_error(self, p_x, p_y, p_z):
-        # one uniform per qubit from the `random` module, C order (planar_model.py:18-40)
+        # planar_model.py:18-40: a Pauli per cell of the 2 x L x L array, then layer 1's unused last row / column cleared
+        from ._surf import pauli_field
         size = self.system_size
-        for i in range(2):
-            for j in range(size):
-                for k in range(size):
-                    q = 0
-                    r = rand.random()
-                    if r < p_z:
-                        q = 3
-                    elif p_z < r < (p_z + p_x):
-                        q = 1
-                    elif (p_z + p_x) < r < (p_z + p_x + p_y):
-                        q = 2
-                    self.qubit_matrix[i, j, k] = q
+        self.qubit_matrix = pauli_field((2, size, size), p_x, p_y, p_z)
         self.qubit_matrix[1, -1, :] = 0
         self.qubit_matrix[1, :, -1] = 0
         self.syndrom()

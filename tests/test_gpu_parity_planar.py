@@ -158,3 +158,24 @@ def test_planar_pteq_dropin_and_exact_classes(q, orc):
     frac = res["counts"] / res["samples"][:, None].astype(np.float64)
     mean, sem = frac.mean(axis=0), frac.std(axis=0, ddof=1) / np.sqrt(R)
     assert np.all(np.abs(mean - P) <= 5 * sem + 0.01), (mean, P, sem)
+
+
+@pytest.mark.parametrize("name", ["planar", "xzzx", "rot"])
+def test_generate_random_error_draw_order(q, name):
+    """generate_random_error consumes one `random.random()` per cell in C order and maps it to Z / X / Y by the open
+    intervals of planar_model.py:18-36 / xzzx_model.py:16-30 / rotated_surface_model.py:25-38."""
+    import random
+    L, (px, py, pz) = 5, (0.07, 0.05, 0.11)
+    code = {"planar": q.Planar_code, "xzzx": q.xzzx_code, "rot": q.RotSurCode}[name](L)
+    random.seed(123)
+    code.generate_random_error(px, py, pz)
+    random.seed(123)
+    shape = (2, L, L) if name == "planar" else (L, L)
+    want = np.zeros(shape, dtype=np.uint8)
+    for idx in np.ndindex(*shape):
+        r = random.random()
+        want[idx] = 3 if r < pz else 1 if pz < r < pz + px else 2 if pz + px < r < pz + px + py else 0
+    if name == "planar":
+        want[1, -1, :] = 0
+        want[1, :, -1] = 0
+    assert np.array_equal(code.qubit_matrix, want) and code.qubit_matrix.dtype == np.uint8
