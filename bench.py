@@ -215,7 +215,7 @@ def main():
         algo_bytes = proposals_per_pass * ALGO_BYTES_PER_PROPOSAL + N * (nq + 4 * ncls)
         achieved = algo_bytes / (k_ms * 1e-3) / 1e9
         out = {
-            "metric": "MCMC sweeps/sec (whole node), L=9 toric p=0.15",
+            "metric": "MCMC sweeps/sec (whole node), L=9 toric p=0.15; eq-class histogram match",
             "value": sweeps_per_s,
             "unit": "chain-sweeps/s (1 sweep = 2*L*L = %d Metropolis proposals on one chain)" % nq,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -246,6 +246,17 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline and toric and args.scan == "random":
             out["cpu_baseline"] = cpu_baseline(init_h, args.p, Nc, args.iters, args.seed)
+            if args.p_logical == 0.5:
+                # the metric's "eq-class histogram match": the oracle (the checker, on the same Philox streams) must give the
+                # class counts the timed GPU pass left in HBM, bit for bit, on a sample of the batch
+                from oracle import oracle as orc
+                n_chk = min(N, 256)
+                ref = orc.toric_pteq_batch(init_h[:n_chk], args.p, Nc, args.ladder_steps, iters=args.iters, tops_burn=2,
+                                           seed=args.seed, n_threads=os.cpu_count() or 1)
+                same = bool(np.array_equal(d_counts[:n_chk].cpu().numpy().astype(np.uint32), ref["counts"]) and
+                            np.array_equal(samples[:n_chk].astype(np.uint64), ref["samples"].astype(np.uint64)))
+                out["histogram_match"] = {"syndromes_checked": n_chk, "ladder_steps": args.ladder_steps,
+                                          "class_counts_bit_identical_to_cpu_oracle": same}
         if world == 1 and toric and args.scan == "random" and args.eta is None and not args.no_sweep:
             # the library's second scan mode on the same batch, for the record (`value` above is the reference's chain)
             pr2 = L_.make_params(code=code_id, L=L, Nc=Nc, p=args.p, p_logical=args.p_logical, iters=args.iters,
