@@ -693,7 +693,7 @@ int qecmc_ptdc_batch(const qecmc_params *params, const uint8_t *init, uint64_t N
     const size_t nq = pl->args.nq, Nc = pl->args.Nc, ncls = pl->args.ncls, D = (size_t)droplets;
     const uint64_t M = N * ncls * D;                                  // ladders
     const uint64_t sets = per_rung ? M * Nc : N * ncls;               // PTRC: one per (ladder, rung); PTDC: one per (syndrome, class)
-    if (M > 0xFFFFFFFFull) return fail(QECMC_ERR_INVALID, "N * classes * droplets = %llu ladders exceed the 32-bit syndrome index", (unsigned long long)M);
+    if (M + p.first_syndrome > 0xFFFFFFFFull) return fail(QECMC_ERR_INVALID, "first_syndrome + N * classes * droplets = %llu ladders exceed the 32-bit syndrome index", (unsigned long long)(M + p.first_syndrome));
     uint64_t cap = 16;
     while (cap < 2 * p.steps * (per_rung ? 1 : Nc * D)) cap <<= 1;    // twice the insertions one set can see
     const uint64_t need = sets * cap * 8 + M * nq + sets * (nq + 1) * 8;
