@@ -114,10 +114,10 @@ def lib():
         _LIB.orc_det_exp.argtypes = [C.c_double]; _LIB.orc_det_exp.restype = C.c_double
         u64p = C.POINTER(C.c_uint64); u32p_ = C.POINTER(C.c_uint32)
         _LIB.orc_ptdc_droplet.argtypes = [mp, u8p, C.c_double, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(_Rng), u64p, C.c_uint64, u32p_,
-                                          C.c_int, u32p_]
+                                          C.c_int, u32p_, C.c_double, u64p]
         _LIB.orc_ptdc_droplet.restype = None
         _LIB.orc_ptdc_batch.argtypes = [mp, u8p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_double, C.c_int, C.c_uint64,
-                                        C.c_uint64, C.c_uint64, C.c_int, u32p_, C.c_int, u32p_]
+                                        C.c_uint64, C.c_uint64, C.c_int, u32p_, C.c_int, u32p_, C.c_double]
         _LIB.orc_ptdc_batch.restype = None
         _LIB.orc_state_key.argtypes = [u8p, C.c_size_t]; _LIB.orc_state_key.restype = C.c_uint64
         _LIB.orc_ladder_new.argtypes = [mp, u8p, C.c_double, C.c_int, C.c_double]
@@ -447,7 +447,7 @@ def pteq_batch(code, init, p, Nc, steps, iters=10, tops_burn=2, seed=0, first_sy
 
 
 # ---- unique-chain estimators (decoders.py:138-233) ---------------------------------------------------------------
-def ptdc_droplet(code, init, p_sampling, Nc, steps, iters=10, rng=None, tab=None, per_rung=False, with_m=False):
+def ptdc_droplet(code, init, p_sampling, Nc, steps, iters=10, rng=None, tab=None, per_rung=False, with_m=False, conv_mult=0.0):
     """PTDC_droplet (conv_mult = 0): returns (N(n) uint32[nq+1] of the chains that were new to `tab`, tab).  Nc=1, iters=5 is
     STDC_droplet / STRC_droplet; per_rung=True is PTRC_droplet (N(n) per rung, uint32[Nc, nq+1]); with_m also returns m(n)."""
     init = _m(init); nq = init.size
@@ -463,14 +463,14 @@ def ptdc_droplet(code, init, p_sampling, Nc, steps, iters=10, rng=None, tab=None
     u32p = C.POINTER(C.c_uint32)
     lib().orc_ptdc_droplet(C.byref(mod), _u8(init), p_sampling, Nc, steps, iters, C.byref(rng.c),
                            tab.ctypes.data_as(C.POINTER(C.c_uint64)), tab.size // nset, hist.ctypes.data_as(u32p), int(per_rung),
-                           mh.ctypes.data_as(u32p) if with_m else None)
+                           mh.ctypes.data_as(u32p) if with_m else None, float(conv_mult), None)
     if not per_rung:
         hist = hist[0]; mh = mh[0] if with_m else None
     return (hist, mh, tab) if with_m else (hist, tab)
 
 
 def ptdc_batch(code, init, p_sampling, Nc, steps, droplets=1, iters=10, seed=0, first_syndrome=0, n_threads=0, per_rung=False,
-               with_m=False):
+               with_m=False, conv_mult=0.0):
     """init uint8[N, ncls, ...] class representatives (or [N, ncls, droplets, ...]) -> N(n) uint32[N, ncls, nq+1]
     (per_rung: [N, ncls, droplets, Nc, nq+1]); with_m: (N(n), m(n))."""
     init = _m(init); N, ncls = init.shape[0], init.shape[1]
@@ -483,7 +483,8 @@ def ptdc_batch(code, init, p_sampling, Nc, steps, droplets=1, iters=10, seed=0, 
     mh = np.zeros(shape, dtype=np.uint32) if with_m else None
     u32p = C.POINTER(C.c_uint32)
     lib().orc_ptdc_batch(C.byref(mod), _u8(init), N, ncls, droplets, int(per_droplet), first_syndrome, p_sampling, Nc, steps, iters,
-                         seed, n_threads, hist.ctypes.data_as(u32p), int(per_rung), mh.ctypes.data_as(u32p) if with_m else None)
+                         seed, n_threads, hist.ctypes.data_as(u32p), int(per_rung), mh.ctypes.data_as(u32p) if with_m else None,
+                         float(conv_mult))
     return (hist, mh) if with_m else hist
 
 

@@ -771,26 +771,37 @@ int orc_uset_insert(uint64_t *tab, uint64_t cap, uint64_t key)
 }
 
 void orc_ptdc_droplet(const orc_model *m, const uint8_t *init, double p_sampling, int Nc, uint64_t steps, uint64_t iters,
-                      orc_rng *rng, uint64_t *tab, uint64_t cap, uint32_t *hist, int per_rung, uint32_t *mhist)
+                      orc_rng *rng, uint64_t *tab, uint64_t cap, uint32_t *hist, int per_rung, uint32_t *mhist,
+                      double conv_mult, uint64_t *steps_done)
 {
     orc_ladder *ld = orc_ladder_new(m, init, p_sampling, Nc, 0.0);      /* decoders.py:182,196: no p_logical */
     const size_t nq = (size_t)ld->nq;
-    for (uint64_t step = 0; step < steps; ++step) {                     /* :142 */
+    /* the early stop looks at the droplet's OWN dictionary (each droplet is a separate process in the reference), while `tab`
+     * may be shared by the droplets of a class: keep a private set for it */
+    uint64_t *own = (conv_mult != 0 && !per_rung) ? (uint64_t *)calloc(cap, sizeof(uint64_t)) : NULL;
+    uint64_t shortest = 2 * (uint64_t)m->L * (uint64_t)m->L;           /* :140, :242 */
+    double stop = (double)steps;                                        /* :241 (PTDC_droplet sets it at step 0, :156) */
+    uint64_t step;
+    for (step = 0; step < steps; ++step) {                              /* :142 */
         orc_ladder_step(ld, iters, rng);                                /* :144 */
         for (int c = 0; c < Nc; ++c) {                                  /* :146-152 */
             const uint8_t *st = ld->states + (size_t)c * nq;
             const size_t set = per_rung ? (size_t)c : 0;
-            const uint64_t n = orc_count_errors(nq, st);
-            if (orc_uset_insert(tab + set * cap, cap, orc_state_key(st, nq))) hist[set * (nq + 1) + n]++;
+            const uint64_t n = orc_count_errors(nq, st), key = orc_state_key(st, nq);
+            if (orc_uset_insert(tab + set * cap, cap, key)) hist[set * (nq + 1) + n]++;
             if (mhist) mhist[set * (nq + 1) + n]++;
+            if (own && orc_uset_insert(own, cap, key) && n <= shortest) { shortest = n; stop = (double)step * conv_mult; }   /* :153-156 */
         }
+        if (own && (double)step >= stop && step * 100 >= steps) { ++step; break; }   /* :159-162 */
     }
+    if (steps_done) *steps_done = step;
+    free(own);
     orc_ladder_free(ld);
 }
 
 void orc_ptdc_batch(const orc_model *m, const uint8_t *init, uint64_t N, int ncls, int D, int init_per_droplet,
                     uint32_t first_syndrome, double p_sampling, int Nc, uint64_t steps, uint64_t iters, uint64_t seed,
-                    int n_threads, uint32_t *hist_out, int per_rung, uint32_t *mhist_out)
+                    int n_threads, uint32_t *hist_out, int per_rung, uint32_t *mhist_out, double conv_mult)
 {
     const size_t nq = (size_t)orc_nq(m->code, m->L);
     uint64_t cap = 16;
@@ -813,7 +824,7 @@ void orc_ptdc_batch(const orc_model *m, const uint8_t *init, uint64_t N, int ncl
             orc_rng rng;
             orc_rng_init_philox(&rng, seed, first_syndrome + (uint32_t)(sc * D + d));
             orc_ptdc_droplet(m, init + (size_t)(init_per_droplet ? sc * D + d : sc) * nq, p_sampling, Nc, steps, iters, &rng, tab, cap,
-                             hist_out + out, per_rung, mhist_out ? mhist_out + out : NULL);
+                             hist_out + out, per_rung, mhist_out ? mhist_out + out : NULL, conv_mult, NULL);
         }
         free(tab);
     }

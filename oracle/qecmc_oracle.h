@@ -165,13 +165,18 @@ int orc_uset_insert(uint64_t *tab, uint64_t cap, uint64_t key);
  * per_rung != 0 is PTRC_droplet (decoders.py:584-631): one set per rung -- tab = [Nc][cap], hist = [Nc][nq+1].
  * mhist (nullable, same shape as hist): m(n), EVERY observation of a chain of length n (the len_counts of :606-618 / STRC_droplet :768-776). */
 void orc_ptdc_droplet(const orc_model *m, const uint8_t *init, double p_sampling, int Nc, uint64_t steps, uint64_t iters,
-                      orc_rng *rng, uint64_t *tab, uint64_t cap, uint32_t *hist /*[nq+1]*/, int per_rung, uint32_t *mhist);
+                      orc_rng *rng, uint64_t *tab, uint64_t cap, uint32_t *hist /*[nq+1]*/, int per_rung, uint32_t *mhist,
+                      double conv_mult, uint64_t *steps_done);
+/* conv_mult != 0: the early stop of PTDC_droplet / STDC_droplet / STRC_droplet (decoders.py:153-162, :256-262, :783-826):
+ * whenever a chain that is new to the droplet's own dictionary has length <= the shortest seen so far, stop = step * conv_mult;
+ * sampling ends after the first step with step >= stop and step * 100 >= steps.  (PTRC_droplet's stop is commented out in
+ * the reference, :627-630.)  steps_done (nullable): the number of steps run. */
 /* N syndromes x ncls class representatives x D droplets; droplet ladders of one (syndrome, class) share a set (the dict
  * merge of decoders.py:220-226).  Ladder l = (s * ncls + c) * D + d draws from Philox syndrome first_syndrome + l.
  * init uint8[N][ncls][nq]; hist_out uint32[N][ncls][nq+1] = number of unique chains of each length, N(n). */
 void orc_ptdc_batch(const orc_model *m, const uint8_t *init, uint64_t N, int ncls, int D, int init_per_droplet,
                     uint32_t first_syndrome, double p_sampling, int Nc, uint64_t steps, uint64_t iters, uint64_t seed,
-                    int n_threads, uint32_t *hist_out, int per_rung, uint32_t *mhist_out);
+                    int n_threads, uint32_t *hist_out, int per_rung, uint32_t *mhist_out, double conv_mult);
 /* init_per_droplet: init is [N][ncls][D][nq] (STDC's rain).  per_rung = 0: one set per (syndrome, class), outputs
  * [N][ncls][nq+1]; per_rung != 0 (PTRC): one set per (ladder, rung), outputs [N][ncls][D][Nc][nq+1].  mhist_out nullable. */   /* deterministic exp for y <= 0 (IEEE +,*,fma only): bit-identical on CPU and GPU */
 

@@ -20,6 +20,7 @@ Fixtures
   f1_surf.npz / f2_surf.npz   the same for the XZZX and rotated codes, incl. the biased chain
   f2_alpha.npz                Chain_alpha / Ladder_alpha / PTEQ_alpha trajectories (src/mcmc_alpha.py)
   f_ptdc.npz                  PTDC_droplet unique-chain length histograms N(n) and PTDC percent vectors (decoders.py:138-233)
+  f_convmult.npz              the conv_mult early stop of PTDC_droplet / STDC_droplet / STDC / STRC (decoders.py:153-162,:256-262,:783-826)
   f_planar.npz                Planar_code stencil KATs and Chain (incl. update_chain_fast) / Ladder / PTEQ trajectories
 """
 import argparse
@@ -644,6 +645,64 @@ def gen_ptdc(tm, pm, mc, dec):
     print("f_ptdc.npz", cases)
 
 
+def gen_convmult(tm, pm, mc, dec):
+    """The conv_mult early stop (decoders.py:153-162, :256-262, :783-826): same set-ups as f_ptdc with conv_mult != 0; the number
+    of draws consumed pins the step at which each droplet stopped."""
+    rng = np.random.default_rng(909)
+    out = {}
+    cases = []
+    for i, (name, L, p, Nc, steps, perr, cm) in enumerate([("toric", 3, 0.1, 3, 400, 0.15, 2.0), ("toric", 5, 0.1, 5, 300, 0.1, 2.0),
+                                                          ("planar", 3, 0.15, 3, 500, 0.15, 3.0), ("planar", 5, 0.1, 4, 300, 0.1, 1.5),
+                                                          ("toric", 4, 0.3, 2, 1000, 0.2, 2.0)]):
+        m = rand_matrix(rng, L, perr) if name == "toric" else rand_planar(rng, L, perr)
+        seed = 9000 + i
+        code = tm.Toric_code(L) if name == "toric" else pm.Planar_code(L)
+        code.qubit_matrix = m.copy()
+        s = Stream(seed); install(s, tm, pm, mc)
+        ld = mc.Ladder(p, code, Nc)
+        samples = dec.PTDC_droplet(ld, steps, 10, cm)
+        restore(tm, pm, mc)
+        tag = f"drop{i}"
+        out[f"{tag}_init"] = m
+        out[f"{tag}_hist"] = np.bincount(np.array(list(samples.values()), dtype=np.int64), minlength=m.size + 1).astype(np.uint32)
+        out[f"{tag}_par"] = np.array([0 if name == "toric" else 3, L, p, Nc, steps, seed, s.n, cm], dtype=np.float64)
+        cases.append(tag)
+    for i, (L, p, steps, perr, cm) in enumerate([(3, 0.15, 600, 0.15, 2.0), (5, 0.1, 800, 0.1, 2.5)]):
+        m = rand_planar(rng, L, perr)
+        seed = 9200 + i
+        code = pm.Planar_code(L); code.qubit_matrix = m.copy()
+        s = Stream(seed); install(s, tm, pm, mc)
+        ch = mc.Chain(p, code)
+        samples = dec.STDC_droplet(ch, steps, False, cm)
+        restore(tm, pm, mc)
+        tag = f"sdrop{i}"
+        out[f"{tag}_init"] = m
+        out[f"{tag}_hist"] = np.bincount(np.array(list(samples.values()), dtype=np.int64), minlength=m.size + 1).astype(np.uint32)
+        out[f"{tag}_par"] = np.array([L, p, steps, seed, s.n, cm], dtype=np.float64)
+        cases.append(tag)
+    for i, (fn, L, p_error, p_sampling, steps, perr, cm) in enumerate([("STDC", 3, 0.1, None, 600, 0.15, 2.0),
+                                                                      ("STRC", 3, 0.1, 0.2, 800, 0.15, 2.0),
+                                                                      ("STRC", 4, 0.08, 0.25, 600, 0.1, 3.0)]):
+        m = rand_planar(rng, L, perr)
+        seed = 9300 + i
+        inits = []
+        for op in range(4):
+            c = pm.Planar_code(L); c.qubit_matrix, _ = pm._apply_logical(m.copy(), op, 0, 0)
+            inits.append(c)
+        inits.sort(key=lambda c: c.define_equivalence_class())
+        s = Stream(seed); install(s, tm, pm, mc)
+        dist = getattr(dec, fn)(inits, p_error, p_sampling=p_sampling, droplets=1, steps=steps, conv_mult=cm)
+        restore(tm, pm, mc)
+        tag = f"{fn.lower()}{i}"
+        out[f"{tag}_classes"] = np.array([c.qubit_matrix for c in inits], dtype=np.uint8)
+        out[f"{tag}_dist"] = np.asarray(dist, dtype=np.float64)
+        out[f"{tag}_par"] = np.array([L, p_error, p_sampling or p_error, steps, seed, s.n, cm], dtype=np.float64)
+        cases.append(tag)
+    out["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(HERE, "f_convmult.npz"), **out)
+    print("f_convmult.npz", cases, {c: int(out[c + "_par"][-2]) for c in cases})
+
+
 def _f3_worker(args):
     (L, p, Nc, iters, steps, burn, m, seed) = args
     tm, mc, dec = import_reference()
@@ -706,14 +765,15 @@ def main():
         print("reference not present; nothing to do")
         return
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="f1,f2,f3,f4,f1s,f2s,f2a,fp,fd")
+    ap.add_argument("--only", default="f1,f2,f3,f4,f1s,f2s,f2a,fp,fd,fc")
     only = set(ap.parse_args().only.split(","))
     tm, mc, dec = import_reference()
     if "f1" in only: gen_f1(tm)
     if "f2" in only: gen_f2(tm, mc, dec)
     if "f4" in only: gen_f4(tm, mc)
-    if "fp" in only or "fd" in only:
+    if "fp" in only or "fd" in only or "fc" in only:
         import src.planar_model as pm
+        if "fc" in only: gen_convmult(tm, pm, mc, dec)
         if "fp" in only: gen_planar(pm, mc, dec)
         if "fd" in only: gen_ptdc(tm, pm, mc, dec)
     if "f1s" in only or "f2s" in only or "f2a" in only:

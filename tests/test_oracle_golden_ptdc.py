@@ -121,3 +121,51 @@ def test_state_key_and_set():
     states = r.integers(0, 4, size=(2000, 50), dtype=np.uint8)
     keys = {int(orc.lib().orc_state_key(orc._u8(s), s.size)) for s in states}
     assert len(keys) == len({s.tobytes() for s in states}) and 0 not in keys
+
+
+# ---- the conv_mult early stop (decoders.py:153-162, :256-262, :783-826), f_convmult.npz ----------------------------------------------
+
+def _loadc():
+    return np.load(os.path.join(GOLDEN, "f_convmult.npz"))
+
+
+def _casesc(prefix):
+    return [str(c) for c in _loadc()["cases"] if str(c).startswith(prefix)]
+
+
+@pytest.mark.parametrize("case", _casesc("drop"))
+def test_convmult_ptdc_droplet(case):
+    """The draws consumed pin the step at which the droplet stopped; N(n) pins what it had seen by then."""
+    g = _loadc()
+    code, L, p, Nc, steps, seed, ndraw, cm = g[f"{case}_par"]
+    rng = orc.Rng.stream(_stream(int(seed), int(ndraw)))
+    hist, _ = orc.ptdc_droplet(int(code), g[f"{case}_init"], float(p), int(Nc), int(steps), rng=rng, conv_mult=float(cm))
+    assert rng.consumed == int(ndraw)
+    assert np.array_equal(hist, g[f"{case}_hist"])
+    full, _ = orc.ptdc_droplet(int(code), g[f"{case}_init"], float(p), int(Nc), int(steps), rng=orc.Rng.stream(_stream(int(seed), 10 ** 5)))
+    assert full.sum() > hist.sum()                       # the stop really cut the run short
+
+
+@pytest.mark.parametrize("case", _casesc("sdrop"))
+def test_convmult_stdc_droplet(case):
+    g = _loadc()
+    L, p, steps, seed, ndraw, cm = g[f"{case}_par"]
+    rng = orc.Rng.stream(_stream(int(seed), int(ndraw)))
+    hist, _ = orc.ptdc_droplet(orc.PLANAR, g[f"{case}_init"], float(p), 1, int(steps), iters=5, rng=rng, conv_mult=float(cm))
+    assert rng.consumed == int(ndraw)
+    assert np.array_equal(hist, g[f"{case}_hist"])
+
+
+@pytest.mark.parametrize("case", _casesc("st"))
+def test_convmult_stdc_strc_distribution(case):
+    from qecmc.decoders import strc_distribution
+    g = _loadc()
+    L, p_error, p_sampling, steps, seed, ndraw, cm = g[f"{case}_par"]
+    rng = orc.Rng.stream(_stream(int(seed), int(ndraw)))
+    res = [orc.ptdc_droplet(orc.PLANAR, r, float(p_sampling), 1, int(steps), iters=5, rng=rng, with_m=True, conv_mult=float(cm))
+           for r in g[f"{case}_classes"]]
+    assert rng.consumed == int(ndraw)
+    hist, mh = np.stack([r[0] for r in res]), np.stack([r[1] for r in res])
+    dist = orc.ptdc_distribution(hist, float(p_error)) if case.startswith("stdc") else \
+        strc_distribution(hist, mh, float(p_error), float(p_sampling))
+    assert np.allclose(dist, g[f"{case}_dist"], rtol=1e-12, atol=0)
