@@ -186,6 +186,17 @@ enum { QECMC_PTDC_INIT_PER_DROPLET = 1, QECMC_PTDC_SET_PER_RUNG = 2 };
 int qecmc_ptdc_batch(const qecmc_params *params, const uint8_t *init, uint64_t N, int32_t droplets,
                      uint32_t flags, uint32_t *hist_out, uint32_t *m_out, qecmc_stats *stats_out);
 
+/* The same with the `conv_mult` early stop of PTDC_droplet (decoders.py:153-162), STDC_droplet (:256-262) and STRC_droplet
+ * (:783-826): whenever a ladder step finds a chain that is new to the DROPLET's own dictionary and no longer than the
+ * shortest it has seen (initially 2 L^2, :140), stop = step * conv_mult; the droplet records nothing after the first step
+ * with step >= stop and step * 100 >= params->steps.  conv_mult = 0 is qecmc_ptdc_batch.  With QECMC_PTDC_SET_PER_RUNG
+ * conv_mult is ignored, as PTRC_droplet's stop is commented out in the reference (:627-630).
+ * steps_done_out (nullable) uint32[N][ncls][droplets]: ladder steps each droplet recorded.  A workgroup of 64 droplets
+ * leaves the step loop once all of them have stopped. */
+int qecmc_ptdc_batch_conv(const qecmc_params *params, const uint8_t *init, uint64_t N, int32_t droplets,
+                          uint32_t flags, double conv_mult, uint32_t *hist_out, uint32_t *m_out,
+                          uint32_t *steps_done_out, qecmc_stats *stats_out);
+
 /* Plan + device-pointer form: build once (validates, uploads threshold tables),
  * then launch asynchronously on a caller stream with buffers already in HBM.
  * d_workspace: qecmc_plan_workspace_bytes() bytes (0 for conv_mode NONE, then NULL is fine). */

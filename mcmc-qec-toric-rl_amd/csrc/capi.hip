@@ -675,8 +675,15 @@ int qecmc_pteq_batch(const qecmc_params *params, const uint8_t *init, uint64_t N
 int qecmc_ptdc_batch(const qecmc_params *params, const uint8_t *init, uint64_t N, int32_t droplets, uint32_t flags,
                      uint32_t *hist_out, uint32_t *m_out, qecmc_stats *stats_out)
 {
+    return qecmc_ptdc_batch_conv(params, init, N, droplets, flags, 0.0, hist_out, m_out, nullptr, stats_out);
+}
+
+int qecmc_ptdc_batch_conv(const qecmc_params *params, const uint8_t *init, uint64_t N, int32_t droplets, uint32_t flags,
+                          double conv_mult, uint32_t *hist_out, uint32_t *m_out, uint32_t *steps_done_out, qecmc_stats *stats_out)
+{
     const auto t0 = std::chrono::steady_clock::now();
     if (!params) return fail(QECMC_ERR_INVALID, "params is NULL");
+    if (!(conv_mult >= 0.0) || !std::isfinite(conv_mult)) return fail(QECMC_ERR_INVALID, "conv_mult=%g must be finite and >= 0", conv_mult);
     qecmc_params p = *params;
     p.p_logical = 0.0;                                   // Ladder(p_sampling, code, Nc): decoders.py:182,196
     p.conv_mode = QECMC_CONV_NONE;
@@ -696,7 +703,11 @@ int qecmc_ptdc_batch(const qecmc_params *params, const uint8_t *init, uint64_t N
     if (M + p.first_syndrome > 0xFFFFFFFFull) return fail(QECMC_ERR_INVALID, "first_syndrome + N * classes * droplets = %llu ladders exceed the 32-bit syndrome index", (unsigned long long)(M + p.first_syndrome));
     uint64_t cap = 16;
     while (cap < 2 * p.steps * (per_rung ? 1 : Nc * D)) cap <<= 1;    // twice the insertions one set can see
-    const uint64_t need = sets * cap * 8 + M * nq + sets * (nq + 1) * 8;
+    if (per_rung) conv_mult = 0.0;                                    // PTRC_droplet's stop is commented out (decoders.py:627-630)
+    const bool own = conv_mult != 0.0 && D > 1;                       // the stop looks at each droplet's own dictionary
+    uint64_t own_cap = 16;
+    while (own_cap < 2 * p.steps * Nc) own_cap <<= 1;
+    const uint64_t need = sets * cap * 8 + M * nq + sets * (nq + 1) * 8 + (own ? M * own_cap * 8 : 0) + M * 4;
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     if (need > free_b - free_b / 8)
@@ -707,8 +718,10 @@ int qecmc_ptdc_batch(const qecmc_params *params, const uint8_t *init, uint64_t N
     for (uint64_t sc = 0; sc < N * ncls; ++sc)
         for (size_t d = 0; d < D; ++d)
             std::memcpy(&st[(sc * D + d) * nq], init + (init_per_droplet ? sc * D + d : sc) * nq, nq);
-    DevBuf ds, dtab, dh, dm;
+    DevBuf ds, dtab, dh, dm, down, dsd;
     HIP_TRY(ds.alloc(st.size()));
+    if (own) { HIP_TRY(down.alloc(M * own_cap * 8)); HIP_TRY(hipMemset(down.p, 0, M * own_cap * 8)); }
+    if (steps_done_out) HIP_TRY(dsd.alloc(M * 4));
     HIP_TRY(dtab.alloc(sets * cap * 8)); HIP_TRY(dh.alloc(sets * (nq + 1) * 4));
     if (m_out) { HIP_TRY(dm.alloc(sets * (nq + 1) * 4)); HIP_TRY(hipMemset(dm.p, 0, sets * (nq + 1) * 4)); }
     HIP_TRY(hipMemcpy(ds.p, st.data(), st.size(), hipMemcpyHostToDevice));
@@ -722,6 +735,8 @@ int qecmc_ptdc_batch(const qecmc_params *params, const uint8_t *init, uint64_t N
     a.N = M; a.first_syndrome = p.first_syndrome; a.nsteps = p.steps; a.step0 = 0; a.prop0 = 0; a.resume = 0; a.write_states = 0;
     a.uset_tab = reinterpret_cast<unsigned long long *>(dtab.p); a.uset_cap = cap; a.uset_hist = dh.as<uint32_t>();
     a.uset_mhist = m_out ? dm.as<uint32_t>() : nullptr; a.uset_D = (uint32_t)D; a.uset_per_rung = per_rung ? 1 : 0;
+    a.uset_conv_mult = conv_mult; a.uset_own = own ? reinterpret_cast<unsigned long long *>(down.p) : nullptr; a.uset_own_cap = own_cap;
+    a.steps_done = steps_done_out ? dsd.as<uint32_t>() : nullptr;
     {
         const hipError_t e = launch_ladder_rs_toric(a, 0);
         if (e != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return fail(QECMC_ERR_HIP, "PTDC launch: %s", hipGetErrorString(e)); }
@@ -733,6 +748,7 @@ int qecmc_ptdc_batch(const qecmc_params *params, const uint8_t *init, uint64_t N
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     HIP_TRY(hipMemcpy(hist_out, dh.p, sets * (nq + 1) * 4, hipMemcpyDeviceToHost));
     if (m_out) HIP_TRY(hipMemcpy(m_out, dm.p, sets * (nq + 1) * 4, hipMemcpyDeviceToHost));
+    if (steps_done_out) HIP_TRY(hipMemcpy(steps_done_out, dsd.p, M * 4, hipMemcpyDeviceToHost));
     if (stats_out) {
         stats_out->proposals = M * Nc * p.iters * p.steps;
         stats_out->swap_tests = M * (Nc - 1) * p.steps;

@@ -33,6 +33,11 @@ struct LadderArgs {
     uint32_t *uset_mhist;           // [sets][nq+1] m(n): observations by length (nullable)
     uint32_t uset_D;                // droplets per set
     int uset_per_rung;
+    // conv_mult early stop (decoders.py:153-162): 0 = off.  uset_own (nullable): one private set per ladder, needed when a
+    // class set is shared by several droplets (the stop looks at the droplet's own dictionary)
+    double uset_conv_mult;
+    unsigned long long *uset_own;   // [N][uset_own_cap]
+    uint64_t uset_own_cap;
     int bias_lds;             //                    the kernel copies bias_tbl into LDS (fits: capi.hip decides)
     const double *alpha_lnb;  // [Nc-1]             ln(pz_tilde[i] / pz_tilde[i+1]) (alpha noise, mcmc_alpha.py:123)
     double alpha;             //                    mcmc_alpha.py:11

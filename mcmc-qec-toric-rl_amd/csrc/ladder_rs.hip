@@ -279,6 +279,9 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
     for (int i = tid; i < NC * W * 64; i += nthreads) st[i] = 0;
     for (int i = tid; i < ncls * 64; i += nthreads) hist[i] = 0;
     if (tid == 0) *stopf = 0;
+    if constexpr (USET) {
+        for (int i = tid; i < 3 * 64; i += nthreads) hist[i] = i < 64 ? 2u * (uint32_t)LL : 0xFFFFFFFFu;   // decoders.py:140,242; "never"
+    }
     if constexpr (kWideGen) {
         for (int i = tid; i < 4 * (int)a.n_gen; i += nthreads) {
             const uint32_t e = reinterpret_cast<const uint16_t *>(a.gen)[i], q = e >> 2;
@@ -351,6 +354,10 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
     // convergence criterion of decoders.py:74-82,93-105 (wave 0 only): window sums over the logged
     // bottom-chain error counts, Q2 = series[l/4 : l/2], Q4 = series[3l/4 : l]
     uint32_t burn = 0, conv_start = 0, conv_streak = 0, done = 0, steps_done = 0, conv_ok = 0;
+    // conv_mult early stop of the unique-chain droplets (USET): replicated on every wave of the ladder
+    [[maybe_unused]] uint32_t cm_done = 0, cm_steps = 0, cm_last = 0;
+    [[maybe_unused]] uint32_t *cm_short = hist;          // [64]     shortest chain the droplet has seen (the histogram rows are idle in USET runs)
+    [[maybe_unused]] uint32_t *cm_trig = hist + 64;      // [2][64]  last step (of each parity) that found a new chain no longer than that
     uint64_t sumA = 0, sumB = 0;
     [[maybe_unused]] uint64_t sumAxy = 0, sumBxy = 0;          // alpha noise: window sums of n_x + n_y (sumA / sumB hold n_z)
     if (a.resume && lane < cnt) {
@@ -935,7 +942,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
 #ifndef QECMC_EXP_NOBARRIER   // QECMC_EXP_*: timing experiments only (tools/exp_build.sh), results are wrong
         __syncthreads();
 #endif
-        if (CONV) {                                         // flags set one step earlier: uniform for the workgroup
+        if (CONV || USET) {                                 // flags set one step earlier: uniform for the workgroup
             volatile uint32_t *f0 = lds_all + (NC * W * 64 + 4 * NC * 64 + ncls * 64 + NC * 9 + NC * kSwapFast);
             if (f0[0]) break;
         }
@@ -1043,9 +1050,17 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             if (CONV && wave_u == 0 && __all(done || lane >= cnt)) *stopf = 1;
             if (slot_u == 0) flag = 0;                                              // :103
             if constexpr (USET) {
+                const bool cm = a.uset_conv_mult != 0.0;
+                if (cm && t > 0 && !cm_done) {
+                    // the stop test that ends step t-1 (decoders.py:159-162, :261-262, :825-826), now that every rung's
+                    // insertion of that step is behind this step's barrier
+                    const uint32_t tp = (uint32_t)t - 1u;
+                    if (cm_trig[(tp & 1u) * 64 + lane] == tp) cm_last = tp;         // stop = step * conv_mult, :156
+                    if ((double)tp >= (double)cm_last * a.uset_conv_mult && (uint64_t)tp * 100u >= a.nsteps) { cm_done = 1; cm_steps = (uint32_t)t; }
+                }
                 // PTDC_droplet / PTRC_droplet (decoders.py:146-152, :596-618): the configuration now in this wave's rung goes into
                 // the set of chains seen so far.  Key = FNV-1a over the packed words (any collision-free key gives the same N(n)).
-                if (lane < cnt) {
+                if (lane < cnt && !cm_done) {
                     const uint32_t *sw = st + sid * W * 64 + lane;
                     uint64_t h = 0xCBF29CE484222325ull;
                     for (int w = 0; w < W; ++w) h = (h ^ sw[w * 64]) * 0x100000001B3ull;
@@ -1056,13 +1071,33 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                     if (a.uset_mhist != nullptr) atomicAdd(a.uset_mhist + set * (uint64_t)(nq + 1) + n, 1u);
                     unsigned long long *tb = a.uset_tab + set * a.uset_cap;
                     uint64_t idx = ((key * 0x9E3779B97F4A7C15ull) >> 20) & (a.uset_cap - 1);
+                    bool fresh = false;
                     for (uint64_t probes = 0; probes < a.uset_cap; ++probes) {     // the table holds twice the insertions it can see
                         const unsigned long long old = atomicCAS(tb + idx, 0ull, key);
-                        if (old == 0ull) { atomicAdd(a.uset_hist + set * (uint64_t)(nq + 1) + n, 1u); break; }
+                        if (old == 0ull) { atomicAdd(a.uset_hist + set * (uint64_t)(nq + 1) + n, 1u); fresh = true; break; }
                         if (old == key) break;
                         idx = (idx + 1) & (a.uset_cap - 1);
                     }
+                    if (cm) {
+                        if (a.uset_own != nullptr) {
+                            // the stop looks at the droplet's own dictionary (one process per droplet in the reference, :213-219),
+                            // the class set above is the union over the droplets (:220-226)
+                            unsigned long long *ob = a.uset_own + ladder * a.uset_own_cap;
+                            uint64_t oi = ((key * 0x9E3779B97F4A7C15ull) >> 20) & (a.uset_own_cap - 1);
+                            fresh = false;
+                            for (uint64_t probes = 0; probes < a.uset_own_cap; ++probes) {
+                                const unsigned long long old = atomicCAS(ob + oi, 0ull, key);
+                                if (old == 0ull) { fresh = true; break; }
+                                if (old == key) break;
+                                oi = (oi + 1) & (a.uset_own_cap - 1);
+                            }
+                        }
+                        // "if conv_mult and length <= shortest" (:153-156) on the rungs in any order: the step extends the run
+                        // iff its shortest new chain is no longer than the shortest seen before, and that rung always passes
+                        if (fresh && n <= atomicMin(&cm_short[lane], n)) cm_trig[((uint32_t)t & 1u) * 64 + lane] = (uint32_t)t;
+                    }
                 }
+                if (cm && wave_u == 0 && __all(cm_done || lane >= cnt)) *stopf = 1;
             }
         }
     }
@@ -1082,7 +1117,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
         }
     if (slot == 0 && lane < cnt) {
         if (a.samples != nullptr) a.samples[s0 + lane] = samples;
-        if (a.steps_done != nullptr) a.steps_done[s0 + lane] = done ? steps_done : (uint32_t)a.nsteps;
+        if (a.steps_done != nullptr) a.steps_done[s0 + lane] = USET ? (cm_done ? cm_steps : (uint32_t)a.nsteps) : done ? steps_done : (uint32_t)a.nsteps;
         if (a.converged != nullptr) a.converged[s0 + lane] = (uint8_t)conv_ok;
         if (a.tops0 != nullptr) a.tops0[s0 + lane] = tops0;
         if (a.flags != nullptr)

@@ -91,8 +91,8 @@ def _pteq(init_code, p, eta, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, conv_c
 
 
 def ptdc_batch(init, p_sampling, Nc=None, steps=2000, droplets=1, iters=10, seed=0, first_syndrome=0, device=0, code=L_.TORIC,
-               return_stats=False, per_rung=False, with_m=False):
-    """The sampling half of PTDC (decoders.py:168-233, conv_mult = 0) on N syndromes at once.
+               return_stats=False, per_rung=False, with_m=False, conv_mult=0.0, return_steps=False):
+    """The sampling half of PTDC (decoders.py:168-233) on N syndromes at once.
 
     init: uint8[N, ncls, ...] -- one representative per equivalence class for every syndrome (what `to_class` / the list
     form of init_code provides) -- or uint8[N, ncls, droplets, ...] with a start of its own for every droplet (STDC's rain).
@@ -100,7 +100,9 @@ def ptdc_batch(init, p_sampling, Nc=None, steps=2000, droplets=1, iters=10, seed
     uint32[N, ncls, nq+1], the number of DISTINCT chains of each length seen by any rung of any droplet (PTDC_droplet's
     dict, decoders.py:146-152,220-226).  `steps` is per ladder: PTDC passes steps // Nc (:201).  Nc = 1, iters = 5 is
     STDC_droplet / STRC_droplet (:236-265, :745-830).  per_rung=True keeps one set per (ladder, rung) as PTRC_droplet
-    does (:584-631): shape [N, ncls, droplets, Nc, nq+1].  with_m=True also returns m(n), all observations by length."""
+    does (:584-631): shape [N, ncls, droplets, Nc, nq+1].  with_m=True also returns m(n), all observations by length.
+    conv_mult != 0 is the early stop of PTDC_droplet / STDC_droplet / STRC_droplet (:153-162, :256-262, :783-826), per
+    droplet; return_steps=True appends steps_done uint32[N, ncls, droplets], the steps each droplet recorded."""
     nd = 3 if code in (L_.TORIC, L_.PLANAR) else 2
     a = np.ascontiguousarray(init, dtype=np.uint8)
     per_droplet = a.ndim == nd + 3
@@ -118,8 +120,12 @@ def ptdc_batch(init, p_sampling, Nc=None, steps=2000, droplets=1, iters=10, seed
     mh = np.zeros(shape, dtype=np.uint32) if with_m else None
     stats = L_.Stats()
     flags = (L_.PTDC_INIT_PER_DROPLET if per_droplet else 0) | (L_.PTDC_SET_PER_RUNG if per_rung else 0)
-    L_.check(L_.lib().qecmc_ptdc_batch(pr, L_.u8(a), N, int(droplets), flags, L_.u32(hist), L_.u32(mh) if with_m else None, stats))
+    sd = np.zeros((N, ncls, int(droplets)), dtype=np.uint32) if return_steps else None
+    L_.check(L_.lib().qecmc_ptdc_batch_conv(pr, L_.u8(a), N, int(droplets), flags, float(conv_mult or 0.0), L_.u32(hist),
+                                            L_.u32(mh) if with_m else None, L_.u32(sd) if return_steps else None, stats))
     out = (hist, mh) if with_m else hist
+    if return_steps:
+        out = (out if isinstance(out, tuple) else (out,)) + (sd,)
     if return_stats:
         return out, dict(proposals=int(stats.proposals), kernel_ms=float(stats.kernel_ms), total_ms=float(stats.total_ms))
     return out
@@ -135,9 +141,7 @@ def ptdc_distribution(hist, p_error):
 
 def PTDC(init_code, p_error, p_sampling=None, droplets=4, Nc=None, steps=20000, conv_mult=0, seed=None):
     """Drop-in for decoders.PTDC (decoders.py:168): same arguments, returns the uint8 percent vector.  init_code is a code
-    with `to_class` (toric) or a list with one code per class.  conv_mult (the early stop of :157-162) must be 0."""
-    if conv_mult:
-        raise NotImplementedError("PTDC's conv_mult early stop is not built; pass conv_mult=0 (the reference's default)")
+    with `to_class` (toric) or a list with one code per class.  conv_mult: the early stop of :153-162."""
     p_sampling = p_sampling or p_error
     if isinstance(init_code, list):
         assert len(init_code) == init_code[0].nbr_eq_classes, 'if init_code is a list, it has to contain one code for each class'
@@ -145,7 +149,7 @@ def PTDC(init_code, p_error, p_sampling=None, droplets=4, Nc=None, steps=20000, 
     else:
         code0, reps = init_code, [init_code.to_class(eq) for eq in range(init_code.nbr_eq_classes)]
     Nc = Nc or code0.system_size
-    hist = ptdc_batch(np.stack(reps)[None], p_sampling, Nc=Nc, steps=steps // Nc, droplets=droplets,
+    hist = ptdc_batch(np.stack(reps)[None], p_sampling, Nc=Nc, steps=steps // Nc, droplets=droplets, conv_mult=conv_mult,
                       seed=_fresh_seed() if seed is None else seed, code=_code_id(code0))
     return ptdc_distribution(hist[0], p_error).astype(np.uint8)
 
@@ -155,9 +159,7 @@ def STDC(init_code, p_error, p_sampling=None, droplets=10, steps=20000, conv_mul
     Z_E from the distinct chains found; returns the float percent vector.  init_code: a list with one code per class
     (no rain, :279), or a code with `to_class` (then every droplet starts from `apply_stabilizers_uniform()`, :246-247,
     :292).  The reference's jitted loop is hard-wired to the planar stencil (quirk Q1), which is the only model it is
-    correct for; here the chain runs on the stencil of the code it is given.  conv_mult must be 0."""
-    if conv_mult:
-        raise NotImplementedError("STDC's conv_mult early stop is not built; pass conv_mult=0 (the reference's default)")
+    correct for; here the chain runs on the stencil of the code it is given.  conv_mult: the early stop of :256-262."""
     p_sampling = p_sampling or p_error
     import copy
     if isinstance(init_code, list):
@@ -173,7 +175,7 @@ def STDC(init_code, p_error, p_sampling=None, droplets=10, steps=20000, conv_mul
             reps.append(np.stack([c.apply_stabilizers_uniform() for _ in range(droplets)]))     # rain, one per droplet
         init = np.stack(reps)[None]
     hist = ptdc_batch(init, p_sampling, Nc=1, steps=steps, droplets=droplets, iters=5, seed=_fresh_seed() if seed is None else seed,
-                      code=_code_id(code0))
+                      code=_code_id(code0), conv_mult=conv_mult)
     return ptdc_distribution(hist[0], p_error)
 
 
@@ -234,12 +236,10 @@ def _class_starts(init_code, droplets, rain):
 
 def STRC(init_code, p_error, p_sampling=None, droplets=10, steps=20000, conv_mult=0, seed=None):
     """Drop-in for decoders.STRC (decoders.py:835-949): single chains as in STDC; the estimate uses m(n) and the number of
-    distinct chains at the two shortest lengths.  Returns the float percent vector.  conv_mult must be 0."""
-    if conv_mult:
-        raise NotImplementedError("STRC's conv_mult early stop is not built; pass conv_mult=0 (the reference's default)")
+    distinct chains at the two shortest lengths.  Returns the float percent vector.  conv_mult: the early stop of :783-826."""
     p_sampling = p_sampling or p_error
     code0, init = _class_starts(init_code, droplets, rain=True)
-    n_u, m_o = ptdc_batch(init, p_sampling, Nc=1, steps=steps, droplets=droplets, iters=5, with_m=True,
+    n_u, m_o = ptdc_batch(init, p_sampling, Nc=1, steps=steps, droplets=droplets, iters=5, with_m=True, conv_mult=conv_mult,
                           seed=_fresh_seed() if seed is None else seed, code=_code_id(code0))
     return strc_distribution(n_u[0], m_o[0], p_error, p_sampling)
 

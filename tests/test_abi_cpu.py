@@ -59,6 +59,15 @@ def test_argument_validation_precedes_everything(kw, frag):
     assert rc in (-1, -4) and frag in L_.lib().qecmc_last_error()
 
 
+def test_ptdc_conv_mult_validation():
+    pr = L_.make_params(L=3, Nc=3, p=0.1, steps=10)
+    h = np.zeros((1, 16, 19), dtype=np.uint32)
+    init = np.zeros((1, 16, 2, 3, 3), dtype=np.uint8)
+    for bad in (-1.0, float("nan"), float("inf")):
+        rc = L_.lib().qecmc_ptdc_batch_conv(pr, L_.u8(init), 1, 1, 0, bad, L_.u32(h), None, None, None)
+        assert rc == -1 and b"conv_mult" in L_.lib().qecmc_last_error()
+
+
 def test_no_cpu_fallback():
     if qecmc.device_count() > 0:
         pytest.skip("a GPU is visible")

@@ -73,8 +73,6 @@ def test_ptdc_dropin_matches_exact_classes(q, orc):
     assert pct.dtype == np.uint8 and pct.shape == (16,)
     P = toric_class_probabilities(m, p, orc.toric_apply_stabilizer, orc.toric_to_class) * 100
     assert pct.argmax() == P.argmax() and 0.5 * np.abs(pct.astype(np.float64) - P).sum() < 6.0
-    with pytest.raises(NotImplementedError):
-        q.PTDC(code, p, conv_mult=2.0)
     # the same ladders through the oracle
     hist = orc.ptdc_batch(orc.TORIC, _toric_reps(q, m)[None], p, 3, 6000 // 3, droplets=4, seed=17)
     assert np.array_equal(pct, orc.ptdc_distribution(hist[0], p).astype(np.uint8))
@@ -161,8 +159,6 @@ def test_strc_ptrc_dropins(q, orc):
     n_u, m_o = orc.ptdc_batch(orc.TORIC, _toric_reps(q, m)[None], 0.2, 1, 3000, droplets=3, iters=5, seed=10, with_m=True)
     assert np.allclose(dist, strc_distribution(n_u[0], m_o[0], p, 0.2), rtol=1e-12)
     assert 0.5 * np.abs(dist - P).sum() < 10.0
-    with pytest.raises(NotImplementedError):
-        q.STRC(codes, p, conv_mult=2.0)
 
 
 def test_single_temp_dropin(q, orc):
@@ -174,3 +170,55 @@ def test_single_temp_dropin(q, orc):
     means = q.single_temp(codes, 0.2, 400, seed=2)
     _, m_o = orc.ptdc_batch(orc.PLANAR, reps[None], 0.2, 1, 399, droplets=1, iters=5, seed=2, with_m=True)
     assert np.allclose(means, (m_o[0] * np.arange(m_o.shape[-1])).sum(axis=-1) / 399, rtol=1e-12) and means.shape == (4,)
+
+
+# ---- the conv_mult early stop (decoders.py:153-162, :256-262, :783-826) -------------------------------------------------------------
+
+@pytest.mark.parametrize("L,p,Nc,steps,droplets,cm,N", [(3, 0.1, 3, 400, 1, 2.0, 2), (5, 0.1, 5, 300, 3, 2.0, 1), (4, 0.3, 2, 1000, 2, 1.5, 2),
+                                                        (3, 0.2, 8, 250, 2, 3.0, 1)])
+def test_conv_mult_toric_bit_exact(q, orc, L, p, Nc, steps, droplets, cm, N):
+    """Every droplet stops on its own (its private dictionary decides), the class sets are the union over the droplets."""
+    rng = np.random.default_rng(L * 11 + steps)
+    init = np.stack([_toric_reps(q, _rand_toric(rng, L, 0.12)) for _ in range(N)])
+    got_n, got_m, sd = q.ptdc_batch(init, p, Nc=Nc, steps=steps, droplets=droplets, seed=41, first_syndrome=3, with_m=True, conv_mult=cm,
+                                    return_steps=True)
+    ref_n, ref_m = orc.ptdc_batch(orc.TORIC, init, p, Nc, steps, droplets=droplets, seed=41, first_syndrome=3, with_m=True, conv_mult=cm)
+    assert np.array_equal(got_n, ref_n) and np.array_equal(got_m, ref_m)
+    assert sd.shape == (N, 16, droplets) and sd.min() >= 1 and sd.max() <= steps and sd.min() < steps      # some droplet stopped early
+    assert np.array_equal(sd.sum(axis=-1) * Nc, got_m.sum(axis=-1))                  # every recorded step observes every rung once
+    assert np.all(sd * 100 >= steps) or np.all(sd[sd * 100 < steps] == steps)        # never before steps / 100 (:160)
+    full = q.ptdc_batch(init, p, Nc=Nc, steps=steps, droplets=droplets, seed=41, first_syndrome=3)
+    assert np.all(got_n <= full) and got_n.sum() < full.sum()                        # a prefix of the full run
+
+
+def test_conv_mult_single_chains_and_dropins(q, orc):
+    """STDC / STRC form (Nc = 1, iters = 5) with per-droplet starts; the drop-ins pass conv_mult through."""
+    rng = np.random.default_rng(77)
+    from qecmc.decoders import strc_distribution
+    m, reps = _planar_reps(rng, 5, 0.1)
+    init = np.stack([np.stack([r, r, r]) for r in reps])[None]                      # [1, 4, droplets = 3, ...]
+    got_n, got_m, sd = q.ptdc_batch(init, 0.15, Nc=1, steps=900, droplets=3, iters=5, seed=9, code=q.PLANAR, with_m=True, conv_mult=2.5,
+                                    return_steps=True)
+    ref_n, ref_m = orc.ptdc_batch(orc.PLANAR, init, 0.15, 1, 900, droplets=3, iters=5, seed=9, with_m=True, conv_mult=2.5)
+    assert np.array_equal(got_n, ref_n) and np.array_equal(got_m, ref_m) and sd.min() < 900
+    codes = []
+    for r in reps:
+        c = q.Planar_code(5); c.qubit_matrix = r.copy(); codes.append(c)
+    ref_n1, ref_m1 = orc.ptdc_batch(orc.PLANAR, reps[None], 0.15, 1, 900, droplets=3, iters=5, seed=9, with_m=True, conv_mult=2.5)
+    assert np.allclose(q.STDC(codes, 0.1, p_sampling=0.15, droplets=3, steps=900, conv_mult=2.5, seed=9),
+                       orc.ptdc_distribution(ref_n1[0], 0.1), rtol=1e-12)
+    a = q.STRC(codes, 0.1, p_sampling=0.15, droplets=3, steps=900, conv_mult=2.5, seed=9)     # list form: no rain (:846-847)
+    assert np.allclose(a, strc_distribution(ref_n1[0], ref_m1[0], 0.1, 0.15), rtol=1e-12) and abs(a.sum() - 100) < 1e-9
+    code = q.Toric_code(3); code.qubit_matrix = _rand_toric(rng, 3, 0.12)
+    pct = q.PTDC(code, 0.1, droplets=2, steps=3000, conv_mult=2.0, seed=5)
+    ref = orc.ptdc_batch(orc.TORIC, _toric_reps(q, code.qubit_matrix)[None], 0.1, 3, 1000, droplets=2, seed=5, conv_mult=2.0)
+    assert np.array_equal(pct, orc.ptdc_distribution(ref[0], 0.1).astype(np.uint8))
+
+
+def test_conv_mult_is_ignored_per_rung(q):
+    """PTRC_droplet's stop is commented out in the reference (decoders.py:627-630)."""
+    rng = np.random.default_rng(5)
+    init = _toric_reps(q, _rand_toric(rng, 3, 0.12))[None]
+    a = q.ptdc_batch(init, 0.1, Nc=3, steps=200, droplets=2, seed=1, per_rung=True, conv_mult=2.0)
+    b = q.ptdc_batch(init, 0.1, Nc=3, steps=200, droplets=2, seed=1, per_rung=True)
+    assert np.array_equal(a, b)
