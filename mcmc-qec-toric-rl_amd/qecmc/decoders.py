@@ -179,6 +179,24 @@ def STDC(init_code, p_error, p_sampling=None, droplets=10, steps=20000, conv_mul
     return ptdc_distribution(hist[0], p_error)
 
 
+def general_noise_distribution(xyz, p_xyz, shortest_only=False):
+    """STDC_general_noise's estimate (decoders.py:390-432; shortest_only / STDC_general_noise_shortest :494-507) from
+    xyz[c] = int[k_c, 3], the (n_x, n_y, n_z) of the distinct chains found in class c: Z_c = sum exp(-sum_i beta_i n_i) over
+    them -- with shortest_only over the chains whose weighted length is `np.isclose` to the smallest -- normalised, x 100."""
+    p_xyz = np.asarray(p_xyz, dtype=np.float64)
+    with np.errstate(divide="ignore"):
+        beta = -np.log((p_xyz / 3) / (1 - p_xyz))                                              # :385
+    Z = np.zeros(len(xyz))
+    for c, q in enumerate(xyz):
+        q = np.asarray(q).reshape(-1, 3)
+        with np.errstate(invalid="ignore"):
+            wl = np.sum(beta * q, axis=1, where=(q > 0))                                       # :403
+        if shortest_only:
+            wl = wl[np.isclose(wl, np.min(wl))]                                                # :407-408
+        Z[c] = np.sum(np.exp(-wl))                                                             # :411
+    return np.divide(Z, sum(Z)) * 100
+
+
 def strc_distribution(n_unique, m_obs, p_error, p_sampling):
     """STRC's estimate (decoders.py:863-949) from the counts of one syndrome: n_unique[c, n] = N(n), the distinct chains of
     length n of class c (union over the droplets); m_obs[c, n] = m(n), all observations (summed over the droplets).

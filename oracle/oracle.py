@@ -30,11 +30,11 @@ class _Rng(C.Structure):
 
 class Model(C.Structure):
     _fields_ = [("code", C.c_int), ("L", C.c_int), ("noise", C.c_int), ("eta", C.c_double), ("alpha", C.c_double),
-                ("det_pow", C.c_int), ("scan", C.c_int)]
+                ("det_pow", C.c_int), ("scan", C.c_int), ("pxyz", C.c_double * 3)]
 
 
 TORIC, XZZX, ROTATED, PLANAR = 0, 1, 2, 3
-DEPOLARIZING, BIASED, ALPHA = 0, 1, 2
+DEPOLARIZING, BIASED, ALPHA, XYZ = 0, 1, 2, 3
 
 
 class _Ladder(C.Structure):
@@ -114,10 +114,10 @@ def lib():
         _LIB.orc_det_exp.argtypes = [C.c_double]; _LIB.orc_det_exp.restype = C.c_double
         u64p = C.POINTER(C.c_uint64); u32p_ = C.POINTER(C.c_uint32)
         _LIB.orc_ptdc_droplet.argtypes = [mp, u8p, C.c_double, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(_Rng), u64p, C.c_uint64, u32p_,
-                                          C.c_int, u32p_, C.c_double, u64p]
+                                          C.c_int, u32p_, C.c_double, u64p, C.POINTER(_XyzSink)]
         _LIB.orc_ptdc_droplet.restype = None
         _LIB.orc_ptdc_batch.argtypes = [mp, u8p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_double, C.c_int, C.c_uint64,
-                                        C.c_uint64, C.c_uint64, C.c_int, u32p_, C.c_int, u32p_, C.c_double]
+                                        C.c_uint64, C.c_uint64, C.c_int, u32p_, C.c_int, u32p_, C.c_double, u32p_]
         _LIB.orc_ptdc_batch.restype = None
         _LIB.orc_state_key.argtypes = [u8p, C.c_size_t]; _LIB.orc_state_key.restype = C.c_uint64
         _LIB.orc_ladder_new.argtypes = [mp, u8p, C.c_double, C.c_int, C.c_double]
@@ -293,8 +293,10 @@ def toric_pteq_batch(init, p, Nc, steps, iters=10, tops_burn=2, seed=0, first_sy
 
 
 # ---- XZZX / rotated surface code (uint8[L,L]) and the code/noise-generic chain, ladder, PTEQ --------
-def _model(code, L, noise=DEPOLARIZING, eta=0.0, scan=0, alpha=0.0, det_pow=0):
-    return Model(code, L, noise, float(eta), float(alpha), det_pow, scan)
+def _model(code, L, noise=DEPOLARIZING, eta=0.0, scan=0, alpha=0.0, det_pow=0, pxyz=None):
+    if pxyz is not None:
+        noise = XYZ
+    return Model(code, L, noise, float(eta), float(alpha), det_pow, scan, (C.c_double * 3)(*(pxyz if pxyz is not None else (0, 0, 0))))
 
 
 def _size(code, m):
@@ -447,11 +449,33 @@ def pteq_batch(code, init, p, Nc, steps, iters=10, tops_burn=2, seed=0, first_sy
 
 
 # ---- unique-chain estimators (decoders.py:138-233) ---------------------------------------------------------------
-def ptdc_droplet(code, init, p_sampling, Nc, steps, iters=10, rng=None, tab=None, per_rung=False, with_m=False, conv_mult=0.0):
+def _sampling_model(code, L, p_sampling):
+    """scalar p_sampling: Chain / Ladder (src/mcmc.py); a (p_x, p_y, p_z) array: Chain_xyz (mcmc.py:106-114), single chains only"""
+    if np.ndim(p_sampling) == 0:
+        return _model(code, L), float(p_sampling)
+    ps = [float(v) for v in p_sampling]
+    return _model(code, L, pxyz=ps), float(sum(ps))
+
+
+class _XyzSink(C.Structure):
+    _fields_ = [("out", C.POINTER(C.c_uint32)), ("n", C.c_uint64)]
+
+
+def unpack_xyz(vals):
+    """n_x | n_y << 10 | n_z << 20 words -> int64[k, 3]; the unused 0xFFFFFFFF tail is dropped."""
+    v = np.asarray(vals, dtype=np.uint32)
+    v = v[v != 0xFFFFFFFF]
+    return np.stack([v & 1023, (v >> 10) & 1023, (v >> 20) & 1023], axis=-1).astype(np.int64)
+
+
+def ptdc_droplet(code, init, p_sampling, Nc, steps, iters=10, rng=None, tab=None, per_rung=False, with_m=False, conv_mult=0.0,
+                 with_xyz=False):
     """PTDC_droplet (conv_mult = 0): returns (N(n) uint32[nq+1] of the chains that were new to `tab`, tab).  Nc=1, iters=5 is
-    STDC_droplet / STRC_droplet; per_rung=True is PTRC_droplet (N(n) per rung, uint32[Nc, nq+1]); with_m also returns m(n)."""
+    STDC_droplet / STRC_droplet; per_rung=True is PTRC_droplet (N(n) per rung, uint32[Nc, nq+1]); with_m also returns m(n).
+    with_xyz: returns (N(n), xyz int64[k, 3], tab) -- (n_x, n_y, n_z) of the k chains new to tab, in the order found
+    (STDC_droplet_general_noise's dict values, decoders.py:325-342)."""
     init = _m(init); nq = init.size
-    mod = _model(code, init.shape[-1])
+    mod, p_sampling = _sampling_model(code, init.shape[-1], p_sampling)
     nset = Nc if per_rung else 1
     if tab is None:
         cap = 16
@@ -461,31 +485,40 @@ def ptdc_droplet(code, init, p_sampling, Nc, steps, iters=10, rng=None, tab=None
     hist = np.zeros((nset, nq + 1), dtype=np.uint32)
     mh = np.zeros((nset, nq + 1), dtype=np.uint32) if with_m else None
     u32p = C.POINTER(C.c_uint32)
+    xv = np.full(steps * Nc, 0xFFFFFFFF, dtype=np.uint32) if with_xyz else None
+    sink = _XyzSink(xv.ctypes.data_as(u32p), 0) if with_xyz else None
     lib().orc_ptdc_droplet(C.byref(mod), _u8(init), p_sampling, Nc, steps, iters, C.byref(rng.c),
                            tab.ctypes.data_as(C.POINTER(C.c_uint64)), tab.size // nset, hist.ctypes.data_as(u32p), int(per_rung),
-                           mh.ctypes.data_as(u32p) if with_m else None, float(conv_mult), None)
+                           mh.ctypes.data_as(u32p) if with_m else None, float(conv_mult), None, C.byref(sink) if with_xyz else None)
     if not per_rung:
         hist = hist[0]; mh = mh[0] if with_m else None
+    if with_xyz:
+        return hist, unpack_xyz(xv[:sink.n]), tab
     return (hist, mh, tab) if with_m else (hist, tab)
 
 
 def ptdc_batch(code, init, p_sampling, Nc, steps, droplets=1, iters=10, seed=0, first_syndrome=0, n_threads=0, per_rung=False,
-               with_m=False, conv_mult=0.0):
+               with_m=False, conv_mult=0.0, with_xyz=False):
     """init uint8[N, ncls, ...] class representatives (or [N, ncls, droplets, ...]) -> N(n) uint32[N, ncls, nq+1]
-    (per_rung: [N, ncls, droplets, Nc, nq+1]); with_m: (N(n), m(n))."""
+    (per_rung: [N, ncls, droplets, Nc, nq+1]); with_m: (N(n), m(n)); with_xyz appends uint32[N, ncls, steps*Nc*droplets],
+    the packed (n_x, n_y, n_z) of every distinct chain of the class set (tail 0xFFFFFFFF)."""
     init = _m(init); N, ncls = init.shape[0], init.shape[1]
     nd = 3 if code in (TORIC, PLANAR) else 2
     per_droplet = init.ndim == nd + 3
     nq = int(np.prod(init.shape[-nd:]))
-    mod = _model(code, init.shape[-1])
+    mod, p_sampling = _sampling_model(code, init.shape[-1], p_sampling)
     shape = (N, ncls, droplets, Nc, nq + 1) if per_rung else (N, ncls, nq + 1)
     hist = np.zeros(shape, dtype=np.uint32)
     mh = np.zeros(shape, dtype=np.uint32) if with_m else None
     u32p = C.POINTER(C.c_uint32)
+    xv = np.zeros((N, ncls, steps * Nc * droplets), dtype=np.uint32) if with_xyz else None
     lib().orc_ptdc_batch(C.byref(mod), _u8(init), N, ncls, droplets, int(per_droplet), first_syndrome, p_sampling, Nc, steps, iters,
                          seed, n_threads, hist.ctypes.data_as(u32p), int(per_rung), mh.ctypes.data_as(u32p) if with_m else None,
-                         float(conv_mult))
-    return (hist, mh) if with_m else hist
+                         float(conv_mult), xv.ctypes.data_as(u32p) if with_xyz else None)
+    out = (hist, mh) if with_m else (hist,)
+    if with_xyz:
+        out = out + (xv,)
+    return out if len(out) > 1 else out[0]
 
 
 def ptdc_distribution(hist, p_error):

@@ -467,6 +467,21 @@ void orc_chain_update(const orc_model *m, uint8_t *state, double p, double p_log
         }
         return;
     }
+    if (m->noise == ORC_NOISE_XYZ) {
+        /* Chain_xyz.update_chain_fast -> _update_chain_fast_xyz, mcmc.py:112-114,162-173 (no logical branch) */
+        const double tot = (m->pxyz[0] + m->pxyz[1]) + m->pxyz[2];                      /* p_xyz.sum() */
+        const double f[3] = {m->pxyz[0] / (1.0 - tot), m->pxyz[1] / (1.0 - tot), m->pxyz[2] / (1.0 - tot)};   /* :110 */
+        for (uint64_t j = 0; j < iters; ++j) {
+            uint64_t k = k0 + j;
+            model_random_stabilizer(m, state, scratch, rng, slot, k, 0);
+            int c0[4] = {0, 0, 0, 0}, c1[4] = {0, 0, 0, 0};
+            for (size_t q = 0; q < nq; ++q) { c0[state[q]]++; c1[scratch[q]]++; }      /* _count_errors_xyz, planar_model.py:225-229 */
+            /* (factors ** qubit_errors_change).prod(), :170 */
+            const double w = (pow(f[0], (double)(c1[1] - c0[1])) * pow(f[1], (double)(c1[2] - c0[2]))) * pow(f[2], (double)(c1[3] - c0[3]));
+            if (nontop_accept(m, rng, slot, k) < w) memcpy(state, scratch, nq);
+        }
+        return;
+    }
     const double factor = (p / 3.0) / (1.0 - p);                  /* mcmc.py:16 */
     if (p_logical != 0) {                                          /* mcmc.py:20 */
         for (uint64_t j = 0; j < iters; ++j) {
@@ -496,7 +511,7 @@ void orc_chain_update(const orc_model *m, uint8_t *state, double p, double p_log
 void orc_toric_chain_update(int L, uint8_t *state, double p, double p_logical, uint64_t iters,
                             orc_rng *rng, uint32_t slot, uint64_t k0, uint8_t *scratch)
 {
-    orc_model m = {ORC_TORIC, L, ORC_NOISE_DEPOLARIZING, 0.0, 0.0, 0, 0};
+    orc_model m = {ORC_TORIC, L, ORC_NOISE_DEPOLARIZING, 0.0, 0.0, 0, 0, {0.0, 0.0, 0.0}};
     orc_chain_update(&m, state, p, p_logical, iters, rng, slot, k0, scratch);
 }
 
@@ -547,7 +562,7 @@ orc_ladder *orc_ladder_new(const orc_model *m, const uint8_t *init, double p_bot
 
 orc_ladder *orc_toric_ladder_new(int L, const uint8_t *init, double p_bottom, int Nc, double p_logical)
 {
-    orc_model m = {ORC_TORIC, L, ORC_NOISE_DEPOLARIZING, 0.0, 0.0, 0, 0};
+    orc_model m = {ORC_TORIC, L, ORC_NOISE_DEPOLARIZING, 0.0, 0.0, 0, 0, {0.0, 0.0, 0.0}};
     return orc_ladder_new(&m, init, p_bottom, Nc, p_logical);
 }
 
@@ -695,7 +710,7 @@ void orc_toric_pteq(int L, const uint8_t *init, double p, int Nc, int SEQ, int T
                     double eps, uint64_t steps, uint64_t iters, int conv_mode, orc_rng *rng,
                     orc_pteq_result *res, uint8_t *final_states)
 {
-    orc_model m = {ORC_TORIC, L, ORC_NOISE_DEPOLARIZING, 0.0, 0.0, 0, 0};
+    orc_model m = {ORC_TORIC, L, ORC_NOISE_DEPOLARIZING, 0.0, 0.0, 0, 0, {0.0, 0.0, 0.0}};
     orc_pteq(&m, init, p, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, conv_mode, rng, res, final_states);
 }
 
@@ -704,7 +719,7 @@ void orc_toric_pteq_batch(int L, const uint8_t *init, uint64_t N, uint32_t first
                           int n_threads, uint32_t *counts_out, uint64_t *samples_out,
                           uint64_t *tops0_out, uint8_t *final_states)
 {
-    orc_model m = {ORC_TORIC, L, ORC_NOISE_DEPOLARIZING, 0.0, 0.0, 0, 0};
+    orc_model m = {ORC_TORIC, L, ORC_NOISE_DEPOLARIZING, 0.0, 0.0, 0, 0, {0.0, 0.0, 0.0}};
     orc_pteq_batch(&m, init, N, first_syndrome, p, Nc, 2, 10, tops_burn, 0.1, steps, iters, 0, seed,
                    n_threads, counts_out, samples_out, tops0_out, NULL, NULL, final_states);
 }
@@ -715,7 +730,7 @@ void orc_toric_pteq_batch_conv(int L, const uint8_t *init, uint64_t N, uint32_t 
                                uint32_t *counts_out, uint64_t *samples_out, uint64_t *tops0_out,
                                uint64_t *steps_done_out, uint8_t *converged_out, uint8_t *final_states)
 {
-    orc_model m = {ORC_TORIC, L, ORC_NOISE_DEPOLARIZING, 0.0, 0.0, 0, 0};
+    orc_model m = {ORC_TORIC, L, ORC_NOISE_DEPOLARIZING, 0.0, 0.0, 0, 0, {0.0, 0.0, 0.0}};
     orc_pteq_batch(&m, init, N, first_syndrome, p, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, conv_mode, seed,
                    n_threads, counts_out, samples_out, tops0_out, steps_done_out, converged_out, final_states);
 }
@@ -772,7 +787,7 @@ int orc_uset_insert(uint64_t *tab, uint64_t cap, uint64_t key)
 
 void orc_ptdc_droplet(const orc_model *m, const uint8_t *init, double p_sampling, int Nc, uint64_t steps, uint64_t iters,
                       orc_rng *rng, uint64_t *tab, uint64_t cap, uint32_t *hist, int per_rung, uint32_t *mhist,
-                      double conv_mult, uint64_t *steps_done)
+                      double conv_mult, uint64_t *steps_done, orc_xyz_sink *xyz)
 {
     orc_ladder *ld = orc_ladder_new(m, init, p_sampling, Nc, 0.0);      /* decoders.py:182,196: no p_logical */
     const size_t nq = (size_t)ld->nq;
@@ -788,7 +803,14 @@ void orc_ptdc_droplet(const orc_model *m, const uint8_t *init, double p_sampling
             const uint8_t *st = ld->states + (size_t)c * nq;
             const size_t set = per_rung ? (size_t)c : 0;
             const uint64_t n = orc_count_errors(nq, st), key = orc_state_key(st, nq);
-            if (orc_uset_insert(tab + set * cap, cap, key)) hist[set * (nq + 1) + n]++;
+            if (orc_uset_insert(tab + set * cap, cap, key)) {
+                hist[set * (nq + 1) + n]++;
+                if (xyz) {
+                    uint32_t c[4] = {0, 0, 0, 0};
+                    for (size_t q = 0; q < nq; ++q) c[st[q]]++;
+                    xyz->out[xyz->n++] = c[1] | c[2] << 10 | c[3] << 20;
+                }
+            }
             if (mhist) mhist[set * (nq + 1) + n]++;
             if (own && orc_uset_insert(own, cap, key) && n <= shortest) { shortest = n; stop = (double)step * conv_mult; }   /* :153-156 */
         }
@@ -801,7 +823,7 @@ void orc_ptdc_droplet(const orc_model *m, const uint8_t *init, double p_sampling
 
 void orc_ptdc_batch(const orc_model *m, const uint8_t *init, uint64_t N, int ncls, int D, int init_per_droplet,
                     uint32_t first_syndrome, double p_sampling, int Nc, uint64_t steps, uint64_t iters, uint64_t seed,
-                    int n_threads, uint32_t *hist_out, int per_rung, uint32_t *mhist_out, double conv_mult)
+                    int n_threads, uint32_t *hist_out, int per_rung, uint32_t *mhist_out, double conv_mult, uint32_t *xyz_out)
 {
     const size_t nq = (size_t)orc_nq(m->code, m->L);
     uint64_t cap = 16;
@@ -814,6 +836,9 @@ void orc_ptdc_batch(const orc_model *m, const uint8_t *init, uint64_t N, int ncl
 #pragma omp parallel for schedule(dynamic, 1)
     for (int64_t sc = 0; sc < (int64_t)(N * (uint64_t)ncls); ++sc) {
         uint64_t *tab = (uint64_t *)calloc(cap * (per_rung ? (size_t)Nc : 1), sizeof(uint64_t));
+        const uint64_t maxu = steps * (uint64_t)Nc * (uint64_t)D;
+        orc_xyz_sink sink = {xyz_out ? xyz_out + (size_t)sc * maxu : NULL, 0};
+        if (xyz_out) memset(sink.out, 0xFF, maxu * sizeof(uint32_t));
         for (int d = 0; d < D; ++d) {
             const size_t out = per_rung ? ((size_t)sc * D + d) * Nc * (nq + 1) : (size_t)sc * (nq + 1);
             if (per_rung || d == 0) {
@@ -824,7 +849,8 @@ void orc_ptdc_batch(const orc_model *m, const uint8_t *init, uint64_t N, int ncl
             orc_rng rng;
             orc_rng_init_philox(&rng, seed, first_syndrome + (uint32_t)(sc * D + d));
             orc_ptdc_droplet(m, init + (size_t)(init_per_droplet ? sc * D + d : sc) * nq, p_sampling, Nc, steps, iters, &rng, tab, cap,
-                             hist_out + out, per_rung, mhist_out ? mhist_out + out : NULL, conv_mult, NULL);
+                             hist_out + out, per_rung, mhist_out ? mhist_out + out : NULL, conv_mult, NULL,
+                             xyz_out && !per_rung ? &sink : NULL);
         }
         free(tab);
     }

@@ -53,7 +53,7 @@ void orc_rng_init_stream(orc_rng *r, const double *stream, uint64_t len);
 void orc_rng_init_philox(orc_rng *r, uint64_t seed, uint32_t syndrome);
 
 enum { ORC_TORIC = 0, ORC_XZZX = 1, ORC_ROTATED = 2, ORC_PLANAR = 3 };
-enum { ORC_NOISE_DEPOLARIZING = 0, ORC_NOISE_BIASED = 1, ORC_NOISE_ALPHA = 2 };
+enum { ORC_NOISE_DEPOLARIZING = 0, ORC_NOISE_BIASED = 1, ORC_NOISE_ALPHA = 2, ORC_NOISE_XYZ = 3 };
 
 /* which code model / acceptance rule a chain uses (duck typing in the reference) */
 typedef struct orc_model {
@@ -67,6 +67,8 @@ typedef struct orc_model {
                       exp(e*ln(base)) the GPU uses (same decision unless u falls within ~1e-16 of the threshold) */
     int scan;      /* 0: the reference's random scan; 1: systematic sweep over the generators (NOT the reference's
                       chain: the deterministic-scan variant the GPU offers as scan=1, same stationary law) */
+    double pxyz[3]; /* ORC_NOISE_XYZ: Chain_xyz's (p_x, p_y, p_z), src/mcmc.py:106-114 -- a single chain without logical
+                      moves whose proposals are accepted with prod_i (p_i / (1 - sum p))^(change of n_i), :162-173 */
 } orc_model;
 
 int orc_nq(int code, int L);
@@ -164,9 +166,13 @@ int orc_uset_insert(uint64_t *tab, uint64_t cap, uint64_t key);
  * hist[n] += 1 for every configuration not seen before in `tab` (its length n = count_errors).
  * per_rung != 0 is PTRC_droplet (decoders.py:584-631): one set per rung -- tab = [Nc][cap], hist = [Nc][nq+1].
  * mhist (nullable, same shape as hist): m(n), EVERY observation of a chain of length n (the len_counts of :606-618 / STRC_droplet :768-776). */
+/* STDC_droplet_general_noise (decoders.py:325-342) / STDC_droplet_alpha (:510-534) keep, for every distinct chain, its
+ * (n_x, n_y, n_z) (count_errors_xyz, planar_model.py:225-229; chain_lengths, xzzx_model.py:39-43): a sink (nullable) that
+ * receives n_x | n_y << 10 | n_z << 20 of every chain that is new to the set `tab`, in the order found. */
+typedef struct { uint32_t *out; uint64_t n; } orc_xyz_sink;
 void orc_ptdc_droplet(const orc_model *m, const uint8_t *init, double p_sampling, int Nc, uint64_t steps, uint64_t iters,
                       orc_rng *rng, uint64_t *tab, uint64_t cap, uint32_t *hist /*[nq+1]*/, int per_rung, uint32_t *mhist,
-                      double conv_mult, uint64_t *steps_done);
+                      double conv_mult, uint64_t *steps_done, orc_xyz_sink *xyz);
 /* conv_mult != 0: the early stop of PTDC_droplet / STDC_droplet / STRC_droplet (decoders.py:153-162, :256-262, :783-826):
  * whenever a chain that is new to the droplet's own dictionary has length <= the shortest seen so far, stop = step * conv_mult;
  * sampling ends after the first step with step >= stop and step * 100 >= steps.  (PTRC_droplet's stop is commented out in
@@ -176,7 +182,8 @@ void orc_ptdc_droplet(const orc_model *m, const uint8_t *init, double p_sampling
  * init uint8[N][ncls][nq]; hist_out uint32[N][ncls][nq+1] = number of unique chains of each length, N(n). */
 void orc_ptdc_batch(const orc_model *m, const uint8_t *init, uint64_t N, int ncls, int D, int init_per_droplet,
                     uint32_t first_syndrome, double p_sampling, int Nc, uint64_t steps, uint64_t iters, uint64_t seed,
-                    int n_threads, uint32_t *hist_out, int per_rung, uint32_t *mhist_out, double conv_mult);
+                    int n_threads, uint32_t *hist_out, int per_rung, uint32_t *mhist_out, double conv_mult,
+                    uint32_t *xyz_out /* nullable: [N*ncls][steps*Nc*D], unused tail 0xFFFFFFFF; not with per_rung */);
 /* init_per_droplet: init is [N][ncls][D][nq] (STDC's rain).  per_rung = 0: one set per (syndrome, class), outputs
  * [N][ncls][nq+1]; per_rung != 0 (PTRC): one set per (ladder, rung), outputs [N][ncls][D][Nc][nq+1].  mhist_out nullable. */   /* deterministic exp for y <= 0 (IEEE +,*,fma only): bit-identical on CPU and GPU */
 

@@ -21,6 +21,8 @@ Fixtures
   f2_alpha.npz                Chain_alpha / Ladder_alpha / PTEQ_alpha trajectories (src/mcmc_alpha.py)
   f_ptdc.npz                  PTDC_droplet unique-chain length histograms N(n) and PTDC percent vectors (decoders.py:138-233)
   f_convmult.npz              the conv_mult early stop of PTDC_droplet / STDC_droplet / STDC / STRC (decoders.py:153-162,:256-262,:783-826)
+  f_xyz.npz                   STDC_droplet_general_noise / STDC_general_noise(_shortest) on the planar code (decoders.py:325-507), with
+                              Chain and Chain_xyz (mcmc.py:106-114,162-173) sampling
   f_planar.npz                Planar_code stencil KATs and Chain (incl. update_chain_fast) / Ladder / PTEQ trajectories
 """
 import argparse
@@ -703,6 +705,56 @@ def gen_convmult(tm, pm, mc, dec):
     print("f_convmult.npz", cases, {c: int(out[c + "_par"][-2]) for c in cases})
 
 
+def gen_xyz(tm, pm, mc, dec):
+    """STDC_droplet_general_noise (decoders.py:325-342): the (n_x, n_y, n_z) of every distinct chain a single planar chain
+    visits, sampled by Chain (scalar p_sampling) or Chain_xyz (array p_sampling, mcmc.py:106-114,162-173); and the estimates
+    STDC_general_noise / STDC_general_noise_shortest form from them (droplets = 1, list form of init_code)."""
+    rng = np.random.default_rng(1010)
+    out = {}
+    cases = []
+    for i, (L, p, steps, perr) in enumerate([(3, 0.15, 300, 0.15), (5, 0.1, 250, 0.1), (3, np.array([0.02, 0.05, 0.11]), 300, 0.15),
+                                            (5, np.array([0.08, 0.01, 0.03]), 250, 0.1), (4, np.array([0.3, 0.2, 0.1]), 200, 0.2)]):
+        m = rand_planar(rng, L, perr)
+        seed = 10000 + i
+        code = pm.Planar_code(L); code.qubit_matrix = m.copy()
+        s = Stream(seed); install(s, tm, pm, mc)
+        ch = mc.Chain_xyz(p, code) if isinstance(p, np.ndarray) else mc.Chain(p, code)
+        samples = dec.STDC_droplet_general_noise(ch, steps, False)
+        restore(tm, pm, mc)
+        tag = f"gdrop{i}"
+        out[f"{tag}_init"] = m
+        out[f"{tag}_xyz"] = np.array(list(samples.values()), dtype=np.int64).reshape(-1, 3)
+        out[f"{tag}_final"] = ch.code.qubit_matrix.astype(np.uint8)
+        out[f"{tag}_p"] = np.atleast_1d(np.asarray(p, dtype=np.float64))
+        out[f"{tag}_par"] = np.array([L, steps, seed, s.n], dtype=np.float64)
+        cases.append(tag)
+    for i, (L, p_xyz, p_sampling, steps, perr) in enumerate([(3, np.array([0.03, 0.02, 0.08]), None, 400, 0.15),
+                                                             (4, np.array([0.01, 0.01, 0.1]), 0.2, 300, 0.1),
+                                                             (3, np.array([0.05, 0.03, 0.04]), np.array([0.1, 0.06, 0.08]), 400, 0.15)]):
+        m = rand_planar(rng, L, perr)
+        seed = 10100 + i
+        inits = []
+        for op in range(4):
+            c = pm.Planar_code(L); c.qubit_matrix, _ = pm._apply_logical(m.copy(), op, 0, 0)
+            inits.append(c)
+        inits.sort(key=lambda c: c.define_equivalence_class())
+        tag = f"gn{i}"
+        for name, fn, kw in [("all", dec.STDC_general_noise, {}), ("short", dec.STDC_general_noise, dict(shortest_only=True)),
+                             ("both", dec.STDC_general_noise_shortest, {})]:
+            s = Stream(seed); install(s, tm, pm, mc)
+            dist = fn(inits, p_xyz, p_sampling=p_sampling, droplets=1, steps=steps, **kw)
+            restore(tm, pm, mc)
+            out[f"{tag}_{name}"] = np.asarray(dist, dtype=np.float64)
+        out[f"{tag}_classes"] = np.array([c.qubit_matrix for c in inits], dtype=np.uint8)
+        out[f"{tag}_pxyz"] = p_xyz
+        out[f"{tag}_ps"] = np.atleast_1d(np.asarray(p_xyz.sum() if p_sampling is None else p_sampling, dtype=np.float64))
+        out[f"{tag}_par"] = np.array([L, steps, seed, s.n], dtype=np.float64)
+        cases.append(tag)
+    out["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(HERE, "f_xyz.npz"), **out)
+    print("f_xyz.npz", cases, {c: int(out[c + "_par"][-1]) for c in cases})
+
+
 def _f3_worker(args):
     (L, p, Nc, iters, steps, burn, m, seed) = args
     tm, mc, dec = import_reference()
@@ -765,15 +817,16 @@ def main():
         print("reference not present; nothing to do")
         return
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="f1,f2,f3,f4,f1s,f2s,f2a,fp,fd,fc")
+    ap.add_argument("--only", default="f1,f2,f3,f4,f1s,f2s,f2a,fp,fd,fc,fg")
     only = set(ap.parse_args().only.split(","))
     tm, mc, dec = import_reference()
     if "f1" in only: gen_f1(tm)
     if "f2" in only: gen_f2(tm, mc, dec)
     if "f4" in only: gen_f4(tm, mc)
-    if "fp" in only or "fd" in only or "fc" in only:
+    if "fp" in only or "fd" in only or "fc" in only or "fg" in only:
         import src.planar_model as pm
         if "fc" in only: gen_convmult(tm, pm, mc, dec)
+        if "fg" in only: gen_xyz(tm, pm, mc, dec)
         if "fp" in only: gen_planar(pm, mc, dec)
         if "fd" in only: gen_ptdc(tm, pm, mc, dec)
     if "f1s" in only or "f2s" in only or "f2a" in only:

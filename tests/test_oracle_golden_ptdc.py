@@ -169,3 +169,45 @@ def test_convmult_stdc_strc_distribution(case):
     dist = orc.ptdc_distribution(hist, float(p_error)) if case.startswith("stdc") else \
         strc_distribution(hist, mh, float(p_error), float(p_sampling))
     assert np.allclose(dist, g[f"{case}_dist"], rtol=1e-12, atol=0)
+
+
+# ---- (n_x, n_y, n_z) of the distinct chains: STDC_general_noise family and Chain_xyz (decoders.py:325-507, mcmc.py:106-114), f_xyz.npz ----
+
+def _loadx():
+    return np.load(os.path.join(GOLDEN, "f_xyz.npz"))
+
+
+def _casesx(prefix):
+    return [str(c) for c in _loadx()["cases"] if str(c).startswith(prefix)]
+
+
+@pytest.mark.parametrize("case", _casesx("gdrop"))
+def test_general_noise_droplet_xyz(case):
+    """STDC_droplet_general_noise's dict values, in the order the chains were found; a 3-vector p = Chain_xyz sampling."""
+    g = _loadx()
+    L, steps, seed, ndraw = g[f"{case}_par"]
+    p = g[f"{case}_p"]
+    rng = orc.Rng.stream(_stream(int(seed), int(ndraw)))
+    hist, xyz, _ = orc.ptdc_droplet(orc.PLANAR, g[f"{case}_init"], p if p.size == 3 else float(p[0]), 1, int(steps), iters=5, rng=rng,
+                                    with_xyz=True)
+    assert rng.consumed == int(ndraw)
+    assert np.array_equal(xyz, g[f"{case}_xyz"])
+    assert np.array_equal(np.bincount(xyz.sum(axis=1), minlength=hist.size), hist)
+
+
+@pytest.mark.parametrize("case", _casesx("gn"))
+def test_general_noise_distributions(case):
+    from qecmc.decoders import general_noise_distribution
+    g = _loadx()
+    L, steps, seed, ndraw = g[f"{case}_par"]
+    ps = g[f"{case}_ps"]
+    rng = orc.Rng.stream(_stream(int(seed), int(ndraw)))
+    xyz = [orc.ptdc_droplet(orc.PLANAR, r, ps if ps.size == 3 else float(ps[0]), 1, int(steps), iters=5, rng=rng, with_xyz=True)[1]
+           for r in g[f"{case}_classes"]]
+    assert rng.consumed == int(ndraw)
+    p_xyz = g[f"{case}_pxyz"]
+    assert np.allclose(general_noise_distribution(xyz, p_xyz), g[f"{case}_all"], rtol=1e-12, atol=0)
+    assert np.allclose(general_noise_distribution(xyz, p_xyz, shortest_only=True), g[f"{case}_short"], rtol=1e-12, atol=0)
+    both = g[f"{case}_both"]
+    assert np.allclose(general_noise_distribution(xyz, p_xyz), both[0], rtol=1e-12, atol=0)
+    assert np.allclose(general_noise_distribution(xyz, p_xyz, shortest_only=True), both[1], rtol=1e-12, atol=0)
