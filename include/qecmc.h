@@ -197,6 +197,20 @@ int qecmc_ptdc_batch_conv(const qecmc_params *params, const uint8_t *init, uint6
                           uint32_t flags, double conv_mult, uint32_t *hist_out, uint32_t *m_out,
                           uint32_t *steps_done_out, qecmc_stats *stats_out);
 
+/* The same sampling for the general-noise estimators STDC_general_noise / STDC_general_noise_shortest (decoders.py:345-507)
+ * and STDC_Nall_n_alpha's weighting (:537-581): xyz_out (nullable) uint32[N][ncls][params->steps * Nc * droplets] receives,
+ * for every (syndrome, class) set, n_x | n_y << 10 | n_z << 20 of each DISTINCT chain (count_errors_xyz,
+ * planar_model.py:225-229 -- the values of STDC_droplet_general_noise's dict, decoders.py:339-340), in no particular
+ * order, the unused tail 0xFFFFFFFF; xyz_count_out (nullable) uint32[N][ncls] their number.  Not with
+ * QECMC_PTDC_SET_PER_RUNG.
+ * p_xyz_sampling (nullable) double[3]: sample with Chain_xyz (src/mcmc.py:106-114,162-173) instead of Chain -- a single
+ * chain (params->Nc must be 1; params->p is ignored) whose proposals are accepted with probability
+ * prod_i (p_i / (1 - sum p))^(change of n_i); planar, xzzx and rotated codes (the reference's runs the planar stencil). */
+int qecmc_ptdc_batch_xyz(const qecmc_params *params, const uint8_t *init, uint64_t N, int32_t droplets,
+                         uint32_t flags, double conv_mult, const double *p_xyz_sampling, uint32_t *hist_out,
+                         uint32_t *m_out, uint32_t *steps_done_out, uint32_t *xyz_out, uint32_t *xyz_count_out,
+                         qecmc_stats *stats_out);
+
 /* Plan + device-pointer form: build once (validates, uploads threshold tables),
  * then launch asynchronously on a caller stream with buffers already in HBM.
  * d_workspace: qecmc_plan_workspace_bytes() bytes (0 for conv_mode NONE, then NULL is fine). */

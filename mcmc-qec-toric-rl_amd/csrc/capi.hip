@@ -681,12 +681,38 @@ int qecmc_ptdc_batch(const qecmc_params *params, const uint8_t *init, uint64_t N
 int qecmc_ptdc_batch_conv(const qecmc_params *params, const uint8_t *init, uint64_t N, int32_t droplets, uint32_t flags,
                           double conv_mult, uint32_t *hist_out, uint32_t *m_out, uint32_t *steps_done_out, qecmc_stats *stats_out)
 {
+    return qecmc_ptdc_batch_xyz(params, init, N, droplets, flags, conv_mult, nullptr, hist_out, m_out, steps_done_out, nullptr, nullptr, stats_out);
+}
+
+int qecmc_ptdc_batch_xyz(const qecmc_params *params, const uint8_t *init, uint64_t N, int32_t droplets, uint32_t flags,
+                         double conv_mult, const double *p_xyz_sampling, uint32_t *hist_out, uint32_t *m_out,
+                         uint32_t *steps_done_out, uint32_t *xyz_out, uint32_t *xyz_count_out, qecmc_stats *stats_out)
+{
     const auto t0 = std::chrono::steady_clock::now();
     if (!params) return fail(QECMC_ERR_INVALID, "params is NULL");
     if (!(conv_mult >= 0.0) || !std::isfinite(conv_mult)) return fail(QECMC_ERR_INVALID, "conv_mult=%g must be finite and >= 0", conv_mult);
     qecmc_params p = *params;
     p.p_logical = 0.0;                                   // Ladder(p_sampling, code, Nc): decoders.py:182,196
     p.conv_mode = QECMC_CONV_NONE;
+    std::vector<uint32_t> xyz_thr;
+    if (p_xyz_sampling) {
+        // Chain_xyz (mcmc.py:106-114): factors = p_xyz / (1 - p_xyz.sum()), accept iff u < (factors ** change).prod() (:170)
+        const double *q = p_xyz_sampling;
+        const double tot = (q[0] + q[1]) + q[2];
+        if (!(q[0] > 0) || !(q[1] > 0) || !(q[2] > 0) || !(tot < 1.0)) return fail(QECMC_ERR_INVALID, "p_xyz_sampling=(%g,%g,%g) must be positive with a sum below 1", q[0], q[1], q[2]);
+        if (p.Nc != 1) return fail(QECMC_ERR_INVALID, "Chain_xyz is a single chain (mcmc.py:106): Nc=%d must be 1", p.Nc);
+        if (p.code == QECMC_TORIC) return fail(QECMC_ERR_UNSUPPORTED, "Chain_xyz is built for the planar, xzzx and rotated codes (the reference's runs the planar stencil, mcmc.py:164)");
+        const double f[3] = {q[0] / (1.0 - tot), q[1] / (1.0 - tot), q[2] / (1.0 - tot)};
+        xyz_thr.resize(729);
+        for (int dx = -4; dx <= 4; ++dx)
+            for (int dy = -4; dy <= 4; ++dy)
+                for (int dz = -4; dz <= 4; ++dz) {
+                    const double w = (std::pow(f[0], (double)dx) * std::pow(f[1], (double)dy)) * std::pow(f[2], (double)dz);
+                    const double c = std::ceil(w * 4294967296.0);                 // u < w  <=>  x < ceil(w 2^32)  <=>  x <= ceil - 1
+                    xyz_thr[((dx + 4) * 9 + (dy + 4)) * 9 + (dz + 4)] = c >= 4294967296.0 ? 0xFFFFFFFFu : c < 1.0 ? 0u : (uint32_t)(c - 1.0);
+                }
+        p.p = tot <= 0.75 ? tot : 0.75;                                           // unused by the rule; keeps the plan's tables valid
+    }
     if (p.noise != QECMC_NOISE_DEPOLARIZING) return fail(QECMC_ERR_UNSUPPORTED, "PTDC is defined for the depolarizing ladder (decoders.py:168)");
     if (p.scan != QECMC_SCAN_RANDOM) return fail(QECMC_ERR_UNSUPPORTED, "PTDC runs the reference's random-scan ladder");
     if (droplets < 1) return fail(QECMC_ERR_INVALID, "droplets=%d must be >= 1", droplets);
@@ -707,7 +733,10 @@ int qecmc_ptdc_batch_conv(const qecmc_params *params, const uint8_t *init, uint6
     const bool own = conv_mult != 0.0 && D > 1;                       // the stop looks at each droplet's own dictionary
     uint64_t own_cap = 16;
     while (own_cap < 2 * p.steps * Nc) own_cap <<= 1;
-    const uint64_t need = sets * cap * 8 + M * nq + sets * (nq + 1) * 8 + (own ? M * own_cap * 8 : 0) + M * 4;
+    const uint64_t maxu = p.steps * Nc * D;                           // distinct chains a (syndrome, class) set can hold
+    if (xyz_out && per_rung) return fail(QECMC_ERR_INVALID, "xyz_out is defined for the per-class sets, not with QECMC_PTDC_SET_PER_RUNG");
+    if (xyz_out && nq > 1023) return fail(QECMC_ERR_UNSUPPORTED, "xyz_out packs counts in 10 bits: nq=%zu", nq);
+    const uint64_t need = sets * cap * 8 + M * nq + sets * (nq + 1) * 8 + (own ? M * own_cap * 8 : 0) + M * 4 + (xyz_out ? sets * (maxu + 1) * 4 : 0);
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     if (need > free_b - free_b / 8)
@@ -718,8 +747,13 @@ int qecmc_ptdc_batch_conv(const qecmc_params *params, const uint8_t *init, uint6
     for (uint64_t sc = 0; sc < N * ncls; ++sc)
         for (size_t d = 0; d < D; ++d)
             std::memcpy(&st[(sc * D + d) * nq], init + (init_per_droplet ? sc * D + d : sc) * nq, nq);
-    DevBuf ds, dtab, dh, dm, down, dsd;
+    DevBuf ds, dtab, dh, dm, down, dsd, dxyz, dxc, dthr;
     HIP_TRY(ds.alloc(st.size()));
+    if (xyz_out) {
+        HIP_TRY(dxyz.alloc(sets * maxu * 4)); HIP_TRY(hipMemset(dxyz.p, 0xFF, sets * maxu * 4));
+        HIP_TRY(dxc.alloc(sets * 4)); HIP_TRY(hipMemset(dxc.p, 0, sets * 4));
+    }
+    if (!xyz_thr.empty()) { HIP_TRY(dthr.alloc(729 * 4)); HIP_TRY(hipMemcpy(dthr.p, xyz_thr.data(), 729 * 4, hipMemcpyHostToDevice)); }
     if (own) { HIP_TRY(down.alloc(M * own_cap * 8)); HIP_TRY(hipMemset(down.p, 0, M * own_cap * 8)); }
     if (steps_done_out) HIP_TRY(dsd.alloc(M * 4));
     HIP_TRY(dtab.alloc(sets * cap * 8)); HIP_TRY(dh.alloc(sets * (nq + 1) * 4));
@@ -737,6 +771,8 @@ int qecmc_ptdc_batch_conv(const qecmc_params *params, const uint8_t *init, uint6
     a.uset_mhist = m_out ? dm.as<uint32_t>() : nullptr; a.uset_D = (uint32_t)D; a.uset_per_rung = per_rung ? 1 : 0;
     a.uset_conv_mult = conv_mult; a.uset_own = own ? reinterpret_cast<unsigned long long *>(down.p) : nullptr; a.uset_own_cap = own_cap;
     a.steps_done = steps_done_out ? dsd.as<uint32_t>() : nullptr;
+    a.uset_xyz = xyz_out ? dxyz.as<uint32_t>() : nullptr; a.uset_xyz_cnt = xyz_out ? dxc.as<uint32_t>() : nullptr; a.uset_xyz_stride = maxu;
+    a.xyz_thr = xyz_thr.empty() ? nullptr : dthr.as<uint32_t>();
     {
         const hipError_t e = launch_ladder_rs_toric(a, 0);
         if (e != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return fail(QECMC_ERR_HIP, "PTDC launch: %s", hipGetErrorString(e)); }
@@ -749,6 +785,8 @@ int qecmc_ptdc_batch_conv(const qecmc_params *params, const uint8_t *init, uint6
     HIP_TRY(hipMemcpy(hist_out, dh.p, sets * (nq + 1) * 4, hipMemcpyDeviceToHost));
     if (m_out) HIP_TRY(hipMemcpy(m_out, dm.p, sets * (nq + 1) * 4, hipMemcpyDeviceToHost));
     if (steps_done_out) HIP_TRY(hipMemcpy(steps_done_out, dsd.p, M * 4, hipMemcpyDeviceToHost));
+    if (xyz_out) HIP_TRY(hipMemcpy(xyz_out, dxyz.p, sets * maxu * 4, hipMemcpyDeviceToHost));
+    if (xyz_out && xyz_count_out) HIP_TRY(hipMemcpy(xyz_count_out, dxc.p, sets * 4, hipMemcpyDeviceToHost));
     if (stats_out) {
         stats_out->proposals = M * Nc * p.iters * p.steps;
         stats_out->swap_tests = M * (Nc - 1) * p.steps;

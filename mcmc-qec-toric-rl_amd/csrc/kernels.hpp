@@ -38,6 +38,13 @@ struct LadderArgs {
     double uset_conv_mult;
     unsigned long long *uset_own;   // [N][uset_own_cap]
     uint64_t uset_own_cap;
+    // (n_x, n_y, n_z) of every distinct chain of a set, n_x | n_y << 10 | n_z << 20, appended in the order the insertions
+    // land (STDC_droplet_general_noise's dict values, decoders.py:339-340); nullable
+    uint32_t *uset_xyz;             // [sets][uset_xyz_stride]
+    uint32_t *uset_xyz_cnt;         // [sets]
+    uint64_t uset_xyz_stride;
+    // Chain_xyz (mcmc.py:106-114,162-173; 1-chain ladders): accept iff x <= xyz_thr[dx+4][dy+4][dz+4]; nullable
+    const uint32_t *xyz_thr;        // [9][9][9]
     int bias_lds;             //                    the kernel copies bias_tbl into LDS (fits: capi.hip decides)
     const double *alpha_lnb;  // [Nc-1]             ln(pz_tilde[i] / pz_tilde[i+1]) (alpha noise, mcmc_alpha.py:123)
     double alpha;             //                    mcmc_alpha.py:11

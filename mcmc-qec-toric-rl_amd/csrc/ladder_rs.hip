@@ -515,9 +515,10 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
         if constexpr (CODE != kCodeToric || BIASED) {
             // ---------- XZZX / rotated codes and the biased acceptance rule ----------------------------
             const bool top = top_logical;
-            if (!SCAN && !top && !BIASED && CODE != kCodeToric) {
+            const bool xyz_rule = USET && a.xyz_thr != nullptr;                     // Chain_xyz: the general path with its own table
+            if (!SCAN && !top && !BIASED && CODE != kCodeToric && !xyz_rule) {
                 if constexpr (kWideGen) random_scan_loop();
-            } else if (!top && !BIASED && CODE != kCodeToric) {
+            } else if (!top && !BIASED && CODE != kCodeToric && !xyz_rule) {
                 // sweep on a plaquette code: generator table lookup, 2 to 4 sites
                 int ni = (int)n;
                 uint32_t gs = SCAN ? (uint32_t)(kbase % a.n_gen) : 0u;
@@ -694,6 +695,8 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                     } else if (top) {
                         acc = acc_all || dE <= 0;                                   // mcmc.py:30
                         if (!acc) acc = philox_block(k, 2, syn, slot_u, a.seed_lo, a.seed_hi).x < a.acc_tbl_top[dE];   // :34
+                    } else if (xyz_rule) {
+                        acc = x.w <= a.xyz_thr[((dx + 4) * 9 + (dy + 4)) * 9 + (dz + 4)];   // mcmc.py:170 (a generator moves <= 4 sites)
                     } else {
                         acc = x.w <= myT[dE < -4 ? -4 : dE];                        // mcmc.py:42 (stabilizers only: |dE| <= 4)
                     }
@@ -1078,6 +1081,12 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                         if (old == key) break;
                         idx = (idx + 1) & (a.uset_cap - 1);
                     }
+                    if (fresh && a.uset_xyz != nullptr) {
+                        int cx = 0, cy = 0, cz = 0;
+                        for (int w = 0; w < W; ++w) count_xyz(sw[w * 64], cx, cy, cz);
+                        const uint32_t pos = atomicAdd(a.uset_xyz_cnt + set, 1u);
+                        if (pos < a.uset_xyz_stride) a.uset_xyz[set * a.uset_xyz_stride + pos] = (uint32_t)cx | ((uint32_t)cy << 10) | ((uint32_t)cz << 20);
+                    }
                     if (cm) {
                         if (a.uset_own != nullptr) {
                             // the stop looks at the droplet's own dictionary (one process per droplet in the reference, :213-219),
@@ -1158,6 +1167,7 @@ hipError_t launch_ladder_rs_toric(const LadderArgs &a, hipStream_t stream)
     if (a.uset_tab != nullptr) {
         // direct-counting runs: depolarizing random scan without logical moves (no general top path), fixed length
         if (a.noise || a.scan || conv || a.thr_logical != 0) return hipErrorInvalidValue;
+        if (a.xyz_thr != nullptr && (a.code == T || a.Nc != 1)) return hipErrorInvalidValue;   // Chain_xyz: single chains, table-driven codes
         const bool gsplit = (int)a.n_gen <= kGenSplit;
 #define QECMC_KU(code) (block <= 512 ? (gsplit ? (const void *)ladder_rs_toric_kernel<512, 8, false, true, code, false, false, false, true>   \
                                               : (const void *)ladder_rs_toric_kernel<512, 8, false, false, code, false, false, false, true>)  \

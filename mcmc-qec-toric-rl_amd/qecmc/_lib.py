@@ -70,6 +70,8 @@ SIGNATURES = {
     "qecmc_ptdc_batch": (C.c_int, [C.POINTER(Params), _u8p, C.c_uint64, C.c_int32, C.c_uint32, _u32p, _u32p, C.POINTER(Stats)]),
     "qecmc_ptdc_batch_conv": (C.c_int, [C.POINTER(Params), _u8p, C.c_uint64, C.c_int32, C.c_uint32, C.c_double, _u32p, _u32p, _u32p,
                                         C.POINTER(Stats)]),
+    "qecmc_ptdc_batch_xyz": (C.c_int, [C.POINTER(Params), _u8p, C.c_uint64, C.c_int32, C.c_uint32, C.c_double, C.POINTER(C.c_double),
+                                       _u32p, _u32p, _u32p, _u32p, _u32p, C.POINTER(Stats)]),
     "qecmc_plan_workspace_bytes": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "qecmc_plan_create": (C.c_int, [C.POINTER(Params), C.POINTER(C.c_void_p)]),
     "qecmc_plan_destroy": (C.c_int, [C.c_void_p]),

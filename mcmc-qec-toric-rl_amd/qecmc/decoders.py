@@ -1,5 +1,7 @@
 """Host-side mirror of the reference's `PTEQ` (decoders.py:25-89) and the new
 batched call `pteq_batch` that the hot path is built around."""
+import ctypes as C
+
 import numpy as np
 
 from . import _lib as L_
@@ -91,7 +93,7 @@ def _pteq(init_code, p, eta, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, conv_c
 
 
 def ptdc_batch(init, p_sampling, Nc=None, steps=2000, droplets=1, iters=10, seed=0, first_syndrome=0, device=0, code=L_.TORIC,
-               return_stats=False, per_rung=False, with_m=False, conv_mult=0.0, return_steps=False):
+               return_stats=False, per_rung=False, with_m=False, conv_mult=0.0, return_steps=False, with_xyz=False):
     """The sampling half of PTDC (decoders.py:168-233) on N syndromes at once.
 
     init: uint8[N, ncls, ...] -- one representative per equivalence class for every syndrome (what `to_class` / the list
@@ -102,7 +104,10 @@ def ptdc_batch(init, p_sampling, Nc=None, steps=2000, droplets=1, iters=10, seed
     STDC_droplet / STRC_droplet (:236-265, :745-830).  per_rung=True keeps one set per (ladder, rung) as PTRC_droplet
     does (:584-631): shape [N, ncls, droplets, Nc, nq+1].  with_m=True also returns m(n), all observations by length.
     conv_mult != 0 is the early stop of PTDC_droplet / STDC_droplet / STRC_droplet (:153-162, :256-262, :783-826), per
-    droplet; return_steps=True appends steps_done uint32[N, ncls, droplets], the steps each droplet recorded."""
+    droplet; return_steps=True appends steps_done uint32[N, ncls, droplets], the steps each droplet recorded.
+    with_xyz=True appends a list[N][ncls] of int64[k, 3] arrays: (n_x, n_y, n_z) of the k distinct chains of each set, sorted
+    (the values of STDC_droplet_general_noise's dict, :325-342).  p_sampling may be an array (p_x, p_y, p_z): the chains
+    are then Chain_xyz (src/mcmc.py:106-114), which needs Nc = 1."""
     nd = 3 if code in (L_.TORIC, L_.PLANAR) else 2
     a = np.ascontiguousarray(init, dtype=np.uint8)
     per_droplet = a.ndim == nd + 3
@@ -113,6 +118,10 @@ def ptdc_batch(init, p_sampling, Nc=None, steps=2000, droplets=1, iters=10, seed
         raise ValueError("one representative per equivalence class is needed")
     nq = int(np.prod(a.shape[-nd:]))
     Nc = Nc or size
+    pxyz = None
+    if np.ndim(p_sampling) != 0:
+        pxyz = (C.c_double * 3)(*[float(v) for v in p_sampling])
+        p_sampling = 0.1                                   # ignored by the Chain_xyz rule
     pr = L_.make_params(code=code, L=size, Nc=Nc, p=float(p_sampling), iters=int(iters), steps=int(steps), seed=seed,
                         first_syndrome=first_syndrome, device=device)
     shape = (N, ncls, int(droplets), Nc, nq + 1) if per_rung else (N, ncls, nq + 1)
@@ -121,11 +130,15 @@ def ptdc_batch(init, p_sampling, Nc=None, steps=2000, droplets=1, iters=10, seed
     stats = L_.Stats()
     flags = (L_.PTDC_INIT_PER_DROPLET if per_droplet else 0) | (L_.PTDC_SET_PER_RUNG if per_rung else 0)
     sd = np.zeros((N, ncls, int(droplets)), dtype=np.uint32) if return_steps else None
-    L_.check(L_.lib().qecmc_ptdc_batch_conv(pr, L_.u8(a), N, int(droplets), flags, float(conv_mult or 0.0), L_.u32(hist),
-                                            L_.u32(mh) if with_m else None, L_.u32(sd) if return_steps else None, stats))
+    xv = np.zeros((N, ncls, int(steps) * Nc * int(droplets)), dtype=np.uint32) if with_xyz else None
+    L_.check(L_.lib().qecmc_ptdc_batch_xyz(pr, L_.u8(a), N, int(droplets), flags, float(conv_mult or 0.0), pxyz, L_.u32(hist),
+                                           L_.u32(mh) if with_m else None, L_.u32(sd) if return_steps else None,
+                                           L_.u32(xv) if with_xyz else None, None, stats))
     out = (hist, mh) if with_m else hist
     if return_steps:
         out = (out if isinstance(out, tuple) else (out,)) + (sd,)
+    if with_xyz:
+        out = (out if isinstance(out, tuple) else (out,)) + ([[unpack_xyz(xv[s, c]) for c in range(ncls)] for s in range(N)],)
     if return_stats:
         return out, dict(proposals=int(stats.proposals), kernel_ms=float(stats.kernel_ms), total_ms=float(stats.total_ms))
     return out
@@ -179,6 +192,13 @@ def STDC(init_code, p_error, p_sampling=None, droplets=10, steps=20000, conv_mul
     return ptdc_distribution(hist[0], p_error)
 
 
+def unpack_xyz(vals):
+    """n_x | n_y << 10 | n_z << 20 words (qecmc_ptdc_batch_xyz) -> sorted int64[k, 3]; the unused 0xFFFFFFFF tail is dropped."""
+    v = np.asarray(vals, dtype=np.uint32)
+    v = np.sort(v[v != 0xFFFFFFFF])
+    return np.stack([v & 1023, (v >> 10) & 1023, (v >> 20) & 1023], axis=-1).astype(np.int64)
+
+
 def general_noise_distribution(xyz, p_xyz, shortest_only=False):
     """STDC_general_noise's estimate (decoders.py:390-432; shortest_only / STDC_general_noise_shortest :494-507) from
     xyz[c] = int[k_c, 3], the (n_x, n_y, n_z) of the distinct chains found in class c: Z_c = sum exp(-sum_i beta_i n_i) over
@@ -195,6 +215,32 @@ def general_noise_distribution(xyz, p_xyz, shortest_only=False):
             wl = wl[np.isclose(wl, np.min(wl))]                                                # :407-408
         Z[c] = np.sum(np.exp(-wl))                                                             # :411
     return np.divide(Z, sum(Z)) * 100
+
+
+def _general_noise_xyz(init_code, p_xyz, p_sampling, droplets, steps, seed):
+    """the sampling of STDC_general_noise / _shortest (decoders.py:345-401): Chain at a scalar p_sampling (default
+    p_xyz.sum()), Chain_xyz at an array; no rain in either form of init_code (`randomize = False`, :364,:378)"""
+    p_xyz = np.asarray(p_xyz, dtype=np.float64)
+    if p_sampling is None:
+        p_sampling = p_xyz.sum()
+    code0, init = _class_starts(init_code, droplets, rain=False)
+    _, xyz = ptdc_batch(init, p_sampling, Nc=1, steps=steps, droplets=droplets, iters=5, with_xyz=True,
+                        seed=_fresh_seed() if seed is None else seed, code=_code_id(code0))
+    return p_xyz, xyz[0]
+
+
+def STDC_general_noise(init_code, p_xyz, p_sampling=None, droplets=10, steps=20000, shortest_only=False, seed=None):
+    """Drop-in for decoders.STDC_general_noise (decoders.py:345-432): single chains (`update_chain_fast(5)` per step) sampled
+    by Chain, or by Chain_xyz when p_sampling is an array; Z_E from the (n_x, n_y, n_z) of the distinct chains with one
+    beta per Pauli type.  Returns the float percent vector."""
+    p_xyz, xyz = _general_noise_xyz(init_code, p_xyz, p_sampling, droplets, steps, seed)
+    return general_noise_distribution(xyz, p_xyz, shortest_only)
+
+
+def STDC_general_noise_shortest(init_code, p_xyz, p_sampling=None, droplets=10, steps=20000, seed=None):
+    """Drop-in for decoders.STDC_general_noise_shortest (decoders.py:435-507): both estimates from one sampling run."""
+    p_xyz, xyz = _general_noise_xyz(init_code, p_xyz, p_sampling, droplets, steps, seed)
+    return general_noise_distribution(xyz, p_xyz), general_noise_distribution(xyz, p_xyz, shortest_only=True)
 
 
 def strc_distribution(n_unique, m_obs, p_error, p_sampling):

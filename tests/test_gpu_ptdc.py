@@ -222,3 +222,72 @@ def test_conv_mult_is_ignored_per_rung(q):
     a = q.ptdc_batch(init, 0.1, Nc=3, steps=200, droplets=2, seed=1, per_rung=True, conv_mult=2.0)
     b = q.ptdc_batch(init, 0.1, Nc=3, steps=200, droplets=2, seed=1, per_rung=True)
     assert np.array_equal(a, b)
+
+
+# ---- (n_x, n_y, n_z) of the distinct chains, Chain_xyz sampling: STDC_general_noise family (decoders.py:325-507) ----------------------
+
+def _sorted_sets(orc, xv):
+    """oracle output uint32[N, ncls, maxu] -> list[N][ncls] of sorted int64[k, 3]"""
+    from qecmc.decoders import unpack_xyz
+    return [[unpack_xyz(xv[s, c]) for c in range(xv.shape[1])] for s in range(xv.shape[0])]
+
+
+def _same_sets(a, b):
+    return len(a) == len(b) and all(len(x) == len(y) and all(np.array_equal(u, v) for u, v in zip(x, y)) for x, y in zip(a, b))
+
+
+def test_xyz_of_distinct_chains_bit_exact(q, orc):
+    rng = np.random.default_rng(88)
+    init = np.stack([_planar_reps(rng, 5, 0.1)[1] for _ in range(2)])
+    hist, xyz = q.ptdc_batch(init, 0.15, Nc=1, steps=300, droplets=3, iters=5, seed=12, first_syndrome=1, code=q.PLANAR, with_xyz=True)
+    rh, rx = orc.ptdc_batch(orc.PLANAR, init, 0.15, 1, 300, droplets=3, iters=5, seed=12, first_syndrome=1, with_xyz=True)
+    assert np.array_equal(hist, rh) and _same_sets(xyz, _sorted_sets(orc, rx))
+    for s in range(2):
+        for c in range(4):
+            assert np.array_equal(np.bincount(xyz[s][c].sum(axis=1), minlength=hist.shape[-1]), hist[s, c])
+    # any ladder: toric, Nc = 3, with the early stop
+    ti = _toric_reps(q, _rand_toric(rng, 3, 0.12))[None]
+    hist, xyz = q.ptdc_batch(ti, 0.1, Nc=3, steps=200, droplets=2, seed=3, with_xyz=True, conv_mult=2.0)
+    rh, rx = orc.ptdc_batch(orc.TORIC, ti, 0.1, 3, 200, droplets=2, seed=3, with_xyz=True, conv_mult=2.0)
+    assert np.array_equal(hist, rh) and _same_sets(xyz, _sorted_sets(orc, rx))
+
+
+@pytest.mark.parametrize("code_name,L,pxyz", [("planar", 5, (0.08, 0.01, 0.03)), ("planar", 3, (0.02, 0.05, 0.11)), ("xzzx", 5, (0.3, 0.2, 0.1)),
+                                              ("rotated", 5, (0.01, 0.02, 0.2))])
+def test_chain_xyz_sampling_bit_exact(q, orc, code_name, L, pxyz):
+    """Chain_xyz (mcmc.py:106-114,162-173): acceptance prod_i factors_i^(change of n_i) from a table of integer thresholds."""
+    rng = np.random.default_rng(L + len(code_name))
+    if code_name == "planar":
+        init = np.stack([_planar_reps(rng, L, 0.1)[1] for _ in range(2)])
+        cg, co = q.PLANAR, orc.PLANAR
+    else:
+        cg, co = (q.XZZX, orc.XZZX) if code_name == "xzzx" else (q.ROTATED, orc.ROTATED)
+        m = rng.integers(0, 4, size=(2, 4, L, L), dtype=np.uint8) * (rng.random((2, 4, L, L)) < 0.15)
+        init = m.astype(np.uint8)                         # the class labels do not matter for the sampling parity
+    pa = np.array(pxyz)
+    hist, xyz = q.ptdc_batch(init, pa, Nc=1, steps=250, droplets=2, iters=5, seed=21, code=cg, with_xyz=True)
+    rh, rx = orc.ptdc_batch(co, init, pa, 1, 250, droplets=2, iters=5, seed=21, with_xyz=True)
+    assert hist.sum() > 50 and np.array_equal(hist, rh) and _same_sets(xyz, _sorted_sets(orc, rx))
+
+
+def test_general_noise_dropins(q, orc):
+    from qecmc.decoders import general_noise_distribution
+    rng = np.random.default_rng(61)
+    _, reps = _planar_reps(rng, 3, 0.12)
+    codes = []
+    for r in reps:
+        c = q.Planar_code(3); c.qubit_matrix = r.copy(); codes.append(c)
+    p_xyz = np.array([0.03, 0.02, 0.08])
+    for ps in (None, 0.2, np.array([0.1, 0.06, 0.08])):
+        dist = q.STDC_general_noise(codes, p_xyz, p_sampling=ps, droplets=3, steps=500, seed=4)
+        _, rx = orc.ptdc_batch(orc.PLANAR, reps[None], p_xyz.sum() if ps is None else ps, 1, 500, droplets=3, iters=5, seed=4, with_xyz=True)
+        sets = _sorted_sets(orc, rx)[0]
+        assert np.allclose(dist, general_noise_distribution(sets, p_xyz), rtol=1e-12) and abs(dist.sum() - 100) < 1e-9
+        both = q.STDC_general_noise_shortest(codes, p_xyz, p_sampling=ps, droplets=3, steps=500, seed=4)
+        assert np.allclose(both[0], dist, rtol=1e-12)
+        assert np.allclose(both[1], general_noise_distribution(sets, p_xyz, shortest_only=True), rtol=1e-12)
+        assert np.allclose(q.STDC_general_noise(codes, p_xyz, p_sampling=ps, droplets=3, steps=500, shortest_only=True, seed=4), both[1], rtol=1e-12)
+    with pytest.raises(q.QecmcError, match="Nc=3 must be 1"):
+        q.ptdc_batch(reps[None], p_xyz, Nc=3, steps=10, code=q.PLANAR)
+    with pytest.raises(q.QecmcError, match="positive"):
+        q.ptdc_batch(reps[None], np.array([0.1, 0.0, 0.1]), Nc=1, steps=10, code=q.PLANAR)
