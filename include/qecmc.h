@@ -205,7 +205,10 @@ int qecmc_ptdc_batch_conv(const qecmc_params *params, const uint8_t *init, uint6
  * QECMC_PTDC_SET_PER_RUNG.
  * p_xyz_sampling (nullable) double[3]: sample with Chain_xyz (src/mcmc.py:106-114,162-173) instead of Chain -- a single
  * chain (params->Nc must be 1; params->p is ignored) whose proposals are accepted with probability
- * prod_i (p_i / (1 - sum p))^(change of n_i); planar, xzzx and rotated codes (the reference's runs the planar stencil). */
+ * prod_i (p_i / (1 - sum p))^(change of n_i); planar, xzzx and rotated codes (the reference's runs the planar stencil).
+ * params->noise = QECMC_NOISE_ALPHA (with params->alpha, params->p = pz_tilde_sampling, Nc = 1, iters = 5) samples with
+ * Chain_alpha instead: STDC_droplet_alpha / STDC_Nall_n_alpha (decoders.py:510-581), whose weights
+ * n_z + alpha (n_x + n_y) the caller forms from xyz_out. */
 int qecmc_ptdc_batch_xyz(const qecmc_params *params, const uint8_t *init, uint64_t N, int32_t droplets,
                          uint32_t flags, double conv_mult, const double *p_xyz_sampling, uint32_t *hist_out,
                          uint32_t *m_out, uint32_t *steps_done_out, uint32_t *xyz_out, uint32_t *xyz_count_out,

@@ -713,6 +713,11 @@ int qecmc_ptdc_batch_xyz(const qecmc_params *params, const uint8_t *init, uint64
                 }
         p.p = tot <= 0.75 ? tot : 0.75;                                           // unused by the rule; keeps the plan's tables valid
     }
+    if (p.noise == QECMC_NOISE_ALPHA) {
+        // STDC_droplet_alpha (decoders.py:510-534): Chain_alpha single chains, `update_chain(5)` per step
+        if (p.Nc != 1) return fail(QECMC_ERR_UNSUPPORTED, "the unique-chain estimators run Chain_alpha as single chains (decoders.py:510): Nc=%d must be 1", p.Nc);
+        if (p_xyz_sampling) return fail(QECMC_ERR_INVALID, "p_xyz_sampling and alpha noise exclude each other");
+    } else
     if (p.noise != QECMC_NOISE_DEPOLARIZING) return fail(QECMC_ERR_UNSUPPORTED, "PTDC is defined for the depolarizing ladder (decoders.py:168)");
     if (p.scan != QECMC_SCAN_RANDOM) return fail(QECMC_ERR_UNSUPPORTED, "PTDC runs the reference's random-scan ladder");
     if (droplets < 1) return fail(QECMC_ERR_INVALID, "droplets=%d must be >= 1", droplets);
@@ -771,6 +776,7 @@ int qecmc_ptdc_batch_xyz(const qecmc_params *params, const uint8_t *init, uint64
     a.uset_mhist = m_out ? dm.as<uint32_t>() : nullptr; a.uset_D = (uint32_t)D; a.uset_per_rung = per_rung ? 1 : 0;
     a.uset_conv_mult = conv_mult; a.uset_own = own ? reinterpret_cast<unsigned long long *>(down.p) : nullptr; a.uset_own_cap = own_cap;
     a.steps_done = steps_done_out ? dsd.as<uint32_t>() : nullptr;
+    a.bias_lds = 0;                                                  // (alpha droplets: one rung's tables, read through the cache)
     a.uset_xyz = xyz_out ? dxyz.as<uint32_t>() : nullptr; a.uset_xyz_cnt = xyz_out ? dxc.as<uint32_t>() : nullptr; a.uset_xyz_stride = maxu;
     a.xyz_thr = xyz_thr.empty() ? nullptr : dthr.as<uint32_t>();
     {

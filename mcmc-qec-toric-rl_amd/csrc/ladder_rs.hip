@@ -1166,8 +1166,14 @@ hipError_t launch_ladder_rs_toric(const LadderArgs &a, hipStream_t stream)
 #define QECMC_K(maxt, minw, g, code, biased) QECMC_K2(maxt, minw, g, code, biased, true)
     if (a.uset_tab != nullptr) {
         // direct-counting runs: depolarizing random scan without logical moves (no general top path), fixed length
-        if (a.noise || a.scan || conv || a.thr_logical != 0) return hipErrorInvalidValue;
-        if (a.xyz_thr != nullptr && (a.code == T || a.Nc != 1)) return hipErrorInvalidValue;   // Chain_xyz: single chains, table-driven codes
+        if ((a.noise && a.noise != 2) || a.scan || conv || a.thr_logical != 0) return hipErrorInvalidValue;
+        if (a.xyz_thr != nullptr && (a.code == T || a.Nc != 1 || a.noise)) return hipErrorInvalidValue;   // Chain_xyz: single chains, table-driven codes
+        if (a.noise == 2) {
+            // STDC_droplet_alpha (decoders.py:510-534): single Chain_alpha chains, power tables read from HBM
+            if (a.Nc != 1 || a.bias_lds || (a.code != X && a.code != R)) return hipErrorInvalidValue;
+            fn = a.code == X ? (const void *)ladder_rs_toric_kernel<1024, 4, false, false, X, true, false, true, true>
+                             : (const void *)ladder_rs_toric_kernel<1024, 4, false, false, R, true, false, true, true>;
+        } else {
         const bool gsplit = (int)a.n_gen <= kGenSplit;
 #define QECMC_KU(code) (block <= 512 ? (gsplit ? (const void *)ladder_rs_toric_kernel<512, 8, false, true, code, false, false, false, true>   \
                                               : (const void *)ladder_rs_toric_kernel<512, 8, false, false, code, false, false, false, true>)  \
@@ -1175,6 +1181,7 @@ hipError_t launch_ladder_rs_toric(const LadderArgs &a, hipStream_t stream)
                                               : (const void *)ladder_rs_toric_kernel<1024, 4, false, false, code, false, false, false, true>))
         fn = a.code == T ? QECMC_KU(T) : a.code == X ? QECMC_KU(X) : a.code == R ? QECMC_KU(R) : QECMC_KU(P);
 #undef QECMC_KU
+        }
     } else
     if (a.code == T && !a.noise) {
         // the general top-chain path is needed only for L > 16 or a top chain below p = 0.75 (1-chain ladder)

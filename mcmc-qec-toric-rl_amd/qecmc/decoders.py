@@ -93,7 +93,7 @@ def _pteq(init_code, p, eta, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, conv_c
 
 
 def ptdc_batch(init, p_sampling, Nc=None, steps=2000, droplets=1, iters=10, seed=0, first_syndrome=0, device=0, code=L_.TORIC,
-               return_stats=False, per_rung=False, with_m=False, conv_mult=0.0, return_steps=False, with_xyz=False):
+               return_stats=False, per_rung=False, with_m=False, conv_mult=0.0, return_steps=False, with_xyz=False, alpha=None):
     """The sampling half of PTDC (decoders.py:168-233) on N syndromes at once.
 
     init: uint8[N, ncls, ...] -- one representative per equivalence class for every syndrome (what `to_class` / the list
@@ -107,7 +107,8 @@ def ptdc_batch(init, p_sampling, Nc=None, steps=2000, droplets=1, iters=10, seed
     droplet; return_steps=True appends steps_done uint32[N, ncls, droplets], the steps each droplet recorded.
     with_xyz=True appends a list[N][ncls] of int64[k, 3] arrays: (n_x, n_y, n_z) of the k distinct chains of each set, sorted
     (the values of STDC_droplet_general_noise's dict, :325-342).  p_sampling may be an array (p_x, p_y, p_z): the chains
-    are then Chain_xyz (src/mcmc.py:106-114), which needs Nc = 1."""
+    are then Chain_xyz (src/mcmc.py:106-114), which needs Nc = 1.  alpha: the chains are Chain_alpha at
+    pz_tilde = p_sampling (src/mcmc_alpha.py; STDC_droplet_alpha, :510-534: Nc = 1, iters = 5; xzzx / rotated codes)."""
     nd = 3 if code in (L_.TORIC, L_.PLANAR) else 2
     a = np.ascontiguousarray(init, dtype=np.uint8)
     per_droplet = a.ndim == nd + 3
@@ -122,8 +123,9 @@ def ptdc_batch(init, p_sampling, Nc=None, steps=2000, droplets=1, iters=10, seed
     if np.ndim(p_sampling) != 0:
         pxyz = (C.c_double * 3)(*[float(v) for v in p_sampling])
         p_sampling = 0.1                                   # ignored by the Chain_xyz rule
+    noise = dict(noise=L_.NOISE_ALPHA, alpha=float(alpha)) if alpha is not None else {}
     pr = L_.make_params(code=code, L=size, Nc=Nc, p=float(p_sampling), iters=int(iters), steps=int(steps), seed=seed,
-                        first_syndrome=first_syndrome, device=device)
+                        first_syndrome=first_syndrome, device=device, **noise)
     shape = (N, ncls, int(droplets), Nc, nq + 1) if per_rung else (N, ncls, nq + 1)
     hist = np.zeros(shape, dtype=np.uint32)
     mh = np.zeros(shape, dtype=np.uint32) if with_m else None
@@ -241,6 +243,36 @@ def STDC_general_noise_shortest(init_code, p_xyz, p_sampling=None, droplets=10, 
     """Drop-in for decoders.STDC_general_noise_shortest (decoders.py:435-507): both estimates from one sampling run."""
     p_xyz, xyz = _general_noise_xyz(init_code, p_xyz, p_sampling, droplets, steps, seed)
     return general_noise_distribution(xyz, p_xyz), general_noise_distribution(xyz, p_xyz, shortest_only=True)
+
+
+def nall_n_alpha_distribution(xyz, alpha, pz_tilde):
+    """STDC_Nall_n_alpha's estimate (decoders.py:569-581) from xyz[c] = int[k_c, 3]: Z_c = sum over the distinct chains of
+    exp(-beta (n_z + alpha (n_x + n_y))) with beta = -ln(pz_tilde) (:522, :569, :578), normalised, x 100."""
+    beta = -np.log(pz_tilde)
+    Z = np.zeros(len(xyz))
+    for c, q in enumerate(xyz):
+        q = np.asarray(q).reshape(-1, 3)
+        Z[c] = np.sum(np.exp(-beta * (q[:, 2] + alpha * (q[:, 0] + q[:, 1]))))
+    return np.divide(Z, sum(Z)) * 100
+
+
+def STDC_Nall_n_alpha(init_code, pz_tilde_sampling=None, alpha=1, pz_tilde=0.1, steps=20000, seed=None):
+    """Drop-in for decoders.STDC_Nall_n_alpha (decoders.py:537-581; `generate_data.py:190-196`, method "STDC_N_n"): one
+    Chain_alpha per class at pz_tilde_sampling, `update_chain(5)` per step, Z_E from the effective lengths of the distinct
+    chains.  init_code: a list with one code per class, or a code (moved to class eq by the logical operator
+    `eq_class ^ eq`, :557-561; no rain either way -- STDC_droplet_alpha takes no `randomize`)."""
+    import copy
+    if isinstance(init_code, list):
+        assert len(init_code) == init_code[0].nbr_eq_classes, 'if init_code is a list, it has to contain one code for each class'
+        code0, reps = init_code[0], [c.qubit_matrix for c in init_code]
+    else:
+        code0, reps = init_code, []
+        for eq in range(init_code.nbr_eq_classes):
+            c = copy.deepcopy(init_code)
+            reps.append(c.apply_logical(c.define_equivalence_class() ^ eq)[0])
+    _, xyz = ptdc_batch(np.stack(reps)[None], pz_tilde_sampling, Nc=1, steps=steps, droplets=1, iters=5, with_xyz=True, alpha=alpha,
+                        seed=_fresh_seed() if seed is None else seed, code=_code_id(code0))
+    return nall_n_alpha_distribution(xyz[0], alpha, pz_tilde)
 
 
 def strc_distribution(n_unique, m_obs, p_error, p_sampling):

@@ -10,7 +10,8 @@ GPU call, and returned / saved as plain arrays (npz instead of the MultiIndex pi
 import numpy as np
 
 from . import _lib as L_
-from .decoders import pteq_batch
+from .decoders import (nall_n_alpha_distribution, pteq_batch, ptdc_batch, ptdc_distribution, ptrc_distribution,
+                       strc_distribution)
 
 _CODES = {"toric": L_.TORIC, "xzzx": L_.XZZX, "rotated": L_.ROTATED, "planar": L_.PLANAR}
 
@@ -89,12 +90,82 @@ def hide_class(code, m, rng):
     return m
 
 
+def class_representatives(code, m):
+    """uint8[n, ...] -> uint8[n, ncls, ...]: the configuration with the same syndrome in every equivalence class, indexed by
+    class (`to_class(eq)` for the toric code, toric_model.py:354; for the 4-class codes the four logical operators, as
+    STDC_Nall_n_alpha does with `apply_logical(eq_class ^ eq)`, decoders.py:557-561)."""
+    from . import _surf, planar_model, toric_model
+    code = _CODES.get(code, code)
+    m = np.ascontiguousarray(m, dtype=np.uint8)
+    if code == L_.TORIC:
+        return np.stack([toric_model.to_class(m, eq) for eq in range(16)], axis=1)
+    out = np.empty((m.shape[0], 4) + m.shape[1:], dtype=np.uint8)
+    for op in range(4):
+        r = planar_model.apply_logical(m, op)[0] if code == L_.PLANAR else _surf.apply_logical(code, m, op)[0]
+        out[np.arange(m.shape[0]), np.asarray(_class_of(code, r))] = r
+    return out
+
+
+def rain(code, m, rng, p=0.5):
+    """`apply_stabilizers_uniform` (toric_model.py:299-314, planar_model.py:355-376) on a batch: every generator is applied
+    to every configuration independently with probability p (STDC's / STRC's high-energy start, decoders.py:246-247)."""
+    from . import planar_model, toric_model
+    code = _CODES.get(code, code)
+    if code not in (L_.TORIC, L_.PLANAR):
+        raise ValueError("rain is defined for the toric and planar codes (the only models with apply_stabilizers_uniform)")
+    mod = toric_model if code == L_.TORIC else planar_model
+    m = np.ascontiguousarray(m, dtype=np.uint8).copy()
+    n, size = m.shape[0], m.shape[-1]
+    pick = rng.random((n, 2, size, size)) < p
+    if code == L_.PLANAR:                       # no X-type generator in the last row, no Z-type in the last column
+        pick[:, 1, size - 1, :] = False
+        pick[:, 0, :, size - 1] = False
+    for o in range(2):
+        for r in range(size):
+            for c in range(size):
+                sel = np.flatnonzero(pick[:, o, r, c])
+                if sel.size:
+                    m[sel] = mod.apply_stabilizer(m[sel], r, c, 3 if o == 0 else 1)[0]
+    return m
+
+
+def _estimate(method, code, reps, p_error, p_sampling, Nc, steps, droplets, conv_mult, seed, first, rng, alpha):
+    """the unique-chain estimators of generate_data.py:168-196 on a batch of class representatives [n, ncls, ...] -> float[n, ncls]"""
+    n = reps.shape[0]
+    if method == "PTDC":                                                       # decoders.py:168-233
+        hist = ptdc_batch(reps, p_sampling, Nc=Nc, steps=steps // Nc, droplets=droplets, conv_mult=conv_mult, seed=seed,
+                          first_syndrome=first, code=code)
+        return ptdc_distribution(hist, p_error)
+    if method == "PTRC":                                                       # decoders.py:638-742
+        n_u, m_o = ptdc_batch(reps, p_sampling, Nc=Nc, steps=steps // Nc, droplets=droplets, per_rung=True, with_m=True, seed=seed,
+                              first_syndrome=first, code=code)
+        return np.stack([ptrc_distribution(n_u[i], m_o[i], p_error, p_sampling) for i in range(n)]).astype(np.float64)
+    if method in ("STDC", "STRC"):                                             # decoders.py:268-322, :835-949: rain per droplet
+        starts = np.stack([rain(code, reps.reshape((-1,) + reps.shape[2:]), rng).reshape(reps.shape) for _ in range(droplets)], axis=2)
+        if method == "STDC":
+            hist = ptdc_batch(starts, p_sampling, Nc=1, steps=steps, droplets=droplets, iters=5, conv_mult=conv_mult, seed=seed,
+                              first_syndrome=first, code=code)
+            return ptdc_distribution(hist, p_error)
+        n_u, m_o = ptdc_batch(starts, p_sampling, Nc=1, steps=steps, droplets=droplets, iters=5, with_m=True, conv_mult=conv_mult,
+                              seed=seed, first_syndrome=first, code=code)
+        return np.stack([strc_distribution(n_u[i], m_o[i], p_error, p_sampling) for i in range(n)])
+    if method == "STDC_N_n":                                                   # decoders.py:537-581 (generate_data.py:190-196)
+        _, xyz = ptdc_batch(reps, p_sampling, Nc=1, steps=steps, droplets=1, iters=5, with_xyz=True, alpha=alpha, seed=seed,
+                            first_syndrome=first, code=code)
+        return np.stack([nall_n_alpha_distribution(xyz[i], alpha, p_error) for i in range(n)])
+    raise ValueError(f"method={method!r}")
+
+
 def generate(params, nbr_datapoints, seed=0, file_path=None, steps=100000, conv_criteria="error_based", biased_decoder="alpha",
              **pteq_kw):
     """params: dict like generate_data.py:276-296 ({'code','size','p_error','noise'[,'eta','alpha']}), method PTEQ.
     noise 'depolarizing' -> PTEQ (:136); 'biased' -> errors from the eta split (:78-83) decoded by PTEQ_alpha with
     (pz_tilde, alpha) derived from (p, eta) exactly as :142-150 does (biased_decoder="biased" decodes with PTEQ_biased
     instead); 'alpha' -> p_error is pz_tilde, errors and decoder from (pz_tilde, alpha) (:84-91,:151-160).
+    params['method'] (default "PTEQ") may also be "PTDC", "PTRC", "STDC", "STRC" or "STDC_N_n" (generate_data.py:168-196): the
+    unique-chain estimators on one representative per class of every syndrome, with params['p_sampling'] (default p_error),
+    params['droplets'], params['conv_mult'] and `steps` as the estimator's own `steps`; `batch` syndromes go into one launch
+    (default 256: the sets of visited chains live in HBM).  They return distr float64[n, ncls] and no counts.
     Returns (and optionally saves as npz) qubit_matrix uint8[n,...] (the raw errors, generate_data.py:120),
     eq_true int32[n], counts uint32[n,ncls], distr uint8[n,ncls] (what PTEQ returns), success bool[n]
     (argmax(distr) == eq_true, generate_data.py:139), steps_done, converged."""
@@ -108,6 +179,23 @@ def generate(params, nbr_datapoints, seed=0, file_path=None, steps=100000, conv_
     raw = draw_errors(code, size, nbr_datapoints, p, rng, eta, rates=alpha_rates(p, params["alpha"]) if noise == "alpha" else None)
     eq_true = np.asarray(_class_of(code, raw), dtype=np.int32)
     init = hide_class(code, raw, rng)
+    method = params.get("method", "PTEQ")
+    if method != "PTEQ":
+        if noise != ("alpha" if method == "STDC_N_n" else "depolarizing"):
+            raise ValueError(f"method {method} is defined for {'alpha' if method == 'STDC_N_n' else 'depolarizing'} noise (generate_data.py:168-196)")
+        batch = int(pteq_kw.pop("batch", 256))
+        ncls = 16 if code == L_.TORIC else 4
+        distr = np.empty((nbr_datapoints, ncls), dtype=np.float64)
+        droplets = params.get("droplets", 1 if method == "STDC_N_n" else 4)
+        for lo in range(0, nbr_datapoints, batch):
+            reps = class_representatives(code, init[lo:lo + batch])
+            # every (syndrome, class, droplet) ladder needs a Philox syndrome index of its own
+            distr[lo:lo + batch] = _estimate(method, code, reps, p, params.get("p_sampling") or p, params.get("Nc") or size, steps, droplets,
+                                             params.get("conv_mult", 0), seed, lo * ncls * droplets, rng, params.get("alpha"))
+        out = dict(qubit_matrix=raw, eq_true=eq_true, distr=distr, success=np.argmax(distr, axis=1) == eq_true)
+        if file_path is not None:
+            np.savez_compressed(file_path, params=np.array([repr(params)]), **out)
+        return out
     dec = dict(eta=eta)
     p_dec = p
     if noise == "alpha":

@@ -449,8 +449,11 @@ def pteq_batch(code, init, p, Nc, steps, iters=10, tops_burn=2, seed=0, first_sy
 
 
 # ---- unique-chain estimators (decoders.py:138-233) ---------------------------------------------------------------
-def _sampling_model(code, L, p_sampling):
-    """scalar p_sampling: Chain / Ladder (src/mcmc.py); a (p_x, p_y, p_z) array: Chain_xyz (mcmc.py:106-114), single chains only"""
+def _sampling_model(code, L, p_sampling, alpha=None):
+    """scalar p_sampling: Chain / Ladder (src/mcmc.py); a (p_x, p_y, p_z) array: Chain_xyz (mcmc.py:106-114), single chains only;
+    alpha: Chain_alpha at pz_tilde = p_sampling (src/mcmc_alpha.py; STDC_droplet_alpha, decoders.py:510-534)"""
+    if alpha is not None:
+        return _model(code, L, noise=ALPHA, alpha=alpha), float(p_sampling)
     if np.ndim(p_sampling) == 0:
         return _model(code, L), float(p_sampling)
     ps = [float(v) for v in p_sampling]
@@ -469,13 +472,13 @@ def unpack_xyz(vals):
 
 
 def ptdc_droplet(code, init, p_sampling, Nc, steps, iters=10, rng=None, tab=None, per_rung=False, with_m=False, conv_mult=0.0,
-                 with_xyz=False):
+                 with_xyz=False, alpha=None):
     """PTDC_droplet (conv_mult = 0): returns (N(n) uint32[nq+1] of the chains that were new to `tab`, tab).  Nc=1, iters=5 is
     STDC_droplet / STRC_droplet; per_rung=True is PTRC_droplet (N(n) per rung, uint32[Nc, nq+1]); with_m also returns m(n).
     with_xyz: returns (N(n), xyz int64[k, 3], tab) -- (n_x, n_y, n_z) of the k chains new to tab, in the order found
     (STDC_droplet_general_noise's dict values, decoders.py:325-342)."""
     init = _m(init); nq = init.size
-    mod, p_sampling = _sampling_model(code, init.shape[-1], p_sampling)
+    mod, p_sampling = _sampling_model(code, init.shape[-1], p_sampling, alpha)
     nset = Nc if per_rung else 1
     if tab is None:
         cap = 16
@@ -498,7 +501,7 @@ def ptdc_droplet(code, init, p_sampling, Nc, steps, iters=10, rng=None, tab=None
 
 
 def ptdc_batch(code, init, p_sampling, Nc, steps, droplets=1, iters=10, seed=0, first_syndrome=0, n_threads=0, per_rung=False,
-               with_m=False, conv_mult=0.0, with_xyz=False):
+               with_m=False, conv_mult=0.0, with_xyz=False, alpha=None):
     """init uint8[N, ncls, ...] class representatives (or [N, ncls, droplets, ...]) -> N(n) uint32[N, ncls, nq+1]
     (per_rung: [N, ncls, droplets, Nc, nq+1]); with_m: (N(n), m(n)); with_xyz appends uint32[N, ncls, steps*Nc*droplets],
     the packed (n_x, n_y, n_z) of every distinct chain of the class set (tail 0xFFFFFFFF)."""
@@ -506,7 +509,7 @@ def ptdc_batch(code, init, p_sampling, Nc, steps, droplets=1, iters=10, seed=0, 
     nd = 3 if code in (TORIC, PLANAR) else 2
     per_droplet = init.ndim == nd + 3
     nq = int(np.prod(init.shape[-nd:]))
-    mod, p_sampling = _sampling_model(code, init.shape[-1], p_sampling)
+    mod, p_sampling = _sampling_model(code, init.shape[-1], p_sampling, alpha)
     shape = (N, ncls, droplets, Nc, nq + 1) if per_rung else (N, ncls, nq + 1)
     hist = np.zeros(shape, dtype=np.uint32)
     mh = np.zeros(shape, dtype=np.uint32) if with_m else None

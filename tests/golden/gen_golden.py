@@ -23,6 +23,7 @@ Fixtures
   f_convmult.npz              the conv_mult early stop of PTDC_droplet / STDC_droplet / STDC / STRC (decoders.py:153-162,:256-262,:783-826)
   f_xyz.npz                   STDC_droplet_general_noise / STDC_general_noise(_shortest) on the planar code (decoders.py:325-507), with
                               Chain and Chain_xyz (mcmc.py:106-114,162-173) sampling
+  f_nalpha.npz                STDC_droplet_alpha / STDC_Nall_n_alpha (decoders.py:510-581) on the xzzx and rotated codes
   f_planar.npz                Planar_code stencil KATs and Chain (incl. update_chain_fast) / Ladder / PTEQ trajectories
 """
 import argparse
@@ -755,6 +756,50 @@ def gen_xyz(tm, pm, mc, dec):
     print("f_xyz.npz", cases, {c: int(out[c + "_par"][-1]) for c in cases})
 
 
+def gen_nalpha(xm, rm, ma, dec):
+    """STDC_droplet_alpha (decoders.py:510-534): effective lengths n_z + alpha (n_x + n_y) of the distinct chains a Chain_alpha
+    visits (`update_chain(5)` per step), in the order found; and STDC_Nall_n_alpha's estimate (:537-581, list form)."""
+    rng = np.random.default_rng(1111)
+    out = {}
+    cases = []
+    mods = (xm, rm)
+    codes = {"xzzx": xm.xzzx_code, "rot": rm.RotSurCode}
+    for i, (name, L, pzt, alpha, steps, perr) in enumerate([("xzzx", 3, 0.2, 2.0, 200, 0.3), ("xzzx", 5, 0.1, 1.7, 200, 0.15),
+                                                           ("rot", 5, 0.15, 1.0, 200, 0.15), ("rot", 7, 0.12, 3.1, 150, 0.1)]):
+        m = rand_matrix2(rng, L, perr)
+        seed = 11000 + i
+        code = codes[name](L); code.qubit_matrix = m.copy()
+        ch = ma.Chain_alpha(np.float64(pzt), alpha, code)
+        s = Stream(seed); install(s, *mods)
+        seen = dec.STDC_droplet_alpha(ch, steps, alpha)
+        restore(*mods)
+        tag = f"adrop{i}"
+        out[f"{tag}_init"] = m
+        out[f"{tag}_eff"] = np.array(list(seen.values()), dtype=np.float64)
+        out[f"{tag}_final"] = ch.code.qubit_matrix.astype(np.uint8)
+        out[f"{tag}_par"] = np.array([0 if name == "xzzx" else 1, L, pzt, alpha, steps, seed, s.n], dtype=np.float64)
+        cases.append(tag)
+    for i, (name, L, pzs, alpha, pzt, steps, perr) in enumerate([("xzzx", 3, 0.25, 2.0, 0.1, 300, 0.2), ("rot", 5, 0.2, 1.5, 0.08, 250, 0.12),
+                                                                ("xzzx", 5, 0.15, 3.0, 0.15, 250, 0.12)]):
+        m = rand_matrix2(rng, L, perr)
+        seed = 11100 + i
+        inits = []
+        for op in range(4):
+            c = codes[name](L); c.qubit_matrix = m.copy(); c.qubit_matrix = c.apply_logical(op)[0]
+            inits.append(c)
+        s = Stream(seed); install(s, *mods)
+        dist = dec.STDC_Nall_n_alpha(inits, pz_tilde_sampling=np.float64(pzs), alpha=alpha, pz_tilde=pzt, steps=steps)
+        restore(*mods)
+        tag = f"nall{i}"
+        out[f"{tag}_classes"] = np.array([c.qubit_matrix for c in inits], dtype=np.uint8)
+        out[f"{tag}_dist"] = np.asarray(dist, dtype=np.float64)
+        out[f"{tag}_par"] = np.array([0 if name == "xzzx" else 1, L, pzs, alpha, pzt, steps, seed, s.n], dtype=np.float64)
+        cases.append(tag)
+    out["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(HERE, "f_nalpha.npz"), **out)
+    print("f_nalpha.npz", cases, {c: int(out[c + "_par"][-1]) for c in cases})
+
+
 def _f3_worker(args):
     (L, p, Nc, iters, steps, burn, m, seed) = args
     tm, mc, dec = import_reference()
@@ -817,7 +862,7 @@ def main():
         print("reference not present; nothing to do")
         return
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="f1,f2,f3,f4,f1s,f2s,f2a,fp,fd,fc,fg")
+    ap.add_argument("--only", default="f1,f2,f3,f4,f1s,f2s,f2a,fp,fd,fc,fg,fa")
     only = set(ap.parse_args().only.split(","))
     tm, mc, dec = import_reference()
     if "f1" in only: gen_f1(tm)
@@ -829,8 +874,11 @@ def main():
         if "fg" in only: gen_xyz(tm, pm, mc, dec)
         if "fp" in only: gen_planar(pm, mc, dec)
         if "fd" in only: gen_ptdc(tm, pm, mc, dec)
-    if "f1s" in only or "f2s" in only or "f2a" in only:
+    if "f1s" in only or "f2s" in only or "f2a" in only or "fa" in only:
         xm, rm, mb, decb = import_reference_surf()
+        if "fa" in only:
+            import src.mcmc_alpha as ma
+            gen_nalpha(xm, rm, ma, dec)
         if "f2a" in only:
             import src.mcmc_alpha as ma
             gen_f2_alpha(xm, rm, ma, decb)

@@ -291,3 +291,34 @@ def test_general_noise_dropins(q, orc):
         q.ptdc_batch(reps[None], p_xyz, Nc=3, steps=10, code=q.PLANAR)
     with pytest.raises(q.QecmcError, match="positive"):
         q.ptdc_batch(reps[None], np.array([0.1, 0.0, 0.1]), Nc=1, steps=10, code=q.PLANAR)
+
+
+@pytest.mark.parametrize("code_name,L,pzs,alpha", [("xzzx", 5, 0.15, 1.7), ("rotated", 5, 0.2, 1.0), ("xzzx", 7, 0.1, 3.0)])
+def test_alpha_droplets_bit_exact(q, orc, code_name, L, pzs, alpha):
+    """STDC_droplet_alpha (decoders.py:510-534): Chain_alpha single chains, 5 proposals per step."""
+    rng = np.random.default_rng(L * 3 + len(code_name))
+    cg, co = (q.XZZX, orc.XZZX) if code_name == "xzzx" else (q.ROTATED, orc.ROTATED)
+    init = (rng.integers(1, 4, size=(2, 4, L, L)) * (rng.random((2, 4, L, L)) < 0.15)).astype(np.uint8)
+    hist, xyz = q.ptdc_batch(init, pzs, Nc=1, steps=300, droplets=2, iters=5, seed=33, first_syndrome=2, code=cg, with_xyz=True, alpha=alpha)
+    rh, rx = orc.ptdc_batch(co, init, pzs, 1, 300, droplets=2, iters=5, seed=33, first_syndrome=2, with_xyz=True, alpha=alpha)
+    assert hist.sum() > 20 and np.array_equal(hist, rh) and _same_sets(xyz, _sorted_sets(orc, rx))
+    with pytest.raises(q.QecmcError, match="must be 1"):
+        q.ptdc_batch(init, pzs, Nc=3, steps=10, code=cg, alpha=alpha)
+
+
+def test_nall_n_alpha_dropin(q, orc):
+    from qecmc.decoders import nall_n_alpha_distribution
+    rng = np.random.default_rng(19)
+    L = 5
+    code = q.xzzx_code(L)
+    code.qubit_matrix = (rng.integers(1, 4, size=(L, L)) * (rng.random((L, L)) < 0.12)).astype(np.uint8)
+    dist = q.STDC_Nall_n_alpha(code, pz_tilde_sampling=0.2, alpha=2.0, pz_tilde=0.1, steps=600, seed=7)
+    import copy
+    reps = np.stack([copy.deepcopy(code).apply_logical(code.define_equivalence_class() ^ eq)[0] for eq in range(4)])
+    assert [orc.surf_eq_class(orc.XZZX, r) for r in reps] == [0, 1, 2, 3]
+    _, rx = orc.ptdc_batch(orc.XZZX, reps[None], 0.2, 1, 600, droplets=1, iters=5, seed=7, with_xyz=True, alpha=2.0)
+    assert np.allclose(dist, nall_n_alpha_distribution(_sorted_sets(orc, rx)[0], 2.0, 0.1), rtol=1e-12) and abs(dist.sum() - 100) < 1e-9
+    codes = []
+    for r in reps:
+        c = q.xzzx_code(L); c.qubit_matrix = r.copy(); codes.append(c)
+    assert np.allclose(q.STDC_Nall_n_alpha(codes, pz_tilde_sampling=0.2, alpha=2.0, pz_tilde=0.1, steps=600, seed=7), dist, rtol=1e-12)

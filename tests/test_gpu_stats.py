@@ -118,3 +118,43 @@ def test_convergence_study_prefix_property(q):
     assert out["counts"].shape == (4, 96, 4) and np.array_equal(out["samples"], np.broadcast_to(out["steps"][:, None], (4, 96)))
     assert np.all(np.diff(out["counts"].astype(np.int64), axis=0) >= 0)
     assert out["tv"][0] > out["tv"][2] and out["tv"][-1] == 0
+
+
+def test_harness_class_representatives_and_rain(q):
+    from qecmc import harness, planar_model, toric_model, _surf
+    rng = np.random.default_rng(2)
+    for name, L in (("toric", 5), ("planar", 5), ("xzzx", 5), ("rotated", 7)):
+        code = harness._CODES[name]
+        raw = harness.draw_errors(name, L, 20, 0.1, rng)
+        reps = harness.class_representatives(name, raw)
+        ncls = 16 if name == "toric" else 4
+        assert reps.shape[:2] == (20, ncls)
+        syn = (lambda m: toric_model.syndrome(m)) if name == "toric" else (lambda m: np.concatenate([d.reshape(len(m), -1) for d in planar_model.syndrome(m)], axis=1)) \
+            if name == "planar" else (lambda m: _surf.syndrome(code, m))
+        for c in range(ncls):
+            assert np.array_equal(np.asarray(harness._class_of(code, reps[:, c])), np.full(20, c))
+            assert np.array_equal(syn(np.ascontiguousarray(reps[:, c])), syn(raw))
+        if name in ("toric", "planar"):
+            wet = harness.rain(name, raw, rng)
+            assert np.array_equal(syn(wet), syn(raw)) and np.array_equal(harness._class_of(code, wet), harness._class_of(code, raw))
+            assert (wet != raw).any()
+
+
+@pytest.mark.parametrize("method,params,steps", [
+    ("PTDC", dict(code="toric", size=3, p_error=0.05, Nc=3, droplets=2), 1500),
+    ("PTRC", dict(code="toric", size=3, p_error=0.05, Nc=3, droplets=2), 1500),
+    ("STDC", dict(code="planar", size=3, p_error=0.05, p_sampling=0.2, droplets=3, conv_mult=2.0), 1500),
+    ("STRC", dict(code="toric", size=3, p_error=0.05, p_sampling=0.2, droplets=3), 1500),
+    ("STDC_N_n", dict(code="xzzx", size=5, p_error=0.05, noise="alpha", alpha=2.0, p_sampling=0.2), 1500)])
+def test_harness_unique_chain_methods(q, method, params, steps):
+    """generate_data.py:168-196 on a batch: the estimators decode low-noise syndromes, chunking does not change the result."""
+    from qecmc import harness
+    params = dict(params, method=method)
+    out = harness.generate(params, 48, seed=5, steps=steps)
+    ncls = 16 if params["code"] == "toric" else 4
+    tot = out["distr"].sum(axis=1)                          # (PTRC returns the truncated uint8 percent vector, decoders.py:742)
+    assert out["distr"].shape == (48, ncls) and np.all(tot <= 100 + 1e-9) and np.all(tot > (100 - ncls if method == "PTRC" else 100 - 1e-9))
+    assert out["success"].mean() > 0.9
+    if method != "STDC" and method != "STRC":                 # (rain draws from the host stream, which chunking reorders)
+        again = harness.generate(params, 48, seed=5, steps=steps, batch=20)
+        assert np.array_equal(again["distr"], out["distr"])

@@ -211,3 +211,36 @@ def test_general_noise_distributions(case):
     both = g[f"{case}_both"]
     assert np.allclose(general_noise_distribution(xyz, p_xyz), both[0], rtol=1e-12, atol=0)
     assert np.allclose(general_noise_distribution(xyz, p_xyz, shortest_only=True), both[1], rtol=1e-12, atol=0)
+
+
+# ---- STDC_droplet_alpha / STDC_Nall_n_alpha (decoders.py:510-581): Chain_alpha sampling, weights n_z + alpha (n_x + n_y), f_nalpha.npz ----
+
+def _loada():
+    return np.load(os.path.join(GOLDEN, "f_nalpha.npz"))
+
+
+def _casesa(prefix):
+    return [str(c) for c in _loada()["cases"] if str(c).startswith(prefix)]
+
+
+@pytest.mark.parametrize("case", _casesa("adrop"))
+def test_alpha_droplet_effective_lengths(case):
+    g = _loada()
+    code, L, pzt, alpha, steps, seed, ndraw = g[f"{case}_par"]
+    rng = orc.Rng.stream(_stream(int(seed), int(ndraw)))
+    _, xyz, _ = orc.ptdc_droplet(orc.XZZX if code == 0 else orc.ROTATED, g[f"{case}_init"], float(pzt), 1, int(steps), iters=5, rng=rng,
+                                 with_xyz=True, alpha=float(alpha))
+    assert rng.consumed == int(ndraw)
+    assert np.array_equal(xyz[:, 2] + float(alpha) * (xyz[:, 0] + xyz[:, 1]), g[f"{case}_eff"])     # decoders.py:522
+
+
+@pytest.mark.parametrize("case", _casesa("nall"))
+def test_nall_n_alpha_distribution(case):
+    from qecmc.decoders import nall_n_alpha_distribution
+    g = _loada()
+    code, L, pzs, alpha, pzt, steps, seed, ndraw = g[f"{case}_par"]
+    rng = orc.Rng.stream(_stream(int(seed), int(ndraw)))
+    xyz = [orc.ptdc_droplet(orc.XZZX if code == 0 else orc.ROTATED, r, float(pzs), 1, int(steps), iters=5, rng=rng, with_xyz=True,
+                            alpha=float(alpha))[1] for r in g[f"{case}_classes"]]
+    assert rng.consumed == int(ndraw)
+    assert np.allclose(nall_n_alpha_distribution(xyz, float(alpha), float(pzt)), g[f"{case}_dist"], rtol=1e-12, atol=0)
