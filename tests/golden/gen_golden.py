@@ -756,7 +756,7 @@ def gen_xyz(tm, pm, mc, dec):
     print("f_xyz.npz", cases, {c: int(out[c + "_par"][-1]) for c in cases})
 
 
-def gen_nalpha(xm, rm, ma, dec):
+def gen_nalpha(xm, rm, ma, dec, decb):
     """STDC_droplet_alpha (decoders.py:510-534): effective lengths n_z + alpha (n_x + n_y) of the distinct chains a Chain_alpha
     visits (`update_chain(5)` per step), in the order found; and STDC_Nall_n_alpha's estimate (:537-581, list form)."""
     rng = np.random.default_rng(1111)
@@ -794,6 +794,26 @@ def gen_nalpha(xm, rm, ma, dec):
         out[f"{tag}_classes"] = np.array([c.qubit_matrix for c in inits], dtype=np.uint8)
         out[f"{tag}_dist"] = np.asarray(dist, dtype=np.float64)
         out[f"{tag}_par"] = np.array([0 if name == "xzzx" else 1, L, pzs, alpha, pzt, steps, seed, s.n], dtype=np.float64)
+        cases.append(tag)
+    # PTEQ_alpha_with_shortest (decoders_biasednoise.py:93-172): PTEQ_alpha plus the shortest-chain statistics of the bottom slot
+    for i, (name, L, pzt, alpha, Nc, steps, tops_burn, conv, perr, SEQ, TOPS, eps) in enumerate([
+            ("xzzx", 3, 0.2, 2.0, 3, 300, 2, None, 0.3, 2, 10, 0.1), ("xzzx", 5, 0.1, 1.7, 5, 200, 0, None, 0.15, 2, 10, 0.1),
+            ("rot", 5, 0.15, 1.3, 5, 200, 1, None, 0.15, 2, 10, 0.1), ("xzzx", 3, 0.3, 2.0, 3, 4000, 2, "error_based", 0.3, 2, 10, 0.6),
+            ("rot", 3, 0.25, 1.0, 3, 4000, 2, "error_based", 0.3, 1, 5, 0.8)]):
+        m = rand_matrix2(rng, L, perr)
+        seed = 11200 + i
+        code = codes[name](L); code.qubit_matrix = m.copy()
+        s = Stream(seed); install(s, *mods)
+        res = decb.PTEQ_alpha_with_shortest(code, np.float64(pzt), alpha=alpha, Nc=Nc, SEQ=SEQ, TOPS=TOPS, tops_burn=tops_burn, eps=eps,
+                                            steps=steps, iters=10, conv_criteria=conv)
+        restore(*mods)
+        tag = f"short{i}"
+        out[f"{tag}_init"] = m
+        out[f"{tag}_percent"] = np.asarray(res[0], dtype=np.uint8)
+        out[f"{tag}_eqdistr"] = np.asarray(res[1], dtype=np.float64)
+        out[f"{tag}_shortn"] = np.asarray(res[2], dtype=np.float64)
+        out[f"{tag}_par"] = np.array([0 if name == "xzzx" else 1, L, pzt, alpha, Nc, steps, tops_burn, 0 if conv is None else 1, SEQ, TOPS, eps,
+                                     seed, s.n], dtype=np.float64)
         cases.append(tag)
     out["cases"] = np.array(cases)
     np.savez_compressed(os.path.join(HERE, "f_nalpha.npz"), **out)
@@ -878,7 +898,7 @@ def main():
         xm, rm, mb, decb = import_reference_surf()
         if "fa" in only:
             import src.mcmc_alpha as ma
-            gen_nalpha(xm, rm, ma, dec)
+            gen_nalpha(xm, rm, ma, dec, decb)
         if "f2a" in only:
             import src.mcmc_alpha as ma
             gen_f2_alpha(xm, rm, ma, decb)

@@ -119,3 +119,22 @@ def test_alpha_rejects(q):
         q.pteq_batch(np.zeros((1, 5, 5), np.uint8), 1.5, Nc=3, code=q.XZZX, alpha=2.0)   # pz_tilde > 1
     with pytest.raises(q.QecmcError):
         q.pteq_batch(np.zeros((1, 5, 5), np.uint8), 0.1, Nc=3, code=q.XZZX, alpha=0.0)
+
+
+@pytest.mark.parametrize("name,L,pzt,alpha,Nc,steps,conv,kw", [("xzzx", 5, 0.1, 1.7, 5, 250, None, dict(tops_burn=0)),
+                                                               ("rotated", 5, 0.2, 2.0, 4, 250, None, dict(tops_burn=1)),
+                                                               ("xzzx", 3, 0.3, 2.0, 3, 3000, "error_based", dict(eps=0.6))])
+def test_pteq_alpha_with_shortest(q, orc, name, L, pzt, alpha, Nc, steps, conv, kw):
+    """PTEQ_alpha_with_shortest (decoders_biasednoise.py:93-172): the GPU ladder, stepped once per launch under the host
+    bookkeeping, against the oracle's ladder under the same bookkeeping (itself pinned to the reference, f_nalpha.npz)."""
+    from qecmc.decoders_biasednoise import _shortest_loop
+    from util_shortest import OracleLadderAlpha
+    rng = np.random.default_rng(L + Nc)
+    code = (q.xzzx_code if name == "xzzx" else q.RotSurCode)(L)
+    code.qubit_matrix = (rng.integers(1, 4, size=(L, L)) * (rng.random((L, L)) < 0.15)).astype(np.uint8)
+    got = q.PTEQ_alpha_with_shortest(code, pzt, alpha=alpha, Nc=Nc, steps=steps, conv_criteria=conv, seed=77, **kw)
+    ld = OracleLadderAlpha(orc.XZZX if name == "xzzx" else orc.ROTATED, code.qubit_matrix, pzt, alpha, Nc, orc.Rng.philox(77, 0), det_pow=1)
+    ref = _shortest_loop(ld, pzt, kw.get("SEQ", 2), kw.get("TOPS", 10), kw.get("tops_burn", 2), kw.get("eps", 0.1), steps, 10, conv)
+    assert got[0].dtype == np.uint8 and np.array_equal(got[0], ref[0])
+    assert np.allclose(got[1], ref[1], rtol=1e-12, equal_nan=True) and np.allclose(got[2], ref[2], rtol=1e-12, equal_nan=True)
+    assert got[0].sum() > 90

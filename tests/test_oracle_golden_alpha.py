@@ -75,3 +75,23 @@ def test_det_exp_accuracy():
     d = np.array([orc.lib().orc_det_exp(float(y)) for y in ys])
     assert np.max(np.abs(d - np.exp(ys)) / np.exp(ys)) < 4e-16
     assert orc.lib().orc_det_exp(0.0) == 1.0 and orc.lib().orc_det_exp(3.0) == 1.0 and orc.lib().orc_det_exp(-800.0) == 0.0
+
+
+@pytest.mark.parametrize("case", [c for c in np.load(os.path.join(GOLDEN, "f_nalpha.npz"))["cases"] if str(c).startswith("short")])
+def test_pteq_alpha_with_shortest_loop(case):
+    """PTEQ_alpha_with_shortest (decoders_biasednoise.py:93-172): qecmc's host bookkeeping around the oracle's Ladder_alpha on
+    the injected stream reproduces the reference's three outputs and consumes the same number of draws."""
+    import random
+    from qecmc.decoders_biasednoise import _shortest_loop
+    from util_shortest import OracleLadderAlpha
+    g = np.load(os.path.join(GOLDEN, "f_nalpha.npz"))
+    code, L, pzt, alpha, Nc, steps, tops_burn, conv, SEQ, TOPS, eps, seed, ndraw = g[f"{case}_par"]
+    r = random.Random(int(seed))
+    rng = orc.Rng.stream(np.array([r.random() for _ in range(int(ndraw))], dtype=np.float64))
+    ld = OracleLadderAlpha(orc.XZZX if code == 0 else orc.ROTATED, g[f"{case}_init"], float(pzt), float(alpha), int(Nc), rng)
+    pct, eqd, sn = _shortest_loop(ld, float(pzt), int(SEQ), int(TOPS), int(tops_burn), float(eps), int(steps), 10,
+                                  "error_based" if conv else None)
+    assert rng.consumed == int(ndraw)
+    assert np.array_equal(pct, g[f"{case}_percent"])
+    assert np.allclose(eqd, g[f"{case}_eqdistr"], rtol=1e-12, atol=0, equal_nan=True)
+    assert np.allclose(sn, g[f"{case}_shortn"], rtol=1e-12, atol=0, equal_nan=True)
