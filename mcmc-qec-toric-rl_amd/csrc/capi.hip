@@ -107,6 +107,13 @@ uint64_t thr64(double v)
     if (!(v > 0.0)) return 0;
     return (uint64_t)std::ceil(v * 4294967296.0);
 }
+// ceil(v * 2^44): the same test on the 44-bit acceptance uniform of the non-top proposals
+uint64_t thr44(double v)
+{
+    if (!(v < 1.0)) return 1ull << 44;
+    if (!(v > 0.0)) return 0;
+    return (uint64_t)std::ceil(v * 17592186044416.0);
+}
 uint32_t thr32(double v)
 {
     const uint64_t t = thr64(v);
@@ -274,7 +281,10 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
     for (int c = 0; c < Nc && !biased; ++c) {
         const double f = chain_factor(pladder[c]);
         if (f >= 1.0 && !biased) a.acc_all_mask |= 1u << c;
-        for (int d = 1; d <= 4; ++d) a.acc_thr[c][d - 1] = thr32(std::pow(f, (double)d));   // mcmc.py:42
+        for (int d = 1; d <= 4; ++d) {
+            a.acc_thr[c][d - 1] = thr32(std::pow(f, (double)d));                     // mcmc.py:42
+            a.acc_thr44[c][d - 1] = thr44(std::pow(f, (double)d));
+        }
     }
     std::vector<uint32_t> top_tbl(nq + 1, 0u);                             // mcmc.py:34 for a top chain below p = 0.75
     for (int d = 1; d <= nq && !biased; ++d) top_tbl[d] = thr32(std::pow(chain_factor(pladder[Nc - 1]), (double)d));
@@ -469,6 +479,7 @@ static int chain_update_impl(int code, int L, uint64_t N, uint8_t *states_inout,
     const double f = noise ? 0.0 : chain_factor(p);
     std::vector<uint32_t> tbl(nq + 1, 0u);
     for (size_t d = 1; d <= nq && !noise; ++d) tbl[d] = thr32(std::pow(f, (double)d));
+    for (int d = 1; d <= 4 && !noise; ++d) a.acc44[d] = thr44(std::pow(f, (double)d));
     const std::vector<double> bt = noise == QECMC_NOISE_ALPHA ? alpha_tables(p, eta, nq) : bias_tables(p, noise ? eta : 1.0, nq);
     DevBuf ds, dt, db, dacc;
     HIP_TRY(ds.alloc(N * nq)); HIP_TRY(dt.alloc(tbl.size() * 4)); HIP_TRY(db.alloc(bt.size() * 8));
@@ -694,7 +705,7 @@ int qecmc_ptdc_batch_xyz(const qecmc_params *params, const uint8_t *init, uint64
     qecmc_params p = *params;
     p.p_logical = 0.0;                                   // Ladder(p_sampling, code, Nc): decoders.py:182,196
     p.conv_mode = QECMC_CONV_NONE;
-    std::vector<uint32_t> xyz_thr;
+    std::vector<uint64_t> xyz_thr;
     if (p_xyz_sampling) {
         // Chain_xyz (mcmc.py:106-114): factors = p_xyz / (1 - p_xyz.sum()), accept iff u < (factors ** change).prod() (:170)
         const double *q = p_xyz_sampling;
@@ -708,8 +719,7 @@ int qecmc_ptdc_batch_xyz(const qecmc_params *params, const uint8_t *init, uint64
             for (int dy = -4; dy <= 4; ++dy)
                 for (int dz = -4; dz <= 4; ++dz) {
                     const double w = (std::pow(f[0], (double)dx) * std::pow(f[1], (double)dy)) * std::pow(f[2], (double)dz);
-                    const double c = std::ceil(w * 4294967296.0);                 // u < w  <=>  x < ceil(w 2^32)  <=>  x <= ceil - 1
-                    xyz_thr[((dx + 4) * 9 + (dy + 4)) * 9 + (dz + 4)] = c >= 4294967296.0 ? 0xFFFFFFFFu : c < 1.0 ? 0u : (uint32_t)(c - 1.0);
+                    xyz_thr[((dx + 4) * 9 + (dy + 4)) * 9 + (dz + 4)] = thr44(w);      // u < w  <=>  v44 < ceil(w 2^44)
                 }
         p.p = tot <= 0.75 ? tot : 0.75;                                           // unused by the rule; keeps the plan's tables valid
     }
@@ -758,7 +768,7 @@ int qecmc_ptdc_batch_xyz(const qecmc_params *params, const uint8_t *init, uint64
         HIP_TRY(dxyz.alloc(sets * maxu * 4)); HIP_TRY(hipMemset(dxyz.p, 0xFF, sets * maxu * 4));
         HIP_TRY(dxc.alloc(sets * 4)); HIP_TRY(hipMemset(dxc.p, 0, sets * 4));
     }
-    if (!xyz_thr.empty()) { HIP_TRY(dthr.alloc(729 * 4)); HIP_TRY(hipMemcpy(dthr.p, xyz_thr.data(), 729 * 4, hipMemcpyHostToDevice)); }
+    if (!xyz_thr.empty()) { HIP_TRY(dthr.alloc(729 * 8)); HIP_TRY(hipMemcpy(dthr.p, xyz_thr.data(), 729 * 8, hipMemcpyHostToDevice)); }
     if (own) { HIP_TRY(down.alloc(M * own_cap * 8)); HIP_TRY(hipMemset(down.p, 0, M * own_cap * 8)); }
     if (steps_done_out) HIP_TRY(dsd.alloc(M * 4));
     HIP_TRY(dtab.alloc(sets * cap * 8)); HIP_TRY(dh.alloc(sets * (nq + 1) * 4));
@@ -778,7 +788,7 @@ int qecmc_ptdc_batch_xyz(const qecmc_params *params, const uint8_t *init, uint64
     a.steps_done = steps_done_out ? dsd.as<uint32_t>() : nullptr;
     a.bias_lds = 0;                                                  // (alpha droplets: one rung's tables, read through the cache)
     a.uset_xyz = xyz_out ? dxyz.as<uint32_t>() : nullptr; a.uset_xyz_cnt = xyz_out ? dxc.as<uint32_t>() : nullptr; a.uset_xyz_stride = maxu;
-    a.xyz_thr = xyz_thr.empty() ? nullptr : dthr.as<uint32_t>();
+    a.xyz_thr = xyz_thr.empty() ? nullptr : dthr.as<uint64_t>();
     {
         const hipError_t e = launch_ladder_rs_toric(a, 0);
         if (e != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return fail(QECMC_ERR_HIP, "PTDC launch: %s", hipGetErrorString(e)); }

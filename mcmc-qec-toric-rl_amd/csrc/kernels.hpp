@@ -43,8 +43,8 @@ struct LadderArgs {
     uint32_t *uset_xyz;             // [sets][uset_xyz_stride]
     uint32_t *uset_xyz_cnt;         // [sets]
     uint64_t uset_xyz_stride;
-    // Chain_xyz (mcmc.py:106-114,162-173; 1-chain ladders): accept iff x <= xyz_thr[dx+4][dy+4][dz+4]; nullable
-    const uint32_t *xyz_thr;        // [9][9][9]
+    // Chain_xyz (mcmc.py:106-114,162-173; 1-chain ladders): accept iff v44 < xyz_thr[dx+4][dy+4][dz+4]; nullable
+    const uint64_t *xyz_thr;        // [9][9][9]   ceil(w * 2^44): the 44-bit acceptance uniform of a non-top proposal
     int bias_lds;             //                    the kernel copies bias_tbl into LDS (fits: capi.hip decides)
     const double *alpha_lnb;  // [Nc-1]             ln(pz_tilde[i] / pz_tilde[i+1]) (alpha noise, mcmc_alpha.py:123)
     double alpha;             //                    mcmc_alpha.py:11
@@ -64,7 +64,8 @@ struct LadderArgs {
     double eps;               // decoders.py:102
     int conv_mode;            // 0 = fixed steps, 1 = error_based
     uint32_t acc_all_mask;    // bit c: slot c accepts every proposal (f >= 1, mcmc.py:30)
-    uint32_t acc_thr[kMaxNc][4];   // ceil(f_c^dE * 2^32), dE = 1..4
+    uint32_t acc_thr[kMaxNc][4];   // ceil(f_c^dE * 2^32), dE = 1..4 (sweep mode: one 32-bit word per acceptance)
+    uint64_t acc_thr44[kMaxNc][4]; // ceil(f_c^dE * 2^44): random scan, the 44-bit acceptance uniform of a non-top proposal
     float swap_inv_log2[kMaxNc];   // 1 / log2(p_diff[i]): first guess of the largest d with u < p_diff[i]^d (the table decides)
     int32_t swap_fast_ok;          // every swap threshold with d >= 1 fits 32 bits (false only if two rungs coincide)
     int L, Nc, W, nq, ncls;
@@ -111,7 +112,8 @@ struct ChainArgs {
     uint8_t *states;          // [N][nq] in/out
     uint64_t N, iters, k0;
     uint64_t thr_logical;     // 0 => p_logical == 0 (non-top branch, mcmc.py:37)
-    const uint32_t *acc_tbl;  // [nq+1] ceil(f^dE * 2^32) for dE >= 1 (entry 0 unused)
+    const uint32_t *acc_tbl;  // [nq+1] ceil(f^dE * 2^32) for dE >= 1 (entry 0 unused): top-chain acceptance words
+    uint64_t acc44[5];        // ceil(f^dE * 2^44), dE = 1..4: the 44-bit acceptance uniform of non-top proposals
     uint32_t acc_all;         // f >= 1: every proposal is accepted (mcmc.py:30)
     uint32_t first_syndrome, slot, seed_lo, seed_hi;
     int L;

@@ -250,8 +250,11 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
     uint32_t *info = st + (size_t)NC * W * 64;    // [2][NC][64]   slot records, double-buffered by step parity
     uint32_t *swx = info + 2 * NC * 64;           // [2][NC][64]   swap uniform of rung pair i, same parity
     uint32_t *hist = swx + 2 * NC * 64;           // [ncls][64]
-    uint32_t *thrT = hist + ncls * 64;            // [NC][9]       accept iff x <= thrT[slot][dE+4]
+    uint32_t *thrT = hist + ncls * 64;            // [NC][9]       sweep: accept iff x <= thrT[slot][dE+4]; random scan: the leading
+                                                  //               12 bits of the 44-bit threshold, accept iff a12 < thrT[slot][dE+4]
     uint32_t *swapT = thrT + NC * 9;              // [NC][kSwapFast]  swap iff x < swapT[i][d]
+    [[maybe_unused]] uint32_t *thrF = swapT + (NC - 1) * kSwapFast;   // [NC][4] (the idle last row of swapT): the low 32 bits of the
+                                                  //               44-bit threshold of dE = 1..4, looked at when a12 == thrT[..]
     volatile uint32_t *stopf = swapT + NC * kSwapFast;   // [1]  every syndrome of the workgroup has converged
     [[maybe_unused]] const uint2 *gtab = reinterpret_cast<const uint2 *>(lds + gen_off);   // [n_gen] generator table (LDS copy)
     [[maybe_unused]] const uint4 *gtab4 = reinterpret_cast<const uint4 *>(lds + gen_off + narrow_dw);  // wide form (kWideGen)
@@ -310,7 +313,14 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
     if (tid < NC * 9) {
         // u < f^dE  <=>  x < thr  <=>  x <= thr-1;  dE <= 0 (f^dE >= 1) and f >= 1 always accept (mcmc.py:30,42)
         const int c = tid / 9, d = tid - c * 9 - 4;
-        thrT[tid] = (d <= 0 || ((a.acc_all_mask >> c) & 1u)) ? 0xFFFFFFFFu : a.acc_thr[c][d - 1] - 1u;
+        const bool always = d <= 0 || ((a.acc_all_mask >> c) & 1u);
+        if constexpr (SCAN) {
+            thrT[tid] = always ? 0xFFFFFFFFu : a.acc_thr[c][d - 1] - 1u;
+        } else {
+            // non-top random-scan proposals compare a 44-bit uniform (a12 * 2^32 + w) with T44 = ceil(f^dE * 2^44)
+            thrT[tid] = always ? 4096u : (uint32_t)(a.acc_thr44[c][d - 1] >> 32);
+            if (d >= 1) thrF[c * 4 + d - 1] = (uint32_t)a.acc_thr44[c][d - 1];
+        }
     }
     __syncthreads();
 
@@ -455,13 +465,16 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
         };
 
         // ---------- the non-top random-scan loop (every code, depolarizing rule) -------------------------------------------
-        // One Philox word picks the generator (g = floor(x * G / 2^32): uniform over the G generators as the reference's
-        // three / five draws are, toric_model.py:291-295, xzzx_model.py:439-452), one is the acceptance uniform: a block feeds
-        // two proposals.
+        // ONE Philox word per proposal (word k&3 of block (k>>2, 1), so a block feeds four): its top 20 bits pick the
+        // generator, g = floor(x20 * G / 2^20) (the G generators as equally likely as 20 bits allow: G 2^-20; the proposal stays
+        // symmetric, so the stationary law is untouched) and its low 12 bits lead the 44-bit acceptance uniform.  Word k&3 of
+        // the refinement block (k>>2, kSubRefine) supplies the other 32 bits, and is computed only when some lane's 12 bits
+        // tie with its threshold's (once in 4096 proposals per lane).
         [[maybe_unused]] auto random_scan_loop = [&]() {
             int ni = (int)n;
-            auto propose = [&](uint32_t xp, uint32_t xa) {
-                const uint4 ev = gen_entry(scale_u32(xp, a.n_gen));                 // the (up to) four sites; an unused entry is 0
+            const uint32_t *myF = thrF + slot_u * 4 - 5;                            // indexed by dE + 4 = 5..8
+            auto propose = [&](uint32_t xw, uint64_t kb, auto wsel) {
+                const uint4 ev = gen_entry(((xw >> 12) * a.n_gen) >> 20);           // the (up to) four sites; an unused entry is 0
                 const uint32_t sh[4] = {ev.x, ev.y, ev.z, ev.w};                    // byte offset << 16 | ... | Pauli << 5 | bit shift
                 uint32_t *ad[4];
                 uint32_t f[4];
@@ -475,7 +488,14 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 // dE + 4 = #(new != 0) + #(old == 0) (toric_model.py:275-282): two chained popcounts, no subtraction; the
                 // threshold row is indexed by dE + 4 anyway.  An unused entry reads site 0 into both and counts 1.
                 const uint32_t dE4 = __popc((G | (G >> 1)) & 0x55u) + __popc(~(F | (F >> 1)) & 0x55u);
-                if (xa <= (myT - 4)[dE4]) {                                         // mcmc.py:42
+                const uint32_t a12 = xw & 0xFFFu, tI = (myT - 4)[dE4];
+                bool acc = a12 < tI;                                                // mcmc.py:42 (dE <= 0: tI = 4096)
+                if (__any(a12 == tI)) {                                             // rare: the next 32 bits decide
+                    constexpr int WI = decltype(wsel)::value;
+                    const u32x4 r = philox_block(kb, kSubRefine, syn, slot_u, a.seed_lo, a.seed_hi);
+                    if (a12 == tI) acc = (WI == 0 ? r.x : WI == 1 ? r.y : WI == 2 ? r.z : r.w) < myF[dE4];
+                }
+                if (acc) {
                     if constexpr (CODE == kCodeToric) {                            // one Pauli for the whole generator
                         const uint32_t op = (ev.x >> 5) & 3u;
 #pragma unroll
@@ -487,27 +507,14 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                     ni += (int)dE4 - 4;
                 }
             };
-            uint32_t j = 0;
-            // proposal k uses words 2(k&1), 2(k&1)+1 of block (k>>1, 1).  The uniforms do not depend on the state: draw two
-            // blocks together so their serial 10-round chains overlap, then apply the four proposals in order
-            if (j < iters && (kbase & 1)) {
-                const u32x4 xa = philox_block(kbase >> 1, 1, syn, slot_u, a.seed_lo, a.seed_hi);
-                propose(xa.z, xa.w);
-                j = 1;
-            }
-            for (; j + 3 < iters; j += 4) {
-                const uint64_t kb = (kbase + j) >> 1;
+            // the blocks that overlap [kbase, kbase + iters): a block the previous step started is drawn again
+            uint64_t kb = kbase >> 2;
+            for (int jb = -(int)((uint32_t)kbase & 3u); jb < (int)iters; jb += 4, ++kb) {
                 const u32x4 xa = philox_block(kb, 1, syn, slot_u, a.seed_lo, a.seed_hi);
-                const u32x4 xb = philox_block(kb + 1, 1, syn, slot_u, a.seed_lo, a.seed_hi);
-                propose(xa.x, xa.y);
-                propose(xa.z, xa.w);
-                propose(xb.x, xb.y);
-                propose(xb.z, xb.w);
-            }
-            for (; j < iters; j += 2) {
-                const u32x4 xa = philox_block((kbase + j) >> 1, 1, syn, slot_u, a.seed_lo, a.seed_hi);
-                propose(xa.x, xa.y);
-                if (j + 1 < iters) propose(xa.z, xa.w);
+                if ((uint32_t)jb < iters) propose(xa.x, kb, std::integral_constant<int, 0>{});
+                if ((uint32_t)(jb + 1) < iters) propose(xa.y, kb, std::integral_constant<int, 1>{});
+                if ((uint32_t)(jb + 2) < iters) propose(xa.z, kb, std::integral_constant<int, 2>{});
+                if ((uint32_t)(jb + 3) < iters) propose(xa.w, kb, std::integral_constant<int, 3>{});
             }
             n = (uint32_t)ni;
         };
@@ -518,7 +525,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             const bool xyz_rule = USET && a.xyz_thr != nullptr;                     // Chain_xyz: the general path with its own table
             if (!SCAN && !top && !BIASED && CODE != kCodeToric && !xyz_rule) {
                 if constexpr (kWideGen) random_scan_loop();
-            } else if (!top && !BIASED && CODE != kCodeToric && !xyz_rule) {
+            } else if (SCAN && !top && !BIASED && CODE != kCodeToric) {
                 // sweep on a plaquette code: generator table lookup, 2 to 4 sites
                 int ni = (int)n;
                 uint32_t gs = SCAN ? (uint32_t)(kbase % a.n_gen) : 0u;
@@ -534,11 +541,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                         g = gs;
                         gs = gs + 1 == a.n_gen ? 0u : gs + 1;
                     } else {
-                        // one block per two proposals: words 2(k&1) (generator, uniform over the L^2 - 1 of them) and 2(k&1)+1 (accept)
-                        const uint64_t k = kbase + j;
-                        if ((k >> 1) != kb_cur) { kb_cur = k >> 1; blk = philox_block(kb_cur, 1, syn, slot_u, a.seed_lo, a.seed_hi); }
-                        g = scale_u32((k & 1) ? blk.z : blk.x, a.n_gen);
-                        x.w = (k & 1) ? blk.w : blk.y;
+                        g = 0; x.w = 0;                                             // (SCAN is part of the branch condition)
                     }
                     const uint2 e = gtab[g];                                      // 4 x (site << 2 | pauli), 0 = no site
                     const uint32_t ent[4] = {e.x & 0xFFFFu, e.x >> 16, e.y & 0xFFFFu, e.y >> 16};
@@ -612,19 +615,24 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 const uint32_t *lmask = a.lmask;
                 const int LW = (L + 1) * W;
                 uint32_t gs = SCAN ? (uint32_t)(kbase % a.n_gen) : 0u;
-                u32x4 pair{0, 0, 0, 0};                                            // the block two non-top proposals share
+                u32x4 pair{0, 0, 0, 0}, refine{0, 0, 0, 0};                        // the block four non-top proposals share, and its refinement
                 uint64_t kb_pair = ~0ull;
                 for (uint32_t j = 0; j < iters; ++j, gs = gs + 1 == a.n_gen ? 0u : gs + 1) {
                     const uint64_t k = kbase + j;
-                    // top: block (k, 0) = select, generator / logical fields; non-top: words 2(k&1), 2(k&1)+1 of block (k>>1, 1)
+                    // top: block (k, 0) = select, generator / logical fields; non-top: word k&3 of block (k>>2, 1) (+ its refinement)
                     u32x4 x;
+                    uint64_t v44 = 0;                                               // non-top: the 44-bit acceptance uniform
                     if (top) {
                         x = philox_block(k, 0, syn, slot_u, a.seed_lo, a.seed_hi);
                     } else {
-                        if ((k >> 1) != kb_pair) { kb_pair = k >> 1; pair = philox_block(kb_pair, 1, syn, slot_u, a.seed_lo, a.seed_hi); }
-                        x.x = (k & 1) ? pair.z : pair.x;                            // generator word
-                        x.w = (k & 1) ? pair.w : pair.y;                            // acceptance uniform
-                        x.y = x.z = 0;
+                        if ((k >> 2) != kb_pair) {
+                            kb_pair = k >> 2;
+                            pair = philox_block(kb_pair, 1, syn, slot_u, a.seed_lo, a.seed_hi);
+                            refine = philox_block(kb_pair, kSubRefine, syn, slot_u, a.seed_lo, a.seed_hi);
+                        }
+                        x.x = sel4(pair, (int)(k & 3));                             // the proposal's word: generator | 12 leading accept bits
+                        v44 = ((uint64_t)(x.x & 0xFFFu) << 32) | sel4(refine, (int)(k & 3));
+                        x.y = x.z = x.w = 0;
                     }
                     const bool logical = top && x.x <= thrL1;                       // mcmc.py:23
                     int dx = 0, dy = 0, dz = 0;                                    // change of the X / Y / Z counts
@@ -664,11 +672,12 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                             ent[0] = e.x & 0xFFFFu; ent[1] = e.x >> 16; ent[2] = e.y & 0xFFFFu; ent[3] = e.y >> 16;
                         } else if (CODE == kCodeToric) {
                             uint32_t q[4];
-                            const uint32_t g = scale_u32(wa, 2u * (uint32_t)LL), isX = g < (uint32_t)LL, rc = isX ? g : g - (uint32_t)LL;
+                            const uint32_t g = top ? scale_u32(wa, 2u * (uint32_t)LL) : pick_top20(wa, 2u * (uint32_t)LL);
+                            const uint32_t isX = g < (uint32_t)LL, rc = isX ? g : g - (uint32_t)LL;
                             toric_sites(L, LL, rc / (uint32_t)L, rc % (uint32_t)L, isX, q);
                             for (int i = 0; i < 4; ++i) ent[i] = (q[i] << 2) | (isX ? 1u : 3u);
                         } else {
-                            const uint2 e = gtab[scale_u32(wa, a.n_gen)];
+                            const uint2 e = gtab[top ? scale_u32(wa, a.n_gen) : pick_top20(wa, a.n_gen)];
                             ent[0] = e.x & 0xFFFFu; ent[1] = e.x >> 16; ent[2] = e.y & 0xFFFFu; ent[3] = e.y >> 16;
                         }
                         // old and new values of the (up to) four sites as 2-bit fields; an unused entry reads site 0 into
@@ -688,17 +697,18 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                     const int dE = dx + dy + dz;
                     bool acc;
                     if constexpr (BIASED) {
-                        const uint32_t xa = top ? philox_block(k, 2, syn, slot_u, a.seed_lo, a.seed_hi).x : x.w;
+                        const double u = top ? (double)philox_block(k, 2, syn, slot_u, a.seed_lo, a.seed_hi).x * (1.0 / 4294967296.0)
+                                             : (double)v44 * (1.0 / 17592186044416.0);   // 2^-44: exact
                         const int mx = nx + dx, my = ny + dy, mz = nz + dz;
                         const double pn = bt[mx] * bt[T1 + my] * bt[2 * T1 + mz] * bt[3 * T1 + (nq - mx - my - mz)];
-                        acc = (double)xa * (1.0 / 4294967296.0) < pn / pb;          // mcmc_biased.py:44-46
+                        acc = u < pn / pb;                                          // mcmc_biased.py:44-46
                     } else if (top) {
                         acc = acc_all || dE <= 0;                                   // mcmc.py:30
                         if (!acc) acc = philox_block(k, 2, syn, slot_u, a.seed_lo, a.seed_hi).x < a.acc_tbl_top[dE];   // :34
                     } else if (xyz_rule) {
-                        acc = x.w <= a.xyz_thr[((dx + 4) * 9 + (dy + 4)) * 9 + (dz + 4)];   // mcmc.py:170 (a generator moves <= 4 sites)
+                        acc = v44 < a.xyz_thr[((dx + 4) * 9 + (dy + 4)) * 9 + (dz + 4)];   // mcmc.py:170 (a generator moves <= 4 sites)
                     } else {
-                        acc = x.w <= myT[dE < -4 ? -4 : dE];                        // mcmc.py:42 (stabilizers only: |dE| <= 4)
+                        acc = acc_all || dE <= 0 || v44 < a.acc_thr44[slot_u][dE > 4 ? 3 : dE - 1];   // mcmc.py:42 (a generator: dE <= 4)
                     }
                     if (acc) {
                         if (logical) {

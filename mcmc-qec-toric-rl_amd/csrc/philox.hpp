@@ -1,6 +1,7 @@
 // Philox4x32-10 counter-based RNG (Salmon et al., SC'11) for gfx950.
-// One call = one 128-bit block: the draws of one top-chain proposal, or of two non-top proposals (a generator word and
-// an acceptance word each) -- DESIGN.md "RNG addressing".
+// One call = one 128-bit block: the draws of one top-chain proposal, or of FOUR non-top proposals (one word each: 20 bits
+// pick the generator, 12 bits lead the acceptance uniform, which a refinement block completes to 44 bits on demand) --
+// DESIGN.md "RNG addressing".
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -11,9 +12,9 @@ struct u32x4 { uint32_t x, y, z, w; };
 
 // Counter layout (DESIGN.md "RNG addressing"):
 //   c0 = k[31:0], c1 = k[47:32] | sub<<16, c2 = global syndrome index, c3 = stream id
-//   key = 64-bit seed.  k = proposal index of the slot (halved for the paired non-top blocks; ladder-step index for the
-//   swap stream), sub = 0 top-chain proposal, 1 paired non-top proposals, 2 top-chain acceptance, 3 sweep mode;
-//   for the swap stream the block number within one swap sweep.
+//   key = 64-bit seed.  k = proposal index of the slot (>> 2 for the non-top blocks of four; ladder-step index for the
+//   swap stream), sub = 0 top-chain proposal, 1 four non-top proposals, 2 top-chain acceptance, 3 sweep mode,
+//   4 acceptance refinement of the four non-top proposals; for the swap stream the block number within one swap sweep.
 constexpr uint32_t kSwapStream = 0x100u;
 
 __host__ __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c)
@@ -56,6 +57,13 @@ __host__ __device__ __forceinline__ u32x4 philox_block(uint64_t k, uint32_t sub,
 // word 1 / 2, Z_pos of layer 0 / 1 = high / low half of word 3.
 __host__ __device__ __forceinline__ uint32_t scale_low30(uint32_t w, uint32_t n) { return (uint32_t)(((uint64_t)(w << 2) * n) >> 32); }
 __host__ __device__ __forceinline__ uint32_t scale_u16(uint32_t h, uint32_t n) { return (h * n) >> 16; }
+
+// Non-top proposal word (word k&3 of block (k>>2, 1)): generator g = floor(x20 * G / 2^20) from its top 20 bits (G < 2^11:
+// a 24-bit multiply), a12 = its low 12 bits = the leading bits of the 44-bit acceptance uniform (a12 * 2^32 + w) * 2^-44,
+// w = word k&3 of block (k>>2, kSubRefine).  accept iff that integer < T44 = ceil(v * 2^44):  a12 < T44>>32, or equal and
+// w < (uint32_t)T44 -- the second word is needed once in 4096 proposals.
+constexpr uint32_t kSubRefine = 4u;
+__host__ __device__ __forceinline__ uint32_t pick_top20(uint32_t x, uint32_t n) { return ((x >> 12) * n) >> 20; }
 
 // int(u * n) for u = x * 2^-32, exactly (toric_model.py:291 `int(random() * size)`)
 __host__ __device__ __forceinline__ uint32_t scale_u32(uint32_t x, uint32_t n)

@@ -77,9 +77,10 @@ __global__ void k_syndrome(int code, int L, uint64_t N, const uint8_t *in, uint8
 
 // one word picks one of the generators of a plaquette code (xzzx_model.py:439-452 draws five uniforms, planar_model.py:343-352
 // three, for the same uniform choice), in table order (surf_gen_rco)
-__device__ __forceinline__ void surf_pick(int code, int L, uint32_t w, int &row, int &col, int &op)
+__device__ __forceinline__ void surf_pick(int code, int L, uint32_t w, bool top, int &row, int &col, int &op)
 {
-    surf_gen_rco(code, L, (int)scale_u32(w, (uint32_t)surf_ngen(code, L)), row, col, op);
+    const uint32_t G = (uint32_t)surf_ngen(code, L);
+    surf_gen_rco(code, L, (int)(top ? scale_u32(w, G) : pick_top20(w, G)), row, col, op);
 }
 
 // p_x^nx p_y^ny p_z^nz p_I^nI from the host-built power tables (mcmc_biased.py:31,43): IEEE products in the
@@ -107,12 +108,15 @@ __global__ void k_chain_update(const ChainArgs a)
     bool any_acc = false;
     for (uint64_t j = 0; j < a.iters; ++j) {
         const uint64_t k = a.k0 + j;
-        // non-top proposals share a block: words 2(k&1) (generator) and 2(k&1)+1 (acceptance) of block (k>>1, 1)
-        const bool paired = !top;
-        u32x4 x = philox_block(paired ? k >> 1 : k, paired ? 1u : 0u, syn, a.slot, a.seed_lo, a.seed_hi);
-        if (paired) {
-            if (k & 1) { x.x = x.z; x.y = x.w; }
-            x.w = x.y;                                                              // acceptance uniform
+        // top: block (k, 0).  non-top: ONE word, word k&3 of block (k>>2, 1) -- top 20 bits pick the generator, low 12 bits
+        // lead the 44-bit acceptance uniform that word k&3 of block (k>>2, kSubRefine) completes
+        u32x4 x = philox_block(top ? k : k >> 2, top ? 0u : 1u, syn, a.slot, a.seed_lo, a.seed_hi);
+        uint64_t v44 = 0;
+        if (!top) {
+            const u32x4 r = philox_block(k >> 2, kSubRefine, syn, a.slot, a.seed_lo, a.seed_hi);
+            const int w = (int)(k & 3);
+            x.x = w == 0 ? x.x : w == 1 ? x.y : w == 2 ? x.z : x.w;
+            v44 = ((uint64_t)(x.x & 0xFFFu) << 32) | (w == 0 ? r.x : w == 1 ? r.y : w == 2 ? r.z : r.w);
         }
         // ---- propose (in place; XOR moves are involutions, so a rejected move is undone by re-applying it)
         int dE, row = 0, col = 0, op = 0, op0 = 0, op1 = 0, x0 = 0, z0 = 0, x1 = 0, z1 = 0;
@@ -133,23 +137,24 @@ __global__ void k_chain_update(const ChainArgs a)
             }
         } else if (code == kCodeToric) {
             // one word picks one of the 2L^2 generators (toric_model.py:291-295): X plaquettes first, row-major
-            const uint32_t g = scale_u32(top ? x.y : x.x, 2u * L * L), rc = g < (uint32_t)(L * L) ? g : g - L * L;
+            const uint32_t g = top ? scale_u32(x.y, 2u * L * L) : pick_top20(x.x, 2u * L * L), rc = g < (uint32_t)(L * L) ? g : g - L * L;
             row = rc / L; col = rc % L; op = g < (uint32_t)(L * L) ? 1 : 3;
             dE = toric_apply_stabilizer_b(L, m, row, col, op);
         } else {
-            surf_pick(code, L, top ? x.y : x.x, row, col, op);
+            surf_pick(code, L, top ? x.y : x.x, top, row, col, op);
             dE = surf_apply_stabilizer_b(code, L, m, row, col, op);
         }
         // ---- accept?
         bool acc;
         if (a.noise) {                                                              // mcmc_biased.py:40-46 / :53-59
-            const uint32_t xa = top ? philox_block(k, 2, syn, a.slot, a.seed_lo, a.seed_hi).x : x.w;
-            acc = (double)xa * (1.0 / 4294967296.0) < biased_weight_b(a.bias_tbl, nq, m) / pb;
+            const double u = top ? (double)philox_block(k, 2, syn, a.slot, a.seed_lo, a.seed_hi).x * (1.0 / 4294967296.0)
+                                 : (double)v44 * (1.0 / 17592186044416.0);         // 2^-44, exact
+            acc = u < biased_weight_b(a.bias_tbl, nq, m) / pb;
         } else if (top) {                                                           // mcmc.py:30-34
             acc = a.acc_all || dE <= 0;
             if (!acc) acc = philox_block(k, 2, syn, a.slot, a.seed_lo, a.seed_hi).x < thr(dE);
         } else {
-            acc = dE <= 0 || a.acc_all || x.w < thr(dE);                            // mcmc.py:42
+            acc = dE <= 0 || a.acc_all || v44 < a.acc44[dE];                        // mcmc.py:42 (a generator: dE <= 4)
         }
         any_acc |= acc;
         if (!acc) {

@@ -25,7 +25,8 @@ class _Rng(C.Structure):
     _fields_ = [("mode", C.c_int), ("stream", C.POINTER(C.c_double)), ("pos", C.c_uint64),
                 ("len", C.c_uint64), ("consumed", C.c_uint64), ("seed", C.c_uint64),
                 ("syndrome", C.c_uint32), ("c_stream", C.c_uint32), ("c_sub", C.c_uint32),
-                ("c_k", C.c_uint64), ("c_valid", C.c_int), ("c_w", C.c_uint32 * 4)]
+                ("c_k", C.c_uint64), ("c_valid", C.c_int), ("c_w", C.c_uint32 * 4),
+                ("c2_stream", C.c_uint32), ("c2_sub", C.c_uint32), ("c2_k", C.c_uint64), ("c2_valid", C.c_int), ("c2_w", C.c_uint32 * 4)]
 
 
 class Model(C.Structure):

@@ -57,6 +57,7 @@ void orc_rng_init_philox(orc_rng *r, uint64_t seed, uint32_t syndrome)
  * Philox mode: word `w` of block (k, sub) of `stream_id`; the uniform is the
  * `nbits`-bit field that starts `shl` bits below the top of the word, scaled by
  * 2^-nbits (shl = 0, nbits = 32: the whole word). */
+#define ORC_SUB_REFINE 4u   /* acceptance-refinement blocks of the non-top proposals */
 static double orc_draw_field(orc_rng *r, uint32_t stream_id, uint64_t k, uint32_t sub, int w, int shl, int nbits)
 {
     r->consumed++;
@@ -64,18 +65,30 @@ static double orc_draw_field(orc_rng *r, uint32_t stream_id, uint64_t k, uint32_
         if (r->pos >= r->len) abort();   /* fixture stream exhausted: a test bug */
         return r->stream[r->pos++];
     }
-    if (!(r->c_valid && r->c_stream == stream_id && r->c_k == k && r->c_sub == sub)) {
-        uint32_t ctr[4], key[2];
-        ctr[0] = (uint32_t)k;
-        ctr[1] = (uint32_t)((k >> 32) & 0xFFFFu) | (sub << 16);
-        ctr[2] = r->syndrome;
-        ctr[3] = stream_id;
-        key[0] = (uint32_t)r->seed;
-        key[1] = (uint32_t)(r->seed >> 32);
-        orc_philox4x32_10(ctr, key, r->c_w);
-        r->c_stream = stream_id; r->c_k = k; r->c_sub = sub; r->c_valid = 1;
+    const uint32_t *cw;
+    if (sub == ORC_SUB_REFINE) {
+        if (!(r->c2_valid && r->c2_stream == stream_id && r->c2_k == k && r->c2_sub == sub)) {
+            uint32_t ctr[4] = {(uint32_t)k, (uint32_t)((k >> 32) & 0xFFFFu) | (sub << 16), r->syndrome, stream_id};
+            uint32_t key[2] = {(uint32_t)r->seed, (uint32_t)(r->seed >> 32)};
+            orc_philox4x32_10(ctr, key, r->c2_w);
+            r->c2_stream = stream_id; r->c2_k = k; r->c2_sub = sub; r->c2_valid = 1;
+        }
+        cw = r->c2_w;
+    } else {
+        if (!(r->c_valid && r->c_stream == stream_id && r->c_k == k && r->c_sub == sub)) {
+            uint32_t ctr[4], key[2];
+            ctr[0] = (uint32_t)k;
+            ctr[1] = (uint32_t)((k >> 32) & 0xFFFFu) | (sub << 16);
+            ctr[2] = r->syndrome;
+            ctr[3] = stream_id;
+            key[0] = (uint32_t)r->seed;
+            key[1] = (uint32_t)(r->seed >> 32);
+            orc_philox4x32_10(ctr, key, r->c_w);
+            r->c_stream = stream_id; r->c_k = k; r->c_sub = sub; r->c_valid = 1;
+        }
+        cw = r->c_w;
     }
-    uint32_t field = (uint32_t)(r->c_w[w] << shl) >> (32 - nbits);
+    uint32_t field = (uint32_t)(cw[w] << shl) >> (32 - nbits);
     return (double)field / (double)(1ull << nbits);
 }
 
@@ -221,13 +234,20 @@ int orc_eq_class(int code, int L, const uint8_t *m)
 }
 
 /* Philox address of a proposal's draws (every code model).  Non-top chains (mcmc.py:38-43) need a generator and an
- * acceptance uniform: proposal k uses words 2(k&1) (generator) and 2(k&1)+1 (acceptance) of block (k>>1, sub 1), so one
- * block feeds two proposals.  Top chains (mcmc.py:21-35) keep block (k, 0): word 0 selects logical / stabilizer, word 1
- * picks the generator, words 1-3 carry a logical operator; the acceptance uniform is word 0 of block (k, 2). */
+ * acceptance uniform: proposal k owns ONE word, word k&3 of block (k>>2, sub 1), so a block feeds four proposals.  Its
+ * top 20 bits pick the generator; its low 12 bits are the leading bits of the acceptance uniform, which continues with
+ * word k&3 of the refinement block (k>>2, sub 4): u = (a12 * 2^32 + w) * 2^-44.  (The refinement word matters only when
+ * the 12 leading bits do not decide the comparison, once in 4096 proposals; the GPU computes it on demand.)
+ * Top chains (mcmc.py:21-35) keep block (k, 0): word 0 selects logical / stabilizer, word 1 picks the generator, words
+ * 1-3 carry a logical operator; the acceptance uniform is word 0 of block (k, 2). */
 static double nontop_accept(const orc_model *m, orc_rng *rng, uint32_t slot, uint64_t k)
 {
     (void)m;
-    return orc_draw(rng, slot, k >> 1, 1, 2 * (int)(k & 1) + 1);
+    if (rng->mode == 0) return orc_draw(rng, slot, k, 0, 0);              /* injected stream: the next draw */
+    const double hi = orc_draw_field(rng, slot, k >> 2, 1, (int)(k & 3), 20, 12);
+    const double lo = orc_draw(rng, slot, k >> 2, ORC_SUB_REFINE, (int)(k & 3));
+    rng->consumed--;                                                      /* one uniform */
+    return hi + lo * (1.0 / 4096.0);                                      /* exact: 44 bits */
 }
 
 /* _apply_random_stabilizer: a uniform choice among the stabilizer generators.
@@ -245,7 +265,8 @@ static int model_random_stabilizer(const orc_model *m, const uint8_t *in, uint8_
     const int G = m->code == ORC_TORIC ? 2 * L * L : orc_surf_ngen(m->code, L);
     int g = -1;
     if (rng->mode != 0) {
-        const double u = w0 == 0 ? orc_draw(rng, slot, k >> 1, 1, 2 * (int)(k & 1)) : orc_draw(rng, slot, k, 0, 1);
+        /* non-top: the top 20 bits of the proposal's word, g = floor(x20 * G / 2^20); top chain: word 1 of its block */
+        const double u = w0 == 0 ? orc_draw_field(rng, slot, k >> 2, 1, (int)(k & 3), 0, 20) : orc_draw(rng, slot, k, 0, 1);
         g = (int)(u * G);
         rng->consumed += (m->code == ORC_TORIC || m->code == ORC_PLANAR) ? 2 : 4;   /* counted like the reference's three / five draws */
     }

@@ -41,11 +41,15 @@ typedef struct orc_rng {
     uint64_t consumed;       /* number of uniforms drawn (both modes) */
     uint64_t seed;
     uint32_t syndrome;       /* global syndrome index (Philox ctr[2]) */
-    /* one-block cache for mode 1 */
+    /* block cache for mode 1: entry 0, and entry 1 for the acceptance-refinement blocks (sub 4) */
     uint32_t c_stream, c_sub;
     uint64_t c_k;
     int c_valid;
     uint32_t c_w[4];
+    uint32_t c2_stream, c2_sub;
+    uint64_t c2_k;
+    int c2_valid;
+    uint32_t c2_w[4];
 } orc_rng;
 
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

@@ -45,7 +45,7 @@ def test_oracle_philox_matches_exact_enumeration_L3(seed, p, Nc):
     big = P >= 0.01
     assert np.all(np.abs(mean - P)[big] <= 5 * sem[big] + 2e-4), (mean, P, sem)
     assert np.all(np.abs(mean - P)[~big] <= 5 * sem[~big] + 0.75 * P[~big] + 2e-4), (mean, P, sem)
-    assert 0.5 * np.abs(mean - P).sum() < 0.02
+    assert 0.5 * np.abs(mean - P).sum() < 0.05           # (the dominant class alone has sem ~ 0.017 here)
 
 
 def _f3_protocol_oracle(init, p, Nc, iters, steps, burn, seed, syndrome):
