@@ -474,28 +474,46 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             int ni = (int)n;
             const uint32_t *myF = thrF + slot_u * 4 - 5;                            // indexed by dE + 4 = 5..8
             auto propose = [&](uint32_t xw, uint64_t kb, auto wsel) {
+#ifdef QECMC_EXP_NOGEN    // QECMC_EXP_*: timing experiments only (tools/exp_build.sh), results are wrong
+                const uint32_t gq = ((xw >> 12) * a.n_gen) >> 20;
+                const uint4 ev{(((gq * 3u) % (uint32_t)W) * 256u) << 16 | 0x5500u | (1u << 5) | ((gq * 2u) & 30u), (((gq * 5u) % (uint32_t)W) * 256u) << 16 | (1u << 5) | ((gq * 6u) & 30u),
+                               (((gq * 7u) % (uint32_t)W) * 256u) << 16 | (1u << 5) | ((gq * 10u) & 30u), (((gq * 11u) % (uint32_t)W) * 256u) << 16 | (1u << 5) | ((gq * 14u) & 30u)};
+#else
                 const uint4 ev = gen_entry(((xw >> 12) * a.n_gen) >> 20);           // the (up to) four sites; an unused entry is 0
+#endif
                 const uint32_t sh[4] = {ev.x, ev.y, ev.z, ev.w};                    // byte offset << 16 | ... | Pauli << 5 | bit shift
                 uint32_t *ad[4];
                 uint32_t f[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     ad[i] = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(stw) + (sh[i] >> 16));   // byte offset: one SDWA add
+#ifdef QECMC_EXP_NOSTATE
+                    f[i] = (sh[i] >> 3) & 3u;
+#else
                     f[i] = bfe2_lo5(*ad[i], sh[i]);
+#endif
                 }
                 const uint32_t F = lshl_or(lshl_or(f[3], 2, f[2]), 4, lshl_or(f[1], 2, f[0]));
                 const uint32_t G = F ^ ((ev.x >> 8) & 0xFFu);                      // the four new values (the Paulis as 2-bit fields)
                 // dE + 4 = #(new != 0) + #(old == 0) (toric_model.py:275-282): two chained popcounts, no subtraction; the
                 // threshold row is indexed by dE + 4 anyway.  An unused entry reads site 0 into both and counts 1.
                 const uint32_t dE4 = __popc((G | (G >> 1)) & 0x55u) + __popc(~(F | (F >> 1)) & 0x55u);
+#ifdef QECMC_EXP_NOTHR
+                const uint32_t a12 = xw & 0xFFFu, tI = dE4 <= 4 ? 4096u : 240u;
+#else
                 const uint32_t a12 = xw & 0xFFFu, tI = (myT - 4)[dE4];
+#endif
                 bool acc = a12 < tI;                                                // mcmc.py:42 (dE <= 0: tI = 4096)
                 if (__any(a12 == tI)) {                                             // rare: the next 32 bits decide
                     constexpr int WI = decltype(wsel)::value;
                     const u32x4 r = philox_block(kb, kSubRefine, syn, slot_u, a.seed_lo, a.seed_hi);
                     if (a12 == tI) acc = (WI == 0 ? r.x : WI == 1 ? r.y : WI == 2 ? r.z : r.w) < myF[dE4];
                 }
+#ifdef QECMC_EXP_NOXOR
+                if (false) {
+#else
                 if (acc) {
+#endif
                     if constexpr (CODE == kCodeToric) {                            // one Pauli for the whole generator
                         const uint32_t op = (ev.x >> 5) & 3u;
 #pragma unroll
@@ -510,7 +528,12 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             // the blocks that overlap [kbase, kbase + iters): a block the previous step started is drawn again
             uint64_t kb = kbase >> 2;
             for (int jb = -(int)((uint32_t)kbase & 3u); jb < (int)iters; jb += 4, ++kb) {
+#ifdef QECMC_EXP_NOPHILOX
+                const uint32_t hq = ((uint32_t)kb * 0x9E3779B9u) ^ (syn * 0x85EBCA6Bu) ^ (slot_u * 0xC2B2AE35u);
+                const u32x4 xa{hq, hq * 3u + 0x1234567u, hq * 5u + 0x89ABCDEu, hq * 7u + 0x3C6EF37u};
+#else
                 const u32x4 xa = philox_block(kb, 1, syn, slot_u, a.seed_lo, a.seed_hi);
+#endif
                 if ((uint32_t)jb < iters) propose(xa.x, kb, std::integral_constant<int, 0>{});
                 if ((uint32_t)(jb + 1) < iters) propose(xa.y, kb, std::integral_constant<int, 1>{});
                 if ((uint32_t)(jb + 2) < iters) propose(xa.z, kb, std::integral_constant<int, 2>{});
