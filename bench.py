@@ -240,7 +240,7 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "algorithmic bytes = 8 B/proposal + N*(nq+4*ncls) (SURVEY.md 8d); the state is "
                                  "LDS-resident so real HBM traffic is ~N*(nq+4*ncls+8) B per launch and the binding "
-                                 "resource is VALU issue (Philox), see DESIGN.md"},
+                                 "resource is instruction issue (Philox) with the LDS array close behind, see DESIGN.md"},
             "mixing": {"frac_syndromes_past_burn_in": float(np.mean(samples > 0)),
                        "mean_tops0": float(np.mean(tops0))},
         }
