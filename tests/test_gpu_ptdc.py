@@ -322,3 +322,23 @@ def test_nall_n_alpha_dropin(q, orc):
     for r in reps:
         c = q.xzzx_code(L); c.qubit_matrix = r.copy(); codes.append(c)
     assert np.allclose(q.STDC_Nall_n_alpha(codes, pz_tilde_sampling=0.2, alpha=2.0, pz_tilde=0.1, steps=600, seed=7), dist, rtol=1e-12)
+
+
+def test_unique_chain_edge_cases(q, orc):
+    """empty batch, a single step, a ragged last workgroup (ladders not a multiple of 64), refused shapes"""
+    rng = np.random.default_rng(8)
+    init = np.stack([_toric_reps(q, _rand_toric(rng, 3, 0.12)) for _ in range(5)])     # 5 x 16 x 3 droplets = 240 ladders
+    assert q.ptdc_batch(init[:0], 0.1, Nc=3, steps=10).shape == (0, 16, 19)
+    got, sd = q.ptdc_batch(init, 0.1, Nc=3, steps=1, droplets=3, seed=2, conv_mult=2.0, return_steps=True)
+    ref = orc.ptdc_batch(orc.TORIC, init, 0.1, 3, 1, droplets=3, seed=2, conv_mult=2.0)
+    assert np.array_equal(got, ref) and np.all(sd == 1) and np.all(got.sum(axis=-1) <= 3 * 3)
+    got, xyz = q.ptdc_batch(init, 0.2, Nc=2, steps=37, droplets=3, seed=4, first_syndrome=1000, with_xyz=True)
+    rh, rx = orc.ptdc_batch(orc.TORIC, init, 0.2, 2, 37, droplets=3, seed=4, first_syndrome=1000, with_xyz=True)
+    assert np.array_equal(got, rh) and _same_sets(xyz, _sorted_sets(orc, rx))
+    with pytest.raises(q.QecmcError, match="per-class sets"):
+        q.ptdc_batch(init, 0.1, Nc=3, steps=5, droplets=3, per_rung=True, with_xyz=True)
+    with pytest.raises(ValueError):
+        q.ptdc_batch(init[:, :4], 0.1, Nc=3, steps=5)
+    big = np.zeros((1, 16, 2, 23, 23), dtype=np.uint8)                                # nq = 1058: the packed counts have 10 bits each
+    with pytest.raises(q.QecmcError, match="10 bits"):
+        q.ptdc_batch(big, 0.1, Nc=2, steps=2, with_xyz=True)
