@@ -966,14 +966,28 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 const float inv = a.swap_inv_log2[i];               // 0: p_diff[i] >= 1 (coinciding rungs), every d passes
                 int d = inv == 0.0f ? nq : (int)((__log2f((float)x + 0.5f) - 32.0f) * inv);
                 d = d < 0 ? 0 : d > nq ? nq : d;
+                if (swap_fast && d + 2 < kSwapFast) {
+                    // the guess is within one of the answer: look at the four thresholds around it at once (independent LDS
+                    // reads) instead of walking the table; entries past nq are 0 and never pass
+                    const int w0 = d > 1 ? d - 1 : 1;
+                    const uint32_t *T = swapT + i * kSwapFast + w0;
+                    const int c = (int)(x < T[0]) + (int)(x < T[1]) + (int)(x < T[2]) + (int)(x < T[3]);   // a prefix passes
+                    d = w0 - 1 + c;
+                    if (c < 4 && (c > 0 || w0 == 1)) return (uint32_t)d;   // the answer lies inside the window
+                }
                 while (d < nq && below(d + 1)) ++d;
                 while (d > 0 && !below(d)) --d;
                 return (uint32_t)d;
             };
-            p[0] = swap_dmax(b.x, swb * 4);
-            if (left > 1) p[64] = swap_dmax(b.y, swb * 4 + 1);
-            if (left > 2) p[128] = swap_dmax(b.z, swb * 4 + 2);
-            if (left > 3) p[192] = swap_dmax(b.w, swb * 4 + 3);
+            // (results first, stores after: the four look-ups are independent and overlap)
+            const uint32_t r0 = swap_dmax(b.x, swb * 4);
+            const uint32_t r1 = left > 1 ? swap_dmax(b.y, swb * 4 + 1) : 0u;
+            const uint32_t r2 = left > 2 ? swap_dmax(b.z, swb * 4 + 2) : 0u;
+            const uint32_t r3 = left > 3 ? swap_dmax(b.w, swb * 4 + 3) : 0u;
+            p[0] = r0;
+            if (left > 1) p[64] = r1;
+            if (left > 2) p[128] = r2;
+            if (left > 3) p[192] = r3;
         }
 #ifndef QECMC_EXP_NOBARRIER   // QECMC_EXP_*: timing experiments only (tools/exp_build.sh), results are wrong
         __syncthreads();
