@@ -474,13 +474,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             int ni = (int)n;
             const uint32_t *myF = thrF + slot_u * 4 - 5;                            // indexed by dE + 4 = 5..8
             auto propose = [&](uint32_t xw, uint64_t kb, auto wsel) {
-#ifdef QECMC_EXP_NOGEN    // QECMC_EXP_*: timing experiments only (tools/exp_build.sh), results are wrong
-                const uint32_t gq = ((xw >> 12) * a.n_gen) >> 20;
-                const uint4 ev{(((gq * 3u) % (uint32_t)W) * 256u) << 16 | 0x5500u | (1u << 5) | ((gq * 2u) & 30u), (((gq * 5u) % (uint32_t)W) * 256u) << 16 | (1u << 5) | ((gq * 6u) & 30u),
-                               (((gq * 7u) % (uint32_t)W) * 256u) << 16 | (1u << 5) | ((gq * 10u) & 30u), (((gq * 11u) % (uint32_t)W) * 256u) << 16 | (1u << 5) | ((gq * 14u) & 30u)};
-#else
                 const uint4 ev = gen_entry(((xw >> 12) * a.n_gen) >> 20);           // the (up to) four sites; an unused entry is 0
-#endif
                 const uint32_t sh[4] = {ev.x, ev.y, ev.z, ev.w};                    // byte offset << 16 | ... | Pauli << 5 | bit shift
                 uint32_t *ad[4];
                 uint32_t f[4];
@@ -798,7 +792,11 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             }
             if constexpr (SCAN) n = (uint32_t)ni;
             else random_scan_loop();
+#ifdef QECMC_EXP_NOTOP     // QECMC_EXP_*: timing experiments only (tools/exp_build.sh), results are wrong
+        } else if (false) {
+#else
         } else if (acc_all && L <= 16) {
+#endif
             // Top chain at p = 0.75: every proposal is accepted (mcmc.py:30), so moves are blind
             // XORs and commute.  Stabilizers go straight to LDS; logical operators are collected
             // in a per-lane frame (which rows / columns carry an operator) and flushed once.
@@ -859,6 +857,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 if (j < iters) blind(philox_block(kbase + j, 0, syn, slot_u, a.seed_lo, a.seed_hi));
             }
             // flush the frame: lattice row r of layer l is the 2L-bit span at bit 2*(l*LL + r*L)
+#ifndef QECMC_EXP_NOTOPFLUSH
             {
                 uint32_t c0 = fr0 >> 16, c1 = fr1 & 0xFFFFu;       // column sets -> one 2-bit field per column
                 c0 = (c0 | (c0 << 8)) & 0x00FF00FFu; c0 = (c0 | (c0 << 4)) & 0x0F0F0F0Fu;
@@ -883,6 +882,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             }
             n = 0;
             for (int w = 0; w < W; ++w) n += nnz2(stw[w * 64]);
+#endif
             if (Lodd) cls ^= cdelta;
         } else if (SCAN && acc_all) {
             if constexpr (SCAN && GENTOP) blind_sweep_tables();                     // toric L > 16 at f = 1
@@ -948,7 +948,11 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
         uint32_t *cur = info + (t & 1) * NC * 64 + lane, *sx = swx + (t & 1) * NC * 64 + lane;
         cur[slot_u * 64] = pack_info(n, sid, cls, flag);
         const int swb = NC - 2 - (int)slot_u;                     // Philox block of swap uniforms this wave draws (if any)
+#ifdef QECMC_EXP_NOSWAPDRAW
+        if (false) {
+#else
         if (swb >= 0 && swb < 4 && swb * 4 < NC - 1) {
+#endif
             // the sweep's uniforms do not depend on the state: the slots just below the top (never the
             // heavier top slot itself) draw one Philox block each
             const u32x4 b = philox_block(a.step0 + t, (uint32_t)swb, syn, kSwapStream, a.seed_lo, a.seed_hi);

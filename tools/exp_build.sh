@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/../mcmc-qec-toric-rl_amd/csrc"
 mkdir -p ../../tools/exp_libs
-for v in ${EXP_VARIANTS:-NOCASCADE NOBARRIER NOPHILOX NOGEN NOSTATE NOTHR NOXOR}; do
+for v in ${EXP_VARIANTS:-NOCASCADE NOBARRIER NOPHILOX NOSTATE NOTHR NOXOR NOTOP NOTOPFLUSH NOSWAPDRAW}; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DQECMC_EXP_$v -shared -o ../../tools/exp_libs/libqecmc_$v.so capi.hip ladder_rs.hip primitives.hip &
 done
 wait
