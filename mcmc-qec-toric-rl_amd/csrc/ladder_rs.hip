@@ -474,7 +474,8 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             int ni = (int)n;
             const uint32_t *myF = thrF + slot_u * 4 - 5;                            // indexed by dE + 4 = 5..8
             auto propose = [&](uint32_t xw, uint64_t kb, auto wsel) {
-                const uint4 ev = gen_entry(((xw >> 12) * a.n_gen) >> 20);           // the (up to) four sites; an unused entry is 0
+                // (20-bit field x 11-bit count: a full-rate 24-bit multiply)
+                const uint4 ev = gen_entry((uint32_t)__mul24((int)(xw >> 12), (int)a.n_gen) >> 20);   // the (up to) four sites; an unused entry is 0
                 const uint32_t sh[4] = {ev.x, ev.y, ev.z, ev.w};                    // byte offset << 16 | ... | Pauli << 5 | bit shift
                 uint32_t *ad[4];
                 uint32_t f[4];
