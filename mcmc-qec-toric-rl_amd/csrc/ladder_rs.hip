@@ -499,10 +499,10 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 const uint32_t a12 = xw & 0xFFFu, tI = (myT - 4)[dE4];
 #endif
                 bool acc = a12 < tI;                                                // mcmc.py:42 (dE <= 0: tI = 4096)
-                if (__any(a12 == tI)) {                                             // rare: the next 32 bits decide
+                if (a12 == tI) {                                                    // rare (a lane in 4096): the next 32 bits decide
                     constexpr int WI = decltype(wsel)::value;
                     const u32x4 r = philox_block(kb, kSubRefine, syn, slot_u, a.seed_lo, a.seed_hi);
-                    if (a12 == tI) acc = (WI == 0 ? r.x : WI == 1 ? r.y : WI == 2 ? r.z : r.w) < myF[dE4];
+                    acc = (WI == 0 ? r.x : WI == 1 ? r.y : WI == 2 ? r.z : r.w) < myF[dE4];
                 }
 #ifdef QECMC_EXP_NOXOR
                 if (false) {
