@@ -529,10 +529,17 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
 #else
                 const u32x4 xa = philox_block(kb, 1, syn, slot_u, a.seed_lo, a.seed_hi);
 #endif
-                if ((uint32_t)jb < iters) propose(xa.x, kb, std::integral_constant<int, 0>{});
-                if ((uint32_t)(jb + 1) < iters) propose(xa.y, kb, std::integral_constant<int, 1>{});
-                if ((uint32_t)(jb + 2) < iters) propose(xa.z, kb, std::integral_constant<int, 2>{});
-                if ((uint32_t)(jb + 3) < iters) propose(xa.w, kb, std::integral_constant<int, 3>{});
+                if (jb >= 0 && jb + 4 <= (int)iters) {                             // a whole block: no per-proposal range tests
+                    propose(xa.x, kb, std::integral_constant<int, 0>{});
+                    propose(xa.y, kb, std::integral_constant<int, 1>{});
+                    propose(xa.z, kb, std::integral_constant<int, 2>{});
+                    propose(xa.w, kb, std::integral_constant<int, 3>{});
+                } else {
+                    if ((uint32_t)jb < iters) propose(xa.x, kb, std::integral_constant<int, 0>{});
+                    if ((uint32_t)(jb + 1) < iters) propose(xa.y, kb, std::integral_constant<int, 1>{});
+                    if ((uint32_t)(jb + 2) < iters) propose(xa.z, kb, std::integral_constant<int, 2>{});
+                    if ((uint32_t)(jb + 3) < iters) propose(xa.w, kb, std::integral_constant<int, 3>{});
+                }
             }
             n = (uint32_t)ni;
         };
