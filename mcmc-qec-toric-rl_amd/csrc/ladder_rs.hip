@@ -874,19 +874,33 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 c1 = (c1 | (c1 << 2)) & 0x33333333u; c1 = (c1 | (c1 << 1)) & 0x55555555u;
                 const uint32_t colpat0 = c0 * 3u;                   // Z (11) on the chosen columns of layer 0
                 const uint32_t colpat1 = c1;                        // X (01) on the chosen columns of layer 1
-                uint32_t off = 0;
-                for (int r = 0; r < L; ++r, off += rowbits) {      // layer 0: X (01) along chosen rows
-                    const uint32_t m = colpat0 ^ (((fr0 >> r) & 1u) ? (0x55555555u & rowmask) : 0u);
-                    const uint32_t wd = off >> 5, shb = off & 31u;
-                    lds_xor(stw + wd * 64, m << shb);
-                    if (shb + rowbits > 32) lds_xor(stw + (wd + 1) * 64, m >> (32 - shb));
+                // The 2L rows of the two layers are one bit stream (row rr at bit rr * rowbits): each row's pattern is appended
+                // to a 32-bit accumulator and a word goes out (one ds_xor) whenever it fills.  A row's pattern is the layer's
+                // column pattern, toggled by the row operator where the row is chosen: (mask & rowpattern) ^ colpattern in one
+                // v_bitop3, the mask being the row's frame bit sign-extended (v_bfe_i32).
+                const uint32_t rowX = 0x55555555u & rowmask;           // X (01) along a chosen row of layer 0
+                uint32_t acc = 0, fill = 0;                            // fill: bits of the accumulator in use (wave-uniform)
+                uint32_t *wp = stw;
+#define QECMC_PUT_ROW(pat_expr)                                                              \
+                {                                                                            \
+                    const uint32_t pat = (pat_expr);                                         \
+                    acc |= pat << fill;                                                      \
+                    if (fill + rowbits >= 32u) {                                             \
+                        lds_xor(wp, acc);                                                    \
+                        wp += 64;                                                            \
+                        const uint32_t rem = fill + rowbits - 32u;                           \
+                        acc = rem ? pat >> (rowbits - rem) : 0u;                             \
+                        fill = rem;                                                          \
+                    } else {                                                                 \
+                        fill += rowbits;                                                     \
+                    }                                                                        \
                 }
-                for (int r = 0; r < L; ++r, off += rowbits) {      // layer 1: Z (11) along chosen rows
-                    const uint32_t m = colpat1 ^ (((fr1 >> (16 + r)) & 1u) ? rowmask : 0u);
-                    const uint32_t wd = off >> 5, shb = off & 31u;
-                    lds_xor(stw + wd * 64, m << shb);
-                    if (shb + rowbits > 32) lds_xor(stw + (wd + 1) * 64, m >> (32 - shb));
-                }
+                for (int r = 0; r < L; ++r)                            // layer 0: Z (11) on chosen columns, X (01) along chosen rows
+                    QECMC_PUT_ROW(__builtin_amdgcn_bitop3_b32((uint32_t)__builtin_amdgcn_sbfe((int)fr0, (uint32_t)r, 1u), rowX, colpat0, 0x6A))
+                for (int r = 0; r < L; ++r)                            // layer 1: X (01) on chosen columns, Z (11) along chosen rows
+                    QECMC_PUT_ROW(__builtin_amdgcn_bitop3_b32((uint32_t)__builtin_amdgcn_sbfe((int)fr1, 16u + (uint32_t)r, 1u), rowmask, colpat1, 0x6A))
+#undef QECMC_PUT_ROW
+                if (fill) lds_xor(wp, acc);
             }
             n = 0;
             for (int w = 0; w < W; ++w) n += nnz2(stw[w * 64]);
