@@ -856,6 +856,16 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 };
                 // two proposals' Philox chains in flight: this wave is the step's longest and often runs alone
                 uint32_t j = 0;
+                for (; j + 3 < iters; j += 4) {
+                    const u32x4 xa = philox_block(kbase + j, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                    const u32x4 xb = philox_block(kbase + j + 1, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                    const u32x4 xc = philox_block(kbase + j + 2, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                    const u32x4 xd = philox_block(kbase + j + 3, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                    blind(xa);
+                    blind(xb);
+                    blind(xc);
+                    blind(xd);
+                }
                 for (; j + 1 < iters; j += 2) {
                     const u32x4 xa = philox_block(kbase + j, 0, syn, slot_u, a.seed_lo, a.seed_hi);
                     const u32x4 xb = philox_block(kbase + j + 1, 0, syn, slot_u, a.seed_lo, a.seed_hi);
