@@ -889,14 +889,18 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 // column pattern, toggled by the row operator where the row is chosen: (mask & rowpattern) ^ colpattern in one
                 // v_bitop3, the mask being the row's frame bit sign-extended (v_bfe_i32).
                 const uint32_t rowX = 0x55555555u & rowmask;           // X (01) along a chosen row of layer 0
+                // The xor returns the word it found, so the step's recount rides along: a finished word is counted while the
+                // next one is being assembled.
                 uint32_t acc = 0, fill = 0;                            // fill: bits of the accumulator in use (wave-uniform)
                 uint32_t *wp = stw;
+                uint32_t pend = 0, cnt_n = 0;                          // the last word written, not counted yet
 #define QECMC_PUT_ROW(pat_expr)                                                              \
                 {                                                                            \
                     const uint32_t pat = (pat_expr);                                         \
                     acc |= pat << fill;                                                      \
                     if (fill + rowbits >= 32u) {                                             \
-                        lds_xor(wp, acc);                                                    \
+                        cnt_n += nnz2(pend);                                                 \
+                        pend = __hip_atomic_fetch_xor(wp, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ^ acc;   \
                         wp += 64;                                                            \
                         const uint32_t rem = fill + rowbits - 32u;                           \
                         acc = rem ? pat >> (rowbits - rem) : 0u;                             \
@@ -910,10 +914,10 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 for (int r = 0; r < L; ++r)                            // layer 1: X (01) on chosen columns, Z (11) along chosen rows
                     QECMC_PUT_ROW(__builtin_amdgcn_bitop3_b32((uint32_t)__builtin_amdgcn_sbfe((int)fr1, 16u + (uint32_t)r, 1u), rowmask, colpat1, 0x6A))
 #undef QECMC_PUT_ROW
-                if (fill) lds_xor(wp, acc);
+                cnt_n += nnz2(pend);
+                if (fill) cnt_n += nnz2(__hip_atomic_fetch_xor(wp, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ^ acc);
+                n = cnt_n;
             }
-            n = 0;
-            for (int w = 0; w < W; ++w) n += nnz2(stw[w * 64]);
 #endif
             if (Lodd) cls ^= cdelta;
         } else if (SCAN && acc_all) {
