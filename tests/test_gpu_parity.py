@@ -238,3 +238,18 @@ def test_sweep_scan_bit_exact(q, orc, code, L, p, Nc, N, steps, tops_burn, iters
     assert np.array_equal(got["samples"], ref["samples"].astype(np.uint32))
     assert np.array_equal(got["counts"], ref["counts"])
     assert np.array_equal(got["states"], ref["states"])
+
+
+@pytest.mark.parametrize("L", [2, 3, 4, 6, 8, 10, 11, 13, 14, 16])
+def test_lattice_size_sweep(q, orc, L):
+    """Every lattice size the fast top-chain path takes (L <= 16): the logical frame is flushed as a stream of 2L-bit rows
+    into 32-bit words, so each L has its own pattern of word boundaries (L = 16: a row is exactly a word); ragged batch,
+    several ladder lengths, iters a multiple of 4 or not."""
+    rng = np.random.default_rng(100 + L)
+    N = 70
+    init = (rng.integers(1, 4, size=(N, 2, L, L)) * (rng.random((N, 2, L, L)) < 0.1)).astype(np.uint8)
+    for Nc, iters in ((2, 10), (5, 7), (8, 10), (8, 12)):
+        got = q.pteq_batch(init, 0.12, Nc=Nc, steps=40, iters=iters, tops_burn=0, seed=5 + L, return_states=True)
+        ref = orc.pteq_batch(orc.TORIC, init, 0.12, Nc, 40, iters=iters, tops_burn=0, seed=5 + L, return_states=True)
+        assert np.array_equal(got["states"], ref["states"]) and np.array_equal(got["counts"], ref["counts"])
+        assert np.array_equal(got["tops0"], ref["tops0"].astype(np.uint32))
