@@ -475,7 +475,9 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             const uint32_t *myF = thrF + slot_u * 4 - 5;                            // indexed by dE + 4 = 5..8
             auto propose = [&](uint32_t xw, uint64_t kb, auto wsel) {
                 // (20-bit field x 11-bit count: a full-rate 24-bit multiply)
-                const uint4 ev = gen_entry((uint32_t)__mul24((int)(xw >> 12), (int)a.n_gen) >> 20);   // the (up to) four sites; an unused entry is 0
+                uint32_t gi = (uint32_t)__mul24((int)(xw >> 12), (int)a.n_gen) >> 20;
+                asm("" : "+v"(gi));                                                 // (keeps index and address as shift + shift-add)
+                const uint4 ev = gen_entry(gi);                                     // the (up to) four sites; an unused entry is 0
                 const uint32_t sh[4] = {ev.x, ev.y, ev.z, ev.w};                    // byte offset << 16 | ... | Pauli << 5 | bit shift
                 uint32_t *ad[4];
                 uint32_t f[4];
