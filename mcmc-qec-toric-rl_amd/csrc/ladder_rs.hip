@@ -594,25 +594,34 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             } else if (SCAN && top && acc_all) {
                 blind_sweep_tables();
             } else if (!BIASED && top && acc_all) {
-                // random scan, top chain at f = 1 (mcmc.py:30): every proposal is applied blindly, n recounted once
-                uint32_t cdelta = 0;
+                // random scan, top chain at f = 1 (mcmc.py:30): every proposal is applied blindly, n recounted once.  With a row
+                // of the lattice inside one word (L <= 16) the logical operators are collected in a per-lane frame and applied
+                // once per step, as on the toric code: xzzx -- parities of the (position-independent) anti-diagonal X and
+                // diagonal Z; rotated -- the set of X columns and of Z rows; planar -- the X rows and Z columns of layer 0.
+                uint32_t cdelta = 0, frX = 0, frZ = 0;
+                const bool framed = L <= 16;
                 for (uint32_t j = 0; j < iters; ++j) {
                     const u32x4 x = philox_block(kbase + j, 0, syn, slot_u, a.seed_lo, a.seed_hi);
                     if (x.x <= thrL1) {                                             // logical (xzzx_model.py:340-357)
                         const uint32_t op = x.y >> 30;
                         const uint32_t xp = ((op ^ (op >> 1)) & 1u) ? scale_low30(x.y, L) : 0u, zp = (op >> 1) ? scale_u16(x.w >> 16, L) : 0u;
                         const uint32_t ax = CODE == kCodeXzzx ? ((op ^ (op >> 1)) & 1u) : (op & 1u), az = op >> 1;
-                        // the operator's L + L sites, generated on the fly (per-lane positions would make the plan's mask rows
-                        // 2 W scattered global loads per proposal): xzzx -- X on the anti-diagonal, Z on the diagonal
-                        // (xzzx_model.py:291-311); rotated -- X on column X_pos, Z on row Z_pos (rotated_surface_model.py:260-280);
-                        // planar -- X on row X_pos, Z on column Z_pos of layer 0 (planar_model.py:264-268)
-                        for (uint32_t i = 0; i < (uint32_t)L; ++i) {
-                            uint32_t qx, qz;
-                            if (CODE == kCodeXzzx) { qx = i * L + ((uint32_t)L - 1u - i); qz = i * L + i; }
-                            else if (CODE == kCodeRotated) { qx = i * L + xp; qz = zp * L + i; }
-                            else { qx = xp * L + i; qz = i * L + zp; }
-                            lds_xor(stw + (qx >> 4) * 64, ax << ((qx & 15u) * 2u));
-                            lds_xor(stw + (qz >> 4) * 64, (az * 3u) << ((qz & 15u) * 2u));
+                        if (framed) {
+                            frX ^= CODE == kCodeXzzx ? ax : ax << xp;
+                            frZ ^= CODE == kCodeXzzx ? az : az << zp;
+                        } else {
+                            // the operator's L + L sites, generated on the fly (per-lane positions would make the plan's mask rows
+                            // 2 W scattered global loads per proposal): xzzx -- X on the anti-diagonal, Z on the diagonal
+                            // (xzzx_model.py:291-311); rotated -- X on column X_pos, Z on row Z_pos (rotated_surface_model.py:260-280);
+                            // planar -- X on row X_pos, Z on column Z_pos of layer 0 (planar_model.py:264-268)
+                            for (uint32_t i = 0; i < (uint32_t)L; ++i) {
+                                uint32_t qx, qz;
+                                if (CODE == kCodeXzzx) { qx = i * L + ((uint32_t)L - 1u - i); qz = i * L + i; }
+                                else if (CODE == kCodeRotated) { qx = i * L + xp; qz = zp * L + i; }
+                                else { qx = xp * L + i; qz = i * L + zp; }
+                                lds_xor(stw + (qx >> 4) * 64, ax << ((qx & 15u) * 2u));
+                                lds_xor(stw + (qz >> 4) * 64, (az * 3u) << ((qz & 15u) * 2u));
+                            }
                         }
                         cdelta ^= ax | (az << 1);
                     } else {
@@ -623,7 +632,44 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                     }
                 }
                 uint32_t cnt_n = 0;
-                for (int w = 0; w < W; ++w) cnt_n += nnz2(stw[w * 64]);
+                if (framed) {
+                    // flush the frame as one bit stream of 2L-bit rows (a returning ds_xor per word; the recount rides along)
+                    auto spread16 = [](uint32_t c) {                                // bit i -> bit 2i
+                        c = (c | (c << 8)) & 0x00FF00FFu; c = (c | (c << 4)) & 0x0F0F0F0Fu;
+                        c = (c | (c << 2)) & 0x33333333u; return (c | (c << 1)) & 0x55555555u;
+                    };
+                    const uint32_t colpat = CODE == kCodeRotated ? spread16(frX) : CODE == kCodePlanar ? spread16(frZ) * 3u : 0u;
+                    const uint32_t rowpat = CODE == kCodeRotated ? rowmask : 0x55555555u & rowmask;   // Z (11) / X (01) along a chosen row
+                    const int rowsel = (int)(CODE == kCodeRotated ? frZ : frX);
+                    const int mX = __builtin_amdgcn_sbfe((int)frX, 0u, 1u), mZ = __builtin_amdgcn_sbfe((int)frZ, 0u, 1u);   // xzzx parities as masks
+                    uint32_t acc = 0, fill = 0, pend = 0;
+                    uint32_t *wp = stw;
+                    const int nrows = CODE == kCodePlanar ? 2 * L : L;
+                    for (int r = 0; r < nrows; ++r) {
+                        uint32_t pat;
+                        if (CODE == kCodeXzzx)
+                            pat = ((uint32_t)mX & (1u << (2 * (L - 1 - r)))) ^ ((uint32_t)mZ & (3u << (2 * r)));
+                        else if (CODE == kCodePlanar && r >= L)
+                            pat = 0u;                                               // layer 1 carries no logical operator
+                        else
+                            pat = __builtin_amdgcn_bitop3_b32((uint32_t)__builtin_amdgcn_sbfe(rowsel, (uint32_t)r, 1u), rowpat, colpat, 0x6A);
+                        acc |= pat << fill;
+                        if (fill + rowbits >= 32u) {
+                            cnt_n += nnz2(pend);
+                            pend = __hip_atomic_fetch_xor(wp, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ^ acc;
+                            wp += 64;
+                            const uint32_t rem = fill + rowbits - 32u;
+                            acc = rem ? pat >> (rowbits - rem) : 0u;
+                            fill = rem;
+                        } else {
+                            fill += rowbits;
+                        }
+                    }
+                    cnt_n += nnz2(pend);
+                    if (fill) cnt_n += nnz2(__hip_atomic_fetch_xor(wp, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ^ acc);
+                } else {
+                    for (int w = 0; w < W; ++w) cnt_n += nnz2(stw[w * 64]);
+                }
                 n = cnt_n;
                 cls ^= cdelta;
             } else {
