@@ -599,7 +599,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 // once per step, as on the toric code: xzzx -- parities of the (position-independent) anti-diagonal X and
                 // diagonal Z; rotated -- the set of X columns and of Z rows; planar -- the X rows and Z columns of layer 0.
                 uint32_t cdelta = 0, frX = 0, frZ = 0;
-                const bool framed = L <= 16;
+                const bool framed = L <= 32;                                       // (a row of up to 64 bits: two words)
                 for (uint32_t j = 0; j < iters; ++j) {
                     const u32x4 x = philox_block(kbase + j, 0, syn, slot_u, a.seed_lo, a.seed_hi);
                     if (x.x <= thrL1) {                                             // logical (xzzx_model.py:340-357)
@@ -632,6 +632,53 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                     }
                 }
                 uint32_t cnt_n = 0;
+                if (framed && L > 16) {
+                    // rows of 34 .. 64 bits (rotated L = 21 is BASELINE config 5's shape): the same stream with two-word patterns
+                    auto spread16 = [](uint32_t c) {
+                        c = (c | (c << 8)) & 0x00FF00FFu; c = (c | (c << 4)) & 0x0F0F0F0Fu;
+                        c = (c | (c << 2)) & 0x33333333u; return (c | (c << 1)) & 0x55555555u;
+                    };
+                    const uint32_t hibits = rowbits - 32u;                          // 2 .. 32 bits of a row live in its second word
+                    const uint32_t rmhi = hibits >= 32u ? 0xFFFFFFFFu : (1u << hibits) - 1u;
+                    const uint32_t csrc = CODE == kCodeRotated ? frX : CODE == kCodePlanar ? frZ : 0u;
+                    const uint32_t cmul = CODE == kCodePlanar ? 3u : 1u;
+                    const uint32_t cplo = spread16(csrc & 0xFFFFu) * cmul, cphi = spread16(csrc >> 16) * cmul;
+                    const uint32_t rplo = CODE == kCodeRotated ? 0xFFFFFFFFu : 0x55555555u, rphi = (CODE == kCodeRotated ? 0xFFFFFFFFu : 0x55555555u) & rmhi;
+                    const int rowsel = (int)(CODE == kCodeRotated ? frZ : frX);
+                    const uint32_t mX = (uint32_t)__builtin_amdgcn_sbfe((int)frX, 0u, 1u), mZ = (uint32_t)__builtin_amdgcn_sbfe((int)frZ, 0u, 1u);
+                    uint32_t acc = 0, fill = 0;
+                    uint32_t *wp = stw;
+                    const int nrows = CODE == kCodePlanar ? 2 * L : L;
+                    for (int r = 0; r < nrows; ++r) {
+                        uint32_t plo, phi;
+                        if (CODE == kCodeXzzx) {
+                            const uint64_t cx = 1ull << (2 * (L - 1 - r)), cz = 3ull << (2 * r);        // wave-uniform
+                            plo = (mX & (uint32_t)cx) ^ (mZ & (uint32_t)cz);
+                            phi = (mX & (uint32_t)(cx >> 32)) ^ (mZ & (uint32_t)(cz >> 32));
+                        } else if (CODE == kCodePlanar && r >= L) {
+                            plo = phi = 0u;
+                        } else {
+                            const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe(rowsel, (uint32_t)r, 1u);
+                            plo = __builtin_amdgcn_bitop3_b32(m, rplo, cplo, 0x6A);
+                            phi = __builtin_amdgcn_bitop3_b32(m, rphi, cphi, 0x6A);
+                        }
+                        // the row's 96-bit window at bit `fill`: lo | mid | hi
+                        const uint32_t lo = acc | (plo << fill);
+                        const uint32_t mid = fill ? (plo >> (32u - fill)) | (phi << fill) : phi;
+                        const uint32_t hi = fill ? phi >> (32u - fill) : 0u;
+                        const uint32_t total = fill + rowbits;                      // 34 .. 95
+                        cnt_n += nnz2(__hip_atomic_fetch_xor(wp, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ^ lo);
+                        wp += 64;
+                        if (total >= 64u) {
+                            cnt_n += nnz2(__hip_atomic_fetch_xor(wp, mid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ^ mid);
+                            wp += 64;
+                            acc = hi; fill = total - 64u;
+                        } else {
+                            acc = mid; fill = total - 32u;
+                        }
+                    }
+                    if (fill) cnt_n += nnz2(__hip_atomic_fetch_xor(wp, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ^ acc);
+                } else
                 if (framed) {
                     // flush the frame as one bit stream of 2L-bit rows (a returning ds_xor per word; the recount rides along)
                     auto spread16 = [](uint32_t c) {                                // bit i -> bit 2i

@@ -179,3 +179,24 @@ def test_generate_random_error_draw_order(q, name):
         want[1, -1, :] = 0
         want[1, :, -1] = 0
     assert np.array_equal(code.qubit_matrix, want) and code.qubit_matrix.dtype == np.uint8
+
+
+@pytest.mark.parametrize("name,L", [("xzzx", 3), ("xzzx", 9), ("xzzx", 15), ("xzzx", 17), ("xzzx", 21), ("xzzx", 31),
+                                    ("rotated", 5), ("rotated", 9), ("rotated", 15), ("rotated", 17), ("rotated", 21), ("rotated", 27),
+                                    ("planar", 3), ("planar", 4), ("planar", 9), ("planar", 16), ("planar", 17), ("planar", 20)])
+def test_plaquette_code_size_sweep(q, orc, name, L):
+    """The top chain of the plaquette codes collects its logical operators in a frame and flushes it as a stream of 2L-bit
+    rows: one-word rows up to L = 16, two-word rows up to L = 32 (rotated L = 21 is BASELINE config 5's shape)."""
+    cg, co = {"xzzx": (q.XZZX, orc.XZZX), "rotated": (q.ROTATED, orc.ROTATED), "planar": (q.PLANAR, orc.PLANAR)}[name]
+    rng = np.random.default_rng(7 * L + len(name))
+    N = 40
+    shape = (N, 2, L, L) if name == "planar" else (N, L, L)
+    init = (rng.integers(1, 4, size=shape) * (rng.random(shape) < 0.1)).astype(np.uint8)
+    if name == "planar":
+        init[:, 1, -1, :] = 0
+        init[:, 1, :, -1] = 0
+    Nc = 4 if L > 20 else 5
+    got = q.pteq_batch(init, 0.12, Nc=Nc, steps=30, iters=10, tops_burn=0, seed=5 + L, code=cg, return_states=True)
+    ref = orc.pteq_batch(co, init, 0.12, Nc, 30, iters=10, tops_burn=0, seed=5 + L, return_states=True)
+    assert np.array_equal(got["states"], ref["states"]) and np.array_equal(got["counts"], ref["counts"])
+    assert np.array_equal(got["tops0"], ref["tops0"].astype(np.uint32))
