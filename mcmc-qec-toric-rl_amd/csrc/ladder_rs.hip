@@ -624,6 +624,12 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                             }
                         }
                         cdelta ^= ax | (az << 1);
+                    } else if constexpr (kWideGen) {
+                        const uint4 ev = gen_entry(scale_u32(x.y, a.n_gen));        // word 1 picks the generator; the expanded entry
+                        const uint32_t e4[4] = {ev.x, ev.y, ev.z, ev.w};            // gives address and shift directly (a null site is 0)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            lds_xor(reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(stw) + (e4[i] >> 16)), shl_lo5((e4[i] >> 5) & 3u, e4[i]));
                     } else {
                         const uint2 e = gtab[scale_u32(x.y, a.n_gen)];              // word 1 picks the generator
                         const uint32_t ent[4] = {e.x & 0xFFFFu, e.x >> 16, e.y & 0xFFFFu, e.y >> 16};
