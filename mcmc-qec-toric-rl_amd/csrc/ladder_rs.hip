@@ -741,7 +741,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 const uint32_t *lmask = a.lmask;
                 const int LW = (L + 1) * W;
                 uint32_t gs = SCAN ? (uint32_t)(kbase % a.n_gen) : 0u;
-                u32x4 pair{0, 0, 0, 0}, refine{0, 0, 0, 0};                        // the block four non-top proposals share, and its refinement
+                u32x4 pair{0, 0, 0, 0};                                            // the block four non-top proposals share
                 uint64_t kb_pair = ~0ull;
                 for (uint32_t j = 0; j < iters; ++j, gs = gs + 1 == a.n_gen ? 0u : gs + 1) {
                     const uint64_t k = kbase + j;
@@ -754,10 +754,9 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                         if ((k >> 2) != kb_pair) {
                             kb_pair = k >> 2;
                             pair = philox_block(kb_pair, 1, syn, slot_u, a.seed_lo, a.seed_hi);
-                            refine = philox_block(kb_pair, kSubRefine, syn, slot_u, a.seed_lo, a.seed_hi);
                         }
                         x.x = sel4(pair, (int)(k & 3));                             // the proposal's word: generator | 12 leading accept bits
-                        v44 = ((uint64_t)(x.x & 0xFFFu) << 32) | sel4(refine, (int)(k & 3));
+                        v44 = (uint64_t)(x.x & 0xFFFu) << 32;                       // ... the low 32 bits are drawn only when they decide
                         x.y = x.z = x.w = 0;
                     }
                     const bool logical = top && x.x <= thrL1;                       // mcmc.py:23
@@ -822,19 +821,30 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                     }
                     const int dE = dx + dy + dz;
                     bool acc;
+                    // non-top: u = (v44 + w) 2^-44 with w the proposal's word of the refinement block, needed only when the 12
+                    // leading bits do not decide (u lies in [v44, v44 + 2^32) 2^-44): drawn by the lanes that tie
+                    auto refinement = [&]() { return (uint64_t)sel4(philox_block(k >> 2, kSubRefine, syn, slot_u, a.seed_lo, a.seed_hi), (int)(k & 3)); };
                     if constexpr (BIASED) {
-                        const double u = top ? (double)philox_block(k, 2, syn, slot_u, a.seed_lo, a.seed_hi).x * (1.0 / 4294967296.0)
-                                             : (double)v44 * (1.0 / 17592186044416.0);   // 2^-44: exact
                         const int mx = nx + dx, my = ny + dy, mz = nz + dz;
                         const double pn = bt[mx] * bt[T1 + my] * bt[2 * T1 + mz] * bt[3 * T1 + (nq - mx - my - mz)];
-                        acc = u < pn / pb;                                          // mcmc_biased.py:44-46
+                        const double ratio = pn / pb;                               // mcmc_biased.py:44-46
+                        if (top) {
+                            acc = (double)philox_block(k, 2, syn, slot_u, a.seed_lo, a.seed_hi).x * (1.0 / 4294967296.0) < ratio;
+                        } else {
+                            const double ulo = (double)v44 * (1.0 / 17592186044416.0);   // 2^-44: exact
+                            acc = ulo + (1.0 / 4096.0) <= ratio;                    // every continuation of the 12 bits is below the ratio
+                            if (!acc && ulo < ratio) acc = (double)(v44 | refinement()) * (1.0 / 17592186044416.0) < ratio;
+                        }
                     } else if (top) {
                         acc = acc_all || dE <= 0;                                   // mcmc.py:30
                         if (!acc) acc = philox_block(k, 2, syn, slot_u, a.seed_lo, a.seed_hi).x < a.acc_tbl_top[dE];   // :34
-                    } else if (xyz_rule) {
-                        acc = v44 < a.xyz_thr[((dx + 4) * 9 + (dy + 4)) * 9 + (dz + 4)];   // mcmc.py:170 (a generator moves <= 4 sites)
                     } else {
-                        acc = acc_all || dE <= 0 || v44 < a.acc_thr44[slot_u][dE > 4 ? 3 : dE - 1];   // mcmc.py:42 (a generator: dE <= 4)
+                        // mcmc.py:170 (Chain_xyz: a generator moves <= 4 sites) / mcmc.py:42 (a generator: dE <= 4)
+                        const bool always = !xyz_rule && (acc_all || dE <= 0);
+                        const uint64_t T = xyz_rule ? a.xyz_thr[((dx + 4) * 9 + (dy + 4)) * 9 + (dz + 4)]
+                                                    : a.acc_thr44[slot_u][dE > 4 ? 3 : dE < 1 ? 0 : dE - 1];
+                        acc = always || v44 + 0x100000000ull <= T;
+                        if (!acc && v44 < T) acc = (v44 | refinement()) < T;
                     }
                     if (acc) {
                         if (logical) {
