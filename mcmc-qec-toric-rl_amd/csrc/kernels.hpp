@@ -88,8 +88,8 @@ inline int ladder_gen_dwords(int code, int noise, int scan, uint32_t n_gen, int 
 {
     // depolarizing random scan: the expanded table of the non-top proposal loop; the plaquette codes also keep the plan's
     // form for their top-chain / general paths
-    const bool wide = !noise && !scan;
-    const int wide_dw = (int)n_gen <= kGenSplit ? 2 * (kGenSplit + (int)n_gen) : 4 * (int)n_gen;
+    const bool wide = !scan;                                   // (biased / alpha kernels: unsplit, next to the plan's form)
+    const int wide_dw = (!noise && (int)n_gen <= kGenSplit) ? 2 * (kGenSplit + (int)n_gen) : 4 * (int)n_gen;
     int d = wide ? (code == 0 ? wide_dw : ((2 * (int)n_gen + 3) & ~3) + wide_dw) : 2 * (int)n_gen;
     if (noise == 2) d = ((d + 3) & ~3) + 2 * Nc * 64;
     if (noise && bias_lds) d = ((d + 3) & ~3) + 2 * Nc * 4 * (nq + 1);

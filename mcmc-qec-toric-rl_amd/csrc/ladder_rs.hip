@@ -230,8 +230,8 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
     // generator table in LDS: 4 x u16 per generator as the plan stores it, or -- for the toric random-scan hot path --
     // expanded to 4 x u32 (byte offset << 16 | Pauli x 0x55 << 8 | Pauli << 5 | bit shift) so a site costs one add (its high
     // half, SDWA) and one bfe
-    constexpr bool kWideGen = !BIASED && !SCAN;                // every code: the non-top random-scan loop reads the expanded table
-    constexpr bool kSplitGen = kWideGen && GSPLIT;
+    constexpr bool kWideGen = !SCAN;                           // every code and rule: the random-scan proposals read the expanded table
+    constexpr bool kSplitGen = kWideGen && GSPLIT && !BIASED;  // (GSPLIT means something else in the BIASED instantiations)
     constexpr bool kNarrowGen = !kWideGen || CODE != kCodeToric;   // the plan's form: sweep, biased rule, plaquette-code top / general paths
     const int narrow_dw = kNarrowGen ? (kWideGen ? (2 * (int)a.n_gen + 3) & ~3 : 2 * (int)a.n_gen) : 0;
     const int wide_dw = kWideGen ? (kSplitGen ? 2 * (kGenSplit + (int)a.n_gen) : 4 * (int)a.n_gen) : 0;
@@ -762,6 +762,8 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                     const bool logical = top && x.x <= thrL1;                       // mcmc.py:23
                     int dx = 0, dy = 0, dz = 0;                                    // change of the X / Y / Z counts
                     uint32_t ent[4] = {0, 0, 0, 0}, cd = 0;
+                    uint32_t *sad[4] = {stw, stw, stw, stw};                        // a stabilizer's sites: LDS word, bit shift (low 5 bits), Paulis
+                    uint32_t ssh[4] = {0, 0, 0, 0}, sops = 0;
                     const uint32_t *m0 = lmask + L * W, *m1 = m0, *m2 = m0, *m3 = m0;   // identity rows
                     if (logical) {
                         if (CODE == kCodeToric) {
@@ -801,19 +803,32 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                             const uint32_t isX = g < (uint32_t)LL, rc = isX ? g : g - (uint32_t)LL;
                             toric_sites(L, LL, rc / (uint32_t)L, rc % (uint32_t)L, isX, q);
                             for (int i = 0; i < 4; ++i) ent[i] = (q[i] << 2) | (isX ? 1u : 3u);
-                        } else {
+                        } else if constexpr (!kWideGen) {
                             const uint2 e = gtab[top ? scale_u32(wa, a.n_gen) : pick_top20(wa, a.n_gen)];
                             ent[0] = e.x & 0xFFFFu; ent[1] = e.x >> 16; ent[2] = e.y & 0xFFFFu; ent[3] = e.y >> 16;
                         }
+                        if constexpr (kWideGen && CODE != kCodeToric) {
+                            // the expanded entry gives each site's LDS address with one add and its field with one bfe
+                            const uint4 ev = gen_entry(top ? scale_u32(wa, a.n_gen) : pick_top20(wa, a.n_gen));
+                            ssh[0] = ev.x; ssh[1] = ev.y; ssh[2] = ev.z; ssh[3] = ev.w;
+                            sops = (ev.x >> 8) & 0xFFu;                             // the four Paulis as 2-bit fields (a null site: 0)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) sad[i] = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(stw) + (ssh[i] >> 16));
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const uint32_t q = ent[i] >> 2;
+                                sad[i] = stw + (q >> 4) * 64;
+                                ssh[i] = (q & 15u) * 2u;
+                                sops |= (ent[i] & 3u) << (2 * i);
+                            }
+                        }
                         // old and new values of the (up to) four sites as 2-bit fields; an unused entry reads site 0 into
                         // both and cancels
-                        uint32_t F = 0, OPS = 0;
+                        uint32_t F = 0;
+                        const uint32_t OPS = sops;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const uint32_t q = ent[i] >> 2;
-                            F |= ((stw[(q >> 4) * 64] >> ((q & 15u) * 2u)) & 3u) << (2 * i);
-                            OPS |= (ent[i] & 3u) << (2 * i);
-                        }
+                        for (int i = 0; i < 4; ++i) F |= bfe2_lo5(*sad[i], ssh[i]) << (2 * i);
                         int ox = 0, oy = 0, oz = 0;
                         count_xyz(F, ox, oy, oz);
                         count_xyz(F ^ OPS, dx, dy, dz);
@@ -851,7 +866,8 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                             for (int w = 0; w < W; ++w) lds_xor(stw + w * 64, m0[w] ^ m1[w] ^ m2[w] ^ m3[w]);
                             cdelta ^= cd;
                         } else {
-                            for (int i = 0; i < 4; ++i) lds_xor(stw + (ent[i] >> 6) * 64, (ent[i] & 3u) << (((ent[i] >> 2) & 15u) * 2u));
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) lds_xor(sad[i], shl_lo5((sops >> (2 * i)) & 3u, ssh[i]));
                         }
                         nx += dx; ny += dy; nz += dz;
                         any_acc = true;
