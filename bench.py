@@ -1,20 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- MCMC sweeps/s of the PTEQ hot path on MI355X (BASELINE.json metric).
 
-A "step" is one pass of the hot path over one batch: qecmc_pteq_launch_dev on
-65 536 toric L=9 syndromes (p=0.15, Nc=8 temperatures, iters=10) for
-`--ladder-steps` ladder steps, inputs already resident in HBM.  With N GPUs
-every rank processes its own 65 536-syndrome shard (weak scaling; Philox keyed
-by the global syndrome index) and the per-class counts are gathered to rank 0
-over RCCL inside the timed region.
+A "step" is one pass of the hot path over one batch: qecmc_pteq_launch_dev on the syndromes of one of BASELINE.json's
+configurations (`--config`, default 2 = the headline: 65 536 toric L=9 syndromes, p=0.15, Nc=8 temperatures, iters=10) for
+`--ladder-steps` ladder steps, inputs already resident in HBM.  With N GPUs every rank processes its own shard of the same
+size (weak scaling; Philox keyed by the global syndrome index) and the per-class counts are gathered to rank 0 over RCCL
+inside the timed region (qecmc.sharding.PteqShard: the library's own sharded call is what is timed).
 
-Prints ONE JSON line (rank 0).  `value` = chain-sweeps/s over all ranks, a sweep
-being 2*L*L = 162 Metropolis proposals on one chain.
+    python bench.py                      1 GPU, config 2
+    python bench.py --gpus 8             starts 8 ranks itself (python -m torch.distributed.run ... bench.py --gpus 8)
+    python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8      the driver's form: ranks already exist
+    python bench.py --config 3|4|5       the other BASELINE configurations (one line each, same fields)
+
+Prints ONE JSON line (rank 0).  `value` = chain-sweeps/s over all ranks, a sweep being G Metropolis proposals on one chain,
+G = number of stabilizer generators (2 L^2 toric, L^2 - 1 xzzx / rotated).
 """
 import argparse
 import ctypes as C
+import glob
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -27,14 +33,24 @@ sys.path.insert(0, os.path.join(ROOT, "mcmc-qec-toric-rl_amd"))
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ALGO_BYTES_PER_PROPOSAL = 8  # 4 one-byte qubit reads + 4 writes (toric_model.py:275-278), SURVEY.md §8d
 
+# BASELINE.json `configs` (index = position in the list, 1-based; configs[0] is the reference's own CPU case)
+CONFIGS = {
+    2: dict(code="toric", L=9, p=0.15, Nc=8, syndromes=65536, eta=None, name="configs[1]: toric L=9 p=0.15, 65 536 syndromes, 8-temperature PT"),
+    3: dict(code="toric", L=15, p=0.18, Nc=8, syndromes=131072, eta=None, name="configs[2]: toric L=15 p=0.18, 1M syndromes over 8 GPUs = 131 072 per GPU"),
+    4: dict(code="xzzx", L=9, p=0.15, Nc=8, syndromes=65536, eta=100.0, name="configs[3]: XZZX L=9 biased noise eta=100 (mcmc_biased chain)"),
+    5: dict(code="rotated", L=21, p=0.17, Nc=8, syndromes=32768, eta=None, name="configs[4]: rotated L=21 p=0.17 long-chain study shape, 32 768 syndromes per GPU (2 workgroups per CU)"),
+}
 
-def synth_batch(N, L, p, seed):
+
+def synth_batch(N, L, p, seed, return_raw=False):
     """Toric_code.generate_random_error(p) (toric_model.py:15-23) followed by one
-    apply_random_logical (generate_data.py:131), vectorised over N syndromes."""
+    apply_random_logical (generate_data.py:131), vectorised over N syndromes.  return_raw: also the error chains before the
+    logical operator (their class is the decoding target, generate_data.py:121-122,139)."""
     rng = np.random.default_rng(seed)
     m = np.zeros((N, 2, L, L), dtype=np.uint8)
     err = rng.random(m.shape) < p
     m[err] = rng.integers(1, 4, size=int(err.sum()), dtype=np.uint8)
+    raw = m.copy() if return_raw else None
     ops = rng.integers(0, 4, size=(N, 2))
     xpos = rng.integers(0, L, size=(N, 2))
     zpos = rng.integers(0, L, size=(N, 2))
@@ -49,7 +65,7 @@ def synth_batch(N, L, p, seed):
             else:
                 m[idx[do_x], 1, i, xpos[do_x, 1]] ^= 1
                 m[idx[do_z], 1, zpos[do_z, 1], i] ^= 3
-    return m
+    return (m, raw) if return_raw else m
 
 
 def synth_batch_plaquette(N, L, px, py, pz, seed):
@@ -64,125 +80,198 @@ def synth_batch_plaquette(N, L, px, py, pz, seed):
     return m
 
 
-def measured_hbm_traffic(args):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN_pmc_summary.json:
-    FETCH_SIZE and WRITE_SIZE collected in separate passes around this same default bench command),
-    or None when the workload differs from the profiled one."""
-    import glob
-    if (args.scan, args.code, args.syndromes, args.L, args.Nc, args.iters, args.ladder_steps, args.p_logical) != ("random", "toric", 65536, 9, 8, 10, 2000, 0.5):
-        return None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
-    if not files:
+def make_batch(args, rank):
+    N, L = args.syndromes, args.L
+    if args.code == "toric":
+        return synth_batch(N, L, args.p, args.seed + rank)
+    if args.code == "planar":   # Planar_code.generate_random_error(p/3, p/3, p/3) (generate_data.py:66-68, planar_model.py:18-40)
+        m = np.stack([synth_batch_plaquette(N, L, args.p / 3, args.p / 3, args.p / 3, args.seed + rank + 7919 * l) for l in range(2)], axis=1)
+        m[:, 1, -1, :] = 0
+        m[:, 1, :, -1] = 0
+        return m
+    if args.eta is None:
+        return synth_batch_plaquette(N, L, args.p / 3, args.p / 3, args.p / 3, args.seed + rank)
+    return synth_batch_plaquette(N, L, args.p / (2 * (args.eta + 1)), args.p / (2 * (args.eta + 1)),
+                                 args.p * args.eta / (args.eta + 1), args.seed + rank)    # generate_data.py:78-83
+
+
+def profile_counters(args):
+    """What the committed rocprofv3 passes of this exact workload say binds the kernel (profiles/rNN_cfgC_pmc_summary.json,
+    written by tools/profile_round.sh around this same command): HBM bytes per launch and the issue / LDS utilisation.
+    None when the workload differs from the profiled one."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cfg%d_pmc_summary.json" % args.config)))
+    if not files or args.scan != "random":
         return None
     d = json.load(open(files[-1]))
-    if "FETCH_SIZE" not in d or "WRITE_SIZE" not in d:
+    w = d.get("_workload", {})
+    same = all(w.get(k) == getattr(args, k) for k in ("code", "L", "Nc", "iters", "syndromes", "ladder_steps")) and w.get("p_logical", 0.5) == args.p_logical
+    if not same or "SQ_INSTS_VALU" not in d:
         return None
-    # 1-byte-per-lane loads (64 B per wave instruction): no x2 FETCH_SIZE correction applies, see profiles/README.md
-    return (d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
+    wave_props = args.syndromes / 64 * args.Nc * args.iters * args.ladder_steps         # wave-proposals per launch
+    cyc = d.get("GRBM_GUI_ACTIVE", 0) / 8.0                                              # per-XCD active cycles of the launch
+    out = {"source": os.path.basename(files[-1]),
+           # 1-byte-per-lane loads (64 B per wave instruction): no x2 FETCH_SIZE correction applies, see profiles/README.md
+           "traffic": (d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0 if "FETCH_SIZE" in d and "WRITE_SIZE" in d else None,
+           "insts_per_wave_proposal": {"valu": d["SQ_INSTS_VALU"] / wave_props, "salu": d["SQ_INSTS_SALU"] / wave_props,
+                                       "lds": d["SQ_INSTS_LDS"] / wave_props}}
+    if cyc and "SQ_ACTIVE_INST_VALU" in d:
+        simd_cycles = cyc * 256 * 4              # SIMD-cycles of the launch: 256 CUs x 4 SIMDs
+        out["valu_busy"] = d["SQ_ACTIVE_INST_VALU"] / simd_cycles
+        out["lds_busy"] = d["SQ_LDS_IDX_ACTIVE"] / (cyc * 256)       # one LDS array per CU
+        out["lds_conflict_frac"] = d["SQ_LDS_BANK_CONFLICT"] / max(d["SQ_LDS_IDX_ACTIVE"], 1.0)
+    return out
 
 
-def cpu_baseline(init, p, Nc, iters, seed, target_s=12.0):
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def oracle_batch(args, init, steps, n_threads, first=0):
+    from oracle import oracle as orc
+    if args.code == "toric":
+        return orc.toric_pteq_batch(init, args.p, args.Nc, steps, iters=args.iters, tops_burn=2, seed=args.seed,
+                                    first_syndrome=first, n_threads=n_threads)
+    code = {"xzzx": orc.XZZX, "rotated": orc.ROTATED, "planar": orc.PLANAR}[args.code]
+    return orc.pteq_batch(code, init, args.p, args.Nc, steps, iters=args.iters, tops_burn=2, seed=args.seed, first_syndrome=first,
+                          n_threads=n_threads, noise=orc.DEPOLARIZING if args.eta is None else orc.BIASED, eta=args.eta or 0.0)
+
+
+def cpu_baseline(args, init, n_gen, target_s=12.0):
     """The oracle (CPU restatement with the reference's random-scan semantics) timed on this
     box's host cores on a bounded sample of the same workload."""
-    from oracle import oracle as orc
     cores = os.cpu_count() or 1
-    L = init.shape[2]
     n_syn = min(init.shape[0], 4 * cores)
-    orc.toric_pteq_batch(init[:n_syn], p, Nc, 200, iters=iters, tops_burn=2, seed=seed, n_threads=cores)   # spin the threads up
+    oracle_batch(args, init[:n_syn], 100, cores)                    # spin the threads up
     t0 = time.perf_counter()
-    orc.toric_pteq_batch(init[:n_syn], p, Nc, 2000, iters=iters, tops_burn=2, seed=seed, n_threads=cores)   # calibration
+    oracle_batch(args, init[:n_syn], 500, cores)                    # calibration
     dt = max(time.perf_counter() - t0, 1e-4)
-    steps = int(max(2000, min(200000, 2000 * target_s / dt)))
+    steps = int(max(500, min(200000, 500 * target_s / dt)))
     t0 = time.perf_counter()
-    orc.toric_pteq_batch(init[:n_syn], p, Nc, steps, iters=iters, tops_burn=2, seed=seed, n_threads=cores)
+    oracle_batch(args, init[:n_syn], steps, cores)
     dt = time.perf_counter() - t0
-    proposals = n_syn * Nc * iters * steps
-    return {"value": proposals / (2 * L * L) / dt, "unit": "chain-sweeps/s", "cores": cores, "kind": "port",
+    proposals = n_syn * args.Nc * args.iters * steps
+    return {"value": proposals / n_gen / dt, "unit": "chain-sweeps/s", "cores": cores, "cpu_model": cpu_model(), "kind": "port",
             "sample": f"{n_syn} syndromes x {steps} ladder steps ({proposals:.3g} proposals, {dt:.1f} s, "
-                      f"OpenMP over syndromes)",
+                      f"OpenMP over syndromes, {cores} threads)",
             "proposals_per_s": proposals / dt}
 
 
-def main():
+def spawn_ranks(n, argv):
+    """`bench.py --gpus N` outside a launcher: start N ranks (one per GPU) as children of this process, which has not
+    touched the GPU, wait, and hand their exit code on.  The same command line the driver uses."""
+    from qecmc.sharding import free_port
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--ladder-steps", type=int, default=2000, help="ladder steps per pass (decoders.py `steps`)")
-    ap.add_argument("--syndromes", type=int, default=65536, help="syndromes per GPU")
-    ap.add_argument("--L", type=int, default=9)
-    ap.add_argument("--p", type=float, default=0.15)
-    ap.add_argument("--Nc", type=int, default=8)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configuration (2 = the metric's)")
+    ap.add_argument("--ladder-steps", type=int, default=10000, help="ladder steps per pass (decoders.py `steps`; SURVEY.md 8d: 1e4 for throughput)")
+    ap.add_argument("--syndromes", type=int, default=None, help="syndromes per GPU")
+    ap.add_argument("--L", type=int, default=None)
+    ap.add_argument("--p", type=float, default=None)
+    ap.add_argument("--Nc", type=int, default=None)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--seed", type=int, default=20200915)
     ap.add_argument("--p-logical", type=float, default=0.5, help="top-chain logical rate (decoders.py:52 uses 0.5)")
-    ap.add_argument("--code", default="toric", choices=["toric", "xzzx", "rotated", "planar"], help="other codes: parity-test configs 4, 5")
+    ap.add_argument("--code", default=None, choices=["toric", "xzzx", "rotated", "planar"])
     ap.add_argument("--eta", type=float, default=None, help="bias: selects the mcmc_biased chain (config 4)")
     ap.add_argument("--scan", default="random", choices=["random", "sweep"],
                     help="random = the reference's random-scan chain; sweep = systematic generator sweep (scan=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-sweep", action="store_true", help="skip the extra scan=1 measurement (profiling runs)")
-    args = ap.parse_args()
+    ap.add_argument("--sweep", action="store_true", help="also time the scan=1 kernel on the same batch (toric, 1 GPU)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / exchange rehearsal without a GPU: gloo, no kernel, zero throughput (tests/test_bench_launcher.py)")
+    args = ap.parse_args(argv)
+    cfg = CONFIGS[args.config]
+    for k in ("code", "L", "p", "Nc", "syndromes", "eta"):
+        if getattr(args, k) is None:
+            setattr(args, k, cfg[k])
+    return args
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))               # before any GPU / torch.cuda call in this process
 
     import torch
     import torch.distributed as dist
     from qecmc import _lib as L_
+    from qecmc.sharding import PteqShard
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise RuntimeError("bench.py needs a GPU: the product has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if world != args.gpus:
+        raise RuntimeError(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)   # launched by torch.distributed.run
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)   # RCCL
-
     N, L, Nc = args.syndromes, args.L, args.Nc
     toric = args.code == "toric"
     code_id = {"toric": L_.TORIC, "xzzx": L_.XZZX, "rotated": L_.ROTATED, "planar": L_.PLANAR}[args.code]
     nq, ncls = (2 * L * L, 16) if toric else (2 * L * L if args.code == "planar" else L * L, 4)
+    n_gen = 2 * L * L if toric else 2 * L * (L - 1) if args.code == "planar" else L * L - 1     # proposals per sweep
     first = rank * N                                    # global syndrome index of this shard
-    if toric:
-        init_h = synth_batch(N, L, args.p, args.seed + rank)
-    elif args.code == "planar":       # Planar_code.generate_random_error(p/3, p/3, p/3) (generate_data.py:66-68, planar_model.py:18-40)
-        init_h = np.stack([synth_batch_plaquette(N, L, args.p / 3, args.p / 3, args.p / 3, args.seed + rank + 7919 * l) for l in range(2)], axis=1)
-        init_h[:, 1, -1, :] = 0
-        init_h[:, 1, :, -1] = 0
-    elif args.eta is None:
-        init_h = synth_batch_plaquette(N, L, args.p / 3, args.p / 3, args.p / 3, args.seed + rank)
-    else:
-        init_h = synth_batch_plaquette(N, L, args.p / (2 * (args.eta + 1)), args.p / (2 * (args.eta + 1)),
-                                       args.p * args.eta / (args.eta + 1), args.seed + rank)
-    d_init = torch.from_numpy(init_h.reshape(N, nq)).to(dev)
-    d_counts = torch.zeros((N, ncls), dtype=torch.int32, device=dev)
-    d_samples = torch.zeros(N, dtype=torch.int32, device=dev)
-    d_tops0 = torch.zeros(N, dtype=torch.int32, device=dev)
-    gathered = [torch.zeros_like(d_counts) for _ in range(world)] if (use_dist and rank == 0) else None
+    proposals_per_pass = N * Nc * args.iters * args.ladder_steps      # per GPU
+    workload = ("%s; %s L=%d p=%g%s, %d syndromes per GPU, Nc=%d parallel tempering, iters=%d, %d ladder steps per pass, scan=%s"
+                % (CONFIGS[args.config]["name"], args.code, L, args.p, "" if args.eta is None else " eta=%g" % args.eta, N, Nc,
+                   args.iters, args.ladder_steps, "random (the reference's chain)" if args.scan == "random" else "sweep"))
 
-    pr = L_.make_params(code=code_id, L=L, Nc=Nc, p=args.p, p_logical=args.p_logical, iters=args.iters,
-                        steps=args.ladder_steps, tops_burn=2, seed=args.seed, device=local_rank,
-                        noise=L_.NOISE_DEPOLARIZING if args.eta is None else L_.NOISE_BIASED, eta=args.eta or 0.0,
-                        scan=L_.SCAN_RANDOM if args.scan == "random" else L_.SCAN_CHECKERBOARD)
-    plan = C.c_void_p()
-    L_.check(L_.lib().qecmc_plan_create(pr, C.byref(plan)))
+    if args.dry_run:
+        # launcher + exchange rehearsal (CPU, gloo): every rank fills its records with a rank-dependent pattern, rank 0 checks
+        # the gather; no kernel runs and no throughput is claimed
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if use_dist:
+            dist.init_process_group("gloo")
+        rec = torch.full((N * (ncls + 2),), rank + 1, dtype=torch.int32)
+        gathered = [torch.empty_like(rec) for _ in range(world)] if (use_dist and rank == 0) else None
+        t0 = time.perf_counter()
+        for _ in range(args.warmup + args.steps):
+            if use_dist:
+                dist.gather(rec, gathered, dst=0)
+        if use_dist:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if rank == 0:
+            ok = all(int(g[0]) == r + 1 and int(g[-1]) == r + 1 for r, g in enumerate(gathered)) if use_dist else True
+            print(json.dumps({"metric": "dry run: launcher and exchange only (no kernel, no throughput)", "value": 0.0, "unit": "chain-sweeps/s",
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
+                              "data": "none (dry run)", "gather_ok": bool(ok), "config": {"workload": "dry run of: " + workload}}))
+        if use_dist:
+            dist.destroy_process_group()
+        return
+
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs a GPU: the product has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)   # RCCL
+
+    init_h = make_batch(args, rank)
+    sh = PteqShard(init_h, args.p, first, n_total=N * world, code=code_id, Nc=Nc, p_logical=args.p_logical, iters=args.iters,
+                   steps=args.ladder_steps, tops_burn=2, seed=args.seed,
+                   noise=L_.NOISE_DEPOLARIZING if args.eta is None else L_.NOISE_BIASED, eta=args.eta or 0.0,
+                   scan=L_.SCAN_RANDOM if args.scan == "random" else L_.SCAN_SWEEP)
     lds, threads, spb = C.c_uint32(), C.c_uint32(), C.c_uint32()
-    L_.check(L_.lib().qecmc_plan_info(plan, lds, threads, spb))
+    L_.check(L_.lib().qecmc_plan_info(sh.plan, lds, threads, spb))
     stream = torch.cuda.current_stream()
 
-    def one_pass():
-        L_.check(L_.lib().qecmc_pteq_launch_dev(plan, d_init.data_ptr(), N, first, d_counts.data_ptr(),
-                                                d_samples.data_ptr(), d_tops0.data_ptr(), None, None, None, None,
-                                                C.c_void_p(stream.cuda_stream)))
-
-    def exchange():
-        if use_dist:                                    # the path's one exchange step: per-class counts -> rank 0
-            dist.gather(d_counts, gathered, dst=0)
-
     for _ in range(args.warmup):
-        one_pass(); exchange()
+        sh.launch(stream); sh.gather()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -190,8 +279,8 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for a, b in ev:
-        a.record(stream); one_pass(); b.record(stream)
-        exchange()
+        a.record(stream); sh.launch(stream); b.record(stream)   # HIP events on the stream the kernel is launched on
+        sh.gather()                                             # the path's one exchange step: per-class counts -> rank 0
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -204,70 +293,84 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
-    proposals_per_pass = N * Nc * args.iters * args.ladder_steps      # per GPU
     total_proposals = proposals_per_pass * args.steps * world
-    sweeps_per_s = total_proposals / nq / elapsed
+    sweeps_per_s = total_proposals / n_gen / elapsed
 
     if rank == 0:
+        d_counts, d_samples, d_tops0 = sh.views()
         samples = d_samples.cpu().numpy()
         tops0 = d_tops0.cpu().numpy()
         k_ms = float(np.mean(kernel_ms))
         algo_bytes = proposals_per_pass * ALGO_BYTES_PER_PROPOSAL + N * (nq + 4 * ncls)
         achieved = algo_bytes / (k_ms * 1e-3) / 1e9
+        pc = profile_counters(args) or {}
+        # the host-pointer boundary (what a caller holding NumPy arrays pays): H2D of the batch + kernel + D2H of the records
+        pinned = torch.from_numpy(init_h.reshape(N, -1)).pin_memory()
+        rec_h = torch.empty_like(sh.rec, device="cpu").pin_memory()
+        incl = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            sh.d_init.copy_(pinned, non_blocking=True)
+            sh.launch(stream)
+            rec_h.copy_(sh.rec, non_blocking=True)
+            torch.cuda.synchronize()
+            incl.append((time.perf_counter() - t1) * 1e3)
         out = {
             "metric": "MCMC sweeps/sec (whole node), L=9 toric p=0.15; eq-class histogram match",
             "value": sweeps_per_s,
-            "unit": "chain-sweeps/s (1 sweep = 2*L*L = %d Metropolis proposals on one chain)" % nq,
+            "unit": "chain-sweeps/s (1 sweep = %d Metropolis proposals on one chain = one per stabilizer generator)" % n_gen,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "%s: %s L=%d p=%g%s, %d syndromes per GPU, Nc=%d parallel tempering, "
-                                   "iters=%d, %d ladder steps per pass, scan=%s"
-                                   % ("configs[1]" if (toric and L == 9) else "parity-test configuration", args.code, L, args.p,
-                                      "" if args.eta is None else " eta=%g" % args.eta, N, Nc, args.iters, args.ladder_steps,
-                                      "random (the reference's chain)" if args.scan == "random" else "sweep (systematic generator sweep)"),
-                       "syndromes_per_gpu": N, "L": L, "p": args.p, "Nc": Nc, "iters": args.iters,
+            "config": {"workload": workload, "baseline_config": args.config,
+                       "syndromes_per_gpu": N, "code": args.code, "L": L, "p": args.p, "eta": args.eta, "Nc": Nc, "iters": args.iters,
                        "ladder_steps": args.ladder_steps, "tops_burn": 2, "seed": args.seed,
                        "lds_bytes_per_workgroup": lds.value, "threads_per_workgroup": threads.value,
                        "parallelism": "syndrome shards x%d, RCCL gather of class counts" % world},
             "proposals_per_s": total_proposals / elapsed,
             "ladder_sweeps_per_s": sweeps_per_s / Nc,
             "kernel_ms_per_launch": k_ms,
+            "ms_per_step_incl_transfers": float(np.median(incl)),
+            "transfers_note": "pinned H2D of the %.1f MB batch + kernel + D2H of the %.1f MB records, 1 GPU, median of 3 (never `value`)"
+                              % (init_h.nbytes / 1e6, sh.rec.numel() * 4 / 1e6),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_hbm_traffic(args),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pc.get("traffic"),
                          "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE+WRITE_SIZE, profiles/)",
                          "algorithmic_bytes_per_launch": algo_bytes,
+                         # what actually binds (instruction issue and the LDS array), from the committed PMC passes of this workload
+                         "counters": {k: v for k, v in pc.items() if k != "traffic"} or None,
                          "note": "algorithmic bytes = 8 B/proposal + N*(nq+4*ncls) (SURVEY.md 8d); the state is "
                                  "LDS-resident so real HBM traffic is ~N*(nq+4*ncls+8) B per launch and the binding "
                                  "resource is instruction issue (Philox) with the LDS array close behind, see DESIGN.md"},
             "mixing": {"frac_syndromes_past_burn_in": float(np.mean(samples > 0)),
-                       "mean_tops0": float(np.mean(tops0))},
+                       "mean_tops0": float(np.mean(tops0)), "frac_tops0_ge_10": float(np.mean(tops0 >= 10))},
         }
-        if world == 1 and not args.no_cpu_baseline and toric and args.scan == "random":
-            out["cpu_baseline"] = cpu_baseline(init_h, args.p, Nc, args.iters, args.seed)
+        if world == 1 and not args.no_cpu_baseline and args.scan == "random":
+            out["cpu_baseline"] = cpu_baseline(args, init_h, n_gen)
             if args.p_logical == 0.5:
                 # the metric's "eq-class histogram match": the oracle (the checker, on the same Philox streams) must give the
-                # class counts the timed GPU pass left in HBM, bit for bit, on a sample of the batch
-                from oracle import oracle as orc
-                n_chk = min(N, 256)
-                ref = orc.toric_pteq_batch(init_h[:n_chk], args.p, Nc, args.ladder_steps, iters=args.iters, tops_burn=2,
-                                           seed=args.seed, n_threads=os.cpu_count() or 1)
+                # class counts the timed GPU pass left in HBM, bit for bit, on a sample of the batch (the statistical
+                # match against the reference's own sampler is tests/test_gpu_stats.py and profiles/rNN_headline_S1e5.json)
+                n_chk = min(N, 256 if args.ladder_steps <= 20000 else 64)
+                ref = oracle_batch(args, init_h[:n_chk], args.ladder_steps, os.cpu_count() or 1)
                 same = bool(np.array_equal(d_counts[:n_chk].cpu().numpy().astype(np.uint32), ref["counts"]) and
                             np.array_equal(samples[:n_chk].astype(np.uint64), ref["samples"].astype(np.uint64)))
                 out["histogram_match"] = {"syndromes_checked": n_chk, "ladder_steps": args.ladder_steps,
+                                          "syndromes_with_samples": int(np.sum(samples[:n_chk] > 0)),
                                           "class_counts_bit_identical_to_cpu_oracle": same}
-        if world == 1 and toric and args.scan == "random" and args.eta is None and not args.no_sweep:
+        if world == 1 and toric and args.scan == "random" and args.eta is None and args.sweep:
             # the library's second scan mode on the same batch, for the record (`value` above is the reference's chain)
             pr2 = L_.make_params(code=code_id, L=L, Nc=Nc, p=args.p, p_logical=args.p_logical, iters=args.iters,
                                  steps=args.ladder_steps, tops_burn=2, seed=args.seed, device=local_rank,
-                                 scan=L_.SCAN_CHECKERBOARD)
+                                 scan=L_.SCAN_SWEEP)
             plan2 = C.c_void_p()
             L_.check(L_.lib().qecmc_plan_create(pr2, C.byref(plan2)))
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             for rep in range(2):
                 e0.record(stream)
-                L_.check(L_.lib().qecmc_pteq_launch_dev(plan2, d_init.data_ptr(), N, first, d_counts.data_ptr(),
+                L_.check(L_.lib().qecmc_pteq_launch_dev(plan2, sh.d_init.data_ptr(), N, first, d_counts.data_ptr(),
                                                         d_samples.data_ptr(), d_tops0.data_ptr(), None, None, None, None,
                                                         C.c_void_p(stream.cuda_stream)))
                 e1.record(stream)
@@ -276,10 +379,10 @@ def main():
             out["sweep_scan"] = {"note": "scan=1: systematic generator sweep (not the reference's chain; same stationary law, "
                                          "validated against exact enumeration), same batch and ladder steps",
                                  "kernel_ms_per_launch": ms2, "proposals_per_s": proposals_per_pass / (ms2 * 1e-3),
-                                 "chain_sweeps_per_s": proposals_per_pass / nq / (ms2 * 1e-3)}
+                                 "chain_sweeps_per_s": proposals_per_pass / n_gen / (ms2 * 1e-3)}
             L_.lib().qecmc_plan_destroy(plan2)
         print(json.dumps(out))
-    L_.lib().qecmc_plan_destroy(plan)
+    sh.close()
     if use_dist:
         dist.destroy_process_group()
 

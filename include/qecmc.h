@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define QECMC_ABI_VERSION 2
+#define QECMC_ABI_VERSION 3
 
 typedef enum qecmc_status {
     QECMC_OK = 0,
@@ -45,7 +45,9 @@ typedef enum qecmc_status {
 } qecmc_status;
 
 typedef enum qecmc_code { QECMC_TORIC = 0, QECMC_XZZX = 1, QECMC_ROTATED = 2, QECMC_PLANAR = 3 } qecmc_code;
-typedef enum qecmc_scan { QECMC_SCAN_RANDOM = 0, QECMC_SCAN_CHECKERBOARD = 1 } qecmc_scan;
+/* SWEEP: systematic sweep over the generators in table order (proposal k tests generator k mod G); no colouring is needed
+ * because a lane owns a whole chain.  Same stationary law, not the reference's chain. */
+typedef enum qecmc_scan { QECMC_SCAN_RANDOM = 0, QECMC_SCAN_SWEEP = 1 } qecmc_scan;
 typedef enum qecmc_noise { QECMC_NOISE_DEPOLARIZING = 0, QECMC_NOISE_BIASED = 1, QECMC_NOISE_ALPHA = 2 } qecmc_noise;
 typedef enum qecmc_conv { QECMC_CONV_NONE = 0, QECMC_CONV_ERROR_BASED = 1 } qecmc_conv;
 
@@ -65,7 +67,9 @@ typedef struct qecmc_params {
     int32_t  tops_burn;     /* decoders.py:63 */
     int32_t  TOPS;          /* decoders.py:74 */
     int32_t  SEQ;           /* decoders.py:78 */
-    int32_t  reserved0;
+    int32_t  replicas;      /* 0 or 1: one ladder per syndrome.  R > 1: R independent ladders per syndrome (Philox syndrome
+                               index first_syndrome + s*R + r), class counts / samples / tops0 summed over the R ladders on the
+                               device -- the reference's "droplets" pattern (decoders.py:215-225) for small batches */
     double   eps;           /* decoders.py:102 */
     double   p;             /* bottom-chain error rate (mcmc.py:50 p_bottom); pz_tilde_bottom for alpha noise (mcmc_alpha.py:76) */
     double   eta;           /* bias (mcmc_biased.py:11); unused otherwise */
@@ -225,6 +229,26 @@ int qecmc_pteq_launch_dev(qecmc_plan *plan, const void *d_init, uint64_t N, uint
                           void *d_counts, void *d_samples, void *d_tops0 /*nullable*/,
                           void *d_steps_done /*nullable*/, void *d_converged /*nullable*/,
                           void *d_final_states /*nullable*/, void *d_workspace /*nullable*/, void *hip_stream);
+/* Optional per-syndrome equilibrium observables of the following launches of `plan` (device pointers, either nullable;
+ * NULL, NULL switches them off again):
+ *   d_swap_accepts uint32[N][Nc-1]: accepted swap tests of rung pair (i, i+1) (Ladder.step's r_flip, src/mcmc.py:96-99);
+ *   d_nerr_sums    uint32[N][Nc]:   sum over the ladder steps of count_errors() of the chain in rung c after the step's
+ *                                   swaps (what mcmc.py:88-89 reads) -- divide by steps for the time average.
+ * Both count every ladder step of the launch (no burn-in) and need nq * steps < 2^32.  Not with replicas > 1. */
+int qecmc_plan_set_stats(qecmc_plan *plan, void *d_swap_accepts, void *d_nerr_sums);
+/* Continue N ladders for params->steps more ladder steps from caller-held device state (exact continuation: Philox is
+ * addressed by step0 = ladder steps already done): d_states uint8[N][Nc][nq] slot order in/out, d_flags uint8[N][Nc] in/out,
+ * d_tops0 uint32[N] in/out; d_counts uint32[N][ncls] and d_samples uint32[N] are ADDED to (decoders.py:60-67 bookkeeping
+ * continues).  A fresh ladder is d_states[s][c] = init[s] for every rung c, d_flags[s][c] = (c == Nc-1), d_tops0[s] = 0,
+ * step0 = 0 (Ladder.__init__, mcmc.py:72-77); chunked runs then reproduce one long run bit for bit.  conv_mode must be NONE. */
+int qecmc_pteq_resume_dev(qecmc_plan *plan, void *d_states, void *d_flags, void *d_tops0, uint64_t N,
+                          uint32_t first_syndrome, uint64_t step0, void *d_counts, void *d_samples, void *hip_stream);
+/* Host-pointer qecmc_pteq_batch with the observables of qecmc_plan_set_stats (swap_accepts_out uint32[N][Nc-1],
+ * nerr_sums_out uint32[N][Nc]; either nullable). */
+int qecmc_pteq_batch_stats(const qecmc_params *params, const uint8_t *init, uint64_t N, uint32_t *counts_out,
+                           uint32_t *samples_out, uint32_t *tops0_out, uint32_t *steps_done_out,
+                           uint8_t *converged_out, uint8_t *final_states_out, uint32_t *swap_accepts_out,
+                           uint32_t *nerr_sums_out, qecmc_stats *stats_out);
 /* Bytes of dynamic LDS and threads per workgroup the plan's kernel uses (for reports). */
 int qecmc_plan_info(const qecmc_plan *plan, uint32_t *lds_bytes, uint32_t *block_threads,
                     uint32_t *syndromes_per_block);

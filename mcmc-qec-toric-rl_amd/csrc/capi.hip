@@ -215,6 +215,7 @@ struct qecmc_plan {
     LadderArgs args;
     DevBuf swap_thr, lmask, acc_top, gen, bias, lnb;
     size_t lds_bytes;
+    uint32_t *d_swap_acc = nullptr, *d_nerr_sum = nullptr;   // qecmc_plan_set_stats (caller-owned)
 };
 
 namespace {
@@ -238,12 +239,13 @@ int validate_params(const qecmc_params *p)
         if (p->code == QECMC_TORIC || p->code == QECMC_PLANAR) return fail(QECMC_ERR_UNSUPPORTED, "biased noise is built for the xzzx and rotated codes (BASELINE config 4)");
     } else if (!(p->p > 0.0) || !(p->p <= 0.75)) return fail(QECMC_ERR_INVALID, "p=%g must be in (0, 0.75]", p->p);
     if (!(p->p_logical >= 0.0) || !(p->p_logical <= 1.0)) return fail(QECMC_ERR_INVALID, "p_logical=%g must be in [0,1]", p->p_logical);
-    if (p->scan != QECMC_SCAN_RANDOM && p->scan != QECMC_SCAN_CHECKERBOARD) return fail(QECMC_ERR_INVALID, "scan mode %d unknown", p->scan);
-    if (p->scan == QECMC_SCAN_CHECKERBOARD && p->noise != QECMC_NOISE_DEPOLARIZING) return fail(QECMC_ERR_UNSUPPORTED, "the systematic sweep is built for the depolarizing rule only");
+    if (p->scan != QECMC_SCAN_RANDOM && p->scan != QECMC_SCAN_SWEEP) return fail(QECMC_ERR_INVALID, "scan mode %d unknown", p->scan);
+    if (p->scan == QECMC_SCAN_SWEEP && p->noise != QECMC_NOISE_DEPOLARIZING) return fail(QECMC_ERR_UNSUPPORTED, "the systematic sweep is built for the depolarizing rule only");
     if (p->conv_mode != QECMC_CONV_NONE && p->conv_mode != QECMC_CONV_ERROR_BASED) return fail(QECMC_ERR_INVALID, "conv_mode %d unknown", p->conv_mode);
     if (p->conv_mode == QECMC_CONV_ERROR_BASED && (p->TOPS < 0 || p->SEQ < 0 || !(p->eps >= 0))) return fail(QECMC_ERR_INVALID, "TOPS, SEQ and eps must be non-negative");
     if (p->iters == 0 || p->iters > 0xFFFFFFFFull) return fail(QECMC_ERR_INVALID, "iters out of range");
     if (p->tops_burn < 0) return fail(QECMC_ERR_INVALID, "tops_burn must be >= 0");
+    if (p->replicas < 0 || p->replicas > 65536) return fail(QECMC_ERR_INVALID, "replicas=%d out of range [0, 65536]", p->replicas);
     return 0;
 }
 
@@ -256,6 +258,7 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
     const bool alpha = p->noise == QECMC_NOISE_ALPHA;
     const bool biased = p->noise == QECMC_NOISE_BIASED || alpha;     // table-driven acceptance pn / pb
     a.code = p->code; a.noise = p->noise; a.alpha = p->alpha;
+    a.replicas = p->replicas > 1 ? (uint32_t)p->replicas : 1u;
     a.L = L; a.Nc = Nc; a.W = W; a.nq = nq; a.ncls = ncls;
     a.iters = (uint32_t)p->iters;
     a.seed_lo = (uint32_t)p->seed; a.seed_hi = (uint32_t)(p->seed >> 32);
@@ -524,6 +527,7 @@ static int ladder_step_impl(const qecmc_params *params, uint64_t N, uint8_t *sta
     qecmc_params p = *params;
     p.iters = iters;
     p.conv_mode = QECMC_CONV_NONE;
+    p.replicas = 0;
     if (int rc = validate_params(&p)) return rc;
     if (!states_inout || !flags_inout || !tops0_inout) return fail(QECMC_ERR_INVALID, "NULL buffer");
     if ((p.noise == QECMC_NOISE_ALPHA) != (neff_inout != nullptr))
@@ -603,7 +607,7 @@ int qecmc_plan_workspace_bytes(const qecmc_plan *plan, uint64_t N, uint64_t *byt
 {
     if (!plan || !bytes_out) return fail(QECMC_ERR_INVALID, "NULL argument");
     // one log entry per (ladder step, syndrome): the bottom chain's error count (u16), or for alpha noise the two counts behind n_eff (2 x u16)
-    *bytes_out = plan->prm.conv_mode == QECMC_CONV_ERROR_BASED ? (plan->prm.noise == QECMC_NOISE_ALPHA ? 4ull : 2ull) * N * plan->prm.steps : 0ull;
+    *bytes_out = plan->prm.conv_mode == QECMC_CONV_ERROR_BASED ? (plan->prm.noise == QECMC_NOISE_ALPHA ? 4ull : 2ull) * N * plan->args.replicas * plan->prm.steps : 0ull;
     return 0;
 }
 
@@ -614,10 +618,25 @@ int qecmc_pteq_launch_dev(qecmc_plan *plan, const void *d_init, uint64_t N, uint
     if (!plan) return fail(QECMC_ERR_INVALID, "plan is NULL");
     if (N == 0) return 0;
     if (!d_init || !d_counts || !d_samples) return fail(QECMC_ERR_INVALID, "NULL device buffer");
-    if (N + first_syndrome > 0xFFFFFFFFull) return fail(QECMC_ERR_INVALID, "global syndrome index exceeds 32 bits");
+    const uint64_t R = plan->args.replicas, M = N * R;              // ladders
+    if (M + first_syndrome > 0xFFFFFFFFull) return fail(QECMC_ERR_INVALID, "global ladder index (first_syndrome + N * replicas) exceeds 32 bits");
     if (plan->prm.conv_mode == QECMC_CONV_ERROR_BASED && !d_workspace)
         return fail(QECMC_ERR_INVALID, "conv_mode error_based needs the workspace of qecmc_plan_workspace_bytes()");
+    if (R > 1 && (plan->d_swap_acc || plan->d_nerr_sum)) return fail(QECMC_ERR_INVALID, "qecmc_plan_set_stats is per ladder: not with replicas > 1");
+    if ((plan->d_swap_acc || plan->d_nerr_sum) && (uint64_t)plan->args.nq * plan->prm.steps > 0xFFFFFFFFull)
+        return fail(QECMC_ERR_INVALID, "qecmc_plan_set_stats: nq * steps exceeds the 32-bit error-count sums");
+    hipStream_t strm = static_cast<hipStream_t>(hip_stream);
+    if (R > 1) {   // the R ladders of a syndrome add into its outputs
+        HIP_TRY(hipMemsetAsync(d_counts, 0, N * plan->args.ncls * 4, strm));
+        HIP_TRY(hipMemsetAsync(d_samples, 0, N * 4, strm));
+        if (d_tops0) HIP_TRY(hipMemsetAsync(d_tops0, 0, N * 4, strm));
+        if (d_steps_done) HIP_TRY(hipMemsetAsync(d_steps_done, 0, N * 4, strm));
+        if (d_converged) HIP_TRY(hipMemsetAsync(d_converged, 1, N, strm));
+    }
     LadderArgs a = plan->args;
+    a.swap_acc = plan->d_swap_acc ? plan->d_swap_acc : nullptr;
+    a.nerr_sum = plan->d_nerr_sum;
+    if (a.nerr_sum && !a.swap_acc) return fail(QECMC_ERR_INVALID, "qecmc_plan_set_stats: d_nerr_sums needs d_swap_accepts");
     a.init = static_cast<const uint8_t *>(d_init);
     a.counts = static_cast<uint32_t *>(d_counts);
     a.samples = static_cast<uint32_t *>(d_samples);
@@ -627,8 +646,41 @@ int qecmc_pteq_launch_dev(qecmc_plan *plan, const void *d_init, uint64_t N, uint
     a.nlog = static_cast<uint16_t *>(d_workspace);
     a.states = static_cast<uint8_t *>(d_final_states);
     a.write_states = d_final_states != nullptr;
-    a.N = N; a.first_syndrome = first_syndrome;
+    a.N = M; a.first_syndrome = first_syndrome;
     a.step0 = 0; a.prop0 = 0; a.nsteps = plan->prm.steps; a.resume = 0;
+    HIP_TRY(launch_ladder_rs_toric(a, strm));
+    return 0;
+}
+
+int qecmc_plan_set_stats(qecmc_plan *plan, void *d_swap_accepts, void *d_nerr_sums)
+{
+    if (!plan) return fail(QECMC_ERR_INVALID, "plan is NULL");
+    if (d_nerr_sums && !d_swap_accepts) return fail(QECMC_ERR_INVALID, "d_nerr_sums needs d_swap_accepts");
+    if (d_swap_accepts && plan->args.Nc < 2) return fail(QECMC_ERR_INVALID, "swap statistics need Nc >= 2");
+    if (d_swap_accepts && plan->lds_bytes + ladder_stats_lds_bytes(plan->args.Nc) > 160 * 1024)
+        return fail(QECMC_ERR_UNSUPPORTED, "no LDS left for the statistics counters at this L / Nc");
+    plan->d_swap_acc = static_cast<uint32_t *>(d_swap_accepts);
+    plan->d_nerr_sum = static_cast<uint32_t *>(d_nerr_sums);
+    return 0;
+}
+
+int qecmc_pteq_resume_dev(qecmc_plan *plan, void *d_states, void *d_flags, void *d_tops0, uint64_t N,
+                          uint32_t first_syndrome, uint64_t step0, void *d_counts, void *d_samples, void *hip_stream)
+{
+    if (!plan) return fail(QECMC_ERR_INVALID, "plan is NULL");
+    if (N == 0) return 0;
+    if (!d_states || !d_flags || !d_tops0) return fail(QECMC_ERR_INVALID, "NULL device buffer");
+    if ((d_counts == nullptr) != (d_samples == nullptr)) return fail(QECMC_ERR_INVALID, "d_counts and d_samples go together");
+    if (plan->prm.conv_mode != QECMC_CONV_NONE) return fail(QECMC_ERR_INVALID, "qecmc_pteq_resume_dev runs fixed-length chunks: conv_mode must be NONE");
+    if (plan->args.replicas > 1) return fail(QECMC_ERR_INVALID, "qecmc_pteq_resume_dev continues single ladders: replicas must be <= 1");
+    if (plan->args.noise == QECMC_NOISE_ALPHA) return fail(QECMC_ERR_UNSUPPORTED, "alpha-noise ladders carry n_eff: continue them with qecmc_ladder_step_alpha");
+    if (N + first_syndrome > 0xFFFFFFFFull) return fail(QECMC_ERR_INVALID, "global syndrome index exceeds 32 bits");
+    LadderArgs a = plan->args;
+    a.states = static_cast<uint8_t *>(d_states); a.flags = static_cast<uint8_t *>(d_flags); a.tops0 = static_cast<uint32_t *>(d_tops0);
+    a.counts = static_cast<uint32_t *>(d_counts); a.samples = static_cast<uint32_t *>(d_samples);
+    a.N = N; a.first_syndrome = first_syndrome;
+    a.step0 = step0; a.prop0 = step0 * plan->prm.iters; a.nsteps = plan->prm.steps;
+    a.resume = 1; a.write_states = 1; a.accumulate = 1;
     HIP_TRY(launch_ladder_rs_toric(a, static_cast<hipStream_t>(hip_stream)));
     return 0;
 }
@@ -637,13 +689,21 @@ int qecmc_pteq_batch(const qecmc_params *params, const uint8_t *init, uint64_t N
                      uint32_t *samples_out, uint32_t *tops0_out, uint32_t *steps_done_out, uint8_t *converged_out,
                      uint8_t *final_states_out, qecmc_stats *stats_out)
 {
+    return qecmc_pteq_batch_stats(params, init, N, counts_out, samples_out, tops0_out, steps_done_out, converged_out,
+                                  final_states_out, nullptr, nullptr, stats_out);
+}
+
+int qecmc_pteq_batch_stats(const qecmc_params *params, const uint8_t *init, uint64_t N, uint32_t *counts_out,
+                           uint32_t *samples_out, uint32_t *tops0_out, uint32_t *steps_done_out, uint8_t *converged_out,
+                           uint8_t *final_states_out, uint32_t *swap_accepts_out, uint32_t *nerr_sums_out, qecmc_stats *stats_out)
+{
     const auto t0 = std::chrono::steady_clock::now();
     qecmc_plan *pl = nullptr;
     if (int rc = qecmc_plan_create(params, &pl)) return rc;
     struct Guard { qecmc_plan *p; ~Guard() { delete p; } } guard{pl};
     if (N == 0) return 0;
     if (!init || !counts_out || !samples_out) return fail(QECMC_ERR_INVALID, "NULL buffer");
-    const size_t nq = pl->args.nq, Nc = pl->args.Nc, ncls = pl->args.ncls;
+    const size_t nq = pl->args.nq, Nc = pl->args.Nc, ncls = pl->args.ncls, R = pl->args.replicas;
     uint64_t ws_bytes = 0;
     qecmc_plan_workspace_bytes(pl, N, &ws_bytes);
     size_t free_b = 0, total_b = 0;
@@ -655,7 +715,13 @@ int qecmc_pteq_batch(const qecmc_params *params, const uint8_t *init, uint64_t N
     HIP_TRY(di.alloc(N * nq)); HIP_TRY(dc.alloc(N * ncls * 4)); HIP_TRY(ds.alloc(N * 4)); HIP_TRY(dt.alloc(N * 4));
     HIP_TRY(dsd.alloc(N * 4)); HIP_TRY(dcv.alloc(N));
     if (ws_bytes) HIP_TRY(dw.alloc(ws_bytes));
-    if (final_states_out) HIP_TRY(df.alloc(N * Nc * nq));
+    if (final_states_out) HIP_TRY(df.alloc(N * R * Nc * nq));
+    DevBuf dsa, dns;
+    if (swap_accepts_out || nerr_sums_out) {
+        HIP_TRY(dsa.alloc(N * (Nc > 1 ? Nc - 1 : 1) * 4));
+        if (nerr_sums_out) HIP_TRY(dns.alloc(N * Nc * 4));
+        if (int rc = qecmc_plan_set_stats(pl, dsa.p, nerr_sums_out ? dns.p : nullptr)) return rc;
+    }
     HIP_TRY(hipMemcpy(di.p, init, N * nq, hipMemcpyHostToDevice));
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
@@ -673,10 +739,12 @@ int qecmc_pteq_batch(const qecmc_params *params, const uint8_t *init, uint64_t N
     if (tops0_out) HIP_TRY(hipMemcpy(tops0_out, dt.p, N * 4, hipMemcpyDeviceToHost));
     if (steps_done_out) HIP_TRY(hipMemcpy(steps_done_out, dsd.p, N * 4, hipMemcpyDeviceToHost));
     if (converged_out) HIP_TRY(hipMemcpy(converged_out, dcv.p, N, hipMemcpyDeviceToHost));
-    if (final_states_out) HIP_TRY(hipMemcpy(final_states_out, df.p, N * Nc * nq, hipMemcpyDeviceToHost));
+    if (final_states_out) HIP_TRY(hipMemcpy(final_states_out, df.p, N * R * Nc * nq, hipMemcpyDeviceToHost));
+    if (swap_accepts_out) HIP_TRY(hipMemcpy(swap_accepts_out, dsa.p, N * (Nc - 1) * 4, hipMemcpyDeviceToHost));
+    if (nerr_sums_out) HIP_TRY(hipMemcpy(nerr_sums_out, dns.p, N * Nc * 4, hipMemcpyDeviceToHost));
     if (stats_out) {
-        stats_out->proposals = N * Nc * params->iters * params->steps;   // upper bound when the criterion stops early
-        stats_out->swap_tests = N * (Nc - 1) * params->steps;
+        stats_out->proposals = N * R * Nc * params->iters * params->steps;   // upper bound when the criterion stops early
+        stats_out->swap_tests = N * R * (Nc - 1) * params->steps;
         stats_out->kernel_ms = ms;
         stats_out->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
@@ -705,6 +773,7 @@ int qecmc_ptdc_batch_xyz(const qecmc_params *params, const uint8_t *init, uint64
     qecmc_params p = *params;
     p.p_logical = 0.0;                                   // Ladder(p_sampling, code, Nc): decoders.py:182,196
     p.conv_mode = QECMC_CONV_NONE;
+    p.replicas = 0;                                      // (droplets are this entry point's own replica dimension)
     std::vector<uint64_t> xyz_thr;
     if (p_xyz_sampling) {
         // Chain_xyz (mcmc.py:106-114): factors = p_xyz / (1 - p_xyz.sum()), accept iff u < (factors ** change).prod() (:170)

@@ -74,9 +74,17 @@ struct LadderArgs {
 #endif
     int resume;               // 0: replicate init into every slot (mcmc.py:72); 1: load states/flags/tops0
     int write_states;
+    // replicas R >= 1: a.N counts LADDERS (syndromes x R); ladder l starts from init row l / R and adds its class counts, samples
+    // and tops0 to the outputs of syndrome l / R (atomics; the caller zeroes them) -- decoders.py:215-225 "droplets"
+    uint32_t replicas;
+    int accumulate;           // counts / samples are added to (qecmc_pteq_resume_dev)
+    // equilibrium observables (qecmc_plan_set_stats; nullable): accepted swaps per rung pair, sum of error counts per rung
+    uint32_t *swap_acc;       // [N][Nc-1]
+    uint32_t *nerr_sum;       // [N][Nc]
 };
 
 size_t ladder_lds_bytes(int L, int Nc, int W, int ncls, int gen_dwords);
+inline size_t ladder_stats_lds_bytes(int Nc) { return sizeof(uint32_t) * 64u * (size_t)(2 * Nc); }   // [Nc] swap accepts (row Nc-1 idle) + [Nc] error sums
 constexpr uint32_t kMaxGenLds = 2048;   // generator tables up to this many entries are staged in LDS
 // dwords of the LDS generator table: the toric random-scan kernels expand each generator to 4 x u32
 // (byte offset << 16 | pauli fields | bit shift), the other paths keep the plan's 4 x u16 form.  Up to kGenSplit

@@ -282,6 +282,8 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
     for (int i = tid; i < NC * W * 64; i += nthreads) st[i] = 0;
     for (int i = tid; i < ncls * 64; i += nthreads) hist[i] = 0;
     if (tid == 0) *stopf = 0;
+    if (a.swap_acc != nullptr)
+        for (int i = tid; i < 2 * NC * 64; i += nthreads) lds_all[gdw + i] = 0;
     if constexpr (USET) {
         for (int i = tid; i < 3 * 64; i += nthreads) hist[i] = i < 64 ? 2u * (uint32_t)LL : 0xFFFFFFFFu;   // decoders.py:140,242; "never"
     }
@@ -325,13 +327,14 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
     __syncthreads();
 
     // ---- stage the batch: coalesced byte stream -> 2-bit fields in LDS -------------
+    const uint32_t R = a.replicas;                // ladders per syndrome (>= 1)
     if (!a.resume) {
-        const uint8_t *src = a.init + s0 * (uint64_t)nq;
+        const uint8_t *src = a.init + (R > 1 ? 0ull : s0 * (uint64_t)nq);
         const int total = cnt * nq;
         for (int o = tid; o < total; o += nthreads) {
-            const uint32_t v = src[o] & 3u;
+            const int j = o / nq, q = o - j * nq;
+            const uint32_t v = (R > 1 ? src[((s0 + (uint64_t)j) / R) * (uint64_t)nq + q] : src[o]) & 3u;   // ladder l starts from init row l / R
             if (v) {
-                const int j = o / nq, q = o - j * nq;
                 const uint32_t bits = v << ((q & 15) * 2);
                 uint32_t *p = st + (q >> 4) * 64 + j;
                 for (int s = 0; s < NC; ++s)      // Ladder.__init__ deep-copies init into every slot (mcmc.py:72)
@@ -484,33 +487,21 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     ad[i] = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(stw) + (sh[i] >> 16));   // byte offset: one SDWA add
-#ifdef QECMC_EXP_NOSTATE
-                    f[i] = (sh[i] >> 3) & 3u;
-#else
                     f[i] = bfe2_lo5(*ad[i], sh[i]);
-#endif
                 }
                 const uint32_t F = lshl_or(lshl_or(f[3], 2, f[2]), 4, lshl_or(f[1], 2, f[0]));
                 const uint32_t G = F ^ ((ev.x >> 8) & 0xFFu);                      // the four new values (the Paulis as 2-bit fields)
                 // dE + 4 = #(new != 0) + #(old == 0) (toric_model.py:275-282): two chained popcounts, no subtraction; the
                 // threshold row is indexed by dE + 4 anyway.  An unused entry reads site 0 into both and counts 1.
                 const uint32_t dE4 = __popc((G | (G >> 1)) & 0x55u) + __popc(~(F | (F >> 1)) & 0x55u);
-#ifdef QECMC_EXP_NOTHR
-                const uint32_t a12 = xw & 0xFFFu, tI = dE4 <= 4 ? 4096u : 240u;
-#else
                 const uint32_t a12 = xw & 0xFFFu, tI = (myT - 4)[dE4];
-#endif
                 bool acc = a12 < tI;                                                // mcmc.py:42 (dE <= 0: tI = 4096)
                 if (a12 == tI) {                                                    // rare (a lane in 4096): the next 32 bits decide
                     constexpr int WI = decltype(wsel)::value;
                     const u32x4 r = philox_block(kb, kSubRefine, syn, slot_u, a.seed_lo, a.seed_hi);
                     acc = (WI == 0 ? r.x : WI == 1 ? r.y : WI == 2 ? r.z : r.w) < myF[dE4];
                 }
-#ifdef QECMC_EXP_NOXOR
-                if (false) {
-#else
                 if (acc) {
-#endif
                     if constexpr (CODE == kCodeToric) {                            // one Pauli for the whole generator
                         const uint32_t op = (ev.x >> 5) & 3u;
 #pragma unroll
@@ -525,12 +516,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             // the blocks that overlap [kbase, kbase + iters): a block the previous step started is drawn again
             uint64_t kb = kbase >> 2;
             for (int jb = -(int)((uint32_t)kbase & 3u); jb < (int)iters; jb += 4, ++kb) {
-#ifdef QECMC_EXP_NOPHILOX
-                const uint32_t hq = ((uint32_t)kb * 0x9E3779B9u) ^ (syn * 0x85EBCA6Bu) ^ (slot_u * 0xC2B2AE35u);
-                const u32x4 xa{hq, hq * 3u + 0x1234567u, hq * 5u + 0x89ABCDEu, hq * 7u + 0x3C6EF37u};
-#else
                 const u32x4 xa = philox_block(kb, 1, syn, slot_u, a.seed_lo, a.seed_hi);
-#endif
                 if (jb >= 0 && jb + 4 <= (int)iters) {                             // a whole block: no per-proposal range tests
                     propose(xa.x, kb, std::integral_constant<int, 0>{});
                     propose(xa.y, kb, std::integral_constant<int, 1>{});
@@ -927,11 +913,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             }
             if constexpr (SCAN) n = (uint32_t)ni;
             else random_scan_loop();
-#ifdef QECMC_EXP_NOTOP     // QECMC_EXP_*: timing experiments only (tools/exp_build.sh), results are wrong
-        } else if (false) {
-#else
         } else if (acc_all && L <= 16) {
-#endif
             // Top chain at p = 0.75: every proposal is accepted (mcmc.py:30), so moves are blind
             // XORs and commute.  Stabilizers go straight to LDS; logical operators are collected
             // in a per-lane frame (which rows / columns carry an operator) and flushed once.
@@ -1002,7 +984,6 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 if (j < iters) blind(philox_block(kbase + j, 0, syn, slot_u, a.seed_lo, a.seed_hi));
             }
             // flush the frame: lattice row r of layer l is the 2L-bit span at bit 2*(l*LL + r*L)
-#ifndef QECMC_EXP_NOTOPFLUSH
             {
                 uint32_t c0 = fr0 >> 16, c1 = fr1 & 0xFFFFu;       // column sets -> one 2-bit field per column
                 c0 = (c0 | (c0 << 8)) & 0x00FF00FFu; c0 = (c0 | (c0 << 4)) & 0x0F0F0F0Fu;
@@ -1045,7 +1026,6 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 if (fill) cnt_n += nnz2(__hip_atomic_fetch_xor(wp, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ^ acc);
                 n = cnt_n;
             }
-#endif
             if (Lodd) cls ^= cdelta;
         } else if (SCAN && acc_all) {
             if constexpr (SCAN && GENTOP) blind_sweep_tables();                     // toric L > 16 at f = 1
@@ -1111,11 +1091,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
         uint32_t *cur = info + (t & 1) * NC * 64 + lane, *sx = swx + (t & 1) * NC * 64 + lane;
         cur[slot_u * 64] = pack_info(n, sid, cls, flag);
         const int swb = NC - 2 - (int)slot_u;                     // Philox block of swap uniforms this wave draws (if any)
-#ifdef QECMC_EXP_NOSWAPDRAW
-        if (false) {
-#else
         if (swb >= 0 && swb < 4 && swb * 4 < NC - 1) {
-#endif
             // the sweep's uniforms do not depend on the state: the slots just below the top (never the
             // heavier top slot itself) draw one Philox block each
             const u32x4 b = philox_block(a.step0 + t, (uint32_t)swb, syn, kSwapStream, a.seed_lo, a.seed_hi);
@@ -1156,9 +1132,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             if (left > 2) p[128] = r2;
             if (left > 3) p[192] = r3;
         }
-#ifndef QECMC_EXP_NOBARRIER   // QECMC_EXP_*: timing experiments only (tools/exp_build.sh), results are wrong
         __syncthreads();
-#endif
         if (CONV || USET) {                                 // flags set one step earlier: uniform for the workgroup
             volatile uint32_t *f0 = lds_all + (NC * W * 64 + 4 * NC * 64 + ncls * 64 + NC * 9 + NC * kSwapFast);
             if (f0[0]) break;
@@ -1173,7 +1147,6 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             const int i_stop = (wave_u == 0 || slot_u == 0) ? 0 : (int)slot_u - 1;
             // four rungs at a time: their records and swap bounds are fetched together, so a rung costs a few integer
             // operations instead of an LDS round trip on the serial path
-#ifndef QECMC_EXP_NOCASCADE
             for (int ib = NC - 2; ib >= i_stop; ib -= 4) {                          // mcmc.py:96
                 uint32_t lo4[4], x4[4];
 #pragma unroll
@@ -1201,15 +1174,10 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                     }
                 }
             }
-#endif
             if (slot_u == 0) mine = car;
             n = mine & 0xFFFFu; sid = (mine >> 16) & 0xFFu; cls = (mine >> 24) & 0x3Fu; flag = mine >> 31;
             if ((int)slot_u == NC - 1) flag = 1;                                    // chains[-1].flag = 1, mcmc.py:100
-#ifdef QECMC_EXP_NOBOOK
-            if (false) {
-#else
             if (wave_u == 0 && !done) {                                             // ladder + PTEQ bookkeeping on slot 0's new state
-#endif
                 tops0 += (NC == 1) | (car >> 31);                                   // chains[0].flag == 1, :101-102
                 const uint32_t n0 = car & 0xFFFFu;
                 if (a.counts != nullptr && tops0 >= a.tops_burn) {                  // decoders.py:60-67
@@ -1263,6 +1231,26 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                         conv_start = tops0;
                     }
                 }
+            }
+            if (a.swap_acc != nullptr && wave_u == 0) {
+                // equilibrium observables (qecmc_plan_set_stats): the cascade once more, with every rung's decision and the error
+                // count each rung ends the step with added to per-lane LDS counters (off the hot path: one scalar branch when off)
+                uint32_t *sacc = lds_all + gdw + lane, *nsum = sacc + NC * 64;
+                uint32_t c2 = cur[(NC - 1) * 64];
+                for (int i = NC - 2; i >= 0; --i) {
+                    const uint32_t lo = cur[i * 64], xi = sx[i * 64];
+                    bool flip = (int)(c2 & 0xFFFFu) - (int)(lo & 0xFFFFu) <= (int)xi;
+                    if (BIASED && alpha_noise) {
+                        const uint32_t *ne = neffb + (t & 1) * NC * 64 + lane;
+                        flip = alpha_flip(xi, ne[(i + 1) * 64], ne[i * 64], a.alpha, a.alpha_lnb[i]);
+                    }
+                    if (!done) {                                                   // (a converged syndrome stops counting)
+                        sacc[i * 64] += flip;
+                        nsum[(i + 1) * 64] += (flip ? lo : c2) & 0xFFFFu;
+                    }
+                    c2 = flip ? c2 : lo;
+                }
+                if (!done) nsum[0] += c2 & 0xFFFFu;
             }
             if (CONV && wave_u == 0 && __all(done || lane >= cnt)) *stopf = 1;
             if (slot_u == 0) flag = 0;                                              // :103
@@ -1336,10 +1324,28 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
 #pragma unroll 1
         for (int i = tid; i < cnt * ncls; i += nthreads) {
             const int j = i / ncls, c = i - j * ncls;
-            a.counts[s0 * ncls + i] = hist[c * 64 + j];
+            const uint32_t v = hist[c * 64 + j];
+            if (R > 1) { if (v) atomicAdd(a.counts + ((s0 + (uint64_t)j) / R) * ncls + c, v); }   // the syndrome's R ladders, summed
+            else if (a.accumulate) a.counts[s0 * ncls + i] += v;
+            else a.counts[s0 * ncls + i] = v;
         }
+    if (a.swap_acc != nullptr) {
+#pragma unroll 1
+        for (int i = tid; i < cnt * (2 * NC - 1); i += nthreads) {
+            const int j = i / (2 * NC - 1), c = i - j * (2 * NC - 1);
+            if (c < NC - 1) a.swap_acc[(s0 + j) * (NC - 1) + c] = lds_all[gdw + c * 64 + j];
+            else if (a.nerr_sum != nullptr) a.nerr_sum[(s0 + j) * NC + (c - (NC - 1))] = lds_all[gdw + (NC + c - (NC - 1)) * 64 + j];
+        }
+    }
+    if (slot == 0 && lane < cnt && R > 1) {
+        const uint64_t row = (s0 + lane) / R;
+        if (a.samples != nullptr) atomicAdd(a.samples + row, samples);
+        if (a.tops0 != nullptr) atomicAdd(a.tops0 + row, tops0);
+        if (a.steps_done != nullptr) atomicMax(a.steps_done + row, done ? steps_done : (uint32_t)a.nsteps);
+        if (a.converged != nullptr && !conv_ok) a.converged[row] = 0;               // the caller presets 1: all R ladders converged
+    } else
     if (slot == 0 && lane < cnt) {
-        if (a.samples != nullptr) a.samples[s0 + lane] = samples;
+        if (a.samples != nullptr) a.samples[s0 + lane] = a.accumulate ? a.samples[s0 + lane] + samples : samples;
         if (a.steps_done != nullptr) a.steps_done[s0 + lane] = USET ? (cm_done ? cm_steps : (uint32_t)a.nsteps) : done ? steps_done : (uint32_t)a.nsteps;
         if (a.converged != nullptr) a.converged[s0 + lane] = (uint8_t)conv_ok;
         if (a.tops0 != nullptr) a.tops0[s0 + lane] = tops0;
@@ -1367,6 +1373,8 @@ hipError_t launch_ladder_rs_toric(const LadderArgs &a, hipStream_t stream)
     unsigned grid = (unsigned)((a.N + 63) / 64);
     unsigned block = (unsigned)a.Nc * 64u;
     size_t lds = ladder_lds_bytes(a.L, a.Nc, a.W, a.ncls, ladder_gen_dwords(a.code, a.noise, a.scan, a.n_gen, a.Nc, a.nq, a.bias_lds));
+    if (a.swap_acc != nullptr) lds += ladder_stats_lds_bytes(a.Nc);   // per-lane counters behind the group's region
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (grid == 0) return hipSuccess;
     // One 64-syndrome group (Nc waves) per workgroup.  (Two groups per workgroup, sharing only the barrier, paid off while a
     // one-round grid ended in a long tail; with the current proposal loop the 8-wave workgroups are faster at every batch

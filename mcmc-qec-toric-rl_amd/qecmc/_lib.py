@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("QECMC_LIBRARY") or os.path.join(_HERE, "libqecmc.so")   # override: another build of the same ABI
 
 TORIC, XZZX, ROTATED, PLANAR = 0, 1, 2, 3
-SCAN_RANDOM, SCAN_CHECKERBOARD = 0, 1
+SCAN_RANDOM, SCAN_SWEEP = 0, 1
 NOISE_DEPOLARIZING, NOISE_BIASED, NOISE_ALPHA = 0, 1, 2
 CONV_NONE, CONV_ERROR_BASED = 0, 1
 PTDC_INIT_PER_DROPLET, PTDC_SET_PER_RUNG = 1, 2
@@ -28,7 +28,7 @@ class Params(C.Structure):
     _fields_ = [("abi_size", C.c_uint32), ("code", C.c_int32), ("L", C.c_int32), ("Nc", C.c_int32),
                 ("noise", C.c_int32), ("scan", C.c_int32), ("conv_mode", C.c_int32), ("device", C.c_int32),
                 ("iters", C.c_uint64), ("steps", C.c_uint64), ("tops_burn", C.c_int32), ("TOPS", C.c_int32),
-                ("SEQ", C.c_int32), ("reserved0", C.c_int32), ("eps", C.c_double), ("p", C.c_double),
+                ("SEQ", C.c_int32), ("replicas", C.c_int32), ("eps", C.c_double), ("p", C.c_double),
                 ("eta", C.c_double), ("alpha", C.c_double), ("p_logical", C.c_double), ("seed", C.c_uint64),
                 ("first_syndrome", C.c_uint32), ("flags", C.c_uint32)]
 
@@ -72,6 +72,11 @@ SIGNATURES = {
                                         C.POINTER(Stats)]),
     "qecmc_ptdc_batch_xyz": (C.c_int, [C.POINTER(Params), _u8p, C.c_uint64, C.c_int32, C.c_uint32, C.c_double, C.POINTER(C.c_double),
                                        _u32p, _u32p, _u32p, _u32p, _u32p, C.POINTER(Stats)]),
+    "qecmc_pteq_batch_stats": (C.c_int, [C.POINTER(Params), _u8p, C.c_uint64, _u32p, _u32p, _u32p, _u32p, _u8p, _u8p, _u32p, _u32p,
+                                         C.POINTER(Stats)]),
+    "qecmc_plan_set_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "qecmc_pteq_resume_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64,
+                                        C.c_void_p, C.c_void_p, C.c_void_p]),
     "qecmc_plan_workspace_bytes": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "qecmc_plan_create": (C.c_int, [C.POINTER(Params), C.POINTER(C.c_void_p)]),
     "qecmc_plan_destroy": (C.c_int, [C.c_void_p]),
@@ -93,7 +98,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
-        if L.qecmc_abi_version() != 2:
+        if L.qecmc_abi_version() != 3:
             raise QecmcError("libqecmc ABI version mismatch")
         _lib = L
     return _lib
@@ -136,11 +141,11 @@ def as_states(m, ndim_state):
 
 def make_params(code=TORIC, L=0, Nc=1, p=0.1, p_logical=0.0, iters=10, steps=0, tops_burn=2, TOPS=10, SEQ=2,
                 eps=0.1, seed=0, first_syndrome=0, conv_mode=CONV_NONE, scan=SCAN_RANDOM,
-                noise=NOISE_DEPOLARIZING, eta=0.0, alpha=0.0, device=0):
+                noise=NOISE_DEPOLARIZING, eta=0.0, alpha=0.0, device=0, replicas=0):
     pr = Params()
     pr.abi_size = C.sizeof(Params)
     pr.code, pr.L, pr.Nc, pr.noise, pr.scan, pr.conv_mode, pr.device = code, L, Nc, noise, scan, conv_mode, device
-    pr.iters, pr.steps, pr.tops_burn, pr.TOPS, pr.SEQ = iters, steps, tops_burn, TOPS, SEQ
+    pr.iters, pr.steps, pr.tops_burn, pr.TOPS, pr.SEQ, pr.replicas = iters, steps, tops_burn, TOPS, SEQ, replicas
     pr.eps, pr.p, pr.eta, pr.alpha, pr.p_logical = eps, p, eta, alpha, p_logical
     pr.seed, pr.first_syndrome, pr.flags = seed & 0xFFFFFFFFFFFFFFFF, first_syndrome, 0
     return pr

@@ -18,7 +18,7 @@ def percent_from_counts(counts, samples):
 
 def pteq_batch(init, p, Nc=None, steps=1000, iters=10, tops_burn=2, p_logical=0.5, seed=0, first_syndrome=0,
                device=0, return_states=False, return_stats=False, conv_criteria=None, SEQ=2, TOPS=10, eps=0.1,
-               code=L_.TORIC, eta=None, scan="random", alpha=None):
+               code=L_.TORIC, eta=None, scan="random", alpha=None, replicas=1, return_swap_stats=False):
     """decoders.PTEQ (decoders.py:25-89) on N syndromes at once.
 
     init: uint8[N, 2, L, L] (toric, code=PLANAR) or uint8[N, L, L] (code=XZZX / ROTATED) seed configurations, one per
@@ -26,6 +26,12 @@ def pteq_batch(init, p, Nc=None, steps=1000, iters=10, tops_burn=2, p_logical=0.
     src/mcmc_alpha.py (PTEQ_alpha; `p` is then pz_tilde); scan="random" is the reference's
     chain, scan="sweep" the systematic generator sweep (same stationary law, faster).  conv_criteria None runs exactly
     `steps` ladder steps; 'error_based' stops each syndrome by the reference's criterion (:74-105).
+    replicas=R > 1 runs R independent ladders per syndrome (Philox index first_syndrome + s*R + r) and sums their class
+    counts, samples and tops0 on the device (steps_done: the slowest ladder; converged: all of them) -- the droplets
+    pattern of decoders.py:215-225, which is how a call with few syndromes fills the GPU; states are then [N*R, Nc, ...].
+    return_swap_stats=True adds swap_accepts uint32[N,Nc-1] (accepted swap tests per rung pair over all `steps` ladder steps)
+    and nerr_sums uint32[N,Nc] (sum over the steps of each rung's error count after the swaps), the per-batch mixing
+    metrics of SURVEY.md 5.
     Returns dict(counts uint32[N,16], samples uint32[N], tops0 uint32[N], steps_done uint32[N],
     converged bool[N], percent uint8[N,16] [, states uint8[N,Nc,2,L,L]] [, stats]).
     """
@@ -41,43 +47,59 @@ def pteq_batch(init, p, Nc=None, steps=1000, iters=10, tops_burn=2, p_logical=0.
                         conv_mode=L_.CONV_ERROR_BASED if conv_criteria else L_.CONV_NONE,
                         noise=L_.NOISE_ALPHA if alpha is not None else L_.NOISE_DEPOLARIZING if eta is None else L_.NOISE_BIASED,
                         eta=0.0 if eta is None else float(eta), alpha=0.0 if alpha is None else float(alpha),
-                        scan={"random": L_.SCAN_RANDOM, "sweep": L_.SCAN_CHECKERBOARD}[scan])
+                        scan={"random": L_.SCAN_RANDOM, "sweep": L_.SCAN_SWEEP}[scan], replicas=int(replicas))
+    R = max(int(replicas), 1)
     counts = np.zeros((N, ncls), dtype=np.uint32)
     samples = np.zeros(N, dtype=np.uint32)
     tops0 = np.zeros(N, dtype=np.uint32)
     steps_done = np.zeros(N, dtype=np.uint32)
     converged = np.zeros(N, dtype=np.uint8)
-    states = np.empty((N, Nc) + a.shape[1:], dtype=np.uint8) if return_states else None
+    states = np.empty((N * R, Nc) + a.shape[1:], dtype=np.uint8) if return_states else None
+    swap_acc = np.zeros((N, max(Nc - 1, 1)), dtype=np.uint32) if return_swap_stats else None
+    nerr = np.zeros((N, Nc), dtype=np.uint32) if return_swap_stats else None
     stats = L_.Stats()
-    L_.check(L_.lib().qecmc_pteq_batch(pr, L_.u8(a), N, L_.u32(counts), L_.u32(samples), L_.u32(tops0),
-                                       L_.u32(steps_done), L_.u8(converged),
-                                       L_.u8(states) if return_states else None, stats))
+    L_.check(L_.lib().qecmc_pteq_batch_stats(pr, L_.u8(a), N, L_.u32(counts), L_.u32(samples), L_.u32(tops0),
+                                             L_.u32(steps_done), L_.u8(converged),
+                                             L_.u8(states) if return_states else None,
+                                             L_.u32(swap_acc) if return_swap_stats else None,
+                                             L_.u32(nerr) if return_swap_stats else None, stats))
     out = dict(counts=counts, samples=samples, tops0=tops0, steps_done=steps_done, converged=converged.astype(bool),
                percent=percent_from_counts(counts, samples))
     if return_states:
         out["states"] = states
+    if return_swap_stats:
+        out["swap_accepts"], out["nerr_sums"] = swap_acc[:, :Nc - 1], nerr
     if return_stats:
         out["stats"] = dict(proposals=int(stats.proposals), swap_tests=int(stats.swap_tests),
                             kernel_ms=float(stats.kernel_ms), total_ms=float(stats.total_ms))
     return out
 
 
+PTEQ_REPLICAS = 64   # ladders per PTEQ(...) call: one wavefront per temperature is 64 lanes wide, so 64 cost what 1 costs
+
+
 def PTEQ(init_code, p, Nc=None, SEQ=2, TOPS=10, tops_burn=2, eps=0.1, steps=50000000, iters=10,
-         conv_criteria='error_based', seed=None):
+         conv_criteria='error_based', seed=None, replicas=None):
     """Drop-in for decoders.PTEQ (decoders.py:25): same arguments, returns the uint8 percent vector of
     the equivalence classes.  With the convergence criterion the run is issued with a growing horizon (65 536
     ladder steps, x4 until it converges or `steps` is reached) so that the default `steps = 5e7` never allocates
     a 5e7-entry error-count log up front.  Philox is counter-based, so a longer horizon replays the same
-    trajectory: the answer equals that of a single run with the full `steps`."""
-    return _pteq(init_code, p, None, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, conv_criteria, seed)
+    trajectory: the answer equals that of a single run with the full `steps`.
+
+    The reference decodes ONE syndrome per call (generate_data.py:136); one ladder would occupy one lane of each of the Nc
+    wavefronts.  `replicas` (default PTEQ_REPLICAS = 64) independent ladders -- each with the reference's bookkeeping and, if
+    asked for, its own convergence stop -- fill the lanes, and the percent vector is formed from their summed class counts:
+    the "droplets" pattern the reference itself uses for its other estimators (decoders.py:215-225).  replicas=1 is the
+    reference's single ladder."""
+    return _pteq(init_code, p, None, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, conv_criteria, seed, replicas=replicas)
 
 
-def _pteq(init_code, p, eta, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, conv_criteria, seed, alpha=None):
+def _pteq(init_code, p, eta, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, conv_criteria, seed, alpha=None, replicas=None):
     if tops_burn >= TOPS:
         print('tops_burn has to be smaller than TOPS')
     seed = _fresh_seed() if seed is None else seed
     kw = dict(Nc=Nc or init_code.system_size, iters=iters, tops_burn=tops_burn, p_logical=0.5, seed=seed,
-              code=_code_id(init_code), eta=eta, alpha=alpha)
+              code=_code_id(init_code), eta=eta, alpha=alpha, replicas=PTEQ_REPLICAS if replicas is None else int(replicas))
     if conv_criteria is None:
         return pteq_batch(init_code.qubit_matrix, p, steps=steps, **kw)["percent"][0]
     horizon = min(int(steps), 1 << 16)

@@ -4,13 +4,13 @@ from .decoders import _pteq
 
 
 def PTEQ_biased(init_code, p, eta=0.5, Nc=None, SEQ=2, TOPS=10, tops_burn=2, eps=0.1, steps=50000000, iters=10,
-                conv_criteria='error_based', seed=None):
-    return _pteq(init_code, p, eta, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, conv_criteria, seed)
+                conv_criteria='error_based', seed=None, replicas=None):
+    return _pteq(init_code, p, eta, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, conv_criteria, seed, replicas=replicas)
 
 
 def PTEQ_alpha(init_code, pz_tilde, alpha=1, Nc=None, SEQ=2, TOPS=10, tops_burn=2, eps=0.1, steps=50000000, iters=10,
-               conv_criteria='error_based', seed=None):
-    return _pteq(init_code, pz_tilde, None, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, conv_criteria, seed, alpha=alpha)
+               conv_criteria='error_based', seed=None, replicas=None):
+    return _pteq(init_code, pz_tilde, None, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, conv_criteria, seed, alpha=alpha, replicas=replicas)
 
 
 def _shortest_loop(ladder, pz_tilde, SEQ, TOPS, tops_burn, eps, steps, iters, conv_criteria):

@@ -157,7 +157,7 @@ def _estimate(method, code, reps, p_error, p_sampling, Nc, steps, droplets, conv
 
 
 def generate(params, nbr_datapoints, seed=0, file_path=None, steps=100000, conv_criteria="error_based", biased_decoder="alpha",
-             **pteq_kw):
+             rng=None, **pteq_kw):
     """params: dict like generate_data.py:276-296 ({'code','size','p_error','noise'[,'eta','alpha']}), method PTEQ.
     noise 'depolarizing' -> PTEQ (:136); 'biased' -> errors from the eta split (:78-83) decoded by PTEQ_alpha with
     (pz_tilde, alpha) derived from (p, eta) exactly as :142-150 does (biased_decoder="biased" decodes with PTEQ_biased
@@ -175,7 +175,7 @@ def generate(params, nbr_datapoints, seed=0, file_path=None, steps=100000, conv_
     if noise not in ("depolarizing", "biased", "alpha"):
         raise ValueError(f"noise={noise!r}")
     eta = params.get("eta") if noise == "biased" else None
-    rng = np.random.default_rng(seed)
+    rng = np.random.default_rng(seed) if rng is None else rng         # (shards pass a generator keyed by (seed, shard id))
     raw = draw_errors(code, size, nbr_datapoints, p, rng, eta, rates=alpha_rates(p, params["alpha"]) if noise == "alpha" else None)
     eq_true = np.asarray(_class_of(code, raw), dtype=np.int32)
     init = hide_class(code, raw, rng)
@@ -203,27 +203,182 @@ def generate(params, nbr_datapoints, seed=0, file_path=None, steps=100000, conv_
     elif noise == "biased" and biased_decoder == "alpha":
         p_dec, a = biased_as_alpha(p, eta)
         dec = dict(alpha=float(a))
-    res = pteq_batch(init, p_dec, Nc=params.get("Nc"), steps=steps, conv_criteria=conv_criteria, seed=seed, code=code, **dec,
-                     **pteq_kw)
+    import time
+    Nc = params.get("Nc") or size
+    t0 = time.perf_counter()
+    res = pteq_batch(init, p_dec, Nc=Nc, steps=steps, conv_criteria=conv_criteria, seed=seed, code=code, return_stats=True,
+                     return_swap_stats=Nc > 1 and int(pteq_kw.get("replicas", 1)) <= 1, **dec, **pteq_kw)
+    wall = time.perf_counter() - t0
     out = dict(qubit_matrix=raw, eq_true=eq_true, counts=res["counts"], distr=res["percent"],
                success=np.argmax(res["percent"], axis=1) == eq_true, steps_done=res["steps_done"],
-               converged=res["converged"], samples=res["samples"])
+               converged=res["converged"], samples=res["samples"], tops0=res["tops0"])
     if file_path is not None:
         np.savez_compressed(file_path, params=np.array([repr(params)]), **out)
+    out["metrics"] = batch_metrics(code, size, Nc, int(pteq_kw.get("iters", 10)), res, wall, out["success"],
+                                   replicas=int(pteq_kw.get("replicas", 1)))
     return out
 
 
-def convergence_study(init, p, checkpoints, Nc=None, iters=10, tops_burn=0, seed=0, code=L_.TORIC, **pteq_kw):
+def batch_metrics(code, size, Nc, iters, res, wall_s, success=None, replicas=1):
+    """The per-batch metrics line (SURVEY.md 5 "Metrics / logging"; the reference only prints a progress counter,
+    generate_data.py:266): proposals, seconds, chain-sweeps/s, swap acceptance per rung pair, mean error count per rung,
+    the tops0 histogram, and the success rate when the true classes are known.  JSON-serialisable."""
+    n_gen = 2 * size * size if code == L_.TORIC else 2 * size * (size - 1) if code == L_.PLANAR else size * size - 1
+    steps_run = res["steps_done"].astype(np.float64)
+    proposals = float(steps_run.sum()) * Nc * iters * max(int(replicas), 1)
+    k_ms = res.get("stats", {}).get("kernel_ms", float("nan"))
+    m = dict(syndromes=int(res["counts"].shape[0]), Nc=int(Nc), iters=int(iters), proposals=proposals, wall_s=float(wall_s),
+             kernel_ms=float(k_ms), chain_sweeps_per_s_kernel=float(proposals / n_gen / (k_ms * 1e-3)) if k_ms == k_ms and k_ms > 0 else None,
+             chain_sweeps_per_s_wall=float(proposals / n_gen / wall_s) if wall_s > 0 else None,
+             converged_frac=float(np.mean(res["converged"])), mean_steps=float(steps_run.mean()) if steps_run.size else 0.0,
+             frac_past_burn_in=float(np.mean(res["samples"] > 0)) if res["samples"].size else 0.0,
+             tops0_hist=np.bincount(np.minimum(res["tops0"], 20).astype(np.int64), minlength=21).tolist())
+    if "swap_accepts" in res and steps_run.sum() > 0:
+        m["swap_acceptance"] = (res["swap_accepts"].sum(axis=0) / steps_run.sum()).tolist()
+        m["mean_errors_per_rung"] = (res["nerr_sums"].sum(axis=0) / steps_run.sum()).tolist()
+    if success is not None and len(success):
+        k, n = int(np.sum(success)), len(success)
+        m["success_rate"] = k / n
+        m["success_rate_err"] = float(np.sqrt(max(k / n * (1 - k / n), 0.0) / n))
+    return m
+
+
+def shard_name(prefix, seed, shard):
+    return f"{prefix}_seed{int(seed)}_shard{int(shard):05d}.npz"
+
+
+def generate_shards(params, n_total, shard_size, out_dir, seed=0, prefix="data", log=None, **gen_kw):
+    """The reference's array job (generate_data.py:251-256,274-276; generate_data_noise_models.py:27-32): the data set is cut
+    into shards keyed by (seed, shard id); a shard whose file exists is skipped, so an interrupted job resumes where it
+    stopped, and any subset of shards can be (re)made on any GPU in any order with the same result -- shard k draws its
+    errors from default_rng([seed, k]) and its ladders from Philox syndrome indices k*shard_size ....
+    One JSON metrics line per shard made is appended to <out_dir>/<prefix>_metrics.jsonl (and to `log`, a list, if given).
+    Returns the list of shard paths (all of them, made or found)."""
+    import json
+    import os
+    os.makedirs(out_dir, exist_ok=True)
+    paths = []
+    n_shards = (int(n_total) + int(shard_size) - 1) // int(shard_size)
+    for k in range(n_shards):
+        path = os.path.join(out_dir, shard_name(prefix, seed, k))
+        paths.append(path)
+        if os.path.exists(path):                                   # resume = skip existing shards
+            continue
+        n = min(int(shard_size), int(n_total) - k * int(shard_size))
+        tmp = path + ".tmp.npz"
+        out = generate(params, n, seed=seed, file_path=tmp, rng=np.random.default_rng([int(seed), k]),
+                       first_syndrome=k * int(shard_size) * max(int(gen_kw.get("replicas", 1)), 1), **gen_kw)
+        os.replace(tmp, path)                                      # a shard file is complete or absent
+        line = dict(shard=k, seed=int(seed), file=os.path.basename(path), **out.get("metrics", {}))
+        with open(os.path.join(out_dir, f"{prefix}_metrics.jsonl"), "a") as f:
+            f.write(json.dumps(line) + "\n")
+        if log is not None:
+            log.append(line)
+    return paths
+
+
+def threshold_curve(params, p_list, n, seed=0, **gen_kw):
+    """Logical success rate against the physical error rate (the p_error scan of generate_data.py:57-60,121-141,276-296 --
+    the reference loops p over [0.05, 0.20] in its job script and evaluates argmax(distr) == true class offline):
+    for every p in p_list, n syndromes at p_error = p decoded in one batched call.
+    Returns dict(p, n, success_rate, err (binomial standard error), converged_frac, metrics [one dict per p])."""
+    rate, err, conv, met = [], [], [], []
+    for i, p in enumerate(p_list):
+        out = generate(dict(params, p_error=float(p)), n, seed=seed + i, **gen_kw)
+        k = float(np.mean(out["success"]))
+        rate.append(k); err.append(float(np.sqrt(max(k * (1 - k), 0.0) / n)))
+        conv.append(float(np.mean(out["converged"])) if "converged" in out else float("nan"))
+        met.append(out.get("metrics"))
+    return dict(p=np.asarray(p_list, dtype=np.float64), n=int(n), success_rate=np.array(rate), err=np.array(err),
+                converged_frac=np.array(conv), metrics=met)
+
+
+class LadderRun:
+    """N ladders resident in HBM, advanced in chunks by qecmc_pteq_resume_dev: chunked runs reproduce one long run bit for
+    bit (Philox is addressed by the steps already done), so a 10^6-sweep study costs one pass, checkpoints are free, and no
+    single launch runs for minutes.  Device memory through torch (plumbing)."""
+
+    def __init__(self, init, p, Nc=None, iters=10, tops_burn=2, p_logical=0.5, seed=0, first_syndrome=0, device=0,
+                 code=L_.TORIC, eta=None):
+        import torch
+        a, _ = L_.as_states(init, 3 if code in (L_.TORIC, L_.PLANAR) else 2)
+        self.N, size = a.shape[0], a.shape[-1]
+        self.Nc = Nc or size
+        self.ncls = 16 if code == L_.TORIC else 4
+        self.shape = a.shape[1:]
+        nq = int(np.prod(self.shape))
+        self._mk = lambda steps: L_.make_params(code=code, L=size, Nc=self.Nc, p=float(p), p_logical=float(p_logical), iters=int(iters),
+                                                steps=int(steps), tops_burn=int(tops_burn), seed=seed, device=device,
+                                                noise=L_.NOISE_DEPOLARIZING if eta is None else L_.NOISE_BIASED, eta=float(eta or 0.0))
+        self.first = int(first_syndrome)
+        dev = torch.device("cuda", device)
+        st = np.broadcast_to(a.reshape(self.N, 1, nq), (self.N, self.Nc, nq))            # Ladder.__init__, mcmc.py:72
+        self.states = torch.from_numpy(np.ascontiguousarray(st)).to(dev)
+        fl = np.zeros((self.N, self.Nc), dtype=np.uint8); fl[:, -1] = 1                    # mcmc.py:75
+        self.flags = torch.from_numpy(fl).to(dev)
+        self.tops0 = torch.zeros(self.N, dtype=torch.int32, device=dev)
+        self.counts = torch.zeros((self.N, self.ncls), dtype=torch.int32, device=dev)
+        self.samples = torch.zeros(self.N, dtype=torch.int32, device=dev)
+        self.steps = 0
+        self._plans = {}
+        self._torch = torch
+
+    def advance(self, steps):
+        import ctypes as C
+        steps = int(steps)
+        if steps <= 0:
+            return self
+        if steps not in self._plans:
+            pl = C.c_void_p()
+            L_.check(L_.lib().qecmc_plan_create(self._mk(steps), C.byref(pl)))
+            self._plans[steps] = pl
+        stream = self._torch.cuda.current_stream(self.states.device)
+        L_.check(L_.lib().qecmc_pteq_resume_dev(self._plans[steps], self.states.data_ptr(), self.flags.data_ptr(), self.tops0.data_ptr(),
+                                                self.N, self.first, self.steps, self.counts.data_ptr(), self.samples.data_ptr(),
+                                                C.c_void_p(stream.cuda_stream)))
+        self.steps += steps
+        return self
+
+    def snapshot(self, states=False):
+        self._torch.cuda.synchronize()
+        out = dict(steps=self.steps, counts=self.counts.cpu().numpy().view(np.uint32), samples=self.samples.cpu().numpy().view(np.uint32),
+                   tops0=self.tops0.cpu().numpy().view(np.uint32))
+        if states:
+            out["states"] = self.states.cpu().numpy().reshape((self.N, self.Nc) + self.shape)
+            out["flags"] = self.flags.cpu().numpy()
+        return out
+
+    def close(self):
+        for pl in self._plans.values():
+            L_.lib().qecmc_plan_destroy(pl)
+        self._plans = {}
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def convergence_study(init, p, checkpoints, Nc=None, iters=10, tops_burn=0, seed=0, code=L_.TORIC, chunk=None, **run_kw):
     """Class histograms of the same chains at increasing run lengths (BASELINE config 5: "long-chain convergence study").
-    Philox is counter-based, so a run of `s` ladder steps is the exact prefix of any longer run with the same seed: the
-    batch is simply re-run to every checkpoint (total cost < 2x the longest run for log-spaced checkpoints).
+    The ladders stay in HBM (LadderRun) and are advanced from checkpoint to checkpoint -- an exact continuation, so the whole
+    study costs one run to the last checkpoint; `chunk` bounds the ladder steps of a single launch (default 2^20).
     Returns dict(steps int64[k], counts uint32[k, N, ncls], samples uint32[k, N], percent uint8[k, N, ncls],
     tv float64[k]) with tv = mean total-variation distance of each checkpoint's class distribution to the last one."""
+    from .decoders import percent_from_counts
     cps = sorted(int(c) for c in checkpoints)
-    runs = [pteq_batch(init, p, Nc=Nc, steps=c, iters=iters, tops_burn=tops_burn, seed=seed, code=code, **pteq_kw) for c in cps]
-    counts = np.stack([r["counts"] for r in runs])
-    samples = np.stack([r["samples"] for r in runs])
+    chunk = int(chunk or (1 << 20))
+    run = LadderRun(init, p, Nc=Nc, iters=iters, tops_burn=tops_burn, seed=seed, code=code, **run_kw)
+    snaps = []
+    for c in cps:
+        while run.steps < c:
+            run.advance(min(chunk, c - run.steps))
+        snaps.append(run.snapshot())
+    run.close()
+    counts = np.stack([r["counts"] for r in snaps])
+    samples = np.stack([r["samples"] for r in snaps])
     frac = counts / np.maximum(samples, 1)[..., None].astype(np.float64)
     tv = 0.5 * np.abs(frac - frac[-1]).sum(axis=-1).mean(axis=-1)
-    return dict(steps=np.array(cps, dtype=np.int64), counts=counts, samples=samples,
-                percent=np.stack([r["percent"] for r in runs]), tv=tv)
+    return dict(steps=np.array(cps, dtype=np.int64), counts=counts, samples=samples, tops0=np.stack([r["tops0"] for r in snaps]),
+                percent=np.stack([percent_from_counts(r["counts"], r["samples"]) for r in snaps]), tv=tv)

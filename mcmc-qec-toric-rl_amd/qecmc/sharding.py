@@ -8,7 +8,14 @@ with Philox keyed by the GLOBAL syndrome index (so the answer does not depend on
 the number of GPUs), and the only exchange is one gather of the per-class
 counts -- 4*ncls + 8 bytes per syndrome, latency-bound on a fully connected
 xGMI node, no collective on the sampling path itself.
+
+    launch(n, fn, ...)            start n ranks on this node (the array job of generate_data.py:274-276 -> one node)
+    PteqShard                     one rank's shard resident in HBM: .launch() (kernel) and .gather() (the exchange)
+    pteq_batch_sharded(init, p)   host-array convenience call over PteqShard
 """
+import os
+import socket
+
 import numpy as np
 
 
@@ -19,25 +26,172 @@ def shard_bounds(n_total, world_size, rank):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _rank_main(rank, world, port, backend, fn, args, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
+    import torch
+    import torch.distributed as dist
+    kw = {}
+    if backend == "nccl":
+        torch.cuda.set_device(rank)
+        kw["device_id"] = torch.device("cuda", rank)
+    dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, **kw)
+    try:
+        res = fn(rank, world, *args)
+        if rank == 0:
+            q.put(res)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def launch(n, fn, args=(), backend="nccl", timeout=3600):
+    """Run fn(rank, world, *args) on n fresh processes of this node, one per GPU (rank r drives cuda:r), inside an initialised
+    process group (backend "nccl" = RCCL; "gloo" for CPU rehearsals), and return rank 0's return value.
+
+    The ranks are started with the `spawn` method BEFORE this process has touched the GPU: a process that has initialised HIP
+    must neither fork workers (HIP is not fork-safe) nor be replaced by another program.  `fn` and `args` must be picklable
+    (a module-level function).  Any rank failing raises RuntimeError with its exit code."""
+    import torch
+    import torch.multiprocessing as mp
+    if backend == "nccl" and torch.cuda.is_initialized():
+        raise RuntimeError("sharding.launch must be called before this process initialises the GPU")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_rank_main, args=(r, n, port, backend, fn, args, q)) for r in range(n)]
+    for p in procs:
+        p.start()
+    res, got = None, False
+    try:
+        res = q.get(timeout=timeout)
+        got = True
+    except Exception:
+        pass
+    for p in procs:
+        p.join(60 if got else 5)
+    bad = [(r, p.exitcode) for r, p in enumerate(procs) if p.exitcode != 0]
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+    if bad or not got:
+        raise RuntimeError(f"sharding.launch: ranks failed (rank, exit code): {bad or 'no result from rank 0'}")
+    return res
+
+
+class PteqShard:
+    """This rank's shard of a PTEQ batch, resident in HBM: plan, input and one packed record buffer
+    (ncls class counts, samples, tops0 per syndrome).  `launch()` enqueues the ladder kernel on the current stream,
+    `gather()` is the path's one exchange (per-class counts -> rank `dst`).  bench.py times exactly these two calls."""
+
+    def __init__(self, init_shard, p, first_syndrome, n_total=None, group=None, dst=0, device=None, **params):
+        import ctypes as C
+        import torch
+        import torch.distributed as dist
+        from . import _lib as L_
+        self._C, self._L, self._torch, self._dist = C, L_, torch, dist
+        self.group, self.dst = group, dst
+        self.dist_on = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.dist_on else 1
+        self.rank = dist.get_rank(group) if self.dist_on else 0
+        dev = torch.cuda.current_device() if device is None else device
+        self.dev = torch.device("cuda", dev)
+        a = np.ascontiguousarray(init_shard, dtype=np.uint8)
+        self.n = a.shape[0]
+        code = params.get("code", L_.TORIC)
+        self.ncls = 16 if code == L_.TORIC else 4
+        size = a.shape[-1]
+        params.setdefault("p_logical", 0.5)            # decoders.py:52
+        params.setdefault("steps", 1000)
+        params["Nc"] = params.get("Nc") or size        # decoders.py:30
+        self.pr = L_.make_params(L=size, p=float(p), device=dev, first_syndrome=0, **params)
+        self.first = int(first_syndrome)
+        self.plan = C.c_void_p()
+        L_.check(L_.lib().qecmc_plan_create(self.pr, C.byref(self.plan)))
+        self.d_init = torch.from_numpy(a.reshape(self.n, int(np.prod(a.shape[1:])))).to(self.dev)
+        self.n_total = int(n_total if n_total is not None else self.n * self.world)
+        self.max_rows = (self.n_total + self.world - 1) // self.world       # equal-size buffers for the collective
+        self.rec = torch.zeros(self.max_rows * (self.ncls + 2), dtype=torch.int32, device=self.dev)
+        self.gathered = ([torch.empty_like(self.rec) for _ in range(self.world)]
+                         if (self.dist_on and self.rank == dst) else None)
+
+    def views(self, rec=None, n=None):
+        rec = self.rec if rec is None else rec
+        n = self.n if n is None else n
+        k = n * self.ncls
+        return rec[:k].view(n, self.ncls), rec[k:k + n], rec[k + n:k + 2 * n]
+
+    def launch(self, stream=None):
+        C, L_, torch = self._C, self._L, self._torch
+        stream = torch.cuda.current_stream(self.dev) if stream is None else stream
+        counts, samples, tops0 = self.views()
+        if self.n:
+            L_.check(L_.lib().qecmc_pteq_launch_dev(self.plan, self.d_init.data_ptr(), self.n, self.first, counts.data_ptr(),
+                                                    samples.data_ptr(), tops0.data_ptr(), None, None, None, None,
+                                                    C.c_void_p(stream.cuda_stream)))
+
+    def gather(self):
+        if self.dist_on:
+            self._dist.gather(self.rec, self.gathered, dst=self.dst, group=self.group)
+
+    def result(self):
+        """On rank `dst`: dict(counts, samples, tops0) in global syndrome order (after gather()); None elsewhere."""
+        if self.rank != self.dst:
+            return None
+        recs = self.gathered if self.dist_on else [self.rec]
+        out = [[], [], []]
+        for r, rec in enumerate(recs):
+            lo, hi = shard_bounds(self.n_total, self.world, r) if self.dist_on else (0, self.n)
+            for o, v in zip(out, self.views(rec, hi - lo)):
+                o.append(v.cpu().numpy().view(np.uint32))
+        return dict(counts=np.concatenate(out[0]), samples=np.concatenate(out[1]), tops0=np.concatenate(out[2]))
+
+    def close(self):
+        if self.plan:
+            self._L.lib().qecmc_plan_destroy(self.plan)
+            self.plan = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def pteq_batch_sharded(init, p, compute=None, group=None, dst=0, **kw):
     """PTEQ on a batch sharded over the ranks of `group`.
 
     init: the FULL uint8[N,2,L,L] batch (every rank passes the same array; only its shard is used).
-    compute(init_shard, p, first_syndrome=..., **kw) -> dict(counts, samples, tops0): defaults to
-    qecmc.pteq_batch (the GPU path); tests inject a stand-in to exercise the exchange on CPU.
+    Default (compute=None): the GPU path -- PteqShard: shard to HBM, ladder kernel, one RCCL gather of the packed records
+    straight from device memory.  compute(init_shard, p, first_syndrome=..., **kw) -> dict(counts, samples, tops0) is the
+    tests' hook to exercise bounds and exchange on CPU with a stand-in.
     Returns the gathered dict on rank `dst` (arrays in global syndrome order) and None elsewhere.
     """
     import torch
     import torch.distributed as dist
-    if compute is None:
-        from .decoders import pteq_batch as compute
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     n_total = int(np.asarray(init).shape[0])
     lo, hi = shard_bounds(n_total, world, rank)
     first = int(kw.pop("first_syndrome", 0))
-    if dist.get_backend(group) == "nccl":
-        kw.setdefault("device", torch.cuda.current_device())
+    if compute is None:
+        kw.pop("device", None)
+        sh = PteqShard(np.asarray(init)[lo:hi], p, first + lo, n_total=n_total, group=group, dst=dst, **kw)
+        sh.launch()
+        sh.gather()
+        torch.cuda.synchronize()
+        out = sh.result()
+        sh.close()
+        return out
     res = compute(np.asarray(init)[lo:hi], p, first_syndrome=first + lo, **kw)
     ncls = res["counts"].shape[1]
     # one packed record per syndrome: ncls class counts + samples + tops0 (uint32 -> int64-safe int32 view)
@@ -46,8 +200,9 @@ def pteq_batch_sharded(init, p, compute=None, group=None, dst=0, **kw):
     max_rows = (n_total + world - 1) // world          # equal-size buffers for the collective
     buf = np.zeros((max_rows, ncls + 2), dtype=np.uint32)
     buf[:hi - lo] = rec
-    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
-    t = torch.from_numpy(buf.view(np.int32)).to(dev)
+    t = torch.from_numpy(buf.view(np.int32))
+    if dist.get_backend(group) == "nccl":
+        t = t.to(torch.device("cuda", torch.cuda.current_device()))
     gathered = [torch.empty_like(t) for _ in range(world)] if rank == dst else None
     dist.gather(t, gathered, dst=dst, group=group)
     if rank != dst:

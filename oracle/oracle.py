@@ -42,7 +42,8 @@ class _Ladder(C.Structure):
     _fields_ = [("model", Model), ("L", C.c_int), ("Nc", C.c_int), ("nq", C.c_int), ("p_logical", C.c_double),
                 ("p_ladder", C.POINTER(C.c_double)), ("p_diff", C.POINTER(C.c_double)),
                 ("states", C.POINTER(C.c_uint8)), ("flags", C.POINTER(C.c_uint8)), ("n_eff", C.POINTER(C.c_double)), ("n_eff_cnt", C.POINTER(C.c_uint32)),
-                ("tops0", C.c_uint64), ("step_index", C.c_uint64), ("scratch", C.POINTER(C.c_uint8))]
+                ("tops0", C.c_uint64), ("step_index", C.c_uint64), ("scratch", C.POINTER(C.c_uint8)),
+                ("swap_acc", C.POINTER(C.c_uint64)), ("nerr_sum", C.POINTER(C.c_uint64))]
 
 
 class PteqResult(C.Structure):
@@ -255,6 +256,9 @@ class ToricLadder:
     def p_diff(self):
         return np.ctypeslib.as_array(self._p.contents.p_diff, shape=(self.Nc - 1,)).copy()
 
+    swap_accepts = property(lambda self: Ladder.swap_accepts.fget(self))
+    nerr_sums = property(lambda self: Ladder.nerr_sums.fget(self))
+
 
 def toric_pteq(init, p, Nc=None, SEQ=2, TOPS=10, tops_burn=2, eps=0.1, steps=1000, iters=10,
                conv_criteria=None, rng=None, return_states=False):
@@ -403,6 +407,16 @@ class Ladder:
     @property
     def p_diff(self):
         return np.ctypeslib.as_array(self._p.contents.p_diff, shape=(self.Nc - 1,)).copy()
+
+    @property
+    def swap_accepts(self):
+        """accepted swap tests per rung pair since construction"""
+        return np.ctypeslib.as_array(self._p.contents.swap_acc, shape=(max(self.Nc - 1, 1),))[:self.Nc - 1].copy()
+
+    @property
+    def nerr_sums(self):
+        """sum over the steps of each rung's error count after the step's swaps"""
+        return np.ctypeslib.as_array(self._p.contents.nerr_sum, shape=(self.Nc,)).copy()
 
     @property
     def n_eff(self):

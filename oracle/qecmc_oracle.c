@@ -563,6 +563,8 @@ orc_ladder *orc_ladder_new(const orc_model *m, const uint8_t *init, double p_bot
     ld->states = (uint8_t *)malloc((size_t)Nc * ld->nq);
     ld->flags = (uint8_t *)calloc((size_t)Nc, 1);
     ld->scratch = (uint8_t *)malloc((size_t)ld->nq);
+    ld->swap_acc = (uint64_t *)calloc((size_t)(Nc > 1 ? Nc - 1 : 1), sizeof(uint64_t));
+    ld->nerr_sum = (uint64_t *)calloc((size_t)Nc, sizeof(uint64_t));
     ld->n_eff = (double *)calloc((size_t)Nc, sizeof(double));
     {   /* Chain_alpha.__init__, mcmc_alpha.py:18-22 */
         int nx = 0, ny = 0, nz = 0;
@@ -591,6 +593,7 @@ void orc_ladder_free(orc_ladder *ld)
 {
     if (!ld) return;
     free(ld->p_ladder); free(ld->p_diff); free(ld->states); free(ld->flags); free(ld->scratch); free(ld->n_eff); free(ld->n_eff_cnt);
+    free(ld->swap_acc); free(ld->nerr_sum);
     free(ld);
 }
 
@@ -629,6 +632,7 @@ void orc_ladder_step(orc_ladder *ld, uint64_t iters, orc_rng *rng)
         if (ld->model.noise != ORC_NOISE_BIASED && ne_hi < ne_lo) flip = 1;
         else flip = orc_draw(rng, ORC_SWAP_STREAM, ld->step_index, (uint32_t)i >> 2, i & 3)
                     < pow(ld->p_diff[i], (double)(ne_hi - ne_lo));  /* :149 */
+        ld->swap_acc[i] += (uint64_t)(flip != 0);
         if (flip) {                                                 /* :98-99 */
             memcpy(ld->scratch, ld->states + (size_t)i * nq, (size_t)nq);
             memcpy(ld->states + (size_t)i * nq, ld->states + (size_t)(i + 1) * nq, (size_t)nq);
@@ -638,6 +642,7 @@ void orc_ladder_step(orc_ladder *ld, uint64_t iters, orc_rng *rng)
     }
     ld->flags[Nc - 1] = 1;                                          /* :100 */
     if (ld->flags[0] == 1) { ld->tops0++; ld->flags[0] = 0; }       /* :101-103 */
+    for (int c = 0; c < Nc; ++c) ld->nerr_sum[c] += (uint64_t)orc_count_errors((size_t)nq, ld->states + (size_t)c * nq);
     ld->step_index++;
 }
 

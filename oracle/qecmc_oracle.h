@@ -113,6 +113,10 @@ typedef struct orc_ladder {
     uint64_t tops0;
     uint64_t step_index; /* ladder steps done so far (Philox addressing) */
     uint8_t *scratch;    /* [nq] */
+    /* equilibrium observables (fixture F5): accepted swap tests per rung pair, and the sum over the steps of every
+     * rung's count_errors() after the step's swaps */
+    uint64_t *swap_acc;  /* [Nc-1] */
+    uint64_t *nerr_sum;  /* [Nc] */
 } orc_ladder;
 
 /* Chain.update_chain(iters), src/mcmc.py:19-43.  `slot`/`k0` only address the

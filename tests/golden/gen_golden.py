@@ -17,6 +17,8 @@ Fixtures
                   seed is stored
   f3_toric.npz    replica-averaged PTEQ class histograms (statistical)
   f4_config1.npz  BASELINE config-1 plumbing vector
+  f5_stats.npz    per-rung <n_errors>, per-pair swap acceptance and class counts after a 20 % burn-in: toric L=9 p=0.15 Nc=8,
+                  rotated L=5/7 p=0.17, Ladder_biased xzzx L=5/7 eta=100 (statistical)
   f1_surf.npz / f2_surf.npz   the same for the XZZX and rotated codes, incl. the biased chain
   f2_alpha.npz                Chain_alpha / Ladder_alpha / PTEQ_alpha trajectories (src/mcmc_alpha.py)
   f_ptdc.npz                  PTDC_droplet unique-chain length histograms N(n) and PTDC percent vectors (decoders.py:138-233)
@@ -859,6 +861,87 @@ def gen_f3(tm):
     np.savez_compressed(os.path.join(HERE, "f3_toric.npz"), **out)
 
 
+# --------------------------------------------------------------------------- F5
+def _f5_worker(args):
+    """One replica of a ladder run with the equilibrium observables SURVEY.md 8c lists as F5: class counts of the bottom
+    chain, time-averaged count_errors per rung and the outcome of every swap test per adjacent pair (Ladder.r_flip wrapped;
+    the sweep visits i = Nc-2 ... 0, src/mcmc.py:96), all after discarding the first `burn` ladder steps."""
+    (kind, L, p, eta, Nc, iters, steps, burn, m, seed) = args
+    tm, mc, dec = import_reference()
+    random.seed(seed)
+    if kind == "toric":
+        code = tm.Toric_code(L)
+    else:
+        xm, rm, mb, decb = import_reference_surf()
+        code = (xm.xzzx_code if kind.startswith("xzzx") else rm.RotSurCode)(L)
+    code.qubit_matrix = m.copy()
+    ld = mb.Ladder_biased(p, code, eta, Nc, 0.5) if kind == "xzzx_biased" else mc.Ladder(p, code, Nc, 0.5)
+    att = np.zeros(Nc - 1, dtype=np.int64); acc = np.zeros(Nc - 1, dtype=np.int64)
+    rec = [False]
+    inner = ld.r_flip
+
+    def logged(i):
+        r = bool(inner(i))
+        if rec[0]:
+            att[i] += 1; acc[i] += r
+        return r
+    ld.r_flip = logged
+    ncls = 16 if kind == "toric" else 4
+    hist = np.zeros(ncls, dtype=np.int64)
+    nerr = np.zeros(Nc)
+    for t in range(steps):
+        rec[0] = t >= burn
+        ld.step(iters)
+        if t >= burn:
+            hist[ld.chains[0].code.define_equivalence_class()] += 1
+            nerr += [c.code.count_errors() for c in ld.chains]
+    return hist, nerr / (steps - burn), ld.tops0, att, acc
+
+
+def gen_f5(only=None):
+    """Statistical fixtures where the benchmark lives (SURVEY.md 8c F3/F5, 8d "mixing calibration"): toric L=9 p=0.15 Nc=8,
+    rotated L=5/7 p=0.17, Ladder_biased on xzzx L=5/7 eta=100.  R replicas per syndrome; per replica the class counts,
+    the per-rung mean error count and the per-pair swap acceptances after a 20 % burn-in."""
+    import multiprocessing as mp
+    rng = np.random.default_rng(23)
+    path = os.path.join(HERE, "f5_stats.npz")
+    out = dict(np.load(path)) if os.path.exists(path) else {}
+    #           name           kind          L   p     eta  Nc iters steps  burn nsyn R
+    configs = [("toric_L9", "toric", 9, 0.15, 0, 8, 10, 20000, 4000, 3, 16),
+               ("rot_L5", "rot", 5, 0.17, 0, 5, 10, 20000, 4000, 3, 16),
+               ("rot_L7", "rot", 7, 0.17, 0, 7, 10, 20000, 4000, 3, 16),
+               ("xzzxb_L5", "xzzx_biased", 5, 0.15, 100, 5, 10, 20000, 4000, 3, 16),
+               ("xzzxb_L7", "xzzx_biased", 7, 0.15, 100, 7, 10, 20000, 4000, 3, 16)]
+    with mp.get_context("spawn").Pool(8) as pool:
+        for name, kind, L, p, eta, Nc, iters, steps, burn, nsyn, R in configs:
+            if kind == "toric":
+                ms = [rand_matrix(rng, L, p) for _ in range(nsyn)]
+            elif kind == "rot":
+                ms = [rand_matrix2(rng, L, p) for _ in range(nsyn)]
+            else:       # generate_data.py:78-83: p_z = p eta/(eta+1), p_x = p_y = p/(2(eta+1))
+                ms = []
+                for _ in range(nsyn):
+                    r = rng.random((L, L)); pz = p * eta / (eta + 1); px = p / (2 * (eta + 1))
+                    m = np.zeros((L, L), dtype=np.uint8)
+                    m[r < pz] = 3; m[(r > pz) & (r < pz + px)] = 1; m[(r > pz + px) & (r < pz + 2 * px)] = 2
+                    ms.append(m)
+            if only and name not in only:
+                continue
+            jobs = [(kind, L, p, eta, Nc, iters, steps, burn, ms[s], 7000 + 100 * s + r) for s in range(nsyn) for r in range(R)]
+            res = pool.map(_f5_worker, jobs)
+            ncls = 16 if kind == "toric" else 4
+            out[f"{name}_init"] = np.array(ms, dtype=np.uint8)
+            out[f"{name}_hist"] = np.array([x[0] for x in res]).reshape(nsyn, R, ncls)
+            out[f"{name}_nerr"] = np.array([x[1] for x in res]).reshape(nsyn, R, Nc)
+            out[f"{name}_tops0"] = np.array([x[2] for x in res]).reshape(nsyn, R)
+            out[f"{name}_swap_att"] = np.array([x[3] for x in res]).reshape(nsyn, R, Nc - 1)
+            out[f"{name}_swap_acc"] = np.array([x[4] for x in res]).reshape(nsyn, R, Nc - 1)
+            out[f"{name}_par"] = np.array([L, p, eta, Nc, iters, steps, burn], dtype=np.float64)
+            print(name, "done: <n> per rung", out[f"{name}_nerr"].mean(axis=(0, 1)).round(1),
+                  "swap acceptance", (out[f"{name}_swap_acc"].sum(axis=(0, 1)) / out[f"{name}_swap_att"].sum(axis=(0, 1))).round(3), flush=True)
+            np.savez_compressed(path, **out)
+
+
 # --------------------------------------------------------------------------- F4
 def gen_f4(tm, mc):
     random.seed(1); np.random.seed(1)
@@ -882,7 +965,7 @@ def main():
         print("reference not present; nothing to do")
         return
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="f1,f2,f3,f4,f1s,f2s,f2a,fp,fd,fc,fg,fa")
+    ap.add_argument("--only", default="f1,f2,f3,f4,f1s,f2s,f2a,fp,fd,fc,fg,fa,f5")
     only = set(ap.parse_args().only.split(","))
     tm, mc, dec = import_reference()
     if "f1" in only: gen_f1(tm)
@@ -905,6 +988,7 @@ def main():
         if "f1s" in only: gen_f1_surf(xm, rm)
         if "f2s" in only: gen_f2_surf(xm, rm, mc, mb, dec, decb)
     if "f3" in only: gen_f3(tm)
+    if "f5" in only: gen_f5()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,84 @@
+"""`bench.py --gpus N` must start N ranks itself.  Rehearsed on CPU: the same launcher command line
+(python -m torch.distributed.run --nproc-per-node N bench.py --gpus N), gloo instead of RCCL and no kernel (`--dry-run`),
+so what is checked is the launch path, the rank environment, the gather and the JSON contract -- not a throughput."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*argv, env=None):
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True, timeout=300, env=e)
+
+
+def test_bench_gpus2_spawns_two_ranks():
+    r = _run("--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1", "--syndromes", "256")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                      # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1
+    assert out["gather_ok"] is True                       # rank 1's records reached rank 0
+    assert out["value"] == 0.0 and "dry run" in out["metric"]          # a rehearsal never reports a throughput
+
+
+def test_bench_single_rank_dry_run_and_rc_propagation():
+    r = _run("--dry-run", "--steps", "1", "--warmup", "0", "--syndromes", "64", "--config", "4")
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 1 and "XZZX" in out["config"]["workload"]
+    # a failing rank must fail the launcher: without --dry-run there is no GPU here, every rank raises
+    r = _run("--gpus", "2", "--steps", "1", "--warmup", "0", "--syndromes", "64")
+    assert r.returncode != 0
+
+
+def test_bench_rejects_mismatched_world():
+    r = _run("--gpus", "2", "--dry-run", env={"WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+def _sharded_oracle(rank, world, n_total):
+    """module-level (picklable) rank function for sharding.launch: the sharded call with the oracle as stand-in compute"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "mcmc-qec-toric-rl_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_shard_gloo import _oracle_compute
+    from qecmc.sharding import pteq_batch_sharded
+    rng = np.random.default_rng(5)
+    init = np.zeros((n_total, 2, 3, 3), dtype=np.uint8)
+    err = rng.random(init.shape) < 0.15
+    init[err] = rng.integers(1, 4, size=int(err.sum()), dtype=np.uint8)
+    out = pteq_batch_sharded(init, 0.1, compute=_oracle_compute, Nc=3, steps=40, tops_burn=0, seed=7)
+    if rank != 0:
+        return None
+    full = _oracle_compute(init, 0.1, Nc=3, steps=40, tops_burn=0, seed=7)
+    return bool(all(np.array_equal(out[k], full[k].astype(np.uint32)) for k in ("counts", "samples", "tops0"))), world
+
+
+def test_sharding_launch_helper_gloo():
+    sys.path.insert(0, os.path.join(ROOT, "mcmc-qec-toric-rl_amd"))
+    from qecmc.sharding import launch
+    ok, world = launch(2, _sharded_oracle, args=(9,), backend="gloo", timeout=120)
+    assert ok is True and world == 2
+
+
+def _failing(rank, world):
+    if rank == 1:
+        raise SystemExit(3)
+    return 1
+
+
+def test_sharding_launch_propagates_failure():
+    sys.path.insert(0, os.path.join(ROOT, "mcmc-qec-toric-rl_amd"))
+    from qecmc.sharding import launch
+    with pytest.raises(RuntimeError):
+        launch(2, _failing, backend="gloo", timeout=60)

@@ -150,7 +150,7 @@ def test_pteq_dropin_signature(q, orc):
     rng = np.random.default_rng(1)
     code = q.Toric_code(5)
     code.qubit_matrix = rand_states(rng, 1, 5, 0.1)[0]
-    pct = q.PTEQ(code, 0.1, Nc=5, steps=400, iters=10, tops_burn=1, conv_criteria=None, seed=77)
+    pct = q.PTEQ(code, 0.1, Nc=5, steps=400, iters=10, tops_burn=1, conv_criteria=None, seed=77, replicas=1)
     ref = orc.toric_pteq(code.qubit_matrix, 0.1, Nc=5, steps=400, iters=10, tops_burn=1, rng=orc.Rng.philox(77, 0))
     assert pct.dtype == np.uint8 and pct.shape == (16,)
     assert np.array_equal(pct, ref["percent"])
@@ -207,7 +207,7 @@ def test_pteq_dropin_default_criterion(q, orc):
     rng = np.random.default_rng(8)
     code = q.Toric_code(3)
     code.qubit_matrix = rand_states(rng, 1, 3, 0.1)[0]
-    pct = q.PTEQ(code, 0.1, seed=5)
+    pct = q.PTEQ(code, 0.1, seed=5, replicas=1)
     ref = orc.toric_pteq_batch(code.qubit_matrix[None], 0.1, 3, 1 << 22, seed=5, conv_criteria="error_based")
     assert ref["converged"][0]
     exp = (np.divide(ref["counts"][0], ref["samples"][0]) * 100).astype(np.uint8)

@@ -103,10 +103,10 @@ def test_pteq_alpha_dropin(q, orc):
     rng = np.random.default_rng(8)
     code = q.xzzx_code(5)
     code.qubit_matrix = rand_states(rng, 1, 5, 0.15)[0]
-    pct = q.PTEQ_alpha(code, 0.1, alpha=1.7, Nc=5, steps=300, conv_criteria=None, seed=21)
+    pct = q.PTEQ_alpha(code, 0.1, alpha=1.7, Nc=5, steps=300, conv_criteria=None, seed=21, replicas=1)
     ref = orc.pteq(q.XZZX, code.qubit_matrix, 0.1, Nc=5, steps=300, rng=orc.Rng.philox(21, 0), noise=orc.ALPHA, alpha=1.7, det_pow=1)
     assert pct.shape == (4,) and np.array_equal(pct, ref["percent"])
-    pct = q.PTEQ_alpha(code, 0.1, alpha=1.7, Nc=5, steps=200000, seed=22)
+    pct = q.PTEQ_alpha(code, 0.1, alpha=1.7, Nc=5, steps=200000, seed=22, replicas=1)
     ref = orc.pteq(q.XZZX, code.qubit_matrix, 0.1, Nc=5, steps=200000, conv_criteria="error_based", rng=orc.Rng.philox(22, 0),
                    noise=orc.ALPHA, alpha=1.7, det_pow=1)
     assert np.array_equal(pct, ref["percent"]) and ref["converged"]

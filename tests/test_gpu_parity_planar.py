@@ -131,7 +131,7 @@ def test_planar_pteq_dropin_and_exact_classes(q, orc):
     rng = np.random.default_rng(6)
     code = q.Planar_code(5)
     code.qubit_matrix = rand_states(rng, 1, 5, 0.12)[0]
-    pct = q.PTEQ(code, 0.12, steps=300, conv_criteria=None, seed=5)
+    pct = q.PTEQ(code, 0.12, steps=300, conv_criteria=None, seed=5, replicas=1)
     ref = orc.pteq(orc.PLANAR, code.qubit_matrix, 0.12, Nc=5, steps=300, rng=orc.Rng.philox(5, 0))
     assert pct.shape == (4,) and np.array_equal(pct, ref["percent"])
     L, p = 3, 0.12

@@ -136,11 +136,11 @@ def test_pteq_biased_dropin(q, orc):
     rng = np.random.default_rng(2)
     code = q.xzzx_code(5)
     code.qubit_matrix = rand_states(rng, 1, 5, 0.15)[0]
-    pct = q.PTEQ_biased(code, 0.15, eta=100, Nc=5, steps=300, conv_criteria=None, seed=12)
+    pct = q.PTEQ_biased(code, 0.15, eta=100, Nc=5, steps=300, conv_criteria=None, seed=12, replicas=1)
     ref = orc.pteq(q.XZZX, code.qubit_matrix, 0.15, Nc=5, steps=300, rng=orc.Rng.philox(12, 0), noise=1, eta=100)
     assert pct.shape == (4,) and np.array_equal(pct, ref["percent"])
     rot = q.RotSurCode(5)
     rot.qubit_matrix = rand_states(rng, 1, 5, 0.15)[0]
-    pct = q.PTEQ(rot, 0.17, steps=300, conv_criteria=None, seed=13)          # decoders.PTEQ works on any code model
+    pct = q.PTEQ(rot, 0.17, steps=300, conv_criteria=None, seed=13, replicas=1)          # decoders.PTEQ works on any code model
     ref = orc.pteq(q.ROTATED, rot.qubit_matrix, 0.17, Nc=5, steps=300, rng=orc.Rng.philox(13, 0))
     assert np.array_equal(pct, ref["percent"])

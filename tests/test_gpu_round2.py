@@ -1,0 +1,218 @@
+"""Round-2 additions of the HIP path against the pinned oracle: replica ladders (the small-batch mode), the equilibrium
+observables (per-pair swap acceptances, per-rung error-count sums), exact chunked continuation, and the harness's shard /
+resume / threshold-curve drivers.  Bit-exact wherever the oracle computes the same thing; fixture F5 (the reference's own
+20 000-step runs at toric L=9, rotated L=5/7, biased xzzx L=5/7) closes the statistical loop where the benchmark lives."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def q():
+    import qecmc
+    assert qecmc.device_count() >= 1
+    return qecmc
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+def rand_states(rng, n, L, p):
+    m = np.zeros((n, 2, L, L), dtype=np.uint8)
+    err = rng.random(m.shape) < p
+    m[err] = rng.integers(1, 4, size=int(err.sum()), dtype=np.uint8)
+    return m
+
+
+def rand_plaq(rng, n, L, p):
+    m = np.zeros((n, L, L), dtype=np.uint8)
+    err = rng.random(m.shape) < p
+    m[err] = rng.integers(1, 4, size=int(err.sum()), dtype=np.uint8)
+    return m
+
+
+# ------------------------------------------------------------------ replicas
+@pytest.mark.parametrize("N,R,L,Nc,first", [(5, 7, 5, 5, 0), (3, 64, 5, 4, 1000), (1, 100, 3, 3, 0), (70, 3, 5, 5, 17)])
+def test_replicas_equal_R_separate_oracle_runs_summed(q, orc, N, R, L, Nc, first):
+    rng = np.random.default_rng(N * 100 + R)
+    init = rand_states(rng, N, L, 0.12)
+    got = q.pteq_batch(init, 0.12, Nc=Nc, steps=150, iters=10, tops_burn=1, seed=99, first_syndrome=first, replicas=R, return_states=True)
+    # ladder l = s*R + r starts from init[s] and draws from Philox syndrome index first + l
+    ref = orc.toric_pteq_batch(np.repeat(init, R, axis=0), 0.12, Nc, 150, iters=10, tops_burn=1, seed=99, first_syndrome=first,
+                               return_states=True)
+    assert np.array_equal(got["counts"], ref["counts"].reshape(N, R, 16).sum(axis=1))
+    assert np.array_equal(got["samples"], ref["samples"].reshape(N, R).sum(axis=1).astype(np.uint32))
+    assert np.array_equal(got["tops0"], ref["tops0"].reshape(N, R).sum(axis=1).astype(np.uint32))
+    assert np.array_equal(got["states"], ref["states"])                       # [N*R, Nc, ...] per ladder
+
+
+def test_replicas_with_convergence_criterion(q, orc):
+    rng = np.random.default_rng(8)
+    init = rand_states(rng, 2, 3, 0.1)
+    R = 20
+    got = q.pteq_batch(init, 0.1, Nc=3, steps=4000, tops_burn=2, seed=4, replicas=R, conv_criteria="error_based", TOPS=6, SEQ=2, eps=0.2)
+    ref = orc.toric_pteq_batch(np.repeat(init, R, axis=0), 0.1, 3, 4000, tops_burn=2, seed=4, conv_criteria="error_based", TOPS=6, SEQ=2, eps=0.2)
+    assert ref["converged"].any()
+    assert np.array_equal(got["counts"], ref["counts"].reshape(2, R, 16).sum(axis=1))
+    assert np.array_equal(got["steps_done"], ref["steps_done"].reshape(2, R).max(axis=1).astype(np.uint32))   # the slowest ladder
+    assert np.array_equal(got["converged"], ref["converged"].reshape(2, R).all(axis=1))
+
+
+def test_pteq_dropin_uses_replicas(q, orc):
+    """decoders.PTEQ(code, p) is one syndrome per call (decoders.py:25): the drop-in fills the wavefronts with
+    PTEQ_REPLICAS independent ladders and forms the percent vector from their summed counts."""
+    from qecmc import decoders
+    rng = np.random.default_rng(2)
+    code = q.Toric_code(5)
+    code.qubit_matrix = rand_states(rng, 1, 5, 0.1)[0]
+    pct = q.PTEQ(code, 0.1, Nc=5, steps=300, iters=10, tops_burn=1, conv_criteria=None, seed=31)
+    R = decoders.PTEQ_REPLICAS
+    ref = orc.toric_pteq_batch(np.repeat(code.qubit_matrix[None], R, axis=0), 0.1, 5, 300, iters=10, tops_burn=1, seed=31)
+    assert np.array_equal(pct, decoders.percent_from_counts(ref["counts"].sum(axis=0), ref["samples"].sum()))
+
+
+# ------------------------------------------------------------------ swap / error-count observables
+def _oracle_stats(orc, kind, init, p, Nc, steps, iters, seed, syn, eta=0.0):
+    rng = orc.Rng.philox(seed, syn)
+    if kind == "toric":
+        ld = orc.ToricLadder(init, p, Nc, 0.5)
+    else:
+        code = {"xzzx": orc.XZZX, "xzzxb": orc.XZZX, "rot": orc.ROTATED, "planar": orc.PLANAR}[kind]
+        ld = orc.Ladder(code, init, p, Nc, 0.5, noise=orc.BIASED if kind == "xzzxb" else orc.DEPOLARIZING, eta=eta)
+    for _ in range(steps):
+        ld.step(iters, rng)
+    return ld.swap_accepts, ld.nerr_sums
+
+
+@pytest.mark.parametrize("kind,L,Nc,p,eta", [("toric", 5, 5, 0.1, 0), ("toric", 9, 8, 0.15, 0), ("toric", 4, 2, 0.1, 0), ("rot", 7, 7, 0.17, 0),
+                                             ("xzzx", 5, 4, 0.15, 0), ("xzzxb", 5, 5, 0.15, 100.0), ("planar", 5, 5, 0.12, 0)])
+def test_swap_and_error_statistics_bit_exact(q, orc, kind, L, Nc, p, eta):
+    rng = np.random.default_rng(L * 10 + Nc)
+    N, steps = 70, 120
+    if kind == "toric":
+        init, code = rand_states(rng, N, L, p), q.TORIC
+    elif kind == "planar":
+        init, code = rand_states(rng, N, L, p), q.PLANAR
+        init[:, 1, -1, :] = 0; init[:, 1, :, -1] = 0
+    else:
+        init, code = rand_plaq(rng, N, L, p), (q.ROTATED if kind == "rot" else q.XZZX)
+    got = q.pteq_batch(init, p, Nc=Nc, steps=steps, iters=10, tops_burn=0, seed=5, first_syndrome=40, code=code,
+                       eta=eta if kind == "xzzxb" else None, return_swap_stats=True)
+    assert got["swap_accepts"].shape == (N, Nc - 1) and got["nerr_sums"].shape == (N, Nc)
+    for s in (0, 1, 33, 63, 64, 69):
+        acc, nsum = _oracle_stats(orc, kind, init[s], p, Nc, steps, 10, 5, 40 + s, eta)
+        assert np.array_equal(got["swap_accepts"][s], acc.astype(np.uint32)), (s, got["swap_accepts"][s], acc)
+        assert np.array_equal(got["nerr_sums"][s], nsum.astype(np.uint32)), (s, got["nerr_sums"][s], nsum)
+    # the observables do not disturb the run
+    plain = q.pteq_batch(init, p, Nc=Nc, steps=steps, iters=10, tops_burn=0, seed=5, first_syndrome=40, code=code,
+                         eta=eta if kind == "xzzxb" else None)
+    assert np.array_equal(plain["counts"], got["counts"]) and np.array_equal(plain["tops0"], got["tops0"])
+
+
+@pytest.mark.parametrize("name", ["toric_L9", "rot_L5", "rot_L7", "xzzxb_L5", "xzzxb_L7"])
+def test_reference_equilibrium_observables_f5(q, name):
+    """Fixture F5: the reference's own ladders (R=16 replicas x 3 syndromes, 20 000 steps, first 20 % discarded) against the GPU
+    (512 replicas per syndrome, the same run length and burn-in: a run of `burn` steps is the exact prefix of the run of
+    `steps`, so the difference of the two is the post-burn-in window).  Per-rung <n_errors> and per-pair swap acceptance
+    within the combined standard error; class histograms with the heavy-tail allowance of test_reference_histograms_f3."""
+    g = np.load(os.path.join(GOLDEN, "f5_stats.npz"))
+    L, p, eta, Nc, iters, steps, burn = g[f"{name}_par"]
+    L, Nc, iters, steps, burn = int(L), int(Nc), int(iters), int(steps), int(burn)
+    code = q.TORIC if name.startswith("toric") else q.XZZX if name.startswith("xzzx") else q.ROTATED
+    kw = dict(Nc=Nc, iters=iters, tops_burn=0, code=code, eta=float(eta) if name.startswith("xzzxb") else None, return_swap_stats=True)
+    R, win = 512, steps - burn
+    for s in range(g[f"{name}_init"].shape[0]):
+        init = np.broadcast_to(g[f"{name}_init"][s], (R,) + g[f"{name}_init"][s].shape).copy()
+        a = q.pteq_batch(init, float(p), steps=burn, seed=600 + s, **kw)
+        b = q.pteq_batch(init, float(p), steps=steps, seed=600 + s, **kw)
+        acc = (b["swap_accepts"].astype(np.int64) - a["swap_accepts"]) / win          # [R, Nc-1] acceptance per replica
+        nerr = (b["nerr_sums"].astype(np.int64) - a["nerr_sums"]) / win               # [R, Nc]
+        hist = (b["counts"].astype(np.int64) - a["counts"]) / win
+        r_acc = g[f"{name}_swap_acc"][s] / g[f"{name}_swap_att"][s]
+        r_n = g[f"{name}_nerr"][s]
+        r_h = g[f"{name}_hist"][s] / win
+
+        def close(ref, gpu, k, floor):
+            se = np.sqrt(ref.var(axis=0, ddof=1) / ref.shape[0] + gpu.var(axis=0, ddof=1) / gpu.shape[0])
+            d = np.abs(ref.mean(axis=0) - gpu.mean(axis=0))
+            assert np.all(d <= k * se + floor), (name, s, ref.mean(axis=0), gpu.mean(axis=0), se)
+        close(r_acc, acc, 4.5, 2e-3)
+        close(r_n, nerr, 4.5, 0.05)
+        close(r_h, hist, 4.5, 0.03)
+
+
+# ------------------------------------------------------------------ exact chunked continuation
+@pytest.mark.parametrize("code_name,L,Nc,eta", [("toric", 5, 5, None), ("rotated", 7, 7, None), ("xzzx", 5, 5, 30.0)])
+def test_chunked_continuation_is_one_long_run(q, orc, code_name, L, Nc, eta):
+    from qecmc import harness
+    rng = np.random.default_rng(4)
+    code = harness._CODES[code_name]
+    init = rand_states(rng, 80, L, 0.1) if code_name == "toric" else rand_plaq(rng, 80, L, 0.1)
+    full = q.pteq_batch(init, 0.12, Nc=Nc, steps=300, iters=10, tops_burn=2, seed=21, first_syndrome=7, code=code, eta=eta, return_states=True)
+    run = harness.LadderRun(init, 0.12, Nc=Nc, iters=10, tops_burn=2, seed=21, first_syndrome=7, code=code, eta=eta)
+    for chunk in (1, 99, 37, 163):
+        run.advance(chunk)
+    snap = run.snapshot(states=True)
+    assert snap["steps"] == 300
+    for k in ("counts", "samples", "tops0", "states"):
+        assert np.array_equal(snap[k], full[k]), k
+
+
+def test_convergence_study_continues_exactly(q):
+    from qecmc import harness
+    rng = np.random.default_rng(9)
+    raw = harness.draw_errors("rotated", 7, 96, 0.12, rng)
+    out = harness.convergence_study(raw, 0.12, [100, 400, 1600], Nc=7, seed=4, code=q.ROTATED, chunk=500)
+    for i, c in enumerate((100, 400, 1600)):
+        one = q.pteq_batch(raw, 0.12, Nc=7, steps=c, iters=10, tops_burn=0, seed=4, code=q.ROTATED)
+        assert np.array_equal(out["counts"][i], one["counts"]) and np.array_equal(out["samples"][i], one["samples"])
+
+
+# ------------------------------------------------------------------ harness: shards, resume, metrics, threshold curve (f1)
+def test_shards_resume_bit_for_bit(q, tmp_path):
+    from qecmc import harness
+    params = {"code": "toric", "size": 5, "p_error": 0.08, "noise": "depolarizing"}
+    kw = dict(steps=400, conv_criteria=None, tops_burn=1)
+    log = []
+    paths = harness.generate_shards(params, 250, 100, str(tmp_path), seed=3, log=log, **kw)
+    assert [os.path.basename(p) for p in paths] == [harness.shard_name("data", 3, k) for k in range(3)]
+    assert len(log) == 3 and all(os.path.exists(p) for p in paths)
+    first = [dict(np.load(p)) for p in paths]
+    assert [f["eq_true"].shape[0] for f in first] == [100, 100, 50]
+    # metrics line: proposals, rates, swap acceptance per rung pair, tops0 histogram, success rate
+    lines = [json.loads(ln) for ln in open(tmp_path / "data_metrics.jsonl")]
+    assert len(lines) == 3 and lines[1]["shard"] == 1 and lines[2]["syndromes"] == 50
+    assert lines[0]["proposals"] == 100 * 5 * 10 * 400 and len(lines[0]["swap_acceptance"]) == 4 and len(lines[0]["tops0_hist"]) == 21
+    assert 0 <= lines[0]["success_rate"] <= 1 and lines[0]["chain_sweeps_per_s_kernel"] > 0
+    # resume: delete one shard, run again -> only that one is remade, bit for bit; the others are untouched
+    mt = [os.path.getmtime(p) for p in paths]
+    os.remove(paths[1])
+    log2 = []
+    harness.generate_shards(params, 250, 100, str(tmp_path), seed=3, log=log2, **kw)
+    assert [ln["shard"] for ln in log2] == [1]
+    again = dict(np.load(paths[1]))
+    assert all(np.array_equal(again[k], first[1][k]) for k in first[1])
+    assert os.path.getmtime(paths[0]) == mt[0] and os.path.getmtime(paths[2]) == mt[2]
+    # a shard does not depend on which other shards were made: shard 2 alone in a fresh directory
+    solo = harness.generate(params, 50, seed=3, rng=np.random.default_rng([3, 2]), first_syndrome=200, **kw)
+    assert np.array_equal(solo["counts"], first[2]["counts"]) and np.array_equal(solo["qubit_matrix"], first[2]["qubit_matrix"])
+
+
+def test_threshold_curve(q):
+    """p in [0.05, 0.20] (generate_data.py's scan): the success rate falls with p and is near 1 well below threshold."""
+    from qecmc import harness
+    params = {"code": "toric", "size": 5, "noise": "depolarizing"}
+    out = harness.threshold_curve(params, [0.05, 0.10, 0.15, 0.20], 512, seed=1, steps=20000, conv_criteria=None, tops_burn=2)
+    assert out["success_rate"].shape == (4,) and np.all(out["err"] < 0.03)
+    assert out["success_rate"][0] > 0.9 and out["success_rate"][0] > out["success_rate"][3] + 5 * out["err"][3]
+    assert np.all(np.diff(out["success_rate"]) < 3 * out["err"][1:] + 1e-9)           # non-increasing within error
+    assert out["metrics"][0]["frac_past_burn_in"] > 0.5

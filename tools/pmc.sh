@@ -1,4 +1,4 @@
-# usage: tools/pmc.sh <tag> <bench args...>   -> gpurun_out/pmc_<tag>.txt
+# usage: tools/pmc.sh <tag> <bench args...>   -> gpurun_out/pmc_<tag>.txt  (two PMC passes of the ladder kernel, averaged per launch)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 tag=$1; shift
 mkdir -p gpurun_out/prof
@@ -15,3 +15,4 @@ with open("gpurun_out/pmc_$tag.txt","w") as o:
     for k in sorted(acc): o.write("%-24s %.4e\n" % (k, sum(acc[k])/len(acc[k])))
 print(open("gpurun_out/pmc_$tag.txt").read())
 PY
+rm -rf gpurun_out/prof/$tag.a gpurun_out/prof/$tag.b
