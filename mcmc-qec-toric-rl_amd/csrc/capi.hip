@@ -213,7 +213,7 @@ std::vector<uint32_t> surf_generator_table(int code, int L)
 struct qecmc_plan {
     qecmc_params prm;
     LadderArgs args;
-    DevBuf swap_thr, lmask, acc_top, gen, bias, lnb;
+    DevBuf swap_thr, lmask, acc_top, gen, bias, lnb, xyz_lut, gen_type;
     size_t lds_bytes;
     uint32_t *d_swap_acc = nullptr, *d_nerr_sum = nullptr;   // qecmc_plan_set_stats (caller-owned)
 };
@@ -259,6 +259,7 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
     const bool biased = p->noise == QECMC_NOISE_BIASED || alpha;     // table-driven acceptance pn / pb
     a.code = p->code; a.noise = p->noise; a.alpha = p->alpha;
     a.replicas = p->replicas > 1 ? (uint32_t)p->replicas : 1u;
+    if (const char *tv = std::getenv("QECMC_TUNE")) a.tune = (uint32_t)std::strtoul(tv, nullptr, 0);   // development knobs, see kernels.hpp
     a.L = L; a.Nc = Nc; a.W = W; a.nq = nq; a.ncls = ncls;
     a.iters = (uint32_t)p->iters;
     a.seed_lo = (uint32_t)p->seed; a.seed_hi = (uint32_t)(p->seed >> 32);
@@ -268,11 +269,36 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
     const uint32_t n_gen = p->code == QECMC_TORIC ? 2u * L * L : (uint32_t)surf_ngen(p->code, L);
     if (n_gen > kMaxGenLds)   // every kernel path stages the generator table in LDS
         return fail(QECMC_ERR_UNSUPPORTED, "L=%d: %u generators exceed the LDS table of %u (needed by scan=1 and by the xzzx / rotated codes)", L, n_gen, kMaxGenLds);
-    pl->lds_bytes = ladder_lds_bytes(L, Nc, W, ncls, ladder_gen_dwords(p->code, p->noise, p->scan, n_gen, Nc));
-    if (biased) {   // the rule's power tables go to LDS when two workgroups still fit a CU (they are read per lane, per proposal)
-        const size_t with = ladder_lds_bytes(L, Nc, W, ncls, ladder_gen_dwords(p->code, p->noise, p->scan, n_gen, Nc, nq, 1));
-        if (with <= 80 * 1024) { a.bias_lds = 1; pl->lds_bytes = with; }
+    const std::vector<uint32_t> gt = p->code == QECMC_TORIC ? toric_generator_table(L) : surf_generator_table(p->code, L);
+    std::vector<uint8_t> gen_type(gt.size() / 2, 0);
+    std::vector<uint32_t> xyz_lut;
+    if (biased) {
+        // the biased / alpha rules' table of count changes: one row of 256 (the four old 2-bit fields) per distinct Pauli
+        // pattern among the generators; entry = dx + (dz << 10) + ((dx + dy) << 20), wrapping (added to packed counts)
+        if (nq > 511) return fail(QECMC_ERR_UNSUPPORTED, "biased / alpha noise packs the error counts in 10-bit fields: nq=%d", nq);
+        std::vector<uint32_t> patterns;
+        for (size_t g = 0; g < gen_type.size(); ++g) {
+            uint32_t ops = 0;
+            for (int u = 0; u < 4; ++u) ops |= ((u < 2 ? gt[2 * g] >> (16 * u) : gt[2 * g + 1] >> (16 * (u - 2))) & 3u) << (2 * u);
+            size_t t = 0;
+            while (t < patterns.size() && patterns[t] != ops) ++t;
+            if (t == patterns.size()) patterns.push_back(ops);
+            gen_type[g] = (uint8_t)t;
+        }
+        if (patterns.size() > 16) return fail(QECMC_ERR_UNSUPPORTED, "%zu distinct generator Pauli patterns (> 16)", patterns.size());
+        a.n_types = (int)patterns.size();
+        xyz_lut.assign(256 * patterns.size(), 0u);
+        for (size_t t = 0; t < patterns.size(); ++t)
+            for (uint32_t F = 0; F < 256; ++F) {
+                int d[4] = {0, 0, 0, 0};                                     // change of the counts of I, X, Y, Z
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t old = (F >> (2 * u)) & 3u, neu = old ^ ((patterns[t] >> (2 * u)) & 3u);
+                    d[old]--; d[neu]++;
+                }
+                xyz_lut[256 * t + F] = (uint32_t)d[1] + ((uint32_t)d[3] << 10) + ((uint32_t)(d[1] + d[2]) << 20);
+            }
     }
+    pl->lds_bytes = ladder_lds_bytes(L, Nc, W, ncls, ladder_gen_dwords(p->code, p->noise, p->scan, n_gen, Nc, nq, a.n_types));
     if (pl->lds_bytes > 160 * 1024)
         return fail(QECMC_ERR_UNSUPPORTED, "L=%d Nc=%d needs %zu B of LDS per workgroup (> 160 KiB)", L, Nc, pl->lds_bytes);
 
@@ -304,7 +330,6 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
     const std::vector<uint32_t> lm = p->code == QECMC_TORIC ? toric_logical_masks(L, W) : surf_logical_masks(p->code, L, W);
     a.scan = p->scan;
     {
-        const std::vector<uint32_t> gt = p->code == QECMC_TORIC ? toric_generator_table(L) : surf_generator_table(p->code, L);
         a.n_gen = (uint32_t)(gt.size() / 2);
         HIP_TRY(pl->gen.alloc(gt.size() * sizeof(uint32_t)));
         HIP_TRY(hipMemcpy(pl->gen.p, gt.data(), gt.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -319,6 +344,18 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
         HIP_TRY(pl->bias.alloc(bt.size() * sizeof(double)));
         HIP_TRY(hipMemcpy(pl->bias.p, bt.data(), bt.size() * sizeof(double), hipMemcpyHostToDevice));
         a.bias_tbl = pl->bias.as<double>();
+        for (int c = 0; c < Nc; ++c) {
+            // log2(px / pI), log2(pz / pI) of rung c (px = py in both models: bias_tables / alpha_tables): the fast test's slopes
+            const double *t = &bt[(size_t)c * 4 * (nq + 1)];
+            a.bias_l2[c][0] = std::log2(t[1] / t[3 * (nq + 1) + 1]);
+            a.bias_l2[c][1] = std::log2(t[2 * (nq + 1) + 1] / t[3 * (nq + 1) + 1]);
+        }
+        HIP_TRY(pl->xyz_lut.alloc(xyz_lut.size() * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpy(pl->xyz_lut.p, xyz_lut.data(), xyz_lut.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(pl->gen_type.alloc(gen_type.size()));
+        HIP_TRY(hipMemcpy(pl->gen_type.p, gen_type.data(), gen_type.size(), hipMemcpyHostToDevice));
+        a.xyz_lut = pl->xyz_lut.as<uint32_t>();
+        a.gen_type = pl->gen_type.as<uint8_t>();
     }
     if (alpha) {
         std::vector<double> lnb(Nc > 1 ? Nc - 1 : 1, 0.0);
@@ -855,7 +892,6 @@ int qecmc_ptdc_batch_xyz(const qecmc_params *params, const uint8_t *init, uint64
     a.uset_mhist = m_out ? dm.as<uint32_t>() : nullptr; a.uset_D = (uint32_t)D; a.uset_per_rung = per_rung ? 1 : 0;
     a.uset_conv_mult = conv_mult; a.uset_own = own ? reinterpret_cast<unsigned long long *>(down.p) : nullptr; a.uset_own_cap = own_cap;
     a.steps_done = steps_done_out ? dsd.as<uint32_t>() : nullptr;
-    a.bias_lds = 0;                                                  // (alpha droplets: one rung's tables, read through the cache)
     a.uset_xyz = xyz_out ? dxyz.as<uint32_t>() : nullptr; a.uset_xyz_cnt = xyz_out ? dxc.as<uint32_t>() : nullptr; a.uset_xyz_stride = maxu;
     a.xyz_thr = xyz_thr.empty() ? nullptr : dthr.as<uint64_t>();
     {

@@ -45,7 +45,12 @@ struct LadderArgs {
     uint64_t uset_xyz_stride;
     // Chain_xyz (mcmc.py:106-114,162-173; 1-chain ladders): accept iff v44 < xyz_thr[dx+4][dy+4][dz+4]; nullable
     const uint64_t *xyz_thr;        // [9][9][9]   ceil(w * 2^44): the 44-bit acceptance uniform of a non-top proposal
-    int bias_lds;             //                    the kernel copies bias_tbl into LDS (fits: capi.hip decides)
+    // biased / alpha rules: the count change of a generator move from an LDS table, and the fast acceptance test
+    const uint32_t *xyz_lut;  // [n_types][256]     dx + (dz << 10) + ((dx + dy) << 20) (wrapping) of applying a generator of Pauli pattern
+                              //                    `type` to four sites holding the 2-bit fields of the index
+    const uint8_t *gen_type;  // [n_gen]            Pauli-pattern id of every generator
+    int n_types;              //                    distinct Pauli patterns among the generators (<= 16)
+    double bias_l2[kMaxNc][2];//                    log2(px / pI), log2(pz / pI) per rung (px = py in both noise models)
     const double *alpha_lnb;  // [Nc-1]             ln(pz_tilde[i] / pz_tilde[i+1]) (alpha noise, mcmc_alpha.py:123)
     double alpha;             //                    mcmc_alpha.py:11
     uint32_t *neff;           // [N][Nc]            alpha noise: the slots' n_eff attributes as n_z | (n_x+n_y) << 16; resume in / out
@@ -76,6 +81,7 @@ struct LadderArgs {
     int write_states;
     // replicas R >= 1: a.N counts LADDERS (syndromes x R); ladder l starts from init row l / R and adds its class counts, samples
     // and tops0 to the outputs of syndrome l / R (atomics; the caller zeroes them) -- decoders.py:215-225 "droplets"
+    uint32_t tune;            // development knobs (QECMC_TUNE; 0 in production): bit 0 = the top-role wave runs at the highest issue priority
     uint32_t replicas;
     int accumulate;           // counts / samples are added to (qecmc_pteq_resume_dev)
     // equilibrium observables (qecmc_plan_set_stats; nullable): accepted swaps per rung pair, sum of error counts per rung
@@ -91,8 +97,10 @@ constexpr uint32_t kMaxGenLds = 2048;   // generator tables up to this many entr
 // generators the expanded table is stored as two halves kGenSplit entries apart (sites 0,1 | sites 2,3).
 // alpha noise appends the double-buffered n_eff records [2][Nc][64] to the region
 constexpr int kGenSplit = 255;      // ds_read2_b64's second offset is an 8-bit count of 8-byte units
-// ... and, when the plan says so (LadderArgs::bias_lds), the biased / alpha rule's power tables double[Nc][4][nq+1]
-inline int ladder_gen_dwords(int code, int noise, int scan, uint32_t n_gen, int Nc, int nq = 0, int bias_lds = 0)
+// ... and the biased / alpha rules' count-change table uint32[n_types][256] and packed per-state counts uint32[Nc][64]
+// lattice size of a plaquette code from its qubit count (xzzx / rotated: L x L; planar: 2 L^2 with an idle row and column)
+inline int nq_L(int code, int nq) { int L = 1; while ((code == 3 ? 2 * L * L : L * L) < nq) ++L; return L; }
+inline int ladder_gen_dwords(int code, int noise, int scan, uint32_t n_gen, int Nc, int nq = 0, int n_types = 0)
 {
     // depolarizing random scan: the expanded table of the non-top proposal loop; the plaquette codes also keep the plan's
     // form for their top-chain / general paths
@@ -100,7 +108,7 @@ inline int ladder_gen_dwords(int code, int noise, int scan, uint32_t n_gen, int 
     const int wide_dw = (!noise && (int)n_gen <= kGenSplit) ? 2 * (kGenSplit + (int)n_gen) : 4 * (int)n_gen;
     int d = wide ? (code == 0 ? wide_dw : ((2 * (int)n_gen + 3) & ~3) + wide_dw) : 2 * (int)n_gen;
     if (noise == 2) d = ((d + 3) & ~3) + 2 * Nc * 64;
-    if (noise && bias_lds) d = ((d + 3) & ~3) + 2 * Nc * 4 * (nq + 1);
+    if (noise) d = ((d + 3) & ~3) + 256 * n_types + Nc * 64 + 2 * (nq_L(code, nq) + 1) * ((nq + 15) / 16);   // + the X / Z logical masks [2][L+1][W]
     return d;
 }
 hipError_t launch_ladder_rs_toric(const LadderArgs &a, hipStream_t stream);

@@ -1,0 +1,1612 @@
+// Random-scan parallel-tempering ladder kernel (gfx950): toric, XZZX, rotated and planar codes; depolarizing, biased and
+// alpha acceptance rules; the reference's random scan and the systematic sweep.
+//
+// This is the reference's Markov chain (src/mcmc.py:19-43 Chain.update_chain,
+// :94-103 Ladder.step, decoders.py:55-68 PTEQ bookkeeping) laid out for CDNA4:
+//
+//   * one workgroup = 64 syndromes x Nc ladder slots; wavefront w owns slot w
+//     (temperature p_ladder[w]) of all 64 syndromes, lane l owns syndrome l.
+//     Acceptance thresholds are therefore wave-uniform and the top slot's
+//     logical-operator branch (mcmc.py:23) never diverges against the
+//     stabilizer-only slots.
+//   * every chain's qubit_matrix lives in LDS for the whole run, packed 2 bits
+//     per qubit: word w of state s of lane l sits at dword (s*W + w)*64 + l, so a
+//     wave's ds_read_b32 / ds_xor_b32 hit bank (l mod 32) whatever (s, w) each
+//     lane picks: random-scan access with zero bank conflicts, and addresses
+//     need one add only.
+//   * proposals: one Philox4x32-10 block feeds TWO non-top proposals (a word that picks one of the G generators,
+//     g = (x * G) >> 32, and the acceptance word, each); the generator's sites come from an LDS table; accept tests
+//     are integer compares against host-built thresholds ceil(f^dE * 2^32), so results are bit-identical to
+//     the CPU oracle fed the same Philox stream.
+//   * the top slot sits at p = 0.75 where every proposal is accepted
+//     (mcmc.py:30): its moves are fire-and-forget LDS XORs (no reads, no dE) and
+//     its error count is recounted once per ladder step.
+//   * swaps (mcmc.py:96-103) move slot->state indices, not data; error counts and
+//     equivalence classes are carried incrementally per state (n += dE; class ^=
+//     logical delta) instead of recounted (mcmc.py:88-89, toric_model.py:317).
+//   * one barrier per ladder step: every wave publishes its slot record (error
+//     count, state id, class, flag) and then replays the whole top-down swap
+//     cascade (mcmc.py:96-103) itself from those records to learn which state
+//     lands in its own slot -- a few integer ops per rung (the swap uniform is turned into the largest accepted
+//     error-count difference before the barrier), no serial section
+//     that leaves seven waves idle, no second barrier.
+//   * HBM traffic is compulsory only: nq bytes in, ncls counters out per syndrome.
+#pragma once
+#include "kernels.hpp"
+#include "philox.hpp"
+#include "stencil_bytes.hpp"   // kCode* constants
+
+namespace qecmc {
+
+// LDS carve-up in dwords (keep in sync with the kernel)
+__host__ __device__ inline int ladder_group_dwords(int Nc, int W, int ncls, int gen_dwords)
+{
+    // st + info[2] + swx[2] + hist + thrT + swapT + stop flag (16) + generator table
+    int d = Nc * W * 64 + 4 * Nc * 64 + ncls * 64 + Nc * 9 + Nc * kSwapFast + 16;
+    d = (d + 3) & ~3;          // 16-byte aligned generator table (ds_read_b128 entries)
+    return d + ((gen_dwords + 3) & ~3);
+}
+
+__device__ __forceinline__ uint32_t nnz2(uint32_t x) { return __popc((x | (x >> 1)) & 0x55555555u); }
+
+__device__ __forceinline__ uint32_t sel4(const u32x4 &b, int i)
+{
+    return i == 0 ? b.x : i == 1 ? b.y : i == 2 ? b.z : b.w;
+}
+
+// single-instruction forms: the hardware uses only bits [4:0] of a shift amount / field offset, so the upper bits of the
+// table entry that supplies them need no masking
+__device__ __forceinline__ uint32_t bfe2_lo5(uint32_t w, uint32_t e)
+{
+    return __builtin_amdgcn_ubfe(w, e, 2u);                 // v_bfe_u32 w, e, 2
+}
+// (a << k) | b in one instruction (left to itself the compiler merges three fields with three shifts and two ors)
+__device__ __forceinline__ uint32_t lshl_or(uint32_t a, int k, uint32_t b)
+{
+    uint32_t r;
+    asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "n"(k), "v"(b));
+    return r;
+}
+
+// a ^ byte 1 of b / (byte 1 of v) << (e & 31): the byte select rides on the instruction (SDWA), no shift or mask of its own
+__device__ __forceinline__ uint32_t xor_byte1(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t shl_byte1(uint32_t e, uint32_t v)
+{
+    uint32_t r;
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(e), "v"(v));
+    return r;
+}
+
+__device__ __forceinline__ uint32_t shl_lo5(uint32_t v, uint32_t e)
+{
+    return v << (e & 31u);                                  // v_lshlrev_b32: the mask folds away
+}
+
+__device__ __forceinline__ void lds_xor(uint32_t *p, uint32_t v)
+{
+    __hip_atomic_fetch_xor(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_xor_b32, no return
+}
+
+// The four qubits of stabilizer (row, col, op), toric_model.py:261-269, as flat
+// indices into uint8[2][L][L]:  X: (1,r,c) (0,r,c) (1,r,c-1) (0,r-1,c)
+//                               Z: (1,r,c) (0,r,c) (0,r,c+1) (1,r+1,c)
+__device__ __forceinline__ void toric_sites(uint32_t L, uint32_t LL, uint32_t row, uint32_t col, uint32_t isX,
+                                            uint32_t q[4])
+{
+    const uint32_t rL = row * L;
+    const uint32_t cm = (col == 0 ? L : col) - 1, cp = (col + 1 == L ? 0 : col + 1);
+    const uint32_t rm = (row == 0 ? L : row) - 1, rp = (row + 1 == L ? 0 : row + 1);
+    const uint32_t cn = isX ? cm : cp, rn = isX ? rm : rp;
+    q[0] = LL + rL + col;
+    q[1] = rL + col;
+    q[2] = rL + cn + (isX ? LL : 0u);
+    q[3] = rn * L + col + (isX ? 0u : LL);
+}
+
+// class of a packed state, toric_model.py:317-351: X component = b0^b1 (values 1,2),
+// Z component = b1 (values 2,3); parity is linear, so XOR the words first.
+__device__ __forceinline__ uint32_t toric_class_packed(const uint32_t *sb, int W, int LL)
+{
+    const int wb = LL >> 4;
+    const uint32_t lowmask = (1u << ((LL & 15) * 2)) - 1u;    // layer-0 fields of the boundary word
+    uint32_t acc0 = 0, acc1 = 0;
+    for (int w = 0; w < W; ++w) {
+        const uint32_t x = sb[w * 64];
+        if (w < wb) acc0 ^= x;
+        else if (w > wb) acc1 ^= x;
+        else { acc0 ^= x & lowmask; acc1 ^= x & ~lowmask; }
+    }
+    const uint32_t x1 = __popc((acc0 ^ (acc0 >> 1)) & 0x55555555u) & 1u, z1 = __popc(acc0 & 0xAAAAAAAAu) & 1u;
+    const uint32_t x2 = __popc((acc1 ^ (acc1 >> 1)) & 0x55555555u) & 1u, z2 = __popc(acc1 & 0xAAAAAAAAu) & 1u;
+    return x1 + 2u * z1 + 4u * x2 + 8u * z2;
+}
+
+// ---- XZZX / rotated codes on the packed state (one L x L layer) ---------------------------------
+// internal class value v = xparity | zparity << 1; rotated class = v (rotated_surface_model.py:411-420),
+// XZZX class = v ^ (v >> 1) (xzzx_model.py:474-486 maps (1,0)->1, (1,1)->2, (0,1)->3)
+__device__ __forceinline__ uint32_t surf_class_packed(int code, const uint32_t *sb, int L)
+{
+    uint32_t x = 0, z = 0;
+    for (int i = 0; i < L; ++i) {
+        const uint32_t qa = (uint32_t)i, qb = (uint32_t)(i * L);
+        const uint32_t fa = (sb[(qa >> 4) * 64] >> ((qa & 15u) * 2u)) & 3u;    // row 0
+        const uint32_t fb = (sb[(qb >> 4) * 64] >> ((qb & 15u) * 2u)) & 3u;    // column 0
+        const uint32_t xa = (fa ^ (fa >> 1)) & 1u, za = fa >> 1, xb = (fb ^ (fb >> 1)) & 1u, zb = fb >> 1;   // X / Z components
+        if (code == kCodeXzzx) {            // row 0 counts Y, X at even i, Z at odd i; column 0 the other way round
+            x ^= (i & 1) ? za : xa;
+            z ^= (i & 1) ? xb : zb;
+        } else if (code == kCodePlanar) {   // X/Y parity of layer 0's first column, Z/Y parity of its first row (planar_model.py:379-390)
+            x ^= xb;
+            z ^= za;
+        } else {
+            x ^= xa;
+            z ^= zb;
+        }
+    }
+    return x | (z << 1);
+}
+
+// counts of X, Y, Z fields in one packed word
+__device__ __forceinline__ void count_xyz(uint32_t w, int &nx, int &ny, int &nz)
+{
+    const uint32_t b0 = w & 0x55555555u, b1 = (w >> 1) & 0x55555555u;
+    nx += __popc(b0 & ~b1); ny += __popc(b1 & ~b0); nz += __popc(b0 & b1);
+}
+
+// slot record published once per ladder step: error count | state id << 16 | class << 24 | flag << 31
+// (flag = "has been at the top since it last reached the bottom", Chain.flag, mcmc.py:75,99-103)
+__device__ __forceinline__ uint32_t pack_info(uint32_t n, uint32_t sid, uint32_t cls, uint32_t flag)
+{
+    return n | (sid << 16) | (cls << 24) | (flag << 31);
+}
+
+// CONV: build with the error_based convergence criterion (its per-lane window sums cost ~10 VGPRs,
+// so fixed-step runs use the instantiation without it)
+// GSPLIT: the expanded generator table of the toric random-scan path is stored as two halves kGenSplit entries apart
+// (sites 0,1 | sites 2,3): one ds_read2_b64 with a constant second offset costs ~15 LDS cycles for random entries,
+// 16 adjacent bytes ~21 (tools/ubench_lds.hip).  Needs n_gen <= kGenSplit (toric L <= 11); unused by the BIASED instantiations.
+// exp(y) for y <= 0 from IEEE multiply / add / fma only: the same operation sequence as the oracle's orc_det_exp, so the
+// swap decision of the alpha ladder is bit-identical on both sides.  y >= 0 returns 1; below 2^-1022 flushes to 0.
+__device__ inline double det_exp(double y)
+{
+#pragma clang fp contract(off)
+    if (!(y < 0.0)) return 1.0;
+    if (y < -745.0) return 0.0;
+    const double t = y * 1.4426950408889634;
+    const int k = (int)(t - 0.5);
+    double r = __builtin_fma(-(double)k, 6.93147180369123816490e-01, y);
+    r = __builtin_fma(-(double)k, 1.90821492927058770002e-10, r);
+    double q = 1.0 / 6227020800.0;
+    q = __builtin_fma(q, r, 1.0 / 479001600.0);
+    q = __builtin_fma(q, r, 1.0 / 39916800.0);
+    q = __builtin_fma(q, r, 1.0 / 3628800.0);
+    q = __builtin_fma(q, r, 1.0 / 362880.0);
+    q = __builtin_fma(q, r, 1.0 / 40320.0);
+    q = __builtin_fma(q, r, 1.0 / 5040.0);
+    q = __builtin_fma(q, r, 1.0 / 720.0);
+    q = __builtin_fma(q, r, 1.0 / 120.0);
+    q = __builtin_fma(q, r, 1.0 / 24.0);
+    q = __builtin_fma(q, r, 1.0 / 6.0);
+    q = __builtin_fma(q, r, 0.5);
+    q = __builtin_fma(q, r, 1.0);
+    q = __builtin_fma(q, r, 1.0);
+    if (k < -1022) return 0.0;
+    return q * __longlong_as_double((long long)(k + 1023) << 52);
+}
+
+// u < (pz_lo / pz_hi) ** (n_eff_hi - n_eff_lo), mcmc_alpha.py:118-123, with n_eff = n_z + alpha (n_x + n_y) rebuilt from the
+// packed counts exactly as the reference forms it (:58) and the power taken as det_exp(e * ln(base))
+__device__ inline bool alpha_flip(uint32_t x, uint32_t hi, uint32_t lo, double alpha, double lnb)
+{
+#pragma clang fp contract(off)
+    const double ne_hi = (double)(hi & 0xFFFFu) + alpha * (double)(hi >> 16);
+    const double ne_lo = (double)(lo & 0xFFFFu) + alpha * (double)(lo >> 16);
+    const double e = ne_hi - ne_lo;
+    return (double)x * (1.0 / 4294967296.0) < det_exp(e * lnb);
+}
+
+// conv_crit_error_based_PT_alpha, decoders_biasednoise.py:229-238: |mean Q2 - mean Q4| < eps on the n_eff series, each mean
+// formed as (sum n_z + alpha sum n_xy) / len from exact integer sums
+__device__ inline bool alpha_series_close(uint64_t z2, uint64_t xy2, uint32_t den2, uint64_t z4, uint64_t xy4, uint32_t den4,
+                                          double alpha, double eps)
+{
+#pragma clang fp contract(off)
+    const double q2 = ((double)z2 + alpha * (double)xy2) / (double)den2;
+    const double q4 = ((double)z4 + alpha * (double)xy4) / (double)den4;
+    return fabs(q2 - q4) < eps;
+}
+
+// CODE / BIASED: code model (toric, xzzx, rotated) and acceptance rule (src/mcmc.py or src/mcmc_biased.py).
+// The tuned paths are toric + depolarizing; the other combinations share the staging, cascade and bookkeeping.
+// SCAN: false = the reference's random scan; true = systematic sweep (proposal k tests generator k mod G):
+// sites are wave-uniform scalars and one Philox block feeds four proposals.
+// GENTOP: keep the table-driven general top-chain path (toric L > 16, or a 1-chain ladder whose top sits below
+// p = 0.75; always needed by the plaquette codes and the biased rule).  The common toric configurations compile it out,
+// which keeps its registers out of the hot loop.
+// ALPHA (with BIASED): the alpha noise model's ladder (slot-bound n_eff records, floating-point swap test, mcmc_alpha.py)
+// DELUT (toric, split table with >= 64 idle entries between its halves, i.e. 2 L^2 <= 191): a proposal's dE comes from a
+// 512-byte LDS table indexed by the four old fields and the generator's type instead of seven VALU instructions -- the kernel
+// is bound by VALU issue (98 % busy), the LDS array has room.
+// PRE: the top chain's Philox blocks are drawn ahead by the wave that will take the top role -- half of them two steps before,
+// while it works on slot 1, the other half one step before on slot 0 -- and wait in registers (48 VGPRs: only for the shapes
+// whose LDS footprint leaves 4 waves per SIMD anyway).  The draws do not depend on the state, so nothing changes but who
+// is the step's longest wave: at L = 15 the top wave's 10 blocks + frame flush were 2.6 x a non-top wave's step.
+template <int MAXT, int MINW, bool CONV, bool GSPLIT, int CODE, bool BIASED, bool SCAN, bool GENTOP, bool USET = false, bool ALPHA = false,
+          bool PRE = false, bool DELUT = false>
+__global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const LadderArgs a)
+{
+    extern __shared__ uint32_t lds_all[];
+    const int NC = a.Nc, W = a.W, L = a.L, LL = L * L, nq = a.nq, ncls = a.ncls;
+    const int nthreads = NC * 64;                 // threads of one group
+    const int tid = (int)threadIdx.x, lane = tid & 63, slot = tid >> 6;
+    // generator table in LDS: 4 x u16 per generator as the plan stores it, or -- for the toric random-scan hot path --
+    // expanded to 4 x u32 (byte offset << 16 | Pauli x 0x55 << 8 | Pauli << 5 | bit shift) so a site costs one add (its high
+    // half, SDWA) and one bfe
+    constexpr bool kWideGen = !SCAN;                           // every code and rule: the random-scan proposals read the expanded table
+    constexpr bool kSplitGen = kWideGen && GSPLIT && !BIASED;  // (GSPLIT means something else in the BIASED instantiations)
+    constexpr bool kNarrowGen = !kWideGen || CODE != kCodeToric;   // the plan's form: sweep, biased rule, plaquette-code top / general paths
+    const int narrow_dw = kNarrowGen ? (kWideGen ? (2 * (int)a.n_gen + 3) & ~3 : 2 * (int)a.n_gen) : 0;
+    const int wide_dw = kWideGen ? (kSplitGen ? 2 * (kGenSplit + (int)a.n_gen) : 4 * (int)a.n_gen) : 0;
+    const int gen_dw = narrow_dw + wide_dw;
+    constexpr bool alpha_noise = BIASED && ALPHA;               // mcmc_alpha.py: biased rule + slot-bound n_eff swap test
+    // biased / alpha rules: the count-change table [n_types][256] and the packed counts of every state [NC][64]
+    const int lm_dw = BIASED ? 2 * (L + 1) * W : 0;             // ... and the X / Z logical-operator masks [2][L+1][W] (row L = identity)
+    const int neff_dw = alpha_noise ? 2 * NC * 64 : 0, bias_dw = BIASED ? 256 * a.n_types + NC * 64 + lm_dw : 0;
+    const int gen_region = (neff_dw || bias_dw) ? ((gen_dw + 3) & ~3) + neff_dw + bias_dw : gen_dw;
+    const int gdw = ladder_group_dwords(NC, W, ncls, gen_region);   // dwords per group
+    const int gen_off = gdw - ((gen_region + 3) & ~3);           // start of the generator table
+    uint32_t *lds = lds_all;
+    [[maybe_unused]] uint32_t *neffb = lds + gen_off + ((gen_dw + 3) & ~3);   // [2][NC][64] n_z | (n_x+n_y) << 16 per slot, by step parity
+    [[maybe_unused]] uint32_t *xlut = lds + gen_off + ((gen_dw + 3) & ~3) + neff_dw;   // [n_types][256] dx + (dz << 10) + ((dx + dy) << 20)
+    [[maybe_unused]] uint32_t *xyc = xlut + (BIASED ? 256 * a.n_types : 0);           // [NC][64] n_x | n_z << 10 | (n_x + n_y) << 20 of state s
+    [[maybe_unused]] uint32_t *lml = xyc + (BIASED ? NC * 64 : 0);                    // [2][L+1][W] LDS copy of the plan's logical masks
+
+    uint32_t *st = lds;                           // [NC][W][64]   packed states
+    uint32_t *info = st + (size_t)NC * W * 64;    // [2][NC][64]   slot records, double-buffered by step parity
+    uint32_t *swx = info + 2 * NC * 64;           // [2][NC][64]   swap uniform of rung pair i, same parity
+    uint32_t *hist = swx + 2 * NC * 64;           // [ncls][64]
+    uint32_t *thrT = hist + ncls * 64;            // [NC][9]       sweep: accept iff x <= thrT[slot][dE+4]; random scan: the leading
+                                                  //               12 bits of the 44-bit threshold, accept iff a12 < thrT[slot][dE+4]
+    uint32_t *swapT = thrT + NC * 9;              // [NC][kSwapFast]  swap iff x < swapT[i][d]
+    [[maybe_unused]] uint32_t *thrF = swapT + (NC - 1) * kSwapFast;   // [NC][4] (the idle last row of swapT): the low 32 bits of the
+                                                  //               44-bit threshold of dE = 1..4, looked at when a12 == thrT[..]
+    volatile uint32_t *stopf = swapT + NC * kSwapFast;   // [1]  every syndrome of the workgroup has converged
+    [[maybe_unused]] const uint2 *gtab = reinterpret_cast<const uint2 *>(lds + gen_off);   // [n_gen] generator table (LDS copy)
+    [[maybe_unused]] const uint4 *gtab4 = reinterpret_cast<const uint4 *>(lds + gen_off + narrow_dw);  // wide form (kWideGen)
+    [[maybe_unused]] const uint2 *gtabw = reinterpret_cast<const uint2 *>(lds + gen_off + narrow_dw);  // ... as two halves
+    [[maybe_unused]] auto gen_entry = [&](uint32_t g) -> uint4 {                          // one ds_read2_b64 either way
+        if constexpr (kSplitGen) {
+            const uint2 lo = gtabw[g], hi = gtabw[g + kGenSplit];
+            return uint4{lo.x, lo.y, hi.x, hi.y};
+        } else {
+            return gtab4[g];
+        }
+    };
+
+#ifdef QECMC_TIMELINE   // diagnostic build only (tools/timeline.hip): per-workgroup start/end stamps and placement
+    if (a.dbg && threadIdx.x == 0) {
+        a.dbg[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+        a.dbg[blockIdx.x * 4 + 1] = ((uint64_t)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) |   // XCC_ID
+                                    __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));                       // HW_ID
+    }
+#endif
+    const uint64_t s0 = (uint64_t)blockIdx.x * 64u;
+    const int cnt = a.N > s0 ? (int)((a.N - s0) < 64u ? (a.N - s0) : 64u) : 0;   // 0: a group past the end of the batch
+    const uint32_t syn = a.first_syndrome + (uint32_t)s0 + (uint32_t)lane;   // Philox ctr[2]
+
+    for (int i = tid; i < NC * W * 64; i += nthreads) st[i] = 0;
+    for (int i = tid; i < ncls * 64; i += nthreads) hist[i] = 0;
+    if (tid == 0) *stopf = 0;
+    if (a.swap_acc != nullptr)
+        for (int i = tid; i < 2 * NC * 64; i += nthreads) lds_all[gdw + i] = 0;
+    if constexpr (USET) {
+        for (int i = tid; i < 3 * 64; i += nthreads) hist[i] = i < 64 ? 2u * (uint32_t)LL : 0xFFFFFFFFu;   // decoders.py:140,242; "never"
+    }
+    if constexpr (kWideGen) {
+        for (int i = tid; i < 4 * (int)a.n_gen; i += nthreads) {
+            const uint32_t e = reinterpret_cast<const uint16_t *>(a.gen)[i], q = e >> 2;
+            const int g = i >> 2, k = i & 3;                                       // generator, site
+            // byte offset of the state dword [31:16] | in site 0: the four Paulis as 2-bit fields [15:8] | Pauli [6:5] | bit shift [4:0]
+            uint32_t ops = 0;
+            if (k == 0)
+                for (int u = 0; u < 4; ++u) ops |= (uint32_t)(reinterpret_cast<const uint16_t *>(a.gen)[4 * g + u] & 3u) << (2 * u);
+            if (BIASED && k == 1) ops = a.gen_type[g];                              // site 1, bits [11:8]: the generator's Pauli-pattern id
+            if (!BIASED && CODE == kCodeToric && k == 1) ops = e & 3u;              // toric: site 1, byte 1 = the generator's one Pauli
+            if (DELUT && k == 2) ops = (e & 3u) == 3u;                              // ... site 2, byte 1 = 1 for a Z generator (table half)
+            (lds + gen_off + narrow_dw)[kSplitGen ? 2 * (g + (k >> 1) * kGenSplit) + (k & 1) : i] =
+                (((q >> 4) * 256u) << 16) | (ops << 8) | ((e & 3u) << 5) | ((q & 15u) * 2u);
+        }
+    }
+    if constexpr (kNarrowGen) {
+        for (int i = tid; i < 2 * (int)a.n_gen; i += nthreads) (lds + gen_off)[i] = reinterpret_cast<const uint32_t *>(a.gen)[i];
+    }
+    // 4 (dE + 4) for old fields F (bits 0-7) under an X (index bit 8 clear) or Z generator: toric_model.py:275-282 tabulated.
+    // It sits in the idle entries between the two halves of the split generator table.
+    [[maybe_unused]] const uint8_t *delut = reinterpret_cast<const uint8_t *>(gtabw + a.n_gen);
+    if constexpr (DELUT) {
+        for (int i = tid; i < 512; i += nthreads) {
+            const uint32_t F = (uint32_t)i & 0xFFu, G = F ^ ((i & 0x100) ? 0xFFu : 0x55u);
+            const uint32_t v = __popc((G | (G >> 1)) & 0x55u) + __popc(~(F | (F >> 1)) & 0x55u);
+            reinterpret_cast<uint8_t *>(lds + gen_off + narrow_dw + 2 * (int)a.n_gen)[i] = (uint8_t)(4u * v);
+        }
+    }
+    for (int i = tid; i < (NC - 1) * kSwapFast; i += nthreads) {
+        // u < p_diff^d  <=>  x < thr; d = 0 always swaps and is never looked up (mcmc.py:146-149)
+        const int pr = i / kSwapFast, d = i - pr * kSwapFast;
+        swapT[i] = (d >= 1 && d <= nq) ? (uint32_t)a.swap_thr[(size_t)pr * (nq + 1) + d] : 0u;
+    }
+    if constexpr (BIASED) {
+        for (int i = tid; i < 256 * a.n_types; i += nthreads) xlut[i] = a.xyz_lut[i];
+        for (int i = tid; i < lm_dw; i += nthreads) lml[i] = a.lmask[i];              // kinds 0 (X) and 1 (Z) are the first two tables
+    }
+    if (tid < NC * 9) {
+        // u < f^dE  <=>  x < thr  <=>  x <= thr-1;  dE <= 0 (f^dE >= 1) and f >= 1 always accept (mcmc.py:30,42)
+        const int c = tid / 9, d = tid - c * 9 - 4;
+        const bool always = d <= 0 || ((a.acc_all_mask >> c) & 1u);
+        if constexpr (SCAN) {
+            thrT[tid] = always ? 0xFFFFFFFFu : a.acc_thr[c][d - 1] - 1u;
+        } else {
+            // non-top random-scan proposals compare a 44-bit uniform (a12 * 2^32 + w) with T44 = ceil(f^dE * 2^44)
+            thrT[tid] = always ? 4096u : (uint32_t)(a.acc_thr44[c][d - 1] >> 32);
+            if (d >= 1) thrF[c * 4 + d - 1] = (uint32_t)a.acc_thr44[c][d - 1];
+        }
+    }
+    __syncthreads();
+
+    // ---- stage the batch: coalesced byte stream -> 2-bit fields in LDS -------------
+    const uint32_t R = a.replicas;                // ladders per syndrome (>= 1)
+    if (!a.resume) {
+        const uint8_t *src = a.init + (R > 1 ? 0ull : s0 * (uint64_t)nq);
+        const int total = cnt * nq;
+        for (int o = tid; o < total; o += nthreads) {
+            const int j = o / nq, q = o - j * nq;
+            const uint32_t v = (R > 1 ? src[((s0 + (uint64_t)j) / R) * (uint64_t)nq + q] : src[o]) & 3u;   // ladder l starts from init row l / R
+            if (v) {
+                const uint32_t bits = v << ((q & 15) * 2);
+                uint32_t *p = st + (q >> 4) * 64 + j;
+                for (int s = 0; s < NC; ++s)      // Ladder.__init__ deep-copies init into every slot (mcmc.py:72)
+                    __hip_atomic_fetch_or(p + s * W * 64, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    } else {
+        const uint8_t *src = a.states + s0 * (uint64_t)NC * nq;
+        const int per = NC * nq, total = cnt * per;
+        for (int o = tid; o < total; o += nthreads) {
+            const uint32_t v = src[o] & 3u;
+            if (v) {
+                const int j = o / per, rem = o - j * per, s = rem / nq, q = rem - s * nq;
+                __hip_atomic_fetch_or(st + (s * W + (q >> 4)) * 64 + j, v << ((q & 15) * 2), __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+    __syncthreads();
+
+    // every wave carries its slot's current state id, error count, class and flag in registers
+    uint32_t sid = (uint32_t)slot, n, cls, flag = (slot == NC - 1);   // chains[-1].flag = 1 (mcmc.py:75)
+    {
+        const uint32_t *sb = st + slot * W * 64 + lane;
+        n = 0;
+        for (int w = 0; w < W; ++w) n += nnz2(sb[w * 64]);
+        cls = CODE == kCodeToric ? toric_class_packed(sb, W, LL) : surf_class_packed(CODE, sb, L);
+    }
+    uint32_t tops0 = 0, samples = 0;              // per-syndrome counters live in wave 0
+    // convergence criterion of decoders.py:74-82,93-105 (wave 0 only): window sums over the logged
+    // bottom-chain error counts, Q2 = series[l/4 : l/2], Q4 = series[3l/4 : l]
+    uint32_t burn = 0, conv_start = 0, conv_streak = 0, done = 0, steps_done = 0, conv_ok = 0;
+    // conv_mult early stop of the unique-chain droplets (USET): replicated on every wave of the ladder
+    [[maybe_unused]] uint32_t cm_done = 0, cm_steps = 0, cm_last = 0;
+    [[maybe_unused]] uint32_t *cm_short = hist;          // [64]     shortest chain the droplet has seen (the histogram rows are idle in USET runs)
+    [[maybe_unused]] uint32_t *cm_trig = hist + 64;      // [2][64]  last step (of each parity) that found a new chain no longer than that
+    uint64_t sumA = 0, sumB = 0;
+    [[maybe_unused]] uint64_t sumAxy = 0, sumBxy = 0;          // alpha noise: window sums of n_x + n_y (sumA / sumB hold n_z)
+    if (a.resume && lane < cnt) {
+        flag = a.flags[(s0 + lane) * NC + slot] != 0;
+        if (slot == 0) tops0 = a.tops0[s0 + lane];
+    }
+    if constexpr (BIASED) {
+        // every state's (n_x, n_y, n_z), packed; carried per state from here on (accepted moves add their change)
+        int nx = 0, ny = 0, nz = 0;
+        for (int w = 0; w < W; ++w) count_xyz(st[(slot * W + w) * 64 + lane], nx, ny, nz);
+        xyc[slot * 64 + lane] = (uint32_t)nx | ((uint32_t)nz << 10) | ((uint32_t)(nx + ny) << 20);
+        if (alpha_noise) {
+            // Chain_alpha.__init__ (mcmc_alpha.py:18-22) on a fresh ladder; the carried attributes on resume.
+            // Parity 1 is "the step before step 0".
+            uint32_t v;
+            if (a.resume) v = lane < cnt ? a.neff[(s0 + lane) * NC + slot] : 0u;
+            else v = (uint32_t)nz | ((uint32_t)(nx + ny) << 16);
+            neffb[(NC + slot) * 64 + lane] = v;
+        }
+        __syncthreads();
+    }
+
+    // Roles rotate: at every ladder step each wave moves on to the next slot, so the heavier top
+    // slot (frame flush + recount) visits every SIMD in turn instead of loading one of them for
+    // the whole run.  Results do not depend on which wave computes a slot.
+    const uint32_t wave_u = __builtin_amdgcn_readfirstlane(slot);
+    uint32_t slot_u = wave_u;                                   // the slot this wave works on in the current step
+    const uint32_t iters = a.iters;
+    const uint32_t thrL1 = (uint32_t)(a.thr_logical - 1);      // x < thr_logical <=> x <= thr_logical-1 (thr in [1, 2^32])
+    const uint32_t Lodd = L & 1;                                // a row/column operator flips L parities
+    const uint32_t rowbits = 2u * (uint32_t)L;                  // bits of one lattice row in the packed stream
+    const uint32_t rowmask = rowbits >= 32 ? 0xFFFFFFFFu : (1u << rowbits) - 1u;
+    const bool swap_fast = a.swap_fast_ok != 0;
+
+    constexpr int kPre = 12;                                    // blocks drawn ahead (a step of more proposals draws the rest in place)
+    [[maybe_unused]] u32x4 pre[PRE ? kPre : 1];
+    [[maybe_unused]] const uint32_t pre_n = iters < (uint32_t)kPre ? iters : (uint32_t)kPre, pre_h = pre_n / 2;
+    for (uint64_t t = 0; t < a.nsteps; ++t) {
+        // Issue arbitration between co-resident workgroups is oldest-first, which lets the first one
+        // race ahead and leaves the last one alone (latency-bound, 2 waves per SIMD) at the end of a
+        // launch.  Lowering a workgroup's priority as it advances (cyclically, every 8 steps) narrows
+        // that spread: +6 % on a one-round grid (measured), neutral otherwise.
+        if (a.tune & 1u) {
+            if (slot_u == (uint32_t)(NC - 1)) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+        } else
+        switch (3u - (uint32_t)((t >> 3) & 3)) {    // s_setprio takes an immediate
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+        }
+        // ---------------- Chain.update_chain(iters) on every slot (mcmc.py:81-83) -----------
+        uint32_t *stw = st + sid * W * 64 + lane;
+        const uint64_t kbase = a.prop0 + t * iters;
+        const bool acc_all = (a.acc_all_mask >> slot_u) & 1u;
+        const bool top_logical = (slot_u == (uint32_t)(NC - 1)) && a.thr_logical != 0;
+        const uint32_t *myT = thrT + slot_u * 9 + 4;
+        // sweep (scan = 1) of a top chain at f = 1 with table-driven logical masks: used by the plaquette codes and by
+        // toric L > 16 (the L <= 16 toric top chain has the frame-based fast path below)
+        [[maybe_unused]] auto blind_sweep_tables = [&]() {
+            const uint32_t *lmask = a.lmask;
+            const int LW = (L + 1) * W;
+            uint32_t gs = (uint32_t)(kbase % a.n_gen), cdelta = 0;
+            u32x4 coins{0, 0, 0, 0};
+            uint64_t cb_cur = ~0ull;
+            for (uint32_t j = 0; j < iters; ++j) {
+                const uint64_t k = kbase + j;
+                if ((k & 7) == 0) {                                                 // one random logical operator
+                    const u32x4 x = philox_block(k, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                    const uint32_t *m0 = lmask + L * W, *m1 = m0, *m2 = m0, *m3 = m0;   // identity rows
+                    if (CODE == kCodeToric) {
+                        const uint32_t op0 = x.y >> 30, op1 = x.z >> 30;
+                        const uint32_t dx0 = (op0 ^ (op0 >> 1)) & 1u, dz0 = op0 >> 1, dx1 = (op1 ^ (op1 >> 1)) & 1u, dz1 = op1 >> 1;
+                        if (dx0) m0 = lmask + scale_low30(x.y, L) * W;
+                        if (dz0) m1 = lmask + LW + scale_u16(x.w >> 16, L) * W;
+                        if (dx1) m2 = lmask + 2 * LW + scale_low30(x.z, L) * W;
+                        if (dz1) m3 = lmask + 3 * LW + scale_u16(x.w & 0xFFFFu, L) * W;
+                        cdelta ^= (L & 1) ? (dx0 | (dz0 << 1) | (dx1 << 2) | (dz1 << 3)) : 0u;
+                    } else {
+                        const uint32_t op = x.y >> 30;
+                        const uint32_t xp = ((op ^ (op >> 1)) & 1u) ? scale_low30(x.y, L) : 0u, zp = (op >> 1) ? scale_u16(x.w >> 16, L) : 0u;
+                        const uint32_t ax = CODE == kCodeXzzx ? ((op ^ (op >> 1)) & 1u) : (op & 1u), az = op >> 1;
+                        if (ax) m0 = lmask + xp * W;
+                        if (az) m1 = lmask + LW + zp * W;
+                        cdelta ^= ax | (az << 1);
+                    }
+                    for (int w = 0; w < W; ++w) lds_xor(stw + w * 64, m0[w] ^ m1[w] ^ m2[w] ^ m3[w]);
+                }
+                if ((k >> 7) != cb_cur) { cb_cur = k >> 7; coins = philox_block(cb_cur, 3, syn, slot_u, a.seed_lo, a.seed_hi); }
+                const uint2 ev = gtab[gs];
+                gs = gs + 1 == a.n_gen ? 0u : gs + 1;
+                if ((sel4(coins, (int)((k >> 5) & 3)) >> (k & 31)) & 1u) {
+                    const uint32_t ent[4] = {ev.x & 0xFFFFu, ev.x >> 16, ev.y & 0xFFFFu, ev.y >> 16};
+                    for (int i = 0; i < 4; ++i) lds_xor(stw + (ent[i] >> 6) * 64, (ent[i] & 3u) << (((ent[i] >> 2) & 15u) * 2u));
+                }
+            }
+            uint32_t cnt_n = 0;
+            for (int w = 0; w < W; ++w) cnt_n += nnz2(stw[w * 64]);
+            n = cnt_n;
+            cls ^= cdelta;
+        };
+
+        // ---------- the non-top random-scan loop (every code, depolarizing rule) -------------------------------------------
+        // ONE Philox word per proposal (word k&3 of block (k>>2, 1), so a block feeds four): its top 20 bits pick the
+        // generator, g = floor(x20 * G / 2^20) (the G generators as equally likely as 20 bits allow: G 2^-20; the proposal stays
+        // symmetric, so the stationary law is untouched) and its low 12 bits lead the 44-bit acceptance uniform.  Word k&3 of
+        // the refinement block (k>>2, kSubRefine) supplies the other 32 bits, and is computed only when some lane's 12 bits
+        // tie with its threshold's (once in 4096 proposals per lane).
+        [[maybe_unused]] auto random_scan_loop = [&]() {
+            int ni = DELUT ? (int)(4u * n) : (int)n;
+            const uint32_t *myF = thrF + slot_u * 4 - 5;                            // indexed by dE + 4 = 5..8
+            auto propose = [&](uint32_t xw, uint64_t kb, auto wsel) {
+                // (20-bit field x 11-bit count: a full-rate 24-bit multiply)
+                uint32_t gi = (uint32_t)__mul24((int)(xw >> 12), (int)a.n_gen) >> 20;
+                asm("" : "+v"(gi));                                                 // (keeps index and address as shift + shift-add)
+                const uint4 ev = gen_entry(gi);                                     // the (up to) four sites; an unused entry is 0
+                const uint32_t sh[4] = {ev.x, ev.y, ev.z, ev.w};                    // byte offset << 16 | ... | Pauli << 5 | bit shift
+                uint32_t *ad[4];
+                uint32_t f[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ad[i] = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(stw) + (sh[i] >> 16));   // byte offset: one SDWA add
+                    f[i] = bfe2_lo5(*ad[i], sh[i]);
+                }
+                const uint32_t F = lshl_or(lshl_or(f[3], 2, f[2]), 4, lshl_or(f[1], 2, f[0]));
+                if constexpr (DELUT) {
+                    // 4 (dE + 4) from the table; the thresholds' rows and the running count (ni = 4 n) take it as a byte offset
+                    const uint32_t v = delut[(ev.z & 0x100u) | F];
+                    const uint32_t a12 = xw & 0xFFFu, tI = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(myT - 4) + v);
+                    bool acc = a12 < tI;                                            // mcmc.py:42 (dE <= 0: tI = 4096)
+                    if (a12 == tI) {                                                // rare (a lane in 4096): the next 32 bits decide
+                        constexpr int WI = decltype(wsel)::value;
+                        const u32x4 r = philox_block(kb, kSubRefine, syn, slot_u, a.seed_lo, a.seed_hi);
+                        acc = (WI == 0 ? r.x : WI == 1 ? r.y : WI == 2 ? r.z : r.w) < *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(myF) + v);
+                    }
+                    if (acc) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) lds_xor(ad[i], shl_byte1(sh[i], ev.y));
+                        ni += (int)v - 16;
+                    }
+                    return;
+                }
+                const uint32_t G = xor_byte1(F, ev.x);                              // the four new values (byte 1 of site 0: the Paulis as 2-bit fields)
+                // dE + 4 = #(new != 0) + #(old == 0) (toric_model.py:275-282) as ONE popcount: the nonzero new fields marked on the
+                // even bits, the zero old fields on the odd bits ((F << 1) | 0x55..55 has every even bit set and F's low field bits
+                // moved up, so ~(u | F) is 1 on odd bit 2i+1 iff field i is 0 -- and on the 12 odd bits above the byte, a constant
+                // the threshold row's base absorbs).  An unused entry reads site 0 into both and counts 1.
+                const uint32_t nzG = (G | (G >> 1)) & 0x55u;
+                const uint32_t uF = lshl_or(F, 1, 0x55555555u);
+                const uint32_t dE16 = __popc(__builtin_amdgcn_bitop3_b32(uF, F, nzG, 0xAB));   // ~(uF | F) | nzG;  = dE + 16
+                const uint32_t a12 = xw & 0xFFFu, tI = (myT - 16)[dE16];
+                bool acc = a12 < tI;                                                // mcmc.py:42 (dE <= 0: tI = 4096)
+                if (a12 == tI) {                                                    // rare (a lane in 4096): the next 32 bits decide
+                    constexpr int WI = decltype(wsel)::value;
+                    const u32x4 r = philox_block(kb, kSubRefine, syn, slot_u, a.seed_lo, a.seed_hi);
+                    acc = (WI == 0 ? r.x : WI == 1 ? r.y : WI == 2 ? r.z : r.w) < (myF - 12)[dE16];
+                }
+                if (acc) {
+                    if constexpr (CODE == kCodeToric) {                            // one Pauli for the whole generator: byte 1 of site 1
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) lds_xor(ad[i], shl_byte1(sh[i], ev.y));
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) lds_xor(ad[i], shl_lo5((sh[i] >> 5) & 3u, sh[i]));
+                    }
+                    ni += (int)dE16 - 16;
+                }
+            };
+            // the blocks that overlap [kbase, kbase + iters): a block the previous step started is drawn again
+            uint64_t kb = kbase >> 2;
+            for (int jb = -(int)((uint32_t)kbase & 3u); jb < (int)iters; jb += 4, ++kb) {
+                const u32x4 xa = philox_block(kb, 1, syn, slot_u, a.seed_lo, a.seed_hi);
+                if (jb >= 0 && jb + 4 <= (int)iters) {                             // a whole block: no per-proposal range tests
+                    propose(xa.x, kb, std::integral_constant<int, 0>{});
+                    propose(xa.y, kb, std::integral_constant<int, 1>{});
+                    propose(xa.z, kb, std::integral_constant<int, 2>{});
+                    propose(xa.w, kb, std::integral_constant<int, 3>{});
+                } else {
+                    if ((uint32_t)jb < iters) propose(xa.x, kb, std::integral_constant<int, 0>{});
+                    if ((uint32_t)(jb + 1) < iters) propose(xa.y, kb, std::integral_constant<int, 1>{});
+                    if ((uint32_t)(jb + 2) < iters) propose(xa.z, kb, std::integral_constant<int, 2>{});
+                    if ((uint32_t)(jb + 3) < iters) propose(xa.w, kb, std::integral_constant<int, 3>{});
+                }
+            }
+            n = DELUT ? (uint32_t)ni >> 2 : (uint32_t)ni;
+        };
+
+        if constexpr (CODE != kCodeToric || BIASED) {
+            // ---------- XZZX / rotated codes and the biased acceptance rule ----------------------------
+            const bool top = top_logical;
+            if constexpr (BIASED) {
+                // ---------- the biased / alpha acceptance rule (mcmc_biased.py:20-59, mcmc_alpha.py:27-70) ------------------------
+                // accept iff u < p_n / p_b with p = px^nx py^ny pz^nz pI^nI from the reference's power tables and p_b frozen at
+                // loop entry (quirk Q3).  The chain's counts travel packed (n_x | n_z << 10 | (n_x + n_y) << 20, carried per
+                // state across steps); a generator move's count change comes from an LDS table indexed by the generator's Pauli
+                // pattern and the four old fields.  The exact test costs eight table look-ups, six fp64 products and a
+                // division, and almost no proposal needs it: log2(p_n / p_b) is lxy (D_x + D_y) + lz D_z with D the count change
+                // since loop entry -- exactly, up to the roundings of the power tables (1e-15) -- so two fp64 fmas and one v_exp_f32 give
+                // 2^12 p_n / p_b to 1e-2 of a unit, and only a proposal whose 12 leading uniform bits lie within one unit of
+                // it (3 cells in 4096; the top chain: 2^15 in 2^32) evaluates the reference's expression.  Decisions are those
+                // of the exact test in every case, hence bit-identical to the CPU.
+                const int T1 = nq + 1;
+                const double *bt = a.bias_tbl + (size_t)slot_u * 4 * T1;
+                auto weight = [&](uint32_t P) -> double {                           // mcmc_biased.py:28-31 on packed counts
+                    const int cx = (int)(P & 1023u), cz = (int)((P >> 10) & 1023u), cxy = (int)(P >> 20);
+                    return bt[cx] * bt[T1 + (cxy - cx)] * bt[2 * T1 + cz] * bt[3 * T1 + (nq - cxy - cz)];
+                };
+                constexpr uint32_t kFieldBias = 512u | (512u << 10) | (512u << 20);
+                uint32_t Np = xyc[sid * 64 + lane];
+                const uint32_t Nb = Np, NbB = Nb - kFieldBias;                      // counts at loop entry (p_b); ... minus the field offsets
+                const double lxy = a.bias_l2[slot_u][0], lz = a.bias_l2[slot_u][1];
+                uint32_t cdelta = 0;
+                bool any_acc = false;
+                // (the loop is compiled once for the top chain and once for the others: the top chain's logical operators and
+                // four-word blocks stay out of the registers of the seven rungs that do not have them)
+                auto biased_loop = [&](auto top_c) {
+                constexpr bool top = decltype(top_c)::value;
+                const double c0 = (top ? 32.0 : 12.0) - 512.0 * (lxy + lz);         // scales the ratio by 2^32 / 2^12, removes the offsets
+                [[maybe_unused]] const int LW = (L + 1) * W;
+                u32x4 pair{0, 0, 0, 0};                                            // the block four non-top proposals share
+                uint64_t kb_pair = ~0ull;
+                // (top chain: the next proposal's block is drawn while this proposal's LDS reads are in flight -- its three
+                // dependent look-ups per proposal make the top wave the step's longest)
+                [[maybe_unused]] u32x4 xnext = top ? philox_block(kbase, 0, syn, slot_u, a.seed_lo, a.seed_hi) : u32x4{0, 0, 0, 0};
+                for (uint32_t j = 0; j < iters; ++j) {
+                    const uint64_t k = kbase + j;
+                    // top: block (k, 0) = select | generator or logical fields | acceptance word | Z position;
+                    // non-top: word k&3 of block (k>>2, 1) (+ its refinement)
+                    u32x4 x;
+                    if constexpr (top) {
+                        x = xnext;
+                        if (j + 1 < iters) xnext = philox_block(k + 1, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                    } else {
+                        if ((k >> 2) != kb_pair) {
+                            kb_pair = k >> 2;
+                            pair = philox_block(kb_pair, 1, syn, slot_u, a.seed_lo, a.seed_hi);
+                        }
+                        x.x = sel4(pair, (int)(k & 3));                             // the proposal's word: generator | 12 leading accept bits
+                        x.y = x.z = x.w = 0;
+                    }
+                    const bool logical = top && x.x <= thrL1;                       // mcmc.py:23
+                    uint32_t Nn, cd = 0;                                            // the proposal's packed counts; its class change
+                    uint32_t *sad[4] = {stw, stw, stw, stw};
+                    uint32_t ssh[4] = {0, 0, 0, 0};
+                    const uint32_t *m0 = lml + L * W, *m1 = m0;                     // identity rows (LDS copy of the plan's masks)
+                    if (logical) {
+                        const uint32_t op = x.y >> 30;                              // xzzx_model.py:346 / rotated_surface_model.py:334
+                        const uint32_t xp = ((op ^ (op >> 1)) & 1u) ? scale_low30(x.y, L) : 0u;   // drawn iff op in {1,2}
+                        const uint32_t zp = (op >> 1) ? scale_u16(x.w >> 16, L) : 0u;             // drawn iff op in {3,2}
+                        // applied operators: xzzx X iff op in {1,2}, Z iff op in {3,2}; rotated X iff op in {1,3}, Z iff op in {2,3}
+                        const uint32_t ax = CODE == kCodeXzzx ? ((op ^ (op >> 1)) & 1u) : (op & 1u);
+                        const uint32_t az = op >> 1;
+                        if (ax) m0 = lml + xp * W;                                  // kind 0: X (xzzx: anti-diagonal at every pos)
+                        if (az) m1 = lml + LW + zp * W;                             // kind 1: Z
+                        cd = ax | (az << 1);
+                        int cx = 0, cy = 0, cz = 0;                                 // the operator moves O(L) sites: recount the result
+                        for (int w = 0; w < W; ++w) count_xyz(stw[w * 64] ^ m0[w] ^ m1[w], cx, cy, cz);
+                        Nn = (uint32_t)cx | ((uint32_t)cz << 10) | ((uint32_t)(cx + cy) << 20);
+                    } else {
+                        // the expanded entry gives each site's LDS address with one add and its field with one bfe
+                        const uint4 ev = gen_entry(top ? scale_u32(x.y, a.n_gen) : pick_top20(x.x, a.n_gen));
+                        ssh[0] = ev.x; ssh[1] = ev.y; ssh[2] = ev.z; ssh[3] = ev.w;
+                        uint32_t f[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            sad[i] = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(stw) + (ssh[i] >> 16));
+                            f[i] = bfe2_lo5(*sad[i], ssh[i]);                       // (an unused entry reads site 0 and applies no Pauli)
+                        }
+                        const uint32_t F = lshl_or(lshl_or(f[3], 2, f[2]), 4, lshl_or(f[1], 2, f[0]));
+                        Nn = Np + xlut[(ev.y & 0xF00u) | F];                        // pattern id << 8 | old fields -> the count change
+                    }
+                    const uint32_t cand = Nn - NbB;                                 // the counts' change since loop entry, every field + 512
+                    const double tl = __builtin_fma(lxy, (double)(cand >> 20), __builtin_fma(lz, (double)((cand >> 10) & 1023u), c0));
+                    float e = __builtin_amdgcn_exp2f((float)tl);                    // 2^12 (top: 2^32) p_n / p_b, relative error < 1e-6
+                    bool acc, amb;
+                    uint32_t a12 = 0;
+                    if constexpr (top) {
+                        // u = x.z 2^-32 < ratio: certain when x.z + 2^14 <= e (e is within 2^13 of 2^32 ratio: float rounding of a
+                        // value below 32 and the 1-ulp exp), impossible when x.z >= e + 2^14
+                        const uint32_t tI = (uint32_t)fminf(e, 4294901760.0f);     // <= 2^32 - 2^16: the sums below cannot wrap
+                        acc = tI >= 16384u && x.z <= tI - 16384u;
+                        amb = !acc && (x.z < tI + 16384u || tI >= 4294901760u);     // (a clamped e says nothing about words above it)
+                    } else {
+                        // u in [a12, a12 + 1) 2^-12: below the ratio for certain when a12 + 2 <= floor(e), above when a12 >= floor(e) + 2
+                        const uint32_t tI = (uint32_t)fminf(e, 8192.0f);
+                        a12 = x.x & 0xFFFu;
+                        acc = a12 + 2u <= tI;
+                        amb = !acc && a12 <= tI + 1u;
+                    }
+                    if (amb) {
+                        const double ratio = weight(Nn) / weight(Nb);               // mcmc_biased.py:44-46
+                        if constexpr (top) {
+                            acc = (double)x.z * (1.0 / 4294967296.0) < ratio;
+                        } else {
+                            // u = (a12 2^32 + w) 2^-44 with w the proposal's word of the refinement block, needed only when the 12
+                            // leading bits do not decide
+                            const double ulo = (double)a12 * (1.0 / 4096.0);
+                            acc = ulo + (1.0 / 4096.0) <= ratio;
+                            if (!acc && ulo < ratio) {
+                                const uint64_t v44 = ((uint64_t)a12 << 32) | sel4(philox_block(k >> 2, kSubRefine, syn, slot_u, a.seed_lo, a.seed_hi), (int)(k & 3));
+                                acc = (double)v44 * (1.0 / 17592186044416.0) < ratio;
+                            }
+                        }
+                    }
+                    if (acc) {
+                        if (logical) {
+                            for (int w = 0; w < W; ++w) lds_xor(stw + w * 64, m0[w] ^ m1[w]);
+                            cdelta ^= cd;
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) lds_xor(sad[i], shl_lo5((ssh[i] >> 5) & 3u, ssh[i]));
+                        }
+                        Np = Nn;
+                        any_acc = true;
+                    }
+                }
+                };
+                if (top) biased_loop(std::true_type{});
+                else biased_loop(std::false_type{});
+                xyc[sid * 64 + lane] = Np;
+                n = (Np >> 20) + ((Np >> 10) & 1023u);
+                cls ^= cdelta;
+                // the slot's n_eff is refreshed by accepted moves only (mcmc_alpha.py:58,70); otherwise it keeps the
+                // value it had, possibly that of a configuration since swapped away (quirk Q4)
+                if (alpha_noise)
+                    neffb[((t & 1) * NC + slot_u) * 64 + lane] = any_acc ? (((Np >> 10) & 1023u) | ((Np >> 20) << 16))
+                                                                         : neffb[(((t & 1) ^ 1) * NC + slot_u) * 64 + lane];
+            } else {
+            const bool xyz_rule = USET && a.xyz_thr != nullptr;                     // Chain_xyz: the general path with its own table
+            if (!SCAN && !top && CODE != kCodeToric && !xyz_rule) {
+                if constexpr (kWideGen) random_scan_loop();
+            } else if (SCAN && !top && CODE != kCodeToric) {
+                // sweep on a plaquette code: generator table lookup, 2 to 4 sites
+                int ni = (int)n;
+                uint32_t gs = SCAN ? (uint32_t)(kbase % a.n_gen) : 0u;
+                u32x4 blk{0, 0, 0, 0};
+                uint64_t kb_cur = ~0ull;
+                for (uint32_t j = 0; j < iters; ++j) {
+                    u32x4 x;
+                    uint32_t g;
+                    if constexpr (SCAN) {                                          // generator k mod G, accept word k&3 of block k>>2
+                        const uint64_t k = kbase + j;
+                        if ((k >> 2) != kb_cur) { kb_cur = k >> 2; blk = philox_block(kb_cur, 3, syn, slot_u, a.seed_lo, a.seed_hi); }
+                        x.w = sel4(blk, (int)(k & 3));
+                        g = gs;
+                        gs = gs + 1 == a.n_gen ? 0u : gs + 1;
+                    } else {
+                        g = 0; x.w = 0;                                             // (SCAN is part of the branch condition)
+                    }
+                    const uint2 e = gtab[g];                                      // 4 x (site << 2 | pauli), 0 = no site
+                    const uint32_t ent[4] = {e.x & 0xFFFFu, e.x >> 16, e.y & 0xFFFFu, e.y >> 16};
+                    uint32_t *ad[4];
+                    uint32_t sh[4], F = 0, OPS = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const uint32_t q = ent[i] >> 2;
+                        ad[i] = stw + (q >> 4) * 64;
+                        sh[i] = (q & 15u) * 2u;
+                        F |= ((*ad[i] >> sh[i]) & 3u) << (2 * i);
+                        OPS |= (ent[i] & 3u) << (2 * i);
+                    }
+                    const uint32_t G = F ^ OPS;
+                    const int dE = __popc((G | (G >> 1)) & 0x55u) - __popc((F | (F >> 1)) & 0x55u);
+                    if (x.w <= myT[dE]) {                                           // mcmc.py:42
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) lds_xor(ad[i], (ent[i] & 3u) << sh[i]);
+                        ni += dE;
+                    }
+                }
+                n = (uint32_t)ni;
+            } else if (SCAN && top && acc_all) {
+                blind_sweep_tables();
+            } else if (top && acc_all) {
+                // random scan, top chain at f = 1 (mcmc.py:30): every proposal is applied blindly, n recounted once.  With a row
+                // of the lattice inside one word (L <= 16) the logical operators are collected in a per-lane frame and applied
+                // once per step, as on the toric code: xzzx -- parities of the (position-independent) anti-diagonal X and
+                // diagonal Z; rotated -- the set of X columns and of Z rows; planar -- the X rows and Z columns of layer 0.
+                uint32_t cdelta = 0, frX = 0, frZ = 0;
+                const bool framed = L <= 32;                                       // (a row of up to 64 bits: two words)
+                auto top_move = [&](const u32x4 &x) {
+                    if (x.x <= thrL1) {                                             // logical (xzzx_model.py:340-357)
+                        const uint32_t op = x.y >> 30;
+                        const uint32_t xp = ((op ^ (op >> 1)) & 1u) ? scale_low30(x.y, L) : 0u, zp = (op >> 1) ? scale_u16(x.w >> 16, L) : 0u;
+                        const uint32_t ax = CODE == kCodeXzzx ? ((op ^ (op >> 1)) & 1u) : (op & 1u), az = op >> 1;
+                        if (framed) {
+                            frX ^= CODE == kCodeXzzx ? ax : ax << xp;
+                            frZ ^= CODE == kCodeXzzx ? az : az << zp;
+                        } else {
+                            // the operator's L + L sites, generated on the fly (per-lane positions would make the plan's mask rows
+                            // 2 W scattered global loads per proposal): xzzx -- X on the anti-diagonal, Z on the diagonal
+                            // (xzzx_model.py:291-311); rotated -- X on column X_pos, Z on row Z_pos (rotated_surface_model.py:260-280);
+                            // planar -- X on row X_pos, Z on column Z_pos of layer 0 (planar_model.py:264-268)
+                            for (uint32_t i = 0; i < (uint32_t)L; ++i) {
+                                uint32_t qx, qz;
+                                if (CODE == kCodeXzzx) { qx = i * L + ((uint32_t)L - 1u - i); qz = i * L + i; }
+                                else if (CODE == kCodeRotated) { qx = i * L + xp; qz = zp * L + i; }
+                                else { qx = xp * L + i; qz = i * L + zp; }
+                                lds_xor(stw + (qx >> 4) * 64, ax << ((qx & 15u) * 2u));
+                                lds_xor(stw + (qz >> 4) * 64, (az * 3u) << ((qz & 15u) * 2u));
+                            }
+                        }
+                        cdelta ^= ax | (az << 1);
+                    } else if constexpr (kWideGen) {
+                        const uint4 ev = gen_entry(scale_u32(x.y, a.n_gen));        // word 1 picks the generator; the expanded entry
+                        const uint32_t e4[4] = {ev.x, ev.y, ev.z, ev.w};            // gives address and shift directly (a null site is 0)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            lds_xor(reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(stw) + (e4[i] >> 16)), shl_lo5((e4[i] >> 5) & 3u, e4[i]));
+                    } else {
+                        const uint2 e = gtab[scale_u32(x.y, a.n_gen)];              // word 1 picks the generator
+                        const uint32_t ent[4] = {e.x & 0xFFFFu, e.x >> 16, e.y & 0xFFFFu, e.y >> 16};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) lds_xor(stw + (ent[i] >> 6) * 64, (ent[i] & 3u) << (((ent[i] >> 2) & 15u) * 2u));
+                    }
+                };
+                {
+                    uint32_t j = 0;
+                    if constexpr (PRE) {
+                        if (t >= 2 && NC >= 3) {                                    // blocks drawn ahead by this wave on slots 1 and 0
+#pragma unroll
+                            for (int jj = 0; jj < kPre; ++jj)
+                                if ((uint32_t)jj < pre_n) top_move(pre[jj]);
+                            j = pre_n;
+                        }
+                    }
+                    for (; j < iters; ++j) top_move(philox_block(kbase + j, 0, syn, slot_u, a.seed_lo, a.seed_hi));
+                }
+                uint32_t cnt_n = 0;
+                if (framed && L > 16) {
+                    // rows of 34 .. 64 bits (rotated L = 21 is BASELINE config 5's shape): the same stream with two-word patterns
+                    auto spread16 = [](uint32_t c) {
+                        c = (c | (c << 8)) & 0x00FF00FFu; c = (c | (c << 4)) & 0x0F0F0F0Fu;
+                        c = (c | (c << 2)) & 0x33333333u; return (c | (c << 1)) & 0x55555555u;
+                    };
+                    const uint32_t hibits = rowbits - 32u;                          // 2 .. 32 bits of a row live in its second word
+                    const uint32_t rmhi = hibits >= 32u ? 0xFFFFFFFFu : (1u << hibits) - 1u;
+                    const uint32_t csrc = CODE == kCodeRotated ? frX : CODE == kCodePlanar ? frZ : 0u;
+                    const uint32_t cmul = CODE == kCodePlanar ? 3u : 1u;
+                    const uint32_t cplo = spread16(csrc & 0xFFFFu) * cmul, cphi = spread16(csrc >> 16) * cmul;
+                    const uint32_t rplo = CODE == kCodeRotated ? 0xFFFFFFFFu : 0x55555555u, rphi = (CODE == kCodeRotated ? 0xFFFFFFFFu : 0x55555555u) & rmhi;
+                    const int rowsel = (int)(CODE == kCodeRotated ? frZ : frX);
+                    const uint32_t mX = (uint32_t)__builtin_amdgcn_sbfe((int)frX, 0u, 1u), mZ = (uint32_t)__builtin_amdgcn_sbfe((int)frZ, 0u, 1u);
+                    uint32_t acc = 0, fill = 0;
+                    uint32_t *wp = stw;
+                    const int nrows = CODE == kCodePlanar ? 2 * L : L;
+                    for (int r = 0; r < nrows; ++r) {
+                        uint32_t plo, phi;
+                        if (CODE == kCodeXzzx) {
+                            const uint64_t cx = 1ull << (2 * (L - 1 - r)), cz = 3ull << (2 * r);        // wave-uniform
+                            plo = (mX & (uint32_t)cx) ^ (mZ & (uint32_t)cz);
+                            phi = (mX & (uint32_t)(cx >> 32)) ^ (mZ & (uint32_t)(cz >> 32));
+                        } else if (CODE == kCodePlanar && r >= L) {
+                            plo = phi = 0u;
+                        } else {
+                            const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe(rowsel, (uint32_t)r, 1u);
+                            plo = __builtin_amdgcn_bitop3_b32(m, rplo, cplo, 0x6A);
+                            phi = __builtin_amdgcn_bitop3_b32(m, rphi, cphi, 0x6A);
+                        }
+                        // the row's 96-bit window at bit `fill`: lo | mid | hi
+                        const uint32_t lo = acc | (plo << fill);
+                        const uint32_t mid = fill ? (plo >> (32u - fill)) | (phi << fill) : phi;
+                        const uint32_t hi = fill ? phi >> (32u - fill) : 0u;
+                        const uint32_t total = fill + rowbits;                      // 34 .. 95
+                        cnt_n += nnz2(__hip_atomic_fetch_xor(wp, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ^ lo);
+                        wp += 64;
+                        if (total >= 64u) {
+                            cnt_n += nnz2(__hip_atomic_fetch_xor(wp, mid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ^ mid);
+                            wp += 64;
+                            acc = hi; fill = total - 64u;
+                        } else {
+                            acc = mid; fill = total - 32u;
+                        }
+                    }
+                    if (fill) cnt_n += nnz2(__hip_atomic_fetch_xor(wp, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ^ acc);
+                } else
+                if (framed) {
+                    // flush the frame as one bit stream of 2L-bit rows (a returning ds_xor per word; the recount rides along)
+                    auto spread16 = [](uint32_t c) {                                // bit i -> bit 2i
+                        c = (c | (c << 8)) & 0x00FF00FFu; c = (c | (c << 4)) & 0x0F0F0F0Fu;
+                        c = (c | (c << 2)) & 0x33333333u; return (c | (c << 1)) & 0x55555555u;
+                    };
+                    const uint32_t colpat = CODE == kCodeRotated ? spread16(frX) : CODE == kCodePlanar ? spread16(frZ) * 3u : 0u;
+                    const uint32_t rowpat = CODE == kCodeRotated ? rowmask : 0x55555555u & rowmask;   // Z (11) / X (01) along a chosen row
+                    const int rowsel = (int)(CODE == kCodeRotated ? frZ : frX);
+                    const int mX = __builtin_amdgcn_sbfe((int)frX, 0u, 1u), mZ = __builtin_amdgcn_sbfe((int)frZ, 0u, 1u);   // xzzx parities as masks
+                    uint32_t acc = 0, fill = 0, pend = 0;
+                    uint32_t *wp = stw;
+                    const int nrows = CODE == kCodePlanar ? 2 * L : L;
+                    for (int r = 0; r < nrows; ++r) {
+                        uint32_t pat;
+                        if (CODE == kCodeXzzx)
+                            pat = ((uint32_t)mX & (1u << (2 * (L - 1 - r)))) ^ ((uint32_t)mZ & (3u << (2 * r)));
+                        else if (CODE == kCodePlanar && r >= L)
+                            pat = 0u;                                               // layer 1 carries no logical operator
+                        else
+                            pat = __builtin_amdgcn_bitop3_b32((uint32_t)__builtin_amdgcn_sbfe(rowsel, (uint32_t)r, 1u), rowpat, colpat, 0x6A);
+                        acc |= pat << fill;
+                        if (fill + rowbits >= 32u) {
+                            cnt_n += nnz2(pend);
+                            pend = __hip_atomic_fetch_xor(wp, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ^ acc;
+                            wp += 64;
+                            const uint32_t rem = fill + rowbits - 32u;
+                            acc = rem ? pat >> (rowbits - rem) : 0u;
+                            fill = rem;
+                        } else {
+                            fill += rowbits;
+                        }
+                    }
+                    cnt_n += nnz2(pend);
+                    if (fill) cnt_n += nnz2(__hip_atomic_fetch_xor(wp, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ^ acc);
+                } else {
+                    for (int w = 0; w < W; ++w) cnt_n += nnz2(stw[w * 64]);
+                }
+                n = cnt_n;
+                cls ^= cdelta;
+            } else {
+                // general path: top chains below p = 0.75 (logical proposals with the full Metropolis test, mcmc.py:20-35) and
+                // Chain_xyz (mcmc.py:106-114,162-173)
+                int nx = 0, ny = 0, nz = 0;
+                for (int w = 0; w < W; ++w) count_xyz(stw[w * 64], nx, ny, nz);
+                uint32_t cdelta = 0;
+                const uint32_t *lmask = a.lmask;
+                const int LW = (L + 1) * W;
+                uint32_t gs = SCAN ? (uint32_t)(kbase % a.n_gen) : 0u;
+                u32x4 pair{0, 0, 0, 0};                                            // the block four non-top proposals share
+                uint64_t kb_pair = ~0ull;
+                for (uint32_t j = 0; j < iters; ++j, gs = gs + 1 == a.n_gen ? 0u : gs + 1) {
+                    const uint64_t k = kbase + j;
+                    // top: block (k, 0) = select, generator / logical fields; non-top: word k&3 of block (k>>2, 1) (+ its refinement)
+                    u32x4 x;
+                    uint64_t v44 = 0;                                               // non-top: the 44-bit acceptance uniform
+                    if (top) {
+                        x = philox_block(k, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                    } else {
+                        if ((k >> 2) != kb_pair) {
+                            kb_pair = k >> 2;
+                            pair = philox_block(kb_pair, 1, syn, slot_u, a.seed_lo, a.seed_hi);
+                        }
+                        x.x = sel4(pair, (int)(k & 3));                             // the proposal's word: generator | 12 leading accept bits
+                        v44 = (uint64_t)(x.x & 0xFFFu) << 32;                       // ... the low 32 bits are drawn only when they decide
+                        x.y = x.z = x.w = 0;
+                    }
+                    const bool logical = top && x.x <= thrL1;                       // mcmc.py:23
+                    int dx = 0, dy = 0, dz = 0;                                    // change of the X / Y / Z counts
+                    uint32_t ent[4] = {0, 0, 0, 0}, cd = 0;
+                    uint32_t *sad[4] = {stw, stw, stw, stw};                        // a stabilizer's sites: LDS word, bit shift (low 5 bits), Paulis
+                    uint32_t ssh[4] = {0, 0, 0, 0}, sops = 0;
+                    const uint32_t *m0 = lmask + L * W, *m1 = m0, *m2 = m0, *m3 = m0;   // identity rows
+                    if (logical) {
+                        if (CODE == kCodeToric) {
+                            const uint32_t op0 = x.y >> 30, op1 = x.z >> 30;
+                            const uint32_t dx0 = (op0 ^ (op0 >> 1)) & 1u, dz0 = op0 >> 1, dx1 = (op1 ^ (op1 >> 1)) & 1u, dz1 = op1 >> 1;
+                            if (dx0) m0 = lmask + scale_low30(x.y, L) * W;
+                            if (dz0) m1 = lmask + LW + scale_u16(x.w >> 16, L) * W;
+                            if (dx1) m2 = lmask + 2 * LW + scale_low30(x.z, L) * W;
+                            if (dz1) m3 = lmask + 3 * LW + scale_u16(x.w & 0xFFFFu, L) * W;
+                            cd = Lodd ? (dx0 | (dz0 << 1) | (dx1 << 2) | (dz1 << 3)) : 0u;
+                        } else {
+                            const uint32_t op = x.y >> 30;                          // xzzx_model.py:346 / rotated_surface_model.py:334
+                            const uint32_t xp = ((op ^ (op >> 1)) & 1u) ? scale_low30(x.y, L) : 0u;   // drawn iff op in {1,2}
+                            const uint32_t zp = (op >> 1) ? scale_u16(x.w >> 16, L) : 0u;             // drawn iff op in {3,2}
+                            // applied operators: xzzx X iff op in {1,2}, Z iff op in {3,2}; rotated X iff op in {1,3}, Z iff op in {2,3}
+                            const uint32_t ax = CODE == kCodeXzzx ? ((op ^ (op >> 1)) & 1u) : (op & 1u);
+                            const uint32_t az = op >> 1;
+                            if (ax) m0 = lmask + xp * W;                            // kind 0: X (xzzx: anti-diagonal at every pos)
+                            if (az) m1 = lmask + LW + zp * W;                       // kind 1: Z
+                            cd = ax | (az << 1);
+                        }
+                        for (int w = 0; w < W; ++w) {
+                            const uint32_t old = stw[w * 64], neu = old ^ m0[w] ^ m1[w] ^ m2[w] ^ m3[w];
+                            int ox = 0, oy = 0, oz = 0;
+                            count_xyz(old, ox, oy, oz);
+                            count_xyz(neu, dx, dy, dz);
+                            dx -= ox; dy -= oy; dz -= oz;
+                        }
+                    } else {
+                        const uint32_t wa = top ? x.y : x.x;                        // the generator word
+                        if constexpr (SCAN) {
+                            const uint2 e = gtab[gs];
+                            ent[0] = e.x & 0xFFFFu; ent[1] = e.x >> 16; ent[2] = e.y & 0xFFFFu; ent[3] = e.y >> 16;
+                        } else if (CODE == kCodeToric) {
+                            uint32_t q[4];
+                            const uint32_t g = top ? scale_u32(wa, 2u * (uint32_t)LL) : pick_top20(wa, 2u * (uint32_t)LL);
+                            const uint32_t isX = g < (uint32_t)LL, rc = isX ? g : g - (uint32_t)LL;
+                            toric_sites(L, LL, rc / (uint32_t)L, rc % (uint32_t)L, isX, q);
+                            for (int i = 0; i < 4; ++i) ent[i] = (q[i] << 2) | (isX ? 1u : 3u);
+                        } else if constexpr (!kWideGen) {
+                            const uint2 e = gtab[top ? scale_u32(wa, a.n_gen) : pick_top20(wa, a.n_gen)];
+                            ent[0] = e.x & 0xFFFFu; ent[1] = e.x >> 16; ent[2] = e.y & 0xFFFFu; ent[3] = e.y >> 16;
+                        }
+                        if constexpr (kWideGen && CODE != kCodeToric) {
+                            // the expanded entry gives each site's LDS address with one add and its field with one bfe
+                            const uint4 ev = gen_entry(top ? scale_u32(wa, a.n_gen) : pick_top20(wa, a.n_gen));
+                            ssh[0] = ev.x; ssh[1] = ev.y; ssh[2] = ev.z; ssh[3] = ev.w;
+                            sops = (ev.x >> 8) & 0xFFu;                             // the four Paulis as 2-bit fields (a null site: 0)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) sad[i] = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(stw) + (ssh[i] >> 16));
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const uint32_t q = ent[i] >> 2;
+                                sad[i] = stw + (q >> 4) * 64;
+                                ssh[i] = (q & 15u) * 2u;
+                                sops |= (ent[i] & 3u) << (2 * i);
+                            }
+                        }
+                        // old and new values of the (up to) four sites as 2-bit fields; an unused entry reads site 0 into
+                        // both and cancels
+                        uint32_t F = 0;
+                        const uint32_t OPS = sops;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) F |= bfe2_lo5(*sad[i], ssh[i]) << (2 * i);
+                        int ox = 0, oy = 0, oz = 0;
+                        count_xyz(F, ox, oy, oz);
+                        count_xyz(F ^ OPS, dx, dy, dz);
+                        dx -= ox; dy -= oy; dz -= oz;
+                    }
+                    const int dE = dx + dy + dz;
+                    bool acc;
+                    // non-top: u = (v44 + w) 2^-44 with w the proposal's word of the refinement block, needed only when the 12
+                    // leading bits do not decide (u lies in [v44, v44 + 2^32) 2^-44): drawn by the lanes that tie
+                    auto refinement = [&]() { return (uint64_t)sel4(philox_block(k >> 2, kSubRefine, syn, slot_u, a.seed_lo, a.seed_hi), (int)(k & 3)); };
+                    if (top) {
+                        acc = acc_all || dE <= 0;                                   // mcmc.py:30
+                        if (!acc) acc = philox_block(k, 2, syn, slot_u, a.seed_lo, a.seed_hi).x < a.acc_tbl_top[dE];   // :34
+                    } else {
+                        // mcmc.py:170 (Chain_xyz: a generator moves <= 4 sites) / mcmc.py:42 (a generator: dE <= 4)
+                        const bool always = !xyz_rule && (acc_all || dE <= 0);
+                        const uint64_t T = xyz_rule ? a.xyz_thr[((dx + 4) * 9 + (dy + 4)) * 9 + (dz + 4)]
+                                                    : a.acc_thr44[slot_u][dE > 4 ? 3 : dE < 1 ? 0 : dE - 1];
+                        acc = always || v44 + 0x100000000ull <= T;
+                        if (!acc && v44 < T) acc = (v44 | refinement()) < T;
+                    }
+                    if (acc) {
+                        if (logical) {
+                            for (int w = 0; w < W; ++w) lds_xor(stw + w * 64, m0[w] ^ m1[w] ^ m2[w] ^ m3[w]);
+                            cdelta ^= cd;
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) lds_xor(sad[i], shl_lo5((sops >> (2 * i)) & 3u, ssh[i]));
+                        }
+                        nx += dx; ny += dy; nz += dz;
+                    }
+                }
+                n = (uint32_t)(nx + ny + nz);
+                cls ^= cdelta;
+            }
+            }   // !BIASED
+        } else
+        if (!top_logical) {
+            [[maybe_unused]] int ni = (int)n;
+            if constexpr (SCAN) {
+                // systematic sweep: generator k mod G -- its sites are wave-uniform scalars from the plan's table --
+                // and one Philox block per four proposals (word k&3 of block k>>2): walk the blocks that overlap
+                // [kbase, kbase+iters) with a static word index
+                const uint64_t kend = kbase + iters;
+                uint32_t gs = (uint32_t)(kbase % a.n_gen);
+                uint2 ev = gtab[gs];                                               // entry of the next proposal, fetched one ahead
+                for (uint64_t kb = kbase >> 2; (kb << 2) < kend; ++kb) {
+                    const u32x4 blk = philox_block(kb, 3, syn, slot_u, a.seed_lo, a.seed_hi);
+                    const uint32_t xs[4] = {blk.x, blk.y, blk.z, blk.w};
+#pragma unroll
+                    for (int wi = 0; wi < 4; ++wi) {
+                        const uint64_t k = (kb << 2) + wi;
+                        if (k < kbase || k >= kend) continue;                       // uniform
+                        const uint32_t e0 = __builtin_amdgcn_readfirstlane(ev.x), e1 = __builtin_amdgcn_readfirstlane(ev.y);
+                        gs = gs + 1 == a.n_gen ? 0u : gs + 1;
+                        ev = gtab[gs];
+                        const uint32_t ent[4] = {e0 & 0xFFFFu, e0 >> 16, e1 & 0xFFFFu, e1 >> 16};
+                        const uint32_t op = e0 & 3u;
+                        uint32_t *ad[4];
+                        uint32_t sh[4], wv[4], F = 0;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            ad[i] = stw + (ent[i] >> 6) * 64;                      // scalar offsets
+                            sh[i] = ((ent[i] >> 2) & 15u) * 2u;
+                            wv[i] = *ad[i];                                        // all four reads in flight before the first use
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) F |= ((wv[i] >> sh[i]) & 3u) << (2 * i);
+                        const uint32_t G = F ^ (op * 0x55u);
+                        const int dE = __popc((G | (G >> 1)) & 0x55u) - __popc((F | (F >> 1)) & 0x55u);
+                        if (xs[wi] <= myT[dE]) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) lds_xor(ad[i], op << sh[i]);
+                            ni += dE;
+                        }
+                    }
+                }
+            }
+            if constexpr (SCAN) n = (uint32_t)ni;
+            else random_scan_loop();
+        } else if (acc_all && L <= 16) {
+            // Top chain at p = 0.75: every proposal is accepted (mcmc.py:30), so moves are blind
+            // XORs and commute.  Stabilizers go straight to LDS; logical operators are collected
+            // in a per-lane frame (which rows / columns carry an operator) and flushed once.
+            //   fr0: bit r      = X on row r of layer 0      bit 16+c = Z on column c of layer 0
+            //   fr1: bit c      = X on column c of layer 1   bit 16+r = Z on row r of layer 1
+            uint32_t fr0 = 0, fr1 = 0, cdelta = 0;
+            auto add_logical = [&](const u32x4 &x) {                                // _apply_random_logical, toric_model.py:228-253
+                const uint32_t op0 = x.y >> 30, op1 = x.z >> 30;
+                const uint32_t dx0 = (op0 ^ (op0 >> 1)) & 1u, dz0 = op0 >> 1;       // X iff op in {1,2}; Z iff op in {2,3}
+                const uint32_t dx1 = (op1 ^ (op1 >> 1)) & 1u, dz1 = op1 >> 1;
+                const uint32_t x0 = scale_low30(x.y, L), z0 = scale_u16(x.w >> 16, L);
+                const uint32_t x1 = scale_low30(x.z, L), z1 = scale_u16(x.w & 0xFFFFu, L);
+                fr0 ^= (dx0 << x0) | (dz0 << (16 + z0));
+                fr1 ^= (dx1 << x1) | (dz1 << (16 + z1));
+                cdelta ^= dx0 | (dz0 << 1) | (dx1 << 2) | (dz1 << 3);
+            };
+            if constexpr (SCAN) {
+                // sweep at f = 1: generator k mod G with probability 1/2 (coin bit k&31 of word (k>>5)&3 of block
+                // k>>7; a coin-less sweep composes to the identity) and one random logical every 8th proposal
+                uint32_t gs = (uint32_t)(kbase % a.n_gen);
+                u32x4 coins{0, 0, 0, 0};
+                uint64_t cb_cur = ~0ull;
+                for (uint32_t j = 0; j < iters; ++j) {
+                    const uint64_t k = kbase + j;
+                    if ((k & 7) == 0) add_logical(philox_block(k, 0, syn, slot_u, a.seed_lo, a.seed_hi));
+                    if ((k >> 7) != cb_cur) { cb_cur = k >> 7; coins = philox_block(cb_cur, 3, syn, slot_u, a.seed_lo, a.seed_hi); }
+                    const uint2 ev = gtab[gs];
+                    const uint32_t e0 = __builtin_amdgcn_readfirstlane(ev.x), e1 = __builtin_amdgcn_readfirstlane(ev.y);
+                    gs = gs + 1 == a.n_gen ? 0u : gs + 1;
+                    if ((sel4(coins, (int)((k >> 5) & 3)) >> (k & 31)) & 1u) {
+                        const uint32_t ent[4] = {e0 & 0xFFFFu, e0 >> 16, e1 & 0xFFFFu, e1 >> 16};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) lds_xor(stw + (ent[i] >> 6) * 64, (ent[i] & 3u) << (((ent[i] >> 2) & 15u) * 2u));
+                    }
+                }
+            } else
+            {
+                auto blind = [&](const u32x4 &x) {
+                    if (x.x <= thrL1) {                                             // mcmc.py:23
+                        add_logical(x);
+                    } else {
+                        const uint4 ev = gen_entry(scale_u32(x.y, 2u * (uint32_t)LL));   // word 1 picks the generator
+                        const uint32_t e4[4] = {ev.x, ev.y, ev.z, ev.w};
+                        const uint32_t op = (ev.x >> 5) & 3u;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            lds_xor(reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(stw) + (e4[i] >> 16)), shl_lo5(op, e4[i]));
+                    }
+                };
+                uint32_t j = 0;
+                if constexpr (PRE) {
+                    if (t >= 2 && NC >= 3) {                                        // (the first two top steps of a launch had no earlier role)
+#pragma unroll
+                        for (int jj = 0; jj < kPre; ++jj)
+                            if ((uint32_t)jj < pre_n) blind(pre[jj]);
+                        j = pre_n;
+                    }
+                }
+                // four proposals' Philox chains in flight: this wave is the step's longest and often runs alone
+                for (; j + 3 < iters; j += 4) {
+                    const u32x4 xa = philox_block(kbase + j, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                    const u32x4 xb = philox_block(kbase + j + 1, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                    const u32x4 xc = philox_block(kbase + j + 2, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                    const u32x4 xd = philox_block(kbase + j + 3, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                    blind(xa);
+                    blind(xb);
+                    blind(xc);
+                    blind(xd);
+                }
+                for (; j + 1 < iters; j += 2) {
+                    const u32x4 xa = philox_block(kbase + j, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                    const u32x4 xb = philox_block(kbase + j + 1, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                    blind(xa);
+                    blind(xb);
+                }
+                if (j < iters) blind(philox_block(kbase + j, 0, syn, slot_u, a.seed_lo, a.seed_hi));
+            }
+            // flush the frame: lattice row r of layer l is the 2L-bit span at bit 2*(l*LL + r*L)
+            {
+                uint32_t c0 = fr0 >> 16, c1 = fr1 & 0xFFFFu;       // column sets -> one 2-bit field per column
+                c0 = (c0 | (c0 << 8)) & 0x00FF00FFu; c0 = (c0 | (c0 << 4)) & 0x0F0F0F0Fu;
+                c0 = (c0 | (c0 << 2)) & 0x33333333u; c0 = (c0 | (c0 << 1)) & 0x55555555u;
+                c1 = (c1 | (c1 << 8)) & 0x00FF00FFu; c1 = (c1 | (c1 << 4)) & 0x0F0F0F0Fu;
+                c1 = (c1 | (c1 << 2)) & 0x33333333u; c1 = (c1 | (c1 << 1)) & 0x55555555u;
+                const uint32_t colpat0 = c0 * 3u;                   // Z (11) on the chosen columns of layer 0
+                const uint32_t colpat1 = c1;                        // X (01) on the chosen columns of layer 1
+                // The 2L rows of the two layers are one bit stream (row rr at bit rr * rowbits): each row's pattern is appended
+                // to a 32-bit accumulator and a word goes out (one ds_xor) whenever it fills.  A row's pattern is the layer's
+                // column pattern, toggled by the row operator where the row is chosen: (mask & rowpattern) ^ colpattern in one
+                // v_bitop3, the mask being the row's frame bit sign-extended (v_bfe_i32).
+                const uint32_t rowX = 0x55555555u & rowmask;           // X (01) along a chosen row of layer 0
+                // The xor returns the word it found, so the step's recount rides along: a finished word is counted while the
+                // next one is being assembled.
+                uint32_t acc = 0, fill = 0;                            // fill: bits of the accumulator in use (wave-uniform)
+                uint32_t *wp = stw;
+                uint32_t pend = 0, cnt_n = 0;                          // the last word written, not counted yet
+#define QECMC_PUT_ROW(pat_expr)                                                              \
+                {                                                                            \
+                    const uint32_t pat = (pat_expr);                                         \
+                    acc |= pat << fill;                                                      \
+                    if (fill + rowbits >= 32u) {                                             \
+                        cnt_n += nnz2(pend);                                                 \
+                        pend = __hip_atomic_fetch_xor(wp, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ^ acc;   \
+                        wp += 64;                                                            \
+                        const uint32_t rem = fill + rowbits - 32u;                           \
+                        acc = rem ? pat >> (rowbits - rem) : 0u;                             \
+                        fill = rem;                                                          \
+                    } else {                                                                 \
+                        fill += rowbits;                                                     \
+                    }                                                                        \
+                }
+                for (int r = 0; r < L; ++r)                            // layer 0: Z (11) on chosen columns, X (01) along chosen rows
+                    QECMC_PUT_ROW(__builtin_amdgcn_bitop3_b32((uint32_t)__builtin_amdgcn_sbfe((int)fr0, (uint32_t)r, 1u), rowX, colpat0, 0x6A))
+                for (int r = 0; r < L; ++r)                            // layer 1: X (01) on chosen columns, Z (11) along chosen rows
+                    QECMC_PUT_ROW(__builtin_amdgcn_bitop3_b32((uint32_t)__builtin_amdgcn_sbfe((int)fr1, 16u + (uint32_t)r, 1u), rowmask, colpat1, 0x6A))
+#undef QECMC_PUT_ROW
+                cnt_n += nnz2(pend);
+                if (fill) cnt_n += nnz2(__hip_atomic_fetch_xor(wp, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ^ acc);
+                n = cnt_n;
+            }
+            if (Lodd) cls ^= cdelta;
+        } else if (SCAN && acc_all) {
+            if constexpr (SCAN && GENTOP) blind_sweep_tables();                     // toric L > 16 at f = 1
+        } else if constexpr (GENTOP) {
+            // general top chain (L > 16, or a 1-chain ladder whose top sits below p = 0.75):
+            // table-driven logical operators and the full Metropolis test, mcmc.py:20-35
+            int ni = (int)n;
+            uint32_t cdelta = 0;
+            const uint32_t *lmask = a.lmask;
+            for (uint32_t j = 0; j < iters; ++j) {
+                const uint64_t k = kbase + j;
+                const u32x4 x = philox_block(k, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                if (x.x <= thrL1) {
+                    const uint32_t op0 = x.y >> 30, op1 = x.z >> 30;
+                    const uint32_t dx0 = (op0 ^ (op0 >> 1)) & 1u, dz0 = op0 >> 1, dx1 = (op1 ^ (op1 >> 1)) & 1u, dz1 = op1 >> 1;
+                    const uint32_t ix0 = dx0 ? scale_low30(x.y, L) : L, iz0 = dz0 ? scale_u16(x.w >> 16, L) : L;   // row L = identity
+                    const uint32_t ix1 = dx1 ? scale_low30(x.z, L) : L, iz1 = dz1 ? scale_u16(x.w & 0xFFFFu, L) : L;
+                    const int LW = (L + 1) * W;
+                    const uint32_t *m0 = lmask + ix0 * W, *m1 = lmask + LW + iz0 * W, *m2 = lmask + 2 * LW + ix1 * W,
+                                   *m3 = lmask + 3 * LW + iz1 * W;
+                    int dE = 0;
+                    for (int w = 0; w < W; ++w) {
+                        const uint32_t old = stw[w * 64];
+                        dE += (int)nnz2(old ^ m0[w] ^ m1[w] ^ m2[w] ^ m3[w]) - (int)nnz2(old);
+                    }
+                    bool acc = true;
+                    if (!acc_all && dE > 0) acc = philox_block(k, 2, syn, slot_u, a.seed_lo, a.seed_hi).x < a.acc_tbl_top[dE];
+                    if (acc) {
+                        for (int w = 0; w < W; ++w) lds_xor(stw + w * 64, m0[w] ^ m1[w] ^ m2[w] ^ m3[w]);
+                        ni += dE;
+                        cdelta ^= dx0 | (dz0 << 1) | (dx1 << 2) | (dz1 << 3);
+                    }
+                } else {
+                    uint32_t q[4], op;
+                    if constexpr (SCAN) {                                          // generator k mod G from the plan's table
+                        const uint2 e = gtab[(uint32_t)(k % a.n_gen)];
+                        q[0] = (e.x & 0xFFFFu) >> 2; q[1] = e.x >> 18; q[2] = (e.y & 0xFFFFu) >> 2; q[3] = e.y >> 18;
+                        op = e.x & 3u;
+                    } else {
+                        const uint32_t g = scale_u32(x.y, 2u * (uint32_t)LL), isX = g < (uint32_t)LL, rc = isX ? g : g - (uint32_t)LL;
+                        toric_sites(L, LL, rc / (uint32_t)L, rc % (uint32_t)L, isX, q);
+                        op = isX ? 1u : 3u;
+                    }
+                    int dE = 0;
+                    for (int i = 0; i < 4; ++i) {
+                        const uint32_t f = (stw[(q[i] >> 4) * 64] >> ((q[i] & 15u) * 2u)) & 3u;
+                        dE += (int)(f == 0u) - (int)(f == op);
+                    }
+                    bool acc = true;
+                    if (!acc_all && dE > 0) acc = philox_block(k, 2, syn, slot_u, a.seed_lo, a.seed_hi).x < a.acc_tbl_top[dE];
+                    if (acc) {
+                        for (int i = 0; i < 4; ++i) lds_xor(stw + (q[i] >> 4) * 64, op << ((q[i] & 15u) * 2u));
+                        ni += dE;
+                    }
+                }
+            }
+            n = (uint32_t)ni;
+            if (Lodd) cls ^= cdelta;
+        }
+
+        // ---------------- swap sweep, Ladder.step mcmc.py:96-103 --------------------------------
+        // (double-buffered by step parity: a fast wave may publish step t+1 while a slow one still reads step t)
+        uint32_t *cur = info + (t & 1) * NC * 64 + lane, *sx = swx + (t & 1) * NC * 64 + lane;
+        cur[slot_u * 64] = pack_info(n, sid, cls, flag);
+        if constexpr (PRE) {
+            // the wave on slot 1 becomes the top chain two steps from now, the wave on slot 0 next step: each draws half of that
+            // step's top-chain blocks (state-independent: block (proposal index, 0) of the top slot's stream) while the others finish
+            if (NC >= 3 && slot_u <= 1u && a.thr_logical != 0) {
+                const uint64_t kb1 = a.prop0 + (t + 1 + slot_u) * iters;
+#pragma unroll
+                for (int jj = 0; jj < kPre; ++jj) {
+                    const bool mine = slot_u == 1u ? (uint32_t)jj < pre_h : ((uint32_t)jj >= pre_h && (uint32_t)jj < pre_n);
+                    if (mine) pre[jj] = philox_block(kb1 + jj, 0, syn, (uint32_t)(NC - 1), a.seed_lo, a.seed_hi);
+                }
+            }
+        }
+        const int swb = NC - 2 - (int)slot_u;                     // Philox block of swap uniforms this wave draws (if any)
+        if (swb >= 0 && swb < 4 && swb * 4 < NC - 1) {
+            // the sweep's uniforms do not depend on the state: the slots just below the top (never the
+            // heavier top slot itself) draw one Philox block each
+            const u32x4 b = philox_block(a.step0 + t, (uint32_t)swb, syn, kSwapStream, a.seed_lo, a.seed_hi);
+            uint32_t *p = sx + swb * 4 * 64;                       // rows 4b .. 4b+3 = rung pairs, NC-1 of them exist
+            const int left = NC - 1 - swb * 4;
+            // The swap test u < p_diff[i]^d (mcmc.py:149) does not need the records: thresholds fall with d, so it reads
+            // d <= dmax with dmax = the largest d whose threshold exceeds x.  dmax is found here, off the cascade's serial
+            // path: a log2 guess, then the exact table moves it up or down (so rounding in the guess cannot matter).
+            auto swap_dmax = [&](uint32_t x, int i) -> uint32_t {
+                if (BIASED && alpha_noise) return x;                // Ladder_alpha compares in floating point (below)
+                auto below = [&](int dd) -> bool {                  // x < ceil(p_diff[i]^dd * 2^32), dd in [1, nq]
+                    return (swap_fast && dd < kSwapFast) ? x < swapT[i * kSwapFast + dd]
+                                                         : (uint64_t)x < a.swap_thr[(size_t)i * (nq + 1) + dd];
+                };
+                const float inv = a.swap_inv_log2[i];               // 0: p_diff[i] >= 1 (coinciding rungs), every d passes
+                int d = inv == 0.0f ? nq : (int)((__log2f((float)x + 0.5f) - 32.0f) * inv);
+                d = d < 0 ? 0 : d > nq ? nq : d;
+                if (swap_fast && d + 2 < kSwapFast) {
+                    // the guess is within one of the answer: look at the four thresholds around it at once (independent LDS
+                    // reads) instead of walking the table; entries past nq are 0 and never pass
+                    const int w0 = d > 1 ? d - 1 : 1;
+                    const uint32_t *T = swapT + i * kSwapFast + w0;
+                    const int c = (int)(x < T[0]) + (int)(x < T[1]) + (int)(x < T[2]) + (int)(x < T[3]);   // a prefix passes
+                    d = w0 - 1 + c;
+                    if (c < 4 && (c > 0 || w0 == 1)) return (uint32_t)d;   // the answer lies inside the window
+                }
+                while (d < nq && below(d + 1)) ++d;
+                while (d > 0 && !below(d)) --d;
+                return (uint32_t)d;
+            };
+            // (results first, stores after: the four look-ups are independent and overlap)
+            const uint32_t r0 = swap_dmax(b.x, swb * 4);
+            const uint32_t r1 = left > 1 ? swap_dmax(b.y, swb * 4 + 1) : 0u;
+            const uint32_t r2 = left > 2 ? swap_dmax(b.z, swb * 4 + 2) : 0u;
+            const uint32_t r3 = left > 3 ? swap_dmax(b.w, swb * 4 + 3) : 0u;
+            p[0] = r0;
+            if (left > 1) p[64] = r1;
+            if (left > 2) p[128] = r2;
+            if (left > 3) p[192] = r3;
+        }
+        __syncthreads();
+        if (CONV || USET) {                                 // flags set one step earlier: uniform for the workgroup
+            volatile uint32_t *f0 = lds_all + (NC * W * 64 + 4 * NC * 64 + ncls * 64 + NC * 9 + NC * kSwapFast);
+            if (f0[0]) break;
+        }
+        {
+            // every wave replays the top-down cascade on the published records; `car` is the record
+            // being carried down, `mine` the one that ends in the slot this wave takes over next
+            slot_u = slot_u == 0 ? (uint32_t)(NC - 1) : slot_u - 1;   // downwards: the wave leaving the top slot needs one rung only
+            uint32_t car = cur[(NC - 1) * 64], mine = car;
+            // a wave only needs the cascade down to the rung that fills its own next slot (wave 0 also does the
+            // slot-0 bookkeeping and runs it to the bottom).  (Compiling the cascade twice -- wave 0 capturing its record on the way,
+            // the others taking what their last rung leaves -- saves a v_cndmask per rung and measured 2 % slower.)
+            const int i_stop = (wave_u == 0 || slot_u == 0) ? 0 : (int)slot_u - 1;
+            // four rungs at a time: their records and swap bounds are fetched together, so a rung costs a few integer
+            // operations instead of an LDS round trip on the serial path
+            for (int ib = NC - 2; ib >= i_stop; ib -= 4) {                          // mcmc.py:96
+                uint32_t lo4[4], x4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int ic = ib - u < 0 ? 0 : ib - u;
+                    lo4[u] = cur[ic * 64];
+                    x4[u] = sx[ic * 64];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = ib - u;
+                    const uint32_t lo = lo4[u], xi = x4[u];
+                    const int d = (int)(car & 0xFFFFu) - (int)(lo & 0xFFFFu);      // ne_hi - ne_lo
+                    bool flip = d <= (int)xi;                                       // _r_flip :146-149: d <= 0, or u < rel_p**d <=> d <= dmax
+                    if (BIASED && alpha_noise) {
+                        // Ladder_alpha.r_flip, mcmc_alpha.py:118-123: slot-bound n_eff, always draws
+                        const uint32_t *ne = neffb + (t & 1) * NC * 64 + lane;
+                        const int ic = i < 0 ? 0 : i;
+                        flip = alpha_flip(xi, ne[(ic + 1) * 64], ne[ic * 64], a.alpha, a.alpha_lnb[ic]);
+                    }
+                    if (i >= i_stop) {                                              // uniform
+                        const uint32_t into = flip ? lo : car;                      // what slot i+1 now holds (:98-99)
+                        car = flip ? car : lo;
+                        if ((int)slot_u == i + 1) mine = into;
+                    }
+                }
+            }
+            if (slot_u == 0) mine = car;
+            n = mine & 0xFFFFu; sid = (mine >> 16) & 0xFFu; cls = (mine >> 24) & 0x3Fu; flag = mine >> 31;
+            if ((int)slot_u == NC - 1) flag = 1;                                    // chains[-1].flag = 1, mcmc.py:100
+            if (wave_u == 0 && !done) {                                             // ladder + PTEQ bookkeeping on slot 0's new state
+                tops0 += (NC == 1) | (car >> 31);                                   // chains[0].flag == 1, :101-102
+                const uint32_t n0 = car & 0xFFFFu;
+                if (a.counts != nullptr && tops0 >= a.tops_burn) {                  // decoders.py:60-67
+                    const uint32_t v = (car >> 24) & 0x3Fu;
+                    hist[(CODE == kCodeXzzx ? (v ^ (v >> 1)) : v) * 64 + lane] += 1;
+                    samples++;
+                    if (CONV && BIASED && alpha_noise) {
+                        // nbr_errors_bottom_chain[since_burn] = chains[0].n_eff (decoders_biasednoise.py:204): slot 0's
+                        // attribute, logged as its two counts; the window sums stay exact integers
+                        if (lane < cnt) {
+                            uint32_t *mylog = reinterpret_cast<uint32_t *>(a.nlog) + (s0 + lane);
+                            const uint32_t v0 = neffb[(t & 1) * NC * 64 + lane];
+                            mylog[(size_t)t * a.N] = v0;
+                            const uint32_t l = samples, lo1 = l - 1;
+                            const uint32_t a0 = lo1 >> 2, b0 = lo1 >> 1, c0 = (3u * lo1) >> 2, a1 = l >> 2, b1 = l >> 1, c1 = (3u * l) >> 2;
+                            sumB += v0 & 0xFFFFu; sumBxy += v0 >> 16;
+                            if (c1 != c0) { const uint32_t v = mylog[(size_t)(burn + c0) * a.N]; sumB -= v & 0xFFFFu; sumBxy -= v >> 16; }
+                            if (b1 != b0) { const uint32_t v = mylog[(size_t)(burn + b0) * a.N]; sumA += v & 0xFFFFu; sumAxy += v >> 16; }
+                            if (a1 != a0) { const uint32_t v = mylog[(size_t)(burn + a0) * a.N]; sumA -= v & 0xFFFFu; sumAxy -= v >> 16; }
+                        }
+                    } else
+                    if (CONV && lane < cnt) {
+                        // nbr_errors_bottom_chain[since_burn] = count_errors (:68); series index i lives in log row burn+i
+                        uint16_t *mylog = a.nlog + (s0 + lane);
+                        mylog[(size_t)t * a.N] = (uint16_t)n0;
+                        const uint32_t l = samples, lo1 = l - 1;
+                        const uint32_t a0 = lo1 >> 2, b0 = lo1 >> 1, c0 = (3u * lo1) >> 2, a1 = l >> 2, b1 = l >> 1, c1 = (3u * l) >> 2;
+                        sumB += n0;
+                        if (c1 != c0) sumB -= mylog[(size_t)(burn + c0) * a.N];
+                        if (b1 != b0) sumA += mylog[(size_t)(burn + b0) * a.N];
+                        if (a1 != a0) sumA -= mylog[(size_t)(burn + a0) * a.N];
+                    }
+                } else {
+                    burn++;                                                         // resulting_burn_in, :71
+                }
+                if (CONV && tops0 >= a.TOPS) {                               // :74
+                    const uint32_t l = samples ? samples : 1u;
+                    const uint32_t den2 = (l >> 1) - (l >> 2), den4 = l - ((3u * l) >> 2);
+                    bool accept = false;                                            // empty slice -> nan -> not accepted
+                    if (samples && den2 && den4) {
+                        if (BIASED && alpha_noise)
+                            accept = alpha_series_close(sumA, sumAxy, den2, sumB, sumBxy, den4, a.alpha, a.eps);
+                        else
+                            accept = fabs((double)sumA / (double)den2 - (double)sumB / (double)den4) < a.eps;   // :96-102
+                    }
+                    if (accept) {
+                        if (conv_streak >= a.SEQ) { done = 1; conv_ok = 1; steps_done = (uint32_t)t + 1; }   // :77-78
+                        else conv_streak = tops0 - conv_start;                      // :79
+                    } else {
+                        conv_streak = 0;                                            // :81-82
+                        conv_start = tops0;
+                    }
+                }
+            }
+            if (a.swap_acc != nullptr && wave_u == 0) {
+                // equilibrium observables (qecmc_plan_set_stats): the cascade once more, with every rung's decision and the error
+                // count each rung ends the step with added to per-lane LDS counters (off the hot path: one scalar branch when off)
+                uint32_t *sacc = lds_all + gdw + lane, *nsum = sacc + NC * 64;
+                uint32_t c2 = cur[(NC - 1) * 64];
+                for (int i = NC - 2; i >= 0; --i) {
+                    const uint32_t lo = cur[i * 64], xi = sx[i * 64];
+                    bool flip = (int)(c2 & 0xFFFFu) - (int)(lo & 0xFFFFu) <= (int)xi;
+                    if (BIASED && alpha_noise) {
+                        const uint32_t *ne = neffb + (t & 1) * NC * 64 + lane;
+                        flip = alpha_flip(xi, ne[(i + 1) * 64], ne[i * 64], a.alpha, a.alpha_lnb[i]);
+                    }
+                    if (!done) {                                                   // (a converged syndrome stops counting)
+                        sacc[i * 64] += flip;
+                        nsum[(i + 1) * 64] += (flip ? lo : c2) & 0xFFFFu;
+                    }
+                    c2 = flip ? c2 : lo;
+                }
+                if (!done) nsum[0] += c2 & 0xFFFFu;
+            }
+            if (CONV && wave_u == 0 && __all(done || lane >= cnt)) *stopf = 1;
+            if (slot_u == 0) flag = 0;                                              // :103
+            if constexpr (USET) {
+                const bool cm = a.uset_conv_mult != 0.0;
+                if (cm && t > 0 && !cm_done) {
+                    // the stop test that ends step t-1 (decoders.py:159-162, :261-262, :825-826), now that every rung's
+                    // insertion of that step is behind this step's barrier
+                    const uint32_t tp = (uint32_t)t - 1u;
+                    if (cm_trig[(tp & 1u) * 64 + lane] == tp) cm_last = tp;         // stop = step * conv_mult, :156
+                    if ((double)tp >= (double)cm_last * a.uset_conv_mult && (uint64_t)tp * 100u >= a.nsteps) { cm_done = 1; cm_steps = (uint32_t)t; }
+                }
+                // PTDC_droplet / PTRC_droplet (decoders.py:146-152, :596-618): the configuration now in this wave's rung goes into
+                // the set of chains seen so far.  Key = FNV-1a over the packed words (any collision-free key gives the same N(n)).
+                if (lane < cnt && !cm_done) {
+                    const uint32_t *sw = st + sid * W * 64 + lane;
+                    uint64_t h = 0xCBF29CE484222325ull;
+                    for (int w = 0; w < W; ++w) h = (h ^ sw[w * 64]) * 0x100000001B3ull;
+                    h ^= h >> 32;
+                    const unsigned long long key = h ? h : 1ull;
+                    const uint64_t ladder = s0 + (uint64_t)lane;
+                    const uint64_t set = a.uset_per_rung ? ladder * (uint64_t)NC + slot_u : ladder / a.uset_D;
+                    if (a.uset_mhist != nullptr) atomicAdd(a.uset_mhist + set * (uint64_t)(nq + 1) + n, 1u);
+                    unsigned long long *tb = a.uset_tab + set * a.uset_cap;
+                    uint64_t idx = ((key * 0x9E3779B97F4A7C15ull) >> 20) & (a.uset_cap - 1);
+                    bool fresh = false;
+                    for (uint64_t probes = 0; probes < a.uset_cap; ++probes) {     // the table holds twice the insertions it can see
+                        const unsigned long long old = atomicCAS(tb + idx, 0ull, key);
+                        if (old == 0ull) { atomicAdd(a.uset_hist + set * (uint64_t)(nq + 1) + n, 1u); fresh = true; break; }
+                        if (old == key) break;
+                        idx = (idx + 1) & (a.uset_cap - 1);
+                    }
+                    if (fresh && a.uset_xyz != nullptr) {
+                        int cx = 0, cy = 0, cz = 0;
+                        for (int w = 0; w < W; ++w) count_xyz(sw[w * 64], cx, cy, cz);
+                        const uint32_t pos = atomicAdd(a.uset_xyz_cnt + set, 1u);
+                        if (pos < a.uset_xyz_stride) a.uset_xyz[set * a.uset_xyz_stride + pos] = (uint32_t)cx | ((uint32_t)cy << 10) | ((uint32_t)cz << 20);
+                    }
+                    if (cm) {
+                        if (a.uset_own != nullptr) {
+                            // the stop looks at the droplet's own dictionary (one process per droplet in the reference, :213-219),
+                            // the class set above is the union over the droplets (:220-226)
+                            unsigned long long *ob = a.uset_own + ladder * a.uset_own_cap;
+                            uint64_t oi = ((key * 0x9E3779B97F4A7C15ull) >> 20) & (a.uset_own_cap - 1);
+                            fresh = false;
+                            for (uint64_t probes = 0; probes < a.uset_own_cap; ++probes) {
+                                const unsigned long long old = atomicCAS(ob + oi, 0ull, key);
+                                if (old == 0ull) { fresh = true; break; }
+                                if (old == key) break;
+                                oi = (oi + 1) & (a.uset_own_cap - 1);
+                            }
+                        }
+                        // "if conv_mult and length <= shortest" (:153-156) on the rungs in any order: the step extends the run
+                        // iff its shortest new chain is no longer than the shortest seen before, and that rung always passes
+                        if (fresh && n <= atomicMin(&cm_short[lane], n)) cm_trig[((uint32_t)t & 1u) * 64 + lane] = (uint32_t)t;
+                    }
+                }
+                if (cm && wave_u == 0 && __all(cm_done || lane >= cnt)) *stopf = 1;
+            }
+        }
+    }
+#ifdef QECMC_TIMELINE
+    if (a.dbg && threadIdx.x == 0) a.dbg[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+#endif
+    uint32_t *fin = info + (a.nsteps & 1) * NC * 64;
+    fin[slot_u * 64 + lane] = pack_info(n, sid, cls, flag);
+    __syncthreads();
+
+    // ---- results: coalesced stores ---------------------------------------------------
+    if (a.counts != nullptr)
+#pragma unroll 1
+        for (int i = tid; i < cnt * ncls; i += nthreads) {
+            const int j = i / ncls, c = i - j * ncls;
+            const uint32_t v = hist[c * 64 + j];
+            if (R > 1) { if (v) atomicAdd(a.counts + ((s0 + (uint64_t)j) / R) * ncls + c, v); }   // the syndrome's R ladders, summed
+            else if (a.accumulate) a.counts[s0 * ncls + i] += v;
+            else a.counts[s0 * ncls + i] = v;
+        }
+    if (a.swap_acc != nullptr) {
+#pragma unroll 1
+        for (int i = tid; i < cnt * (2 * NC - 1); i += nthreads) {
+            const int j = i / (2 * NC - 1), c = i - j * (2 * NC - 1);
+            if (c < NC - 1) a.swap_acc[(s0 + j) * (NC - 1) + c] = lds_all[gdw + c * 64 + j];
+            else if (a.nerr_sum != nullptr) a.nerr_sum[(s0 + j) * NC + (c - (NC - 1))] = lds_all[gdw + (NC + c - (NC - 1)) * 64 + j];
+        }
+    }
+    if (slot == 0 && lane < cnt && R > 1) {
+        const uint64_t row = (s0 + lane) / R;
+        if (a.samples != nullptr) atomicAdd(a.samples + row, samples);
+        if (a.tops0 != nullptr) atomicAdd(a.tops0 + row, tops0);
+        if (a.steps_done != nullptr) atomicMax(a.steps_done + row, done ? steps_done : (uint32_t)a.nsteps);
+        if (a.converged != nullptr && !conv_ok) a.converged[row] = 0;               // the caller presets 1: all R ladders converged
+    } else
+    if (slot == 0 && lane < cnt) {
+        if (a.samples != nullptr) a.samples[s0 + lane] = a.accumulate ? a.samples[s0 + lane] + samples : samples;
+        if (a.steps_done != nullptr) a.steps_done[s0 + lane] = USET ? (cm_done ? cm_steps : (uint32_t)a.nsteps) : done ? steps_done : (uint32_t)a.nsteps;
+        if (a.converged != nullptr) a.converged[s0 + lane] = (uint8_t)conv_ok;
+        if (a.tops0 != nullptr) a.tops0[s0 + lane] = tops0;
+        if (a.flags != nullptr)
+            for (int c = 0; c < NC; ++c) a.flags[(s0 + lane) * NC + c] = (uint8_t)(fin[c * 64 + lane] >> 31);
+    }
+    if constexpr (BIASED) {
+        if (alpha_noise && a.neff != nullptr && lane < cnt)
+            a.neff[(s0 + lane) * NC + slot] = neffb[((((uint32_t)a.nsteps & 1u) ^ 1u) * NC + slot) * 64 + lane];
+    }
+    if (a.write_states && a.states != nullptr) {
+        uint8_t *dst = a.states + s0 * (uint64_t)NC * nq;
+        const int per = NC * nq, total = cnt * per;
+#pragma unroll 1      // (unrolled, its index divisions spill a register of the whole kernel to scratch)
+        for (int o = tid; o < total; o += nthreads) {
+            const int j = o / per, rem = o - j * per, c = rem / nq, q = rem - c * nq;
+            const uint32_t sidc = (fin[c * 64 + j] >> 16) & 0xFFu;
+            dst[o] = (uint8_t)((st[(sidc * W + (q >> 4)) * 64 + j] >> ((q & 15) * 2)) & 3u);
+        }
+    }
+}
+
+// dynamic LDS of one workgroup
+inline size_t ladder_launch_lds(const LadderArgs &a)
+{
+    size_t lds = sizeof(uint32_t) * (size_t)ladder_group_dwords(a.Nc, a.W, a.ncls, ladder_gen_dwords(a.code, a.noise, a.scan, a.n_gen, a.Nc, a.nq, a.n_types));
+    if (a.swap_acc != nullptr) lds += ladder_stats_lds_bytes(a.Nc);   // per-lane counters behind the group's region
+    return lds;
+}
+// a workgroup whose LDS footprint lets at most two of them share a CU (or which has more than 8 waves) runs at most 4 waves
+// per SIMD whatever its register count: such shapes take the 128-VGPR instantiations that draw the top chain's Philox blocks
+// ahead (PRE)
+inline bool ladder_wants_pre(const LadderArgs &a)
+{
+    return a.Nc >= 3 && (a.Nc * 64 > 512 || 3 * ladder_launch_lds(a) > 160 * 1024) && a.thr_logical != 0 && !(a.tune & 2u);
+}
+
+// launch `fn` (one of the instantiations above) on the grid the arguments imply
+inline hipError_t launch_ladder_fn(const void *fn, const LadderArgs &a, hipStream_t stream)
+{
+    const unsigned grid = (unsigned)((a.N + 63) / 64), block = (unsigned)a.Nc * 64u;
+    const size_t lds = ladder_launch_lds(a);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (lds > 64 * 1024) {   // beyond the default dynamic-LDS window (160 KiB per CU on gfx950)
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    void *kargs[] = {const_cast<LadderArgs *>(&a)};
+    hipError_t e = hipLaunchKernel(fn, dim3(grid), dim3(block), kargs, lds, stream);
+    if (e != hipSuccess) return e;
+    return hipGetLastError();
+}
+
+// one translation unit per kernel family (parallel builds): each picks among its own instantiations
+hipError_t launch_ladder_toric(const LadderArgs &a, hipStream_t stream);      // ladder_toric.hip: toric, depolarizing, random scan
+hipError_t launch_ladder_sweep(const LadderArgs &a, hipStream_t stream);      // ladder_sweep.hip: scan = 1, every code
+hipError_t launch_ladder_surf(const LadderArgs &a, hipStream_t stream);       // ladder_surf.hip: xzzx / rotated / planar, depolarizing, random scan
+hipError_t launch_ladder_biased(const LadderArgs &a, hipStream_t stream);     // ladder_biased.hip: biased and alpha rules
+hipError_t launch_ladder_uset(const LadderArgs &a, hipStream_t stream);       // ladder_uset.hip: the unique-chain estimators' set insertion
+
+}  // namespace qecmc

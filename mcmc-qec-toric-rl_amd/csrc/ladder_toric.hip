@@ -1,0 +1,38 @@
+// Toric code, depolarizing rule, the reference's random scan: the headline kernel family.
+#include "ladder_kernel.hpp"
+
+namespace qecmc {
+
+hipError_t launch_ladder_toric(const LadderArgs &a, hipStream_t stream)
+{
+    constexpr int T = kCodeToric;
+    const unsigned block = (unsigned)a.Nc * 64u;
+    const bool conv = a.conv_mode != 0;
+    // the general top-chain path is needed only for L > 16 or a top chain below p = 0.75 (1-chain ladder)
+    const bool gentop = a.thr_logical != 0 && (a.L > 16 || !((a.acc_all_mask >> (a.Nc - 1)) & 1u));
+    const bool gsplit = (int)a.n_gen <= kGenSplit;      // the table layout of ladder_gen_dwords()
+    const void *fn;
+#define QECMC_K(maxt, minw, g, gentop) (conv ? (const void *)ladder_rs_toric_kernel<maxt, minw, true, g, T, false, false, gentop> \
+                                             : (const void *)ladder_rs_toric_kernel<maxt, minw, false, g, T, false, false, gentop>)
+    if (gentop) {
+        if (block <= 512) fn = gsplit ? QECMC_K(512, 8, true, true) : QECMC_K(512, 8, false, true);
+        else fn = gsplit ? QECMC_K(1024, 4, true, true) : QECMC_K(1024, 4, false, true);
+    } else if (ladder_wants_pre(a)) {
+#define QECMC_KP(maxt, g) (conv ? (const void *)ladder_rs_toric_kernel<maxt, 4, true, g, T, false, false, false, false, false, true> \
+                                : (const void *)ladder_rs_toric_kernel<maxt, 4, false, g, T, false, false, false, false, false, true>)
+        if (block <= 512) fn = gsplit ? QECMC_KP(512, true) : QECMC_KP(512, false);
+        else fn = gsplit ? QECMC_KP(1024, true) : QECMC_KP(1024, false);
+#undef QECMC_KP
+    } else if (block <= 512 && gsplit && (int)a.n_gen + 64 <= kGenSplit && !(a.tune & 4u)) {
+        // the dE look-up table fits the idle entries between the split table's halves (2 L^2 <= 191: the headline's L = 9)
+        fn = conv ? (const void *)ladder_rs_toric_kernel<512, 8, true, true, T, false, false, false, false, false, false, true>
+                  : (const void *)ladder_rs_toric_kernel<512, 8, false, true, T, false, false, false, false, false, false, true>;
+    } else {
+        if (block <= 512) fn = gsplit ? QECMC_K(512, 8, true, false) : QECMC_K(512, 8, false, false);
+        else fn = gsplit ? QECMC_K(1024, 4, true, false) : QECMC_K(1024, 4, false, false);
+    }
+#undef QECMC_K
+    return launch_ladder_fn(fn, a, stream);
+}
+
+}  // namespace qecmc

@@ -147,7 +147,8 @@ __global__ void k_chain_update(const ChainArgs a)
         // ---- accept?
         bool acc;
         if (a.noise) {                                                              // mcmc_biased.py:40-46 / :53-59
-            const double u = top ? (double)philox_block(k, 2, syn, a.slot, a.seed_lo, a.seed_hi).x * (1.0 / 4294967296.0)
+            // top: word 2 of the proposal's own block (the plaquette codes' logical draws leave it unused)
+            const double u = top ? (double)x.z * (1.0 / 4294967296.0)
                                  : (double)v44 * (1.0 / 17592186044416.0);         // 2^-44, exact
             acc = u < biased_weight_b(a.bias_tbl, nq, m) / pb;
         } else if (top) {                                                           // mcmc.py:30-34

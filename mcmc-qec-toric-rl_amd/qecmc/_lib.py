@@ -88,12 +88,30 @@ SIGNATURES = {
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """PyTorch's ROCm wheels bundle their own HIP runtime.  A process that loads libqecmc (linked against /opt/rocm) first and
+    initialises torch.cuda afterwards would hold two runtimes and torch then finds no device; loading torch's copy first makes
+    both sides resolve the same libamdhip64 (what happens anyway when torch is imported before this module is used).
+    No torch installed: nothing to do -- the library does not need it."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise QecmcError(f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` "
                              "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        _share_torch_hip_runtime()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)

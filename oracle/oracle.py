@@ -54,7 +54,7 @@ class PteqResult(C.Structure):
 def lib():
     global _LIB
     if _LIB is None:
-        _LIB = C.CDLL(build())
+        _LIB = C.CDLL(os.environ.get("QECMC_ORACLE_LIB") or build())   # (override: the sanitizer build, oracle/Makefile `asan`)
         u8p = C.POINTER(C.c_uint8)
         _LIB.orc_toric_apply_stabilizer.argtypes = [C.c_int, u8p, u8p, C.c_int, C.c_int, C.c_int]
         _LIB.orc_toric_apply_stabilizer.restype = C.c_int

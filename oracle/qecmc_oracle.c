@@ -440,7 +440,7 @@ int orc_chain_update_alpha(const orc_model *m, uint8_t *state, double pz_tilde, 
         if (p_logical != 0) {
             if (orc_draw(rng, slot, k, 0, 0) < p_logical) model_random_logical(m, state, scratch, rng, slot, k);
             else model_random_stabilizer(m, state, scratch, rng, slot, k, 1);
-            u = orc_draw(rng, slot, k, 2, 0);
+            u = orc_draw(rng, slot, k, 0, 2);     /* word 2 of the proposal block: unused by the plaquette codes' logical draws */
         } else {
             model_random_stabilizer(m, state, scratch, rng, slot, k, 0);
             u = nontop_accept(m, rng, slot, k);
@@ -477,7 +477,7 @@ void orc_chain_update(const orc_model *m, uint8_t *state, double p, double p_log
                 if (orc_draw(rng, slot, k, 0, 0) < p_logical) model_random_logical(m, state, scratch, rng, slot, k);
                 else model_random_stabilizer(m, state, scratch, rng, slot, k, 1);
                 const double pn = biased_weight(scratch, (int)nq, px, py, pz);
-                u = orc_draw(rng, slot, k, 2, 0);
+                u = orc_draw(rng, slot, k, 0, 2);     /* word 2 of the proposal block: unused by the plaquette codes' logical draws */
                 if (u < pn / pb) memcpy(state, scratch, nq);
             } else {                                                                    /* :49-59 */
                 model_random_stabilizer(m, state, scratch, rng, slot, k, 0);
