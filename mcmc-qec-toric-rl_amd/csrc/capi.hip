@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -213,7 +214,8 @@ std::vector<uint32_t> surf_generator_table(int code, int L)
 struct qecmc_plan {
     qecmc_params prm;
     LadderArgs args;
-    DevBuf swap_thr, lmask, acc_top, gen, bias, lnb, xyz_lut, gen_type;
+    DevBuf swap_thr, lmask, acc_top, gen, bias, lnb, xyz_lut, gen_type, queue;
+    uint32_t queue_grid = 0;                                   // persistent grid of the work-queue kernels (0: not a queue plan)
     size_t lds_bytes;
     uint32_t *d_swap_acc = nullptr, *d_nerr_sum = nullptr;   // qecmc_plan_set_stats (caller-owned)
 };
@@ -301,6 +303,18 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
     pl->lds_bytes = ladder_lds_bytes(L, Nc, W, ncls, ladder_gen_dwords(p->code, p->noise, p->scan, n_gen, Nc, nq, a.n_types));
     if (pl->lds_bytes > 160 * 1024)
         return fail(QECMC_ERR_UNSUPPORTED, "L=%d Nc=%d needs %zu B of LDS per workgroup (> 160 KiB)", L, Nc, pl->lds_bytes);
+    if (ladder_uses_queue(p->code, p->noise, p->scan, p->conv_mode, L, Nc, p->p_logical)) {
+        // runs that stop by the convergence criterion: a persistent grid (what one launch keeps resident) fed from a counter
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, p->device));
+        const size_t per_cu_lds = (160 * 1024) / pl->lds_bytes, per_cu_waves = (size_t)(Nc * 64 <= 512 ? 32 : 16) / (size_t)Nc;
+        size_t per_cu = per_cu_lds < per_cu_waves ? per_cu_lds : per_cu_waves;
+        if (per_cu < 1) per_cu = 1;
+        pl->queue_grid = (uint32_t)(per_cu * (size_t)prop.multiProcessorCount);
+        if (const char *qg = std::getenv("QECMC_QUEUE_GRID")) pl->queue_grid = (uint32_t)std::strtoul(qg, nullptr, 0);   // tests: force refills on small batches
+        if (pl->queue_grid == 0) pl->queue_grid = 1;
+        HIP_TRY(pl->queue.alloc(sizeof(uint32_t)));
+    }
 
     std::vector<double> pladder, pdiff;
     // p_top = 0.75 (mcmc.py:62) or (eta+1)/(2 eta+1) (mcmc_biased.py:81)
@@ -685,6 +699,12 @@ int qecmc_pteq_launch_dev(qecmc_plan *plan, const void *d_init, uint64_t N, uint
     a.write_states = d_final_states != nullptr;
     a.N = M; a.first_syndrome = first_syndrome;
     a.step0 = 0; a.prop0 = 0; a.nsteps = plan->prm.steps; a.resume = 0;
+    if (plan->queue_grid && !a.swap_acc && !d_final_states) {
+        // (one launch at a time per plan: the counter belongs to the plan)
+        HIP_TRY(hipMemsetAsync(plan->queue.p, 0, sizeof(uint32_t), strm));
+        a.queue = plan->queue.as<uint32_t>();
+        a.grid_cap = plan->queue_grid;
+    }
     HIP_TRY(launch_ladder_rs_toric(a, strm));
     return 0;
 }
@@ -743,6 +763,11 @@ int qecmc_pteq_batch_stats(const qecmc_params *params, const uint8_t *init, uint
     const size_t nq = pl->args.nq, Nc = pl->args.Nc, ncls = pl->args.ncls, R = pl->args.replicas;
     uint64_t ws_bytes = 0;
     qecmc_plan_workspace_bytes(pl, N, &ws_bytes);
+    if (pl->queue_grid && !swap_accepts_out && !nerr_sums_out && !final_states_out) {
+        // the work-queue kernels log one column per lane of the persistent grid, not per ladder
+        const uint64_t cols = std::min<uint64_t>(N * R, (uint64_t)pl->queue_grid * 64u);
+        ws_bytes = 2ull * cols * pl->prm.steps;
+    }
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     if (ws_bytes > free_b / 2)

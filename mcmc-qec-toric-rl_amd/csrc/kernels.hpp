@@ -81,6 +81,8 @@ struct LadderArgs {
     int write_states;
     // replicas R >= 1: a.N counts LADDERS (syndromes x R); ladder l starts from init row l / R and adds its class counts, samples
     // and tops0 to the outputs of syndrome l / R (atomics; the caller zeroes them) -- decoders.py:215-225 "droplets"
+    uint32_t *queue;          // QUEUE kernels: the batch's counter of ladders handed out after launch (zeroed by the caller)
+    uint32_t grid_cap;        // ... the persistent grid: at most this many workgroups (0: one per 64 ladders)
     uint32_t tune;            // development knobs (QECMC_TUNE; 0 in production): bit 0 = the top-role wave runs at the highest issue priority
     uint32_t replicas;
     int accumulate;           // counts / samples are added to (qecmc_pteq_resume_dev)
@@ -110,6 +112,12 @@ inline int ladder_gen_dwords(int code, int noise, int scan, uint32_t n_gen, int 
     if (noise == 2) d = ((d + 3) & ~3) + 2 * Nc * 64;
     if (noise) d = ((d + 3) & ~3) + 256 * n_types + Nc * 64 + 2 * (nq_L(code, nq) + 1) * ((nq + 15) / 16);   // + the X / Z logical masks [2][L+1][W]
     return d;
+}
+// the shapes the work-queue kernels exist for: toric, depolarizing, random scan, error_based criterion, the framed top chain
+// (L <= 16, a top rung at p = 0.75, i.e. Nc >= 2 or p = 0.75, with logical moves)
+inline bool ladder_uses_queue(int code, int noise, int scan, int conv_mode, int L, int Nc, double p_logical)
+{
+    return code == 0 && noise == 0 && scan == 0 && conv_mode != 0 && L <= 16 && Nc >= 2 && p_logical > 0.0;
 }
 hipError_t launch_ladder_rs_toric(const LadderArgs &a, hipStream_t stream);
 

@@ -232,12 +232,19 @@ __device__ inline bool alpha_series_close(uint64_t z2, uint64_t xy2, uint32_t de
 // DELUT (toric, split table with >= 64 idle entries between its halves, i.e. 2 L^2 <= 191): a proposal's dE comes from a
 // 512-byte LDS table indexed by the four old fields and the generator's type instead of seven VALU instructions -- the kernel
 // is bound by VALU issue (98 % busy), the LDS array has room.
+// QUEUE (with CONV; toric, depolarizing, random scan, no general top path): a persistent grid with a work queue for the runs
+// that stop by the convergence criterion (decoders.py:74-82).  Stopping times spread over a decade (4e4 ... 3e5
+// ladder steps at L = 9), and a lane whose syndrome has converged would otherwise idle until the slowest of its 64 finishes.
+// Here a finished lane writes its results out at once, takes the next unassigned ladder from a global counter and starts
+// it in place: every wave re-stages its slot's state for that lane, and the lane's Philox addresses are offset by the step it
+// started at (aligned so that the four-proposal blocks of all lanes stay in phase).  A ladder's trajectory depends on its
+// global index only, so the results are those of the one-ladder-per-lane launch, bit for bit.
 // PRE: the top chain's Philox blocks are drawn ahead by the wave that will take the top role -- half of them two steps before,
 // while it works on slot 1, the other half one step before on slot 0 -- and wait in registers (48 VGPRs: only for the shapes
 // whose LDS footprint leaves 4 waves per SIMD anyway).  The draws do not depend on the state, so nothing changes but who
 // is the step's longest wave: at L = 15 the top wave's 10 blocks + frame flush were 2.6 x a non-top wave's step.
 template <int MAXT, int MINW, bool CONV, bool GSPLIT, int CODE, bool BIASED, bool SCAN, bool GENTOP, bool USET = false, bool ALPHA = false,
-          bool PRE = false, bool DELUT = false>
+          bool PRE = false, bool DELUT = false, bool QUEUE = false>
 __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const LadderArgs a)
 {
     extern __shared__ uint32_t lds_all[];
@@ -297,11 +304,14 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
 #endif
     const uint64_t s0 = (uint64_t)blockIdx.x * 64u;
     const int cnt = a.N > s0 ? (int)((a.N - s0) < 64u ? (a.N - s0) : 64u) : 0;   // 0: a group past the end of the batch
-    const uint32_t syn = a.first_syndrome + (uint32_t)s0 + (uint32_t)lane;   // Philox ctr[2]
+    uint32_t syn = a.first_syndrome + (uint32_t)s0 + (uint32_t)lane;   // Philox ctr[2] (QUEUE: of the ladder the lane works on now)
+    [[maybe_unused]] uint32_t qi = (uint32_t)s0 + (uint32_t)lane;      // QUEUE: that ladder's index in this launch (0xFFFFFFFF: none left)
+    [[maybe_unused]] uint32_t t0 = 0;                                  // ... the workgroup step it started at
+    [[maybe_unused]] uint64_t kq = 0;                                  // ... t0 * iters: its proposal indices are (t * iters + j) - kq
 
     for (int i = tid; i < NC * W * 64; i += nthreads) st[i] = 0;
     for (int i = tid; i < ncls * 64; i += nthreads) hist[i] = 0;
-    if (tid == 0) *stopf = 0;
+    if (tid == 0) { stopf[0] = 0; stopf[2] = 0; stopf[3] = 0; }   // [0] stop, [2], [3] QUEUE: refill requested (by step parity)
     if (a.swap_acc != nullptr)
         for (int i = tid; i < 2 * NC * 64; i += nthreads) lds_all[gdw + i] = 0;
     if constexpr (USET) {
@@ -440,7 +450,13 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
     constexpr int kPre = 12;                                    // blocks drawn ahead (a step of more proposals draws the rest in place)
     [[maybe_unused]] u32x4 pre[PRE ? kPre : 1];
     [[maybe_unused]] const uint32_t pre_n = iters < (uint32_t)kPre ? iters : (uint32_t)kPre, pre_h = pre_n / 2;
-    for (uint64_t t = 0; t < a.nsteps; ++t) {
+    // QUEUE: finished lanes take new ladders until the counter runs out; the loop ends by the stop flag.  A new ladder may
+    // start only at a step that keeps its four-proposal blocks in phase with the others': t0 * iters = 0 (mod 4).
+    [[maybe_unused]] const uint32_t q_period = (iters & 3u) == 0 ? 1u : (iters & 1u) == 0 ? 2u : 4u;
+    [[maybe_unused]] uint32_t *qidx = swx + (NC - 1) * 64, *qt0 = swx + (2 * NC - 1) * 64;   // the idle last rows of swx: [64] each
+    [[maybe_unused]] bool q_dead = lane >= cnt, q_flushed = false;                           // (wave 0) no ladder left for this lane / its results are written
+    [[maybe_unused]] bool q_empty = a.N <= (uint64_t)gridDim.x * 64u;                        // ... the counter is exhausted (uniform)
+    for (uint64_t t = 0; QUEUE || t < a.nsteps; ++t) {
         // Issue arbitration between co-resident workgroups is oldest-first, which lets the first one
         // race ahead and leaves the last one alone (latency-bound, 2 waves per SIMD) at the end of a
         // launch.  Lowering a workgroup's priority as it advances (cyclically, every 8 steps) narrows
@@ -535,7 +551,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                     bool acc = a12 < tI;                                            // mcmc.py:42 (dE <= 0: tI = 4096)
                     if (a12 == tI) {                                                // rare (a lane in 4096): the next 32 bits decide
                         constexpr int WI = decltype(wsel)::value;
-                        const u32x4 r = philox_block(kb, kSubRefine, syn, slot_u, a.seed_lo, a.seed_hi);
+                        const u32x4 r = philox_block(kb - (kq >> 2), kSubRefine, syn, slot_u, a.seed_lo, a.seed_hi);
                         acc = (WI == 0 ? r.x : WI == 1 ? r.y : WI == 2 ? r.z : r.w) < *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(myF) + v);
                     }
                     if (acc) {
@@ -557,7 +573,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 bool acc = a12 < tI;                                                // mcmc.py:42 (dE <= 0: tI = 4096)
                 if (a12 == tI) {                                                    // rare (a lane in 4096): the next 32 bits decide
                     constexpr int WI = decltype(wsel)::value;
-                    const u32x4 r = philox_block(kb, kSubRefine, syn, slot_u, a.seed_lo, a.seed_hi);
+                    const u32x4 r = philox_block(kb - (kq >> 2), kSubRefine, syn, slot_u, a.seed_lo, a.seed_hi);
                     acc = (WI == 0 ? r.x : WI == 1 ? r.y : WI == 2 ? r.z : r.w) < (myF - 12)[dE16];
                 }
                 if (acc) {
@@ -574,7 +590,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             // the blocks that overlap [kbase, kbase + iters): a block the previous step started is drawn again
             uint64_t kb = kbase >> 2;
             for (int jb = -(int)((uint32_t)kbase & 3u); jb < (int)iters; jb += 4, ++kb) {
-                const u32x4 xa = philox_block(kb, 1, syn, slot_u, a.seed_lo, a.seed_hi);
+                const u32x4 xa = philox_block(kb - (kq >> 2), 1, syn, slot_u, a.seed_lo, a.seed_hi);
                 if (jb >= 0 && jb + 4 <= (int)iters) {                             // a whole block: no per-proposal range tests
                     propose(xa.x, kb, std::integral_constant<int, 0>{});
                     propose(xa.y, kb, std::integral_constant<int, 1>{});
@@ -624,17 +640,13 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 [[maybe_unused]] const int LW = (L + 1) * W;
                 u32x4 pair{0, 0, 0, 0};                                            // the block four non-top proposals share
                 uint64_t kb_pair = ~0ull;
-                // (top chain: the next proposal's block is drawn while this proposal's LDS reads are in flight -- its three
-                // dependent look-ups per proposal make the top wave the step's longest)
-                [[maybe_unused]] u32x4 xnext = top ? philox_block(kbase, 0, syn, slot_u, a.seed_lo, a.seed_hi) : u32x4{0, 0, 0, 0};
                 for (uint32_t j = 0; j < iters; ++j) {
                     const uint64_t k = kbase + j;
                     // top: block (k, 0) = select | generator or logical fields | acceptance word | Z position;
                     // non-top: word k&3 of block (k>>2, 1) (+ its refinement)
                     u32x4 x;
                     if constexpr (top) {
-                        x = xnext;
-                        if (j + 1 < iters) xnext = philox_block(k + 1, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                        x = philox_block(k, 0, syn, slot_u, a.seed_lo, a.seed_hi);   // (drawing the next proposal's block ahead, behind this one's LDS reads: -1 %)
                     } else {
                         if ((k >> 2) != kb_pair) {
                             kb_pair = k >> 2;
@@ -1156,22 +1168,22 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 }
                 // four proposals' Philox chains in flight: this wave is the step's longest and often runs alone
                 for (; j + 3 < iters; j += 4) {
-                    const u32x4 xa = philox_block(kbase + j, 0, syn, slot_u, a.seed_lo, a.seed_hi);
-                    const u32x4 xb = philox_block(kbase + j + 1, 0, syn, slot_u, a.seed_lo, a.seed_hi);
-                    const u32x4 xc = philox_block(kbase + j + 2, 0, syn, slot_u, a.seed_lo, a.seed_hi);
-                    const u32x4 xd = philox_block(kbase + j + 3, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                    const u32x4 xa = philox_block(kbase - kq + j, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                    const u32x4 xb = philox_block(kbase - kq + j + 1, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                    const u32x4 xc = philox_block(kbase - kq + j + 2, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                    const u32x4 xd = philox_block(kbase - kq + j + 3, 0, syn, slot_u, a.seed_lo, a.seed_hi);
                     blind(xa);
                     blind(xb);
                     blind(xc);
                     blind(xd);
                 }
                 for (; j + 1 < iters; j += 2) {
-                    const u32x4 xa = philox_block(kbase + j, 0, syn, slot_u, a.seed_lo, a.seed_hi);
-                    const u32x4 xb = philox_block(kbase + j + 1, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                    const u32x4 xa = philox_block(kbase - kq + j, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                    const u32x4 xb = philox_block(kbase - kq + j + 1, 0, syn, slot_u, a.seed_lo, a.seed_hi);
                     blind(xa);
                     blind(xb);
                 }
-                if (j < iters) blind(philox_block(kbase + j, 0, syn, slot_u, a.seed_lo, a.seed_hi));
+                if (j < iters) blind(philox_block(kbase - kq + j, 0, syn, slot_u, a.seed_lo, a.seed_hi));
             }
             // flush the frame: lattice row r of layer l is the 2L-bit span at bit 2*(l*LL + r*L)
             {
@@ -1296,7 +1308,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
         if (swb >= 0 && swb < 4 && swb * 4 < NC - 1) {
             // the sweep's uniforms do not depend on the state: the slots just below the top (never the
             // heavier top slot itself) draw one Philox block each
-            const u32x4 b = philox_block(a.step0 + t, (uint32_t)swb, syn, kSwapStream, a.seed_lo, a.seed_hi);
+            const u32x4 b = philox_block(a.step0 + t - t0, (uint32_t)swb, syn, kSwapStream, a.seed_lo, a.seed_hi);
             uint32_t *p = sx + swb * 4 * 64;                       // rows 4b .. 4b+3 = rung pairs, NC-1 of them exist
             const int left = NC - 1 - swb * 4;
             // The swap test u < p_diff[i]^d (mcmc.py:149) does not need the records: thresholds fall with d, so it reads
@@ -1335,9 +1347,11 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             if (left > 3) p[192] = r3;
         }
         __syncthreads();
+        [[maybe_unused]] bool q_refill = false;
         if (CONV || USET) {                                 // flags set one step earlier: uniform for the workgroup
             volatile uint32_t *f0 = lds_all + (NC * W * 64 + 4 * NC * 64 + ncls * 64 + NC * 9 + NC * kSwapFast);
             if (f0[0]) break;
+            if constexpr (QUEUE) q_refill = f0[2 + (t & 1)] != 0;   // (written by wave 0 before this step's barrier: double-buffered by parity)
         }
         {
             // every wave replays the top-down cascade on the published records; `car` is the record
@@ -1402,16 +1416,18 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                             if (a1 != a0) { const uint32_t v = mylog[(size_t)(burn + a0) * a.N]; sumA -= v & 0xFFFFu; sumAxy -= v >> 16; }
                         }
                     } else
-                    if (CONV && lane < cnt) {
+                    if (CONV && (QUEUE ? !q_dead : lane < cnt)) {
                         // nbr_errors_bottom_chain[since_burn] = count_errors (:68); series index i lives in log row burn+i
+                        // (QUEUE: one log column per lane of the persistent grid, rows = the ladder's own steps)
+                        const size_t lN = QUEUE ? (size_t)gridDim.x * 64u : (size_t)a.N;
                         uint16_t *mylog = a.nlog + (s0 + lane);
-                        mylog[(size_t)t * a.N] = (uint16_t)n0;
+                        mylog[(size_t)(t - t0) * lN] = (uint16_t)n0;
                         const uint32_t l = samples, lo1 = l - 1;
                         const uint32_t a0 = lo1 >> 2, b0 = lo1 >> 1, c0 = (3u * lo1) >> 2, a1 = l >> 2, b1 = l >> 1, c1 = (3u * l) >> 2;
                         sumB += n0;
-                        if (c1 != c0) sumB -= mylog[(size_t)(burn + c0) * a.N];
-                        if (b1 != b0) sumA += mylog[(size_t)(burn + b0) * a.N];
-                        if (a1 != a0) sumA -= mylog[(size_t)(burn + a0) * a.N];
+                        if (c1 != c0) sumB -= mylog[(size_t)(burn + c0) * lN];
+                        if (b1 != b0) sumA += mylog[(size_t)(burn + b0) * lN];
+                        if (a1 != a0) sumA -= mylog[(size_t)(burn + a0) * lN];
                     }
                 } else {
                     burn++;                                                         // resulting_burn_in, :71
@@ -1427,7 +1443,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                             accept = fabs((double)sumA / (double)den2 - (double)sumB / (double)den4) < a.eps;   // :96-102
                     }
                     if (accept) {
-                        if (conv_streak >= a.SEQ) { done = 1; conv_ok = 1; steps_done = (uint32_t)t + 1; }   // :77-78
+                        if (conv_streak >= a.SEQ) { done = 1; conv_ok = 1; steps_done = (uint32_t)(t - t0) + 1; }   // :77-78
                         else conv_streak = tops0 - conv_start;                      // :79
                     } else {
                         conv_streak = 0;                                            // :81-82
@@ -1455,6 +1471,38 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 }
                 if (!done) nsum[0] += c2 & 0xFFFFu;
             }
+            if constexpr (QUEUE) {
+                if (wave_u == 0) {
+                    // a ladder ends by the criterion or at the horizon of `nsteps` of its own steps; its results go out at once
+                    if (!q_dead && !done && (t - t0) + 1 >= a.nsteps) { done = 1; steps_done = (uint32_t)a.nsteps; }
+                    if (!q_dead && done && !q_flushed) {
+                        const uint64_t row = (uint64_t)qi / R;
+                        for (int c = 0; c < ncls; ++c) {
+                            const uint32_t v = hist[c * 64 + lane];
+                            hist[c * 64 + lane] = 0;
+                            if (R > 1) { if (v) atomicAdd(a.counts + row * ncls + c, v); }
+                            else a.counts[row * ncls + c] = v;
+                        }
+                        if (R > 1) {
+                            atomicAdd(a.samples + row, samples);
+                            if (a.tops0 != nullptr) atomicAdd(a.tops0 + row, tops0);
+                            if (a.steps_done != nullptr) atomicMax(a.steps_done + row, steps_done);
+                            if (a.converged != nullptr && !conv_ok) a.converged[row] = 0;
+                        } else {
+                            a.samples[row] = samples;
+                            if (a.tops0 != nullptr) a.tops0[row] = tops0;
+                            if (a.steps_done != nullptr) a.steps_done[row] = steps_done;
+                            if (a.converged != nullptr) a.converged[row] = (uint8_t)conv_ok;
+                        }
+                        q_flushed = true;
+                        if (q_empty) q_dead = true;
+                    }
+                    volatile uint32_t *f0 = lds_all + (NC * W * 64 + 4 * NC * 64 + ncls * 64 + NC * 9 + NC * kSwapFast);
+                    if (__all(q_dead)) f0[0] = 1;
+                    // ask for a refill at the end of the next step if lanes wait for work and that step's successor keeps the blocks in phase
+                    f0[2 + ((t + 1) & 1)] = (!q_empty && __any(done && !q_dead) && ((t + 2) % q_period) == 0) ? 1u : 0u;
+                }
+            } else
             if (CONV && wave_u == 0 && __all(done || lane >= cnt)) *stopf = 1;
             if (slot_u == 0) flag = 0;                                              // :103
             if constexpr (USET) {
@@ -1513,6 +1561,54 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 }
                 if (cm && wave_u == 0 && __all(cm_done || lane >= cnt)) *stopf = 1;
             }
+            if constexpr (QUEUE) {
+                if (q_refill) {                                                     // uniform for the workgroup (read behind the barrier)
+                    if (wave_u == 0) {
+                        // the finished lanes take the next ladders of the batch: one atomic per wave, ranks by prefix count
+                        const bool want = done && !q_dead;
+                        const uint64_t m = __ballot(want);
+                        const uint32_t nw = (uint32_t)__popcll(m);
+                        uint32_t base = 0;
+                        if (lane == 0 && nw) base = atomicAdd(a.queue, nw);
+                        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + gridDim.x * 64u;   // the first grid x 64 ladders were handed out at launch
+                        const uint32_t mine = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                        uint32_t nqi = qi, nt0 = t0;
+                        if (want) {
+                            if ((uint64_t)mine < a.N) { nqi = mine; nt0 = (uint32_t)t + 1u; }
+                            else { nqi = 0xFFFFFFFFu; q_dead = true; }
+                        }
+                        qidx[lane] = nqi;
+                        qt0[lane] = nt0;
+                        if ((uint64_t)base + nw >= a.N) q_empty = true;
+                        if (q_empty && done && !q_dead) q_dead = true;              // (flushed above: nothing will come for it)
+                    }
+                    __syncthreads();
+                    // every wave adopts the assignment and stages its next slot's chain for the lanes that changed ladder
+                    const uint32_t nqi = qidx[lane], nt0 = qt0[lane];
+                    if (nqi != 0xFFFFFFFFu && (nqi != qi || nt0 != t0)) {
+                        qi = nqi; t0 = nt0; kq = (uint64_t)t0 * iters;
+                        syn = a.first_syndrome + qi;
+                        const uint8_t *src = a.init + (uint64_t)(qi / R) * (uint64_t)nq;
+                        uint32_t *dstw = st + (size_t)slot_u * W * 64 + lane;        // Ladder.__init__: every slot starts from the seed (mcmc.py:72)
+                        uint32_t cn = 0;
+                        for (int w = 0; w < W; ++w) {
+                            uint32_t word = 0;
+                            for (int b = 0; b < 16; ++b) {
+                                const int q = w * 16 + b;
+                                if (q < nq) word |= (uint32_t)(src[q] & 3u) << (2 * b);
+                            }
+                            dstw[w * 64] = word;
+                            cn += nnz2(word);
+                        }
+                        sid = slot_u; n = cn; flag = slot_u == (uint32_t)(NC - 1);
+                        cls = toric_class_packed(dstw, W, LL);
+                        if (wave_u == 0) {
+                            tops0 = 0; samples = 0; burn = 0; conv_start = 0; conv_streak = 0; done = 0; steps_done = 0; conv_ok = 0;
+                            sumA = 0; sumB = 0; q_flushed = false;
+                        }
+                    }
+                }
+            }
         }
     }
 #ifdef QECMC_TIMELINE
@@ -1523,6 +1619,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
     __syncthreads();
 
     // ---- results: coalesced stores ---------------------------------------------------
+    if constexpr (QUEUE) return;                  // (every ladder wrote its results when it finished)
     if (a.counts != nullptr)
 #pragma unroll 1
         for (int i = tid; i < cnt * ncls; i += nthreads) {
@@ -1589,7 +1686,9 @@ inline bool ladder_wants_pre(const LadderArgs &a)
 // launch `fn` (one of the instantiations above) on the grid the arguments imply
 inline hipError_t launch_ladder_fn(const void *fn, const LadderArgs &a, hipStream_t stream)
 {
-    const unsigned grid = (unsigned)((a.N + 63) / 64), block = (unsigned)a.Nc * 64u;
+    unsigned grid = (unsigned)((a.N + 63) / 64);
+    const unsigned block = (unsigned)a.Nc * 64u;
+    if (a.grid_cap && grid > a.grid_cap) grid = a.grid_cap;       // QUEUE kernels: a persistent grid, the rest comes from the counter
     const size_t lds = ladder_launch_lds(a);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (lds > 64 * 1024) {   // beyond the default dynamic-LDS window (160 KiB per CU on gfx950)

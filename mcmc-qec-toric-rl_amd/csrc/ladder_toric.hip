@@ -14,6 +14,14 @@ hipError_t launch_ladder_toric(const LadderArgs &a, hipStream_t stream)
     const void *fn;
 #define QECMC_K(maxt, minw, g, gentop) (conv ? (const void *)ladder_rs_toric_kernel<maxt, minw, true, g, T, false, false, gentop> \
                                              : (const void *)ladder_rs_toric_kernel<maxt, minw, false, g, T, false, false, gentop>)
+    if (a.queue != nullptr && conv && !gentop) {
+        // runs that stop by the criterion: the persistent-grid kernels with the work queue (capi.hip decides, ladder_uses_queue)
+#define QECMC_KQ(maxt, minw, g, lut) (const void *)ladder_rs_toric_kernel<maxt, minw, true, g, T, false, false, false, false, false, false, lut, true>
+        const bool lut = gsplit && (int)a.n_gen + 64 <= kGenSplit;
+        if (block <= 512) fn = lut ? QECMC_KQ(512, 8, true, true) : gsplit ? QECMC_KQ(512, 8, true, false) : QECMC_KQ(512, 8, false, false);
+        else fn = gsplit ? QECMC_KQ(1024, 4, true, false) : QECMC_KQ(1024, 4, false, false);
+#undef QECMC_KQ
+    } else
     if (gentop) {
         if (block <= 512) fn = gsplit ? QECMC_K(512, 8, true, true) : QECMC_K(512, 8, false, true);
         else fn = gsplit ? QECMC_K(1024, 4, true, true) : QECMC_K(1024, 4, false, true);

@@ -224,3 +224,44 @@ def test_threshold_curve(q):
     assert out["success_rate"][0] > 0.75 and out["success_rate"][0] > out["success_rate"][3] + 5 * out["err"][3]
     assert np.all(np.diff(out["success_rate"]) < 3 * out["err"][1:] + 0.02)            # non-increasing within error
     assert len(out["metrics"]) == 4 and out["metrics"][3]["frac_past_burn_in"] > 0.5
+
+
+# ------------------------------------------------------------------ work queue for runs that stop by the criterion (f3)
+@pytest.mark.parametrize("L,p,Nc,N,steps,iters,grid,kw", [
+    (3, 0.10, 3, 300, 3000, 10, 1, dict(tops_burn=1, SEQ=1, TOPS=4, eps=0.5)),        # one workgroup eats 300 ladders
+    (3, 0.10, 3, 333, 1500, 5, 2, dict(tops_burn=2, SEQ=2, TOPS=6, eps=0.3)),         # iters = 5: ladders may start every 4th step only
+    (5, 0.10, 5, 200, 2500, 8, 1, dict(tops_burn=2, SEQ=2, TOPS=6, eps=0.4)),         # iters = 8: any step
+    (5, 0.12, 4, 150, 400, 10, 1, dict(tops_burn=1, SEQ=1, TOPS=4, eps=0.6)),         # short horizon: many ladders end unconverged
+    (9, 0.15, 8, 140, 300, 10, 1, dict(tops_burn=0, SEQ=0, TOPS=1, eps=5.0)),         # the headline shape (dE table), quick criterion
+    (3, 0.2, 2, 130, 500, 10, 0, dict(tops_burn=0, SEQ=0, TOPS=1, eps=1.0))])         # grid 0: the production grid (no refill needed)
+def test_work_queue_bit_exact(q, orc, monkeypatch, L, p, Nc, N, steps, iters, grid, kw):
+    """A finished lane takes the next ladder of the batch in place; with the persistent grid forced down to one or two
+    workgroups every lane runs several ladders one after the other.  Every ladder must come out as the oracle's single run."""
+    if grid:
+        monkeypatch.setenv("QECMC_QUEUE_GRID", str(grid))
+    rng = np.random.default_rng(L * 100 + N)
+    init = rand_states(rng, N, L, p)
+    kw = dict(kw, steps=steps, iters=iters, seed=99, first_syndrome=5, conv_criteria="error_based")
+    got = q.pteq_batch(init, p, Nc=Nc, **kw)
+    ref = orc.toric_pteq_batch(init, p, Nc, kw.pop("steps"), **kw)
+    assert np.array_equal(got["converged"], ref["converged"])
+    assert np.array_equal(got["steps_done"], ref["steps_done"].astype(np.uint32))
+    assert np.array_equal(got["samples"], ref["samples"].astype(np.uint32))
+    assert np.array_equal(got["tops0"], ref["tops0"].astype(np.uint32))
+    assert np.array_equal(got["counts"], ref["counts"])
+    assert got["converged"].any()
+    if steps <= 400:
+        assert not got["converged"].all()                                              # the horizon ended some
+
+
+def test_work_queue_with_replicas(q, orc, monkeypatch):
+    monkeypatch.setenv("QECMC_QUEUE_GRID", "1")
+    rng = np.random.default_rng(77)
+    init = rand_states(rng, 20, 3, 0.1)
+    R = 9
+    kw = dict(tops_burn=2, seed=4, conv_criteria="error_based", TOPS=6, SEQ=2, eps=0.2)
+    got = q.pteq_batch(init, 0.1, Nc=3, steps=4000, replicas=R, **kw)
+    ref = orc.toric_pteq_batch(np.repeat(init, R, axis=0), 0.1, 3, 4000, **kw)
+    assert np.array_equal(got["counts"], ref["counts"].reshape(20, R, 16).sum(axis=1))
+    assert np.array_equal(got["steps_done"], ref["steps_done"].reshape(20, R).max(axis=1).astype(np.uint32))
+    assert np.array_equal(got["converged"], ref["converged"].reshape(20, R).all(axis=1))
