@@ -116,7 +116,7 @@ def profile_counters(args):
                                        "lds": d["SQ_INSTS_LDS"] / wave_props}}
     if cyc and "SQ_ACTIVE_INST_VALU" in d:
         simd_cycles = cyc * 256 * 4              # SIMD-cycles of the launch: 256 CUs x 4 SIMDs
-        out["valu_busy"] = d["SQ_ACTIVE_INST_VALU"] / simd_cycles
+        out["valu_busy"] = 4.0 * d["SQ_ACTIVE_INST_VALU"] / simd_cycles   # the SQ_ACTIVE_* / SQ_WAVE_CYCLES counters tick in quad-cycles (MI355X_MICROARCH.md)
         out["lds_busy"] = d["SQ_LDS_IDX_ACTIVE"] / (cyc * 256)       # one LDS array per CU
         out["lds_conflict_frac"] = d["SQ_LDS_BANK_CONFLICT"] / max(d["SQ_LDS_IDX_ACTIVE"], 1.0)
     return out

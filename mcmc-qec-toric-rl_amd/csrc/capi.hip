@@ -658,7 +658,9 @@ int qecmc_plan_workspace_bytes(const qecmc_plan *plan, uint64_t N, uint64_t *byt
 {
     if (!plan || !bytes_out) return fail(QECMC_ERR_INVALID, "NULL argument");
     // one log entry per (ladder step, syndrome): the bottom chain's error count (u16), or for alpha noise the two counts behind n_eff (2 x u16)
-    *bytes_out = plan->prm.conv_mode == QECMC_CONV_ERROR_BASED ? (plan->prm.noise == QECMC_NOISE_ALPHA ? 4ull : 2ull) * N * plan->args.replicas * plan->prm.steps : 0ull;
+    // (rounded up to whole 64-lane groups: the work-queue kernels keep one column per lane of their grid)
+    const uint64_t cols = (N * plan->args.replicas + 63) / 64 * 64;
+    *bytes_out = plan->prm.conv_mode == QECMC_CONV_ERROR_BASED ? (plan->prm.noise == QECMC_NOISE_ALPHA ? 4ull : 2ull) * cols * plan->prm.steps : 0ull;
     return 0;
 }
 
@@ -765,7 +767,7 @@ int qecmc_pteq_batch_stats(const qecmc_params *params, const uint8_t *init, uint
     qecmc_plan_workspace_bytes(pl, N, &ws_bytes);
     if (pl->queue_grid && !swap_accepts_out && !nerr_sums_out && !final_states_out) {
         // the work-queue kernels log one column per lane of the persistent grid, not per ladder
-        const uint64_t cols = std::min<uint64_t>(N * R, (uint64_t)pl->queue_grid * 64u);
+        const uint64_t cols = std::min<uint64_t>((N * R + 63) / 64 * 64, (uint64_t)pl->queue_grid * 64u);
         ws_bytes = 2ull * cols * pl->prm.steps;
     }
     size_t free_b = 0, total_b = 0;

@@ -1579,8 +1579,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                         }
                         qidx[lane] = nqi;
                         qt0[lane] = nt0;
-                        if ((uint64_t)base + nw >= a.N) q_empty = true;
-                        if (q_empty && done && !q_dead) q_dead = true;              // (flushed above: nothing will come for it)
+                        if ((uint64_t)base + nw >= a.N) q_empty = true;             // (later finishers retire when they write their results)
                     }
                     __syncthreads();
                     // every wave adopts the assignment and stages its next slot's chain for the lanes that changed ladder
