@@ -263,6 +263,8 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
     constexpr bool alpha_noise = BIASED && ALPHA;               // mcmc_alpha.py: biased rule + slot-bound n_eff swap test
     // biased / alpha rules: the count-change table [n_types][256] and the packed counts of every state [NC][64]
     const int lm_dw = BIASED ? 2 * (L + 1) * W : 0;             // ... and the X / Z logical-operator masks [2][L+1][W] (row L = identity)
+    // (xzzx: its operators do not depend on a position, so rows 0 .. 3 of the X table are overwritten with the four products
+    // I, X, Z, XZ indexed by the class change -- one look-up per word instead of two and an xor)
     const int neff_dw = alpha_noise ? 2 * NC * 64 : 0, bias_dw = BIASED ? 256 * a.n_types + NC * 64 + lm_dw : 0;
     const int gen_region = (neff_dw || bias_dw) ? ((gen_dw + 3) & ~3) + neff_dw + bias_dw : gen_dw;
     const int gdw = ladder_group_dwords(NC, W, ncls, gen_region);   // dwords per group
@@ -353,6 +355,14 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
     if constexpr (BIASED) {
         for (int i = tid; i < 256 * a.n_types; i += nthreads) xlut[i] = a.xyz_lut[i];
         for (int i = tid; i < lm_dw; i += nthreads) lml[i] = a.lmask[i];              // kinds 0 (X) and 1 (Z) are the first two tables
+        if (CODE == kCodeXzzx && L >= 3) {
+            __syncthreads();
+            uint32_t v = 0;
+            const int c = tid / W, w = tid - c * W;                                  // product c = ax | az << 1, word w
+            if (tid < 4 * W) v = ((c & 1) ? a.lmask[w] : 0u) ^ ((c & 2) ? a.lmask[(L + 1) * W + w] : 0u);
+            __syncthreads();
+            if (tid < 4 * W) lml[c * W + w] = v;
+        }
     }
     if (tid < NC * 9) {
         // u < f^dE  <=>  x < thr  <=>  x <= thr-1;  dE <= 0 (f^dE >= 1) and f >= 1 always accept (mcmc.py:30,42)
@@ -461,9 +471,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
         // race ahead and leaves the last one alone (latency-bound, 2 waves per SIMD) at the end of a
         // launch.  Lowering a workgroup's priority as it advances (cyclically, every 8 steps) narrows
         // that spread: +6 % on a one-round grid (measured), neutral otherwise.
-        if (a.tune & 1u) {
-            if (slot_u == (uint32_t)(NC - 1)) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
-        } else
+        // (Tried in round 2: the top-role wave at the highest priority instead: -10 % at L = 9, +3 % at L = 15, 0 at rotated L = 21.)
         switch (3u - (uint32_t)((t >> 3) & 3)) {    // s_setprio takes an immediate
             case 0: __builtin_amdgcn_s_setprio(0); break;
             case 1: __builtin_amdgcn_s_setprio(1); break;
@@ -667,11 +675,16 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                         // applied operators: xzzx X iff op in {1,2}, Z iff op in {3,2}; rotated X iff op in {1,3}, Z iff op in {2,3}
                         const uint32_t ax = CODE == kCodeXzzx ? ((op ^ (op >> 1)) & 1u) : (op & 1u);
                         const uint32_t az = op >> 1;
-                        if (ax) m0 = lml + xp * W;                                  // kind 0: X (xzzx: anti-diagonal at every pos)
-                        if (az) m1 = lml + LW + zp * W;                             // kind 1: Z
                         cd = ax | (az << 1);
+                        if (CODE == kCodeXzzx) {
+                            m0 = lml + cd * W;                                      // the product's mask (rows 0 .. 3: I, X, Z, XZ)
+                        } else {
+                            if (ax) m0 = lml + xp * W;                              // kind 0: X on column X_pos
+                            if (az) m1 = lml + LW + zp * W;                         // kind 1: Z on row Z_pos
+                        }
                         int cx = 0, cy = 0, cz = 0;                                 // the operator moves O(L) sites: recount the result
-                        for (int w = 0; w < W; ++w) count_xyz(stw[w * 64] ^ m0[w] ^ m1[w], cx, cy, cz);
+                        if (CODE == kCodeXzzx) { for (int w = 0; w < W; ++w) count_xyz(stw[w * 64] ^ m0[w], cx, cy, cz); }
+                        else { for (int w = 0; w < W; ++w) count_xyz(stw[w * 64] ^ m0[w] ^ m1[w], cx, cy, cz); }
                         Nn = (uint32_t)cx | ((uint32_t)cz << 10) | ((uint32_t)(cx + cy) << 20);
                     } else {
                         // the expanded entry gives each site's LDS address with one add and its field with one bfe
@@ -721,7 +734,8 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                     }
                     if (acc) {
                         if (logical) {
-                            for (int w = 0; w < W; ++w) lds_xor(stw + w * 64, m0[w] ^ m1[w]);
+                            if (CODE == kCodeXzzx) { for (int w = 0; w < W; ++w) lds_xor(stw + w * 64, m0[w]); }
+                            else { for (int w = 0; w < W; ++w) lds_xor(stw + w * 64, m0[w] ^ m1[w]); }
                             cdelta ^= cd;
                         } else {
 #pragma unroll

@@ -265,3 +265,39 @@ def test_work_queue_with_replicas(q, orc, monkeypatch):
     assert np.array_equal(got["counts"], ref["counts"].reshape(20, R, 16).sum(axis=1))
     assert np.array_equal(got["steps_done"], ref["steps_done"].reshape(20, R).max(axis=1).astype(np.uint32))
     assert np.array_equal(got["converged"], ref["converged"].reshape(20, R).all(axis=1))
+
+
+# ------------------------------------------------------------------ top-chain Philox blocks drawn ahead (PRE instantiations)
+@pytest.mark.parametrize("name,L,Nc,iters,steps,N", [
+    ("toric", 15, 8, 10, 30, 70), ("toric", 15, 8, 13, 12, 40), ("toric", 15, 8, 3, 40, 40), ("toric", 15, 8, 1, 50, 20),
+    ("toric", 15, 3, 10, 20, 33), ("toric", 15, 15, 10, 12, 20), ("toric", 13, 8, 7, 25, 30), ("toric", 16, 9, 10, 10, 10),
+    ("rotated", 21, 8, 10, 20, 40), ("rotated", 21, 3, 5, 20, 20), ("rotated", 21, 12, 10, 8, 10), ("xzzx", 19, 8, 10, 12, 20)])
+def test_top_blocks_drawn_ahead_bit_exact(q, orc, name, L, Nc, iters, steps, N):
+    """Shapes whose LDS footprint leaves 4 waves per SIMD take the instantiations in which the wave that will be the top chain
+    draws that step's Philox blocks one and two steps earlier (half each): more or fewer proposals than the 12 blocks kept,
+    odd halves, three-rung ladders, 960-thread workgroups, the plaquette codes' framed top chain."""
+    rng = np.random.default_rng(L * 7 + Nc + iters)
+    if name == "toric":
+        init = rand_states(rng, N, L, 0.15)
+        got = q.pteq_batch(init, 0.15, Nc=Nc, steps=steps, iters=iters, tops_burn=0, seed=31, first_syndrome=9, return_states=True)
+        ref = orc.toric_pteq_batch(init, 0.15, Nc, steps, iters=iters, tops_burn=0, seed=31, first_syndrome=9, return_states=True)
+    else:
+        code, ocode = (q.ROTATED, orc.ROTATED) if name == "rotated" else (q.XZZX, orc.XZZX)
+        init = rand_plaq(rng, N, L, 0.15)
+        got = q.pteq_batch(init, 0.15, Nc=Nc, steps=steps, iters=iters, tops_burn=0, seed=31, first_syndrome=9, return_states=True, code=code)
+        ref = orc.pteq_batch(ocode, init, 0.15, Nc, steps, iters=iters, tops_burn=0, seed=31, first_syndrome=9, return_states=True)
+    assert np.array_equal(got["states"], ref["states"])
+    assert np.array_equal(got["counts"], ref["counts"]) and np.array_equal(got["tops0"], ref["tops0"].astype(np.uint32))
+
+
+def test_top_blocks_drawn_ahead_across_chunks(q):
+    """Every launch starts without blocks in hand (its first two top steps draw in place): chunked continuation stays exact."""
+    from qecmc import harness
+    rng = np.random.default_rng(12)
+    init = rand_states(rng, 40, 15, 0.15)
+    full = q.pteq_batch(init, 0.18, Nc=8, steps=23, iters=10, tops_burn=0, seed=8, return_states=True)
+    run = harness.LadderRun(init, 0.18, Nc=8, iters=10, tops_burn=0, seed=8)
+    for chunk in (1, 2, 5, 3, 12):
+        run.advance(chunk)
+    snap = run.snapshot(states=True)
+    assert np.array_equal(snap["states"], full["states"]) and np.array_equal(snap["counts"], full["counts"])
