@@ -701,7 +701,7 @@ int qecmc_pteq_launch_dev(qecmc_plan *plan, const void *d_init, uint64_t N, uint
     a.write_states = d_final_states != nullptr;
     a.N = M; a.first_syndrome = first_syndrome;
     a.step0 = 0; a.prop0 = 0; a.nsteps = plan->prm.steps; a.resume = 0;
-    if (plan->queue_grid && !a.swap_acc && !d_final_states) {
+    if (plan->queue_grid && !a.swap_acc && !d_final_states && plan->prm.steps > 0) {
         // (one launch at a time per plan: the counter belongs to the plan)
         HIP_TRY(hipMemsetAsync(plan->queue.p, 0, sizeof(uint32_t), strm));
         a.queue = plan->queue.as<uint32_t>();
@@ -765,7 +765,7 @@ int qecmc_pteq_batch_stats(const qecmc_params *params, const uint8_t *init, uint
     const size_t nq = pl->args.nq, Nc = pl->args.Nc, ncls = pl->args.ncls, R = pl->args.replicas;
     uint64_t ws_bytes = 0;
     qecmc_plan_workspace_bytes(pl, N, &ws_bytes);
-    if (pl->queue_grid && !swap_accepts_out && !nerr_sums_out && !final_states_out) {
+    if (pl->queue_grid && !swap_accepts_out && !nerr_sums_out && !final_states_out && pl->prm.steps > 0) {
         // the work-queue kernels log one column per lane of the persistent grid, not per ladder
         const uint64_t cols = std::min<uint64_t>((N * R + 63) / 64 * 64, (uint64_t)pl->queue_grid * 64u);
         ws_bytes = 2ull * cols * pl->prm.steps;

@@ -13,13 +13,13 @@ sys.path.insert(0, ".")
 import qecmc
 import bench
 
-L, p, Nc, N, H = 5, 0.10, 5, 1 << 18, 1 << 16
+L, p, Nc, N, H = (int(sys.argv[1]), float(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (5, 0.10, 5, 1 << 18, 1 << 16)
 init = bench.synth_batch(N, L, p, 7)
 out = {}
 for name, grid in (("queue", None), ("one_ladder_per_lane", str(1 << 30))):
     if grid: os.environ["QECMC_QUEUE_GRID"] = grid
     else: os.environ.pop("QECMC_QUEUE_GRID", None)
-    for rep in range(2):
+    for rep in range(1 if L > 5 else 2):
         t0 = time.time()
         r = qecmc.pteq_batch(init, p, Nc=Nc, steps=H, iters=10, tops_burn=2, seed=3, conv_criteria="error_based", return_stats=True)
         dt = time.time() - t0
@@ -31,5 +31,5 @@ for name, grid in (("queue", None), ("one_ladder_per_lane", str(1 << 30))):
     print(name, json.dumps(out[name]), flush=True)
 out["speedup"] = out["one_ladder_per_lane"]["kernel_ms"] / out["queue"]["kernel_ms"]
 out["workload"] = "toric L=%d p=%g Nc=%d, %d syndromes, error_based criterion (SEQ=2, TOPS=10, eps=0.1), horizon %d ladder steps" % (L, p, Nc, N, H)
-json.dump(out, open("gpurun_out/r02_conv_queue.json", "w"), indent=1)
+json.dump(out, open("gpurun_out/r02_conv_queue_L%d.json" % L, "w"), indent=1)
 print("speedup", out["speedup"])
