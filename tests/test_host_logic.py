@@ -2,6 +2,7 @@
 import os
 
 import numpy as np
+import pytest
 
 from conftest import GOLDEN
 
@@ -54,3 +55,32 @@ def test_generate_random_error_follows_numpy_global_rng():
         exp[i] = np.where(q < 0.1, pauli, 0)
     g = np.load(os.path.join(GOLDEN, "f4_config1.npz"))
     assert np.array_equal(exp, g["init"])            # the reference's own matrix under np.random.seed(1)
+
+
+def test_batch_metrics_line_is_json_and_consistent():
+    """The per-batch metrics line from a synthetic result: proposals, rates, swap acceptance, tops0 histogram."""
+    import json
+    from qecmc import harness, _lib as L_
+    res = dict(counts=np.zeros((4, 16), dtype=np.uint32), samples=np.array([10, 0, 5, 7], dtype=np.uint32),
+               tops0=np.array([0, 3, 25, 1], dtype=np.uint32), steps_done=np.array([100, 100, 50, 100], dtype=np.uint32),
+               converged=np.array([False, False, True, False]), stats=dict(kernel_ms=2.0),
+               swap_accepts=np.array([[10, 5], [20, 5], [5, 0], [15, 10]], dtype=np.uint32),
+               nerr_sums=np.array([[100, 200, 300]] * 4, dtype=np.uint32))
+    m = harness.batch_metrics(L_.TORIC, 5, 3, 10, res, wall_s=0.01, success=np.array([True, False, True, True]))
+    m = json.loads(json.dumps(m))
+    assert m["proposals"] == 350 * 3 * 10 and m["syndromes"] == 4
+    assert m["chain_sweeps_per_s_kernel"] == pytest.approx(350 * 30 / 50 / 2e-3)
+    assert m["tops0_hist"][0] == 1 and m["tops0_hist"][20] == 1 and sum(m["tops0_hist"]) == 4
+    assert m["swap_acceptance"] == pytest.approx([50 / 350, 20 / 350]) and m["mean_errors_per_rung"][2] == pytest.approx(1200 / 350)
+    assert m["success_rate"] == 0.75 and m["converged_frac"] == 0.25 and m["frac_past_burn_in"] == 0.75
+
+
+def test_shard_names_and_bench_configs():
+    from qecmc import harness
+    assert harness.shard_name("data", 3, 12) == "data_seed3_shard00012.npz"
+    import bench
+    for c, (code, L, N) in {2: ("toric", 9, 65536), 3: ("toric", 15, 131072), 4: ("xzzx", 9, 65536), 5: ("rotated", 21, 32768)}.items():
+        a = bench.parse_args(["--config", str(c)])
+        assert (a.code, a.L, a.syndromes, a.Nc, a.ladder_steps) == (code, L, N, 8, 10000)
+    assert bench.parse_args(["--config", "4"]).eta == 100.0 and bench.parse_args([]).config == 2
+    assert bench.parse_args(["--config", "3", "--Nc", "15"]).Nc == 15
