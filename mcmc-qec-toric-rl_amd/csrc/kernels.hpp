@@ -113,11 +113,11 @@ inline int ladder_gen_dwords(int code, int noise, int scan, uint32_t n_gen, int 
     if (noise) d = ((d + 3) & ~3) + 256 * n_types + Nc * 64 + 2 * (nq_L(code, nq) + 1) * ((nq + 15) / 16);   // + the X / Z logical masks [2][L+1][W]
     return d;
 }
-// the shapes the work-queue kernels exist for: toric, depolarizing, random scan, error_based criterion, the framed top chain
-// (L <= 16, a top rung at p = 0.75, i.e. Nc >= 2 or p = 0.75, with logical moves)
+// the shapes the work-queue kernels exist for: depolarizing rule, random scan, error_based criterion, the framed top chain
+// (toric L <= 16, plaquette codes L <= 32; a top rung at p = 0.75, i.e. Nc >= 2, with logical moves)
 inline bool ladder_uses_queue(int code, int noise, int scan, int conv_mode, int L, int Nc, double p_logical)
 {
-    return code == 0 && noise == 0 && scan == 0 && conv_mode != 0 && L <= 16 && Nc >= 2 && p_logical > 0.0;
+    return noise == 0 && scan == 0 && conv_mode != 0 && L <= (code == 0 ? 16 : 32) && Nc >= 2 && p_logical > 0.0;
 }
 hipError_t launch_ladder_rs_toric(const LadderArgs &a, hipStream_t stream);
 

@@ -232,7 +232,7 @@ __device__ inline bool alpha_series_close(uint64_t z2, uint64_t xy2, uint32_t de
 // DELUT (toric, split table with >= 64 idle entries between its halves, i.e. 2 L^2 <= 191): a proposal's dE comes from a
 // 512-byte LDS table indexed by the four old fields and the generator's type instead of seven VALU instructions -- the kernel
 // is bound by VALU issue (98 % busy), the LDS array has room.
-// QUEUE (with CONV; toric, depolarizing, random scan, no general top path): a persistent grid with a work queue for the runs
+// QUEUE (with CONV; depolarizing rule, random scan, the framed top chain at p = 0.75): a persistent grid with a work queue for the runs
 // that stop by the convergence criterion (decoders.py:74-82).  Stopping times spread over a decade (4e4 ... 3e5
 // ladder steps at L = 9), and a lane whose syndrome has converged would otherwise idle until the slowest of its 64 finishes.
 // Here a finished lane writes its results out at once, takes the next unassigned ladder from a global counter and starts
@@ -854,7 +854,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                             j = pre_n;
                         }
                     }
-                    for (; j < iters; ++j) top_move(philox_block(kbase + j, 0, syn, slot_u, a.seed_lo, a.seed_hi));
+                    for (; j < iters; ++j) top_move(philox_block(kbase - kq + j, 0, syn, slot_u, a.seed_lo, a.seed_hi));
                 }
                 uint32_t cnt_n = 0;
                 if (framed && L > 16) {
@@ -1602,7 +1602,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                         qi = nqi; t0 = nt0; kq = (uint64_t)t0 * iters;
                         syn = a.first_syndrome + qi;
                         const uint8_t *src = a.init + (uint64_t)(qi / R) * (uint64_t)nq;
-                        uint32_t *dstw = st + (size_t)slot_u * W * 64 + lane;        // Ladder.__init__: every slot starts from the seed (mcmc.py:72)
+                        const int dbase = (int)slot_u * W * 64 + lane;               // Ladder.__init__: every slot starts from the seed (mcmc.py:72)
                         uint32_t cn = 0;
                         for (int w = 0; w < W; ++w) {
                             uint32_t word = 0;
@@ -1610,11 +1610,12 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                                 const int q = w * 16 + b;
                                 if (q < nq) word |= (uint32_t)(src[q] & 3u) << (2 * b);
                             }
-                            dstw[w * 64] = word;
+                            st[dbase + w * 64] = word;
                             cn += nnz2(word);
                         }
                         sid = slot_u; n = cn; flag = slot_u == (uint32_t)(NC - 1);
-                        cls = toric_class_packed(dstw, W, LL);
+                        if constexpr (CODE == kCodeToric) cls = toric_class_packed(st + dbase, W, LL);
+                        else cls = surf_class_packed(CODE, st + dbase, L);
                         if (wave_u == 0) {
                             tops0 = 0; samples = 0; burn = 0; conv_start = 0; conv_streak = 0; done = 0; steps_done = 0; conv_ok = 0;
                             sumA = 0; sumB = 0; q_flushed = false;

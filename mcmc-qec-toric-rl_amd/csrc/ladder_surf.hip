@@ -13,6 +13,13 @@ hipError_t launch_ladder_surf(const LadderArgs &a, hipStream_t stream)
                                         : (const void *)ladder_rs_toric_kernel<maxt, minw, false, false, code, false, false, true>)
 #define QECMC_KP(maxt, code) (conv ? (const void *)ladder_rs_toric_kernel<maxt, 4, true, false, code, false, false, true, false, false, true> \
                                    : (const void *)ladder_rs_toric_kernel<maxt, 4, false, false, code, false, false, true, false, false, true>)
+    if (a.queue != nullptr && conv && ((a.acc_all_mask >> (a.Nc - 1)) & 1u)) {
+        // runs that stop by the criterion: the persistent-grid kernels with the work queue
+#define QECMC_KQ(maxt, minw, code) (const void *)ladder_rs_toric_kernel<maxt, minw, true, false, code, false, false, true, false, false, false, false, true>
+        if (block <= 512) fn = a.code == X ? QECMC_KQ(512, 8, X) : a.code == R ? QECMC_KQ(512, 8, R) : a.code == P ? QECMC_KQ(512, 8, P) : nullptr;
+        else fn = a.code == X ? QECMC_KQ(1024, 4, X) : a.code == R ? QECMC_KQ(1024, 4, R) : a.code == P ? QECMC_KQ(1024, 4, P) : nullptr;
+#undef QECMC_KQ
+    } else
     if (ladder_wants_pre(a) && ((a.acc_all_mask >> (a.Nc - 1)) & 1u)) {   // (a top chain at p = 0.75: the blind path the blocks feed)
         if (block <= 512) fn = a.code == X ? QECMC_KP(512, X) : a.code == R ? QECMC_KP(512, R) : a.code == P ? QECMC_KP(512, P) : nullptr;
         else fn = a.code == X ? QECMC_KP(1024, X) : a.code == R ? QECMC_KP(1024, R) : a.code == P ? QECMC_KP(1024, P) : nullptr;

@@ -301,3 +301,23 @@ def test_top_blocks_drawn_ahead_across_chunks(q):
         run.advance(chunk)
     snap = run.snapshot(states=True)
     assert np.array_equal(snap["states"], full["states"]) and np.array_equal(snap["counts"], full["counts"])
+
+
+@pytest.mark.parametrize("name,L,Nc,N,steps,iters", [("rotated", 5, 5, 200, 3000, 10), ("xzzx", 5, 4, 150, 2000, 8), ("planar", 5, 5, 140, 2500, 10),
+                                                     ("rotated", 7, 3, 100, 1500, 5)])
+def test_work_queue_plaquette_codes_bit_exact(q, orc, monkeypatch, name, L, Nc, N, steps, iters):
+    monkeypatch.setenv("QECMC_QUEUE_GRID", "1")
+    rng = np.random.default_rng(L * 11 + N)
+    code, ocode = {"rotated": (q.ROTATED, orc.ROTATED), "xzzx": (q.XZZX, orc.XZZX), "planar": (q.PLANAR, orc.PLANAR)}[name]
+    if name == "planar":
+        init = rand_states(rng, N, L, 0.1)
+        init[:, 1, -1, :] = 0; init[:, 1, :, -1] = 0
+    else:
+        init = rand_plaq(rng, N, L, 0.12)
+    kw = dict(steps=steps, iters=iters, tops_burn=1, seed=17, first_syndrome=3, conv_criteria="error_based", SEQ=1, TOPS=4, eps=0.5)
+    got = q.pteq_batch(init, 0.12, Nc=Nc, code=code, **kw)
+    ref = orc.pteq_batch(ocode, init, 0.12, Nc, kw.pop("steps"), **kw)
+    for k in ("converged", "steps_done", "samples", "tops0"):
+        assert np.array_equal(got[k], ref[k].astype(got[k].dtype)), k
+    assert np.array_equal(got["counts"], ref["counts"])
+    assert got["converged"].any() or L == 7          # (the three-rung L = 7 ladders all run to the horizon: refills by horizon only)
