@@ -116,6 +116,21 @@ int qecmc_to_class(int code, int L, uint64_t N, const uint8_t *in, uint8_t *out,
  * (planar_model.py:134-153): defects_out uint8[N][2 L (L-1)] = vertex_defects [L-1][L] then plaquette_defects [L][L-1]. */
 int qecmc_syndrome(int code, int L, uint64_t N, const uint8_t *in, uint8_t *defects_out);
 
+/* ---- syndrome generation (the data-generation recipe of generate_data.py:57-60,110-131, batched) --------------------
+ * N random error chains -- Toric_code.generate_random_error(p) (toric_model.py:15-23; pass p_x = p_y = p_z = p / 3) or
+ * generate_random_error(p_x, p_y, p_z) of the xzzx / rotated / planar models (xzzx_model.py:16-30, planar_model.py:18-40) --
+ * then, if hide_class != 0, one apply_random_logical on each (generate_data.py:131), all on the device.
+ * init_out uint8[N][nq] = the seed configurations for the decoder; raw_out (nullable) = the errors themselves
+ * (generate_data.py:120 keeps them); eq_true_out (nullable) int32[N] = their equivalence class (:121-122), the decoding target.
+ * Syndrome s draws from Philox (seed, first_syndrome + s): independent of how a data set is cut into batches.
+ * The _dev form takes device pointers and a hipStream_t, allocates nothing and does not synchronise. */
+int qecmc_generate_syndromes(int code, int L, uint64_t N, double p_x, double p_y, double p_z, int hide_class,
+                             uint64_t seed, uint32_t first_syndrome, uint8_t *init_out, uint8_t *raw_out,
+                             int32_t *eq_true_out);
+int qecmc_generate_syndromes_dev(int code, int L, uint64_t N, double p_x, double p_y, double p_z, int hide_class,
+                                 uint64_t seed, uint32_t first_syndrome, void *d_init_out, void *d_raw_out,
+                                 void *d_eq_true_out, void *hip_stream);
+
 /* ---- chain / ladder on caller-owned state (host pointers) ----------------- */
 
 /* Chain.update_chain(iters), src/mcmc.py:19-43, on N independent chains.

@@ -512,6 +512,57 @@ int qecmc_syndrome(int code, int L, uint64_t N, const uint8_t *in, uint8_t *defe
     return 0;
 }
 
+// ---------------------------------------------------------------- syndrome generation
+static int generate_args(int code, int L, uint64_t N, double p_x, double p_y, double p_z, int hide_class, uint64_t seed,
+                         uint32_t first_syndrome, GenArgs &a)
+{
+    if (int rc = check_code_L(code, L)) return rc;
+    if (!(p_x >= 0.0) || !(p_y >= 0.0) || !(p_z >= 0.0) || !(p_x + p_y + p_z <= 1.0))
+        return fail(QECMC_ERR_INVALID, "(p_x, p_y, p_z) = (%g, %g, %g) must be non-negative with a sum <= 1", p_x, p_y, p_z);
+    if (code == QECMC_TORIC && !(p_x == p_y && p_y == p_z))
+        return fail(QECMC_ERR_INVALID, "the toric model's generate_random_error(p) draws the Pauli uniformly (toric_model.py:15-23): pass p_x = p_y = p_z = p / 3");
+    if (N + first_syndrome > 0xFFFFFFFFull) return fail(QECMC_ERR_INVALID, "global syndrome index exceeds 32 bits");
+    std::memset(&a, 0, sizeof a);
+    a.N = N; a.code = code; a.L = L; a.nq = (int)code_nq(code, L); a.hide = hide_class != 0;
+    a.first_syndrome = first_syndrome; a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
+    if (code == QECMC_TORIC) a.thr_z = thr64((p_x + p_y) + p_z);
+    else { a.thr_z = thr64(p_z); a.thr_zx = thr64(p_z + p_x); a.thr_zxy = thr64((p_z + p_x) + p_y); }
+    return 0;
+}
+
+int qecmc_generate_syndromes_dev(int code, int L, uint64_t N, double p_x, double p_y, double p_z, int hide_class, uint64_t seed,
+                                 uint32_t first_syndrome, void *d_init_out, void *d_raw_out, void *d_eq_true_out, void *hip_stream)
+{
+    GenArgs a;
+    if (int rc = generate_args(code, L, N, p_x, p_y, p_z, hide_class, seed, first_syndrome, a)) return rc;
+    if (N == 0) return 0;
+    if (!d_init_out) return fail(QECMC_ERR_INVALID, "NULL device buffer");
+    a.out = static_cast<uint8_t *>(d_init_out); a.raw = static_cast<uint8_t *>(d_raw_out); a.eq_true = static_cast<int32_t *>(d_eq_true_out);
+    HIP_TRY(launch_generate(a, static_cast<hipStream_t>(hip_stream)));
+    return 0;
+}
+
+int qecmc_generate_syndromes(int code, int L, uint64_t N, double p_x, double p_y, double p_z, int hide_class, uint64_t seed,
+                             uint32_t first_syndrome, uint8_t *init_out, uint8_t *raw_out, int32_t *eq_true_out)
+{
+    GenArgs a;
+    if (int rc = generate_args(code, L, N, p_x, p_y, p_z, hide_class, seed, first_syndrome, a)) return rc;
+    if (int rc = use_device(0)) return rc;
+    if (N == 0) return 0;
+    if (!init_out) return fail(QECMC_ERR_INVALID, "NULL buffer");
+    const size_t nq = (size_t)a.nq;
+    DevBuf dout, draw, deq;
+    HIP_TRY(dout.alloc(N * nq));
+    if (raw_out) HIP_TRY(draw.alloc(N * nq));
+    if (eq_true_out) HIP_TRY(deq.alloc(N * 4));
+    a.out = dout.as<uint8_t>(); a.raw = raw_out ? draw.as<uint8_t>() : nullptr; a.eq_true = eq_true_out ? deq.as<int32_t>() : nullptr;
+    HIP_TRY(launch_generate(a, 0));
+    HIP_TRY(hipMemcpy(init_out, dout.p, N * nq, hipMemcpyDeviceToHost));
+    if (raw_out) HIP_TRY(hipMemcpy(raw_out, draw.p, N * nq, hipMemcpyDeviceToHost));
+    if (eq_true_out) HIP_TRY(hipMemcpy(eq_true_out, deq.p, N * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 // ---------------------------------------------------------------- chain / ladder
 static int chain_update_impl(int code, int L, uint64_t N, uint8_t *states_inout, double p, double eta, int noise,
                              double p_logical, uint64_t iters, uint64_t seed, uint32_t first_syndrome, uint32_t slot, uint64_t k0,

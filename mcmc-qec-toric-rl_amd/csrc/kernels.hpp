@@ -148,4 +148,17 @@ struct ChainArgs {
 };
 hipError_t launch_chain_update(const ChainArgs &a, hipStream_t s);
 
+// device-side syndrome generation (primitives.hip)
+constexpr uint32_t kGenStream = 0x200u;   // Philox stream id of the error / logical-operator draws of the generator
+struct GenArgs {
+    uint8_t *out;             // [N][nq] seed configurations (errors, then the random logical operator if `hide`)
+    uint8_t *raw;             // [N][nq] the errors before the logical operator (nullable)
+    int32_t *eq_true;         // [N] class of the raw errors (nullable)
+    uint64_t N;
+    uint64_t thr_z, thr_zx, thr_zxy;   // ceil(p_z 2^32), ceil((p_z + p_x) 2^32), ceil((p_z + p_x + p_y) 2^32); toric: thr_z = ceil(p 2^32)
+    uint32_t first_syndrome, seed_lo, seed_hi;
+    int code, L, nq, hide;
+};
+hipError_t launch_generate(const GenArgs &a, hipStream_t s);
+
 }  // namespace qecmc

@@ -203,6 +203,79 @@ hipError_t launch_syndrome(int code, int L, uint64_t N, const uint8_t *in, uint8
 {
     QECMC_LAUNCH(k_syndrome, N, s, code, L, N, in, defects);
 }
+// ---- syndrome generation on the device (generate_data.py:57-60,110-131) --------------------------------------------
+// Toric_code.generate_random_error(p) (toric_model.py:15-23: a qubit errs with probability p, its Pauli uniform on {1,2,3}) and
+// xzzx_code / RotSurCode / Planar_code.generate_random_error(p_x, p_y, p_z) (xzzx_model.py:16-30, rotated_surface_model.py:25-38,
+// planar_model.py:18-40: one uniform r per qubit: r < p_z -> Z, < p_z + p_x -> X, < p_z + p_x + p_y -> Y).  Qubit q of syndrome s
+// draws words (2 (q & 1), 2 (q & 1) + 1) of Philox block (q >> 1, sub 0) of stream kGenStream: two qubits per block, one
+// thread per block; HBM-bound byte work (one byte written per qubit, twice when the raw errors are kept).
+__global__ void k_generate_errors(const GenArgs a)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t npairs = (uint32_t)(a.nq + 1) / 2;
+    if (i >= a.N * (uint64_t)npairs) return;
+    const uint64_t s = i / npairs;
+    const uint32_t b = (uint32_t)(i - s * npairs);
+    const u32x4 x = philox_block(b, 0, a.first_syndrome + (uint32_t)s, kGenStream, a.seed_lo, a.seed_hi);
+    const uint32_t u1[2] = {x.x, x.z}, u2[2] = {x.y, x.w};
+    for (int h = 0; h < 2; ++h) {
+        const uint32_t q = 2 * b + h;
+        if (q >= (uint32_t)a.nq) break;
+        uint8_t v = 0;
+        if (a.code == kCodeToric) {
+            if ((uint64_t)u1[h] < a.thr_z) v = (uint8_t)(1u + scale_u32(u2[h], 3u));            // thr_z = ceil(p 2^32)
+        } else {
+            const uint64_t r = u1[h];
+            v = r < a.thr_z ? 3 : r < a.thr_zx ? 1 : r < a.thr_zxy ? 2 : 0;
+            if (a.code == kCodePlanar && q >= (uint32_t)(a.L * a.L)) {                            // layer 1 lives on its first L-1 rows / columns
+                const uint32_t rc = q - (uint32_t)(a.L * a.L), row = rc / (uint32_t)a.L, col = rc - row * (uint32_t)a.L;
+                if (row == (uint32_t)a.L - 1u || col == (uint32_t)a.L - 1u) v = 0;
+            }
+        }
+        a.out[s * (uint64_t)a.nq + q] = v;
+        if (a.raw) a.raw[s * (uint64_t)a.nq + q] = v;
+    }
+}
+
+// define_equivalence_class of the raw errors (generate_data.py:121-122) and one apply_random_logical on top (:131;
+// toric_model.py:228-253, xzzx_model.py:340-357): the operator fields of block (0, 1) of the generation stream, laid out as in
+// a top-chain proposal block (word 1: op / X position, word 2: layer 1's, word 3: the Z positions)
+__global__ void k_hide_class(const GenArgs a)
+{
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= a.N) return;
+    uint8_t *m = a.out + s * (uint64_t)a.nq;
+    const int L = a.L;
+    if (a.eq_true) a.eq_true[s] = a.code == kCodeToric ? toric_eq_class_b(L, m) : surf_eq_class_b(a.code, L, m);
+    if (!a.hide) return;
+    const u32x4 x = philox_block(0, 1, a.first_syndrome + (uint32_t)s, kGenStream, a.seed_lo, a.seed_hi);
+    if (a.code == kCodeToric) {
+        const int op0 = (int)(x.y >> 30), op1 = (int)(x.z >> 30);
+        const int x0 = (op0 == 1 || op0 == 2) ? (int)scale_low30(x.y, L) : 0, z0 = (op0 == 3 || op0 == 2) ? (int)scale_u16(x.w >> 16, L) : 0;
+        const int x1 = (op1 == 1 || op1 == 2) ? (int)scale_low30(x.z, L) : 0, z1 = (op1 == 3 || op1 == 2) ? (int)scale_u16(x.w & 0xFFFFu, L) : 0;
+        toric_apply_logical_b(L, m, op0, 0, x0, z0);
+        toric_apply_logical_b(L, m, op1, 1, x1, z1);
+    } else {
+        const int op = (int)(x.y >> 30);
+        const int xp = (op == 1 || op == 2) ? (int)scale_low30(x.y, L) : 0, zp = (op == 3 || op == 2) ? (int)scale_u16(x.w >> 16, L) : 0;
+        surf_apply_logical_b(a.code, L, m, op, xp, zp);
+    }
+}
+
+hipError_t launch_generate(const GenArgs &a, hipStream_t s)
+{
+    const uint64_t threads = a.N * (uint64_t)((a.nq + 1) / 2);
+    if (threads == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_generate_errors, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (a.hide || a.eq_true) {
+        hipLaunchKernelGGL(k_hide_class, dim3(grid_for(a.N)), dim3(kBlock), 0, s, a);
+        e = hipGetLastError();
+    }
+    return e;
+}
+
 hipError_t launch_chain_update(const ChainArgs &a, hipStream_t s)
 {
     QECMC_LAUNCH(k_chain_update, a.N, s, a);

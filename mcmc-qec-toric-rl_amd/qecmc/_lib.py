@@ -55,6 +55,10 @@ SIGNATURES = {
     "qecmc_eq_class": (C.c_int, [C.c_int, C.c_int, C.c_uint64, _u8p, _i32p]),
     "qecmc_to_class": (C.c_int, [C.c_int, C.c_int, C.c_uint64, _u8p, _u8p, _i32p]),
     "qecmc_syndrome": (C.c_int, [C.c_int, C.c_int, C.c_uint64, _u8p, _u8p]),
+    "qecmc_generate_syndromes": (C.c_int, [C.c_int, C.c_int, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_int, C.c_uint64,
+                                           C.c_uint32, _u8p, _u8p, _i32p]),
+    "qecmc_generate_syndromes_dev": (C.c_int, [C.c_int, C.c_int, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_int,
+                                               C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "qecmc_chain_update": (C.c_int, [C.c_int, C.c_int, C.c_uint64, _u8p, C.c_double, C.c_double, C.c_uint64,
                                      C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64]),
     "qecmc_chain_update_biased": (C.c_int, [C.c_int, C.c_int, C.c_uint64, _u8p, C.c_double, C.c_double, C.c_double,

@@ -67,6 +67,28 @@ def draw_errors(code, size, n, p_error, rng, eta=None, rates=None):
     return m
 
 
+def generate_syndromes(code, size, n, p_error=None, eta=None, rates=None, hide=True, seed=0, first_syndrome=0):
+    """The generation half of the recipe ON THE DEVICE (qecmc_generate_syndromes): n error chains by the model's
+    generate_random_error, their equivalence class, and -- hide=True -- one apply_random_logical on top (generate_data.py:110-131).
+    Rates as in draw_errors: toric / depolarizing p_x = p_y = p_z = p_error / 3, the Z-biased split for eta, or explicit `rates`.
+    Syndrome s draws from Philox (seed, first_syndrome + s).  Returns (init uint8[n, ...], raw uint8[n, ...], eq_true int32[n])."""
+    code = _CODES.get(code, code)
+    if rates is not None:
+        px, py, pz = rates
+    elif eta is None or code == L_.TORIC:
+        px = py = pz = p_error / 3
+    else:
+        pz, px = p_error * eta / (eta + 1), p_error / (2 * (eta + 1))
+        py = px
+    shape = (n, 2, size, size) if code in (L_.TORIC, L_.PLANAR) else (n, size, size)
+    init = np.zeros(shape, dtype=np.uint8)
+    raw = np.zeros(shape, dtype=np.uint8)
+    eq = np.zeros(n, dtype=np.int32)
+    L_.check(L_.lib().qecmc_generate_syndromes(code, size, n, float(px), float(py), float(pz), int(bool(hide)), seed & 0xFFFFFFFFFFFFFFFF,
+                                               first_syndrome, L_.u8(init), L_.u8(raw), L_.i32(eq)))
+    return init, raw, eq
+
+
 def hide_class(code, m, rng):
     """`init_code.qubit_matrix, _ = init_code.apply_random_logical()` (generate_data.py:131) on a batch:
     the operator draws of toric_model.py:234-248 / xzzx_model.py:346-355, applied by the device stencil."""
@@ -157,7 +179,7 @@ def _estimate(method, code, reps, p_error, p_sampling, Nc, steps, droplets, conv
 
 
 def generate(params, nbr_datapoints, seed=0, file_path=None, steps=100000, conv_criteria="error_based", biased_decoder="alpha",
-             rng=None, **pteq_kw):
+             rng=None, device_generation=False, **pteq_kw):
     """params: dict like generate_data.py:276-296 ({'code','size','p_error','noise'[,'eta','alpha']}), method PTEQ.
     noise 'depolarizing' -> PTEQ (:136); 'biased' -> errors from the eta split (:78-83) decoded by PTEQ_alpha with
     (pz_tilde, alpha) derived from (p, eta) exactly as :142-150 does (biased_decoder="biased" decodes with PTEQ_biased
@@ -166,6 +188,7 @@ def generate(params, nbr_datapoints, seed=0, file_path=None, steps=100000, conv_
     unique-chain estimators on one representative per class of every syndrome, with params['p_sampling'] (default p_error),
     params['droplets'], params['conv_mult'] and `steps` as the estimator's own `steps`; `batch` syndromes go into one launch
     (default 256: the sets of visited chains live in HBM).  They return distr float64[n, ncls] and no counts.
+    device_generation=True draws the errors and the hiding logical operator on the GPU (`generate_syndromes`) instead of NumPy.
     Returns (and optionally saves as npz) qubit_matrix uint8[n,...] (the raw errors, generate_data.py:120),
     eq_true int32[n], counts uint32[n,ncls], distr uint8[n,ncls] (what PTEQ returns), success bool[n]
     (argmax(distr) == eq_true, generate_data.py:139), steps_done, converged."""
@@ -176,9 +199,15 @@ def generate(params, nbr_datapoints, seed=0, file_path=None, steps=100000, conv_
         raise ValueError(f"noise={noise!r}")
     eta = params.get("eta") if noise == "biased" else None
     rng = np.random.default_rng(seed) if rng is None else rng         # (shards pass a generator keyed by (seed, shard id))
-    raw = draw_errors(code, size, nbr_datapoints, p, rng, eta, rates=alpha_rates(p, params["alpha"]) if noise == "alpha" else None)
-    eq_true = np.asarray(_class_of(code, raw), dtype=np.int32)
-    init = hide_class(code, raw, rng)
+    rates = alpha_rates(p, params["alpha"]) if noise == "alpha" else None
+    if device_generation:
+        # errors, true class and the hiding logical operator drawn on the GPU (Philox keyed by the global syndrome index: the data
+        # set does not depend on how it is cut into shards)
+        init, raw, eq_true = generate_syndromes(code, size, nbr_datapoints, p, eta, rates, True, seed, int(pteq_kw.get("first_syndrome", 0)))
+    else:
+        raw = draw_errors(code, size, nbr_datapoints, p, rng, eta, rates=rates)
+        eq_true = np.asarray(_class_of(code, raw), dtype=np.int32)
+        init = hide_class(code, raw, rng)
     method = params.get("method", "PTEQ")
     if method != "PTEQ":
         if noise != ("alpha" if method == "STDC_N_n" else "depolarizing"):

@@ -545,3 +545,12 @@ def ptdc_distribution(hist, p_error):
     n = np.arange(hist.shape[-1], dtype=np.float64)
     Z = (hist.astype(np.float64) * np.exp(-beta * n)).sum(axis=-1)
     return Z / Z.sum(axis=-1, keepdims=True) * 100
+
+
+def generate_syndromes(code, L, N, p_x, p_y, p_z, hide_class=True, seed=0, first_syndrome=0):
+    """N error chains + (hide_class) a random logical operator, Philox mode: (init, raw, eq_true)."""
+    shape = (N, 2, L, L) if code in (TORIC, PLANAR) else (N, L, L)
+    init = np.zeros(shape, dtype=np.uint8); raw = np.zeros(shape, dtype=np.uint8); eq = np.zeros(N, dtype=np.int32)
+    lib().orc_generate_syndromes(code, L, C.c_uint64(N), C.c_double(p_x), C.c_double(p_y), C.c_double(p_z), int(bool(hide_class)),
+                                 C.c_uint64(seed), C.c_uint32(first_syndrome), _u8(init), _u8(raw), eq.ctypes.data_as(C.POINTER(C.c_int32)))
+    return init, raw, eq

@@ -881,3 +881,70 @@ void orc_ptdc_batch(const orc_model *m, const uint8_t *init, uint64_t N, int ncl
         free(tab);
     }
 }
+
+/* ------------------------------------------------------------------------ */
+/* Syndrome generation (generate_data.py:57-60,110-131): N error chains from    */
+/* generate_random_error -- toric_model.py:15-23 (error w.p. p, Pauli uniform),  */
+/* xzzx_model.py:16-30 / rotated_surface_model.py:25-38 / planar_model.py:18-40  */
+/* (one uniform against p_z, p_z + p_x, p_z + p_x + p_y) -- then, if `hide`, one  */
+/* apply_random_logical (toric_model.py:228-253, xzzx_model.py:340-357).  Philox  */
+/* mode only: qubit q draws words (2 (q & 1), 2 (q & 1) + 1) of block (q >> 1, 0)  */
+/* of stream 0x200, the logical operator's fields come from block (0, 1).          */
+/* ------------------------------------------------------------------------ */
+static uint64_t gen_thr64(double v)          /* u < v  <=>  x < ceil(v 2^32) for u = x 2^-32 */
+{
+    if (!(v < 1.0)) return 1ull << 32;
+    if (!(v > 0.0)) return 0;
+    return (uint64_t)ceil(v * 4294967296.0);
+}
+
+void orc_generate_syndromes(int code, int L, uint64_t N, double p_x, double p_y, double p_z, int hide, uint64_t seed,
+                            uint32_t first_syndrome, uint8_t *init_out, uint8_t *raw_out, int32_t *eq_true_out)
+{
+    const int nq = orc_nq(code, L);
+    const uint64_t tz = code == ORC_TORIC ? gen_thr64((p_x + p_y) + p_z) : gen_thr64(p_z);
+    const uint64_t tzx = gen_thr64(p_z + p_x), tzxy = gen_thr64((p_z + p_x) + p_y);
+    const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint8_t *tmp = (uint8_t *)malloc((size_t)nq);
+    for (uint64_t s = 0; s < N; ++s) {
+        uint8_t *m = init_out + s * (size_t)nq;
+        const uint32_t syn = first_syndrome + (uint32_t)s;
+        for (int q = 0; q < nq; ++q) {
+            uint32_t ctr[4] = {(uint32_t)(q >> 1), 0u, syn, 0x200u}, w[4];
+            orc_philox4x32_10(ctr, key, w);
+            const uint32_t u1 = w[2 * (q & 1)], u2 = w[2 * (q & 1) + 1];
+            uint8_t v = 0;
+            if (code == ORC_TORIC) {
+                if ((uint64_t)u1 < tz) v = (uint8_t)(1u + (uint32_t)(((uint64_t)u2 * 3u) >> 32));      /* randint(3) + 1 */
+            } else {
+                v = (uint64_t)u1 < tz ? 3 : (uint64_t)u1 < tzx ? 1 : (uint64_t)u1 < tzxy ? 2 : 0;
+                if (code == ORC_PLANAR && q >= L * L) {                 /* planar_model.py:38-39 */
+                    const int rc = q - L * L, row = rc / L, col = rc % L;
+                    if (row == L - 1 || col == L - 1) v = 0;
+                }
+            }
+            m[q] = v;
+        }
+        if (raw_out) memcpy(raw_out + s * (size_t)nq, m, (size_t)nq);
+        if (eq_true_out) eq_true_out[s] = orc_eq_class(code, L, m);
+        if (!hide) continue;
+        uint32_t ctr[4] = {0u, 1u << 16, syn, 0x200u}, x[4];
+        orc_philox4x32_10(ctr, key, x);
+        if (code == ORC_TORIC) {
+            const int op0 = (int)(x[1] >> 30), op1 = (int)(x[2] >> 30);
+            const int x0 = (op0 == 1 || op0 == 2) ? (int)(((uint64_t)(uint32_t)(x[1] << 2) * (uint32_t)L) >> 32) : 0;
+            const int z0 = (op0 == 3 || op0 == 2) ? (int)(((x[3] >> 16) * (uint32_t)L) >> 16) : 0;
+            const int x1 = (op1 == 1 || op1 == 2) ? (int)(((uint64_t)(uint32_t)(x[2] << 2) * (uint32_t)L) >> 32) : 0;
+            const int z1 = (op1 == 3 || op1 == 2) ? (int)(((x[3] & 0xFFFFu) * (uint32_t)L) >> 16) : 0;
+            orc_toric_apply_logical(L, m, tmp, op0, 0, x0, z0);
+            orc_toric_apply_logical(L, tmp, m, op1, 1, x1, z1);
+        } else {
+            const int op = (int)(x[1] >> 30);
+            const int xp = (op == 1 || op == 2) ? (int)(((uint64_t)(uint32_t)(x[1] << 2) * (uint32_t)L) >> 32) : 0;
+            const int zp = (op == 3 || op == 2) ? (int)(((x[3] >> 16) * (uint32_t)L) >> 16) : 0;
+            orc_surf_apply_logical(code, L, m, tmp, op, xp, zp);
+            memcpy(m, tmp, (size_t)nq);
+        }
+    }
+    free(tmp);
+}

@@ -214,4 +214,9 @@ void orc_toric_pteq_batch_conv(int L, const uint8_t *init, uint64_t N, uint32_t 
 #ifdef __cplusplus
 }
 #endif
+/* Syndrome generation in Philox mode (the checker of qecmc_generate_syndromes): error chains by the models'
+ * generate_random_error, their equivalence class, and one apply_random_logical on top (generate_data.py:110-131). */
+void orc_generate_syndromes(int code, int L, uint64_t N, double p_x, double p_y, double p_z, int hide, uint64_t seed,
+                            uint32_t first_syndrome, uint8_t *init_out, uint8_t *raw_out, int32_t *eq_true_out);
+
 #endif

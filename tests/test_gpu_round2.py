@@ -321,3 +321,33 @@ def test_work_queue_plaquette_codes_bit_exact(q, orc, monkeypatch, name, L, Nc, 
         assert np.array_equal(got[k], ref[k].astype(got[k].dtype)), k
     assert np.array_equal(got["counts"], ref["counts"])
     assert got["converged"].any() or L == 7          # (the three-rung L = 7 ladders all run to the horizon: refills by horizon only)
+
+
+# ------------------------------------------------------------------ syndrome generation on the device (row f1)
+@pytest.mark.parametrize("name,L,rates,N,first", [("toric", 9, (0.05, 0.05, 0.05), 1000, 0), ("toric", 4, (0.1, 0.1, 0.1), 77, 4000),
+                                                  ("xzzx", 9, (7.4257e-4, 7.4257e-4, 0.148515), 600, 12), ("rotated", 21, (0.17 / 3,) * 3, 65, 1),
+                                                  ("planar", 5, (0.03, 0.04, 0.05), 300, 0), ("xzzx", 3, (0.3, 0.0, 0.2), 50, 9)])
+def test_generate_syndromes_bit_exact(q, orc, name, L, rates, N, first):
+    from qecmc import harness
+    code, ocode = {"toric": (q.TORIC, orc.TORIC), "xzzx": (q.XZZX, orc.XZZX), "rotated": (q.ROTATED, orc.ROTATED), "planar": (q.PLANAR, orc.PLANAR)}[name]
+    for hide in (True, False):
+        init, raw, eq = harness.generate_syndromes(code, L, N, rates=rates, hide=hide, seed=77, first_syndrome=first)
+        ri, rr, re = orc.generate_syndromes(ocode, L, N, *rates, hide_class=hide, seed=77, first_syndrome=first)
+        assert np.array_equal(raw, rr) and np.array_equal(eq, re) and np.array_equal(init, ri)
+        assert hide or np.array_equal(init, raw)
+
+
+def test_generate_syndromes_validation_and_harness(q):
+    from qecmc import harness, _lib as L_
+    import ctypes as C
+    out = np.zeros((4, 2, 5, 5), dtype=np.uint8)
+    rc = L_.lib().qecmc_generate_syndromes(L_.TORIC, 5, 4, 0.1, 0.05, 0.05, 1, 0, 0, L_.u8(out), None, None)
+    assert rc == -1 and b"p_x = p_y = p_z" in L_.lib().qecmc_last_error()
+    assert L_.lib().qecmc_generate_syndromes(L_.XZZX, 5, 4, 0.6, 0.3, 0.3, 1, 0, 0, L_.u8(out), None, None) == -1
+    assert L_.lib().qecmc_generate_syndromes(L_.TORIC, 5, 4, 0.05, 0.05, 0.05, 1, 0, 0, L_.u8(out), None, None) == 0      # nullable outputs
+    # the batched recipe with the errors drawn on the GPU: low noise decodes, shards do not depend on the cut
+    params = {"code": "rotated", "size": 5, "p_error": 0.05, "noise": "depolarizing"}
+    a = harness.generate(params, 200, seed=3, steps=3000, conv_criteria=None, tops_burn=0, device_generation=True)
+    assert a["success"].mean() > 0.9
+    b = harness.generate(params, 100, seed=3, steps=3000, conv_criteria=None, tops_burn=0, device_generation=True, first_syndrome=100)
+    assert np.array_equal(b["qubit_matrix"], a["qubit_matrix"][100:]) and np.array_equal(b["counts"], a["counts"][100:])

@@ -100,3 +100,38 @@ def test_philox_generator_pick_is_uniform_over_generators(code, L, G, top):
     cnt = np.array(list(seen.values()), dtype=np.float64)
     chi2 = np.sum((cnt - n / G) ** 2 / (n / G))
     assert chi2 < G + 6 * np.sqrt(2 * G)      # mean G-1, sd sqrt(2(G-1)): a > 6 sigma excess would be a broken decode
+
+
+@pytest.mark.parametrize("code,L,rates", [("toric", 9, (0.05, 0.05, 0.05)), ("xzzx", 9, (7.4257e-4, 7.4257e-4, 0.148515)), ("rotated", 7, (0.17 / 3,) * 3),
+                                          ("planar", 5, (0.03, 0.03, 0.03))])
+def test_oracle_syndrome_generator_distribution(code, L, rates):
+    """The oracle's Philox-mode restatement of generate_random_error + apply_random_logical (generate_data.py:110-131): Pauli
+    rates within binomial error, the hiding operator keeps the syndrome and spreads the classes, the raw class is what is
+    reported, planar layer 1 keeps its idle row / column."""
+    cid = {"toric": orc.TORIC, "xzzx": orc.XZZX, "rotated": orc.ROTATED, "planar": orc.PLANAR}[code]
+    N = 6000
+    init, raw, eq = orc.generate_syndromes(cid, L, N, *rates, hide_class=True, seed=11, first_syndrome=100)
+    px, py, pz = rates
+    live = np.ones(raw.shape[1:], dtype=bool)
+    if code == "planar":
+        live[1, -1, :] = False; live[1, :, -1] = False
+        assert not raw[:, 1, -1, :].any() and not raw[:, 1, :, -1].any()
+    n = N * int(live.sum())
+    for val, pr in ((1, px), (2, py), (3, pz)):
+        k = int((raw[:, live] == val).sum())
+        assert abs(k - n * pr) <= 5 * np.sqrt(n * pr * (1 - pr)) + 1, (code, val, k / n, pr)
+    ncls = 16 if code == "toric" else 4
+    for s in range(0, N, 500):
+        if code == "toric":
+            assert orc.toric_eq_class(raw[s]) == eq[s] and np.array_equal(orc.toric_syndrome(init[s]), orc.toric_syndrome(raw[s]))
+        else:
+            assert orc.surf_eq_class(cid, raw[s]) == eq[s]
+            if code != "planar":
+                assert np.array_equal(orc.surf_syndrome(cid, init[s]), orc.surf_syndrome(cid, raw[s]))
+    hidden = np.array([orc.toric_eq_class(m) if code == "toric" else orc.surf_eq_class(cid, m) for m in init[:2000]])
+    # class change = the applied operator: uniform over the ncls operators (toric: 4 x 4 per layer pair; others: 4), odd L
+    delta = np.bincount(hidden ^ eq[:2000] if code in ("toric", "rotated", "planar") else (hidden - eq[:2000]) % 4, minlength=ncls)
+    assert delta.min() > 2000 / ncls * 0.6, delta
+    # a second call with another first_syndrome continues the same data set
+    a, _, _ = orc.generate_syndromes(cid, L, 10, *rates, hide_class=True, seed=11, first_syndrome=105)
+    assert np.array_equal(a, init[5:15])
