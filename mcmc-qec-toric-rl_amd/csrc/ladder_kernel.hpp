@@ -313,7 +313,8 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
 
     for (int i = tid; i < NC * W * 64; i += nthreads) st[i] = 0;
     for (int i = tid; i < ncls * 64; i += nthreads) hist[i] = 0;
-    if (tid == 0) { stopf[0] = 0; stopf[2] = 0; stopf[3] = 0; }   // [0] stop, [2], [3] QUEUE: refill requested (by step parity)
+    if (tid == 0) { stopf[0] = 0; stopf[1] = 0; stopf[2] = 0; stopf[3] = 0; }   // [0], [1] stop; [2], [3] QUEUE: refill requested -- each by step parity:
+                                                                                //  wave 0 writes the flag of step t+1 during step t, every wave reads it behind step t+1's barrier
     if (a.swap_acc != nullptr)
         for (int i = tid; i < 2 * NC * 64; i += nthreads) lds_all[gdw + i] = 0;
     if constexpr (USET) {
@@ -1364,7 +1365,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
         [[maybe_unused]] bool q_refill = false;
         if (CONV || USET) {                                 // flags set one step earlier: uniform for the workgroup
             volatile uint32_t *f0 = lds_all + (NC * W * 64 + 4 * NC * 64 + ncls * 64 + NC * 9 + NC * kSwapFast);
-            if (f0[0]) break;
+            if (f0[t & 1]) break;
             if constexpr (QUEUE) q_refill = f0[2 + (t & 1)] != 0;   // (written by wave 0 before this step's barrier: double-buffered by parity)
         }
         {
@@ -1512,12 +1513,12 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                         if (q_empty) q_dead = true;
                     }
                     volatile uint32_t *f0 = lds_all + (NC * W * 64 + 4 * NC * 64 + ncls * 64 + NC * 9 + NC * kSwapFast);
-                    if (__all(q_dead)) f0[0] = 1;
+                    if (__all(q_dead)) f0[(t + 1) & 1] = 1;
                     // ask for a refill at the end of the next step if lanes wait for work and that step's successor keeps the blocks in phase
                     f0[2 + ((t + 1) & 1)] = (!q_empty && __any(done && !q_dead) && ((t + 2) % q_period) == 0) ? 1u : 0u;
                 }
             } else
-            if (CONV && wave_u == 0 && __all(done || lane >= cnt)) *stopf = 1;
+            if (CONV && wave_u == 0 && __all(done || lane >= cnt)) stopf[(t + 1) & 1] = 1;
             if (slot_u == 0) flag = 0;                                              // :103
             if constexpr (USET) {
                 const bool cm = a.uset_conv_mult != 0.0;
@@ -1573,7 +1574,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                         if (fresh && n <= atomicMin(&cm_short[lane], n)) cm_trig[((uint32_t)t & 1u) * 64 + lane] = (uint32_t)t;
                     }
                 }
-                if (cm && wave_u == 0 && __all(cm_done || lane >= cnt)) *stopf = 1;
+                if (cm && wave_u == 0 && __all(cm_done || lane >= cnt)) stopf[(t + 1) & 1] = 1;
             }
             if constexpr (QUEUE) {
                 if (q_refill) {                                                     // uniform for the workgroup (read behind the barrier)
