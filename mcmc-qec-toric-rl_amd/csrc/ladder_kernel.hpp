@@ -232,6 +232,12 @@ __device__ inline bool alpha_series_close(uint64_t z2, uint64_t xy2, uint32_t de
 // DELUT (toric, split table with >= 64 idle entries between its halves, i.e. 2 L^2 <= 191): a proposal's dE comes from a
 // 512-byte LDS table indexed by the four old fields and the generator's type instead of seven VALU instructions -- the kernel
 // is bound by VALU issue (98 % busy), the LDS array has room.
+// SSW: the swap sweep (mcmc.py:96-103) is run once, by wave 0, on the published records -- the raw swap uniforms against the
+// threshold table -- and its result handed to the other waves through the idle half of the record buffer behind a second
+// barrier, instead of every wave replaying the cascade on acceptance bounds two waves prepared.  Fewer VALU instructions
+// (the kernel's bound) for a short serial section the other workgroups of the CU cover: +7 % where four 8-wave workgroups
+// share a CU (toric L <= 9), -10 ... -14 % where the LDS footprint leaves two or three (measured on every family), so only the
+// former are instantiated with it.
 // QUEUE (with CONV; depolarizing rule, random scan, the framed top chain at p = 0.75): a persistent grid with a work queue for the runs
 // that stop by the convergence criterion (decoders.py:74-82).  Stopping times spread over a decade (4e4 ... 3e5
 // ladder steps at L = 9), and a lane whose syndrome has converged would otherwise idle until the slowest of its 64 finishes.
@@ -244,7 +250,7 @@ __device__ inline bool alpha_series_close(uint64_t z2, uint64_t xy2, uint32_t de
 // whose LDS footprint leaves 4 waves per SIMD anyway).  The draws do not depend on the state, so nothing changes but who
 // is the step's longest wave: at L = 15 the top wave's 10 blocks + frame flush were 2.6 x a non-top wave's step.
 template <int MAXT, int MINW, bool CONV, bool GSPLIT, int CODE, bool BIASED, bool SCAN, bool GENTOP, bool USET = false, bool ALPHA = false,
-          bool PRE = false, bool DELUT = false, bool QUEUE = false>
+          bool PRE = false, bool DELUT = false, bool QUEUE = false, bool SSW = false>
 __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const LadderArgs a)
 {
     extern __shared__ uint32_t lds_all[];
@@ -1330,7 +1336,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             // d <= dmax with dmax = the largest d whose threshold exceeds x.  dmax is found here, off the cascade's serial
             // path: a log2 guess, then the exact table moves it up or down (so rounding in the guess cannot matter).
             auto swap_dmax = [&](uint32_t x, int i) -> uint32_t {
-                if (BIASED && alpha_noise) return x;                // Ladder_alpha compares in floating point (below)
+                if (SSW || (BIASED && alpha_noise)) return x;       // SSW: wave 0 tests the raw uniform; Ladder_alpha compares in floating point (below)
                 auto below = [&](int dd) -> bool {                  // x < ceil(p_diff[i]^dd * 2^32), dd in [1, nq]
                     return (swap_fast && dd < kSwapFast) ? x < swapT[i * kSwapFast + dd]
                                                          : (uint64_t)x < a.swap_thr[(size_t)i * (nq + 1) + dd];
@@ -1372,7 +1378,40 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             // every wave replays the top-down cascade on the published records; `car` is the record
             // being carried down, `mine` the one that ends in the slot this wave takes over next
             slot_u = slot_u == 0 ? (uint32_t)(NC - 1) : slot_u - 1;   // downwards: the wave leaving the top slot needs one rung only
+            // _r_flip (mcmc.py:146-149) of rung pair i for the carried record and the one below: d <= 0, or u < rel_p**d
+            auto swap_flip = [&](int i, uint32_t hi, uint32_t lo, uint32_t xi) -> bool {
+                const int d = (int)(hi & 0xFFFFu) - (int)(lo & 0xFFFFu);           // ne_hi - ne_lo
+                if (BIASED && alpha_noise) {
+                    // Ladder_alpha.r_flip, mcmc_alpha.py:118-123: slot-bound n_eff, always draws
+                    const uint32_t *ne = neffb + (t & 1) * NC * 64 + lane;
+                    const int ic = i < 0 ? 0 : i;
+                    return alpha_flip(xi, ne[(ic + 1) * 64], ne[ic * 64], a.alpha, a.alpha_lnb[ic]);
+                }
+                if constexpr (SSW) {
+                    // xi is the raw uniform: x < ceil(p_diff[i]^d 2^32) from the LDS table (d < 64; entry 0 never passes), else HBM
+                    const int ic = i < 0 ? 0 : i, dd = d < 1 ? 1 : d;
+                    bool lt = xi < swapT[ic * kSwapFast + (dd < kSwapFast ? dd : 0)];
+                    if (!swap_fast || dd >= kSwapFast) lt = (uint64_t)xi < a.swap_thr[(size_t)ic * (nq + 1) + dd];
+                    return d <= 0 || lt;
+                } else {
+                    return d <= (int)xi;                                            // xi = the largest accepted difference (thresholds fall with d)
+                }
+            };
             uint32_t car = cur[(NC - 1) * 64], mine = car;
+            if constexpr (SSW) {
+                uint32_t *nxt = info + ((t + 1) & 1) * NC * 64 + lane;             // the other parity's records: idle until the waves publish step t+1
+                if (wave_u == 0) {
+                    for (int i = NC - 2; i >= 0; --i) {                             // mcmc.py:96
+                        const uint32_t lo = cur[i * 64];
+                        const bool flip = swap_flip(i, car, lo, sx[i * 64]);
+                        nxt[(i + 1) * 64] = flip ? lo : car;                        // what slot i+1 now holds (:98-99)
+                        car = flip ? car : lo;
+                    }
+                    nxt[0] = car;
+                }
+                __syncthreads();
+                mine = nxt[slot_u * 64];
+            } else {
             // a wave only needs the cascade down to the rung that fills its own next slot (wave 0 also does the
             // slot-0 bookkeeping and runs it to the bottom).  (Compiling the cascade twice -- wave 0 capturing its record on the way,
             // the others taking what their last rung leaves -- saves a v_cndmask per rung and measured 2 % slower.)
@@ -1391,14 +1430,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 for (int u = 0; u < 4; ++u) {
                     const int i = ib - u;
                     const uint32_t lo = lo4[u], xi = x4[u];
-                    const int d = (int)(car & 0xFFFFu) - (int)(lo & 0xFFFFu);      // ne_hi - ne_lo
-                    bool flip = d <= (int)xi;                                       // _r_flip :146-149: d <= 0, or u < rel_p**d <=> d <= dmax
-                    if (BIASED && alpha_noise) {
-                        // Ladder_alpha.r_flip, mcmc_alpha.py:118-123: slot-bound n_eff, always draws
-                        const uint32_t *ne = neffb + (t & 1) * NC * 64 + lane;
-                        const int ic = i < 0 ? 0 : i;
-                        flip = alpha_flip(xi, ne[(ic + 1) * 64], ne[ic * 64], a.alpha, a.alpha_lnb[ic]);
-                    }
+                    const bool flip = swap_flip(i, car, lo, xi);
                     if (i >= i_stop) {                                              // uniform
                         const uint32_t into = flip ? lo : car;                      // what slot i+1 now holds (:98-99)
                         car = flip ? car : lo;
@@ -1406,7 +1438,8 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                     }
                 }
             }
-            if (slot_u == 0) mine = car;
+            }   // !SSW
+            if (!SSW && slot_u == 0) mine = car;
             n = mine & 0xFFFFu; sid = (mine >> 16) & 0xFFu; cls = (mine >> 24) & 0x3Fu; flag = mine >> 31;
             if ((int)slot_u == NC - 1) flag = 1;                                    // chains[-1].flag = 1, mcmc.py:100
             if (wave_u == 0 && !done) {                                             // ladder + PTEQ bookkeeping on slot 0's new state
@@ -1473,11 +1506,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 uint32_t c2 = cur[(NC - 1) * 64];
                 for (int i = NC - 2; i >= 0; --i) {
                     const uint32_t lo = cur[i * 64], xi = sx[i * 64];
-                    bool flip = (int)(c2 & 0xFFFFu) - (int)(lo & 0xFFFFu) <= (int)xi;
-                    if (BIASED && alpha_noise) {
-                        const uint32_t *ne = neffb + (t & 1) * NC * 64 + lane;
-                        flip = alpha_flip(xi, ne[(i + 1) * 64], ne[i * 64], a.alpha, a.alpha_lnb[i]);
-                    }
+                    const bool flip = swap_flip(i, c2, lo, xi);
                     if (!done) {                                                   // (a converged syndrome stops counting)
                         sacc[i * 64] += flip;
                         nsum[(i + 1) * 64] += (flip ? lo : c2) & 0xFFFFu;

@@ -26,6 +26,12 @@ hipError_t launch_ladder_surf(const LadderArgs &a, hipStream_t stream)
     }
     else
 #undef QECMC_KP
+    if (!conv && block <= 512 && 4 * ladder_launch_lds(a) <= 160 * 1024 && !(a.tune & 8u)) {
+        // four workgroups per CU: the VALU-bound shapes take the swap sweep run once by wave 0 (SSW, ladder_kernel.hpp)
+#define QECMC_KS(code) (const void *)ladder_rs_toric_kernel<512, 8, false, false, code, false, false, true, false, false, false, false, false, true>
+        fn = a.code == X ? QECMC_KS(X) : a.code == R ? QECMC_KS(R) : a.code == P ? QECMC_KS(P) : nullptr;
+#undef QECMC_KS
+    } else
     if (a.code == X) fn = block <= 512 ? QECMC_K(512, 8, X) : QECMC_K(1024, 4, X);
     else if (a.code == R) fn = block <= 512 ? QECMC_K(512, 8, R) : QECMC_K(1024, 4, R);
     else if (a.code == P) fn = block <= 512 ? QECMC_K(512, 8, P) : QECMC_K(1024, 4, P);

@@ -11,6 +11,8 @@ hipError_t launch_ladder_toric(const LadderArgs &a, hipStream_t stream)
     // the general top-chain path is needed only for L > 16 or a top chain below p = 0.75 (1-chain ladder)
     const bool gentop = a.thr_logical != 0 && (a.L > 16 || !((a.acc_all_mask >> (a.Nc - 1)) & 1u));
     const bool gsplit = (int)a.n_gen <= kGenSplit;      // the table layout of ladder_gen_dwords()
+    // the swap sweep run once by wave 0 (SSW) pays where four workgroups share a CU: the VALU-bound shapes
+    const bool ssw = block <= 512 && 4 * ladder_launch_lds(a) <= 160 * 1024 && !(a.tune & 8u);
     const void *fn;
 #define QECMC_K(maxt, minw, g, gentop) (conv ? (const void *)ladder_rs_toric_kernel<maxt, minw, true, g, T, false, false, gentop> \
                                              : (const void *)ladder_rs_toric_kernel<maxt, minw, false, g, T, false, false, gentop>)
@@ -33,8 +35,13 @@ hipError_t launch_ladder_toric(const LadderArgs &a, hipStream_t stream)
 #undef QECMC_KP
     } else if (block <= 512 && gsplit && (int)a.n_gen + 64 <= kGenSplit && !(a.tune & 4u)) {
         // the dE look-up table fits the idle entries between the split table's halves (2 L^2 <= 191: the headline's L = 9)
+        if (!conv && ssw)
+            fn = (const void *)ladder_rs_toric_kernel<512, 8, false, true, T, false, false, false, false, false, false, true, false, true>;
+        else
         fn = conv ? (const void *)ladder_rs_toric_kernel<512, 8, true, true, T, false, false, false, false, false, false, true>
                   : (const void *)ladder_rs_toric_kernel<512, 8, false, true, T, false, false, false, false, false, false, true>;
+    } else if (!conv && ssw && gsplit) {
+        fn = (const void *)ladder_rs_toric_kernel<512, 8, false, true, T, false, false, false, false, false, false, false, false, true>;
     } else {
         if (block <= 512) fn = gsplit ? QECMC_K(512, 8, true, false) : QECMC_K(512, 8, false, false);
         else fn = gsplit ? QECMC_K(1024, 4, true, false) : QECMC_K(1024, 4, false, false);
