@@ -459,6 +459,8 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
     uint32_t slot_u = wave_u;                                   // the slot this wave works on in the current step
     const uint32_t iters = a.iters;
     const uint32_t thrL1 = (uint32_t)(a.thr_logical - 1);      // x < thr_logical <=> x <= thr_logical-1 (thr in [1, 2^32])
+    // the packed toric top chain's 16-bit select: A[31:16] < thr16 = ceil(p_logical * 2^16)  <=>  A <= (thr16 << 16) - 1
+    [[maybe_unused]] const uint32_t thrA1 = (uint32_t)((((a.thr_logical + 65535u) >> 16) << 16) - 1u);
     const uint32_t Lodd = L & 1;                                // a row/column operator flips L parities
     const uint32_t rowbits = 2u * (uint32_t)L;                  // bits of one lattice row in the packed stream
     const uint32_t rowmask = rowbits >= 32 ? 0xFFFFFFFFu : (1u << rowbits) - 1u;
@@ -1135,15 +1137,19 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             //   fr0: bit r      = X on row r of layer 0      bit 16+c = Z on column c of layer 0
             //   fr1: bit c      = X on column c of layer 1   bit 16+r = Z on row r of layer 1
             uint32_t fr0 = 0, fr1 = 0, cdelta = 0;
-            auto add_logical = [&](const u32x4 &x) {                                // _apply_random_logical, toric_model.py:228-253
-                const uint32_t op0 = x.y >> 30, op1 = x.z >> 30;
+            auto frame_logical = [&](uint32_t op0, uint32_t op1, uint32_t x0, uint32_t z0, uint32_t x1, uint32_t z1) {
                 const uint32_t dx0 = (op0 ^ (op0 >> 1)) & 1u, dz0 = op0 >> 1;       // X iff op in {1,2}; Z iff op in {2,3}
                 const uint32_t dx1 = (op1 ^ (op1 >> 1)) & 1u, dz1 = op1 >> 1;
-                const uint32_t x0 = scale_low30(x.y, L), z0 = scale_u16(x.w >> 16, L);
-                const uint32_t x1 = scale_low30(x.z, L), z1 = scale_u16(x.w & 0xFFFFu, L);
                 fr0 ^= (dx0 << x0) | (dz0 << (16 + z0));
                 fr1 ^= (dx1 << x1) | (dz1 << (16 + z1));
                 cdelta ^= dx0 | (dz0 << 1) | (dx1 << 2) | (dz1 << 3);
+            };
+            [[maybe_unused]] auto add_logical = [&](const u32x4 &x) {               // _apply_random_logical, toric_model.py:228-253 (sweep: block (k, 0))
+                frame_logical(x.y >> 30, x.z >> 30, scale_low30(x.y, L), scale_u16(x.w >> 16, L), scale_low30(x.z, L), scale_u16(x.w & 0xFFFFu, L));
+            };
+            [[maybe_unused]] auto add_logical2 = [&](uint32_t A, uint32_t B) {       // random scan: the packed words (philox.hpp, kSubTopPair)
+                frame_logical((A >> 14) & 3u, (A >> 12) & 3u, ((A & 0xFFFu) * (uint32_t)L) >> 12, ((B >> 21) * (uint32_t)L) >> 11,
+                              (((B >> 10) & 0x7FFu) * (uint32_t)L) >> 11, ((B & 0x3FFu) * (uint32_t)L) >> 10);
             };
             if constexpr (SCAN) {
                 // sweep at f = 1: generator k mod G with probability 1/2 (coin bit k&31 of word (k>>5)&3 of block
@@ -1166,11 +1172,11 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 }
             } else
             {
-                auto blind = [&](const u32x4 &x) {
-                    if (x.x <= thrL1) {                                             // mcmc.py:23
-                        add_logical(x);
+                auto blind = [&](uint32_t A, uint32_t B) {
+                    if (A <= thrA1) {                                               // mcmc.py:23 (A[31:16] < thr16)
+                        add_logical2(A, B);
                     } else {
-                        const uint4 ev = gen_entry(scale_u32(x.y, 2u * (uint32_t)LL));   // word 1 picks the generator
+                        const uint4 ev = gen_entry(scale_u32(B, 2u * (uint32_t)LL));     // word B picks the generator
                         const uint32_t e4[4] = {ev.x, ev.y, ev.z, ev.w};
                         const uint32_t op = (ev.x >> 5) & 3u;
 #pragma unroll
@@ -1178,33 +1184,33 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                             lds_xor(reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(stw) + (e4[i] >> 16)), shl_lo5(op, e4[i]));
                     }
                 };
-                uint32_t j = 0;
+                // the step's proposals [kbase, kbase + iters) lie in blocks b0 .. b0 + nblk - 1, two per block: the first block
+                // may start at its second proposal and the last may end at its first (all wave-uniform)
+                const uint64_t b0 = (kbase >> 1) - (kq >> 1);                       // (kq is a multiple of 4)
+                const bool skip_first = (kbase & 1) != 0, skip_last = ((kbase + iters) & 1) != 0;
+                const uint32_t nblk = (uint32_t)(((kbase + iters - 1) >> 1) - (kbase >> 1)) + 1u;
+                auto both = [&](const u32x4 &x, uint32_t bi) {
+                    if (!(skip_first && bi == 0)) blind(x.x, x.y);
+                    if (!(skip_last && bi == nblk - 1)) blind(x.z, x.w);
+                };
+                uint32_t bi = 0;
                 if constexpr (PRE) {
                     if (t >= 2 && NC >= 3) {                                        // (the first two top steps of a launch had no earlier role)
+                        const uint32_t pn = nblk < (uint32_t)kPre ? nblk : (uint32_t)kPre;
 #pragma unroll
                         for (int jj = 0; jj < kPre; ++jj)
-                            if ((uint32_t)jj < pre_n) blind(pre[jj]);
-                        j = pre_n;
+                            if ((uint32_t)jj < pn) both(pre[jj], (uint32_t)jj);
+                        bi = pn;
                     }
                 }
-                // four proposals' Philox chains in flight: this wave is the step's longest and often runs alone
-                for (; j + 3 < iters; j += 4) {
-                    const u32x4 xa = philox_block(kbase - kq + j, 0, syn, slot_u, a.seed_lo, a.seed_hi);
-                    const u32x4 xb = philox_block(kbase - kq + j + 1, 0, syn, slot_u, a.seed_lo, a.seed_hi);
-                    const u32x4 xc = philox_block(kbase - kq + j + 2, 0, syn, slot_u, a.seed_lo, a.seed_hi);
-                    const u32x4 xd = philox_block(kbase - kq + j + 3, 0, syn, slot_u, a.seed_lo, a.seed_hi);
-                    blind(xa);
-                    blind(xb);
-                    blind(xc);
-                    blind(xd);
+                // two blocks' (four proposals') Philox chains in flight: this wave is the step's longest and often runs alone
+                for (; bi + 1 < nblk; bi += 2) {
+                    const u32x4 xa = philox_block(b0 + bi, kSubTopPair, syn, slot_u, a.seed_lo, a.seed_hi);
+                    const u32x4 xb = philox_block(b0 + bi + 1, kSubTopPair, syn, slot_u, a.seed_lo, a.seed_hi);
+                    both(xa, bi);
+                    both(xb, bi + 1);
                 }
-                for (; j + 1 < iters; j += 2) {
-                    const u32x4 xa = philox_block(kbase - kq + j, 0, syn, slot_u, a.seed_lo, a.seed_hi);
-                    const u32x4 xb = philox_block(kbase - kq + j + 1, 0, syn, slot_u, a.seed_lo, a.seed_hi);
-                    blind(xa);
-                    blind(xb);
-                }
-                if (j < iters) blind(philox_block(kbase - kq + j, 0, syn, slot_u, a.seed_lo, a.seed_hi));
+                if (bi < nblk) both(philox_block(b0 + bi, kSubTopPair, syn, slot_u, a.seed_lo, a.seed_hi), bi);
             }
             // flush the frame: lattice row r of layer l is the 2L-bit span at bit 2*(l*LL + r*L)
             {
@@ -1260,12 +1266,19 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             const uint32_t *lmask = a.lmask;
             for (uint32_t j = 0; j < iters; ++j) {
                 const uint64_t k = kbase + j;
-                const u32x4 x = philox_block(k, 0, syn, slot_u, a.seed_lo, a.seed_hi);
-                if (x.x <= thrL1) {
-                    const uint32_t op0 = x.y >> 30, op1 = x.z >> 30;
+                // random scan: the packed words A, B of block (k >> 1, kSubTopPair); sweep: block (k, 0)
+                const u32x4 x = SCAN ? philox_block(k, 0, syn, slot_u, a.seed_lo, a.seed_hi)
+                                     : philox_block(k >> 1, kSubTopPair, syn, slot_u, a.seed_lo, a.seed_hi);
+                [[maybe_unused]] const uint32_t pA = (k & 1) ? x.z : x.x, pB = (k & 1) ? x.w : x.y;
+                if (SCAN ? x.x <= thrL1 : pA <= thrA1) {
+                    const uint32_t op0 = SCAN ? x.y >> 30 : (pA >> 14) & 3u, op1 = SCAN ? x.z >> 30 : (pA >> 12) & 3u;
                     const uint32_t dx0 = (op0 ^ (op0 >> 1)) & 1u, dz0 = op0 >> 1, dx1 = (op1 ^ (op1 >> 1)) & 1u, dz1 = op1 >> 1;
-                    const uint32_t ix0 = dx0 ? scale_low30(x.y, L) : L, iz0 = dz0 ? scale_u16(x.w >> 16, L) : L;   // row L = identity
-                    const uint32_t ix1 = dx1 ? scale_low30(x.z, L) : L, iz1 = dz1 ? scale_u16(x.w & 0xFFFFu, L) : L;
+                    const uint32_t px0 = SCAN ? scale_low30(x.y, L) : ((pA & 0xFFFu) * (uint32_t)L) >> 12;
+                    const uint32_t pz0 = SCAN ? scale_u16(x.w >> 16, L) : ((pB >> 21) * (uint32_t)L) >> 11;
+                    const uint32_t px1 = SCAN ? scale_low30(x.z, L) : (((pB >> 10) & 0x7FFu) * (uint32_t)L) >> 11;
+                    const uint32_t pz1 = SCAN ? scale_u16(x.w & 0xFFFFu, L) : ((pB & 0x3FFu) * (uint32_t)L) >> 10;
+                    const uint32_t ix0 = dx0 ? px0 : L, iz0 = dz0 ? pz0 : L;       // row L = identity
+                    const uint32_t ix1 = dx1 ? px1 : L, iz1 = dz1 ? pz1 : L;
                     const int LW = (L + 1) * W;
                     const uint32_t *m0 = lmask + ix0 * W, *m1 = lmask + LW + iz0 * W, *m2 = lmask + 2 * LW + ix1 * W,
                                    *m3 = lmask + 3 * LW + iz1 * W;
@@ -1288,7 +1301,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                         q[0] = (e.x & 0xFFFFu) >> 2; q[1] = e.x >> 18; q[2] = (e.y & 0xFFFFu) >> 2; q[3] = e.y >> 18;
                         op = e.x & 3u;
                     } else {
-                        const uint32_t g = scale_u32(x.y, 2u * (uint32_t)LL), isX = g < (uint32_t)LL, rc = isX ? g : g - (uint32_t)LL;
+                        const uint32_t g = scale_u32(pB, 2u * (uint32_t)LL), isX = g < (uint32_t)LL, rc = isX ? g : g - (uint32_t)LL;
                         toric_sites(L, LL, rc / (uint32_t)L, rc % (uint32_t)L, isX, q);
                         op = isX ? 1u : 3u;
                     }
@@ -1318,10 +1331,20 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             // step's top-chain blocks (state-independent: block (proposal index, 0) of the top slot's stream) while the others finish
             if (NC >= 3 && slot_u <= 1u && a.thr_logical != 0) {
                 const uint64_t kb1 = a.prop0 + (t + 1 + slot_u) * iters;
+                if constexpr (CODE == kCodeToric) {
+                    // toric: the packed blocks (two proposals each) of that step, the first kPre of them
+                    const uint32_t nb = (uint32_t)(((kb1 + iters - 1) >> 1) - (kb1 >> 1)) + 1u, pn = nb < (uint32_t)kPre ? nb : (uint32_t)kPre, ph = pn / 2;
+#pragma unroll
+                    for (int jj = 0; jj < kPre; ++jj) {
+                        const bool mine = slot_u == 1u ? (uint32_t)jj < ph : ((uint32_t)jj >= ph && (uint32_t)jj < pn);
+                        if (mine) pre[jj] = philox_block((kb1 >> 1) + jj, kSubTopPair, syn, (uint32_t)(NC - 1), a.seed_lo, a.seed_hi);
+                    }
+                } else {
 #pragma unroll
                 for (int jj = 0; jj < kPre; ++jj) {
                     const bool mine = slot_u == 1u ? (uint32_t)jj < pre_h : ((uint32_t)jj >= pre_h && (uint32_t)jj < pre_n);
                     if (mine) pre[jj] = philox_block(kb1 + jj, 0, syn, (uint32_t)(NC - 1), a.seed_lo, a.seed_hi);
+                }
                 }
             }
         }

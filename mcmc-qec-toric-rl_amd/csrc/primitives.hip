@@ -110,7 +110,10 @@ __global__ void k_chain_update(const ChainArgs a)
         const uint64_t k = a.k0 + j;
         // top: block (k, 0).  non-top: ONE word, word k&3 of block (k>>2, 1) -- top 20 bits pick the generator, low 12 bits
         // lead the 44-bit acceptance uniform that word k&3 of block (k>>2, kSubRefine) completes
-        u32x4 x = philox_block(top ? k : k >> 2, top ? 0u : 1u, syn, a.slot, a.seed_lo, a.seed_hi);
+        // (the toric depolarizing top chain packs two proposals into block (k >> 1, kSubTopPair): words A, B = 2 (k & 1), 2 (k & 1) + 1)
+        const bool packed = top && code == kCodeToric && !a.noise;
+        u32x4 x = philox_block(packed ? k >> 1 : top ? k : k >> 2, packed ? kSubTopPair : top ? 0u : 1u, syn, a.slot, a.seed_lo, a.seed_hi);
+        const uint32_t pA = (k & 1) ? x.z : x.x, pB = (k & 1) ? x.w : x.y;
         uint64_t v44 = 0;
         if (!top) {
             const u32x4 r = philox_block(k >> 2, kSubRefine, syn, a.slot, a.seed_lo, a.seed_hi);
@@ -120,9 +123,18 @@ __global__ void k_chain_update(const ChainArgs a)
         }
         // ---- propose (in place; XOR moves are involutions, so a rejected move is undone by re-applying it)
         int dE, row = 0, col = 0, op = 0, op0 = 0, op1 = 0, x0 = 0, z0 = 0, x1 = 0, z1 = 0;
-        const bool logical = top && (uint64_t)x.x < a.thr_logical;                 // mcmc.py:23
+        const bool logical = packed ? (uint64_t)(pA >> 16) < ((a.thr_logical + 65535u) >> 16)    // a 16-bit select: A[31:16] < ceil(p_logical * 2^16)
+                                    : top && (uint64_t)x.x < a.thr_logical;        // mcmc.py:23
         if (logical) {
-            if (code == kCodeToric) {
+            if (packed) {
+                // A = select[31:16] | op0[15:14] | op1[13:12] | X_pos0[11:0];  B = Z_pos0[31:21] | X_pos1[20:10] | Z_pos1[9:0]
+                op0 = (pA >> 14) & 3u; op1 = (pA >> 12) & 3u;                       // toric_model.py:234
+                if (op0 == 1 || op0 == 2) x0 = ((pA & 0xFFFu) * (uint32_t)L) >> 12; // :241-248
+                if (op0 == 3 || op0 == 2) z0 = ((pB >> 21) * (uint32_t)L) >> 11;
+                if (op1 == 1 || op1 == 2) x1 = (((pB >> 10) & 0x7FFu) * (uint32_t)L) >> 11;
+                if (op1 == 3 || op1 == 2) z1 = ((pB & 0x3FFu) * (uint32_t)L) >> 10;
+                dE = toric_apply_logical_b(L, m, op0, 0, x0, z0) + toric_apply_logical_b(L, m, op1, 1, x1, z1);
+            } else if (code == kCodeToric) {
                 op0 = x.y >> 30; op1 = x.z >> 30;                                   // toric_model.py:234
                 if (op0 == 1 || op0 == 2) x0 = scale_low30(x.y, L);                 // :241-248 (positions share block (k,0))
                 if (op0 == 3 || op0 == 2) z0 = scale_u16(x.w >> 16, L);
@@ -137,7 +149,7 @@ __global__ void k_chain_update(const ChainArgs a)
             }
         } else if (code == kCodeToric) {
             // one word picks one of the 2L^2 generators (toric_model.py:291-295): X plaquettes first, row-major
-            const uint32_t g = top ? scale_u32(x.y, 2u * L * L) : pick_top20(x.x, 2u * L * L), rc = g < (uint32_t)(L * L) ? g : g - L * L;
+            const uint32_t g = packed ? scale_u32(pB, 2u * L * L) : top ? scale_u32(x.y, 2u * L * L) : pick_top20(x.x, 2u * L * L), rc = g < (uint32_t)(L * L) ? g : g - L * L;
             row = rc / L; col = rc % L; op = g < (uint32_t)(L * L) ? 1 : 3;
             dE = toric_apply_stabilizer_b(L, m, row, col, op);
         } else {

@@ -239,7 +239,10 @@ int orc_eq_class(int code, int L, const uint8_t *m)
  * word k&3 of the refinement block (k>>2, sub 4): u = (a12 * 2^32 + w) * 2^-44.  (The refinement word matters only when
  * the 12 leading bits do not decide the comparison, once in 4096 proposals; the GPU computes it on demand.)
  * Top chains (mcmc.py:21-35) keep block (k, 0): word 0 selects logical / stabilizer, word 1 picks the generator, words
- * 1-3 carry a logical operator; the acceptance uniform is word 0 of block (k, 2). */
+ * 1-3 carry a logical operator; the acceptance uniform is word 0 of block (k, 2).  The toric depolarizing top chain in
+ * random scan -- whose proposals need no more than two words -- shares a block between two proposals instead: words
+ * A, B = 2 (k & 1), 2 (k & 1) + 1 of block (k >> 1, sub 5); A[31:16] selects, B picks the generator, and a logical
+ * operator's fields are cut from A[15:0] and B (model_random_logical_ex). */
 static double nontop_accept(const orc_model *m, orc_rng *rng, uint32_t slot, uint64_t k)
 {
     (void)m;
@@ -266,7 +269,9 @@ static int model_random_stabilizer(const orc_model *m, const uint8_t *in, uint8_
     int g = -1;
     if (rng->mode != 0) {
         /* non-top: the top 20 bits of the proposal's word, g = floor(x20 * G / 2^20); top chain: word 1 of its block */
-        const double u = w0 == 0 ? orc_draw_field(rng, slot, k >> 2, 1, (int)(k & 3), 0, 20) : orc_draw(rng, slot, k, 0, 1);
+        /* (w0 == 2: the toric top chain's packed layout -- two proposals per block (k >> 1, 5), the generator from the second word) */
+        const double u = w0 == 0 ? orc_draw_field(rng, slot, k >> 2, 1, (int)(k & 3), 0, 20)
+                       : w0 == 2 ? orc_draw(rng, slot, k >> 1, 5, 2 * (int)(k & 1) + 1) : orc_draw(rng, slot, k, 0, 1);
         g = (int)(u * G);
         rng->consumed += (m->code == ORC_TORIC || m->code == ORC_PLANAR) ? 2 : 4;   /* counted like the reference's three / five draws */
     }
@@ -311,10 +316,28 @@ static int model_random_stabilizer(const orc_model *m, const uint8_t *in, uint8_
  * 0 / 1 = the high / low half of word 3.  xzzx / rotated (xzzx_model.py:340-357,
  * rotated_surface_model.py:331-346): one operator (top two bits of word 1), X_pos iff op in {1,2} (low 30
  * bits of word 1), Z_pos iff op in {3,2} (high half of word 3). */
-static int model_random_logical(const orc_model *m, const uint8_t *in, uint8_t *out, orc_rng *rng,
-                                uint32_t slot, uint64_t k)
+static int model_random_logical_ex(const orc_model *m, const uint8_t *in, uint8_t *out, orc_rng *rng,
+                                   uint32_t slot, uint64_t k, int packed)
 {
     const int L = m->L;
+    if (m->code == ORC_TORIC && packed) {
+        /* the random-scan top chain: words A, B = words 2 (k & 1), 2 (k & 1) + 1 of block (k >> 1, 5).
+         * A = select[31:16] | op0[15:14] | op1[13:12] | X_pos0[11:0];  B = Z_pos0[31:21] | X_pos1[20:10] | Z_pos1[9:0] */
+        const uint64_t kb = k >> 1;
+        const int wa = 2 * (int)(k & 1), wb = wa + 1;
+        int ops[2];
+        ops[0] = (int)(orc_draw_field(rng, slot, kb, 5, wa, 16, 2) * 4);
+        ops[1] = (int)(orc_draw_field(rng, slot, kb, 5, wa, 18, 2) * 4);
+        int dE = 0;
+        if (out != in) memcpy(out, in, (size_t)2 * L * L);
+        for (int layer = 0; layer < 2; ++layer) {
+            int op = ops[layer], xpos = 0, zpos = 0;
+            if (op == 1 || op == 2) xpos = (int)((layer == 0 ? orc_draw_field(rng, slot, kb, 5, wa, 20, 12) : orc_draw_field(rng, slot, kb, 5, wb, 11, 11)) * L);
+            if (op == 3 || op == 2) zpos = (int)((layer == 0 ? orc_draw_field(rng, slot, kb, 5, wb, 0, 11) : orc_draw_field(rng, slot, kb, 5, wb, 22, 10)) * L);
+            dE += orc_toric_apply_logical(L, out, out, op, layer, xpos, zpos);
+        }
+        return dE;
+    }
     if (m->code == ORC_TORIC) {
         int ops[2];
         ops[0] = (int)(orc_draw(rng, slot, k, 0, 1) * 4);
@@ -333,6 +356,11 @@ static int model_random_logical(const orc_model *m, const uint8_t *in, uint8_t *
     if (op == 1 || op == 2) xpos = (int)(orc_draw_field(rng, slot, k, 0, 1, 2, 30) * L);
     if (op == 3 || op == 2) zpos = (int)(orc_draw_field(rng, slot, k, 0, 3, 0, 16) * L);
     return orc_surf_apply_logical(m->code, L, in, out, op, xpos, zpos);
+}
+
+static int model_random_logical(const orc_model *m, const uint8_t *in, uint8_t *out, orc_rng *rng, uint32_t slot, uint64_t k)
+{
+    return model_random_logical_ex(m, in, out, rng, slot, k, 0);
 }
 
 /* scan = 1: proposal k of a chain tests generator k mod G, in the fixed order "all X-type (row-major), then all
@@ -508,10 +536,13 @@ void orc_chain_update(const orc_model *m, uint8_t *state, double p, double p_log
         for (uint64_t j = 0; j < iters; ++j) {
             uint64_t k = k0 + j;
             int dE;
-            if (orc_draw(rng, slot, k, 0, 0) < p_logical)          /* mcmc.py:23 */
-                dE = model_random_logical(m, state, scratch, rng, slot, k);
+            /* toric: the packed layout (two proposals per block): the select is a 16-bit uniform, A[31:16] */
+            const int packed = m->code == ORC_TORIC;
+            const double usel = packed ? orc_draw_field(rng, slot, k >> 1, 5, 2 * (int)(k & 1), 0, 16) : orc_draw(rng, slot, k, 0, 0);
+            if (usel < p_logical)                                  /* mcmc.py:23 */
+                dE = model_random_logical_ex(m, state, scratch, rng, slot, k, packed);
             else
-                dE = model_random_stabilizer(m, state, scratch, rng, slot, k, 1);
+                dE = model_random_stabilizer(m, state, scratch, rng, slot, k, packed ? 2 : 1);
             if (p >= 0.75 || dE <= 0) {                            /* mcmc.py:30 */
                 memcpy(state, scratch, nq);
                 continue;
