@@ -458,6 +458,14 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
     const uint32_t wave_u = __builtin_amdgcn_readfirstlane(slot);
     uint32_t slot_u = wave_u;                                   // the slot this wave works on in the current step
     const uint32_t iters = a.iters;
+    // the wave's diagonal stream (philox.hpp): slot_u + T is constant while roles rotate downwards (QUEUE: per lane, T counts
+    // from the step the lane's ladder started at), and the last non-top block drawn, for the step that continues it
+    uint32_t dstrm = kDiagStream + (wave_u + (uint32_t)(a.step0 % (uint64_t)NC)) % (uint32_t)NC;
+    // (kept across steps where 8 waves per SIMD hide little: with 4 -- the PRE shapes, the large plaquette codes -- the four
+    // registers and the branch measured -1 ... -2 %)
+    constexpr bool kCarry = MINW >= 8;
+    [[maybe_unused]] u32x4 carry{0, 0, 0, 0};
+    [[maybe_unused]] uint64_t carry_kb = ~0ull;
     const uint32_t thrL1 = (uint32_t)(a.thr_logical - 1);      // x < thr_logical <=> x <= thr_logical-1 (thr in [1, 2^32])
     // the packed toric top chain's 16-bit select: A[31:16] < thr16 = ceil(p_logical * 2^16)  <=>  A <= (thr16 << 16) - 1
     [[maybe_unused]] const uint32_t thrA1 = (uint32_t)((((a.thr_logical + 65535u) >> 16) << 16) - 1u);
@@ -492,6 +500,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
         const uint64_t kbase = a.prop0 + t * iters;
         const bool acc_all = (a.acc_all_mask >> slot_u) & 1u;
         const bool top_logical = (slot_u == (uint32_t)(NC - 1)) && a.thr_logical != 0;
+        const uint32_t strm = top_logical ? slot_u : dstrm;                         // Philox stream of this step's proposals (philox.hpp)
         const uint32_t *myT = thrT + slot_u * 9 + 4;
         // sweep (scan = 1) of a top chain at f = 1 with table-driven logical masks: used by the plaquette codes and by
         // toric L > 16 (the L <= 16 toric top chain has the frame-based fast path below)
@@ -504,7 +513,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             for (uint32_t j = 0; j < iters; ++j) {
                 const uint64_t k = kbase + j;
                 if ((k & 7) == 0) {                                                 // one random logical operator
-                    const u32x4 x = philox_block(k, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                    const u32x4 x = philox_block(k, 0, syn, strm, a.seed_lo, a.seed_hi);
                     const uint32_t *m0 = lmask + L * W, *m1 = m0, *m2 = m0, *m3 = m0;   // identity rows
                     if (CODE == kCodeToric) {
                         const uint32_t op0 = x.y >> 30, op1 = x.z >> 30;
@@ -524,7 +533,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                     }
                     for (int w = 0; w < W; ++w) lds_xor(stw + w * 64, m0[w] ^ m1[w] ^ m2[w] ^ m3[w]);
                 }
-                if ((k >> 7) != cb_cur) { cb_cur = k >> 7; coins = philox_block(cb_cur, 3, syn, slot_u, a.seed_lo, a.seed_hi); }
+                if ((k >> 7) != cb_cur) { cb_cur = k >> 7; coins = philox_block(cb_cur, 3, syn, strm, a.seed_lo, a.seed_hi); }
                 const uint2 ev = gtab[gs];
                 gs = gs + 1 == a.n_gen ? 0u : gs + 1;
                 if ((sel4(coins, (int)((k >> 5) & 3)) >> (k & 31)) & 1u) {
@@ -568,7 +577,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                     bool acc = a12 < tI;                                            // mcmc.py:42 (dE <= 0: tI = 4096)
                     if (a12 == tI) {                                                // rare (a lane in 4096): the next 32 bits decide
                         constexpr int WI = decltype(wsel)::value;
-                        const u32x4 r = philox_block(kb - (kq >> 2), kSubRefine, syn, slot_u, a.seed_lo, a.seed_hi);
+                        const u32x4 r = philox_block(kb - (kq >> 2), kSubRefine, syn, strm, a.seed_lo, a.seed_hi);
                         acc = (WI == 0 ? r.x : WI == 1 ? r.y : WI == 2 ? r.z : r.w) < *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(myF) + v);
                     }
                     if (acc) {
@@ -590,7 +599,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 bool acc = a12 < tI;                                                // mcmc.py:42 (dE <= 0: tI = 4096)
                 if (a12 == tI) {                                                    // rare (a lane in 4096): the next 32 bits decide
                     constexpr int WI = decltype(wsel)::value;
-                    const u32x4 r = philox_block(kb - (kq >> 2), kSubRefine, syn, slot_u, a.seed_lo, a.seed_hi);
+                    const u32x4 r = philox_block(kb - (kq >> 2), kSubRefine, syn, strm, a.seed_lo, a.seed_hi);
                     acc = (WI == 0 ? r.x : WI == 1 ? r.y : WI == 2 ? r.z : r.w) < (myF - 12)[dE16];
                 }
                 if (acc) {
@@ -604,10 +613,14 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                     ni += (int)dE16 - 16;
                 }
             };
-            // the blocks that overlap [kbase, kbase + iters): a block the previous step started is drawn again
+            // the blocks that overlap [kbase, kbase + iters)
             uint64_t kb = kbase >> 2;
+            if constexpr (!kCarry) carry_kb = ~0ull;                               // (a block the previous step started is drawn again)
             for (int jb = -(int)((uint32_t)kbase & 3u); jb < (int)iters; jb += 4, ++kb) {
-                const u32x4 xa = philox_block(kb - (kq >> 2), 1, syn, slot_u, a.seed_lo, a.seed_hi);
+                // (the current block lives in `carry`: the one a step ends in is still there for the next step, which starts in it
+                // unless the top role came between)
+                if (kb != carry_kb) { carry = philox_block(kb - (kq >> 2), 1, syn, strm, a.seed_lo, a.seed_hi); carry_kb = kb; }
+                const u32x4 &xa = carry;
                 if (jb >= 0 && jb + 4 <= (int)iters) {                             // a whole block: no per-proposal range tests
                     propose(xa.x, kb, std::integral_constant<int, 0>{});
                     propose(xa.y, kb, std::integral_constant<int, 1>{});
@@ -655,19 +668,19 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 constexpr bool top = decltype(top_c)::value;
                 const double c0 = (top ? 32.0 : 12.0) - 512.0 * (lxy + lz);         // scales the ratio by 2^32 / 2^12, removes the offsets
                 [[maybe_unused]] const int LW = (L + 1) * W;
-                u32x4 pair{0, 0, 0, 0};                                            // the block four non-top proposals share
-                uint64_t kb_pair = ~0ull;
+                u32x4 pair = carry;                                                // the block four non-top proposals share (the last one of
+                uint64_t kb_pair = (top || !kCarry) ? ~0ull : carry_kb;            //  the previous step continues into this one)
                 for (uint32_t j = 0; j < iters; ++j) {
                     const uint64_t k = kbase + j;
                     // top: block (k, 0) = select | generator or logical fields | acceptance word | Z position;
                     // non-top: word k&3 of block (k>>2, 1) (+ its refinement)
                     u32x4 x;
                     if constexpr (top) {
-                        x = philox_block(k, 0, syn, slot_u, a.seed_lo, a.seed_hi);   // (drawing the next proposal's block ahead, behind this one's LDS reads: -1 %)
+                        x = philox_block(k, 0, syn, strm, a.seed_lo, a.seed_hi);   // (drawing the next proposal's block ahead, behind this one's LDS reads: -1 %)
                     } else {
                         if ((k >> 2) != kb_pair) {
                             kb_pair = k >> 2;
-                            pair = philox_block(kb_pair, 1, syn, slot_u, a.seed_lo, a.seed_hi);
+                            pair = philox_block(kb_pair, 1, syn, strm, a.seed_lo, a.seed_hi);
                         }
                         x.x = sel4(pair, (int)(k & 3));                             // the proposal's word: generator | 12 leading accept bits
                         x.y = x.z = x.w = 0;
@@ -736,7 +749,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                             const double ulo = (double)a12 * (1.0 / 4096.0);
                             acc = ulo + (1.0 / 4096.0) <= ratio;
                             if (!acc && ulo < ratio) {
-                                const uint64_t v44 = ((uint64_t)a12 << 32) | sel4(philox_block(k >> 2, kSubRefine, syn, slot_u, a.seed_lo, a.seed_hi), (int)(k & 3));
+                                const uint64_t v44 = ((uint64_t)a12 << 32) | sel4(philox_block(k >> 2, kSubRefine, syn, strm, a.seed_lo, a.seed_hi), (int)(k & 3));
                                 acc = (double)v44 * (1.0 / 17592186044416.0) < ratio;
                             }
                         }
@@ -754,6 +767,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                         any_acc = true;
                     }
                 }
+                if constexpr (!top && kCarry) { carry = pair; carry_kb = kb_pair; }
                 };
                 if (top) biased_loop(std::true_type{});
                 else biased_loop(std::false_type{});
@@ -780,7 +794,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                     uint32_t g;
                     if constexpr (SCAN) {                                          // generator k mod G, accept word k&3 of block k>>2
                         const uint64_t k = kbase + j;
-                        if ((k >> 2) != kb_cur) { kb_cur = k >> 2; blk = philox_block(kb_cur, 3, syn, slot_u, a.seed_lo, a.seed_hi); }
+                        if ((k >> 2) != kb_cur) { kb_cur = k >> 2; blk = philox_block(kb_cur, 3, syn, strm, a.seed_lo, a.seed_hi); }
                         x.w = sel4(blk, (int)(k & 3));
                         g = gs;
                         gs = gs + 1 == a.n_gen ? 0u : gs + 1;
@@ -863,7 +877,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                             j = pre_n;
                         }
                     }
-                    for (; j < iters; ++j) top_move(philox_block(kbase - kq + j, 0, syn, slot_u, a.seed_lo, a.seed_hi));
+                    for (; j < iters; ++j) top_move(philox_block(kbase - kq + j, 0, syn, strm, a.seed_lo, a.seed_hi));
                 }
                 uint32_t cnt_n = 0;
                 if (framed && L > 16) {
@@ -970,11 +984,11 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                     u32x4 x;
                     uint64_t v44 = 0;                                               // non-top: the 44-bit acceptance uniform
                     if (top) {
-                        x = philox_block(k, 0, syn, slot_u, a.seed_lo, a.seed_hi);
+                        x = philox_block(k, 0, syn, strm, a.seed_lo, a.seed_hi);
                     } else {
                         if ((k >> 2) != kb_pair) {
                             kb_pair = k >> 2;
-                            pair = philox_block(kb_pair, 1, syn, slot_u, a.seed_lo, a.seed_hi);
+                            pair = philox_block(kb_pair, 1, syn, strm, a.seed_lo, a.seed_hi);
                         }
                         x.x = sel4(pair, (int)(k & 3));                             // the proposal's word: generator | 12 leading accept bits
                         v44 = (uint64_t)(x.x & 0xFFFu) << 32;                       // ... the low 32 bits are drawn only when they decide
@@ -1059,10 +1073,10 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                     bool acc;
                     // non-top: u = (v44 + w) 2^-44 with w the proposal's word of the refinement block, needed only when the 12
                     // leading bits do not decide (u lies in [v44, v44 + 2^32) 2^-44): drawn by the lanes that tie
-                    auto refinement = [&]() { return (uint64_t)sel4(philox_block(k >> 2, kSubRefine, syn, slot_u, a.seed_lo, a.seed_hi), (int)(k & 3)); };
+                    auto refinement = [&]() { return (uint64_t)sel4(philox_block(k >> 2, kSubRefine, syn, strm, a.seed_lo, a.seed_hi), (int)(k & 3)); };
                     if (top) {
                         acc = acc_all || dE <= 0;                                   // mcmc.py:30
-                        if (!acc) acc = philox_block(k, 2, syn, slot_u, a.seed_lo, a.seed_hi).x < a.acc_tbl_top[dE];   // :34
+                        if (!acc) acc = philox_block(k, 2, syn, strm, a.seed_lo, a.seed_hi).x < a.acc_tbl_top[dE];   // :34
                     } else {
                         // mcmc.py:170 (Chain_xyz: a generator moves <= 4 sites) / mcmc.py:42 (a generator: dE <= 4)
                         const bool always = !xyz_rule && (acc_all || dE <= 0);
@@ -1097,7 +1111,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 uint32_t gs = (uint32_t)(kbase % a.n_gen);
                 uint2 ev = gtab[gs];                                               // entry of the next proposal, fetched one ahead
                 for (uint64_t kb = kbase >> 2; (kb << 2) < kend; ++kb) {
-                    const u32x4 blk = philox_block(kb, 3, syn, slot_u, a.seed_lo, a.seed_hi);
+                    const u32x4 blk = philox_block(kb, 3, syn, strm, a.seed_lo, a.seed_hi);
                     const uint32_t xs[4] = {blk.x, blk.y, blk.z, blk.w};
 #pragma unroll
                     for (int wi = 0; wi < 4; ++wi) {
@@ -1159,8 +1173,8 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 uint64_t cb_cur = ~0ull;
                 for (uint32_t j = 0; j < iters; ++j) {
                     const uint64_t k = kbase + j;
-                    if ((k & 7) == 0) add_logical(philox_block(k, 0, syn, slot_u, a.seed_lo, a.seed_hi));
-                    if ((k >> 7) != cb_cur) { cb_cur = k >> 7; coins = philox_block(cb_cur, 3, syn, slot_u, a.seed_lo, a.seed_hi); }
+                    if ((k & 7) == 0) add_logical(philox_block(k, 0, syn, strm, a.seed_lo, a.seed_hi));
+                    if ((k >> 7) != cb_cur) { cb_cur = k >> 7; coins = philox_block(cb_cur, 3, syn, strm, a.seed_lo, a.seed_hi); }
                     const uint2 ev = gtab[gs];
                     const uint32_t e0 = __builtin_amdgcn_readfirstlane(ev.x), e1 = __builtin_amdgcn_readfirstlane(ev.y);
                     gs = gs + 1 == a.n_gen ? 0u : gs + 1;
@@ -1205,12 +1219,12 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 }
                 // two blocks' (four proposals') Philox chains in flight: this wave is the step's longest and often runs alone
                 for (; bi + 1 < nblk; bi += 2) {
-                    const u32x4 xa = philox_block(b0 + bi, kSubTopPair, syn, slot_u, a.seed_lo, a.seed_hi);
-                    const u32x4 xb = philox_block(b0 + bi + 1, kSubTopPair, syn, slot_u, a.seed_lo, a.seed_hi);
+                    const u32x4 xa = philox_block(b0 + bi, kSubTopPair, syn, strm, a.seed_lo, a.seed_hi);
+                    const u32x4 xb = philox_block(b0 + bi + 1, kSubTopPair, syn, strm, a.seed_lo, a.seed_hi);
                     both(xa, bi);
                     both(xb, bi + 1);
                 }
-                if (bi < nblk) both(philox_block(b0 + bi, kSubTopPair, syn, slot_u, a.seed_lo, a.seed_hi), bi);
+                if (bi < nblk) both(philox_block(b0 + bi, kSubTopPair, syn, strm, a.seed_lo, a.seed_hi), bi);
             }
             // flush the frame: lattice row r of layer l is the 2L-bit span at bit 2*(l*LL + r*L)
             {
@@ -1267,8 +1281,8 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             for (uint32_t j = 0; j < iters; ++j) {
                 const uint64_t k = kbase + j;
                 // random scan: the packed words A, B of block (k >> 1, kSubTopPair); sweep: block (k, 0)
-                const u32x4 x = SCAN ? philox_block(k, 0, syn, slot_u, a.seed_lo, a.seed_hi)
-                                     : philox_block(k >> 1, kSubTopPair, syn, slot_u, a.seed_lo, a.seed_hi);
+                const u32x4 x = SCAN ? philox_block(k, 0, syn, strm, a.seed_lo, a.seed_hi)
+                                     : philox_block(k >> 1, kSubTopPair, syn, strm, a.seed_lo, a.seed_hi);
                 [[maybe_unused]] const uint32_t pA = (k & 1) ? x.z : x.x, pB = (k & 1) ? x.w : x.y;
                 if (SCAN ? x.x <= thrL1 : pA <= thrA1) {
                     const uint32_t op0 = SCAN ? x.y >> 30 : (pA >> 14) & 3u, op1 = SCAN ? x.z >> 30 : (pA >> 12) & 3u;
@@ -1288,7 +1302,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                         dE += (int)nnz2(old ^ m0[w] ^ m1[w] ^ m2[w] ^ m3[w]) - (int)nnz2(old);
                     }
                     bool acc = true;
-                    if (!acc_all && dE > 0) acc = philox_block(k, 2, syn, slot_u, a.seed_lo, a.seed_hi).x < a.acc_tbl_top[dE];
+                    if (!acc_all && dE > 0) acc = philox_block(k, 2, syn, strm, a.seed_lo, a.seed_hi).x < a.acc_tbl_top[dE];
                     if (acc) {
                         for (int w = 0; w < W; ++w) lds_xor(stw + w * 64, m0[w] ^ m1[w] ^ m2[w] ^ m3[w]);
                         ni += dE;
@@ -1311,7 +1325,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                         dE += (int)(f == 0u) - (int)(f == op);
                     }
                     bool acc = true;
-                    if (!acc_all && dE > 0) acc = philox_block(k, 2, syn, slot_u, a.seed_lo, a.seed_hi).x < a.acc_tbl_top[dE];
+                    if (!acc_all && dE > 0) acc = philox_block(k, 2, syn, strm, a.seed_lo, a.seed_hi).x < a.acc_tbl_top[dE];
                     if (acc) {
                         for (int i = 0; i < 4; ++i) lds_xor(stw + (q[i] >> 4) * 64, op << ((q[i] & 15u) * 2u));
                         ni += dE;
@@ -1630,6 +1644,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             }
             if constexpr (QUEUE) {
                 if (q_refill) {                                                     // uniform for the workgroup (read behind the barrier)
+                    carry_kb = ~0ull;                                               // (a new ladder starts on a block boundary)
                     if (wave_u == 0) {
                         // the finished lanes take the next ladders of the batch: one atomic per wave, ranks by prefix count
                         const bool want = done && !q_dead;
@@ -1654,6 +1669,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                     if (nqi != 0xFFFFFFFFu && (nqi != qi || nt0 != t0)) {
                         qi = nqi; t0 = nt0; kq = (uint64_t)t0 * iters;
                         syn = a.first_syndrome + qi;
+                        dstrm = kDiagStream + slot_u;                                // its step 0: the slot this wave has just moved to
                         const uint8_t *src = a.init + (uint64_t)(qi / R) * (uint64_t)nq;
                         const int dbase = (int)slot_u * W * 64 + lane;               // Ladder.__init__: every slot starts from the seed (mcmc.py:72)
                         uint32_t cn = 0;

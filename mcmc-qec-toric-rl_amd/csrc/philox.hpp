@@ -68,6 +68,11 @@ constexpr uint32_t kSubRefine = 4u;
 //   A = select[31:16] | op0[15:14] | op1[13:12] | X_pos0[11:0]        logical iff A[31:16] < ceil(p_logical * 2^16)
 //   B = the generator word (g = floor(B * 2 L^2 / 2^32)), or for a logical  Z_pos0[31:21] | X_pos1[20:10] | Z_pos1[9:0]
 constexpr uint32_t kSubTopPair = 5u;
+// Chains updated by the non-top rule (mcmc.py:37-43) draw from the DIAGONAL streams: the chain on slot c at ladder step T uses
+// stream kDiagStream + (c + T) mod Nc.  Roles rotate downwards in the kernel (a wave works on slot (w - T) mod Nc), so a wave
+// stays on one stream for the whole run and the words a step leaves over in its last four-proposal block (two of twelve at
+// iters = 10) are still in its registers when the next step needs them.  The top rule keeps stream c = Nc - 1.
+constexpr uint32_t kDiagStream = 0x400u;
 __host__ __device__ __forceinline__ uint32_t pick_top20(uint32_t x, uint32_t n) { return ((x >> 12) * n) >> 20; }
 
 // int(u * n) for u = x * 2^-32, exactly (toric_model.py:291 `int(random() * size)`)

@@ -98,6 +98,10 @@ static double orc_draw(orc_rng *r, uint32_t stream_id, uint64_t k, uint32_t sub,
 }
 
 #define ORC_SWAP_STREAM 0x100u
+/* Chains updated by the non-top rule (mcmc.py:37-43) draw from the "diagonal" streams: slot c at ladder step T uses stream
+ * ORC_DIAG_STREAM + (c + T) mod Nc; the top rule keeps stream Nc - 1.  (Any one-to-one assignment of (slot, step) to
+ * (stream, index) is as good as another; this one lets a GPU wave, whose slot moves down by one every step, stay on one stream.) */
+#define ORC_DIAG_STREAM 0x400u
 
 /* ------------------------------------------------------------------------ */
 /* toric stencils                                                            */
@@ -635,17 +639,18 @@ void orc_ladder_step(orc_ladder *ld, uint64_t iters, orc_rng *rng)
     const uint64_t k0 = ld->step_index * iters;
     const int is_alpha = ld->model.noise == ORC_NOISE_ALPHA;
     for (int c = 0; c < Nc; ++c) {                                  /* update_ladder :81-83 */
+        const double pl = c == Nc - 1 ? ld->p_logical : 0.0;
+        const uint32_t strm = pl != 0 ? (uint32_t)c : ORC_DIAG_STREAM + (uint32_t)(((uint64_t)c + ld->step_index) % (uint64_t)Nc);
         if (is_alpha) {
-            if (orc_chain_update_alpha(&ld->model, ld->states + (size_t)c * nq, ld->p_ladder[c], c == Nc - 1 ? ld->p_logical : 0.0,
-                                       iters, rng, (uint32_t)c, k0, ld->scratch, &ld->n_eff[c])) {
+            if (orc_chain_update_alpha(&ld->model, ld->states + (size_t)c * nq, ld->p_ladder[c], pl,
+                                       iters, rng, strm, k0, ld->scratch, &ld->n_eff[c])) {
                 const uint8_t *st = ld->states + (size_t)c * nq;         /* the counts n_eff was formed from */
                 uint32_t nz = 0, nxy = 0;
                 for (int q = 0; q < (int)nq; ++q) { nz += st[q] == 3; nxy += st[q] == 1 || st[q] == 2; }
                 ld->n_eff_cnt[2 * c] = nz; ld->n_eff_cnt[2 * c + 1] = nxy;
             }
         } else
-            orc_chain_update(&ld->model, ld->states + (size_t)c * nq, ld->p_ladder[c],
-                             c == Nc - 1 ? ld->p_logical : 0.0, iters, rng, (uint32_t)c, k0, ld->scratch);
+            orc_chain_update(&ld->model, ld->states + (size_t)c * nq, ld->p_ladder[c], pl, iters, rng, strm, k0, ld->scratch);
     }
     for (int i = Nc - 2; i >= 0; --i) {                             /* :96 */
         int64_t ne_lo = orc_count_errors((size_t)nq, ld->states + (size_t)i * nq);

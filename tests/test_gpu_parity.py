@@ -186,7 +186,7 @@ def test_full_size_properties(q, orc):
 # ------------------------------------------------------------------ convergence criterion (decoders.py:74-105)
 @pytest.mark.parametrize("L,p,Nc,N,steps,tops_burn,SEQ,TOPS,eps", [
     (3, 0.10, 3, 70, 3000, 1, 1, 4, 0.5), (3, 0.10, 3, 64, 6000, 2, 2, 10, 0.25), (5, 0.10, 5, 40, 4000, 2, 2, 3, 0.4),
-    (5, 0.12, 4, 33, 6000, 1, 1, 4, 0.6), (3, 0.2, 2, 10, 500, 0, 0, 1, 1.0)])
+    (5, 0.12, 4, 33, 6000, 1, 1, 4, 0.6), (3, 0.3, 2, 10, 500, 0, 0, 1, 1.0)])
 def test_pteq_error_based_bit_exact(q, orc, L, p, Nc, N, steps, tops_burn, SEQ, TOPS, eps):
     rng = np.random.default_rng(L * 31 + N)
     init = rand_states(rng, N, L, p)

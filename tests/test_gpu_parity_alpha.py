@@ -122,7 +122,7 @@ def test_alpha_rejects(q):
 
 
 @pytest.mark.parametrize("name,L,pzt,alpha,Nc,steps,conv,kw", [("xzzx", 5, 0.1, 1.7, 5, 250, None, dict(tops_burn=0)),
-                                                               ("rotated", 5, 0.2, 2.0, 4, 250, None, dict(tops_burn=1)),
+                                                               ("rotated", 5, 0.2, 2.0, 4, 600, None, dict(tops_burn=1)),
                                                                ("xzzx", 3, 0.3, 2.0, 3, 3000, "error_based", dict(eps=0.6))])
 def test_pteq_alpha_with_shortest(q, orc, name, L, pzt, alpha, Nc, steps, conv, kw):
     """PTEQ_alpha_with_shortest (decoders_biasednoise.py:93-172): the GPU ladder, stepped once per launch under the host

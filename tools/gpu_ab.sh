@@ -1,11 +1,10 @@
 b() { tag=$1; shift; timeout -k 10 200 python bench.py --no-cpu-baseline --steps 3 "$@" 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('$tag', '%.3e prop/s' % d['proposals_per_s'], 'frac %.3f' % d['roofline']['frac'], '%.2f ms' % d['kernel_ms_per_launch'], 'hist', d.get('histogram_match'))"; }
+import json,sys; d=json.loads(sys.stdin.read()); print('$tag', '%.3e prop/s' % d['proposals_per_s'], 'frac %.3f' % d['roofline']['frac'], '%.2f ms' % d['kernel_ms_per_launch'])"; }
 mkdir -p gpurun_out
-python -m pytest tests -m gpu -q > gpurun_out/gpu_tests.log 2>&1; echo "tests rc=$?"; tail -6 gpurun_out/gpu_tests.log
+python -m pytest tests -m gpu -q > gpurun_out/gpu_tests.log 2>&1; echo "tests rc=$?"; tail -3 gpurun_out/gpu_tests.log
 b cfg2 --config 2
-b cfg2 --config 2
-b L7 --L 7 --Nc 7
-b L9 --L 9
 b L10 --L 10
 b L13 --L 13 --Nc 9
 b cfg3 --config 3
+b cfg4 --config 4
+b cfg5 --config 5
