@@ -274,11 +274,9 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
     const std::vector<uint32_t> gt = p->code == QECMC_TORIC ? toric_generator_table(L) : surf_generator_table(p->code, L);
     std::vector<uint8_t> gen_type(gt.size() / 2, 0);
     std::vector<uint32_t> xyz_lut;
-    if (biased) {
-        // the biased / alpha rules' table of count changes: one row of 256 (the four old 2-bit fields) per distinct Pauli
-        // pattern among the generators; entry = dx + (dz << 10) + ((dx + dy) << 20), wrapping (added to packed counts)
-        if (nq > 511) return fail(QECMC_ERR_UNSUPPORTED, "biased / alpha noise packs the error counts in 10-bit fields: nq=%d", nq);
-        std::vector<uint32_t> patterns;
+    const bool typed = biased || (p->code != QECMC_TORIC && !p->scan);   // the generators' Pauli patterns: the biased rules' count-change table,
+    std::vector<uint32_t> patterns;                                      // the plaquette codes' dE table (ladder_kernel.hpp, DELUT)
+    if (typed) {
         for (size_t g = 0; g < gen_type.size(); ++g) {
             uint32_t ops = 0;
             for (int u = 0; u < 4; ++u) ops |= ((u < 2 ? gt[2 * g] >> (16 * u) : gt[2 * g + 1] >> (16 * (u - 2))) & 3u) << (2 * u);
@@ -289,6 +287,12 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
         }
         if (patterns.size() > 16) return fail(QECMC_ERR_UNSUPPORTED, "%zu distinct generator Pauli patterns (> 16)", patterns.size());
         a.n_types = (int)patterns.size();
+        for (size_t t = 0; t < patterns.size(); ++t) a.type_ops[t] = (uint8_t)patterns[t];
+    }
+    if (biased) {
+        // the biased / alpha rules' table of count changes: one row of 256 (the four old 2-bit fields) per distinct Pauli
+        // pattern among the generators; entry = dx + (dz << 10) + ((dx + dy) << 20), wrapping (added to packed counts)
+        if (nq > 511) return fail(QECMC_ERR_UNSUPPORTED, "biased / alpha noise packs the error counts in 10-bit fields: nq=%d", nq);
         xyz_lut.assign(256 * patterns.size(), 0u);
         for (size_t t = 0; t < patterns.size(); ++t)
             for (uint32_t F = 0; F < 256; ++F) {
@@ -366,9 +370,11 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
         }
         HIP_TRY(pl->xyz_lut.alloc(xyz_lut.size() * sizeof(uint32_t)));
         HIP_TRY(hipMemcpy(pl->xyz_lut.p, xyz_lut.data(), xyz_lut.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        a.xyz_lut = pl->xyz_lut.as<uint32_t>();
+    }
+    if (typed) {
         HIP_TRY(pl->gen_type.alloc(gen_type.size()));
         HIP_TRY(hipMemcpy(pl->gen_type.p, gen_type.data(), gen_type.size(), hipMemcpyHostToDevice));
-        a.xyz_lut = pl->xyz_lut.as<uint32_t>();
         a.gen_type = pl->gen_type.as<uint8_t>();
     }
     if (alpha) {

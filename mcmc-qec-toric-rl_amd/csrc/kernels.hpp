@@ -50,6 +50,7 @@ struct LadderArgs {
                               //                    `type` to four sites holding the 2-bit fields of the index
     const uint8_t *gen_type;  // [n_gen]            Pauli-pattern id of every generator
     int n_types;              //                    distinct Pauli patterns among the generators (<= 16)
+    uint8_t type_ops[16];     //                    ... each as four 2-bit Paulis (site 0 in bits 1:0; 0 = no site): the plaquette codes' dE table
     double bias_l2[kMaxNc][2];//                    log2(px / pI), log2(pz / pI) per rung (px = py in both noise models)
     const double *alpha_lnb;  // [Nc-1]             ln(pz_tilde[i] / pz_tilde[i+1]) (alpha noise, mcmc_alpha.py:123)
     double alpha;             //                    mcmc_alpha.py:11
@@ -98,6 +99,7 @@ constexpr uint32_t kMaxGenLds = 2048;   // generator tables up to this many entr
 // (byte offset << 16 | pauli fields | bit shift), the other paths keep the plan's 4 x u16 form.  Up to kGenSplit
 // generators the expanded table is stored as two halves kGenSplit entries apart (sites 0,1 | sites 2,3).
 // alpha noise appends the double-buffered n_eff records [2][Nc][64] to the region
+constexpr int kLutTypes = 8;        // rows of the plaquette codes' dE look-up table (Pauli patterns of their generators; more: no table)
 constexpr int kGenSplit = 255;      // ds_read2_b64's second offset is an 8-bit count of 8-byte units
 // ... and the biased / alpha rules' count-change table uint32[n_types][256] and packed per-state counts uint32[Nc][64]
 // lattice size of a plaquette code from its qubit count (xzzx / rotated: L x L; planar: 2 L^2 with an idle row and column)
@@ -107,7 +109,10 @@ inline int ladder_gen_dwords(int code, int noise, int scan, uint32_t n_gen, int 
     // depolarizing random scan: the expanded table of the non-top proposal loop; the plaquette codes also keep the plan's
     // form for their top-chain / general paths
     const bool wide = !scan;                                   // (biased / alpha kernels: unsplit, next to the plan's form)
-    const int wide_dw = (!noise && (int)n_gen <= kGenSplit) ? 2 * (kGenSplit + (int)n_gen) : 4 * (int)n_gen;
+    // (toric, unsplit: 128 dwords behind the table for the dE look-up table, which the split form keeps between its halves)
+    // (plaquette codes: 256 bytes per Pauli pattern behind their expanded table)
+    const int lut_tail = noise ? 0 : code == 0 ? ((int)n_gen > kGenSplit ? 128 : 0) : 64 * kLutTypes;
+    const int wide_dw = ((!noise && (int)n_gen <= kGenSplit) ? 2 * (kGenSplit + (int)n_gen) : 4 * (int)n_gen) + lut_tail;
     int d = wide ? (code == 0 ? wide_dw : ((2 * (int)n_gen + 3) & ~3) + wide_dw) : 2 * (int)n_gen;
     if (noise == 2) d = ((d + 3) & ~3) + 2 * Nc * 64;
     if (noise) d = ((d + 3) & ~3) + 256 * n_types + Nc * 64 + 2 * (nq_L(code, nq) + 1) * ((nq + 15) / 16);   // + the X / Z logical masks [2][L+1][W]

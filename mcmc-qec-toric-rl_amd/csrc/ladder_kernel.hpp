@@ -229,9 +229,10 @@ __device__ inline bool alpha_series_close(uint64_t z2, uint64_t xy2, uint32_t de
 // p = 0.75; always needed by the plaquette codes and the biased rule).  The common toric configurations compile it out,
 // which keeps its registers out of the hot loop.
 // ALPHA (with BIASED): the alpha noise model's ladder (slot-bound n_eff records, floating-point swap test, mcmc_alpha.py)
-// DELUT (toric, split table with >= 64 idle entries between its halves, i.e. 2 L^2 <= 191): a proposal's dE comes from a
-// 512-byte LDS table indexed by the four old fields and the generator's type instead of seven VALU instructions -- the kernel
-// is bound by VALU issue (98 % busy), the LDS array has room.
+// DELUT (toric; the table sits in the >= 64 idle entries between the halves of a split generator table, 2 L^2 <= 191, or behind
+// an unsplit one, 2 L^2 > 255): a proposal's dE comes from a 512-byte LDS table indexed by the four old fields and the generator's
+// type instead of seven VALU instructions -- where the kernel is bound by VALU issue and the LDS array has room (L = 9: +4 %,
+// L = 15: +3.3 %; L = 10, 11 -- three workgroups per CU, LDS-bound -- measured -1.5 % and keep the popcount).
 // SSW: the swap sweep (mcmc.py:96-103) is run once, by wave 0, on the published records -- the raw swap uniforms against the
 // threshold table -- and its result handed to the other waves through the idle half of the record buffer behind a second
 // barrier, instead of every wave replaying the cascade on acceptance bounds two waves prepared.  Fewer VALU instructions
@@ -264,7 +265,10 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
     constexpr bool kSplitGen = kWideGen && GSPLIT && !BIASED;  // (GSPLIT means something else in the BIASED instantiations)
     constexpr bool kNarrowGen = !kWideGen || CODE != kCodeToric;   // the plan's form: sweep, biased rule, plaquette-code top / general paths
     const int narrow_dw = kNarrowGen ? (kWideGen ? (2 * (int)a.n_gen + 3) & ~3 : 2 * (int)a.n_gen) : 0;
-    const int wide_dw = kWideGen ? (kSplitGen ? 2 * (kGenSplit + (int)a.n_gen) : 4 * (int)a.n_gen) : 0;
+    // toric: 128 dwords behind an unsplit table for the dE look-up table (a split one keeps it in the idle entries between its halves);
+    // plaquette codes: 256 bytes per Pauli pattern of their generators
+    const int lut_tail = (!kWideGen || BIASED) ? 0 : CODE == kCodeToric ? ((int)a.n_gen > kGenSplit ? 128 : 0) : 64 * kLutTypes;
+    const int wide_dw = kWideGen ? (kSplitGen ? 2 * (kGenSplit + (int)a.n_gen) : 4 * (int)a.n_gen) + lut_tail : 0;
     const int gen_dw = narrow_dw + wide_dw;
     constexpr bool alpha_noise = BIASED && ALPHA;               // mcmc_alpha.py: biased rule + slot-bound n_eff swap test
     // biased / alpha rules: the count-change table [n_types][256] and the packed counts of every state [NC][64]
@@ -336,7 +340,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 for (int u = 0; u < 4; ++u) ops |= (uint32_t)(reinterpret_cast<const uint16_t *>(a.gen)[4 * g + u] & 3u) << (2 * u);
             if (BIASED && k == 1) ops = a.gen_type[g];                              // site 1, bits [11:8]: the generator's Pauli-pattern id
             if (!BIASED && CODE == kCodeToric && k == 1) ops = e & 3u;              // toric: site 1, byte 1 = the generator's one Pauli
-            if (DELUT && k == 2) ops = (e & 3u) == 3u;                              // ... site 2, byte 1 = 1 for a Z generator (table half)
+            if (DELUT && k == 2) ops = CODE == kCodeToric ? (e & 3u) == 3u : a.gen_type[g];   // ... site 2, byte 1 = the row of the dE table (toric: 1 for a Z generator)
             (lds + gen_off + narrow_dw)[kSplitGen ? 2 * (g + (k >> 1) * kGenSplit) + (k & 1) : i] =
                 (((q >> 4) * 256u) << 16) | (ops << 8) | ((e & 3u) << 5) | ((q & 15u) * 2u);
         }
@@ -345,13 +349,18 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
         for (int i = tid; i < 2 * (int)a.n_gen; i += nthreads) (lds + gen_off)[i] = reinterpret_cast<const uint32_t *>(a.gen)[i];
     }
     // 4 (dE + 4) for old fields F (bits 0-7) under an X (index bit 8 clear) or Z generator: toric_model.py:275-282 tabulated.
-    // It sits in the idle entries between the two halves of the split generator table.
-    [[maybe_unused]] const uint8_t *delut = reinterpret_cast<const uint8_t *>(gtabw + a.n_gen);
+    // It sits in the idle entries between the two halves of the split generator table, or behind the unsplit one.
+    const int delut_dw = gen_off + narrow_dw + (lut_tail ? wide_dw - lut_tail : 2 * (int)a.n_gen);
+    [[maybe_unused]] const uint8_t *delut = reinterpret_cast<const uint8_t *>(lds + delut_dw);
     if constexpr (DELUT) {
-        for (int i = tid; i < 512; i += nthreads) {
-            const uint32_t F = (uint32_t)i & 0xFFu, G = F ^ ((i & 0x100) ? 0xFFu : 0x55u);
-            const uint32_t v = __popc((G | (G >> 1)) & 0x55u) + __popc(~(F | (F >> 1)) & 0x55u);
-            reinterpret_cast<uint8_t *>(lds + gen_off + narrow_dw + 2 * (int)a.n_gen)[i] = (uint8_t)(4u * v);
+        static_assert(kWideGen && !BIASED, "no room for the dE look-up table in this layout");
+        for (int t = 0; t < (CODE == kCodeToric ? 2 : a.n_types); ++t) {           // one row per Pauli pattern (toric: X, Z)
+            const uint32_t ops = CODE == kCodeToric ? (t ? 0xFFu : 0x55u) : (uint32_t)a.type_ops[t];
+            for (int i = tid; i < 256; i += nthreads) {
+                const uint32_t F = (uint32_t)i, G = F ^ ops;
+                const uint32_t v = __popc((G | (G >> 1)) & 0x55u) + __popc(~(F | (F >> 1)) & 0x55u);
+                reinterpret_cast<uint8_t *>(lds + delut_dw)[256 * t + i] = (uint8_t)(4u * v);
+            }
         }
     }
     for (int i = tid; i < (NC - 1) * kSwapFast; i += nthreads) {
@@ -572,7 +581,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 const uint32_t F = lshl_or(lshl_or(f[3], 2, f[2]), 4, lshl_or(f[1], 2, f[0]));
                 if constexpr (DELUT) {
                     // 4 (dE + 4) from the table; the thresholds' rows and the running count (ni = 4 n) take it as a byte offset
-                    const uint32_t v = delut[(ev.z & 0x100u) | F];
+                    const uint32_t v = delut[(ev.z & 0xF00u) | F];
                     const uint32_t a12 = xw & 0xFFFu, tI = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(myT - 4) + v);
                     bool acc = a12 < tI;                                            // mcmc.py:42 (dE <= 0: tI = 4096)
                     if (a12 == tI) {                                                // rare (a lane in 4096): the next 32 bits decide
@@ -582,7 +591,8 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                     }
                     if (acc) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) lds_xor(ad[i], shl_byte1(sh[i], ev.y));
+                        for (int i = 0; i < 4; ++i)
+                            lds_xor(ad[i], CODE == kCodeToric ? shl_byte1(sh[i], ev.y) : shl_lo5((sh[i] >> 5) & 3u, sh[i]));
                         ni += (int)v - 16;
                     }
                     return;
