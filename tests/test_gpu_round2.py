@@ -271,6 +271,7 @@ def test_work_queue_with_replicas(q, orc, monkeypatch):
 @pytest.mark.parametrize("name,L,Nc,iters,steps,N", [
     ("toric", 15, 8, 10, 30, 70), ("toric", 15, 8, 13, 12, 40), ("toric", 15, 8, 3, 40, 40), ("toric", 15, 8, 1, 50, 20),
     ("toric", 15, 3, 10, 20, 33), ("toric", 15, 15, 10, 12, 20), ("toric", 13, 8, 7, 25, 30), ("toric", 16, 9, 10, 10, 10),
+    ("toric", 15, 8, 30, 8, 20), ("toric", 15, 8, 27, 9, 20),          # more proposals than the 12 two-proposal blocks kept; an odd count
     ("rotated", 21, 8, 10, 20, 40), ("rotated", 21, 3, 5, 20, 20), ("rotated", 21, 12, 10, 8, 10), ("xzzx", 19, 8, 10, 12, 20)])
 def test_top_blocks_drawn_ahead_bit_exact(q, orc, name, L, Nc, iters, steps, N):
     """Shapes whose LDS footprint leaves 4 waves per SIMD take the instantiations in which the wave that will be the top chain
