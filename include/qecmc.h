@@ -154,7 +154,8 @@ int qecmc_chain_update_alpha(int code, int L, uint64_t N, uint8_t *states_inout,
 
 /* Ladder.step(iters) x nsteps, src/mcmc.py:94-103, on N ladders in slot order.
  * states uint8[N][Nc][nq], flags uint8[N][Nc], tops0 uint32[N]; step0 / prop0 =
- * ladder steps / proposals per slot already done (Philox addressing).  Uses
+ * ladder steps / proposals per slot already done (Philox addressing: at ladder step T the top chain draws from
+ * stream Nc-1, the chain on a lower slot c from the "diagonal" stream 0x400 + (c + T) mod Nc).  Uses
  * params->{code,L,Nc,p,p_logical,seed,first_syndrome,device}. */
 int qecmc_ladder_step(const qecmc_params *params, uint64_t N, uint8_t *states_inout, uint8_t *flags_inout,
                       uint32_t *tops0_inout, uint64_t iters, uint64_t nsteps, uint64_t step0, uint64_t prop0);
