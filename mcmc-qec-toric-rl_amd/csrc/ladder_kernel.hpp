@@ -485,7 +485,6 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
 
     constexpr int kPre = 12;                                    // blocks drawn ahead (a step of more proposals draws the rest in place)
     [[maybe_unused]] u32x4 pre[PRE ? kPre : 1];
-    [[maybe_unused]] const uint32_t pre_n = iters < (uint32_t)kPre ? iters : (uint32_t)kPre, pre_h = pre_n / 2;
     // QUEUE: finished lanes take new ladders until the counter runs out; the loop ends by the stop flag.  A new ladder may
     // start only at a step that keeps its four-proposal blocks in phase with the others': t0 * iters = 0 (mod 4).
     [[maybe_unused]] const uint32_t q_period = (iters & 3u) == 0 ? 1u : (iters & 1u) == 0 ? 2u : 4u;
@@ -510,6 +509,36 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
         const bool acc_all = (a.acc_all_mask >> slot_u) & 1u;
         const bool top_logical = (slot_u == (uint32_t)(NC - 1)) && a.thr_logical != 0;
         const uint32_t strm = top_logical ? slot_u : dstrm;                         // Philox stream of this step's proposals (philox.hpp)
+        // The blind top chain's proposals (random scan, p = 0.75): move(A, B) for each proposal of the step, in order.  The step's
+        // proposals [kbase, kbase + iters) lie in blocks b0 .. b0 + nblk - 1, two per block: the first block may start at its
+        // second proposal and the last may end at its first (all wave-uniform).
+        [[maybe_unused]] auto top_blocks = [&](auto &&move) {
+            const uint64_t b0 = (kbase >> 1) - (kq >> 1);                           // (kq is a multiple of 4)
+            const bool skip_first = (kbase & 1) != 0, skip_last = ((kbase + iters) & 1) != 0;
+            const uint32_t nblk = (uint32_t)(((kbase + iters - 1) >> 1) - (kbase >> 1)) + 1u;
+            auto both = [&](const u32x4 &x, uint32_t bi) {
+                if (!(skip_first && bi == 0)) move(x.x, x.y);
+                if (!(skip_last && bi == nblk - 1)) move(x.z, x.w);
+            };
+            uint32_t bi = 0;
+            if constexpr (PRE) {
+                if (t >= 2 && NC >= 3) {                                            // (the first two top steps of a launch had no earlier role)
+                    const uint32_t pn = nblk < (uint32_t)kPre ? nblk : (uint32_t)kPre;
+#pragma unroll
+                    for (int jj = 0; jj < kPre; ++jj)
+                        if ((uint32_t)jj < pn) both(pre[jj], (uint32_t)jj);
+                    bi = pn;
+                }
+            }
+            // two blocks' (four proposals') Philox chains in flight: this wave is the step's longest and often runs alone
+            for (; bi + 1 < nblk; bi += 2) {
+                const u32x4 xa = philox_block(b0 + bi, kSubTopPair, syn, slot_u, a.seed_lo, a.seed_hi);
+                const u32x4 xb = philox_block(b0 + bi + 1, kSubTopPair, syn, slot_u, a.seed_lo, a.seed_hi);
+                both(xa, bi);
+                both(xb, bi + 1);
+            }
+            if (bi < nblk) both(philox_block(b0 + bi, kSubTopPair, syn, slot_u, a.seed_lo, a.seed_hi), bi);
+        };
         const uint32_t *myT = thrT + slot_u * 9 + 4;
         // sweep (scan = 1) of a top chain at f = 1 with table-driven logical masks: used by the plaquette codes and by
         // toric L > 16 (the L <= 16 toric top chain has the frame-based fast path below)
@@ -841,10 +870,10 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 // diagonal Z; rotated -- the set of X columns and of Z rows; planar -- the X rows and Z columns of layer 0.
                 uint32_t cdelta = 0, frX = 0, frZ = 0;
                 const bool framed = L <= 32;                                       // (a row of up to 64 bits: two words)
-                auto top_move = [&](const u32x4 &x) {
-                    if (x.x <= thrL1) {                                             // logical (xzzx_model.py:340-357)
-                        const uint32_t op = x.y >> 30;
-                        const uint32_t xp = ((op ^ (op >> 1)) & 1u) ? scale_low30(x.y, L) : 0u, zp = (op >> 1) ? scale_u16(x.w >> 16, L) : 0u;
+                auto top_move = [&](uint32_t A, uint32_t B) {                       // the packed words (philox.hpp, kSubTopPair)
+                    if (A <= thrA1) {                                               // logical (xzzx_model.py:340-357)
+                        const uint32_t op = (A >> 14) & 3u;
+                        const uint32_t xp = ((op ^ (op >> 1)) & 1u) ? ((A & 0x3FFFu) * (uint32_t)L) >> 14 : 0u, zp = (op >> 1) ? scale_u16(B >> 16, L) : 0u;
                         const uint32_t ax = CODE == kCodeXzzx ? ((op ^ (op >> 1)) & 1u) : (op & 1u), az = op >> 1;
                         if (framed) {
                             frX ^= CODE == kCodeXzzx ? ax : ax << xp;
@@ -865,30 +894,19 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                         }
                         cdelta ^= ax | (az << 1);
                     } else if constexpr (kWideGen) {
-                        const uint4 ev = gen_entry(scale_u32(x.y, a.n_gen));        // word 1 picks the generator; the expanded entry
+                        const uint4 ev = gen_entry(scale_u32(B, a.n_gen));          // word B picks the generator; the expanded entry
                         const uint32_t e4[4] = {ev.x, ev.y, ev.z, ev.w};            // gives address and shift directly (a null site is 0)
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
                             lds_xor(reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(stw) + (e4[i] >> 16)), shl_lo5((e4[i] >> 5) & 3u, e4[i]));
                     } else {
-                        const uint2 e = gtab[scale_u32(x.y, a.n_gen)];              // word 1 picks the generator
+                        const uint2 e = gtab[scale_u32(B, a.n_gen)];                // word B picks the generator
                         const uint32_t ent[4] = {e.x & 0xFFFFu, e.x >> 16, e.y & 0xFFFFu, e.y >> 16};
 #pragma unroll
                         for (int i = 0; i < 4; ++i) lds_xor(stw + (ent[i] >> 6) * 64, (ent[i] & 3u) << (((ent[i] >> 2) & 15u) * 2u));
                     }
                 };
-                {
-                    uint32_t j = 0;
-                    if constexpr (PRE) {
-                        if (t >= 2 && NC >= 3) {                                    // blocks drawn ahead by this wave on slots 1 and 0
-#pragma unroll
-                            for (int jj = 0; jj < kPre; ++jj)
-                                if ((uint32_t)jj < pre_n) top_move(pre[jj]);
-                            j = pre_n;
-                        }
-                    }
-                    for (; j < iters; ++j) top_move(philox_block(kbase - kq + j, 0, syn, strm, a.seed_lo, a.seed_hi));
-                }
+                top_blocks(top_move);
                 uint32_t cnt_n = 0;
                 if (framed && L > 16) {
                     // rows of 34 .. 64 bits (rotated L = 21 is BASELINE config 5's shape): the same stream with two-word patterns
@@ -993,7 +1011,13 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                     // top: block (k, 0) = select, generator / logical fields; non-top: word k&3 of block (k>>2, 1) (+ its refinement)
                     u32x4 x;
                     uint64_t v44 = 0;                                               // non-top: the 44-bit acceptance uniform
-                    if (top) {
+                    // (random scan: the top chain's packed words A, B of block (k >> 1, kSubTopPair), philox.hpp; sweep: block (k, 0))
+                    const bool packed = top && !SCAN;
+                    uint32_t pA = 0, pB = 0;
+                    if (packed) {
+                        x = philox_block(k >> 1, kSubTopPair, syn, strm, a.seed_lo, a.seed_hi);
+                        pA = (k & 1) ? x.z : x.x; pB = (k & 1) ? x.w : x.y;
+                    } else if (top) {
                         x = philox_block(k, 0, syn, strm, a.seed_lo, a.seed_hi);
                     } else {
                         if ((k >> 2) != kb_pair) {
@@ -1004,7 +1028,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                         v44 = (uint64_t)(x.x & 0xFFFu) << 32;                       // ... the low 32 bits are drawn only when they decide
                         x.y = x.z = x.w = 0;
                     }
-                    const bool logical = top && x.x <= thrL1;                       // mcmc.py:23
+                    const bool logical = packed ? pA <= thrA1 : (top && x.x <= thrL1);   // mcmc.py:23
                     int dx = 0, dy = 0, dz = 0;                                    // change of the X / Y / Z counts
                     uint32_t ent[4] = {0, 0, 0, 0}, cd = 0;
                     uint32_t *sad[4] = {stw, stw, stw, stw};                        // a stabilizer's sites: LDS word, bit shift (low 5 bits), Paulis
@@ -1020,9 +1044,11 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                             if (dz1) m3 = lmask + 3 * LW + scale_u16(x.w & 0xFFFFu, L) * W;
                             cd = Lodd ? (dx0 | (dz0 << 1) | (dx1 << 2) | (dz1 << 3)) : 0u;
                         } else {
-                            const uint32_t op = x.y >> 30;                          // xzzx_model.py:346 / rotated_surface_model.py:334
-                            const uint32_t xp = ((op ^ (op >> 1)) & 1u) ? scale_low30(x.y, L) : 0u;   // drawn iff op in {1,2}
-                            const uint32_t zp = (op >> 1) ? scale_u16(x.w >> 16, L) : 0u;             // drawn iff op in {3,2}
+                            const uint32_t op = packed ? (pA >> 14) & 3u : x.y >> 30;   // xzzx_model.py:346 / rotated_surface_model.py:334
+                            const uint32_t xpos = packed ? ((pA & 0x3FFFu) * (uint32_t)L) >> 14 : scale_low30(x.y, L);
+                            const uint32_t zpos = scale_u16((packed ? pB : x.w) >> 16, L);
+                            const uint32_t xp = ((op ^ (op >> 1)) & 1u) ? xpos : 0u;   // drawn iff op in {1,2}
+                            const uint32_t zp = (op >> 1) ? zpos : 0u;                 // drawn iff op in {3,2}
                             // applied operators: xzzx X iff op in {1,2}, Z iff op in {3,2}; rotated X iff op in {1,3}, Z iff op in {2,3}
                             const uint32_t ax = CODE == kCodeXzzx ? ((op ^ (op >> 1)) & 1u) : (op & 1u);
                             const uint32_t az = op >> 1;
@@ -1038,7 +1064,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                             dx -= ox; dy -= oy; dz -= oz;
                         }
                     } else {
-                        const uint32_t wa = top ? x.y : x.x;                        // the generator word
+                        const uint32_t wa = packed ? pB : top ? x.y : x.x;          // the generator word
                         if constexpr (SCAN) {
                             const uint2 e = gtab[gs];
                             ent[0] = e.x & 0xFFFFu; ent[1] = e.x >> 16; ent[2] = e.y & 0xFFFFu; ent[3] = e.y >> 16;
@@ -1208,33 +1234,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                             lds_xor(reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(stw) + (e4[i] >> 16)), shl_lo5(op, e4[i]));
                     }
                 };
-                // the step's proposals [kbase, kbase + iters) lie in blocks b0 .. b0 + nblk - 1, two per block: the first block
-                // may start at its second proposal and the last may end at its first (all wave-uniform)
-                const uint64_t b0 = (kbase >> 1) - (kq >> 1);                       // (kq is a multiple of 4)
-                const bool skip_first = (kbase & 1) != 0, skip_last = ((kbase + iters) & 1) != 0;
-                const uint32_t nblk = (uint32_t)(((kbase + iters - 1) >> 1) - (kbase >> 1)) + 1u;
-                auto both = [&](const u32x4 &x, uint32_t bi) {
-                    if (!(skip_first && bi == 0)) blind(x.x, x.y);
-                    if (!(skip_last && bi == nblk - 1)) blind(x.z, x.w);
-                };
-                uint32_t bi = 0;
-                if constexpr (PRE) {
-                    if (t >= 2 && NC >= 3) {                                        // (the first two top steps of a launch had no earlier role)
-                        const uint32_t pn = nblk < (uint32_t)kPre ? nblk : (uint32_t)kPre;
-#pragma unroll
-                        for (int jj = 0; jj < kPre; ++jj)
-                            if ((uint32_t)jj < pn) both(pre[jj], (uint32_t)jj);
-                        bi = pn;
-                    }
-                }
-                // two blocks' (four proposals') Philox chains in flight: this wave is the step's longest and often runs alone
-                for (; bi + 1 < nblk; bi += 2) {
-                    const u32x4 xa = philox_block(b0 + bi, kSubTopPair, syn, strm, a.seed_lo, a.seed_hi);
-                    const u32x4 xb = philox_block(b0 + bi + 1, kSubTopPair, syn, strm, a.seed_lo, a.seed_hi);
-                    both(xa, bi);
-                    both(xb, bi + 1);
-                }
-                if (bi < nblk) both(philox_block(b0 + bi, kSubTopPair, syn, strm, a.seed_lo, a.seed_hi), bi);
+                top_blocks(blind);
             }
             // flush the frame: lattice row r of layer l is the 2L-bit span at bit 2*(l*LL + r*L)
             {
@@ -1355,20 +1355,14 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             // step's top-chain blocks (state-independent: block (proposal index, 0) of the top slot's stream) while the others finish
             if (NC >= 3 && slot_u <= 1u && a.thr_logical != 0) {
                 const uint64_t kb1 = a.prop0 + (t + 1 + slot_u) * iters;
-                if constexpr (CODE == kCodeToric) {
-                    // toric: the packed blocks (two proposals each) of that step, the first kPre of them
+                {
+                    // the packed blocks (two proposals each) of that step, the first kPre of them
                     const uint32_t nb = (uint32_t)(((kb1 + iters - 1) >> 1) - (kb1 >> 1)) + 1u, pn = nb < (uint32_t)kPre ? nb : (uint32_t)kPre, ph = pn / 2;
 #pragma unroll
                     for (int jj = 0; jj < kPre; ++jj) {
                         const bool mine = slot_u == 1u ? (uint32_t)jj < ph : ((uint32_t)jj >= ph && (uint32_t)jj < pn);
                         if (mine) pre[jj] = philox_block((kb1 >> 1) + jj, kSubTopPair, syn, (uint32_t)(NC - 1), a.seed_lo, a.seed_hi);
                     }
-                } else {
-#pragma unroll
-                for (int jj = 0; jj < kPre; ++jj) {
-                    const bool mine = slot_u == 1u ? (uint32_t)jj < pre_h : ((uint32_t)jj >= pre_h && (uint32_t)jj < pre_n);
-                    if (mine) pre[jj] = philox_block(kb1 + jj, 0, syn, (uint32_t)(NC - 1), a.seed_lo, a.seed_hi);
-                }
                 }
             }
         }

@@ -63,10 +63,12 @@ __host__ __device__ __forceinline__ uint32_t scale_u16(uint32_t h, uint32_t n) {
 // w = word k&3 of block (k>>2, kSubRefine).  accept iff that integer < T44 = ceil(v * 2^44):  a12 < T44>>32, or equal and
 // w < (uint32_t)T44 -- the second word is needed once in 4096 proposals.
 constexpr uint32_t kSubRefine = 4u;
-// The toric depolarizing top chain (random scan) spends TWO words per proposal, so one block feeds two proposals: proposal k
-// owns words A, B = 2 (k & 1), 2 (k & 1) + 1 of block (k >> 1, kSubTopPair).
-//   A = select[31:16] | op0[15:14] | op1[13:12] | X_pos0[11:0]        logical iff A[31:16] < ceil(p_logical * 2^16)
-//   B = the generator word (g = floor(B * 2 L^2 / 2^32)), or for a logical  Z_pos0[31:21] | X_pos1[20:10] | Z_pos1[9:0]
+// The depolarizing top chain (random scan) spends TWO words per proposal, so one block feeds two proposals: proposal k
+// owns words A, B = 2 (k & 1), 2 (k & 1) + 1 of block (k >> 1, kSubTopPair); logical iff A[31:16] < ceil(p_logical * 2^16).
+//   toric:      A = select[31:16] | op0[15:14] | op1[13:12] | X_pos0[11:0]
+//               B = the generator word (g = floor(B * 2 L^2 / 2^32)), or for a logical  Z_pos0[31:21] | X_pos1[20:10] | Z_pos1[9:0]
+//   plaquette:  A = select[31:16] | op[15:14] | X_pos[13:0];   B = the generator word, or for a logical  Z_pos = B[31:16]
+// (pos = (field * L) >> bits)
 constexpr uint32_t kSubTopPair = 5u;
 // Chains updated by the non-top rule (mcmc.py:37-43) draw from the DIAGONAL streams: the chain on slot c at ladder step T uses
 // stream kDiagStream + (c + T) mod Nc.  Roles rotate downwards in the kernel (a wave works on slot (w - T) mod Nc), so a wave

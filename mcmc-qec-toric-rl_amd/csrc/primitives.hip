@@ -110,8 +110,8 @@ __global__ void k_chain_update(const ChainArgs a)
         const uint64_t k = a.k0 + j;
         // top: block (k, 0).  non-top: ONE word, word k&3 of block (k>>2, 1) -- top 20 bits pick the generator, low 12 bits
         // lead the 44-bit acceptance uniform that word k&3 of block (k>>2, kSubRefine) completes
-        // (the toric depolarizing top chain packs two proposals into block (k >> 1, kSubTopPair): words A, B = 2 (k & 1), 2 (k & 1) + 1)
-        const bool packed = top && code == kCodeToric && !a.noise;
+        // (the depolarizing top chain packs two proposals into block (k >> 1, kSubTopPair): words A, B = 2 (k & 1), 2 (k & 1) + 1)
+        const bool packed = top && !a.noise;
         u32x4 x = philox_block(packed ? k >> 1 : top ? k : k >> 2, packed ? kSubTopPair : top ? 0u : 1u, syn, a.slot, a.seed_lo, a.seed_hi);
         const uint32_t pA = (k & 1) ? x.z : x.x, pB = (k & 1) ? x.w : x.y;
         uint64_t v44 = 0;
@@ -126,7 +126,13 @@ __global__ void k_chain_update(const ChainArgs a)
         const bool logical = packed ? (uint64_t)(pA >> 16) < ((a.thr_logical + 65535u) >> 16)    // a 16-bit select: A[31:16] < ceil(p_logical * 2^16)
                                     : top && (uint64_t)x.x < a.thr_logical;        // mcmc.py:23
         if (logical) {
-            if (packed) {
+            if (packed && code != kCodeToric) {
+                // A = select[31:16] | op[15:14] | X_pos[13:0];  Z_pos = B[31:16]
+                op0 = (pA >> 14) & 3u;                                              // xzzx_model.py:346-355
+                if (op0 == 1 || op0 == 2) x0 = ((pA & 0x3FFFu) * (uint32_t)L) >> 14;
+                if (op0 == 3 || op0 == 2) z0 = scale_u16(pB >> 16, L);
+                dE = surf_apply_logical_b(code, L, m, op0, x0, z0);
+            } else if (packed) {
                 // A = select[31:16] | op0[15:14] | op1[13:12] | X_pos0[11:0];  B = Z_pos0[31:21] | X_pos1[20:10] | Z_pos1[9:0]
                 op0 = (pA >> 14) & 3u; op1 = (pA >> 12) & 3u;                       // toric_model.py:234
                 if (op0 == 1 || op0 == 2) x0 = ((pA & 0xFFFu) * (uint32_t)L) >> 12; // :241-248
@@ -153,7 +159,7 @@ __global__ void k_chain_update(const ChainArgs a)
             row = rc / L; col = rc % L; op = g < (uint32_t)(L * L) ? 1 : 3;
             dE = toric_apply_stabilizer_b(L, m, row, col, op);
         } else {
-            surf_pick(code, L, top ? x.y : x.x, top, row, col, op);
+            surf_pick(code, L, packed ? pB : top ? x.y : x.x, top, row, col, op);
             dE = surf_apply_stabilizer_b(code, L, m, row, col, op);
         }
         // ---- accept?

@@ -243,7 +243,7 @@ int orc_eq_class(int code, int L, const uint8_t *m)
  * word k&3 of the refinement block (k>>2, sub 4): u = (a12 * 2^32 + w) * 2^-44.  (The refinement word matters only when
  * the 12 leading bits do not decide the comparison, once in 4096 proposals; the GPU computes it on demand.)
  * Top chains (mcmc.py:21-35) keep block (k, 0): word 0 selects logical / stabilizer, word 1 picks the generator, words
- * 1-3 carry a logical operator; the acceptance uniform is word 0 of block (k, 2).  The toric depolarizing top chain in
+ * 1-3 carry a logical operator; the acceptance uniform is word 0 of block (k, 2).  The depolarizing top chain in
  * random scan -- whose proposals need no more than two words -- shares a block between two proposals instead: words
  * A, B = 2 (k & 1), 2 (k & 1) + 1 of block (k >> 1, sub 5); A[31:16] selects, B picks the generator, and a logical
  * operator's fields are cut from A[15:0] and B (model_random_logical_ex). */
@@ -273,7 +273,7 @@ static int model_random_stabilizer(const orc_model *m, const uint8_t *in, uint8_
     int g = -1;
     if (rng->mode != 0) {
         /* non-top: the top 20 bits of the proposal's word, g = floor(x20 * G / 2^20); top chain: word 1 of its block */
-        /* (w0 == 2: the toric top chain's packed layout -- two proposals per block (k >> 1, 5), the generator from the second word) */
+        /* (w0 == 2: the top chain's packed layout -- two proposals per block (k >> 1, 5), the generator from the second word) */
         const double u = w0 == 0 ? orc_draw_field(rng, slot, k >> 2, 1, (int)(k & 3), 0, 20)
                        : w0 == 2 ? orc_draw(rng, slot, k >> 1, 5, 2 * (int)(k & 1) + 1) : orc_draw(rng, slot, k, 0, 1);
         g = (int)(u * G);
@@ -355,6 +355,15 @@ static int model_random_logical_ex(const orc_model *m, const uint8_t *in, uint8_
             dE += orc_toric_apply_logical(L, out, out, op, layer, xpos, zpos);
         }
         return dE;
+    }
+    if (packed) {
+        /* plaquette codes, random-scan depolarizing top chain: A = select[31:16] | op[15:14] | X_pos[13:0], Z_pos = B[31:16] */
+        const uint64_t kb = k >> 1;
+        const int wa = 2 * (int)(k & 1), wb = wa + 1;
+        int op = (int)(orc_draw_field(rng, slot, kb, 5, wa, 16, 2) * 4), xpos = 0, zpos = 0;
+        if (op == 1 || op == 2) xpos = (int)(orc_draw_field(rng, slot, kb, 5, wa, 18, 14) * L);
+        if (op == 3 || op == 2) zpos = (int)(orc_draw_field(rng, slot, kb, 5, wb, 0, 16) * L);
+        return orc_surf_apply_logical(m->code, L, in, out, op, xpos, zpos);
     }
     int op = (int)(orc_draw(rng, slot, k, 0, 1) * 4), xpos = 0, zpos = 0;
     if (op == 1 || op == 2) xpos = (int)(orc_draw_field(rng, slot, k, 0, 1, 2, 30) * L);
@@ -540,8 +549,8 @@ void orc_chain_update(const orc_model *m, uint8_t *state, double p, double p_log
         for (uint64_t j = 0; j < iters; ++j) {
             uint64_t k = k0 + j;
             int dE;
-            /* toric: the packed layout (two proposals per block): the select is a 16-bit uniform, A[31:16] */
-            const int packed = m->code == ORC_TORIC;
+            /* the packed layout (two proposals per block): the select is a 16-bit uniform, A[31:16] */
+            const int packed = 1;
             const double usel = packed ? orc_draw_field(rng, slot, k >> 1, 5, 2 * (int)(k & 1), 0, 16) : orc_draw(rng, slot, k, 0, 0);
             if (usel < p_logical)                                  /* mcmc.py:23 */
                 dE = model_random_logical_ex(m, state, scratch, rng, slot, k, packed);

@@ -94,10 +94,16 @@ def test_philox_generator_pick_is_uniform_over_generators(code, L, G, top):
     rng = orc.Rng.philox(77, 5)
     for k in range(n):
         m = orc.chain_update(cid, zero, 0.75, 1e-300 if top else 0.0, 1, rng, slot=3, k0=k)   # tiny p_logical: top-branch addressing
-        if top and code == "toric" and (np.count_nonzero(m[0]), np.count_nonzero(m[1])) != (2, 2):   # a generator: two qubits per layer
-            continue          # the packed toric top layout has a 16-bit select: a logical operator comes up once in 2^16 proposals
-        assert np.count_nonzero(m) in (2, 3, 4)
         seen[m.tobytes()] = seen.get(m.tobytes(), 0) + 1
+    if top:
+        # the top chain's packed layout has a 16-bit select: with p_logical -> 0 a logical operator still comes up once in 2^16
+        # proposals (0.2 expected here); such a state is seen once or twice, a generator ~400 times
+        rare = [k for k, v in seen.items() if v < 20]
+        assert len(rare) <= 2
+        for k in rare:
+            del seen[k]
+    for k in seen:
+        assert np.count_nonzero(np.frombuffer(k, np.uint8)) in (2, 3, 4)
     assert len(seen) == G
     cnt = np.array(list(seen.values()), dtype=np.float64)
     chi2 = np.sum((cnt - n / G) ** 2 / (n / G))
