@@ -1008,7 +1008,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 uint64_t kb_pair = ~0ull;
                 for (uint32_t j = 0; j < iters; ++j, gs = gs + 1 == a.n_gen ? 0u : gs + 1) {
                     const uint64_t k = kbase + j;
-                    // top: block (k, 0) = select, generator / logical fields; non-top: word k&3 of block (k>>2, 1) (+ its refinement)
+                    // non-top: word k&3 of block (k>>2, 1) (+ its refinement); top:
                     u32x4 x;
                     uint64_t v44 = 0;                                               // non-top: the 44-bit acceptance uniform
                     // (random scan: the top chain's packed words A, B of block (k >> 1, kSubTopPair), philox.hpp; sweep: block (k, 0))
@@ -1352,7 +1352,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
         cur[slot_u * 64] = pack_info(n, sid, cls, flag);
         if constexpr (PRE) {
             // the wave on slot 1 becomes the top chain two steps from now, the wave on slot 0 next step: each draws half of that
-            // step's top-chain blocks (state-independent: block (proposal index, 0) of the top slot's stream) while the others finish
+            // step's top-chain blocks (state-independent: the packed blocks of the top slot's stream) while the others finish
             if (NC >= 3 && slot_u <= 1u && a.thr_logical != 0) {
                 const uint64_t kb1 = a.prop0 + (t + 1 + slot_u) * iters;
                 {

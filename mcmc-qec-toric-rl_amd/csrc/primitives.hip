@@ -108,7 +108,7 @@ __global__ void k_chain_update(const ChainArgs a)
     bool any_acc = false;
     for (uint64_t j = 0; j < a.iters; ++j) {
         const uint64_t k = a.k0 + j;
-        // top: block (k, 0).  non-top: ONE word, word k&3 of block (k>>2, 1) -- top 20 bits pick the generator, low 12 bits
+        // top: block (k, 0) under the biased rules, the packed block (k >> 1, kSubTopPair) otherwise.  non-top: ONE word, word k&3 of block (k>>2, 1) -- top 20 bits pick the generator, low 12 bits
         // lead the 44-bit acceptance uniform that word k&3 of block (k>>2, kSubRefine) completes
         // (the depolarizing top chain packs two proposals into block (k >> 1, kSubTopPair): words A, B = 2 (k & 1), 2 (k & 1) + 1)
         const bool packed = top && !a.noise;
