@@ -2,12 +2,10 @@ b() { tag=$1; shift; timeout -k 10 200 python bench.py --no-cpu-baseline --steps
 import json,sys; d=json.loads(sys.stdin.read()); print('$tag', '%.3e prop/s' % d['proposals_per_s'], 'frac %.3f' % d['roofline']['frac'], '%.2f ms' % d['kernel_ms_per_launch'])"; }
 mkdir -p gpurun_out
 python -m pytest tests -m gpu -q > gpurun_out/gpu_tests.log 2>&1; echo "tests rc=$?"; tail -5 gpurun_out/gpu_tests.log
-b cfg5 --config 5
-b cfg5 --config 5
-b xzzx9 --code xzzx --L 9
-b rot9 --code rotated --L 9 --p 0.17
-b planar9 --code planar --L 9
-b rot13 --code rotated --L 13 --p 0.17
-b xzzx15 --code xzzx --L 15
-b cfg2 --config 2
-b cfg3 --config 3
+b cfg4 --config 4
+b cfg4 --config 4
+b xzzx5b --code xzzx --L 5 --eta 100
+b rot9b --code rotated --L 9 --eta 10 --p 0.17
+b xzzx13b --code xzzx --L 13 --eta 100
+python bench.py --config 4 --steps 2 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('cfg4 histogram_match', d.get('histogram_match'))"
