@@ -372,12 +372,11 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
         for (int i = tid; i < 256 * a.n_types; i += nthreads) xlut[i] = a.xyz_lut[i];
         for (int i = tid; i < lm_dw; i += nthreads) lml[i] = a.lmask[i];              // kinds 0 (X) and 1 (Z) are the first two tables
         if (CODE == kCodeXzzx && L >= 3) {
-            __syncthreads();
-            uint32_t v = 0;
-            const int c = tid / W, w = tid - c * W;                                  // product c = ax | az << 1, word w
-            if (tid < 4 * W) v = ((c & 1) ? a.lmask[w] : 0u) ^ ((c & 2) ? a.lmask[(L + 1) * W + w] : 0u);
-            __syncthreads();
-            if (tid < 4 * W) lml[c * W + w] = v;
+            __syncthreads();                                                         // (rows 0 .. 3 of the copy above are replaced)
+            for (int i = tid; i < 4 * W; i += nthreads) {                            // (a 1-rung ladder has 64 threads: 4 W can exceed them)
+                const int c = i / W, w = i - c * W;                                  // product c = ax | az << 1, word w
+                lml[i] = ((c & 1) ? a.lmask[w] : 0u) ^ ((c & 2) ? a.lmask[(L + 1) * W + w] : 0u);
+            }
         }
     }
     if (tid < NC * 9) {

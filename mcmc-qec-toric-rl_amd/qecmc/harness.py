@@ -342,7 +342,7 @@ class LadderRun:
         self.first = int(first_syndrome)
         dev = torch.device("cuda", device)
         st = np.broadcast_to(a.reshape(self.N, 1, nq), (self.N, self.Nc, nq))            # Ladder.__init__, mcmc.py:72
-        self.states = torch.from_numpy(np.ascontiguousarray(st)).to(dev)
+        self.states = torch.from_numpy(np.array(st, order="C")).to(dev)                  # (a writable copy of the broadcast view)
         fl = np.zeros((self.N, self.Nc), dtype=np.uint8); fl[:, -1] = 1                    # mcmc.py:75
         self.flags = torch.from_numpy(fl).to(dev)
         self.tops0 = torch.zeros(self.N, dtype=torch.int32, device=dev)

@@ -41,7 +41,11 @@ def draw_case(rng):
     N = int(rng.choice([1, 7, 33, 64, 65, 100, 130]))
     N = max(1, min(N, int(2e8 // (work * steps)) + 1))
     p = float(rng.choice([0.05, 0.1, 0.15, 0.18, 0.3]))
-    return dict(code=code, L=L, Nc=Nc, noise=noise, scan=scan, conv=conv, iters=iters, steps=steps, N=N, p=p,
+    # runs that stop by the criterion: a persistent grid of one or two workgroups makes finished lanes take new ladders from the
+    # queue; fixed-length random-scan runs: sometimes cut into chunks continued from device-resident state (harness.LadderRun)
+    grid = str(rng.choice(["", "1", "2"])) if conv else ""
+    chunks = noise != "alpha" and scan == "random" and not conv and rng.random() < 0.25
+    return dict(code=code, L=L, Nc=Nc, noise=noise, scan=scan, conv=conv, iters=iters, steps=steps, N=N, p=p, grid=grid, chunks=bool(chunks),
                 tops_burn=int(rng.choice([0, 1, 2])), seed=int(rng.integers(1, 1 << 30)), first=int(rng.integers(0, 1000)),
                 eta=float(rng.choice([3.0, 10.0, 100.0])), alpha=float(rng.choice([1.3, 2.0, 3.1])))
 
@@ -65,7 +69,23 @@ def run_case(c, rng):
     elif c["noise"] == "alpha":
         gk["alpha"] = c["alpha"]; ok.update(noise=orc.ALPHA, alpha=c["alpha"], det_pow=1)
     steps = ok.pop("steps")
-    got = q.pteq_batch(init, p, **gk)
+    if c["grid"]:
+        os.environ["QECMC_QUEUE_GRID"] = c["grid"]
+    else:
+        os.environ.pop("QECMC_QUEUE_GRID", None)
+    if c["chunks"]:
+        from qecmc import harness
+        run = harness.LadderRun(init, p, Nc=c["Nc"], iters=c["iters"], tops_burn=c["tops_burn"], seed=c["seed"], first_syndrome=c["first"],
+                                code=qcode, eta=c["eta"] if c["noise"] == "biased" else None)
+        left = steps
+        while left > 0:
+            n = int(min(left, rng.integers(1, max(2, steps // 2 + 1))))
+            run.advance(n); left -= n
+        got = run.snapshot(states=True)
+        got["steps_done"] = np.full(c["N"], steps); got["converged"] = np.zeros(c["N"], bool)
+        run.close()
+    else:
+        got = q.pteq_batch(init, p, **gk)
     ref = orc.pteq_batch(ocode, init, p, c["Nc"], steps, **ok)
     bad = []
     for key in ("counts", "samples", "tops0", "steps_done", "converged"):
@@ -96,7 +116,8 @@ def main():
             print("MISMATCH", c, bad, flush=True)
         if bad is not None:
             done += 1
-            k = "%s/%s/%s%s" % (c["code"], c["noise"], c["scan"], "/conv" if c["conv"] else "")
+            k = "%s/%s/%s%s%s%s" % (c["code"], c["noise"], c["scan"], "/conv" if c["conv"] else "", "/queue-grid-" + c["grid"] if c["grid"] else "",
+                                    "/chunked" if c["chunks"] else "")
             kinds[k] = kinds.get(k, 0) + 1
         if i % 20 == 19:
             print("%d cases, %d compared, %d failures, %.0f s" % (i + 1, done, len(failures), time.time() - t0), flush=True)

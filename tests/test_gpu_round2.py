@@ -352,3 +352,23 @@ def test_generate_syndromes_validation_and_harness(q):
     assert a["success"].mean() > 0.9
     b = harness.generate(params, 100, seed=3, steps=3000, conv_criteria=None, tops_burn=0, device_generation=True, first_syndrome=100)
     assert np.array_equal(b["qubit_matrix"], a["qubit_matrix"][100:]) and np.array_equal(b["counts"], a["counts"][100:])
+
+
+# ------------------------------------------------------------------ regressions found by tests/fuzz_gpu.py
+@pytest.mark.parametrize("L,Nc,noise", [(17, 1, "alpha"), (17, 1, "biased"), (21, 1, "biased"), (21, 2, "alpha"), (19, 3, "biased")])
+def test_xzzx_logical_product_rows_small_workgroups(q, orc, L, Nc, noise):
+    """The biased / alpha kernels keep the xzzx code's four logical-operator products (I, X, Z, XZ) as 4 W mask words in LDS.  A
+    1-rung ladder has 64 threads, fewer than 4 W from L = 17 on: the rows must be filled by a strided loop (found by the
+    randomised sweep: xzzx L = 17, Nc = 1, alpha noise)."""
+    rng = np.random.default_rng(L + Nc)
+    init = rand_plaq(rng, 70, L, 0.2)
+    kw = dict(steps=120, iters=10, tops_burn=0, seed=661175579, first_syndrome=484)
+    if noise == "alpha":
+        got = q.pteq_batch(init, 0.3, Nc=Nc, code=q.XZZX, alpha=1.3, return_states=True, **kw)
+        ref = orc.pteq_batch(orc.XZZX, init, 0.3, Nc, kw["steps"], iters=10, tops_burn=0, seed=kw["seed"], first_syndrome=484,
+                             noise=orc.ALPHA, alpha=1.3, det_pow=1, return_states=True)
+    else:
+        got = q.pteq_batch(init, 0.15, Nc=Nc, code=q.XZZX, eta=10.0, return_states=True, **kw)
+        ref = orc.pteq_batch(orc.XZZX, init, 0.15, Nc, kw["steps"], iters=10, tops_burn=0, seed=kw["seed"], first_syndrome=484,
+                             noise=orc.BIASED, eta=10.0, return_states=True)
+    assert np.array_equal(got["states"], ref["states"]) and np.array_equal(got["counts"], ref["counts"])
