@@ -3,7 +3,8 @@ configurations at random -- code, lattice size, number of rungs, proposals per s
 convergence criterion, batch sizes that leave ragged workgroups -- runs `pteq_batch` on the GPU and the CPU oracle on the same
 Philox streams, and demands identical class counts, sample counts, tops0, stopping steps and (fixed-length runs) final states
 of every rung.  The oracle is the checker here, as in tests/ proper; nothing under oracle/ is on the product path.
-Writes gpurun_out/fuzz_<seed>.json."""
+Writes gpurun_out/fuzz_<seed>.json.  `python tests/fuzz_gpu.py other [cases] [seed]` does the same for the other entry points
+(chain updates, Ladder.step in chunks, the unique-chain estimators' ptdc_batch).""" 
 import json
 import os
 import sys
@@ -56,6 +57,8 @@ def run_case(c, rng):
     init = np.zeros(shape, np.uint8)
     err = rng.random(shape) < c["p"]
     init[err] = rng.integers(1, 4, size=int(err.sum()), dtype=np.uint8)
+    if code == "planar":
+        init[:, 1, -1, :] = 0; init[:, 1, :, -1] = 0                       # (the idle row and column of layer 1)
     qcode = {"toric": q.TORIC, "xzzx": q.XZZX, "rotated": q.ROTATED, "planar": q.PLANAR}[code]
     ocode = {"toric": orc.TORIC, "xzzx": orc.XZZX, "rotated": orc.ROTATED, "planar": orc.PLANAR}[code]
     kw = dict(steps=c["steps"], iters=c["iters"], tops_burn=c["tops_burn"], seed=c["seed"], first_syndrome=c["first"])
@@ -96,7 +99,104 @@ def run_case(c, rng):
     return bad
 
 
+def run_other(rng):
+    """The other entry points: Chain.update_chain / Chain_biased (one chain, caller's stream and proposal index), Ladder.step in
+    chunks, and the unique-chain estimators' fused sampling + set-insertion launches (ptdc_batch: PTDC / STDC / PTRC / STRC)."""
+    kind = str(rng.choice(["chain", "chain", "ladder", "ptdc"]))
+    name = str(rng.choice(["toric", "xzzx", "rotated", "planar"]))
+    L = int(rng.choice([3, 4, 5, 7, 9] if name in ("toric", "planar") else [3, 5, 7, 9, 13]))
+    cls = {"toric": q.Toric_code, "xzzx": q.xzzx_code, "rotated": q.RotSurCode, "planar": q.Planar_code}[name]
+    ocode = {"toric": orc.TORIC, "xzzx": orc.XZZX, "rotated": orc.ROTATED, "planar": orc.PLANAR}[name]
+    qcode = {"toric": q.TORIC, "xzzx": q.XZZX, "rotated": q.ROTATED, "planar": q.PLANAR}[name]
+    shape = (2, L, L) if name in ("toric", "planar") else (L, L)
+    m = (rng.integers(1, 4, size=shape) * (rng.random(shape) < 0.15)).astype(np.uint8)
+    if name == "planar":
+        m[1, -1, :] = 0; m[1, :, -1] = 0                                    # (the idle row and column of layer 1)
+    seed, stream = int(rng.integers(1, 1 << 40)), int(rng.integers(0, 50))
+    p = float(rng.choice([0.05, 0.12, 0.2, 0.4, 0.75]))
+    desc = dict(kind=kind, code=name, L=L, p=p, seed=seed, stream=stream)
+    if kind == "chain":
+        eta = float(rng.choice([3.0, 100.0])) if (name in ("xzzx", "rotated") and rng.random() < 0.4) else None
+        p_logical = float(rng.choice([0.0, 0.0, 0.25, 0.5, 1.0]))
+        iters, slot, k0 = int(rng.integers(1, 600)), int(rng.integers(0, 16)), int(rng.integers(0, 100000))
+        desc.update(eta=eta, p_logical=p_logical, iters=iters, slot=slot, k0=k0)
+        code = cls(L); code.qubit_matrix = m.copy()
+        ch = q.Chain(p, code, seed=seed, stream=stream) if eta is None else q.Chain_biased(min(p, 0.4), eta, code, seed=seed, stream=stream)
+        ch.p_logical, ch.slot, ch.proposals_done = p_logical, slot, k0
+        ch.update_chain(iters)
+        ref = orc.chain_update(ocode, m, p if eta is None else min(p, 0.4), p_logical, iters, orc.Rng.philox(seed, stream), slot=slot, k0=k0,
+                               noise=0 if eta is None else 1, eta=eta or 0.0)
+        return desc, ([] if np.array_equal(ch.code.qubit_matrix, ref) else ["state"])
+    if kind == "ladder":
+        Nc, iters = int(rng.choice([1, 2, 3, 5, 8, 16])), int(rng.choice([1, 3, 5, 10, 13]))
+        pb = min(p, 0.3)
+        desc.update(Nc=Nc, iters=iters, p=pb)
+        code = cls(L); code.qubit_matrix = m.copy()
+        ld = q.Ladder(pb, code, Nc, 0.5, seed=seed, stream=stream)
+        ref = orc.Ladder(ocode, m, pb, Nc, 0.5)
+        r = orc.Rng.philox(seed, stream)
+        bad = []
+        for chunk in (1, int(rng.integers(1, 5)), int(rng.integers(1, 30))):
+            ld.step(iters, nsteps=chunk)
+            for _ in range(chunk):
+                ref.step(iters, r)
+            got = np.stack([c.code.qubit_matrix for c in ld.chains])
+            if not np.array_equal(got, ref.states) or [c.flag for c in ld.chains] != ref.flags.tolist() or ld.tops0 != ref.tops0:
+                bad.append("ladder state")
+                break
+        return desc, bad
+    # ptdc: class representatives as the seeds, one row of 16 / 4 per syndrome
+    if name in ("xzzx", "rotated"):
+        name, L = "toric", int(rng.choice([3, 4, 5]))
+        ocode, qcode, shape = orc.TORIC, q.TORIC, (2, L, L)
+        m = (rng.integers(1, 4, size=shape) * (rng.random(shape) < 0.15)).astype(np.uint8)
+    ncls = 16 if name == "toric" else 4
+    Nc, droplets, N = int(rng.choice([1, 1, 3, 4])), int(rng.integers(1, 4)), int(rng.integers(1, 4))
+    steps, iters = int(rng.integers(20, 300)), (5 if Nc == 1 else 10)
+    per_rung = bool(Nc > 1 and rng.random() < 0.3)
+    desc.update(code=name, L=L, Nc=Nc, droplets=droplets, N=N, steps=steps, per_rung=per_rung, p=min(p, 0.3))
+    if name == "toric":
+        reps = np.stack([q.toric_model.to_class(m, e) for e in range(16)])
+    else:
+        from qecmc import planar_model as pm
+        reps = np.stack([pm.apply_logical(m, op, 0, 0)[0] for op in range(4)])
+    init = np.stack([reps] * N)
+    kw = dict(steps=steps, droplets=droplets, iters=iters, seed=seed & 0xFFFFFFFF, first_syndrome=stream, with_m=True, per_rung=per_rung)
+    got_n, got_m = q.ptdc_batch(init, min(p, 0.3), Nc=Nc, code=qcode, **kw)
+    ref_n, ref_m = orc.ptdc_batch(ocode, init, min(p, 0.3), Nc, kw.pop("steps"), **kw)
+    bad = ([] if np.array_equal(got_n, ref_n) else ["N(n)"]) + ([] if np.array_equal(got_m, ref_m) else ["m(n)"])
+    return desc, bad
+
+
+def main_other(cases, seed):
+    rng = np.random.default_rng(seed)
+    t0 = time.time()
+    failures, kinds = [], {}
+    for i in range(cases):
+        try:
+            desc, bad = run_other(rng)
+        except q.QecmcError as e:
+            kinds["refused"] = kinds.get("refused", 0) + 1
+            print("refused:", e, flush=True)
+            continue
+        kinds[desc["kind"] + "/" + desc["code"]] = kinds.get(desc["kind"] + "/" + desc["code"], 0) + 1
+        if bad:
+            failures.append(dict(case=desc, differs=bad))
+            print("MISMATCH", desc, bad, flush=True)
+        if i % 50 == 49:
+            print("%d cases, %d failures, %.0f s" % (i + 1, len(failures), time.time() - t0), flush=True)
+    out = dict(mode="other", seed=seed, cases=cases, compared=sum(v for k, v in kinds.items() if k != "refused"), failures=failures, kinds=kinds,
+               seconds=time.time() - t0)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "fuzz_other_%d.json" % seed), "w"), indent=1)
+    print(json.dumps({k: v for k, v in out.items() if k != "failures"}))
+    print("FAILURES: %d" % len(failures))
+    return 1 if failures else 0
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "other":
+        return main_other(int(sys.argv[2]) if len(sys.argv) > 2 else 300, int(sys.argv[3]) if len(sys.argv) > 3 else 1)
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
