@@ -46,7 +46,11 @@ def draw_case(rng):
     # queue; fixed-length random-scan runs: sometimes cut into chunks continued from device-resident state (harness.LadderRun)
     grid = str(rng.choice(["", "1", "2"])) if conv else ""
     chunks = noise != "alpha" and scan == "random" and not conv and rng.random() < 0.25
-    return dict(code=code, L=L, Nc=Nc, noise=noise, scan=scan, conv=conv, iters=iters, steps=steps, N=N, p=p, grid=grid, chunks=bool(chunks),
+    # replica ladders (R per syndrome, results summed on the device) in some of the one-launch fixed-length runs
+    R = int(rng.choice([2, 3, 5])) if (not conv and not chunks and noise != "alpha" and rng.random() < 0.2) else 1
+    if R > 1:
+        N = max(1, N // R)
+    return dict(code=code, L=L, Nc=Nc, noise=noise, scan=scan, conv=conv, iters=iters, steps=steps, N=N, p=p, grid=grid, chunks=bool(chunks), R=R,
                 tops_burn=int(rng.choice([0, 1, 2])), seed=int(rng.integers(1, 1 << 30)), first=int(rng.integers(0, 1000)),
                 eta=float(rng.choice([3.0, 10.0, 100.0])), alpha=float(rng.choice([1.3, 2.0, 3.1])))
 
@@ -88,8 +92,13 @@ def run_case(c, rng):
         got["steps_done"] = np.full(c["N"], steps); got["converged"] = np.zeros(c["N"], bool)
         run.close()
     else:
-        got = q.pteq_batch(init, p, **gk)
-    ref = orc.pteq_batch(ocode, init, p, c["Nc"], steps, **ok)
+        got = q.pteq_batch(init, p, **gk, **({"replicas": c["R"]} if c["R"] > 1 else {}))
+    ref = orc.pteq_batch(ocode, np.repeat(init, c["R"], axis=0), p, c["Nc"], steps, **ok)
+    if c["R"] > 1:                                                          # ladder l = s R + r: Philox index first + l, summed per syndrome
+        ncls = ref["counts"].shape[1]
+        ref = dict(ref, counts=ref["counts"].reshape(c["N"], c["R"], ncls).sum(axis=1), samples=ref["samples"].reshape(c["N"], c["R"]).sum(axis=1),
+                   tops0=ref["tops0"].reshape(c["N"], c["R"]).sum(axis=1), steps_done=ref["steps_done"].reshape(c["N"], c["R"]).max(axis=1),
+                   converged=ref["converged"].reshape(c["N"], c["R"]).all(axis=1))
     bad = []
     for key in ("counts", "samples", "tops0", "steps_done", "converged"):
         if not np.array_equal(np.asarray(got[key]).astype(np.uint64), np.asarray(ref[key]).astype(np.uint64)):
@@ -216,8 +225,8 @@ def main():
             print("MISMATCH", c, bad, flush=True)
         if bad is not None:
             done += 1
-            k = "%s/%s/%s%s%s%s" % (c["code"], c["noise"], c["scan"], "/conv" if c["conv"] else "", "/queue-grid-" + c["grid"] if c["grid"] else "",
-                                    "/chunked" if c["chunks"] else "")
+            k = "%s/%s/%s%s%s%s%s" % (c["code"], c["noise"], c["scan"], "/conv" if c["conv"] else "", "/queue-grid-" + c["grid"] if c["grid"] else "",
+                                      "/chunked" if c["chunks"] else "", "/replicas" if c["R"] > 1 else "")
             kinds[k] = kinds.get(k, 0) + 1
         if i % 20 == 19:
             print("%d cases, %d compared, %d failures, %.0f s" % (i + 1, done, len(failures), time.time() - t0), flush=True)
