@@ -5,6 +5,7 @@ profiles/).  Prints a progress line per stage so that a long run is never silent
     python tests/evidence.py headline [--steps 100000] [--oracle 1024]     config 2 at the SURVEY 8d headline length
     python tests/evidence.py cfg3 [--steps 10000]                          config 3's per-GPU shard, full size, with property checks
     python tests/evidence.py cfg5 [--sweeps 1e5] [--syndromes 32768]       config 5: long-chain convergence study
+    python tests/evidence.py threshold [--steps 300000] [--syndromes 16384] the harness end to end: success rate against p_error, L = 5, 7, 9
 """
 import argparse
 import json
@@ -159,9 +160,30 @@ def cfg5(a):
             "chain_sweeps_per_s_wall": proposals / G / dt, "roofline_frac_algorithmic_wall": proposals * 8 / dt / 8e12}
 
 
+def threshold(a):
+    """The reference's data-generation recipe end to end (generate_data.py:57-60,110-141,276-296), batched: for toric L = 5, 7, 9 and
+    p_error over [0.05, 0.20], `--syndromes` errors drawn on the GPU, their class hidden by a random logical operator, decoded by PTEQ with the
+    reference's defaults (Nc = L, error_based criterion SEQ = 2 / TOPS = 10 / eps = 0.1, horizon `--steps` ladder steps); success =
+    argmax(distribution) == true class.  The curves of different L cross near the code's threshold for depolarizing noise."""
+    from qecmc import harness
+    ps = [0.05, 0.08, 0.11, 0.13, 0.15, 0.16, 0.17, 0.18, 0.19, 0.20]
+    rec = {"workload": "toric L = 5, 7, 9, depolarizing noise, %d syndromes per (L, p) generated on the device, PTEQ defaults (Nc = L, error_based "
+                       "criterion, horizon %d ladder steps)" % (a.syndromes, a.steps), "p": ps, "curves": {}}
+    for L in (5, 7, 9):
+        t0 = time.time()
+        out = harness.threshold_curve({"code": "toric", "size": L, "noise": "depolarizing"}, ps, a.syndromes, seed=100 * L, steps=a.steps,
+                                      conv_criteria="error_based", device_generation=True)
+        rec["curves"]["L%d" % L] = dict(success_rate=[float(x) for x in out["success_rate"]], err=[float(x) for x in out["err"]],
+                                        converged_frac=[float(x) for x in out["converged_frac"]],
+                                        mean_steps=[float(m["mean_steps"]) if m and "mean_steps" in m else None for m in out["metrics"]],
+                                        wall_s=time.time() - t0)
+        say("threshold: L=%d done in %.1f s: " % (L, time.time() - t0) + " ".join("%.3f" % x for x in out["success_rate"]))
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["headline", "cfg3", "cfg5"])
+    ap.add_argument("what", choices=["headline", "cfg3", "cfg5", "threshold"])
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--oracle", type=int, default=1024)
     ap.add_argument("--sweeps", type=float, default=1e5)
@@ -170,10 +192,12 @@ def main():
     a = ap.parse_args()
     if a.steps is None:
         a.steps = 100000 if a.what == "headline" else 10000
-    rec = {"headline": headline, "cfg3": cfg3, "cfg5": cfg5}[a.what](a)
+    if a.what == "threshold" and a.syndromes == 32768:
+        a.syndromes = 16384
+    rec = {"headline": headline, "cfg3": cfg3, "cfg5": cfg5, "threshold": threshold}[a.what](a)
     os.makedirs(OUT, exist_ok=True)
     name = {"headline": "%s_headline_S%g.json" % (a.tag, a.steps), "cfg3": "%s_cfg3_full_S%g.json" % (a.tag, a.steps),
-            "cfg5": "%s_cfg5_convergence_%gsweeps.json" % (a.tag, a.sweeps)}[a.what]
+            "cfg5": "%s_cfg5_convergence_%gsweeps.json" % (a.tag, a.sweeps), "threshold": "%s_threshold_curves.json" % a.tag}[a.what]
     with open(os.path.join(OUT, name), "w") as f:
         json.dump(rec, f, indent=1)
     say("wrote", name)
