@@ -5,6 +5,7 @@ profiles/).  Prints a progress line per stage so that a long run is never silent
     python tests/evidence.py headline [--steps 100000] [--oracle 1024]     config 2 at the SURVEY 8d headline length
     python tests/evidence.py cfg3 [--steps 10000]                          config 3's per-GPU shard, full size, with property checks
     python tests/evidence.py cfg5 [--sweeps 1e5] [--syndromes 32768]       config 5: long-chain convergence study
+    python tests/evidence.py cfg3long [--sweeps 1e5] [--syndromes 16384]   config 3's shape (toric L=15 p=0.18) run long: when do the ladders mix
     python tests/evidence.py threshold [--steps 300000] [--syndromes 16384] the harness end to end: success rate against p_error, L = 5, 7, 9
 """
 import argparse
@@ -121,26 +122,27 @@ def cfg3(a):
     return rec
 
 
-def cfg5(a):
+def cfg5(a, name="rotated", L=21, p=0.17, Nc=8, label="configs[4] on one GPU: rotated L=21 p=0.17", tag="cfg5"):
     import qecmc
     from qecmc import harness
-    N, L, p, Nc = a.syndromes, 21, 0.17, 8
-    G = L * L - 1
+    N = a.syndromes
+    qcode = {"rotated": qecmc.ROTATED, "toric": qecmc.TORIC}[name]
+    G = L * L - 1 if name == "rotated" else 2 * L * L
     total_steps = int(round(a.sweeps * G / 10))                      # ladder steps of iters=10 for `sweeps` sweeps per chain
     rng = np.random.default_rng(5)
-    raw = harness.draw_errors("rotated", L, N, p, rng)
-    true = np.asarray(harness._class_of(qecmc.ROTATED, raw))
-    init = harness.hide_class("rotated", raw, rng)
+    raw = harness.draw_errors(name, L, N, p, rng)
+    true = np.asarray(harness._class_of(qcode, raw))
+    init = harness.hide_class(name, raw, rng)
     sw = [s for s in (10, 30, 100, 300, 1e3, 3e3, 1e4, 3e4, 1e5, 3e5, 1e6) if s < a.sweeps] + [a.sweeps]
     cps = [int(round(s * G / 10)) for s in sw]
-    run = harness.LadderRun(init, p, Nc=Nc, iters=10, tops_burn=2, seed=5, code=qecmc.ROTATED)
+    run = harness.LadderRun(init, p, Nc=Nc, iters=10, tops_burn=2, seed=5, code=qcode)
     rows, t0 = [], time.time()
     chunk = 1 << 19
     for c in cps:
         while run.steps < c:
             run.advance(min(chunk, c - run.steps))
             run._torch.cuda.synchronize()
-            say("cfg5: %d / %d ladder steps (%.1f s)" % (run.steps, total_steps, time.time() - t0))
+            say("%s: %d / %d ladder steps (%.1f s)" % (tag, run.steps, total_steps, time.time() - t0))
         s = run.snapshot()
         has = s["samples"] > 0
         ok = np.argmax(s["counts"], axis=1) == true
@@ -155,9 +157,14 @@ def cfg5(a):
         r["mean_tv_distance_to_last_checkpoint"] = float(0.5 * np.abs(r.pop("_frac") - last).sum(axis=1).mean())
     proposals = float(run.steps) * N * Nc * 10
     run.close()
-    return {"workload": "configs[4] on one GPU: rotated L=21 p=0.17 Nc=8 iters=10, %d syndromes (class hidden by a random logical), %.3g sweeps per chain = %d ladder steps, exact chunked continuation (LadderRun, %d-step launches)" % (N, a.sweeps, total_steps, chunk),
+    return {"workload": "%s Nc=%d iters=10, %d syndromes (class hidden by a random logical), %.3g sweeps per chain = %d ladder steps, exact chunked continuation (LadderRun, %d-step launches)" % (label, Nc, N, a.sweeps, total_steps, chunk),
             "checkpoints": rows, "wall_s": dt, "proposals": proposals, "proposals_per_s_wall": proposals / dt,
             "chain_sweeps_per_s_wall": proposals / G / dt, "roofline_frac_algorithmic_wall": proposals * 8 / dt / 8e12}
+
+
+def cfg3long(a):
+    """Config 3's shape run long: at 10^4 ladder steps (the bench length) almost no toric L=15 ladder at p=0.18 has passed the tops0 burn-in."""
+    return cfg5(a, name="toric", L=15, p=0.18, Nc=8, label="configs[2]'s shape run long on one GPU: toric L=15 p=0.18", tag="cfg3long")
 
 
 def threshold(a):
@@ -183,7 +190,7 @@ def threshold(a):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["headline", "cfg3", "cfg5", "threshold"])
+    ap.add_argument("what", choices=["headline", "cfg3", "cfg5", "cfg3long", "threshold"])
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--oracle", type=int, default=1024)
     ap.add_argument("--sweeps", type=float, default=1e5)
@@ -194,10 +201,11 @@ def main():
         a.steps = 100000 if a.what == "headline" else 10000
     if a.what == "threshold" and a.syndromes == 32768:
         a.syndromes = 16384
-    rec = {"headline": headline, "cfg3": cfg3, "cfg5": cfg5, "threshold": threshold}[a.what](a)
+    rec = {"headline": headline, "cfg3": cfg3, "cfg5": cfg5, "cfg3long": cfg3long, "threshold": threshold}[a.what](a)
     os.makedirs(OUT, exist_ok=True)
     name = {"headline": "%s_headline_S%g.json" % (a.tag, a.steps), "cfg3": "%s_cfg3_full_S%g.json" % (a.tag, a.steps),
-            "cfg5": "%s_cfg5_convergence_%gsweeps.json" % (a.tag, a.sweeps), "threshold": "%s_threshold_curves.json" % a.tag}[a.what]
+            "cfg5": "%s_cfg5_convergence_%gsweeps.json" % (a.tag, a.sweeps), "threshold": "%s_threshold_curves.json" % a.tag,
+            "cfg3long": "%s_cfg3_convergence_%gsweeps.json" % (a.tag, a.sweeps)}[a.what]
     with open(os.path.join(OUT, name), "w") as f:
         json.dump(rec, f, indent=1)
     say("wrote", name)
