@@ -469,9 +469,11 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
     // the wave's diagonal stream (philox.hpp): slot_u + T is constant while roles rotate downwards (QUEUE: per lane, T counts
     // from the step the lane's ladder started at), and the last non-top block drawn, for the step that continues it
     uint32_t dstrm = kDiagStream + (wave_u + (uint32_t)(a.step0 % (uint64_t)NC)) % (uint32_t)NC;
-    // (kept across steps where 8 waves per SIMD hide little: with 4 -- the PRE shapes, the large plaquette codes -- the four
-    // registers and the branch measured -1 ... -2 %)
-    constexpr bool kCarry = MINW >= 8;
+    // (measured against a build without it on the same box: +1 % on the 8-waves-per-SIMD shapes, +1.5 ... +1.8 % on the 4-wave ones)
+    constexpr bool kCarry = true;
+    // table entries fetched one proposal ahead (random_scan_loop): same-box A/B +1.9 % at rotated L = 21 and at toric L = 13 with 9 rungs,
+    // +0.5 % at toric L = 15 with 15 rungs, -2.4 % at toric L = 15 with 8 (512 threads, dE table) -- which keeps the plain order
+    constexpr bool kAhead = MINW < 8 && (CODE != kCodeToric || MAXT > 512);
     [[maybe_unused]] u32x4 carry{0, 0, 0, 0};
     [[maybe_unused]] uint64_t carry_kb = ~0ull;
     const uint32_t thrL1 = (uint32_t)(a.thr_logical - 1);      // x < thr_logical <=> x <= thr_logical-1 (thr in [1, 2^32])
@@ -593,11 +595,13 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
         [[maybe_unused]] auto random_scan_loop = [&]() {
             int ni = DELUT ? (int)(4u * n) : (int)n;
             const uint32_t *myF = thrF + slot_u * 4 - 5;                            // indexed by dE + 4 = 5..8
-            auto propose = [&](uint32_t xw, uint64_t kb, auto wsel) {
+            auto fetch = [&](uint32_t xw) -> uint4 {
                 // (20-bit field x 11-bit count: a full-rate 24-bit multiply)
                 uint32_t gi = (uint32_t)__mul24((int)(xw >> 12), (int)a.n_gen) >> 20;
                 asm("" : "+v"(gi));                                                 // (keeps index and address as shift + shift-add)
-                const uint4 ev = gen_entry(gi);                                     // the (up to) four sites; an unused entry is 0
+                return gen_entry(gi);                                               // the (up to) four sites; an unused entry is 0
+            };
+            auto propose_e = [&](uint32_t xw, const uint4 ev, uint64_t kb, auto wsel) {
                 const uint32_t sh[4] = {ev.x, ev.y, ev.z, ev.w};                    // byte offset << 16 | ... | Pauli << 5 | bit shift
                 uint32_t *ad[4];
                 uint32_t f[4];
@@ -651,6 +655,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                     ni += (int)dE16 - 16;
                 }
             };
+            auto propose = [&](uint32_t xw, uint64_t kb, auto wsel) { propose_e(xw, fetch(xw), kb, wsel); };
             // the blocks that overlap [kbase, kbase + iters)
             uint64_t kb = kbase >> 2;
             if constexpr (!kCarry) carry_kb = ~0ull;                               // (a block the previous step started is drawn again)
@@ -660,10 +665,22 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 if (kb != carry_kb) { carry = philox_block(kb - (kq >> 2), 1, syn, strm, a.seed_lo, a.seed_hi); carry_kb = kb; }
                 const u32x4 &xa = carry;
                 if (jb >= 0 && jb + 4 <= (int)iters) {                             // a whole block: no per-proposal range tests
+                    if constexpr (kAhead) {
+                        // the next proposal's table entry is fetched before this one's test (its LDS round trip is then off the chain
+                        // entry -> sites -> dE -> threshold, which 4 waves per SIMD cover badly)
+                        const uint4 e0 = fetch(xa.x), e1 = fetch(xa.y);
+                        propose_e(xa.x, e0, kb, std::integral_constant<int, 0>{});
+                        const uint4 e2 = fetch(xa.z);
+                        propose_e(xa.y, e1, kb, std::integral_constant<int, 1>{});
+                        const uint4 e3 = fetch(xa.w);
+                        propose_e(xa.z, e2, kb, std::integral_constant<int, 2>{});
+                        propose_e(xa.w, e3, kb, std::integral_constant<int, 3>{});
+                    } else {
                     propose(xa.x, kb, std::integral_constant<int, 0>{});
                     propose(xa.y, kb, std::integral_constant<int, 1>{});
                     propose(xa.z, kb, std::integral_constant<int, 2>{});
                     propose(xa.w, kb, std::integral_constant<int, 3>{});
+                    }
                 } else {
                     if ((uint32_t)jb < iters) propose(xa.x, kb, std::integral_constant<int, 0>{});
                     if ((uint32_t)(jb + 1) < iters) propose(xa.y, kb, std::integral_constant<int, 1>{});
