@@ -1473,27 +1473,16 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             // slot-0 bookkeeping and runs it to the bottom).  (Compiling the cascade twice -- wave 0 capturing its record on the way,
             // the others taking what their last rung leaves -- saves a v_cndmask per rung and measured 2 % slower.)
             const int i_stop = (wave_u == 0 || slot_u == 0) ? 0 : (int)slot_u - 1;
-            // four rungs at a time: their records and swap bounds are fetched together, so a rung costs a few integer
-            // operations instead of an LDS round trip on the serial path
-            for (int ib = NC - 2; ib >= i_stop; ib -= 4) {                          // mcmc.py:96
-                uint32_t lo4[4], x4[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int ic = ib - u < 0 ? 0 : ib - u;
-                    lo4[u] = cur[ic * 64];
-                    x4[u] = sx[ic * 64];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int i = ib - u;
-                    const uint32_t lo = lo4[u], xi = x4[u];
-                    const bool flip = swap_flip(i, car, lo, xi);
-                    if (i >= i_stop) {                                              // uniform
-                        const uint32_t into = flip ? lo : car;                      // what slot i+1 now holds (:98-99)
-                        car = flip ? car : lo;
-                        if ((int)slot_u == i + 1) mine = into;
-                    }
-                }
+            // one rung at a time.  (Fetching four rungs' records and bounds together took the LDS round trips off the serial path when
+            // every wave ran the whole cascade; a wave now stops at its own rung -- 4.4 rungs on average at 8 temperatures, one for the
+            // wave that moves to the top -- and the eight look-ups per group cost more than they hid: one at a time is +1.8 % at
+            // toric L = 15, +2.8 % at rotated L = 21, +3.5 % at L = 10, same-box A/B against groups of 2, 3, 4 and 8.)
+            for (int i = NC - 2; i >= i_stop; --i) {                                // mcmc.py:96
+                const uint32_t lo = cur[i * 64], xi = sx[i * 64];
+                const bool flip = swap_flip(i, car, lo, xi);
+                const uint32_t into = flip ? lo : car;                              // what slot i+1 now holds (:98-99)
+                car = flip ? car : lo;
+                if ((int)slot_u == i + 1) mine = into;
             }
             }   // !SSW
             if (!SSW && slot_u == 0) mine = car;

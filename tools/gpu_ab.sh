@@ -1,11 +1,14 @@
 b() { tag=$1; shift; timeout -k 10 200 python bench.py --no-cpu-baseline --steps 3 "$@" 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('$tag', '%.3e prop/s' % d['proposals_per_s'], 'frac %.3f' % d['roofline']['frac'], '%.2f ms' % d['kernel_ms_per_launch'])"; }
-W=$PWD/tools/exp_libs/libqecmc_c8.so
-ab() { tag=$1; shift; b $tag "$@"; QECMC_LIBRARY=$W b ${tag}_c8 "$@"; }
-ab cfg3 --config 3
-ab cfg5 --config 5
-ab cfg3 --config 3
-ab cfg5 --config 5
-ab L10 --L 10
-ab xzzx15 --code xzzx --L 15
-ab L13c9 --L 13 --Nc 9
+mkdir -p gpurun_out
+python -m pytest tests -m gpu -q > gpurun_out/gpu_tests.log 2>&1; echo "tests rc=$?"; tail -3 gpurun_out/gpu_tests.log
+b cfg2 --config 2
+QECMC_TUNE=8 b cfg2_nossw --config 2
+b xzzx9 --code xzzx --L 9
+QECMC_TUNE=8 b xzzx9_nossw --code xzzx --L 9
+b L5c5 --L 5 --Nc 5 --p 0.10
+QECMC_TUNE=8 b L5c5_nossw --L 5 --Nc 5 --p 0.10
+b cfg3 --config 3
+b cfg4 --config 4
+b cfg5 --config 5
+python tools/bench_conv.py 2>/dev/null | tail -1
