@@ -469,11 +469,10 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
     // the wave's diagonal stream (philox.hpp): slot_u + T is constant while roles rotate downwards (QUEUE: per lane, T counts
     // from the step the lane's ladder started at), and the last non-top block drawn, for the step that continues it
     uint32_t dstrm = kDiagStream + (wave_u + (uint32_t)(a.step0 % (uint64_t)NC)) % (uint32_t)NC;
-    // (measured against a build without it on the same box: +1 % on the 8-waves-per-SIMD shapes, +1.5 ... +1.8 % on the 4-wave ones)
-    constexpr bool kCarry = true;
     // table entries fetched one proposal ahead (random_scan_loop): same-box A/B +1.9 % at rotated L = 21 and at toric L = 13 with 9 rungs,
     // +0.5 % at toric L = 15 with 15 rungs, -2.4 % at toric L = 15 with 8 (512 threads, dE table) -- which keeps the plain order
     constexpr bool kAhead = MINW < 8 && (CODE != kCodeToric || MAXT > 512);
+    // (the carry, measured against a build without it on the same box: +1 % on the 8-waves-per-SIMD shapes, +1.5 ... +1.8 % on the 4-wave ones)
     [[maybe_unused]] u32x4 carry{0, 0, 0, 0};
     [[maybe_unused]] uint64_t carry_kb = ~0ull;
     const uint32_t thrL1 = (uint32_t)(a.thr_logical - 1);      // x < thr_logical <=> x <= thr_logical-1 (thr in [1, 2^32])
@@ -658,7 +657,6 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             auto propose = [&](uint32_t xw, uint64_t kb, auto wsel) { propose_e(xw, fetch(xw), kb, wsel); };
             // the blocks that overlap [kbase, kbase + iters)
             uint64_t kb = kbase >> 2;
-            if constexpr (!kCarry) carry_kb = ~0ull;                               // (a block the previous step started is drawn again)
             for (int jb = -(int)((uint32_t)kbase & 3u); jb < (int)iters; jb += 4, ++kb) {
                 // (the current block lives in `carry`: the one a step ends in is still there for the next step, which starts in it
                 // unless the top role came between)
@@ -715,6 +713,9 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 uint32_t Np = xyc[sid * 64 + lane];
                 const uint32_t Nb = Np, NbB = Nb - kFieldBias;                      // counts at loop entry (p_b); ... minus the field offsets
                 const double lxy = a.bias_l2[slot_u][0], lz = a.bias_l2[slot_u][1];
+                const float lxyf = (float)lxy, lzf = (float)lz;
+                // (a count changes by at most 4 per proposal since loop entry)
+                const bool f32ok = 4.0 * (double)iters * __builtin_fmax(__builtin_fabs(lxy), __builtin_fabs(lz)) <= 2000.0;
                 uint32_t cdelta = 0;
                 bool any_acc = false;
                 // (the loop is compiled once for the top chain and once for the others: the top chain's logical operators and
@@ -723,23 +724,9 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                 constexpr bool top = decltype(top_c)::value;
                 const double c0 = (top ? 32.0 : 12.0) - 512.0 * (lxy + lz);         // scales the ratio by 2^32 / 2^12, removes the offsets
                 [[maybe_unused]] const int LW = (L + 1) * W;
-                u32x4 pair = carry;                                                // the block four non-top proposals share (the last one of
-                uint64_t kb_pair = (top || !kCarry) ? ~0ull : carry_kb;            //  the previous step continues into this one)
-                for (uint32_t j = 0; j < iters; ++j) {
-                    const uint64_t k = kbase + j;
-                    // top: block (k, 0) = select | generator or logical fields | acceptance word | Z position;
-                    // non-top: word k&3 of block (k>>2, 1) (+ its refinement)
-                    u32x4 x;
-                    if constexpr (top) {
-                        x = philox_block(k, 0, syn, strm, a.seed_lo, a.seed_hi);   // (drawing the next proposal's block ahead, behind this one's LDS reads: -1 %)
-                    } else {
-                        if ((k >> 2) != kb_pair) {
-                            kb_pair = k >> 2;
-                            pair = philox_block(kb_pair, 1, syn, strm, a.seed_lo, a.seed_hi);
-                        }
-                        x.x = sel4(pair, (int)(k & 3));                             // the proposal's word: generator | 12 leading accept bits
-                        x.y = x.z = x.w = 0;
-                    }
+                // one proposal.  top: x = block (k, 0) = select | generator or logical fields | acceptance word | Z position;
+                // non-top: x.x = word k&3 (= WI) of block (k>>2, 1) (+ its refinement)
+                auto one = [&](const uint64_t k, const u32x4 x, auto wsel) {
                     const bool logical = top && x.x <= thrL1;                       // mcmc.py:23
                     uint32_t Nn, cd = 0;                                            // the proposal's packed counts; its class change
                     uint32_t *sad[4] = {stw, stw, stw, stw};
@@ -777,8 +764,19 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                         Nn = Np + xlut[(ev.y & 0xF00u) | F];                        // pattern id << 8 | old fields -> the count change
                     }
                     const uint32_t cand = Nn - NbB;                                 // the counts' change since loop entry, every field + 512
-                    const double tl = __builtin_fma(lxy, (double)(cand >> 20), __builtin_fma(lz, (double)((cand >> 10) & 1023u), c0));
-                    float e = __builtin_amdgcn_exp2f((float)tl);                    // 2^12 (top: 2^32) p_n / p_b, relative error < 1e-6
+                    float e;                                                        // 2^12 (top: 2^32) p_n / p_b
+                    if (!top && f32ok) {
+                        // single precision is enough for the 12-bit comparison once the offsets are out (a field + 512 with its top bit
+                        // flipped is the change in 10-bit two's complement): the products are exact inside the fmas, the roundings are
+                        // those of l as a float (6e-8 |l d|) and of a partial sum of magnitude <= |l d| + 12, so with |l d| <= 2000 the
+                        // error of the exponent stays below 2.5e-4 / 0.7 of a unit at e = 4096; a unit is what the margins below allow
+                        const uint32_t cx = cand ^ kFieldBias;
+                        const float dxy = (float)(int)__builtin_amdgcn_sbfe((int)cx, 20u, 10u), dzz = (float)(int)__builtin_amdgcn_sbfe((int)cx, 10u, 10u);
+                        e = __builtin_amdgcn_exp2f(__builtin_fmaf(lxyf, dxy, __builtin_fmaf(lzf, dzz, 12.0f)));
+                    } else {
+                        const double tl = __builtin_fma(lxy, (double)(cand >> 20), __builtin_fma(lz, (double)((cand >> 10) & 1023u), c0));
+                        e = __builtin_amdgcn_exp2f((float)tl);                      // relative error < 1e-6
+                    }
                     bool acc, amb;
                     uint32_t a12 = 0;
                     if constexpr (top) {
@@ -804,7 +802,9 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                             const double ulo = (double)a12 * (1.0 / 4096.0);
                             acc = ulo + (1.0 / 4096.0) <= ratio;
                             if (!acc && ulo < ratio) {
-                                const uint64_t v44 = ((uint64_t)a12 << 32) | sel4(philox_block(k >> 2, kSubRefine, syn, strm, a.seed_lo, a.seed_hi), (int)(k & 3));
+                                constexpr int WI = decltype(wsel)::value;
+                                const u32x4 r = philox_block(k >> 2, kSubRefine, syn, strm, a.seed_lo, a.seed_hi);
+                                const uint64_t v44 = ((uint64_t)a12 << 32) | (WI == 0 ? r.x : WI == 1 ? r.y : WI == 2 ? r.z : r.w);
                                 acc = (double)v44 * (1.0 / 17592186044416.0) < ratio;
                             }
                         }
@@ -821,8 +821,24 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                         Np = Nn;
                         any_acc = true;
                     }
+                };
+                if constexpr (top) {
+                    // (drawing the next proposal's block ahead, behind this one's LDS reads: -1 %)
+                    for (uint32_t j = 0; j < iters; ++j)
+                        one(kbase + j, philox_block(kbase + j, 0, syn, strm, a.seed_lo, a.seed_hi), std::integral_constant<int, 0>{});
+                } else {
+                    // the blocks that overlap [kbase, kbase + iters), a static word index per proposal (+1 % against a rolled loop with a
+                    // dynamic word select); the current block lives in `carry`, so the one a step ends in is still there for the next step
+                    uint64_t kb = kbase >> 2;
+                    for (int jb = -(int)((uint32_t)kbase & 3u); jb < (int)iters; jb += 4, ++kb) {
+                        if (kb != carry_kb) { carry = philox_block(kb, 1, syn, strm, a.seed_lo, a.seed_hi); carry_kb = kb; }
+                        const uint64_t k4 = kb << 2;
+                        if ((uint32_t)jb < iters) one(k4, u32x4{carry.x, 0, 0, 0}, std::integral_constant<int, 0>{});
+                        if ((uint32_t)(jb + 1) < iters) one(k4 + 1, u32x4{carry.y, 0, 0, 0}, std::integral_constant<int, 1>{});
+                        if ((uint32_t)(jb + 2) < iters) one(k4 + 2, u32x4{carry.z, 0, 0, 0}, std::integral_constant<int, 2>{});
+                        if ((uint32_t)(jb + 3) < iters) one(k4 + 3, u32x4{carry.w, 0, 0, 0}, std::integral_constant<int, 3>{});
+                    }
                 }
-                if constexpr (!top && kCarry) { carry = pair; carry_kb = kb_pair; }
                 };
                 if (top) biased_loop(std::true_type{});
                 else biased_loop(std::false_type{});
