@@ -338,8 +338,9 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
             uint32_t ops = 0;
             if (k == 0)
                 for (int u = 0; u < 4; ++u) ops |= (uint32_t)(reinterpret_cast<const uint16_t *>(a.gen)[4 * g + u] & 3u) << (2 * u);
-            if (BIASED && k == 1) ops = a.gen_type[g];                              // site 1, bits [11:8]: the generator's Pauli-pattern id
+            if (BIASED) ops = k == 1 ? a.gen_type[g] : (e & 3u);                    // site 1, bits [11:8]: the generator's Pauli-pattern id; the others: their own Pauli
             if (!BIASED && CODE == kCodeToric && k == 1) ops = e & 3u;              // toric: site 1, byte 1 = the generator's one Pauli
+            if (DELUT && CODE != kCodeToric && !BIASED && (k & 1)) ops = e & 3u;      // plaquette codes with the dE table: sites 1, 3: byte 1 = the site's own Pauli
             if (DELUT && k == 2) ops = CODE == kCodeToric ? (e & 3u) == 3u : a.gen_type[g];   // ... site 2, byte 1 = the row of the dE table (toric: 1 for a Z generator)
             (lds + gen_off + narrow_dw)[kSplitGen ? 2 * (g + (k >> 1) * kGenSplit) + (k & 1) : i] =
                 (((q >> 4) * 256u) << 16) | (ops << 8) | ((e & 3u) << 5) | ((q & 15u) * 2u);
@@ -623,7 +624,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                     if (acc) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
-                            lds_xor(ad[i], CODE == kCodeToric ? shl_byte1(sh[i], ev.y) : shl_lo5((sh[i] >> 5) & 3u, sh[i]));
+                            lds_xor(ad[i], CODE == kCodeToric ? shl_byte1(sh[i], ev.y) : (i & 1) ? shl_byte1(sh[i], sh[i]) : shl_lo5((sh[i] >> 5) & 3u, sh[i]));
                         ni += (int)v - 16;
                     }
                     return;
@@ -816,7 +817,8 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
                             cdelta ^= cd;
                         } else {
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) lds_xor(sad[i], shl_lo5((ssh[i] >> 5) & 3u, ssh[i]));
+                            for (int i = 0; i < 4; ++i)                             // (byte 1 of sites 0, 2, 3 is the site's Pauli: one SDWA shift)
+                                lds_xor(sad[i], i == 1 ? shl_lo5((ssh[i] >> 5) & 3u, ssh[i]) : shl_byte1(ssh[i], ssh[i]));
                         }
                         Np = Nn;
                         any_acc = true;
