@@ -372,3 +372,18 @@ def test_xzzx_logical_product_rows_small_workgroups(q, orc, L, Nc, noise):
         ref = orc.pteq_batch(orc.XZZX, init, 0.15, Nc, kw["steps"], iters=10, tops_burn=0, seed=kw["seed"], first_syndrome=484,
                              noise=orc.BIASED, eta=10.0, return_states=True)
     assert np.array_equal(got["states"], ref["states"]) and np.array_equal(got["counts"], ref["counts"])
+
+
+@pytest.mark.parametrize("name,iters,eta", [("xzzx", 64, 100.0), ("rotated", 100, 10.0), ("xzzx", 10, 1e6)])
+def test_biased_fast_test_precision_fallback(q, orc, name, iters, eta):
+    """The biased rule's fast test runs in single precision while 4 iters max|log2 ratio| <= 2000 and in fp64 beyond (many proposals per
+    step, extreme bias): both sides of the switch stay bit-identical to the oracle."""
+    rng = np.random.default_rng(iters)
+    L, Nc = 5, 4
+    init = rand_plaq(rng, 90, L, 0.12)
+    code, ocode = (q.XZZX, orc.XZZX) if name == "xzzx" else (q.ROTATED, orc.ROTATED)
+    kw = dict(steps=60, iters=iters, tops_burn=0, seed=4242, first_syndrome=7)
+    got = q.pteq_batch(init, 0.12, Nc=Nc, code=code, eta=eta, return_states=True, **kw)
+    ref = orc.pteq_batch(ocode, init, 0.12, Nc, kw["steps"], iters=iters, tops_burn=0, seed=4242, first_syndrome=7, noise=orc.BIASED, eta=eta,
+                         return_states=True)
+    assert np.array_equal(got["states"], ref["states"]) and np.array_equal(got["counts"], ref["counts"])
