@@ -510,6 +510,9 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const Ladde
         const bool acc_all = (a.acc_all_mask >> slot_u) & 1u;
         const bool top_logical = (slot_u == (uint32_t)(NC - 1)) && a.thr_logical != 0;
         const uint32_t strm = top_logical ? slot_u : dstrm;                         // Philox stream of this step's proposals (philox.hpp)
+        // (the top-role wave at the highest priority: same-box A/B +2.2 % / +1.6 % in the 1024-thread PRE kernels -- L = 15 with 15 rungs, L = 13
+        // with 9 --, -1.6 % in the 512-thread ones, configs 3 and 5, which keep the workgroup's level)
+        if constexpr (PRE && MAXT > 512) { if (top_logical) __builtin_amdgcn_s_setprio(3); }
         // The blind top chain's proposals (random scan, p = 0.75): move(A, B) for each proposal of the step, in order.  The step's
         // proposals [kbase, kbase + iters) lie in blocks b0 .. b0 + nblk - 1, two per block: the first block may start at its
         // second proposal and the last may end at its first (all wave-uniform).

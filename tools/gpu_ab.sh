@@ -1,10 +1,10 @@
 b() { tag=$1; shift; timeout -k 10 200 python bench.py --no-cpu-baseline --steps 3 "$@" 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('$tag', '%.3e prop/s' % d['proposals_per_s'], 'frac %.3f' % d['roofline']['frac'], '%.2f ms' % d['kernel_ms_per_launch'])"; }
-mkdir -p gpurun_out
-python -m pytest tests -m gpu -q > gpurun_out/gpu_tests.log 2>&1; echo "tests rc=$?"; tail -3 gpurun_out/gpu_tests.log
-b cfg2 --config 2
-b xzzx9 --code xzzx --L 9
-b rot9 --code rotated --L 9 --p 0.17
-b planar9 --code planar --L 9
-b L7c7 --L 7 --Nc 7
-b L5c5 --L 5 --Nc 5 --p 0.10
+E=$PWD/tools/exp_libs
+ab() { v=$1; tag=$2; shift; shift; b $tag "$@"; QECMC_LIBRARY=$E/libqecmc_$v.so b ${tag}_$v "$@"; }
+ab topprio cfg3 --config 3
+ab topprio cfg5 --config 5
+ab topprio cfg3 --config 3
+ab topprio cfg5 --config 5
+ab topprio cfg3c15 --config 3 --Nc 15
+ab topprio L13c9 --L 13 --Nc 9
