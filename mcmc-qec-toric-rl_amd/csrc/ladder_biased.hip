@@ -6,17 +6,12 @@ namespace qecmc {
 hipError_t launch_ladder_biased(const LadderArgs &a, hipStream_t stream)
 {
     constexpr int X = kCodeXzzx, R = kCodeRotated;
-    const bool conv = a.conv_mode != 0;
-    const void *fn;
-#define QECMC_KB(maxt, minw, code, alpha) (conv ? (const void *)ladder_rs_toric_kernel<maxt, minw, true, false, code, true, false, true, false, alpha> \
-                                                : (const void *)ladder_rs_toric_kernel<maxt, minw, false, false, code, true, false, true, false, alpha>)
-    const unsigned block = (unsigned)a.Nc * 64u;
-    const bool alpha = a.noise == 2;
-    if (a.code == X) fn = block <= 512 ? (alpha ? QECMC_KB(512, 8, X, true) : QECMC_KB(512, 8, X, false)) : (alpha ? QECMC_KB(1024, 4, X, true) : QECMC_KB(1024, 4, X, false));
-    else if (a.code == R) fn = block <= 512 ? (alpha ? QECMC_KB(512, 8, R, true) : QECMC_KB(512, 8, R, false)) : (alpha ? QECMC_KB(1024, 4, R, true) : QECMC_KB(1024, 4, R, false));
-    else return hipErrorInvalidValue;
-#undef QECMC_KB
-    return launch_ladder_fn(fn, a, stream);
+    const bool big = (unsigned)a.Nc * 64u > 512;
+    const uint32_t want = kBiased | kGentop | (a.conv_mode != 0 ? kConv : 0u) | (a.noise == 2 ? kAlpha : 0u);
+    const void *fn = big ? LadderKernels<1024, 4, kBiased | kGentop, kBiased | kGentop | kConv, kBiased | kGentop | kAlpha, kBiased | kGentop | kAlpha | kConv>::of<X, R>(a.code, want)
+                         : LadderKernels<512, 8, kBiased | kGentop, kBiased | kGentop | kConv, kBiased | kGentop | kAlpha, kBiased | kGentop | kAlpha | kConv>::of<X, R>(a.code, want);
+    if (!fn) return hipErrorInvalidValue;
+    return launch_ladder_fn(fn, a, stream, false);
 }
 
 }  // namespace qecmc

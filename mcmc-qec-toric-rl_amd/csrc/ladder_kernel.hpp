@@ -250,10 +250,23 @@ __device__ inline bool alpha_series_close(uint64_t z2, uint64_t xy2, uint32_t de
 // while it works on slot 1, the other half one step before on slot 0 -- and wait in registers (48 VGPRs: only for the shapes
 // whose LDS footprint leaves 4 waves per SIMD anyway).  The draws do not depend on the state, so nothing changes but who
 // is the step's longest wave: at L = 15 the top wave's 10 blocks + frame flush were 2.6 x a non-top wave's step.
-template <int MAXT, int MINW, bool CONV, bool GSPLIT, int CODE, bool BIASED, bool SCAN, bool GENTOP, bool USET = false, bool ALPHA = false,
-          bool PRE = false, bool DELUT = false, bool QUEUE = false, bool SSW = false>
-__global__ __launch_bounds__(MAXT, MINW) void ladder_rs_toric_kernel(const LadderArgs a)
+//
+// The variant is named, not positional: ladder_kernel<MAXT, MINW, CODE, kConv | kDelut | ...> (LadderFlag below).  A
+// translation unit lists the flag sets it instantiates in one select_ladder_kernel<...>() call and asks for one of them at
+// run time; a set that is not on the list yields no kernel (an error), never a neighbouring one.
+enum LadderFlag : uint32_t {
+    kConv = 1u << 0, kGsplit = 1u << 1, kBiased = 1u << 2, kScan = 1u << 3, kGentop = 1u << 4, kUset = 1u << 5, kAlpha = 1u << 6,
+    kPre = 1u << 7, kDelut = 1u << 8, kQueue = 1u << 9, kSsw = 1u << 10,
+};
+
+template <int MAXT, int MINW, int CODE, uint32_t FLAGS>
+__global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
 {
+    constexpr bool CONV = (FLAGS & kConv) != 0, GSPLIT = (FLAGS & kGsplit) != 0, BIASED = (FLAGS & kBiased) != 0, SCAN = (FLAGS & kScan) != 0;
+    constexpr bool GENTOP = (FLAGS & kGentop) != 0, USET = (FLAGS & kUset) != 0, ALPHA = (FLAGS & kAlpha) != 0, PRE = (FLAGS & kPre) != 0;
+    constexpr bool DELUT = (FLAGS & kDelut) != 0, QUEUE = (FLAGS & kQueue) != 0, SSW = (FLAGS & kSsw) != 0;
+    static_assert(!ALPHA || BIASED, "the alpha model is a variant of the biased rule");
+    static_assert(!QUEUE || CONV, "the work queue serves the runs that stop by the criterion");
     extern __shared__ uint32_t lds_all[];
     const int NC = a.Nc, W = a.W, L = a.L, LL = L * L, nq = a.nq, ncls = a.ncls;
     const int nthreads = NC * 64;                 // threads of one group
@@ -1812,11 +1825,14 @@ inline bool ladder_wants_pre(const LadderArgs &a)
 }
 
 // launch `fn` (one of the instantiations above) on the grid the arguments imply
-inline hipError_t launch_ladder_fn(const void *fn, const LadderArgs &a, hipStream_t stream)
+// (`persistent`: fn is a QUEUE instantiation -- only those run on the capped grid and take the rest of the batch from the
+// counter; a.queue without such a kernel is an error here, so a plain kernel can never run on a grid that skips ladders)
+inline hipError_t launch_ladder_fn(const void *fn, const LadderArgs &a, hipStream_t stream, bool persistent)
 {
     unsigned grid = (unsigned)((a.N + 63) / 64);
     const unsigned block = (unsigned)a.Nc * 64u;
-    if (a.grid_cap && grid > a.grid_cap) grid = a.grid_cap;       // QUEUE kernels: a persistent grid, the rest comes from the counter
+    if ((a.queue != nullptr) != persistent) return hipErrorInvalidValue;
+    if (persistent && a.grid_cap && grid > a.grid_cap) grid = a.grid_cap;
     const size_t lds = ladder_launch_lds(a);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (lds > 64 * 1024) {   // beyond the default dynamic-LDS window (160 KiB per CU on gfx950)
@@ -1828,6 +1844,26 @@ inline hipError_t launch_ladder_fn(const void *fn, const LadderArgs &a, hipStrea
     if (e != hipSuccess) return e;
     return hipGetLastError();
 }
+
+// the instantiation <MAXT, MINW, CODE, want> if `want` is one of the listed flag sets Fs..., else nullptr
+template <int MAXT, int MINW, int CODE, uint32_t... Fs>
+inline const void *select_ladder_kernel(uint32_t want)
+{
+    const void *fn = nullptr;
+    ((want == Fs ? (void)(fn = (const void *)ladder_kernel<MAXT, MINW, CODE, Fs>) : (void)0), ...);
+    return fn;
+}
+// ... the same over the code models Cs... (`code` picks)
+template <int MAXT, int MINW, uint32_t... Fs>
+struct LadderKernels {
+    template <int... Cs>
+    static const void *of(int code, uint32_t want)
+    {
+        const void *fn = nullptr;
+        ((code == Cs ? (void)(fn = select_ladder_kernel<MAXT, MINW, Cs, Fs...>(want)) : (void)0), ...);
+        return fn;
+    }
+};
 
 // one translation unit per kernel family (parallel builds): each picks among its own instantiations
 hipError_t launch_ladder_toric(const LadderArgs &a, hipStream_t stream);      // ladder_toric.hip: toric, depolarizing, random scan

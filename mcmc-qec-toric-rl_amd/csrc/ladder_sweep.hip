@@ -6,21 +6,19 @@ namespace qecmc {
 hipError_t launch_ladder_sweep(const LadderArgs &a, hipStream_t stream)
 {
     constexpr int T = kCodeToric, X = kCodeXzzx, R = kCodeRotated, P = kCodePlanar;
-    const unsigned block = (unsigned)a.Nc * 64u;
-    const bool conv = a.conv_mode != 0;
+    const bool big = (unsigned)a.Nc * 64u > 512;
+    // toric: the general top-chain path only for L > 16 or a top chain below p = 0.75; the plaquette codes always keep it
+    const bool gentop = a.code != T || (a.thr_logical != 0 && (a.L > 16 || !((a.acc_all_mask >> (a.Nc - 1)) & 1u)));
+    const uint32_t want = kScan | (a.conv_mode != 0 ? kConv : 0u) | (gentop ? kGentop : 0u);
     const void *fn;
-#define QECMC_K(maxt, minw, code, gentop) (conv ? (const void *)ladder_rs_toric_kernel<maxt, minw, true, false, code, false, true, gentop> \
-                                                : (const void *)ladder_rs_toric_kernel<maxt, minw, false, false, code, false, true, gentop>)
-    if (a.code == T) {
-        const bool gentop = a.thr_logical != 0 && (a.L > 16 || !((a.acc_all_mask >> (a.Nc - 1)) & 1u));
-        if (gentop) fn = block <= 512 ? QECMC_K(512, 8, T, true) : QECMC_K(1024, 4, T, true);
-        else fn = block <= 512 ? QECMC_K(512, 8, T, false) : QECMC_K(1024, 4, T, false);
-    } else if (a.code == X) fn = block <= 512 ? QECMC_K(512, 8, X, true) : QECMC_K(1024, 4, X, true);
-    else if (a.code == R) fn = block <= 512 ? QECMC_K(512, 8, R, true) : QECMC_K(1024, 4, R, true);
-    else if (a.code == P) fn = block <= 512 ? QECMC_K(512, 8, P, true) : QECMC_K(1024, 4, P, true);
-    else return hipErrorInvalidValue;
-#undef QECMC_K
-    return launch_ladder_fn(fn, a, stream);
+    if (a.code == T)
+        fn = big ? select_ladder_kernel<1024, 4, T, kScan, kScan | kConv, kScan | kGentop, kScan | kGentop | kConv>(want)
+                 : select_ladder_kernel<512, 8, T, kScan, kScan | kConv, kScan | kGentop, kScan | kGentop | kConv>(want);
+    else
+        fn = big ? LadderKernels<1024, 4, kScan | kGentop, kScan | kGentop | kConv>::of<X, R, P>(a.code, want)
+                 : LadderKernels<512, 8, kScan | kGentop, kScan | kGentop | kConv>::of<X, R, P>(a.code, want);
+    if (!fn) return hipErrorInvalidValue;
+    return launch_ladder_fn(fn, a, stream, false);
 }
 
 }  // namespace qecmc
