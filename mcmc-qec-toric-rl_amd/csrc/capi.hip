@@ -367,6 +367,12 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
             const double *t = &bt[(size_t)c * 4 * (nq + 1)];
             a.bias_l2[c][0] = std::log2(t[1] / t[3 * (nq + 1) + 1]);
             a.bias_l2[c][1] = std::log2(t[2 * (nq + 1) + 1] / t[3 * (nq + 1) + 1]);
+            a.bias_l2f[c][0] = (float)a.bias_l2[c][0];
+            a.bias_l2f[c][1] = (float)a.bias_l2[c][1];
+            // the fast test may run in single precision / fp16 count changes on this rung (ladder_kernel.hpp: a count changes by at
+            // most 4 per proposal since loop entry; fp16 holds integers up to 2048; |l d| <= 2000 keeps the exponent's error below a unit)
+            if (a.iters <= 512u && 4.0 * (double)a.iters * std::max(std::fabs(a.bias_l2[c][0]), std::fabs(a.bias_l2[c][1])) <= 2000.0)
+                a.bias_f32ok |= 1u << c;
         }
         HIP_TRY(pl->xyz_lut.alloc(xyz_lut.size() * sizeof(uint32_t)));
         HIP_TRY(hipMemcpy(pl->xyz_lut.p, xyz_lut.data(), xyz_lut.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -582,6 +588,7 @@ static int chain_update_impl(int code, int L, uint64_t N, uint8_t *states_inout,
     } else
     if (noise) {
         if (!(p > 0.0) || !(p < 1.0) || !(eta > 0.0)) return fail(QECMC_ERR_INVALID, "biased noise needs p in (0,1) and eta > 0 (p=%g eta=%g)", p, eta);
+        if (code == QECMC_TORIC || code == QECMC_PLANAR) return fail(QECMC_ERR_UNSUPPORTED, "biased noise is built for the xzzx and rotated codes (BASELINE config 4)");
     } else if (!(p > 0.0) || !(p <= 0.75)) return fail(QECMC_ERR_INVALID, "p=%g must be in (0, 0.75]", p);
     if (!(p_logical >= 0.0) || !(p_logical <= 1.0)) return fail(QECMC_ERR_INVALID, "p_logical=%g must be in [0,1]", p_logical);
     if (slot >= 0x100u) return fail(QECMC_ERR_INVALID, "slot %u collides with the swap stream id", slot);

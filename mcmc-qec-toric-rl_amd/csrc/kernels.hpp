@@ -52,6 +52,8 @@ struct LadderArgs {
     int n_types;              //                    distinct Pauli patterns among the generators (<= 16)
     uint8_t type_ops[16];     //                    ... each as four 2-bit Paulis (site 0 in bits 1:0; 0 = no site): the plaquette codes' dE table
     double bias_l2[kMaxNc][2];//                    log2(px / pI), log2(pz / pI) per rung (px = py in both noise models)
+    float bias_l2f[kMaxNc][2];//                    ... rounded to single precision
+    uint32_t bias_f32ok;      //                    bit c: rung c's fast test may use them (4 iters max|l| <= 2000, iters <= 512)
     const double *alpha_lnb;  // [Nc-1]             ln(pz_tilde[i] / pz_tilde[i+1]) (alpha noise, mcmc_alpha.py:123)
     double alpha;             //                    mcmc_alpha.py:11
     uint32_t *neff;           // [N][Nc]            alpha noise: the slots' n_eff attributes as n_z | (n_x+n_y) << 16; resume in / out
@@ -101,7 +103,7 @@ constexpr uint32_t kMaxGenLds = 2048;   // generator tables up to this many entr
 // alpha noise appends the double-buffered n_eff records [2][Nc][64] to the region
 constexpr int kLutTypes = 8;        // rows of the plaquette codes' dE look-up table (Pauli patterns of their generators; more: no table)
 constexpr int kGenSplit = 255;      // ds_read2_b64's second offset is an 8-bit count of 8-byte units
-// ... and the biased / alpha rules' count-change table uint32[n_types][256] and packed per-state counts uint32[Nc][64]
+// ... and the biased / alpha rules' count-change table uint2[n_types][256] and packed per-state counts uint32[Nc][64]
 // lattice size of a plaquette code from its qubit count (xzzx / rotated: L x L; planar: 2 L^2 with an idle row and column)
 inline int nq_L(int code, int nq) { int L = 1; while ((code == 3 ? 2 * L * L : L * L) < nq) ++L; return L; }
 inline int ladder_gen_dwords(int code, int noise, int scan, uint32_t n_gen, int Nc, int nq = 0, int n_types = 0)
@@ -115,7 +117,8 @@ inline int ladder_gen_dwords(int code, int noise, int scan, uint32_t n_gen, int 
     const int wide_dw = ((!noise && (int)n_gen <= kGenSplit) ? 2 * (kGenSplit + (int)n_gen) : 4 * (int)n_gen) + lut_tail;
     int d = wide ? (code == 0 ? wide_dw : ((2 * (int)n_gen + 3) & ~3) + wide_dw) : 2 * (int)n_gen;
     if (noise == 2) d = ((d + 3) & ~3) + 2 * Nc * 64;
-    if (noise) d = ((d + 3) & ~3) + 256 * n_types + Nc * 64 + 2 * (nq_L(code, nq) + 1) * ((nq + 15) / 16);   // + the X / Z logical masks [2][L+1][W]
+    // (8 bytes per count-change entry; + the X / Z logical masks [2][L+1][W]; xzzx: + the logical operators' fields per generator)
+    if (noise) d = ((d + 3) & ~3) + 512 * n_types + Nc * 64 + 2 * (nq_L(code, nq) + 1) * ((nq + 15) / 16) + (code == 1 ? (((int)n_gen + 1) & ~1) + 3 * 64 : 0);
     return d;
 }
 // the shapes the work-queue kernels exist for: depolarizing rule, random scan, error_based criterion, the framed top chain

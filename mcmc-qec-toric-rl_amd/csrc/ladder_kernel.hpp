@@ -288,15 +288,21 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
     const int lm_dw = BIASED ? 2 * (L + 1) * W : 0;             // ... and the X / Z logical-operator masks [2][L+1][W] (row L = identity)
     // (xzzx: its operators do not depend on a position, so rows 0 .. 3 of the X table are overwritten with the four products
     // I, X, Z, XZ indexed by the class change -- one look-up per word instead of two and an xor)
-    const int neff_dw = alpha_noise ? 2 * NC * 64 : 0, bias_dw = BIASED ? 256 * a.n_types + NC * 64 + lm_dw : 0;
+    // (xzzx: mtab[n_gen], the logical operators' fields at every generator's four sites -- the top chain's frame, below)
+    // ... and rk[3][64], the top chain's packed counts under the three logical products
+    const int mtab_dw = (BIASED && CODE == kCodeXzzx) ? (((int)a.n_gen + 1) & ~1) + 3 * 64 : 0;
+    const int neff_dw = alpha_noise ? 2 * NC * 64 : 0, bias_dw = BIASED ? 512 * a.n_types + NC * 64 + lm_dw + mtab_dw : 0;
     const int gen_region = (neff_dw || bias_dw) ? ((gen_dw + 3) & ~3) + neff_dw + bias_dw : gen_dw;
     const int gdw = ladder_group_dwords(NC, W, ncls, gen_region);   // dwords per group
     const int gen_off = gdw - ((gen_region + 3) & ~3);           // start of the generator table
     uint32_t *lds = lds_all;
     [[maybe_unused]] uint32_t *neffb = lds + gen_off + ((gen_dw + 3) & ~3);   // [2][NC][64] n_z | (n_x+n_y) << 16 per slot, by step parity
-    [[maybe_unused]] uint32_t *xlut = lds + gen_off + ((gen_dw + 3) & ~3) + neff_dw;   // [n_types][256] dx + (dz << 10) + ((dx + dy) << 20)
-    [[maybe_unused]] uint32_t *xyc = xlut + (BIASED ? 256 * a.n_types : 0);           // [NC][64] n_x | n_z << 10 | (n_x + n_y) << 20 of state s
+    // [n_types][256] x 8 bytes: .x = dx + (dz << 10) + ((dx + dy) << 20) (wrapping), .y = the same change as two halves (dx + dy | dz << 16, fp16)
+    [[maybe_unused]] uint2 *xlut = reinterpret_cast<uint2 *>(lds + gen_off + ((gen_dw + 3) & ~3) + neff_dw);
+    [[maybe_unused]] uint32_t *xyc = reinterpret_cast<uint32_t *>(xlut) + (BIASED ? 512 * a.n_types : 0);   // [NC][64] n_x | n_z << 10 | (n_x + n_y) << 20 of state s
     [[maybe_unused]] uint32_t *lml = xyc + (BIASED ? NC * 64 : 0);                    // [2][L+1][W] LDS copy of the plan's logical masks
+    [[maybe_unused]] uint32_t *mtab = lml + lm_dw;                                    // [n_gen] 0 | M_X << 8 | M_Z << 16 | M_XZ << 24 (xzzx)
+    [[maybe_unused]] uint32_t *rk = mtab + (((int)a.n_gen + 1) & ~1);                 // [3][64] (xzzx, the wave in the top role)
 
     uint32_t *st = lds;                           // [NC][W][64]   packed states
     uint32_t *info = st + (size_t)NC * W * 64;    // [2][NC][64]   slot records, double-buffered by step parity
@@ -383,7 +389,25 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
         swapT[i] = (d >= 1 && d <= nq) ? (uint32_t)a.swap_thr[(size_t)pr * (nq + 1) + d] : 0u;
     }
     if constexpr (BIASED) {
-        for (int i = tid; i < 256 * a.n_types; i += nthreads) xlut[i] = a.xyz_lut[i];
+        for (int i = tid; i < 256 * a.n_types; i += nthreads) {
+            // the change of (n_x + n_y, n_z) once more, as two fp16 numbers: what the fast acceptance test multiplies (each in [-4, 4])
+            const uint32_t d = a.xyz_lut[i], v = d + (512u | (512u << 10) | (512u << 20));
+            const _Float16 hxy = (_Float16)((int)(v >> 20) - 512), hz = (_Float16)((int)((v >> 10) & 1023u) - 512);
+            xlut[i] = uint2{d, (uint32_t)__builtin_bit_cast(uint16_t, hxy) | ((uint32_t)__builtin_bit_cast(uint16_t, hz) << 16)};
+        }
+        if constexpr (CODE == kCodeXzzx) {
+            // the fields of the X (anti-diagonal) and Z (diagonal) logical operators at every generator's sites (a null site: 0)
+            for (int g = tid; g < (int)a.n_gen; g += nthreads) {
+                uint32_t mx = 0, mz = 0;
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t e = reinterpret_cast<const uint16_t *>(a.gen)[4 * g + k], q = e >> 2;
+                    if (e == 0) continue;
+                    mx |= ((a.lmask[q >> 4] >> ((q & 15u) * 2u)) & 3u) << (2 * k);
+                    mz |= ((a.lmask[(L + 1) * W + (q >> 4)] >> ((q & 15u) * 2u)) & 3u) << (2 * k);
+                }
+                mtab[g] = (mx << 8) | (mz << 16) | ((mx ^ mz) << 24);
+            }
+        }
         for (int i = tid; i < lm_dw; i += nthreads) lml[i] = a.lmask[i];              // kinds 0 (X) and 1 (Z) are the first two tables
         if (CODE == kCodeXzzx && L >= 3) {
             __syncthreads();                                                         // (rows 0 .. 3 of the copy above are replaced)
@@ -497,6 +521,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
     const uint32_t rowmask = rowbits >= 32 ? 0xFFFFFFFFu : (1u << rowbits) - 1u;
     const bool swap_fast = a.swap_fast_ok != 0;
 
+    constexpr bool kLaunderLane = BIASED && MINW >= 8;
     constexpr int kPre = 12;                                    // blocks drawn ahead (a step of more proposals draws the rest in place)
     [[maybe_unused]] u32x4 pre[PRE ? kPre : 1];
     // QUEUE: finished lanes take new ladders until the counter runs out; the loop ends by the stop flag.  A new ladder may
@@ -506,6 +531,11 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
     [[maybe_unused]] bool q_dead = lane >= cnt, q_flushed = false;                           // (wave 0) no ladder left for this lane / its results are written
     [[maybe_unused]] bool q_empty = a.N <= (uint64_t)gridDim.x * 64u;                        // ... the counter is exhausted (uniform)
     for (uint64_t t = 0; QUEUE || t < a.nsteps; ++t) {
+        // The lane index of this step.  In the register-starved instantiations (kLaunderLane) it is opaque to the compiler, so the
+        // dozen LDS addresses derived from it (records, swap uniforms, histogram rows, count tables ...) are formed where a step
+        // uses them -- one add each -- instead of being hoisted out of the step loop into registers the 64-VGPR cap then spills.
+        int lane_t = lane;
+        if constexpr (kLaunderLane) asm volatile("" : "+v"(lane_t));
         // Issue arbitration between co-resident workgroups is oldest-first, which lets the first one
         // race ahead and leaves the last one alone (latency-bound, 2 waves per SIMD) at the end of a
         // launch.  Lowering a workgroup's priority as it advances (cyclically, every 8 steps) narrows
@@ -518,7 +548,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
             default: __builtin_amdgcn_s_setprio(3); break;
         }
         // ---------------- Chain.update_chain(iters) on every slot (mcmc.py:81-83) -----------
-        uint32_t *stw = st + sid * W * 64 + lane;
+        uint32_t *stw = st + sid * W * 64 + lane_t;
         const uint64_t kbase = a.prop0 + t * iters;
         const bool acc_all = (a.acc_all_mask >> slot_u) & 1u;
         const bool top_logical = (slot_u == (uint32_t)(NC - 1)) && a.thr_logical != 0;
@@ -606,8 +636,8 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
         // ONE Philox word per proposal (word k&3 of block (k>>2, 1), so a block feeds four): its top 20 bits pick the
         // generator, g = floor(x20 * G / 2^20) (the G generators as equally likely as 20 bits allow: G 2^-20; the proposal stays
         // symmetric, so the stationary law is untouched) and its low 12 bits lead the 44-bit acceptance uniform.  Word k&3 of
-        // the refinement block (k>>2, kSubRefine) supplies the other 32 bits, and is computed only when some lane's 12 bits
-        // tie with its threshold's (once in 4096 proposals per lane).
+        // the refinement block (k>>2, kSubRefine) supplies the other 32 bits, and is computed only when some lane_t's 12 bits
+        // tie with its threshold's (once in 4096 proposals per lane_t).
         [[maybe_unused]] auto random_scan_loop = [&]() {
             int ni = DELUT ? (int)(4u * n) : (int)n;
             const uint32_t *myF = thrF + slot_u * 4 - 5;                            // indexed by dE + 4 = 5..8
@@ -632,7 +662,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
                     const uint32_t v = delut[(ev.z & 0xF00u) | F];
                     const uint32_t a12 = xw & 0xFFFu, tI = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(myT - 4) + v);
                     bool acc = a12 < tI;                                            // mcmc.py:42 (dE <= 0: tI = 4096)
-                    if (a12 == tI) {                                                // rare (a lane in 4096): the next 32 bits decide
+                    if (a12 == tI) {                                                // rare (a lane_t in 4096): the next 32 bits decide
                         constexpr int WI = decltype(wsel)::value;
                         const u32x4 r = philox_block(kb - (kq >> 2), kSubRefine, syn, strm, a.seed_lo, a.seed_hi);
                         acc = (WI == 0 ? r.x : WI == 1 ? r.y : WI == 2 ? r.z : r.w) < *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(myF) + v);
@@ -655,7 +685,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
                 const uint32_t dE16 = __popc(__builtin_amdgcn_bitop3_b32(uF, F, nzG, 0xAB));   // ~(uF | F) | nzG;  = dE + 16
                 const uint32_t a12 = xw & 0xFFFu, tI = (myT - 16)[dE16];
                 bool acc = a12 < tI;                                                // mcmc.py:42 (dE <= 0: tI = 4096)
-                if (a12 == tI) {                                                    // rare (a lane in 4096): the next 32 bits decide
+                if (a12 == tI) {                                                    // rare (a lane_t in 4096): the next 32 bits decide
                     constexpr int WI = decltype(wsel)::value;
                     const u32x4 r = philox_block(kb - (kq >> 2), kSubRefine, syn, strm, a.seed_lo, a.seed_hi);
                     acc = (WI == 0 ? r.x : WI == 1 ? r.y : WI == 2 ? r.z : r.w) < (myF - 12)[dE16];
@@ -716,10 +746,10 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
                 // state across steps); a generator move's count change comes from an LDS table indexed by the generator's Pauli
                 // pattern and the four old fields.  The exact test costs eight table look-ups, six fp64 products and a
                 // division, and almost no proposal needs it: log2(p_n / p_b) is lxy (D_x + D_y) + lz D_z with D the count change
-                // since loop entry -- exactly, up to the roundings of the power tables (1e-15) -- so two fp64 fmas and one v_exp_f32 give
+                // since loop entry -- exactly, up to the roundings of the power tables (1e-15) -- so two fmas and one v_exp_f32 give
                 // 2^12 p_n / p_b to 1e-2 of a unit, and only a proposal whose 12 leading uniform bits lie within one unit of
-                // it (3 cells in 4096; the top chain: 2^15 in 2^32) evaluates the reference's expression.  Decisions are those
-                // of the exact test in every case, hence bit-identical to the CPU.
+                // it (3 cells in 4096) evaluates the reference's expression.  Decisions are those of the exact test in every
+                // case, hence bit-identical to the CPU.
                 const int T1 = nq + 1;
                 const double *bt = a.bias_tbl + (size_t)slot_u * 4 * T1;
                 auto weight = [&](uint32_t P) -> double {                           // mcmc_biased.py:28-31 on packed counts
@@ -727,147 +757,230 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
                     return bt[cx] * bt[T1 + (cxy - cx)] * bt[2 * T1 + cz] * bt[3 * T1 + (nq - cxy - cz)];
                 };
                 constexpr uint32_t kFieldBias = 512u | (512u << 10) | (512u << 20);
-                uint32_t Np = xyc[sid * 64 + lane];
-                const uint32_t Nb = Np, NbB = Nb - kFieldBias;                      // counts at loop entry (p_b); ... minus the field offsets
-                const double lxy = a.bias_l2[slot_u][0], lz = a.bias_l2[slot_u][1];
-                const float lxyf = (float)lxy, lzf = (float)lz;
-                // (a count changes by at most 4 per proposal since loop entry)
-                const bool f32ok = 4.0 * (double)iters * __builtin_fmax(__builtin_fabs(lxy), __builtin_fabs(lz)) <= 2000.0;
+                uint32_t Np = xyc[sid * 64 + lane_t];
+                // (the counts at loop entry -- p_b's -- stay in xyc until the step ends: the rare paths read them back from there)
+                auto entry_counts = [&]() -> uint32_t { uint32_t v = xyc[sid * 64 + lane_t]; asm volatile("" : "+v"(v)); return v; };
+                const float lxyf = a.bias_l2f[slot_u][0], lzf = a.bias_l2f[slot_u][1];
+                // (a count changes by at most 4 per proposal since loop entry: the changes stay exact as fp16 integers up to 2048;
+                // the host has checked iters <= 512 and 4 iters max|l| <= 2000 for this rung)
+                const bool f32ok = (a.bias_f32ok >> slot_u) & 1u;
                 uint32_t cdelta = 0;
                 bool any_acc = false;
-                // (the loop is compiled once for the top chain and once for the others: the top chain's logical operators and
-                // four-word blocks stay out of the registers of the seven rungs that do not have them)
-                auto biased_loop = [&](auto top_c) {
-                constexpr bool top = decltype(top_c)::value;
-                const double c0 = (top ? 32.0 : 12.0) - 512.0 * (lxy + lz);         // scales the ratio by 2^32 / 2^12, removes the offsets
-                [[maybe_unused]] const int LW = (L + 1) * W;
-                // one proposal.  top: x = block (k, 0) = select | generator or logical fields | acceptance word | Z position;
-                // non-top: x.x = word k&3 (= WI) of block (k>>2, 1) (+ its refinement)
-                auto one = [&](const uint64_t k, const u32x4 x, auto wsel) {
-                    const bool logical = top && x.x <= thrL1;                       // mcmc.py:23
-                    uint32_t Nn, cd = 0;                                            // the proposal's packed counts; its class change
-                    uint32_t *sad[4] = {stw, stw, stw, stw};
-                    uint32_t ssh[4] = {0, 0, 0, 0};
-                    const uint32_t *m0 = lml + L * W, *m1 = m0;                     // identity rows (LDS copy of the plan's masks)
-                    if (logical) {
-                        const uint32_t op = x.y >> 30;                              // xzzx_model.py:346 / rotated_surface_model.py:334
-                        const uint32_t xp = ((op ^ (op >> 1)) & 1u) ? scale_low30(x.y, L) : 0u;   // drawn iff op in {1,2}
-                        const uint32_t zp = (op >> 1) ? scale_u16(x.w >> 16, L) : 0u;             // drawn iff op in {3,2}
-                        // applied operators: xzzx X iff op in {1,2}, Z iff op in {3,2}; rotated X iff op in {1,3}, Z iff op in {2,3}
-                        const uint32_t ax = CODE == kCodeXzzx ? ((op ^ (op >> 1)) & 1u) : (op & 1u);
-                        const uint32_t az = op >> 1;
-                        cd = ax | (az << 1);
-                        if (CODE == kCodeXzzx) {
-                            m0 = lml + cd * W;                                      // the product's mask (rows 0 .. 3: I, X, Z, XZ)
-                        } else {
-                            if (ax) m0 = lml + xp * W;                              // kind 0: X on column X_pos
-                            if (az) m1 = lml + LW + zp * W;                         // kind 1: Z on row Z_pos
-                        }
-                        int cx = 0, cy = 0, cz = 0;                                 // the operator moves O(L) sites: recount the result
-                        if (CODE == kCodeXzzx) { for (int w = 0; w < W; ++w) count_xyz(stw[w * 64] ^ m0[w], cx, cy, cz); }
-                        else { for (int w = 0; w < W; ++w) count_xyz(stw[w * 64] ^ m0[w] ^ m1[w], cx, cy, cz); }
-                        Nn = (uint32_t)cx | ((uint32_t)cz << 10) | ((uint32_t)(cx + cy) << 20);
-                    } else {
-                        // the expanded entry gives each site's LDS address with one add and its field with one bfe
-                        const uint4 ev = gen_entry(top ? scale_u32(x.y, a.n_gen) : pick_top20(x.x, a.n_gen));
-                        ssh[0] = ev.x; ssh[1] = ev.y; ssh[2] = ev.z; ssh[3] = ev.w;
-                        uint32_t f[4];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            sad[i] = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(stw) + (ssh[i] >> 16));
-                            f[i] = bfe2_lo5(*sad[i], ssh[i]);                       // (an unused entry reads site 0 and applies no Pauli)
-                        }
-                        const uint32_t F = lshl_or(lshl_or(f[3], 2, f[2]), 4, lshl_or(f[1], 2, f[0]));
-                        Nn = Np + xlut[(ev.y & 0xF00u) | F];                        // pattern id << 8 | old fields -> the count change
-                    }
-                    const uint32_t cand = Nn - NbB;                                 // the counts' change since loop entry, every field + 512
-                    float e;                                                        // 2^12 (top: 2^32) p_n / p_b
-                    if (!top && f32ok) {
+                // 2^12 p_n / p_b, to 1e-2 of a unit, from the packed counts of the proposal
+                auto ratio12_packed = [&](uint32_t Nn, uint32_t Nb) -> float {
+                    const uint32_t cand = Nn - (Nb - kFieldBias);                   // the counts' change since loop entry, every field + 512
+                    const uint32_t cx = cand ^ kFieldBias;                          // ... as 10-bit two's complement fields
+                    const int dxyi = __builtin_amdgcn_sbfe((int)cx, 20u, 10u), dzi = __builtin_amdgcn_sbfe((int)cx, 10u, 10u);
+                    if (f32ok) {
                         // single precision is enough for the 12-bit comparison once the offsets are out (a field + 512 with its top bit
                         // flipped is the change in 10-bit two's complement): the products are exact inside the fmas, the roundings are
                         // those of l as a float (6e-8 |l d|) and of a partial sum of magnitude <= |l d| + 12, so with |l d| <= 2000 the
                         // error of the exponent stays below 2.5e-4 / 0.7 of a unit at e = 4096; a unit is what the margins below allow
-                        const uint32_t cx = cand ^ kFieldBias;
-                        const float dxy = (float)(int)__builtin_amdgcn_sbfe((int)cx, 20u, 10u), dzz = (float)(int)__builtin_amdgcn_sbfe((int)cx, 10u, 10u);
-                        e = __builtin_amdgcn_exp2f(__builtin_fmaf(lxyf, dxy, __builtin_fmaf(lzf, dzz, 12.0f)));
-                    } else {
-                        const double tl = __builtin_fma(lxy, (double)(cand >> 20), __builtin_fma(lz, (double)((cand >> 10) & 1023u), c0));
-                        e = __builtin_amdgcn_exp2f((float)tl);                      // relative error < 1e-6
+                        return __builtin_amdgcn_exp2f(__builtin_fmaf(lxyf, (float)dxyi, __builtin_fmaf(lzf, (float)dzi, 12.0f)));
                     }
-                    bool acc, amb;
-                    uint32_t a12 = 0;
-                    if constexpr (top) {
-                        // u = x.z 2^-32 < ratio: certain when x.z + 2^14 <= e (e is within 2^13 of 2^32 ratio: float rounding of a
-                        // value below 32 and the 1-ulp exp), impossible when x.z >= e + 2^14
-                        const uint32_t tI = (uint32_t)fminf(e, 4294901760.0f);     // <= 2^32 - 2^16: the sums below cannot wrap
-                        acc = tI >= 16384u && x.z <= tI - 16384u;
-                        amb = !acc && (x.z < tI + 16384u || tI >= 4294901760u);     // (a clamped e says nothing about words above it)
-                    } else {
-                        // u in [a12, a12 + 1) 2^-12: below the ratio for certain when a12 + 2 <= floor(e), above when a12 >= floor(e) + 2
-                        const uint32_t tI = (uint32_t)fminf(e, 8192.0f);
-                        a12 = x.x & 0xFFFu;
-                        acc = a12 + 2u <= tI;
-                        amb = !acc && a12 <= tI + 1u;
-                    }
-                    if (amb) {
-                        const double ratio = weight(Nn) / weight(Nb);               // mcmc_biased.py:44-46
-                        if constexpr (top) {
-                            acc = (double)x.z * (1.0 / 4294967296.0) < ratio;
-                        } else {
-                            // u = (a12 2^32 + w) 2^-44 with w the proposal's word of the refinement block, needed only when the 12
-                            // leading bits do not decide
-                            const double ulo = (double)a12 * (1.0 / 4096.0);
-                            acc = ulo + (1.0 / 4096.0) <= ratio;
-                            if (!acc && ulo < ratio) {
-                                constexpr int WI = decltype(wsel)::value;
-                                const u32x4 r = philox_block(k >> 2, kSubRefine, syn, strm, a.seed_lo, a.seed_hi);
-                                const uint64_t v44 = ((uint64_t)a12 << 32) | (WI == 0 ? r.x : WI == 1 ? r.y : WI == 2 ? r.z : r.w);
-                                acc = (double)v44 * (1.0 / 17592186044416.0) < ratio;
-                            }
-                        }
-                    }
-                    if (acc) {
-                        if (logical) {
-                            if (CODE == kCodeXzzx) { for (int w = 0; w < W; ++w) lds_xor(stw + w * 64, m0[w]); }
-                            else { for (int w = 0; w < W; ++w) lds_xor(stw + w * 64, m0[w] ^ m1[w]); }
-                            cdelta ^= cd;
-                        } else {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i)                             // (byte 1 of sites 0, 2, 3 is the site's Pauli: one SDWA shift)
-                                lds_xor(sad[i], i == 1 ? shl_lo5((ssh[i] >> 5) & 3u, ssh[i]) : shl_byte1(ssh[i], ssh[i]));
-                        }
-                        Np = Nn;
-                        any_acc = true;
-                    }
+                    const double tl = __builtin_fma(a.bias_l2[slot_u][0], (double)dxyi, __builtin_fma(a.bias_l2[slot_u][1], (double)dzi, 12.0));
+                    return __builtin_amdgcn_exp2f((float)tl);                       // relative error < 1e-6
                 };
-                if constexpr (top) {
-                    // (drawing the next proposal's block ahead, behind this one's LDS reads: -1 %)
-                    for (uint32_t j = 0; j < iters; ++j)
-                        one(kbase + j, philox_block(kbase + j, 0, syn, strm, a.seed_lo, a.seed_hi), std::integral_constant<int, 0>{});
-                } else {
+                // The test u < p_n / p_b on the 44-bit uniform u = (a12 2^32 + w) 2^-44 (philox.hpp): a12 = the proposal word's low 12
+                // bits, e = 2^12 p_n / p_b within a unit.  u lies in [a12, a12 + 1) 2^-12: below the ratio for certain when
+                // a12 + 2 <= e, above when a12 - 1 > e (for an integer i, i <= floor(e) <=> i <= e: the comparisons stay in floating
+                // point, exact on 12-bit integers).  In between (3 cells in 4096) the reference's expression decides, and only a true
+                // 12-bit tie draws w = refine(), the proposal's word of the refinement block.
+                auto test12 = [&](float e, uint32_t word, uint32_t Nn, auto &&refine) -> bool {
+                    const uint32_t a12 = word & 0xFFFu;
+                    const float af = (float)a12;
+                    bool acc = af + 2.0f <= e;
+                    if (!acc && af - 1.0f <= e) {
+                        const double ratio = weight(Nn) / weight(entry_counts());   // mcmc_biased.py:44-46 (p_b's table addresses stay out of the hot loop)
+                        const double ulo = (double)a12 * (1.0 / 4096.0);
+                        acc = ulo + (1.0 / 4096.0) <= ratio;
+                        if (!acc && ulo < ratio) {
+                            const uint64_t v44 = ((uint64_t)a12 << 32) | refine();
+                            acc = (double)v44 * (1.0 / 17592186044416.0) < ratio;
+                        }
+                    }
+                    return acc;
+                };
+                // a generator's four sites: LDS addresses, table words (shift / Pauli), old fields as F = f3 f2 f1 f0
+                auto sites = [&](const uint4 ev, uint32_t *(&sad)[4], uint32_t (&ssh)[4]) -> uint32_t {
+                    ssh[0] = ev.x; ssh[1] = ev.y; ssh[2] = ev.z; ssh[3] = ev.w;
+                    uint32_t f[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        sad[i] = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(stw) + (ssh[i] >> 16));   // the expanded entry: one add
+                        f[i] = bfe2_lo5(*sad[i], ssh[i]);                           // (an unused entry reads site 0 and applies no Pauli)
+                    }
+                    return lshl_or(lshl_or(f[3], 2, f[2]), 4, lshl_or(f[1], 2, f[0]));
+                };
+                auto apply_gen = [&](uint32_t *const (&sad)[4], const uint32_t (&ssh)[4]) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)                                     // (byte 1 of sites 0, 2, 3 is the site's Pauli: one SDWA shift)
+                        lds_xor(sad[i], i == 1 ? shl_lo5((ssh[i] >> 5) & 3u, ssh[i]) : shl_byte1(ssh[i], ssh[i]));
+                };
+                if (!top) {
+                    // ---- non-top chains: word k&3 of block (k>>2, 1): 20 bits pick the generator, 12 lead the acceptance uniform.
+                    // The count change since loop entry rides along as two fp16 integers (D_xy | D_z): one packed add forms the
+                    // proposal's, two mixed-precision fmas its exponent.
+                    typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+                    half2_t Dh = {(_Float16)0.0f, (_Float16)0.0f};
+                    auto one = [&](uint32_t xw, uint64_t kb, auto wsel) {
+                        uint32_t gi = (uint32_t)__mul24((int)(xw >> 12), (int)a.n_gen) >> 20;   // (20-bit field x 11-bit count: the full-rate multiply)
+                        asm("" : "+v"(gi));
+                        const uint4 ev = gen_entry(gi);
+                        uint32_t *sad[4];
+                        uint32_t ssh[4];
+                        const uint32_t F = sites(ev, sad, ssh);
+                        const uint2 d = xlut[(ev.y & 0xF00u) | F];                  // pattern id << 8 | old fields -> the count change
+                        const uint32_t Nn = Np + d.x;
+                        const half2_t pD = Dh + __builtin_bit_cast(half2_t, d.y);
+                        const float e = f32ok ? __builtin_amdgcn_exp2f(__builtin_fmaf((float)pD.x, lxyf, __builtin_fmaf((float)pD.y, lzf, 12.0f)))
+                                              : ratio12_packed(Nn, entry_counts());
+                        const bool acc = test12(e, xw, Nn, [&]() -> uint32_t {
+                            constexpr int WI = decltype(wsel)::value;
+                            const u32x4 r = philox_block(kb, kSubRefine, syn, strm, a.seed_lo, a.seed_hi);
+                            return WI == 0 ? r.x : WI == 1 ? r.y : WI == 2 ? r.z : r.w;
+                        });
+                        if (acc) {
+                            apply_gen(sad, ssh);
+                            Np = Nn;
+                            Dh = pD;
+                            any_acc = true;
+                        }
+                    };
                     // the blocks that overlap [kbase, kbase + iters), a static word index per proposal (+1 % against a rolled loop with a
                     // dynamic word select); the current block lives in `carry`, so the one a step ends in is still there for the next step
                     uint64_t kb = kbase >> 2;
                     for (int jb = -(int)((uint32_t)kbase & 3u); jb < (int)iters; jb += 4, ++kb) {
                         if (kb != carry_kb) { carry = philox_block(kb, 1, syn, strm, a.seed_lo, a.seed_hi); carry_kb = kb; }
-                        const uint64_t k4 = kb << 2;
-                        if ((uint32_t)jb < iters) one(k4, u32x4{carry.x, 0, 0, 0}, std::integral_constant<int, 0>{});
-                        if ((uint32_t)(jb + 1) < iters) one(k4 + 1, u32x4{carry.y, 0, 0, 0}, std::integral_constant<int, 1>{});
-                        if ((uint32_t)(jb + 2) < iters) one(k4 + 2, u32x4{carry.z, 0, 0, 0}, std::integral_constant<int, 2>{});
-                        if ((uint32_t)(jb + 3) < iters) one(k4 + 3, u32x4{carry.w, 0, 0, 0}, std::integral_constant<int, 3>{});
+                        if ((uint32_t)jb < iters) one(carry.x, kb, std::integral_constant<int, 0>{});
+                        if ((uint32_t)(jb + 1) < iters) one(carry.y, kb, std::integral_constant<int, 1>{});
+                        if ((uint32_t)(jb + 2) < iters) one(carry.z, kb, std::integral_constant<int, 2>{});
+                        if ((uint32_t)(jb + 3) < iters) one(carry.w, kb, std::integral_constant<int, 3>{});
+                    }
+                } else {
+                    // ---- the top chain (mcmc_biased.py:32-46): two proposals per block (k >> 1, kSubTopPair), words A, B (philox.hpp):
+                    // A[31:16] selects logical / generator, op = A[15:14], X_pos from A[13:0], Z_pos from B[31:16]; B's top 20 bits pick
+                    // the generator and its low 12 bits lead the acceptance uniform, as in a non-top word.
+                    //
+                    // xzzx: the logical operators do not depend on a position (X on the anti-diagonal, Z on the diagonal,
+                    // xzzx_model.py:291-311), so a logical proposal is O(1): the wave keeps R[d] = the packed counts of (state ^ mask_d)
+                    // for the four products d = I, X, Z, XZ relative to the state the chain is in -- recounted when the step begins,
+                    // updated by every accepted generator move with three more look-ups (the fields under mask d are F ^ M_d, M_d =
+                    // the operator's fields at the generator's sites, mtab) -- so the proposal's counts are R[cd] and an accepted one
+                    // permutes R.  The accepted operators are collected in a frame `fr` (the LDS state lags by mask_fr, so the fields
+                    // read from it are corrected by M_fr) and applied once, when the step ends.
+                    [[maybe_unused]] uint32_t fr8 = 0;                                // the frame, times 8 (a byte select of mtab's word)
+                    [[maybe_unused]] uint32_t *rkl = rk + lane_t;                      // R[1 .. 3] at rkl[0], rkl[64], rkl[128]
+                    const uint32_t Nb = Np;
+                    [[maybe_unused]] const int LW = (L + 1) * W;
+                    if constexpr (CODE == kCodeXzzx) {
+                        uint32_t c1x = 0, c1z = 0, c1s = 0, c2x = 0, c2z = 0, c2s = 0, c3x = 0, c3z = 0, c3s = 0;
+                        auto cnt = [](uint32_t v, uint32_t &cx, uint32_t &cz, uint32_t &cs) {
+                            const uint32_t h = v >> 1;
+                            cx += __popc(__builtin_amdgcn_bitop3_b32(v, h, 0x55555555u, 0x20));   // v & ~h & m: X
+                            cz += __popc(__builtin_amdgcn_bitop3_b32(v, h, 0x55555555u, 0x80));   // v & h & m:  Z
+                            cs += __popc(__builtin_amdgcn_bitop3_b32(v, h, 0x55555555u, 0x28));   // (v ^ h) & m: X or Y
+                        };
+                        for (int w = 0; w < W; ++w) {
+                            const uint32_t v = stw[w * 64], mx = lml[W + w], mz = lml[2 * W + w];   // rows 0 .. 3: I, X, Z, XZ
+                            cnt(v ^ mx, c1x, c1z, c1s);
+                            cnt(v ^ mz, c2x, c2z, c2s);
+                            cnt(v ^ mx ^ mz, c3x, c3z, c3s);
+                        }
+                        rkl[0] = c1x | (c1z << 10) | (c1s << 20); rkl[64] = c2x | (c2z << 10) | (c2s << 20); rkl[128] = c3x | (c3z << 10) | (c3s << 20);
+                    }
+                    auto one = [&](uint32_t A, uint32_t B, uint64_t kb, auto wsel) {
+                        const bool logical = A <= thrA1;                            // mcmc.py:23 (A[31:16] < ceil(p_logical 2^16))
+                        const uint32_t op = (A >> 14) & 3u;                         // xzzx_model.py:346 / rotated_surface_model.py:334
+                        // applied operators: xzzx X iff op in {1,2}, Z iff op in {3,2}; rotated X iff op in {1,3}, Z iff op in {2,3}
+                        const uint32_t ax = CODE == kCodeXzzx ? ((op ^ (op >> 1)) & 1u) : (op & 1u), az = op >> 1;
+                        const uint32_t cd = ax | (az << 1);
+                        uint32_t gi = (uint32_t)__mul24((int)(B >> 12), (int)a.n_gen) >> 20;
+                        asm("" : "+v"(gi));
+                        uint32_t *sad[4] = {stw, stw, stw, stw};
+                        uint32_t ssh[4] = {0, 0, 0, 0};
+                        uint32_t Nn, idx0 = 0, mw = 0;
+                        [[maybe_unused]] const uint32_t *m0 = lml + L * W, *m1 = m0;   // identity rows (LDS copy of the plan's masks)
+                        if constexpr (CODE == kCodeXzzx) {
+                            // branch-free: every lane_t reads its generator (harmless where the proposal is a logical operator)
+                            const uint4 ev = gen_entry(gi);
+                            mw = mtab[gi];
+                            const uint32_t F = sites(ev, sad, ssh);
+                            idx0 = (ev.y & 0xF00u) | (F ^ __builtin_amdgcn_ubfe(mw, fr8, 8u));   // the fields of the chain's state: LDS ^ M_fr
+                            const uint32_t Ngen = Np + xlut[idx0].x;
+                            const uint32_t Rcd = rkl[((cd ? cd : 1u) - 1u) * 64u];
+                            const uint32_t Nlog = cd ? Rcd : Np;
+                            Nn = logical ? Nlog : Ngen;
+                        } else if (logical) {
+                            const uint32_t xp = ((op ^ (op >> 1)) & 1u) ? ((A & 0x3FFFu) * (uint32_t)L) >> 14 : 0u;   // drawn iff op in {1,2}
+                            const uint32_t zp = (op >> 1) ? scale_u16(B >> 16, L) : 0u;                               // drawn iff op in {3,2}
+                            if (ax) m0 = lml + xp * W;                              // kind 0: X on column X_pos
+                            if (az) m1 = lml + LW + zp * W;                         // kind 1: Z on row Z_pos
+                            int cx = 0, cy = 0, cz = 0;                             // the operator moves O(L) sites: recount the result
+                            for (int w = 0; w < W; ++w) count_xyz(stw[w * 64] ^ m0[w] ^ m1[w], cx, cy, cz);
+                            Nn = (uint32_t)cx | ((uint32_t)cz << 10) | ((uint32_t)(cx + cy) << 20);
+                        } else {
+                            const uint4 ev = gen_entry(gi);
+                            const uint32_t F = sites(ev, sad, ssh);
+                            Nn = Np + xlut[(ev.y & 0xF00u) | F].x;
+                        }
+                        const bool acc = test12(ratio12_packed(Nn, Nb), B, Nn, [&]() -> uint32_t {
+                            constexpr int WI = decltype(wsel)::value;               // 1 or 3: the word B's index
+                            const u32x4 r = philox_block(kb, kSubRefine, syn, strm, a.seed_lo, a.seed_hi);
+                            return WI == 1 ? r.y : r.w;
+                        });
+                        if (acc) {
+                            any_acc = true;
+                            if (logical) {
+                                if constexpr (CODE == kCodeXzzx) {
+                                    // R'[d] = R[d ^ cd]: two conditional pair swaps
+                                    const bool s1 = (cd & 1u) != 0, s2 = (cd & 2u) != 0;
+                                    uint32_t r0 = Np, r1 = rkl[0], r2 = rkl[64], r3 = rkl[128];
+                                    { const uint32_t t0 = s1 ? r1 : r0, t1 = s1 ? r0 : r1, t2 = s1 ? r3 : r2, t3 = s1 ? r2 : r3; r0 = t0; r1 = t1; r2 = t2; r3 = t3; }
+                                    { const uint32_t t0 = s2 ? r2 : r0, t1 = s2 ? r3 : r1, t2 = s2 ? r0 : r2, t3 = s2 ? r1 : r3; r0 = t0; r1 = t1; r2 = t2; r3 = t3; }
+                                    Np = r0; rkl[0] = r1; rkl[64] = r2; rkl[128] = r3;
+                                    fr8 ^= cd << 3;
+                                } else {
+                                    for (int w = 0; w < W; ++w) lds_xor(stw + w * 64, m0[w] ^ m1[w]);
+                                    Np = Nn;
+                                }
+                                cdelta ^= cd;
+                            } else {
+                                apply_gen(sad, ssh);
+                                Np = Nn;
+                                if constexpr (CODE == kCodeXzzx) {
+                                    // idx0 carries the chain's fields: those under mask d are F ^ M_d
+                                    __hip_atomic_fetch_add(rkl, xlut[idx0 ^ ((mw >> 8) & 0xFFu)].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    __hip_atomic_fetch_add(rkl + 64, xlut[idx0 ^ ((mw >> 16) & 0xFFu)].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    __hip_atomic_fetch_add(rkl + 128, xlut[idx0 ^ (mw >> 24)].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                }
+                            }
+                        }
+                    };
+                    // the packed blocks that overlap [kbase, kbase + iters): the first may start at its second proposal, the last may
+                    // end at its first (wave-uniform)
+                    const uint64_t b0 = kbase >> 1;
+                    const bool skip_first = (kbase & 1) != 0, skip_last = ((kbase + iters) & 1) != 0;
+                    const uint32_t nblk = (uint32_t)(((kbase + iters - 1) >> 1) - b0) + 1u;
+                    for (uint32_t bi = 0; bi < nblk; ++bi) {
+                        const u32x4 x = philox_block(b0 + bi, kSubTopPair, syn, strm, a.seed_lo, a.seed_hi);
+                        if (!(skip_first && bi == 0)) one(x.x, x.y, b0 + bi, std::integral_constant<int, 1>{});
+                        if (!(skip_last && bi == nblk - 1)) one(x.z, x.w, b0 + bi, std::integral_constant<int, 3>{});
+                    }
+                    if constexpr (CODE == kCodeXzzx) {
+                        // the step's accepted logical operators, applied at once (row fr of the product masks; row 0 = identity)
+                        const uint32_t *mf = lml + (fr8 >> 3) * W;
+                        for (int w = 0; w < W; ++w) lds_xor(stw + w * 64, mf[w]);
                     }
                 }
-                };
-                if (top) biased_loop(std::true_type{});
-                else biased_loop(std::false_type{});
-                xyc[sid * 64 + lane] = Np;
+                xyc[sid * 64 + lane_t] = Np;
                 n = (Np >> 20) + ((Np >> 10) & 1023u);
                 cls ^= cdelta;
                 // the slot's n_eff is refreshed by accepted moves only (mcmc_alpha.py:58,70); otherwise it keeps the
                 // value it had, possibly that of a configuration since swapped away (quirk Q4)
                 if (alpha_noise)
-                    neffb[((t & 1) * NC + slot_u) * 64 + lane] = any_acc ? (((Np >> 10) & 1023u) | ((Np >> 20) << 16))
-                                                                         : neffb[(((t & 1) ^ 1) * NC + slot_u) * 64 + lane];
+                    neffb[((t & 1) * NC + slot_u) * 64 + lane_t] = any_acc ? (((Np >> 10) & 1023u) | ((Np >> 20) << 16))
+                                                                         : neffb[(((t & 1) ^ 1) * NC + slot_u) * 64 + lane_t];
             } else {
             const bool xyz_rule = USET && a.xyz_thr != nullptr;                     // Chain_xyz: the general path with its own table
             if (!SCAN && !top && CODE != kCodeToric && !xyz_rule) {
@@ -915,7 +1028,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
                 blind_sweep_tables();
             } else if (top && acc_all) {
                 // random scan, top chain at f = 1 (mcmc.py:30): every proposal is applied blindly, n recounted once.  With a row
-                // of the lattice inside one word (L <= 16) the logical operators are collected in a per-lane frame and applied
+                // of the lattice inside one word (L <= 16) the logical operators are collected in a per-lane_t frame and applied
                 // once per step, as on the toric code: xzzx -- parities of the (position-independent) anti-diagonal X and
                 // diagonal Z; rotated -- the set of X columns and of Z rows; planar -- the X rows and Z columns of layer 0.
                 uint32_t cdelta = 0, frX = 0, frZ = 0;
@@ -929,7 +1042,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
                             frX ^= CODE == kCodeXzzx ? ax : ax << xp;
                             frZ ^= CODE == kCodeXzzx ? az : az << zp;
                         } else {
-                            // the operator's L + L sites, generated on the fly (per-lane positions would make the plan's mask rows
+                            // the operator's L + L sites, generated on the fly (per-lane_t positions would make the plan's mask rows
                             // 2 W scattered global loads per proposal): xzzx -- X on the anti-diagonal, Z on the diagonal
                             // (xzzx_model.py:291-311); rotated -- X on column X_pos, Z on row Z_pos (rotated_surface_model.py:260-280);
                             // planar -- X on row X_pos, Z on column Z_pos of layer 0 (planar_model.py:264-268)
@@ -1233,7 +1346,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
         } else if (acc_all && L <= 16) {
             // Top chain at p = 0.75: every proposal is accepted (mcmc.py:30), so moves are blind
             // XORs and commute.  Stabilizers go straight to LDS; logical operators are collected
-            // in a per-lane frame (which rows / columns carry an operator) and flushed once.
+            // in a per-lane_t frame (which rows / columns carry an operator) and flushed once.
             //   fr0: bit r      = X on row r of layer 0      bit 16+c = Z on column c of layer 0
             //   fr1: bit c      = X on column c of layer 1   bit 16+r = Z on row r of layer 1
             uint32_t fr0 = 0, fr1 = 0, cdelta = 0;
@@ -1398,7 +1511,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
 
         // ---------------- swap sweep, Ladder.step mcmc.py:96-103 --------------------------------
         // (double-buffered by step parity: a fast wave may publish step t+1 while a slow one still reads step t)
-        uint32_t *cur = info + (t & 1) * NC * 64 + lane, *sx = swx + (t & 1) * NC * 64 + lane;
+        uint32_t *cur = info + (t & 1) * NC * 64 + lane_t, *sx = swx + (t & 1) * NC * 64 + lane_t;
         cur[slot_u * 64] = pack_info(n, sid, cls, flag);
         if constexpr (PRE) {
             // the wave on slot 1 becomes the top chain two steps from now, the wave on slot 0 next step: each draws half of that
@@ -1474,7 +1587,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
                 const int d = (int)(hi & 0xFFFFu) - (int)(lo & 0xFFFFu);           // ne_hi - ne_lo
                 if (BIASED && alpha_noise) {
                     // Ladder_alpha.r_flip, mcmc_alpha.py:118-123: slot-bound n_eff, always draws
-                    const uint32_t *ne = neffb + (t & 1) * NC * 64 + lane;
+                    const uint32_t *ne = neffb + (t & 1) * NC * 64 + lane_t;
                     const int ic = i < 0 ? 0 : i;
                     return alpha_flip(xi, ne[(ic + 1) * 64], ne[ic * 64], a.alpha, a.alpha_lnb[ic]);
                 }
@@ -1490,7 +1603,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
             };
             uint32_t car = cur[(NC - 1) * 64], mine = car;
             if constexpr (SSW) {
-                uint32_t *nxt = info + ((t + 1) & 1) * NC * 64 + lane;             // the other parity's records: idle until the waves publish step t+1
+                uint32_t *nxt = info + ((t + 1) & 1) * NC * 64 + lane_t;             // the other parity's records: idle until the waves publish step t+1
                 if (wave_u == 0) {
                     // the other seven waves wait for this sweep: it runs at the highest issue priority.  Afterwards wave 0 drops to the lowest
                     // until the next step sets the workgroup's level again on the toric / planar codes (its bookkeeping then yields to
@@ -1542,14 +1655,14 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
                 const uint32_t n0 = car & 0xFFFFu;
                 if (a.counts != nullptr && tops0 >= a.tops_burn) {                  // decoders.py:60-67
                     const uint32_t v = (car >> 24) & 0x3Fu;
-                    hist[(CODE == kCodeXzzx ? (v ^ (v >> 1)) : v) * 64 + lane] += 1;
+                    hist[(CODE == kCodeXzzx ? (v ^ (v >> 1)) : v) * 64 + lane_t] += 1;
                     samples++;
                     if (CONV && BIASED && alpha_noise) {
                         // nbr_errors_bottom_chain[since_burn] = chains[0].n_eff (decoders_biasednoise.py:204): slot 0's
                         // attribute, logged as its two counts; the window sums stay exact integers
-                        if (lane < cnt) {
-                            uint32_t *mylog = reinterpret_cast<uint32_t *>(a.nlog) + (s0 + lane);
-                            const uint32_t v0 = neffb[(t & 1) * NC * 64 + lane];
+                        if (lane_t < cnt) {
+                            uint32_t *mylog = reinterpret_cast<uint32_t *>(a.nlog) + (s0 + lane_t);
+                            const uint32_t v0 = neffb[(t & 1) * NC * 64 + lane_t];
                             mylog[(size_t)t * a.N] = v0;
                             const uint32_t l = samples, lo1 = l - 1;
                             const uint32_t a0 = lo1 >> 2, b0 = lo1 >> 1, c0 = (3u * lo1) >> 2, a1 = l >> 2, b1 = l >> 1, c1 = (3u * l) >> 2;
@@ -1559,11 +1672,11 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
                             if (a1 != a0) { const uint32_t v = mylog[(size_t)(burn + a0) * a.N]; sumA -= v & 0xFFFFu; sumAxy -= v >> 16; }
                         }
                     } else
-                    if (CONV && (QUEUE ? !q_dead : lane < cnt)) {
+                    if (CONV && (QUEUE ? !q_dead : lane_t < cnt)) {
                         // nbr_errors_bottom_chain[since_burn] = count_errors (:68); series index i lives in log row burn+i
-                        // (QUEUE: one log column per lane of the persistent grid, rows = the ladder's own steps)
+                        // (QUEUE: one log column per lane_t of the persistent grid, rows = the ladder's own steps)
                         const size_t lN = QUEUE ? (size_t)gridDim.x * 64u : (size_t)a.N;
-                        uint16_t *mylog = a.nlog + (s0 + lane);
+                        uint16_t *mylog = a.nlog + (s0 + lane_t);
                         mylog[(size_t)(t - t0) * lN] = (uint16_t)n0;
                         const uint32_t l = samples, lo1 = l - 1;
                         const uint32_t a0 = lo1 >> 2, b0 = lo1 >> 1, c0 = (3u * lo1) >> 2, a1 = l >> 2, b1 = l >> 1, c1 = (3u * l) >> 2;
@@ -1596,8 +1709,8 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
             }
             if (a.swap_acc != nullptr && wave_u == 0) {
                 // equilibrium observables (qecmc_plan_set_stats): the cascade once more, with every rung's decision and the error
-                // count each rung ends the step with added to per-lane LDS counters (off the hot path: one scalar branch when off)
-                uint32_t *sacc = lds_all + gdw + lane, *nsum = sacc + NC * 64;
+                // count each rung ends the step with added to per-lane_t LDS counters (off the hot path: one scalar branch when off)
+                uint32_t *sacc = lds_all + gdw + lane_t, *nsum = sacc + NC * 64;
                 uint32_t c2 = cur[(NC - 1) * 64];
                 for (int i = NC - 2; i >= 0; --i) {
                     const uint32_t lo = cur[i * 64], xi = sx[i * 64];
@@ -1617,8 +1730,8 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
                     if (!q_dead && done && !q_flushed) {
                         const uint64_t row = (uint64_t)qi / R;
                         for (int c = 0; c < ncls; ++c) {
-                            const uint32_t v = hist[c * 64 + lane];
-                            hist[c * 64 + lane] = 0;
+                            const uint32_t v = hist[c * 64 + lane_t];
+                            hist[c * 64 + lane_t] = 0;
                             if (R > 1) { if (v) atomicAdd(a.counts + row * ncls + c, v); }
                             else a.counts[row * ncls + c] = v;
                         }
@@ -1642,7 +1755,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
                     f0[2 + ((t + 1) & 1)] = (!q_empty && __any(done && !q_dead) && ((t + 2) % q_period) == 0) ? 1u : 0u;
                 }
             } else
-            if (CONV && wave_u == 0 && __all(done || lane >= cnt)) stopf[(t + 1) & 1] = 1;
+            if (CONV && wave_u == 0 && __all(done || lane_t >= cnt)) stopf[(t + 1) & 1] = 1;
             if (slot_u == 0) flag = 0;                                              // :103
             if constexpr (USET) {
                 const bool cm = a.uset_conv_mult != 0.0;
@@ -1650,18 +1763,18 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
                     // the stop test that ends step t-1 (decoders.py:159-162, :261-262, :825-826), now that every rung's
                     // insertion of that step is behind this step's barrier
                     const uint32_t tp = (uint32_t)t - 1u;
-                    if (cm_trig[(tp & 1u) * 64 + lane] == tp) cm_last = tp;         // stop = step * conv_mult, :156
+                    if (cm_trig[(tp & 1u) * 64 + lane_t] == tp) cm_last = tp;         // stop = step * conv_mult, :156
                     if ((double)tp >= (double)cm_last * a.uset_conv_mult && (uint64_t)tp * 100u >= a.nsteps) { cm_done = 1; cm_steps = (uint32_t)t; }
                 }
                 // PTDC_droplet / PTRC_droplet (decoders.py:146-152, :596-618): the configuration now in this wave's rung goes into
                 // the set of chains seen so far.  Key = FNV-1a over the packed words (any collision-free key gives the same N(n)).
-                if (lane < cnt && !cm_done) {
-                    const uint32_t *sw = st + sid * W * 64 + lane;
+                if (lane_t < cnt && !cm_done) {
+                    const uint32_t *sw = st + sid * W * 64 + lane_t;
                     uint64_t h = 0xCBF29CE484222325ull;
                     for (int w = 0; w < W; ++w) h = (h ^ sw[w * 64]) * 0x100000001B3ull;
                     h ^= h >> 32;
                     const unsigned long long key = h ? h : 1ull;
-                    const uint64_t ladder = s0 + (uint64_t)lane;
+                    const uint64_t ladder = s0 + (uint64_t)lane_t;
                     const uint64_t set = a.uset_per_rung ? ladder * (uint64_t)NC + slot_u : ladder / a.uset_D;
                     if (a.uset_mhist != nullptr) atomicAdd(a.uset_mhist + set * (uint64_t)(nq + 1) + n, 1u);
                     unsigned long long *tb = a.uset_tab + set * a.uset_cap;
@@ -1695,10 +1808,10 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
                         }
                         // "if conv_mult and length <= shortest" (:153-156) on the rungs in any order: the step extends the run
                         // iff its shortest new chain is no longer than the shortest seen before, and that rung always passes
-                        if (fresh && n <= atomicMin(&cm_short[lane], n)) cm_trig[((uint32_t)t & 1u) * 64 + lane] = (uint32_t)t;
+                        if (fresh && n <= atomicMin(&cm_short[lane_t], n)) cm_trig[((uint32_t)t & 1u) * 64 + lane_t] = (uint32_t)t;
                     }
                 }
-                if (cm && wave_u == 0 && __all(cm_done || lane >= cnt)) stopf[(t + 1) & 1] = 1;
+                if (cm && wave_u == 0 && __all(cm_done || lane_t >= cnt)) stopf[(t + 1) & 1] = 1;
             }
             if constexpr (QUEUE) {
                 if (q_refill) {                                                     // uniform for the workgroup (read behind the barrier)
@@ -1709,27 +1822,27 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
                         const uint64_t m = __ballot(want);
                         const uint32_t nw = (uint32_t)__popcll(m);
                         uint32_t base = 0;
-                        if (lane == 0 && nw) base = atomicAdd(a.queue, nw);
+                        if (lane_t == 0 && nw) base = atomicAdd(a.queue, nw);
                         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + gridDim.x * 64u;   // the first grid x 64 ladders were handed out at launch
-                        const uint32_t mine = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                        const uint32_t mine = base + (uint32_t)__popcll(m & ((1ull << lane_t) - 1ull));
                         uint32_t nqi = qi, nt0 = t0;
                         if (want) {
                             if ((uint64_t)mine < a.N) { nqi = mine; nt0 = (uint32_t)t + 1u; }
                             else { nqi = 0xFFFFFFFFu; q_dead = true; }
                         }
-                        qidx[lane] = nqi;
-                        qt0[lane] = nt0;
+                        qidx[lane_t] = nqi;
+                        qt0[lane_t] = nt0;
                         if ((uint64_t)base + nw >= a.N) q_empty = true;             // (later finishers retire when they write their results)
                     }
                     __syncthreads();
                     // every wave adopts the assignment and stages its next slot's chain for the lanes that changed ladder
-                    const uint32_t nqi = qidx[lane], nt0 = qt0[lane];
+                    const uint32_t nqi = qidx[lane_t], nt0 = qt0[lane_t];
                     if (nqi != 0xFFFFFFFFu && (nqi != qi || nt0 != t0)) {
                         qi = nqi; t0 = nt0; kq = (uint64_t)t0 * iters;
                         syn = a.first_syndrome + qi;
                         dstrm = kDiagStream + slot_u;                                // its step 0: the slot this wave has just moved to
                         const uint8_t *src = a.init + (uint64_t)(qi / R) * (uint64_t)nq;
-                        const int dbase = (int)slot_u * W * 64 + lane;               // Ladder.__init__: every slot starts from the seed (mcmc.py:72)
+                        const int dbase = (int)slot_u * W * 64 + lane_t;               // Ladder.__init__: every slot starts from the seed (mcmc.py:72)
                         uint32_t cn = 0;
                         for (int w = 0; w < W; ++w) {
                             uint32_t word = 0;

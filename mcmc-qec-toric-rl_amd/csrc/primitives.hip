@@ -108,11 +108,13 @@ __global__ void k_chain_update(const ChainArgs a)
     bool any_acc = false;
     for (uint64_t j = 0; j < a.iters; ++j) {
         const uint64_t k = a.k0 + j;
-        // top: block (k, 0) under the biased rules, the packed block (k >> 1, kSubTopPair) otherwise.  non-top: ONE word, word k&3 of block (k>>2, 1) -- top 20 bits pick the generator, low 12 bits
-        // lead the 44-bit acceptance uniform that word k&3 of block (k>>2, kSubRefine) completes
-        // (the depolarizing top chain packs two proposals into block (k >> 1, kSubTopPair): words A, B = 2 (k & 1), 2 (k & 1) + 1)
-        const bool packed = top && !a.noise;
-        u32x4 x = philox_block(packed ? k >> 1 : top ? k : k >> 2, packed ? kSubTopPair : top ? 0u : 1u, syn, a.slot, a.seed_lo, a.seed_hi);
+        // top: the packed block (k >> 1, kSubTopPair), two proposals per block: words A, B = 2 (k & 1), 2 (k & 1) + 1 (philox.hpp).
+        // non-top: ONE word, word k&3 of block (k>>2, 1) -- top 20 bits pick the generator, low 12 bits lead the 44-bit
+        // acceptance uniform that word k&3 of block (k>>2, kSubRefine) completes.  Under the biased / alpha rules the top chain's
+        // word B is such a word too: its top 20 bits pick the generator (a logical operator: Z_pos = B[31:16]), its low 12 bits
+        // lead the acceptance uniform that word 2 (k & 1) + 1 of block (k >> 1, kSubRefine) completes.
+        const bool packed = top;
+        u32x4 x = philox_block(packed ? k >> 1 : k >> 2, packed ? kSubTopPair : 1u, syn, a.slot, a.seed_lo, a.seed_hi);
         const uint32_t pA = (k & 1) ? x.z : x.x, pB = (k & 1) ? x.w : x.y;
         uint64_t v44 = 0;
         if (!top) {
@@ -120,11 +122,13 @@ __global__ void k_chain_update(const ChainArgs a)
             const int w = (int)(k & 3);
             x.x = w == 0 ? x.x : w == 1 ? x.y : w == 2 ? x.z : x.w;
             v44 = ((uint64_t)(x.x & 0xFFFu) << 32) | (w == 0 ? r.x : w == 1 ? r.y : w == 2 ? r.z : r.w);
+        } else if (a.noise) {
+            const u32x4 r = philox_block(k >> 1, kSubRefine, syn, a.slot, a.seed_lo, a.seed_hi);
+            v44 = ((uint64_t)(pB & 0xFFFu) << 32) | ((k & 1) ? r.w : r.y);
         }
         // ---- propose (in place; XOR moves are involutions, so a rejected move is undone by re-applying it)
         int dE, row = 0, col = 0, op = 0, op0 = 0, op1 = 0, x0 = 0, z0 = 0, x1 = 0, z1 = 0;
-        const bool logical = packed ? (uint64_t)(pA >> 16) < ((a.thr_logical + 65535u) >> 16)    // a 16-bit select: A[31:16] < ceil(p_logical * 2^16)
-                                    : top && (uint64_t)x.x < a.thr_logical;        // mcmc.py:23
+        const bool logical = packed && (uint64_t)(pA >> 16) < ((a.thr_logical + 65535u) >> 16);   // mcmc.py:23 with a 16-bit select: A[31:16] < ceil(p_logical * 2^16)
         if (logical) {
             if (packed && code != kCodeToric) {
                 // A = select[31:16] | op[15:14] | X_pos[13:0];  Z_pos = B[31:16]
@@ -132,7 +136,7 @@ __global__ void k_chain_update(const ChainArgs a)
                 if (op0 == 1 || op0 == 2) x0 = ((pA & 0x3FFFu) * (uint32_t)L) >> 14;
                 if (op0 == 3 || op0 == 2) z0 = scale_u16(pB >> 16, L);
                 dE = surf_apply_logical_b(code, L, m, op0, x0, z0);
-            } else if (packed) {
+            } else {
                 // A = select[31:16] | op0[15:14] | op1[13:12] | X_pos0[11:0];  B = Z_pos0[31:21] | X_pos1[20:10] | Z_pos1[9:0]
                 op0 = (pA >> 14) & 3u; op1 = (pA >> 12) & 3u;                       // toric_model.py:234
                 if (op0 == 1 || op0 == 2) x0 = ((pA & 0xFFFu) * (uint32_t)L) >> 12; // :241-248
@@ -140,34 +144,20 @@ __global__ void k_chain_update(const ChainArgs a)
                 if (op1 == 1 || op1 == 2) x1 = (((pB >> 10) & 0x7FFu) * (uint32_t)L) >> 11;
                 if (op1 == 3 || op1 == 2) z1 = ((pB & 0x3FFu) * (uint32_t)L) >> 10;
                 dE = toric_apply_logical_b(L, m, op0, 0, x0, z0) + toric_apply_logical_b(L, m, op1, 1, x1, z1);
-            } else if (code == kCodeToric) {
-                op0 = x.y >> 30; op1 = x.z >> 30;                                   // toric_model.py:234
-                if (op0 == 1 || op0 == 2) x0 = scale_low30(x.y, L);                 // :241-248 (positions share block (k,0))
-                if (op0 == 3 || op0 == 2) z0 = scale_u16(x.w >> 16, L);
-                if (op1 == 1 || op1 == 2) x1 = scale_low30(x.z, L);
-                if (op1 == 3 || op1 == 2) z1 = scale_u16(x.w & 0xFFFFu, L);
-                dE = toric_apply_logical_b(L, m, op0, 0, x0, z0) + toric_apply_logical_b(L, m, op1, 1, x1, z1);
-            } else {
-                op0 = x.y >> 30;                                                    // xzzx_model.py:346-355
-                if (op0 == 1 || op0 == 2) x0 = scale_low30(x.y, L);
-                if (op0 == 3 || op0 == 2) z0 = scale_u16(x.w >> 16, L);
-                dE = surf_apply_logical_b(code, L, m, op0, x0, z0);
             }
         } else if (code == kCodeToric) {
             // one word picks one of the 2L^2 generators (toric_model.py:291-295): X plaquettes first, row-major
-            const uint32_t g = packed ? scale_u32(pB, 2u * L * L) : top ? scale_u32(x.y, 2u * L * L) : pick_top20(x.x, 2u * L * L), rc = g < (uint32_t)(L * L) ? g : g - L * L;
+            const uint32_t g = packed ? scale_u32(pB, 2u * L * L) : pick_top20(x.x, 2u * L * L), rc = g < (uint32_t)(L * L) ? g : g - L * L;
             row = rc / L; col = rc % L; op = g < (uint32_t)(L * L) ? 1 : 3;
             dE = toric_apply_stabilizer_b(L, m, row, col, op);
         } else {
-            surf_pick(code, L, packed ? pB : top ? x.y : x.x, top, row, col, op);
+            surf_pick(code, L, packed ? pB : x.x, top && !a.noise, row, col, op);   // (depolarizing top chain: the whole word B picks)
             dE = surf_apply_stabilizer_b(code, L, m, row, col, op);
         }
         // ---- accept?
         bool acc;
         if (a.noise) {                                                              // mcmc_biased.py:40-46 / :53-59
-            // top: word 2 of the proposal's own block (the plaquette codes' logical draws leave it unused)
-            const double u = top ? (double)x.z * (1.0 / 4294967296.0)
-                                 : (double)v44 * (1.0 / 17592186044416.0);         // 2^-44, exact
+            const double u = (double)v44 * (1.0 / 17592186044416.0);               // 2^-44, exact
             acc = u < biased_weight_b(a.bias_tbl, nq, m) / pb;
         } else if (top) {                                                           // mcmc.py:30-34
             acc = a.acc_all || dE <= 0;

@@ -242,11 +242,11 @@ int orc_eq_class(int code, int L, const uint8_t *m)
  * top 20 bits pick the generator; its low 12 bits are the leading bits of the acceptance uniform, which continues with
  * word k&3 of the refinement block (k>>2, sub 4): u = (a12 * 2^32 + w) * 2^-44.  (The refinement word matters only when
  * the 12 leading bits do not decide the comparison, once in 4096 proposals; the GPU computes it on demand.)
- * Top chains (mcmc.py:21-35) keep block (k, 0): word 0 selects logical / stabilizer, word 1 picks the generator, words
- * 1-3 carry a logical operator; the acceptance uniform is word 0 of block (k, 2).  The depolarizing top chain in
- * random scan -- whose proposals need no more than two words -- shares a block between two proposals instead: words
- * A, B = 2 (k & 1), 2 (k & 1) + 1 of block (k >> 1, sub 5); A[31:16] selects, B picks the generator, and a logical
- * operator's fields are cut from A[15:0] and B (model_random_logical_ex). */
+ * Top chains (mcmc.py:21-35) in sweep mode keep block (k, 0): word 0 selects logical / stabilizer, word 1 picks the generator,
+ * words 1-3 carry a logical operator; the acceptance uniform is word 0 of block (k, 2).  In random scan a top-chain
+ * proposal needs no more than two words, so two proposals share a block: words A, B = 2 (k & 1), 2 (k & 1) + 1 of block
+ * (k >> 1, sub 5); A[31:16] selects, B picks the generator, and a logical operator's fields are cut from A[15:0] and B
+ * (model_random_logical_ex; the biased / alpha rules: top_accept44 below). */
 static double nontop_accept(const orc_model *m, orc_rng *rng, uint32_t slot, uint64_t k)
 {
     (void)m;
@@ -255,6 +255,25 @@ static double nontop_accept(const orc_model *m, orc_rng *rng, uint32_t slot, uin
     const double lo = orc_draw(rng, slot, k >> 2, ORC_SUB_REFINE, (int)(k & 3));
     rng->consumed--;                                                      /* one uniform */
     return hi + lo * (1.0 / 4096.0);                                      /* exact: 44 bits */
+}
+
+/* The top chain under the biased / alpha rules (mcmc_biased.py:32-46, mcmc_alpha.py:42-58) always draws an acceptance uniform.
+ * Philox mode: like the depolarizing top chain, proposal k owns words A, B = 2 (k & 1), 2 (k & 1) + 1 of block (k >> 1, sub 5):
+ * A[31:16] selects logical / stabilizer, a logical operator's fields are cut from A[15:0] and B[31:16]
+ * (model_random_logical_ex, packed), and B is used like a non-top proposal's word: its top 20 bits pick the generator, its low
+ * 12 bits lead the 44-bit acceptance uniform that word 2 (k & 1) + 1 of the refinement block (k >> 1, sub 4) completes. */
+static double top_accept44(orc_rng *rng, uint32_t slot, uint64_t k)
+{
+    if (rng->mode == 0) return orc_draw(rng, slot, k, 0, 0);              /* injected stream: the next draw */
+    const int wb = 2 * (int)(k & 1) + 1;
+    const double hi = orc_draw_field(rng, slot, k >> 1, 5, wb, 20, 12);
+    const double lo = orc_draw(rng, slot, k >> 1, ORC_SUB_REFINE, wb);
+    rng->consumed--;                                                      /* one uniform */
+    return hi + lo * (1.0 / 4096.0);                                      /* exact: 44 bits */
+}
+static int top_select_logical(orc_rng *rng, uint32_t slot, uint64_t k, double p_logical)
+{
+    return orc_draw_field(rng, slot, k >> 1, 5, 2 * (int)(k & 1), 0, 16) < p_logical;   /* mcmc.py:23 (a 16-bit uniform) */
 }
 
 /* _apply_random_stabilizer: a uniform choice among the stabilizer generators.
@@ -274,8 +293,10 @@ static int model_random_stabilizer(const orc_model *m, const uint8_t *in, uint8_
     if (rng->mode != 0) {
         /* non-top: the top 20 bits of the proposal's word, g = floor(x20 * G / 2^20); top chain: word 1 of its block */
         /* (w0 == 2: the top chain's packed layout -- two proposals per block (k >> 1, 5), the generator from the second word) */
+        /* (w0 == 3: the biased / alpha top chain -- the same packed block, the generator from the top 20 bits of the second word) */
         const double u = w0 == 0 ? orc_draw_field(rng, slot, k >> 2, 1, (int)(k & 3), 0, 20)
-                       : w0 == 2 ? orc_draw(rng, slot, k >> 1, 5, 2 * (int)(k & 1) + 1) : orc_draw(rng, slot, k, 0, 1);
+                       : w0 == 2 ? orc_draw(rng, slot, k >> 1, 5, 2 * (int)(k & 1) + 1)
+                       : w0 == 3 ? orc_draw_field(rng, slot, k >> 1, 5, 2 * (int)(k & 1) + 1, 0, 20) : orc_draw(rng, slot, k, 0, 1);
         g = (int)(u * G);
         rng->consumed += (m->code == ORC_TORIC || m->code == ORC_PLANAR) ? 2 : 4;   /* counted like the reference's three / five draws */
     }
@@ -479,9 +500,9 @@ int orc_chain_update_alpha(const orc_model *m, uint8_t *state, double pz_tilde, 
         const uint64_t k = k0 + j;
         double u;
         if (p_logical != 0) {
-            if (orc_draw(rng, slot, k, 0, 0) < p_logical) model_random_logical(m, state, scratch, rng, slot, k);
-            else model_random_stabilizer(m, state, scratch, rng, slot, k, 1);
-            u = orc_draw(rng, slot, k, 0, 2);     /* word 2 of the proposal block: unused by the plaquette codes' logical draws */
+            if (top_select_logical(rng, slot, k, p_logical)) model_random_logical_ex(m, state, scratch, rng, slot, k, 1);
+            else model_random_stabilizer(m, state, scratch, rng, slot, k, 3);
+            u = top_accept44(rng, slot, k);
         } else {
             model_random_stabilizer(m, state, scratch, rng, slot, k, 0);
             u = nontop_accept(m, rng, slot, k);
@@ -515,10 +536,10 @@ void orc_chain_update(const orc_model *m, uint8_t *state, double p, double p_log
             uint64_t k = k0 + j;
             double u;
             if (p_logical != 0) {                                                       /* :32-46 */
-                if (orc_draw(rng, slot, k, 0, 0) < p_logical) model_random_logical(m, state, scratch, rng, slot, k);
-                else model_random_stabilizer(m, state, scratch, rng, slot, k, 1);
+                if (top_select_logical(rng, slot, k, p_logical)) model_random_logical_ex(m, state, scratch, rng, slot, k, 1);
+                else model_random_stabilizer(m, state, scratch, rng, slot, k, 3);
                 const double pn = biased_weight(scratch, (int)nq, px, py, pz);
-                u = orc_draw(rng, slot, k, 0, 2);     /* word 2 of the proposal block: unused by the plaquette codes' logical draws */
+                u = top_accept44(rng, slot, k);
                 if (u < pn / pb) memcpy(state, scratch, nq);
             } else {                                                                    /* :49-59 */
                 model_random_stabilizer(m, state, scratch, rng, slot, k, 0);
