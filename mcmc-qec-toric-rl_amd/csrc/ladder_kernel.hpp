@@ -482,6 +482,16 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
         flag = a.flags[(s0 + lane) * NC + slot] != 0;
         if (slot == 0) tops0 = a.tops0[s0 + lane];
     }
+    // kLdsCounters (the register-starved instantiations): wave 0's per-syndrome counters wait in LDS between its bookkeeping
+    // blocks -- the idle last row of each parity's swap-uniform buffer (rung pairs 0 .. NC-2 exist; the QUEUE kernels keep their
+    // refill records there) -- instead of occupying two registers of every wave for the whole run
+    constexpr bool kLaunderLane = BIASED && MINW >= 8;
+    constexpr bool kLdsCounters = kLaunderLane && !QUEUE;
+    [[maybe_unused]] uint32_t *ctrT = swx + (NC - 1) * 64, *ctrS = swx + (2 * NC - 1) * 64;
+    if constexpr (kLdsCounters) {
+        if (slot == 0) { ctrT[lane] = tops0; ctrS[lane] = 0; }
+        tops0 = 0;
+    }
     if constexpr (BIASED) {
         // every state's (n_x, n_y, n_z), packed; carried per state from here on (accepted moves add their change)
         int nx = 0, ny = 0, nz = 0;
@@ -521,7 +531,6 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
     const uint32_t rowmask = rowbits >= 32 ? 0xFFFFFFFFu : (1u << rowbits) - 1u;
     const bool swap_fast = a.swap_fast_ok != 0;
 
-    constexpr bool kLaunderLane = BIASED && MINW >= 8;
     constexpr int kPre = 12;                                    // blocks drawn ahead (a step of more proposals draws the rest in place)
     [[maybe_unused]] u32x4 pre[PRE ? kPre : 1];
     // QUEUE: finished lanes take new ladders until the counter runs out; the loop ends by the stop flag.  A new ladder may
@@ -758,6 +767,9 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
                 };
                 constexpr uint32_t kFieldBias = 512u | (512u << 10) | (512u << 20);
                 uint32_t Np = xyc[sid * 64 + lane_t];
+                // (state id, class and flag wait in one register while the proposals run: the loops below are the kernel's register peak)
+                uint32_t rec3 = sid | (cls << 8) | (flag << 16);
+                if constexpr (kLaunderLane) { asm volatile("" : "+v"(rec3)); sid = rec3 & 0xFFu; }
                 // (the counts at loop entry -- p_b's -- stay in xyc until the step ends: the rare paths read them back from there)
                 auto entry_counts = [&]() -> uint32_t { uint32_t v = xyc[sid * 64 + lane_t]; asm volatile("" : "+v"(v)); return v; };
                 const float lxyf = a.bias_l2f[slot_u][0], lzf = a.bias_l2f[slot_u][1];
@@ -973,6 +985,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
                         for (int w = 0; w < W; ++w) lds_xor(stw + w * 64, mf[w]);
                     }
                 }
+                if constexpr (kLaunderLane) { asm volatile("" : "+v"(rec3)); sid = rec3 & 0xFFu; cls = (rec3 >> 8) & 0xFFu; flag = rec3 >> 16; }
                 xyc[sid * 64 + lane_t] = Np;
                 n = (Np >> 20) + ((Np >> 10) & 1023u);
                 cls ^= cdelta;
@@ -1651,6 +1664,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
             n = mine & 0xFFFFu; sid = (mine >> 16) & 0xFFu; cls = (mine >> 24) & 0x3Fu; flag = mine >> 31;
             if ((int)slot_u == NC - 1) flag = 1;                                    // chains[-1].flag = 1, mcmc.py:100
             if (wave_u == 0 && !done) {                                             // ladder + PTEQ bookkeeping on slot 0's new state
+                if constexpr (kLdsCounters) { tops0 = ctrT[lane_t]; samples = ctrS[lane_t]; }
                 tops0 += (NC == 1) | (car >> 31);                                   // chains[0].flag == 1, :101-102
                 const uint32_t n0 = car & 0xFFFFu;
                 if (a.counts != nullptr && tops0 >= a.tops_burn) {                  // decoders.py:60-67
@@ -1706,6 +1720,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
                         conv_start = tops0;
                     }
                 }
+                if constexpr (kLdsCounters) { ctrT[lane_t] = tops0; ctrS[lane_t] = samples; tops0 = 0; samples = 0; }
             }
             if (a.swap_acc != nullptr && wave_u == 0) {
                 // equilibrium observables (qecmc_plan_set_stats): the cascade once more, with every rung's decision and the error
@@ -1868,9 +1883,15 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
 #ifdef QECMC_TIMELINE
     if (a.dbg && threadIdx.x == 0) a.dbg[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
 #endif
+    // (the epilogue's addresses are formed here, not carried through the step loop)
+    int lane_e = lane;
+    if constexpr (kLaunderLane) asm volatile("" : "+v"(lane_e));
     uint32_t *fin = info + (a.nsteps & 1) * NC * 64;
-    fin[slot_u * 64 + lane] = pack_info(n, sid, cls, flag);
+    fin[slot_u * 64 + lane_e] = pack_info(n, sid, cls, flag);
     __syncthreads();
+    if constexpr (kLdsCounters) {
+        if (slot == 0) { tops0 = ctrT[lane_e]; samples = ctrS[lane_e]; }
+    }
 
     // ---- results: coalesced stores ---------------------------------------------------
     if constexpr (QUEUE) return;                  // (every ladder wrote its results when it finished)
@@ -1891,24 +1912,24 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
             else if (a.nerr_sum != nullptr) a.nerr_sum[(s0 + j) * NC + (c - (NC - 1))] = lds_all[gdw + (NC + c - (NC - 1)) * 64 + j];
         }
     }
-    if (slot == 0 && lane < cnt && R > 1) {
-        const uint64_t row = (s0 + lane) / R;
+    if (slot == 0 && lane_e < cnt && R > 1) {
+        const uint64_t row = (s0 + lane_e) / R;
         if (a.samples != nullptr) atomicAdd(a.samples + row, samples);
         if (a.tops0 != nullptr) atomicAdd(a.tops0 + row, tops0);
         if (a.steps_done != nullptr) atomicMax(a.steps_done + row, done ? steps_done : (uint32_t)a.nsteps);
         if (a.converged != nullptr && !conv_ok) a.converged[row] = 0;               // the caller presets 1: all R ladders converged
     } else
-    if (slot == 0 && lane < cnt) {
-        if (a.samples != nullptr) a.samples[s0 + lane] = a.accumulate ? a.samples[s0 + lane] + samples : samples;
-        if (a.steps_done != nullptr) a.steps_done[s0 + lane] = USET ? (cm_done ? cm_steps : (uint32_t)a.nsteps) : done ? steps_done : (uint32_t)a.nsteps;
-        if (a.converged != nullptr) a.converged[s0 + lane] = (uint8_t)conv_ok;
-        if (a.tops0 != nullptr) a.tops0[s0 + lane] = tops0;
+    if (slot == 0 && lane_e < cnt) {
+        if (a.samples != nullptr) a.samples[s0 + lane_e] = a.accumulate ? a.samples[s0 + lane_e] + samples : samples;
+        if (a.steps_done != nullptr) a.steps_done[s0 + lane_e] = USET ? (cm_done ? cm_steps : (uint32_t)a.nsteps) : done ? steps_done : (uint32_t)a.nsteps;
+        if (a.converged != nullptr) a.converged[s0 + lane_e] = (uint8_t)conv_ok;
+        if (a.tops0 != nullptr) a.tops0[s0 + lane_e] = tops0;
         if (a.flags != nullptr)
-            for (int c = 0; c < NC; ++c) a.flags[(s0 + lane) * NC + c] = (uint8_t)(fin[c * 64 + lane] >> 31);
+            for (int c = 0; c < NC; ++c) a.flags[(s0 + lane_e) * NC + c] = (uint8_t)(fin[c * 64 + lane_e] >> 31);
     }
     if constexpr (BIASED) {
-        if (alpha_noise && a.neff != nullptr && lane < cnt)
-            a.neff[(s0 + lane) * NC + slot] = neffb[((((uint32_t)a.nsteps & 1u) ^ 1u) * NC + slot) * 64 + lane];
+        if (alpha_noise && a.neff != nullptr && lane_e < cnt)
+            a.neff[(s0 + lane_e) * NC + slot] = neffb[((((uint32_t)a.nsteps & 1u) ^ 1u) * NC + slot) * 64 + lane_e];
     }
     if (a.write_states && a.states != nullptr) {
         uint8_t *dst = a.states + s0 * (uint64_t)NC * nq;
