@@ -158,3 +158,80 @@ def test_harness_unique_chain_methods(q, method, params, steps):
     if method != "STDC" and method != "STRC":                 # (rain draws from the host stream, which chunking reorders)
         again = harness.generate(params, 48, seed=5, steps=steps, batch=20)
         assert np.array_equal(again["distr"], out["distr"])
+
+
+# ---- exact pins for the plaquette codes and the biased weights (the CPU twins: tests/test_stats_cpu.py) -------
+# Reference-independent: the stabilizer group of an L = 3 xzzx / rotated syndrome has 2^8 elements x 4 classes; the class law
+# is their weights summed.  4096 replicas, 5 sigma -- the sharp statistical pin on the Philox re-parametrisation of these paths
+# (one 20-bit generator pick instead of five draws, the packed top-chain words, the 12-bit acceptance lead).
+
+def _surf_api(q):
+    import types
+    from qecmc import _surf
+    from oracle import oracle as orc     # (only the generator ordering, to span the group; the stencils are the device's)
+    return types.SimpleNamespace(apply_stabilizer=_surf.apply_stabilizer, apply_logical=_surf.apply_logical, eq_class=_surf.eq_class,
+                                 ngen=orc.surf_ngen, gen_rco=orc.surf_gen_rco)
+
+
+def _rand_surf(seed, L=3, p=0.3):
+    rng = np.random.default_rng(seed)
+    return (rng.integers(1, 4, size=(L, L)) * (rng.random((L, L)) < p)).astype(np.uint8)
+
+
+def _class_fractions(res, ok):
+    frac = res["counts"][ok] / res["samples"][ok, None].astype(np.float64)
+    return frac.mean(axis=0), frac.std(axis=0, ddof=1) / np.sqrt(ok.sum())
+
+
+@pytest.mark.parametrize("name,seed,p,Nc", [("xzzx", 11, 0.20, 3), ("xzzx", 13, 0.15, 4), ("rotated", 12, 0.25, 4), ("rotated", 14, 0.17, 3)])
+def test_plaquette_depolarizing_exact_L3(q, name, seed, p, Nc):
+    from util_exact import SurfEnumeration, depolarizing_weight
+    code = {"xzzx": q.XZZX, "rotated": q.ROTATED}[name]
+    init = _rand_surf(seed)
+    P = SurfEnumeration(code, init, _surf_api(q)).class_probabilities(depolarizing_weight(p))
+    R, steps = 4096, 4000
+    res = q.pteq_batch(np.broadcast_to(init, (R,) + init.shape).copy(), p, Nc=Nc, steps=steps, iters=10, tops_burn=5, seed=2000 + seed, code=code)
+    ok = res["samples"] > steps // 2
+    assert ok.mean() > 0.97
+    mean, sem = _class_fractions(res, ok)
+    assert np.all(np.abs(mean - P) <= 5 * sem + 2e-4), (mean, P, sem)
+    assert mean.argmax() == P.argmax()
+
+
+@pytest.mark.parametrize("name,seed,p,eta", [("xzzx", 21, 0.25, 3.0), ("xzzx", 23, 0.15, 100.0), ("rotated", 22, 0.30, 10.0)])
+def test_biased_ladder_exact_L3_iters1(q, name, seed, p, eta):
+    """Ladder_biased at iters = 1, where quirk Q3 is vacuous: each rung is a Metropolis chain for px^nx py^ny pz^nz pI^nI
+    (mcmc_biased.py:25-31) and the swap rule on total counts is the exact exchange ratio for those weights (the eta factors do
+    not depend on the rung), so the bottom rung samples the biased class law."""
+    from util_exact import SurfEnumeration, biased_weight
+    code = {"xzzx": q.XZZX, "rotated": q.ROTATED}[name]
+    init = _rand_surf(seed)
+    P = SurfEnumeration(code, init, _surf_api(q)).class_probabilities(biased_weight(p, eta))
+    R, steps = 4096, 40000
+    res = q.pteq_batch(np.broadcast_to(init, (R,) + init.shape).copy(), p, Nc=3, steps=steps, iters=1, tops_burn=5, seed=3000 + seed, code=code, eta=eta)
+    ok = res["samples"] > steps // 2
+    assert ok.mean() > 0.9
+    mean, sem = _class_fractions(res, ok)
+    assert np.all(np.abs(mean - P) <= 5 * sem + 2e-4), (mean, P, sem)
+    assert mean.argmax() == P.argmax()
+
+
+@pytest.mark.parametrize("name,seed,p,eta", [("xzzx", 31, 0.25, 3.0), ("rotated", 32, 0.30, 10.0)])
+def test_biased_chain_q3_law_L3_iters10(q, name, seed, p, eta):
+    """What iters = 10 converges to instead (quirk Q3: every proposal of an update_chain call is tested against the configuration
+    at the START of the call): not the biased law, but a law that is still exactly computable for a single chain
+    (SurfEnumeration.q3_class_law).  The sampler sits on it -- and measurably off the biased law."""
+    from util_exact import SurfEnumeration, biased_weight
+    code = {"xzzx": q.XZZX, "rotated": q.ROTATED}[name]
+    init = _rand_surf(seed)
+    e = SurfEnumeration(code, init, _surf_api(q))
+    w = biased_weight(p, eta)
+    Q, P = e.q3_class_law(w, 0.5, 10), e.class_probabilities(w)
+    assert 0.5 * np.abs(Q - P).sum() > 0.02
+    R, steps = 4096, 6000
+    res = q.pteq_batch(np.broadcast_to(init, (R,) + init.shape).copy(), p, Nc=1, steps=steps, iters=10, tops_burn=0, seed=4000 + seed, code=code, eta=eta)
+    ok = res["samples"] == steps
+    assert ok.all()
+    mean, sem = _class_fractions(res, ok)
+    assert np.all(np.abs(mean - Q) <= 5 * sem + 1e-3), (mean, Q, sem)      # (every step from the seed is recorded: a 1/steps transient)
+    assert np.abs(mean - P).max() > 10 * sem.max()

@@ -143,3 +143,84 @@ def test_oracle_syndrome_generator_distribution(code, L, rates):
     # a second call with another first_syndrome continues the same data set
     a, _, _ = orc.generate_syndromes(cid, L, 10, *rates, hide_class=True, seed=11, first_syndrome=105)
     assert np.array_equal(a, init[5:15])
+
+
+# ---- exact pins for the plaquette codes and the biased weights ("2^8 elements x 4" at L = 3) -----------------
+# These pin the Philox re-parametrisation of the xzzx / rotated paths (one 20-bit pick instead of five draws, packed top-chain
+# words) to a reference-independent answer.  The same cases run on the GPU with 4096 replicas (tests/test_gpu_stats.py).
+import types
+
+from util_exact import SurfEnumeration, biased_weight, depolarizing_weight
+
+ORC_API = types.SimpleNamespace(apply_stabilizer=orc.surf_apply_stabilizer, apply_logical=orc.surf_apply_logical,
+                                eq_class=orc.surf_eq_class, ngen=orc.surf_ngen, gen_rco=orc.surf_gen_rco)
+
+
+def _rand_surf(seed, L=3, p=0.3):
+    rng = np.random.default_rng(seed)
+    return (rng.integers(1, 4, size=(L, L)) * (rng.random((L, L)) < p)).astype(np.uint8)
+
+
+def _check_classes(frac, P, nsig=5.0, floor=3e-4, rare=0.75):
+    """class frequencies of R replicas against the exact law: 5 sigma on the classes that carry weight, a relative allowance on the
+    rare ones (visited in a few long bursts per replica, so the spread over the replicas understates their error)"""
+    mean, sem = frac.mean(axis=0), frac.std(axis=0, ddof=1) / np.sqrt(frac.shape[0])
+    big = P >= 0.01
+    assert np.all(np.abs(mean - P)[big] <= nsig * sem[big] + floor), (mean, P, sem)
+    assert np.all(np.abs(mean - P)[~big] <= nsig * sem[~big] + rare * P[~big] + floor), (mean, P, sem)
+    return mean, sem
+
+
+@pytest.mark.parametrize("code", [orc.XZZX, orc.ROTATED])
+def test_plaquette_enumeration_is_representative_independent(code):
+    m = _rand_surf(5)
+    e = SurfEnumeration(code, m, ORC_API)
+    P = e.class_probabilities(depolarizing_weight(0.2))
+    assert abs(P.sum() - 1) < 1e-12 and (P > 0).all()
+    m2 = orc.surf_apply_logical(code, orc.surf_apply_stabilizer(code, m, 1, 1, 1)[0], 3, 0, 0)[0]     # same syndrome, another class
+    assert np.allclose(P, SurfEnumeration(code, m2, ORC_API).class_probabilities(depolarizing_weight(0.2)), rtol=1e-12)
+    # the Q3 law at iters = 1 is the plain biased law: one proposal per call is tested against the current configuration
+    w = biased_weight(0.25, 3.0)
+    assert np.allclose(e.q3_class_law(w, 0.5, 1), e.class_probabilities(w), atol=1e-9)
+
+
+@pytest.mark.parametrize("code,seed,p,Nc", [(orc.XZZX, 11, 0.20, 3), (orc.ROTATED, 12, 0.25, 4)])
+def test_oracle_plaquette_depolarizing_exact_L3(code, seed, p, Nc):
+    init = _rand_surf(seed)
+    P = SurfEnumeration(code, init, ORC_API).class_probabilities(depolarizing_weight(p))
+    R, steps = 96, 6000
+    res = orc.pteq_batch(code, np.broadcast_to(init, (R,) + init.shape).copy(), p, Nc, steps, iters=10, tops_burn=5, seed=300 + seed, n_threads=8)
+    assert (res["samples"] > steps // 2).all()
+    _check_classes(res["counts"] / res["samples"][:, None].astype(np.float64), P)
+
+
+@pytest.mark.parametrize("code,seed,p,eta", [(orc.XZZX, 21, 0.25, 3.0), (orc.ROTATED, 22, 0.30, 10.0)])
+def test_oracle_biased_ladder_exact_L3_iters1(code, seed, p, eta):
+    """Ladder_biased at iters = 1, where quirk Q3 is vacuous: every rung's chain is a Metropolis chain for its own weights
+    px^nx py^ny pz^nz pI^nI, and the swap rule p_diff^(n_hi - n_lo) on TOTAL counts (mcmc_biased.py:107-113) is the exact
+    exchange ratio for them (the eta-dependent factors do not depend on the rung) -- so the bottom rung samples the biased law."""
+    init = _rand_surf(seed)
+    P = SurfEnumeration(code, init, ORC_API).class_probabilities(biased_weight(p, eta))
+    R, steps = 96, 40000
+    res = orc.pteq_batch(code, np.broadcast_to(init, (R,) + init.shape).copy(), p, 3, steps, iters=1, tops_burn=5, seed=400 + seed, n_threads=8,
+                         noise=orc.BIASED, eta=eta)
+    assert (res["samples"] > steps // 2).all()
+    _check_classes(res["counts"] / res["samples"][:, None].astype(np.float64), P)
+
+
+@pytest.mark.parametrize("code,seed,p,eta", [(orc.XZZX, 31, 0.25, 3.0), (orc.ROTATED, 32, 0.30, 10.0)])
+def test_oracle_biased_chain_q3_law_L3_iters10(code, seed, p, eta):
+    """What iters = 10 converges to instead: the acceptance of every proposal of a call is relative to the configuration at the
+    START of the call (quirk Q3), so detailed balance for the biased weights is lost.  For a single chain the limit is still
+    computable exactly (SurfEnumeration.q3_class_law): the sampler must sit on THAT law, which differs visibly from the biased one."""
+    init = _rand_surf(seed)
+    e = SurfEnumeration(code, init, ORC_API)
+    w = biased_weight(p, eta)
+    Q, P = e.q3_class_law(w, 0.5, 10), e.class_probabilities(w)
+    assert 0.5 * np.abs(Q - P).sum() > 0.02                       # the two laws are not the same thing
+    R, steps = 96, 6000
+    res = orc.pteq_batch(code, np.broadcast_to(init, (R,) + init.shape).copy(), p, 1, steps, iters=10, tops_burn=0, seed=500 + seed, n_threads=8,
+                         noise=orc.BIASED, eta=eta)
+    assert (res["samples"] == steps).all()
+    mean, sem = _check_classes(res["counts"] / res["samples"][:, None].astype(np.float64), Q, floor=2e-3)   # (steps from the seed: a 1/steps transient)
+    assert np.abs(mean - P).max() > 10 * sem.max()                # ... and measurably not on the biased law
