@@ -122,6 +122,23 @@ def profile_counters(args):
     return out
 
 
+def metric_name(args):
+    """BASELINE.json's metric, named after the workload that was run (config 2 gives BASELINE's own string)"""
+    return "MCMC sweeps/sec (whole node), L=%d %s p=%g%s; eq-class histogram match" % (
+        args.L, args.code, args.p, "" if args.eta is None else " eta=%g" % args.eta)
+
+
+def rank_records(dist, use_dist, world, rank, device_name, device_uuid, kernel_ms, first):
+    """What every rank ran, gathered to rank 0 so that an N > 1 line certifies itself: the ranks RCCL saw, the device each one
+    sat on, its own kernel time and the first global syndrome index of its shard."""
+    mine = {"rank": rank, "device": device_name, "device_uuid": device_uuid, "kernel_ms_mean": kernel_ms, "first_syndrome": first}
+    if not use_dist:
+        return [mine]
+    got = [None] * world
+    dist.all_gather_object(got, mine)
+    return got
+
+
 def cpu_model():
     try:
         for ln in open("/proc/cpuinfo"):
@@ -132,14 +149,14 @@ def cpu_model():
     return "unknown"
 
 
-def oracle_batch(args, init, steps, n_threads, first=0):
+def oracle_batch(args, init, steps, n_threads, first=0, states=False):
     from oracle import oracle as orc
     if args.code == "toric":
         return orc.toric_pteq_batch(init, args.p, args.Nc, steps, iters=args.iters, tops_burn=2, seed=args.seed,
-                                    first_syndrome=first, n_threads=n_threads)
+                                    first_syndrome=first, n_threads=n_threads, return_states=states)
     code = {"xzzx": orc.XZZX, "rotated": orc.ROTATED, "planar": orc.PLANAR}[args.code]
     return orc.pteq_batch(code, init, args.p, args.Nc, steps, iters=args.iters, tops_burn=2, seed=args.seed, first_syndrome=first,
-                          n_threads=n_threads, noise=orc.DEPOLARIZING if args.eta is None else orc.BIASED, eta=args.eta or 0.0)
+                          n_threads=n_threads, noise=orc.DEPOLARIZING if args.eta is None else orc.BIASED, eta=args.eta or 0.0, return_states=states)
 
 
 def cpu_baseline(args, init, n_gen, target_s=12.0):
@@ -191,6 +208,8 @@ def parse_args(argv=None):
     ap.add_argument("--scan", default="random", choices=["random", "sweep"],
                     help="random = the reference's random-scan chain; sweep = systematic generator sweep (scan=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--library", default=None, help="time another build of libqecmc.so (same ABI) instead of the in-tree one: A/B runs on one box")
+    ap.add_argument("--flags", type=lambda v: int(v, 0), default=0, help="qecmc_params.flags: developer switches between equivalent kernel variants (include/qecmc.h)")
     ap.add_argument("--sweep", action="store_true", help="also time the scan=1 kernel on the same batch (toric, 1 GPU)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / exchange rehearsal without a GPU: gloo, no kernel, zero throughput (tests/test_bench_launcher.py)")
@@ -211,6 +230,8 @@ def main():
     import torch.distributed as dist
     from qecmc import _lib as L_
     from qecmc.sharding import PteqShard
+    if args.library:
+        L_.use_library(args.library)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -244,11 +265,14 @@ def main():
         if use_dist:
             dist.barrier()
         elapsed = time.perf_counter() - t0
+        ranks = rank_records(dist, use_dist, world, rank, "cpu (dry run)", None, 0.0, first)
         if rank == 0:
             ok = all(int(g[0]) == r + 1 and int(g[-1]) == r + 1 for r, g in enumerate(gathered)) if use_dist else True
             print(json.dumps({"metric": "dry run: launcher and exchange only (no kernel, no throughput)", "value": 0.0, "unit": "chain-sweeps/s",
                               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
-                              "data": "none (dry run)", "gather_ok": bool(ok), "config": {"workload": "dry run of: " + workload}}))
+                              "data": "none (dry run)", "gather_ok": bool(ok), "config": {"workload": "dry run of: " + workload},
+                              "comm": {"backend": dist.get_backend() if use_dist else None, "world": dist.get_world_size() if use_dist else 1},
+                              "ranks": ranks}))
         if use_dist:
             dist.destroy_process_group()
         return
@@ -265,7 +289,7 @@ def main():
     sh = PteqShard(init_h, args.p, first, n_total=N * world, code=code_id, Nc=Nc, p_logical=args.p_logical, iters=args.iters,
                    steps=args.ladder_steps, tops_burn=2, seed=args.seed,
                    noise=L_.NOISE_DEPOLARIZING if args.eta is None else L_.NOISE_BIASED, eta=args.eta or 0.0,
-                   scan=L_.SCAN_RANDOM if args.scan == "random" else L_.SCAN_SWEEP)
+                   scan=L_.SCAN_RANDOM if args.scan == "random" else L_.SCAN_SWEEP, flags=args.flags)
     lds, threads, spb = C.c_uint32(), C.c_uint32(), C.c_uint32()
     L_.check(L_.lib().qecmc_plan_info(sh.plan, lds, threads, spb))
     stream = torch.cuda.current_stream()
@@ -295,6 +319,8 @@ def main():
 
     total_proposals = proposals_per_pass * args.steps * world
     sweeps_per_s = total_proposals / n_gen / elapsed
+    props = torch.cuda.get_device_properties(dev)
+    ranks = rank_records(dist, use_dist, world, rank, props.name, str(getattr(props, "uuid", "")) or None, float(np.mean(kernel_ms)), first)
 
     if rank == 0:
         d_counts, d_samples, d_tops0 = sh.views()
@@ -317,7 +343,7 @@ def main():
             torch.cuda.synchronize()
             incl.append((time.perf_counter() - t1) * 1e3)
         out = {
-            "metric": "MCMC sweeps/sec (whole node), L=9 toric p=0.15; eq-class histogram match",
+            "metric": metric_name(args),
             "value": sweeps_per_s,
             "unit": "chain-sweeps/s (1 sweep = %d Metropolis proposals on one chain = one per stabilizer generator)" % n_gen,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -330,6 +356,8 @@ def main():
                        "lds_bytes_per_workgroup": lds.value, "threads_per_workgroup": threads.value,
                        "parallelism": "syndrome shards x%d, RCCL gather of class counts" % world},
             "proposals_per_s": total_proposals / elapsed,
+            "comm": {"backend": (dist.get_backend() + " (RCCL)") if use_dist else None, "world": dist.get_world_size() if use_dist else 1},
+            "ranks": ranks,
             "ladder_sweeps_per_s": sweeps_per_s / Nc,
             "kernel_ms_per_launch": k_ms,
             "ms_per_step_incl_transfers": float(np.median(incl)),
@@ -354,12 +382,25 @@ def main():
                 # class counts the timed GPU pass left in HBM, bit for bit, on a sample of the batch (the statistical
                 # match against the reference's own sampler is tests/test_gpu_stats.py and profiles/rNN_headline_S1e5.json)
                 n_chk = min(N, 256 if args.ladder_steps <= 20000 else 64)
-                ref = oracle_batch(args, init_h[:n_chk], args.ladder_steps, os.cpu_count() or 1)
+                ref = oracle_batch(args, init_h[:n_chk], args.ladder_steps, os.cpu_count() or 1, states=True)
+                with_samples = int(np.sum(samples[:n_chk] > 0))
                 same = bool(np.array_equal(d_counts[:n_chk].cpu().numpy().astype(np.uint32), ref["counts"]) and
                             np.array_equal(samples[:n_chk].astype(np.uint64), ref["samples"].astype(np.uint64)))
+                # state-dependent outputs that are non-zero whatever the burn-in did (the long-lattice configurations pass
+                # tops_burn = 2 for few or none of their ladders in 10 000 steps): tops0 of the timed pass, and -- from one more
+                # pass of the same ladders through the host-pointer entry point -- every rung's final configuration
+                import qecmc
+                again = qecmc.pteq_batch(init_h[:n_chk], args.p, Nc=Nc, steps=args.ladder_steps, iters=args.iters, tops_burn=2, seed=args.seed,
+                                         first_syndrome=first, code=code_id, eta=args.eta, return_states=True, flags=args.flags)
                 out["histogram_match"] = {"syndromes_checked": n_chk, "ladder_steps": args.ladder_steps,
-                                          "syndromes_with_samples": int(np.sum(samples[:n_chk] > 0)),
-                                          "class_counts_bit_identical_to_cpu_oracle": same}
+                                          "syndromes_with_samples": with_samples,
+                                          # (null: no ladder of the sample got past the burn-in, the counts are all zero on both sides)
+                                          "class_counts_bit_identical_to_cpu_oracle": same if with_samples else None,
+                                          "tops0_bit_identical_to_cpu_oracle": bool(np.array_equal(tops0[:n_chk].astype(np.uint64), ref["tops0"].astype(np.uint64))),
+                                          "final_states_bit_identical_to_cpu_oracle": bool(np.array_equal(again["states"], ref["states"]) and
+                                                                                           np.array_equal(again["counts"], ref["counts"])),
+                                          "match": bool(same and np.array_equal(tops0[:n_chk].astype(np.uint64), ref["tops0"].astype(np.uint64)) and
+                                                        np.array_equal(again["states"], ref["states"]))}
         if world == 1 and toric and args.scan == "random" and args.eta is None and args.sweep:
             # the library's second scan mode on the same batch, for the record (`value` above is the reference's chain)
             pr2 = L_.make_params(code=code_id, L=L, Nc=Nc, p=args.p, p_logical=args.p_logical, iters=args.iters,

@@ -78,8 +78,18 @@ typedef struct qecmc_params {
     uint64_t seed;          /* Philox key */
     uint32_t first_syndrome;/* global index of syndrome 0 of this call: results do not
                                depend on how a batch is sharded over GPUs */
-    uint32_t flags;         /* reserved, 0 */
+    uint32_t flags;         /* 0 in production.  Developer switches (results are identical with any value; they select among kernel
+                               variants that compute the same thing): QECMC_FLAG_* below in bits 0-15, and in bits 16-31 the size of
+                               the work-queue kernels' persistent grid in workgroups (0: what fits the chip; the tests force 1-2
+                               workgroups so that every lane runs several ladders) */
 } qecmc_params;
+
+enum qecmc_flag {
+    QECMC_FLAG_NO_PRE   = 2,   /* no instantiations that draw the top chain's Philox blocks ahead */
+    QECMC_FLAG_NO_DELUT = 4,   /* no dE look-up table (popcount form) */
+    QECMC_FLAG_NO_SSW   = 8    /* no swap sweep run once by wave 0 (every wave replays the cascade) */
+};
+#define QECMC_FLAGS_QUEUE_GRID(n) ((uint32_t)(n) << 16)
 
 typedef struct qecmc_stats {
     uint64_t proposals;     /* Metropolis trials executed (all chains, all syndromes) */

@@ -248,6 +248,10 @@ int validate_params(const qecmc_params *p)
     if (p->iters == 0 || p->iters > 0xFFFFFFFFull) return fail(QECMC_ERR_INVALID, "iters out of range");
     if (p->tops_burn < 0) return fail(QECMC_ERR_INVALID, "tops_burn must be >= 0");
     if (p->replicas < 0 || p->replicas > 65536) return fail(QECMC_ERR_INVALID, "replicas=%d out of range [0, 65536]", p->replicas);
+    // the R ladders of a syndrome add their class counts / samples / tops0 into uint32 outputs: at most `steps` each
+    if (p->replicas > 1 && (uint64_t)p->replicas * p->steps > 0xFFFFFFFFull)
+        return fail(QECMC_ERR_INVALID, "replicas * steps = %llu overflows the summed 32-bit class counts: lower one of them",
+                    (unsigned long long)((uint64_t)p->replicas * p->steps));
     return 0;
 }
 
@@ -261,7 +265,7 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
     const bool biased = p->noise == QECMC_NOISE_BIASED || alpha;     // table-driven acceptance pn / pb
     a.code = p->code; a.noise = p->noise; a.alpha = p->alpha;
     a.replicas = p->replicas > 1 ? (uint32_t)p->replicas : 1u;
-    if (const char *tv = std::getenv("QECMC_TUNE")) a.tune = (uint32_t)std::strtoul(tv, nullptr, 0);   // development knobs, see kernels.hpp
+    a.tune = p->flags & 0xFFFFu;                                // developer switches (qecmc_flag): which variant runs, never what it computes
     a.L = L; a.Nc = Nc; a.W = W; a.nq = nq; a.ncls = ncls;
     a.iters = (uint32_t)p->iters;
     a.seed_lo = (uint32_t)p->seed; a.seed_hi = (uint32_t)(p->seed >> 32);
@@ -315,7 +319,7 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
         size_t per_cu = per_cu_lds < per_cu_waves ? per_cu_lds : per_cu_waves;
         if (per_cu < 1) per_cu = 1;
         pl->queue_grid = (uint32_t)(per_cu * (size_t)prop.multiProcessorCount);
-        if (const char *qg = std::getenv("QECMC_QUEUE_GRID")) pl->queue_grid = (uint32_t)std::strtoul(qg, nullptr, 0);   // tests: force refills on small batches
+        if (p->flags >> 16) pl->queue_grid = p->flags >> 16;   // tests: force refills on small batches
         if (pl->queue_grid == 0) pl->queue_grid = 1;
         HIP_TRY(pl->queue.alloc(sizeof(uint32_t)));
     }

@@ -485,7 +485,8 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
     // kLdsCounters (the register-starved instantiations): wave 0's per-syndrome counters wait in LDS between its bookkeeping
     // blocks -- the idle last row of each parity's swap-uniform buffer (rung pairs 0 .. NC-2 exist; the QUEUE kernels keep their
     // refill records there) -- instead of occupying two registers of every wave for the whole run
-    constexpr bool kLaunderLane = BIASED && MINW >= 8;
+    // (every 64-VGPR instantiation but the toric fixed-length family, which fits its registers as it is)
+    constexpr bool kLaunderLane = MINW >= 8 && (BIASED || CONV || GENTOP || USET || SCAN || CODE != kCodeToric);
     constexpr bool kLdsCounters = kLaunderLane && !QUEUE;
     [[maybe_unused]] uint32_t *ctrT = swx + (NC - 1) * 64, *ctrS = swx + (2 * NC - 1) * 64;
     if constexpr (kLdsCounters) {
@@ -507,6 +508,10 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
         }
         __syncthreads();
     }
+
+    // (the slot record waits in one register while the wave-uniform set-up below is formed)
+    [[maybe_unused]] uint32_t rec0 = pack_info(n, sid, cls, flag);
+    if constexpr (kLaunderLane) asm volatile("" : "+v"(rec0));
 
     // Roles rotate: at every ladder step each wave moves on to the next slot, so the heavier top
     // slot (frame flush + recount) visits every SIMD in turn instead of loading one of them for
@@ -539,6 +544,10 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
     [[maybe_unused]] uint32_t *qidx = swx + (NC - 1) * 64, *qt0 = swx + (2 * NC - 1) * 64;   // the idle last rows of swx: [64] each
     [[maybe_unused]] bool q_dead = lane >= cnt, q_flushed = false;                           // (wave 0) no ladder left for this lane / its results are written
     [[maybe_unused]] bool q_empty = a.N <= (uint64_t)gridDim.x * 64u;                        // ... the counter is exhausted (uniform)
+    if constexpr (kLaunderLane) {
+        asm volatile("" : "+v"(rec0));
+        n = rec0 & 0xFFFFu; sid = (rec0 >> 16) & 0xFFu; cls = (rec0 >> 24) & 0x3Fu; flag = rec0 >> 31;
+    }
     for (uint64_t t = 0; QUEUE || t < a.nsteps; ++t) {
         // The lane index of this step.  In the register-starved instantiations (kLaunderLane) it is opaque to the compiler, so the
         // dozen LDS addresses derived from it (records, swap uniforms, histogram rows, count tables ...) are formed where a step

@@ -10,7 +10,22 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("QECMC_LIBRARY") or os.path.join(_HERE, "libqecmc.so")   # override: another build of the same ABI
+LIB_PATH = os.path.join(_HERE, "libqecmc.so")
+FLAG_NO_PRE, FLAG_NO_DELUT, FLAG_NO_SSW = 2, 4, 8          # qecmc_flag (include/qecmc.h): developer switches between equivalent kernel variants
+
+
+def dev_flags(switches=0, queue_grid=0):
+    """qecmc_params.flags: qecmc_flag switches | the work-queue kernels' persistent grid in workgroups (0: what fits the chip)"""
+    return (int(switches) & 0xFFFF) | (int(queue_grid) << 16)
+
+
+def use_library(path):
+    """Load another build of the same ABI instead of the in-tree libqecmc.so (A/B timing of two builds in one process tree:
+    `bench.py --library`).  Must be called before the first entry point is used."""
+    global LIB_PATH, _lib
+    if _lib is not None:
+        raise QecmcError("use_library() after the library has been loaded")
+    LIB_PATH = os.path.abspath(path)
 
 TORIC, XZZX, ROTATED, PLANAR = 0, 1, 2, 3
 SCAN_RANDOM, SCAN_SWEEP = 0, 1
@@ -163,11 +178,11 @@ def as_states(m, ndim_state):
 
 def make_params(code=TORIC, L=0, Nc=1, p=0.1, p_logical=0.0, iters=10, steps=0, tops_burn=2, TOPS=10, SEQ=2,
                 eps=0.1, seed=0, first_syndrome=0, conv_mode=CONV_NONE, scan=SCAN_RANDOM,
-                noise=NOISE_DEPOLARIZING, eta=0.0, alpha=0.0, device=0, replicas=0):
+                noise=NOISE_DEPOLARIZING, eta=0.0, alpha=0.0, device=0, replicas=0, flags=0):
     pr = Params()
     pr.abi_size = C.sizeof(Params)
     pr.code, pr.L, pr.Nc, pr.noise, pr.scan, pr.conv_mode, pr.device = code, L, Nc, noise, scan, conv_mode, device
     pr.iters, pr.steps, pr.tops_burn, pr.TOPS, pr.SEQ, pr.replicas = iters, steps, tops_burn, TOPS, SEQ, replicas
     pr.eps, pr.p, pr.eta, pr.alpha, pr.p_logical = eps, p, eta, alpha, p_logical
-    pr.seed, pr.first_syndrome, pr.flags = seed & 0xFFFFFFFFFFFFFFFF, first_syndrome, 0
+    pr.seed, pr.first_syndrome, pr.flags = seed & 0xFFFFFFFFFFFFFFFF, first_syndrome, int(flags)
     return pr

@@ -18,7 +18,7 @@ def percent_from_counts(counts, samples):
 
 def pteq_batch(init, p, Nc=None, steps=1000, iters=10, tops_burn=2, p_logical=0.5, seed=0, first_syndrome=0,
                device=0, return_states=False, return_stats=False, conv_criteria=None, SEQ=2, TOPS=10, eps=0.1,
-               code=L_.TORIC, eta=None, scan="random", alpha=None, replicas=1, return_swap_stats=False):
+               code=L_.TORIC, eta=None, scan="random", alpha=None, replicas=1, return_swap_stats=False, flags=0):
     """decoders.PTEQ (decoders.py:25-89) on N syndromes at once.
 
     init: uint8[N, 2, L, L] (toric, code=PLANAR) or uint8[N, L, L] (code=XZZX / ROTATED) seed configurations, one per
@@ -31,7 +31,7 @@ def pteq_batch(init, p, Nc=None, steps=1000, iters=10, tops_burn=2, p_logical=0.
     pattern of decoders.py:215-225, which is how a call with few syndromes fills the GPU; states are then [N*R, Nc, ...].
     return_swap_stats=True adds swap_accepts uint32[N,Nc-1] (accepted swap tests per rung pair over all `steps` ladder steps)
     and nerr_sums uint32[N,Nc] (sum over the steps of each rung's error count after the swaps), the per-batch mixing
-    metrics of SURVEY.md 5.
+    metrics of SURVEY.md 5.  flags: qecmc_params.flags (developer switches between equivalent kernel variants, _lib.dev_flags).
     Returns dict(counts uint32[N,16], samples uint32[N], tops0 uint32[N], steps_done uint32[N],
     converged bool[N], percent uint8[N,16] [, states uint8[N,Nc,2,L,L]] [, stats]).
     """
@@ -47,7 +47,7 @@ def pteq_batch(init, p, Nc=None, steps=1000, iters=10, tops_burn=2, p_logical=0.
                         conv_mode=L_.CONV_ERROR_BASED if conv_criteria else L_.CONV_NONE,
                         noise=L_.NOISE_ALPHA if alpha is not None else L_.NOISE_DEPOLARIZING if eta is None else L_.NOISE_BIASED,
                         eta=0.0 if eta is None else float(eta), alpha=0.0 if alpha is None else float(alpha),
-                        scan={"random": L_.SCAN_RANDOM, "sweep": L_.SCAN_SWEEP}[scan], replicas=int(replicas))
+                        scan={"random": L_.SCAN_RANDOM, "sweep": L_.SCAN_SWEEP}[scan], replicas=int(replicas), flags=int(flags))
     R = max(int(replicas), 1)
     counts = np.zeros((N, ncls), dtype=np.uint32)
     samples = np.zeros(N, dtype=np.uint32)
@@ -75,7 +75,11 @@ def pteq_batch(init, p, Nc=None, steps=1000, iters=10, tops_burn=2, p_logical=0.
     return out
 
 
-PTEQ_REPLICAS = 64   # ladders per PTEQ(...) call: one wavefront per temperature is 64 lanes wide, so 64 cost what 1 costs
+# Ladders per PTEQ(...) call.  1 = the reference's estimator: one ladder, its own stopping rule (decoders.py:25-89), which is what a
+# caller that "drops in unchanged" must get.  A wavefront per temperature is 64 lanes wide, so replicas=64 costs what one costs and
+# gives a lower-variance estimate (summed class counts; `converged` then means all 64 have converged, so the run ends with the
+# slowest of them): opt in per call (replicas=64) or for a whole script (decoders.PTEQ_REPLICAS = 64).
+PTEQ_REPLICAS = 1
 
 
 def PTEQ(init_code, p, Nc=None, SEQ=2, TOPS=10, tops_burn=2, eps=0.1, steps=50000000, iters=10,
@@ -86,11 +90,12 @@ def PTEQ(init_code, p, Nc=None, SEQ=2, TOPS=10, tops_burn=2, eps=0.1, steps=5000
     a 5e7-entry error-count log up front.  Philox is counter-based, so a longer horizon replays the same
     trajectory: the answer equals that of a single run with the full `steps`.
 
-    The reference decodes ONE syndrome per call (generate_data.py:136); one ladder would occupy one lane of each of the Nc
-    wavefronts.  `replicas` (default PTEQ_REPLICAS = 64) independent ladders -- each with the reference's bookkeeping and, if
-    asked for, its own convergence stop -- fill the lanes, and the percent vector is formed from their summed class counts:
-    the "droplets" pattern the reference itself uses for its other estimators (decoders.py:215-225).  replicas=1 is the
-    reference's single ladder."""
+    The reference decodes ONE syndrome per call (generate_data.py:136) with one ladder, which occupies one lane of each of the
+    Nc wavefronts; that is the default here too (PTEQ_REPLICAS = 1).  `replicas=R` runs R independent ladders -- each with the
+    reference's bookkeeping and, if asked for, its own convergence stop -- in the lanes that would otherwise idle, and forms the
+    percent vector from their summed class counts: the "droplets" pattern the reference itself uses for its other estimators
+    (decoders.py:215-225).  R = 64 fills the wavefronts at the price of one; it is a different (lower-variance) estimator
+    whose run ends when the slowest of the R ladders has converged, so it is opt-in."""
     return _pteq(init_code, p, None, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, conv_criteria, seed, replicas=replicas)
 
 

@@ -179,7 +179,7 @@ def _estimate(method, code, reps, p_error, p_sampling, Nc, steps, droplets, conv
 
 
 def generate(params, nbr_datapoints, seed=0, file_path=None, steps=100000, conv_criteria="error_based", biased_decoder="alpha",
-             rng=None, device_generation=False, **pteq_kw):
+             rng=None, device_generation=False, metrics="basic", **pteq_kw):
     """params: dict like generate_data.py:276-296 ({'code','size','p_error','noise'[,'eta','alpha']}), method PTEQ.
     noise 'depolarizing' -> PTEQ (:136); 'biased' -> errors from the eta split (:78-83) decoded by PTEQ_alpha with
     (pz_tilde, alpha) derived from (p, eta) exactly as :142-150 does (biased_decoder="biased" decodes with PTEQ_biased
@@ -189,6 +189,9 @@ def generate(params, nbr_datapoints, seed=0, file_path=None, steps=100000, conv_
     params['droplets'], params['conv_mult'] and `steps` as the estimator's own `steps`; `batch` syndromes go into one launch
     (default 256: the sets of visited chains live in HBM).  They return distr float64[n, ncls] and no counts.
     device_generation=True draws the errors and the hiding logical operator on the GPU (`generate_syndromes`) instead of NumPy.
+    metrics="basic" (default) costs nothing: throughput, convergence, burn-in and success figures.  metrics="full" also attaches the
+    mixing counters (swap acceptance per rung pair, mean error count per rung) -- which rule out the work-queue kernels
+    (their lanes run several ladders) and need nq * steps < 2^32, so they are dropped, not failed on, where they do not fit.
     Returns (and optionally saves as npz) qubit_matrix uint8[n,...] (the raw errors, generate_data.py:120),
     eq_true int32[n], counts uint32[n,ncls], distr uint8[n,ncls] (what PTEQ returns), success bool[n]
     (argmax(distr) == eq_true, generate_data.py:139), steps_done, converged."""
@@ -235,8 +238,12 @@ def generate(params, nbr_datapoints, seed=0, file_path=None, steps=100000, conv_
     import time
     Nc = params.get("Nc") or size
     t0 = time.perf_counter()
+    if metrics not in ("basic", "full"):
+        raise ValueError(f"metrics={metrics!r}")
+    nq = int(np.prod(init.shape[1:]))
+    swap_stats = metrics == "full" and Nc > 1 and int(pteq_kw.get("replicas", 1)) <= 1 and nq * int(steps) < 2 ** 32
     res = pteq_batch(init, p_dec, Nc=Nc, steps=steps, conv_criteria=conv_criteria, seed=seed, code=code, return_stats=True,
-                     return_swap_stats=Nc > 1 and int(pteq_kw.get("replicas", 1)) <= 1, **dec, **pteq_kw)
+                     return_swap_stats=swap_stats, **dec, **pteq_kw)
     wall = time.perf_counter() - t0
     out = dict(qubit_matrix=raw, eq_true=eq_true, counts=res["counts"], distr=res["percent"],
                success=np.argmax(res["percent"], axis=1) == eq_true, steps_done=res["steps_done"],
@@ -310,16 +317,24 @@ def threshold_curve(params, p_list, n, seed=0, **gen_kw):
     """Logical success rate against the physical error rate (the p_error scan of generate_data.py:57-60,121-141,276-296 --
     the reference loops p over [0.05, 0.20] in its job script and evaluates argmax(distr) == true class offline):
     for every p in p_list, n syndromes at p_error = p decoded in one batched call.
-    Returns dict(p, n, success_rate, err (binomial standard error), converged_frac, metrics [one dict per p])."""
-    rate, err, conv, met = [], [], [], []
+    Returns dict(p, n, success_rate, err (binomial standard error), converged_frac, metrics [one dict per p]) and, beside the raw
+    rate, success_rate_sampled / err_sampled / frac_sampled: the rate among the syndromes whose ladder got past the burn-in
+    (samples > 0).  The reference's burn-in trap (decoders.py:63,89: a ladder that never sees tops0 >= tops_burn returns an all-zero
+    vector, argmax 0) counts as a failure in the raw rate; at low p and a short horizon it, not the decoder, sets that number."""
+    rate, err, conv, met, rate_s, err_s, frac_s = [], [], [], [], [], [], []
     for i, p in enumerate(p_list):
         out = generate(dict(params, p_error=float(p)), n, seed=seed + i, **gen_kw)
         k = float(np.mean(out["success"]))
         rate.append(k); err.append(float(np.sqrt(max(k * (1 - k), 0.0) / n)))
         conv.append(float(np.mean(out["converged"])) if "converged" in out else float("nan"))
         met.append(out.get("metrics"))
+        sampled = out["samples"] > 0 if "samples" in out else np.ones(len(out["success"]), dtype=bool)
+        ns = int(sampled.sum())
+        ks = float(np.mean(out["success"][sampled])) if ns else float("nan")
+        rate_s.append(ks); err_s.append(float(np.sqrt(max(ks * (1 - ks), 0.0) / ns)) if ns else float("nan")); frac_s.append(ns / max(n, 1))
     return dict(p=np.asarray(p_list, dtype=np.float64), n=int(n), success_rate=np.array(rate), err=np.array(err),
-                converged_frac=np.array(conv), metrics=met)
+                converged_frac=np.array(conv), metrics=met, success_rate_sampled=np.array(rate_s), err_sampled=np.array(err_s),
+                frac_sampled=np.array(frac_s))
 
 
 class LadderRun:

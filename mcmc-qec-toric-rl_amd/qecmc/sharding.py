@@ -71,18 +71,32 @@ def launch(n, fn, args=(), backend="nccl", timeout=3600):
     procs = [ctx.Process(target=_rank_main, args=(r, n, port, backend, fn, args, q)) for r in range(n)]
     for p in procs:
         p.start()
+    # wait for rank 0's result while watching the children: a rank that dies (GPU fault, import error, an exception in fn) leaves
+    # the others in a barrier, so on the first non-zero exit code the remaining ranks are ended and the failure raised at once
+    import queue as _queue
+    import time as _time
     res, got = None, False
-    try:
-        res = q.get(timeout=timeout)
-        got = True
-    except Exception:
-        pass
-    for p in procs:
-        p.join(60 if got else 5)
-    bad = [(r, p.exitcode) for r, p in enumerate(procs) if p.exitcode != 0]
+    deadline = _time.monotonic() + timeout
+
+    def failed():
+        return [(r, p.exitcode) for r, p in enumerate(procs) if p.exitcode not in (None, 0)]
+    while not got and not failed() and _time.monotonic() < deadline:
+        try:
+            res = q.get(timeout=0.5)
+            got = True
+        except _queue.Empty:
+            if all(p.exitcode is not None for p in procs):
+                break                                        # everyone has left and rank 0 put nothing
+    # rank 0 has delivered: the others only have the closing barrier left
+    end = _time.monotonic() + (60 if got else 0)
+    while got and not failed() and any(p.exitcode is None for p in procs) and _time.monotonic() < end:
+        _time.sleep(0.05)
+    bad = failed()
     for p in procs:
         if p.is_alive():
             p.kill()
+    for p in procs:
+        p.join(5)
     if bad or not got:
         raise RuntimeError(f"sharding.launch: ranks failed (rank, exit code): {bad or 'no result from rank 0'}")
     return res

@@ -77,9 +77,7 @@ def run_case(c, rng):
         gk["alpha"] = c["alpha"]; ok.update(noise=orc.ALPHA, alpha=c["alpha"], det_pow=1)
     steps = ok.pop("steps")
     if c["grid"]:
-        os.environ["QECMC_QUEUE_GRID"] = c["grid"]
-    else:
-        os.environ.pop("QECMC_QUEUE_GRID", None)
+        gk["flags"] = q.dev_flags(queue_grid=int(c["grid"]))
     if c["chunks"]:
         from qecmc import harness
         run = harness.LadderRun(init, p, Nc=c["Nc"], iters=c["iters"], tops_burn=c["tops_burn"], seed=c["seed"], first_syndrome=c["first"],

@@ -28,6 +28,11 @@ def test_bench_gpus2_spawns_two_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1
     assert out["gather_ok"] is True                       # rank 1's records reached rank 0
+    # the line certifies its own ranks: the communicator's world and backend, one record per rank with its shard's first syndrome
+    assert out["comm"] == {"backend": "gloo", "world": 2}
+    assert [r["rank"] for r in out["ranks"]] == [0, 1]
+    assert [r["first_syndrome"] for r in out["ranks"]] == [0, 256]
+    assert all("device" in r and "kernel_ms_mean" in r for r in out["ranks"])
     assert out["value"] == 0.0 and "dry run" in out["metric"]          # a rehearsal never reports a throughput
 
 

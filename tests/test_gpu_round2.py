@@ -67,17 +67,19 @@ def test_replicas_with_convergence_criterion(q, orc):
     assert np.array_equal(got["converged"], ref["converged"].reshape(2, R).all(axis=1))
 
 
-def test_pteq_dropin_uses_replicas(q, orc):
-    """decoders.PTEQ(code, p) is one syndrome per call (decoders.py:25): the drop-in fills the wavefronts with
-    PTEQ_REPLICAS independent ladders and forms the percent vector from their summed counts."""
+def test_pteq_dropin_replicas_are_opt_in(q, orc):
+    """decoders.PTEQ(code, p) is one syndrome per call (decoders.py:25).  The drop-in's default is the reference's estimator, ONE
+    ladder; replicas=64 (per call, or decoders.PTEQ_REPLICAS for a script) fills the wavefronts with independent ladders and
+    forms the percent vector from their summed counts."""
     from qecmc import decoders
+    assert decoders.PTEQ_REPLICAS == 1
     rng = np.random.default_rng(2)
     code = q.Toric_code(5)
     code.qubit_matrix = rand_states(rng, 1, 5, 0.1)[0]
-    pct = q.PTEQ(code, 0.1, Nc=5, steps=300, iters=10, tops_burn=1, conv_criteria=None, seed=31)
-    R = decoders.PTEQ_REPLICAS
-    ref = orc.toric_pteq_batch(np.repeat(code.qubit_matrix[None], R, axis=0), 0.1, 5, 300, iters=10, tops_burn=1, seed=31)
-    assert np.array_equal(pct, decoders.percent_from_counts(ref["counts"].sum(axis=0), ref["samples"].sum()))
+    for R, kw in ((1, {}), (64, dict(replicas=64))):
+        pct = q.PTEQ(code, 0.1, Nc=5, steps=300, iters=10, tops_burn=1, conv_criteria=None, seed=31, **kw)
+        ref = orc.toric_pteq_batch(np.repeat(code.qubit_matrix[None], R, axis=0), 0.1, 5, 300, iters=10, tops_burn=1, seed=31)
+        assert np.array_equal(pct, decoders.percent_from_counts(ref["counts"].sum(axis=0), ref["samples"].sum()))
 
 
 # ------------------------------------------------------------------ swap / error-count observables
@@ -151,9 +153,13 @@ def test_reference_equilibrium_observables_f5(q, name):
             assert np.all(dm <= 4.5 * 1.2533 * se + floor), (name, s, "medians", np.median(ref, axis=0), np.median(gpu, axis=0), se)
             d = np.abs(ref.mean(axis=0) - gpu.mean(axis=0))
             assert np.all(d <= 4.5 * se + loose), (name, s, "means", ref.mean(axis=0), gpu.mean(axis=0), se)
-        close(r_acc, acc, 2e-3, 0.03)
-        close(r_n, nerr, 0.05, 0.03 * r_n.mean(axis=0).max())
-        close(r_h, hist, 0.03, 0.06)
+        # Allowances on top of the combined standard error: what the data uses (tools/f5_margins.py, profiles/r03_f5_margins.json)
+        # is nothing at all for the toric, rotated and biased L = 7 ladders; the biased xzzx L = 5 ladder needs 0.015 on the
+        # class-histogram means (1 GPU replica in 9 sits in a mode the reference's 16 never visited) and < 1e-3 elsewhere.
+        # The sharp pins of these paths are the exact enumerations of test_gpu_stats.py (5 sigma, 4096 replicas).
+        close(r_acc, acc, 1e-3, 5e-3)
+        close(r_n, nerr, 0.02, 5e-3 * r_n.mean(axis=0).max())
+        close(r_h, hist, 5e-3, 0.02)
 
 
 # ------------------------------------------------------------------ exact chunked continuation
@@ -187,7 +193,7 @@ def test_convergence_study_continues_exactly(q):
 def test_shards_resume_bit_for_bit(q, tmp_path):
     from qecmc import harness
     params = {"code": "toric", "size": 5, "p_error": 0.08, "noise": "depolarizing"}
-    kw = dict(steps=400, conv_criteria=None, tops_burn=1)
+    kw = dict(steps=400, conv_criteria=None, tops_burn=1, metrics="full")
     log = []
     paths = harness.generate_shards(params, 250, 100, str(tmp_path), seed=3, log=log, **kw)
     assert [os.path.basename(p) for p in paths] == [harness.shard_name("data", 3, k) for k in range(3)]
@@ -224,6 +230,26 @@ def test_threshold_curve(q):
     assert out["success_rate"][0] > 0.75 and out["success_rate"][0] > out["success_rate"][3] + 5 * out["err"][3]
     assert np.all(np.diff(out["success_rate"][1:]) < 3 * out["err"][2:] + 0.02)        # non-increasing within error (past the burn-in bound at p = 0.05)
     assert len(out["metrics"]) == 4 and out["metrics"][3]["frac_past_burn_in"] > 0.5
+    # beside the raw rate: the rate among the syndromes whose ladder got past the burn-in (the trap is not the decoder's failure)
+    assert np.all(out["frac_sampled"] > 0.5) and np.all(out["success_rate_sampled"] >= out["success_rate"] - 1e-12)
+    assert out["success_rate_sampled"][0] > 0.97
+
+
+def test_generate_with_criterion_takes_the_work_queue(q, orc):
+    """harness.generate(conv_criteria='error_based') -- the reference's default route -- must run on the work-queue kernels
+    (per-batch mixing counters used to switch them off).  With the persistent grid forced to one workgroup every lane
+    runs several ladders; results equal the oracle's one run per syndrome, and metrics='full' (which cannot use the queue)
+    gives the same answers from the one-ladder-per-lane kernel."""
+    from qecmc import harness
+    params = {"code": "toric", "size": 3, "p_error": 0.1, "noise": "depolarizing", "Nc": 3}
+    kw = dict(steps=1500, conv_criteria="error_based", tops_burn=2, SEQ=2, TOPS=6, eps=0.3, iters=5)
+    a = harness.generate(params, 333, seed=9, flags=q.dev_flags(queue_grid=1), **kw)
+    assert "swap_acceptance" not in a["metrics"]
+    b = harness.generate(params, 333, seed=9, metrics="full", **kw)
+    assert "swap_acceptance" in b["metrics"]
+    for k in ("counts", "steps_done", "converged", "samples", "tops0"):
+        assert np.array_equal(a[k], b[k]), k
+    assert a["converged"].any() and np.unique(a["steps_done"]).size > 10          # lanes did finish at different steps and refill
 
 
 # ------------------------------------------------------------------ work queue for runs that stop by the criterion (f3)
@@ -234,15 +260,13 @@ def test_threshold_curve(q):
     (3, 0.12, 3, 150, 400, 10, 1, dict(tops_burn=1, SEQ=1, TOPS=4, eps=0.5)),         # short horizon: many ladders end unconverged
     (9, 0.15, 8, 140, 300, 10, 1, dict(tops_burn=0, SEQ=0, TOPS=0, eps=0.05)),        # the headline shape (dE table); ladders of a few steps each
     (3, 0.2, 2, 130, 500, 10, 0, dict(tops_burn=0, SEQ=0, TOPS=1, eps=1.0))])         # grid 0: the production grid (no refill needed)
-def test_work_queue_bit_exact(q, orc, monkeypatch, L, p, Nc, N, steps, iters, grid, kw):
+def test_work_queue_bit_exact(q, orc, L, p, Nc, N, steps, iters, grid, kw):
     """A finished lane takes the next ladder of the batch in place; with the persistent grid forced down to one or two
     workgroups every lane runs several ladders one after the other.  Every ladder must come out as the oracle's single run."""
-    if grid:
-        monkeypatch.setenv("QECMC_QUEUE_GRID", str(grid))
     rng = np.random.default_rng(L * 100 + N)
     init = rand_states(rng, N, L, p)
     kw = dict(kw, steps=steps, iters=iters, seed=99, first_syndrome=5, conv_criteria="error_based")
-    got = q.pteq_batch(init, p, Nc=Nc, **kw)
+    got = q.pteq_batch(init, p, Nc=Nc, flags=q.dev_flags(queue_grid=grid), **kw)
     ref = orc.toric_pteq_batch(init, p, Nc, kw.pop("steps"), **kw)
     assert np.array_equal(got["converged"], ref["converged"])
     assert np.array_equal(got["steps_done"], ref["steps_done"].astype(np.uint32))
@@ -254,13 +278,12 @@ def test_work_queue_bit_exact(q, orc, monkeypatch, L, p, Nc, N, steps, iters, gr
         assert not got["converged"].all()                                              # the horizon ended some
 
 
-def test_work_queue_with_replicas(q, orc, monkeypatch):
-    monkeypatch.setenv("QECMC_QUEUE_GRID", "1")
+def test_work_queue_with_replicas(q, orc):
     rng = np.random.default_rng(77)
     init = rand_states(rng, 20, 3, 0.1)
     R = 9
     kw = dict(tops_burn=2, seed=4, conv_criteria="error_based", TOPS=6, SEQ=2, eps=0.2)
-    got = q.pteq_batch(init, 0.1, Nc=3, steps=4000, replicas=R, **kw)
+    got = q.pteq_batch(init, 0.1, Nc=3, steps=4000, replicas=R, flags=q.dev_flags(queue_grid=1), **kw)
     ref = orc.toric_pteq_batch(np.repeat(init, R, axis=0), 0.1, 3, 4000, **kw)
     assert np.array_equal(got["counts"], ref["counts"].reshape(20, R, 16).sum(axis=1))
     assert np.array_equal(got["steps_done"], ref["steps_done"].reshape(20, R).max(axis=1).astype(np.uint32))
@@ -306,8 +329,7 @@ def test_top_blocks_drawn_ahead_across_chunks(q):
 
 @pytest.mark.parametrize("name,L,Nc,N,steps,iters", [("rotated", 5, 5, 200, 3000, 10), ("xzzx", 5, 4, 150, 2000, 8), ("planar", 5, 5, 140, 2500, 10),
                                                      ("rotated", 7, 3, 100, 1500, 5)])
-def test_work_queue_plaquette_codes_bit_exact(q, orc, monkeypatch, name, L, Nc, N, steps, iters):
-    monkeypatch.setenv("QECMC_QUEUE_GRID", "1")
+def test_work_queue_plaquette_codes_bit_exact(q, orc, name, L, Nc, N, steps, iters):
     rng = np.random.default_rng(L * 11 + N)
     code, ocode = {"rotated": (q.ROTATED, orc.ROTATED), "xzzx": (q.XZZX, orc.XZZX), "planar": (q.PLANAR, orc.PLANAR)}[name]
     if name == "planar":
@@ -316,7 +338,7 @@ def test_work_queue_plaquette_codes_bit_exact(q, orc, monkeypatch, name, L, Nc, 
     else:
         init = rand_plaq(rng, N, L, 0.12)
     kw = dict(steps=steps, iters=iters, tops_burn=1, seed=17, first_syndrome=3, conv_criteria="error_based", SEQ=1, TOPS=4, eps=0.5)
-    got = q.pteq_batch(init, 0.12, Nc=Nc, code=code, **kw)
+    got = q.pteq_batch(init, 0.12, Nc=Nc, code=code, flags=q.dev_flags(queue_grid=1), **kw)
     ref = orc.pteq_batch(ocode, init, 0.12, Nc, kw.pop("steps"), **kw)
     for k in ("converged", "steps_done", "samples", "tops0"):
         assert np.array_equal(got[k], ref[k].astype(got[k].dtype)), k

@@ -195,7 +195,8 @@ def test_plaquette_depolarizing_exact_L3(q, name, seed, p, Nc):
     assert ok.mean() > 0.97
     mean, sem = _class_fractions(res, ok)
     assert np.all(np.abs(mean - P) <= 5 * sem + 2e-4), (mean, P, sem)
-    assert mean.argmax() == P.argmax()
+    if np.sort(P)[-1] - np.sort(P)[-2] > 0.01:        # (seed 13 draws the empty lattice at L = 3: the four classes tie exactly)
+        assert mean.argmax() == P.argmax()
 
 
 @pytest.mark.parametrize("name,seed,p,eta", [("xzzx", 21, 0.25, 3.0), ("xzzx", 23, 0.15, 100.0), ("rotated", 22, 0.30, 10.0)])
