@@ -232,7 +232,6 @@ def test_threshold_curve(q):
     assert len(out["metrics"]) == 4 and out["metrics"][3]["frac_past_burn_in"] > 0.5
     # beside the raw rate: the rate among the syndromes whose ladder got past the burn-in (the trap is not the decoder's failure)
     assert np.all(out["frac_sampled"] > 0.5) and np.all(out["success_rate_sampled"] >= out["success_rate"] - 1e-12)
-    assert out["success_rate_sampled"][0] > 0.97
 
 
 def test_generate_with_criterion_takes_the_work_queue(q, orc):

@@ -209,7 +209,9 @@ def test_biased_ladder_exact_L3_iters1(q, name, seed, p, eta):
     init = _rand_surf(seed)
     P = SurfEnumeration(code, init, _surf_api(q)).class_probabilities(biased_weight(p, eta))
     R, steps = 4096, 40000
-    res = q.pteq_batch(np.broadcast_to(init, (R,) + init.shape).copy(), p, Nc=3, steps=steps, iters=1, tops_burn=5, seed=3000 + seed, code=code, eta=eta)
+    # (tops_burn = 50: with the reference's handful of tops the histogram still starts in the class the first arrivals from the top
+    # happened to bring -- a transient of 36 / steps on P(class 1) in the first case, 25 sigma here, gone by 50 tops)
+    res = q.pteq_batch(np.broadcast_to(init, (R,) + init.shape).copy(), p, Nc=3, steps=steps, iters=1, tops_burn=50, seed=3000 + seed, code=code, eta=eta)
     ok = res["samples"] > steps // 2
     assert ok.mean() > 0.9
     mean, sem = _class_fractions(res, ok)
@@ -230,9 +232,10 @@ def test_biased_chain_q3_law_L3_iters10(q, name, seed, p, eta):
     Q, P = e.q3_class_law(w, 0.5, 10), e.class_probabilities(w)
     assert 0.5 * np.abs(Q - P).sum() > 0.02
     R, steps = 4096, 6000
-    res = q.pteq_batch(np.broadcast_to(init, (R,) + init.shape).copy(), p, Nc=1, steps=steps, iters=10, tops_burn=0, seed=4000 + seed, code=code, eta=eta)
-    ok = res["samples"] == steps
+    # (a 1-rung ladder counts every step as a top: tops_burn = 500 discards the first 500 calls, the transient from the seed)
+    res = q.pteq_batch(np.broadcast_to(init, (R,) + init.shape).copy(), p, Nc=1, steps=steps, iters=10, tops_burn=500, seed=4000 + seed, code=code, eta=eta)
+    ok = res["samples"] == steps - 499
     assert ok.all()
     mean, sem = _class_fractions(res, ok)
-    assert np.all(np.abs(mean - Q) <= 5 * sem + 1e-3), (mean, Q, sem)      # (every step from the seed is recorded: a 1/steps transient)
+    assert np.all(np.abs(mean - Q) <= 5 * sem + 2e-4), (mean, Q, sem)
     assert np.abs(mean - P).max() > 10 * sem.max()
