@@ -17,8 +17,10 @@
 
 #include "kernels.hpp"
 #include "stencil_bytes.hpp"
+#include "tables.hpp"
 
 using namespace qecmc;
+using namespace qecmc::tables;
 
 namespace {
 
@@ -70,151 +72,12 @@ int check_code_L(int code, int L)
 
 inline size_t code_nq(int code, int L) { return (size_t)code_nq_of(code, L); }
 
-// px^n, py^n, pz^n, pI^n for n = 0..nq (mcmc_biased.py:25-31): the same libm pow() the reference calls
-std::vector<double> bias_tables(double p, double eta, size_t nq)
-{
-    const double pz = p * eta / (eta + 1), px = p / (2 * (eta + 1)), py = px, pi = 1 - px - py - pz;
-    std::vector<double> t(4 * (nq + 1));
-    for (size_t n = 0; n <= nq; ++n) {
-        t[n] = std::pow(px, (double)n);
-        t[(nq + 1) + n] = std::pow(py, (double)n);
-        t[2 * (nq + 1) + n] = std::pow(pz, (double)n);
-        t[3 * (nq + 1) + n] = std::pow(pi, (double)n);
-    }
-    return t;
-}
-
-// The same table for the "alpha" noise model: (p_x, p_y, p_z) from (pz_tilde, alpha) exactly as Chain_alpha.update_chain
-// forms them (mcmc_alpha.py:31-36)
-std::vector<double> alpha_tables(double pz_tilde, double alpha, size_t nq)
-{
-    const double p_tilde = pz_tilde + 2 * std::pow(pz_tilde, alpha);
-    const double p = p_tilde / (1 + p_tilde);
-    const double pz = pz_tilde * (1 - p), px = std::pow(pz_tilde, alpha) * (1 - p), py = px, pi = 1 - px - py - pz;
-    std::vector<double> t(4 * (nq + 1));
-    for (size_t n = 0; n <= nq; ++n) {
-        t[n] = std::pow(px, (double)n);
-        t[(nq + 1) + n] = std::pow(py, (double)n);
-        t[2 * (nq + 1) + n] = std::pow(pz, (double)n);
-        t[3 * (nq + 1) + n] = std::pow(pi, (double)n);
-    }
-    return t;
-}
-
-// ceil(v * 2^32) as used by every integer acceptance test: u < v  <=>  x < ceil(v*2^32) for u = x*2^-32
-uint64_t thr64(double v)
-{
-    if (!(v < 1.0)) return 1ull << 32;
-    if (!(v > 0.0)) return 0;
-    return (uint64_t)std::ceil(v * 4294967296.0);
-}
-// ceil(v * 2^44): the same test on the 44-bit acceptance uniform of the non-top proposals
-uint64_t thr44(double v)
-{
-    if (!(v < 1.0)) return 1ull << 44;
-    if (!(v > 0.0)) return 0;
-    return (uint64_t)std::ceil(v * 17592186044416.0);
-}
-uint32_t thr32(double v)
-{
-    const uint64_t t = thr64(v);
-    return t > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)t;
-}
-
-// np.linspace(p_bottom, p_top, Nc) and Ladder.p_diff (src/mcmc.py:65,69)
-void ladder_probabilities(double p_bottom, double p_top, int Nc, std::vector<double> &pl, std::vector<double> &pd)
-{
-    pl.assign(Nc, p_bottom);
-    pd.assign(Nc > 1 ? Nc - 1 : 0, 1.0);
-    if (Nc > 1) {
-        const double step = (p_top - p_bottom) / (double)(Nc - 1);
-        for (int i = 0; i < Nc; ++i) pl[i] = (double)i * step + p_bottom;
-        pl[Nc - 1] = p_top;
-    }
-    for (int i = 0; i + 1 < Nc; ++i) pd[i] = (pl[i] * (1 - pl[i + 1])) / (pl[i + 1] * (1 - pl[i]));
-}
-
-inline double chain_factor(double p) { return (p / 3.0) / (1.0 - p); }   // src/mcmc.py:16
-
-// XOR masks of the toric logical operators on the 2-bit packed state
-// (toric_model.py:192-223): kind 0 = X on layer-0 row, 1 = Z on layer-0 column,
-// 2 = X on layer-1 column, 3 = Z on layer-1 row; position L = identity.
-std::vector<uint32_t> toric_logical_masks(int L, int W)
-{
-    const int LL = L * L;
-    std::vector<uint32_t> m((size_t)4 * (L + 1) * W, 0u);
-    auto set = [&](int kind, int pos, int q, uint32_t op) { m[((size_t)kind * (L + 1) + pos) * W + (q >> 4)] ^= op << ((q & 15) * 2); };
-    for (int pos = 0; pos < L; ++pos)
-        for (int i = 0; i < L; ++i) {
-            set(0, pos, pos * L + i, 1);
-            set(1, pos, i * L + pos, 3);
-            set(2, pos, LL + i * L + pos, 1);
-            set(3, pos, LL + pos * L + i, 3);
-        }
-    return m;
-}
-
-// XOR masks of the xzzx / rotated logical operators, same [4][L+1][W] layout as the toric table
-// (kinds 2, 3 unused): kind 0 = X (xzzx: anti-diagonal for every position; rotated: column `pos`),
-// kind 1 = Z (xzzx: diagonal; rotated: row `pos`); xzzx_model.py:291-311, rotated_surface_model.py:260-280
-std::vector<uint32_t> surf_logical_masks(int code, int L, int W)
-{
-    std::vector<uint32_t> m((size_t)4 * (L + 1) * W, 0u);
-    auto set = [&](int kind, int pos, int q, uint32_t op) { m[((size_t)kind * (L + 1) + pos) * W + (q >> 4)] ^= op << ((q & 15) * 2); };
-    for (int pos = 0; pos < L; ++pos)
-        for (int i = 0; i < L; ++i) {
-            if (code == QECMC_XZZX) { set(0, pos, i * L + (L - 1 - i), 1); set(1, pos, i * L + i, 3); }
-            else if (code == QECMC_PLANAR) { set(0, pos, pos * L + i, 1); set(1, pos, i * L + pos, 3); }   // row X_pos / column Z_pos of layer 0
-            else { set(0, pos, i * L + pos, 1); set(1, pos, pos * L + i, 3); }
-        }
-    return m;
-}
-
-// generator table of the toric code in sweep order: all X-type (row-major), then all Z-type; the four sites of
-// toric_model.py:261-269, each as u16 (flat site << 2 | pauli)
-std::vector<uint32_t> toric_generator_table(int L)
-{
-    const int LL = L * L;
-    std::vector<uint32_t> t((size_t)4 * LL, 0u);
-    for (int op = 0; op < 2; ++op)
-        for (int r = 0; r < L; ++r)
-            for (int c = 0; c < L; ++c) {
-                const int rm = (r + L - 1) % L, rp = (r + 1) % L, cm = (c + L - 1) % L, cp = (c + 1) % L;
-                const uint32_t pauli = op == 0 ? 1u : 3u;
-                uint32_t q[4];
-                q[0] = LL + r * L + c; q[1] = r * L + c;
-                if (op == 0) { q[2] = LL + r * L + cm; q[3] = rm * L + c; }
-                else { q[2] = r * L + cp; q[3] = LL + rp * L + c; }
-                const int g = op * LL + r * L + c;
-                t[2 * g] = ((q[0] << 2) | pauli) | (((q[1] << 2) | pauli) << 16);
-                t[2 * g + 1] = ((q[2] << 2) | pauli) | (((q[3] << 2) | pauli) << 16);
-            }
-    return t;
-}
-
-// generator table of the plaquette codes: entry g = 4 x u16 (site << 2 | pauli), two u32 per generator
-std::vector<uint32_t> surf_generator_table(int code, int L)
-{
-    const int n_gen = surf_ngen(code, L);
-    std::vector<uint32_t> t((size_t)2 * n_gen, 0u);
-    for (int g = 0; g < n_gen; ++g) {
-        int row, col, op, sites[4], paulis[4];
-        surf_gen_rco(code, L, g, row, col, op);
-        const int n = surf_generator(code, L, row, col, op, sites, paulis);
-        uint32_t e[4] = {0, 0, 0, 0};
-        for (int i = 0; i < n; ++i) e[i] = ((uint32_t)sites[i] << 2) | (uint32_t)paulis[i];
-        t[2 * g] = e[0] | (e[1] << 16);
-        t[2 * g + 1] = e[2] | (e[3] << 16);
-    }
-    return t;
-}
-
 }  // namespace
 
 struct qecmc_plan {
     qecmc_params prm;
     LadderArgs args;
-    DevBuf swap_thr, lmask, acc_top, gen, bias, lnb, xyz_lut, gen_type, queue;
+    DevBuf swap_thr, lmask, acc_top, gen, bias, lnb, xyz_lut, gen_type, queue, phases;
     uint32_t queue_grid = 0;                                   // persistent grid of the work-queue kernels (0: not a queue plan)
     size_t lds_bytes;
     uint32_t *d_swap_acc = nullptr, *d_nerr_sum = nullptr;   // qecmc_plan_set_stats (caller-owned)
@@ -241,8 +104,12 @@ int validate_params(const qecmc_params *p)
         if (p->code == QECMC_TORIC || p->code == QECMC_PLANAR) return fail(QECMC_ERR_UNSUPPORTED, "biased noise is built for the xzzx and rotated codes (BASELINE config 4)");
     } else if (!(p->p > 0.0) || !(p->p <= 0.75)) return fail(QECMC_ERR_INVALID, "p=%g must be in (0, 0.75]", p->p);
     if (!(p->p_logical >= 0.0) || !(p->p_logical <= 1.0)) return fail(QECMC_ERR_INVALID, "p_logical=%g must be in [0,1]", p->p_logical);
-    if (p->scan != QECMC_SCAN_RANDOM && p->scan != QECMC_SCAN_SWEEP) return fail(QECMC_ERR_INVALID, "scan mode %d unknown", p->scan);
-    if (p->scan == QECMC_SCAN_SWEEP && p->noise != QECMC_NOISE_DEPOLARIZING) return fail(QECMC_ERR_UNSUPPORTED, "the systematic sweep is built for the depolarizing rule only");
+    if (p->scan != QECMC_SCAN_RANDOM && p->scan != QECMC_SCAN_SWEEP && p->scan != QECMC_SCAN_COLOUR) return fail(QECMC_ERR_INVALID, "scan mode %d unknown", p->scan);
+    if (p->scan != QECMC_SCAN_RANDOM && p->noise != QECMC_NOISE_DEPOLARIZING) return fail(QECMC_ERR_UNSUPPORTED, "the systematic scans (sweep, colour) are built for the depolarizing rule only");
+    if (p->scan == QECMC_SCAN_COLOUR) {
+        if (p->conv_mode != QECMC_CONV_NONE) return fail(QECMC_ERR_UNSUPPORTED, "scan = colour runs fixed-length ladders (steps_done reports the first step with tops0 >= TOPS)");
+        if (p->p_logical > 0.0 && p->Nc < 2) return fail(QECMC_ERR_UNSUPPORTED, "scan = colour needs the top rung at p = 0.75 (Nc >= 2) when logical moves are on");
+    }
     if (p->conv_mode != QECMC_CONV_NONE && p->conv_mode != QECMC_CONV_ERROR_BASED) return fail(QECMC_ERR_INVALID, "conv_mode %d unknown", p->conv_mode);
     if (p->conv_mode == QECMC_CONV_ERROR_BASED && (p->TOPS < 0 || p->SEQ < 0 || !(p->eps >= 0))) return fail(QECMC_ERR_INVALID, "TOPS, SEQ and eps must be non-negative");
     if (p->iters == 0 || p->iters > 0xFFFFFFFFull) return fail(QECMC_ERR_INVALID, "iters out of range");
@@ -281,34 +148,18 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
     const bool typed = biased || (p->code != QECMC_TORIC && !p->scan);   // the generators' Pauli patterns: the biased rules' count-change table,
     std::vector<uint32_t> patterns;                                      // the plaquette codes' dE table (ladder_kernel.hpp, DELUT)
     if (typed) {
-        for (size_t g = 0; g < gen_type.size(); ++g) {
-            uint32_t ops = 0;
-            for (int u = 0; u < 4; ++u) ops |= ((u < 2 ? gt[2 * g] >> (16 * u) : gt[2 * g + 1] >> (16 * (u - 2))) & 3u) << (2 * u);
-            size_t t = 0;
-            while (t < patterns.size() && patterns[t] != ops) ++t;
-            if (t == patterns.size()) patterns.push_back(ops);
-            gen_type[g] = (uint8_t)t;
-        }
+        generator_patterns(gt, gen_type, patterns);
         if (patterns.size() > 16) return fail(QECMC_ERR_UNSUPPORTED, "%zu distinct generator Pauli patterns (> 16)", patterns.size());
         a.n_types = (int)patterns.size();
         for (size_t t = 0; t < patterns.size(); ++t) a.type_ops[t] = (uint8_t)patterns[t];
     }
     if (biased) {
-        // the biased / alpha rules' table of count changes: one row of 256 (the four old 2-bit fields) per distinct Pauli
-        // pattern among the generators; entry = dx + (dz << 10) + ((dx + dy) << 20), wrapping (added to packed counts)
+        // the biased / alpha rules' table of count changes (tables.hpp)
         if (nq > 511) return fail(QECMC_ERR_UNSUPPORTED, "biased / alpha noise packs the error counts in 10-bit fields: nq=%d", nq);
-        xyz_lut.assign(256 * patterns.size(), 0u);
-        for (size_t t = 0; t < patterns.size(); ++t)
-            for (uint32_t F = 0; F < 256; ++F) {
-                int d[4] = {0, 0, 0, 0};                                     // change of the counts of I, X, Y, Z
-                for (int u = 0; u < 4; ++u) {
-                    const uint32_t old = (F >> (2 * u)) & 3u, neu = old ^ ((patterns[t] >> (2 * u)) & 3u);
-                    d[old]--; d[neu]++;
-                }
-                xyz_lut[256 * t + F] = (uint32_t)d[1] + ((uint32_t)d[3] << 10) + ((uint32_t)(d[1] + d[2]) << 20);
-            }
+        xyz_lut = count_change_table(patterns);
     }
-    pl->lds_bytes = ladder_lds_bytes(L, Nc, W, ncls, ladder_gen_dwords(p->code, p->noise, p->scan, n_gen, Nc, nq, a.n_types));
+    pl->lds_bytes = p->scan == QECMC_SCAN_COLOUR ? sizeof(uint32_t) * ((size_t)Nc * W + 4 * (size_t)Nc + (size_t)ncls)   // (ladder_colour.hip: one ladder per workgroup)
+                                                 : ladder_lds_bytes(L, Nc, W, ncls, ladder_gen_dwords(p->code, p->noise, p->scan, n_gen, Nc, nq, a.n_types));
     if (pl->lds_bytes > 160 * 1024)
         return fail(QECMC_ERR_UNSUPPORTED, "L=%d Nc=%d needs %zu B of LDS per workgroup (> 160 KiB)", L, Nc, pl->lds_bytes);
     if (ladder_uses_queue(p->code, p->noise, p->scan, p->conv_mode, L, Nc, p->p_logical)) {
@@ -339,9 +190,7 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
     }
     std::vector<uint32_t> top_tbl(nq + 1, 0u);                             // mcmc.py:34 for a top chain below p = 0.75
     for (int d = 1; d <= nq && !biased; ++d) top_tbl[d] = thr32(std::pow(chain_factor(pladder[Nc - 1]), (double)d));
-    std::vector<uint64_t> sw((size_t)(Nc > 1 ? Nc - 1 : 1) * (nq + 1), 0);
-    for (int i = 0; i + 1 < Nc; ++i)
-        for (int d = 0; d <= nq; ++d) sw[(size_t)i * (nq + 1) + d] = thr64(std::pow(pdiff[i], (double)d));   // mcmc.py:149
+    const std::vector<uint64_t> sw = swap_thresholds(pdiff, nq);             // mcmc.py:149
     for (int i = 0; i + 1 < Nc; ++i) {
         const double l2 = std::log2(pdiff[i]);
         a.swap_inv_log2[i] = (std::isfinite(l2) && l2 < 0) ? (float)(1.0 / l2) : 0.0f;
@@ -351,6 +200,17 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
         if (nq >= 1 && sw[(size_t)i * (nq + 1) + 1] > 0xFFFFFFFFull) a.swap_fast_ok = 0;
     const std::vector<uint32_t> lm = p->code == QECMC_TORIC ? toric_logical_masks(L, W) : surf_logical_masks(p->code, L, W);
     a.scan = p->scan;
+    if (p->scan == QECMC_SCAN_COLOUR) {
+        // the colour phases: groups of mutually disjoint generators, one wavefront pass each (tables.hpp)
+        int n_phases = 0;
+        const std::vector<uint16_t> ph = colour_phases(gt, n_phases);
+        HIP_TRY(pl->phases.alloc(ph.size() * sizeof(uint16_t)));
+        HIP_TRY(hipMemcpy(pl->phases.p, ph.data(), ph.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        a.phase_tab = pl->phases.as<uint16_t>();
+        a.n_phases = (uint32_t)n_phases;
+        if (p->p_logical > 0.0 && !((a.acc_all_mask >> (Nc - 1)) & 1u))
+            return fail(QECMC_ERR_UNSUPPORTED, "scan = colour needs a top rung that accepts every move (p_top = 0.75) when logical moves are on");
+    }
     {
         a.n_gen = (uint32_t)(gt.size() / 2);
         HIP_TRY(pl->gen.alloc(gt.size() * sizeof(uint32_t)));
@@ -648,6 +508,7 @@ static int ladder_step_impl(const qecmc_params *params, uint64_t N, uint8_t *sta
     p.conv_mode = QECMC_CONV_NONE;
     p.replicas = 0;
     if (int rc = validate_params(&p)) return rc;
+    if (p.scan == QECMC_SCAN_COLOUR) return fail(QECMC_ERR_UNSUPPORTED, "scan = colour starts its ladders from seed configurations (qecmc_pteq_batch / qecmc_pteq_launch_dev)");
     if (!states_inout || !flags_inout || !tops0_inout) return fail(QECMC_ERR_INVALID, "NULL buffer");
     if ((p.noise == QECMC_NOISE_ALPHA) != (neff_inout != nullptr))
         return fail(QECMC_ERR_INVALID, "alpha-noise ladders step through qecmc_ladder_step_alpha (which carries the slots' n_eff), the others through qecmc_ladder_step");
@@ -784,6 +645,7 @@ int qecmc_plan_set_stats(qecmc_plan *plan, void *d_swap_accepts, void *d_nerr_su
     if (!plan) return fail(QECMC_ERR_INVALID, "plan is NULL");
     if (d_nerr_sums && !d_swap_accepts) return fail(QECMC_ERR_INVALID, "d_nerr_sums needs d_swap_accepts");
     if (d_swap_accepts && plan->args.Nc < 2) return fail(QECMC_ERR_INVALID, "swap statistics need Nc >= 2");
+    if (d_swap_accepts && plan->args.scan == QECMC_SCAN_COLOUR) return fail(QECMC_ERR_UNSUPPORTED, "swap statistics are not collected by the scan = colour kernel");
     if (d_swap_accepts && plan->lds_bytes + ladder_stats_lds_bytes(plan->args.Nc) > 160 * 1024)
         return fail(QECMC_ERR_UNSUPPORTED, "no LDS left for the statistics counters at this L / Nc");
     plan->d_swap_acc = static_cast<uint32_t *>(d_swap_accepts);
@@ -801,6 +663,7 @@ int qecmc_pteq_resume_dev(qecmc_plan *plan, void *d_states, void *d_flags, void 
     if (plan->prm.conv_mode != QECMC_CONV_NONE) return fail(QECMC_ERR_INVALID, "qecmc_pteq_resume_dev runs fixed-length chunks: conv_mode must be NONE");
     if (plan->args.replicas > 1) return fail(QECMC_ERR_INVALID, "qecmc_pteq_resume_dev continues single ladders: replicas must be <= 1");
     if (plan->args.noise == QECMC_NOISE_ALPHA) return fail(QECMC_ERR_UNSUPPORTED, "alpha-noise ladders carry n_eff: continue them with qecmc_ladder_step_alpha");
+    if (plan->args.scan == QECMC_SCAN_COLOUR) return fail(QECMC_ERR_UNSUPPORTED, "scan = colour starts its ladders from seed configurations: no chunked continuation");
     if (N + first_syndrome > 0xFFFFFFFFull) return fail(QECMC_ERR_INVALID, "global syndrome index exceeds 32 bits");
     LadderArgs a = plan->args;
     a.states = static_cast<uint8_t *>(d_states); a.flags = static_cast<uint8_t *>(d_flags); a.tops0 = static_cast<uint32_t *>(d_tops0);

@@ -59,6 +59,8 @@ struct LadderArgs {
     uint32_t *neff;           // [N][Nc]            alpha noise: the slots' n_eff attributes as n_z | (n_x+n_y) << 16; resume in / out
     int code, noise;          // qecmc_code, qecmc_noise
     int scan;                 // qecmc_scan
+    const uint16_t *phase_tab;//                    scan = 2: [n_phases][64] generator indices of every colour phase, 0xFFFF = idle lane
+    uint32_t n_phases;
     uint32_t n_gen;           // number of stabilizer generators G (sweep order = table order)
     const uint32_t *acc_tbl_top; // [nq+1]          ceil(f_top^dE * 2^32): top slot below p = 0.75 (Nc == 1 only)
     uint64_t N;

@@ -1,0 +1,259 @@
+// scan = 2 (QECMC_SCAN_COLOUR): the latency layout.  One workgroup per LADDER (one syndrome), one wavefront per rung, the lanes
+// of a wavefront = the stabilizer generators of one colour phase, proposed all at once.
+//
+// The reference decodes ONE syndrome per call (decoders.py:25, generate_data.py:136).  The throughput kernels (ladder_kernel.hpp)
+// give every chain one lane and advance it one proposal at a time -- 64 syndromes per wavefront; a single syndrome then waits for
+// 162 sequential proposals per sweep at L = 9.  Here the parallelism is inside the chain (BASELINE.json's north star:
+// "thread-block per syndrome, checkerboard-parallel stabilizer flips, wavefront reductions for the dE count"): generators that
+// share no qubit commute and their Metropolis tests are independent, so a whole phase of them is one wavefront instruction
+// stream; a sweep is n_phases of those (7 at toric L = 9) instead of 162 proposals.
+//
+// This is NOT the reference's Markov chain (a systematic scan, like scan = 1): every single-generator Metropolis kernel keeps
+// the rung's stationary law, hence so does their composition.  The rule, which the oracle restates (orc_model.scan = 2):
+//   * the plan cuts the generators into phases (tables.hpp colour_phases: greedy colouring in table order, chunks of <= 64);
+//     phase index K of a rung counts from prop0 = step0 * iters; a ladder step = `iters` phases of every rung, phase K uses
+//     phase (K mod n_phases) of the table;
+//   * top rung (slot Nc - 1, p_logical > 0; it sits at p = 0.75 where every move is accepted, mcmc.py:30): before the phase, with
+//     probability p_logical (word 0 of block (K, 0) < ceil(p_logical 2^32)) one uniformly random logical operator drawn from
+//     words 1-3 of that block exactly as scan = 1 draws it (toric_model.py:228-253 / xzzx_model.py:340-357);
+//   * generator i of the phase draws u = word (i & 3) of block (K, 8 + (i >> 2)) of the rung's stream (the slot's own for the
+//     top rule, the diagonal stream kDiagStream + (slot + step) mod Nc otherwise, as in the other scans);
+//     a rung with f < 1 accepts iff u < ceil(f^dE 2^32) (dE <= 0: always; mcmc.py:42); a rung with f >= 1 (where a
+//     coin-less sweep would compose to the identity) applies the generator iff the top bit of u is set;
+//   * swap sweep, tops0 / class histogram bookkeeping: mcmc.py:94-103 and decoders.py:60-68 unchanged (swap uniforms: word i & 3
+//     of block (t, i >> 2) of the swap stream, as in the other scans).
+// steps_done (no convergence criterion in this layout) reports the first ladder step after which tops0 >= TOPS (or `steps`),
+// converged whether it was reached: the "time to tops0 >= 10" the latency table of profiles/ quotes.
+#include "ladder_kernel.hpp"
+
+namespace qecmc {
+
+__device__ __forceinline__ int wave_sum(int v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int CODE>
+__global__ __launch_bounds__(1024) void ladder_colour_kernel(const LadderArgs a)
+{
+    extern __shared__ uint32_t lds[];
+    const int NC = a.Nc, W = a.W, L = a.L, LL = L * L, nq = a.nq, ncls = a.ncls;
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);      // this wave's rung: fixed (states move by id)
+    uint32_t *st = lds;                                  // [NC][W]   packed states, 2 bits per qubit
+    uint32_t *rec = st + NC * W;                         // [2][NC]   slot records by step parity (pack_info)
+    uint32_t *swu = rec + 2 * NC;                        // [2][NC]   swap uniforms by step parity
+    uint32_t *hist = swu + 2 * NC;                       // [ncls]
+    const uint32_t R = a.replicas;
+    const uint64_t ladder = blockIdx.x;                  // one workgroup per ladder
+    if (ladder >= a.N) return;
+    const uint32_t syn = a.first_syndrome + (uint32_t)ladder;
+    const uint64_t row = ladder / R;
+
+    // ---- stage: this wave packs the seed configuration into its own slot (Ladder.__init__ copies it into every rung, mcmc.py:72)
+    const uint8_t *src = a.init + row * (uint64_t)nq;
+    int cnt0 = 0;
+    for (int w = lane; w < W; w += 64) {
+        uint32_t word = 0;
+        for (int b = 0; b < 16; ++b) {
+            const int q = w * 16 + b;
+            if (q < nq) word |= (uint32_t)(src[q] & 3u) << (2 * b);
+        }
+        st[slot * W + w] = word;
+        cnt0 += (int)nnz2(word);
+    }
+    for (int c = tid; c < ncls; c += NC * 64) hist[c] = 0;
+    __syncthreads();
+    // wave-uniform slot state: error count, state id, class, flag (Chain.flag, mcmc.py:75)
+    uint32_t n = (uint32_t)wave_sum(cnt0), sid = slot, flag = slot == (uint32_t)(NC - 1);
+    uint32_t cls;
+    {
+        uint32_t c = 0;
+        if (lane == 0) {                                 // W words, once: the serial class functions of ladder_kernel.hpp with a lane stride of 1
+            if constexpr (CODE == kCodeToric) {
+                const int wb = LL >> 4;
+                const uint32_t lowmask = (1u << ((LL & 15) * 2)) - 1u;
+                uint32_t acc0 = 0, acc1 = 0;
+                for (int w = 0; w < W; ++w) {
+                    const uint32_t x = st[slot * W + w];
+                    if (w < wb) acc0 ^= x;
+                    else if (w > wb) acc1 ^= x;
+                    else { acc0 ^= x & lowmask; acc1 ^= x & ~lowmask; }
+                }
+                c = (__popc((acc0 ^ (acc0 >> 1)) & 0x55555555u) & 1u) + 2u * (__popc(acc0 & 0xAAAAAAAAu) & 1u) +
+                    4u * (__popc((acc1 ^ (acc1 >> 1)) & 0x55555555u) & 1u) + 8u * (__popc(acc1 & 0xAAAAAAAAu) & 1u);
+            } else {
+                uint32_t x = 0, z = 0;
+                const uint32_t *sb = st + slot * W;
+                for (int i = 0; i < L; ++i) {
+                    const uint32_t qa = (uint32_t)i, qb = (uint32_t)(i * L);
+                    const uint32_t fa = (sb[qa >> 4] >> ((qa & 15u) * 2u)) & 3u, fb = (sb[qb >> 4] >> ((qb & 15u) * 2u)) & 3u;
+                    const uint32_t xa = (fa ^ (fa >> 1)) & 1u, za = fa >> 1, xb = (fb ^ (fb >> 1)) & 1u, zb = fb >> 1;
+                    if (CODE == kCodeXzzx) { x ^= (i & 1) ? za : xa; z ^= (i & 1) ? xb : zb; }
+                    else if (CODE == kCodePlanar) { x ^= xb; z ^= za; }
+                    else { x ^= xa; z ^= zb; }
+                }
+                c = x | (z << 1);
+            }
+        }
+        cls = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+    }
+    n = (uint32_t)__builtin_amdgcn_readfirstlane((int)n);
+    uint32_t tops0 = 0, samples = 0, t_reached = 0;     // wave 0's bookkeeping (uniform)
+    const bool acc_all = (a.acc_all_mask >> slot) & 1u;
+    const bool top_logical = slot == (uint32_t)(NC - 1) && a.thr_logical != 0;
+    const uint32_t thrL1 = (uint32_t)(a.thr_logical - 1);
+    // accept iff u <= thr[dE + 4] (dE <= 0 or f >= 1: always -- a rung with f >= 1 takes the coin instead)
+    const uint32_t thr1 = a.acc_thr[slot][0] - 1u, thr2 = a.acc_thr[slot][1] - 1u, thr3 = a.acc_thr[slot][2] - 1u, thr4 = a.acc_thr[slot][3] - 1u;
+    const uint32_t iters = a.iters, P = a.n_phases;
+    const uint32_t *lmask = a.lmask;
+    const int LW = (L + 1) * W;
+
+    for (uint64_t t = 0; t < a.nsteps; ++t) {
+        uint32_t *sb = st + sid * W;
+        bool recount = false;
+        // the rung's Philox stream at this step: the slot's own for the top rule, the diagonal one otherwise (philox.hpp)
+        const uint32_t strm = top_logical ? slot : kDiagStream + (uint32_t)(((uint64_t)slot + a.step0 + t) % (uint64_t)NC);
+        for (uint32_t j = 0; j < iters; ++j) {
+            const uint64_t K = a.prop0 + t * iters + j;
+            if (top_logical) {
+                const u32x4 x = philox_block(K, 0, syn, strm, a.seed_lo, a.seed_hi);     // (wave-uniform)
+                if (x.x <= thrL1) {
+                    const uint32_t *m0 = lmask + L * W, *m1 = m0, *m2 = m0, *m3 = m0;    // identity rows
+                    uint32_t cdelta;
+                    if constexpr (CODE == kCodeToric) {
+                        const uint32_t op0 = x.y >> 30, op1 = x.z >> 30;
+                        const uint32_t dx0 = (op0 ^ (op0 >> 1)) & 1u, dz0 = op0 >> 1, dx1 = (op1 ^ (op1 >> 1)) & 1u, dz1 = op1 >> 1;
+                        if (dx0) m0 = lmask + scale_low30(x.y, L) * W;
+                        if (dz0) m1 = lmask + LW + scale_u16(x.w >> 16, L) * W;
+                        if (dx1) m2 = lmask + 2 * LW + scale_low30(x.z, L) * W;
+                        if (dz1) m3 = lmask + 3 * LW + scale_u16(x.w & 0xFFFFu, L) * W;
+                        cdelta = (L & 1) ? (dx0 | (dz0 << 1) | (dx1 << 2) | (dz1 << 3)) : 0u;
+                    } else {
+                        const uint32_t op = x.y >> 30;
+                        const uint32_t xp = ((op ^ (op >> 1)) & 1u) ? scale_low30(x.y, L) : 0u, zp = (op >> 1) ? scale_u16(x.w >> 16, L) : 0u;
+                        const uint32_t ax = CODE == kCodeXzzx ? ((op ^ (op >> 1)) & 1u) : (op & 1u), az = op >> 1;
+                        if (ax) m0 = lmask + xp * W;
+                        if (az) m1 = lmask + LW + zp * W;
+                        cdelta = ax | (az << 1);
+                    }
+                    for (int w = lane; w < W; w += 64) sb[w] ^= m0[w] ^ m1[w] ^ m2[w] ^ m3[w];
+                    cls ^= cdelta;
+                    recount = true;
+                }
+            }
+            // ---- one phase: every lane its generator
+            const uint32_t gid = a.phase_tab[(size_t)(K % P) * 64 + lane];
+            const bool active = gid != 0xFFFFu;
+            const uint2 e = a.gen[active ? gid : 0u];                         // 4 x (site << 2 | pauli), 0 = no site
+            const uint32_t ent[4] = {e.x & 0xFFFFu, e.x >> 16, e.y & 0xFFFFu, e.y >> 16};
+            uint32_t *ad[4];
+            uint32_t sh[4], F = 0, OPS = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t q = ent[i] >> 2;
+                ad[i] = sb + (q >> 4);
+                sh[i] = (q & 15u) * 2u;
+                F |= ((*ad[i] >> sh[i]) & 3u) << (2 * i);                     // (an unused entry reads site 0 into both and cancels)
+                OPS |= (ent[i] & 3u) << (2 * i);
+            }
+            const uint32_t G = F ^ OPS;
+            const int dE = (int)__popc((G | (G >> 1)) & 0x55u) - (int)__popc((F | (F >> 1)) & 0x55u);      // toric_model.py:275-282
+            const u32x4 xb = philox_block(K, 8u + ((uint32_t)lane >> 2), syn, strm, a.seed_lo, a.seed_hi);
+            const uint32_t u = sel4(xb, lane & 3);
+            const uint32_t thr = dE == 1 ? thr1 : dE == 2 ? thr2 : dE == 3 ? thr3 : thr4;
+            const bool acc = active && (acc_all ? (u >> 31) != 0u : (dE <= 0 || u <= thr));   // mcmc.py:42 / :30 with the coin
+            if (acc) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) lds_xor(ad[i], (ent[i] & 3u) << sh[i]);     // (same-word updates of different lanes: LDS atomics)
+            }
+            n = (uint32_t)((int)n + __builtin_amdgcn_readfirstlane(wave_sum(acc ? dE : 0)));
+        }
+        if (recount) {                                                        // the logical operators moved O(L) sites
+            int c = 0;
+            for (int w = lane; w < W; w += 64) c += (int)nnz2(sb[w]);
+            n = (uint32_t)__builtin_amdgcn_readfirstlane(wave_sum(c));
+        }
+        // ---- Ladder.step's swap sweep (mcmc.py:96-103): records and uniforms out, one barrier, every wave replays the cascade
+        uint32_t *cur = rec + (t & 1) * NC, *sx = swu + (t & 1) * NC;
+        if (lane == 0) cur[slot] = pack_info(n, sid, cls, flag);
+        if ((int)slot * 4 < NC - 1) {
+            const u32x4 b = philox_block(a.step0 + t, slot, syn, kSwapStream, a.seed_lo, a.seed_hi);
+            if (lane < 4 && (int)slot * 4 + lane < NC - 1) sx[slot * 4 + lane] = sel4(b, lane);
+        }
+        __syncthreads();
+        uint32_t car = cur[NC - 1], mine = car;
+        for (int i = NC - 2; i >= 0; --i) {
+            const uint32_t lo = cur[i], xi = sx[i];
+            const int d = (int)(car & 0xFFFFu) - (int)(lo & 0xFFFFu);                  // ne_hi - ne_lo, _r_flip mcmc.py:146-149
+            const bool flip = d <= 0 || (uint64_t)xi < a.swap_thr[(size_t)i * (nq + 1) + d];
+            const uint32_t into = flip ? lo : car;
+            car = flip ? car : lo;
+            if ((int)slot == i + 1) mine = into;
+        }
+        if (slot == 0) mine = car;
+        mine = (uint32_t)__builtin_amdgcn_readfirstlane((int)mine);
+        n = mine & 0xFFFFu; sid = (mine >> 16) & 0xFFu; cls = (mine >> 24) & 0x3Fu; flag = mine >> 31;
+        if ((int)slot == NC - 1) flag = 1;                                               // mcmc.py:100
+        if (slot == 0) {
+            tops0 += (NC == 1) | flag;                                                   // :101-102
+            flag = 0;                                                                    // :103
+            if (a.counts != nullptr && tops0 >= a.tops_burn) {                           // decoders.py:60-67
+                if (lane == 0) hist[CODE == kCodeXzzx ? (cls ^ (cls >> 1)) : cls] += 1;
+                samples++;
+            }
+            if (!t_reached && tops0 >= a.TOPS) t_reached = (uint32_t)t + 1u;
+        }
+    }
+    __syncthreads();
+    // ---- results
+    uint32_t *fin = rec;                                                                 // every wave's final record, for the state dump
+    if (lane == 0) fin[slot] = pack_info(n, sid, cls, flag);
+    __syncthreads();
+    if (slot == 0) {
+        if (a.counts != nullptr)
+            for (int c = lane; c < ncls; c += 64) {
+                if (R > 1) { if (hist[c]) atomicAdd(a.counts + row * ncls + c, hist[c]); }
+                else a.counts[row * ncls + c] = hist[c];
+            }
+        if (lane == 0) {
+            const uint32_t sd = t_reached ? t_reached : (uint32_t)a.nsteps;
+            if (R > 1) {
+                if (a.samples != nullptr) atomicAdd(a.samples + row, samples);
+                if (a.tops0 != nullptr) atomicAdd(a.tops0 + row, tops0);
+                if (a.steps_done != nullptr) atomicMax(a.steps_done + row, sd);
+                if (a.converged != nullptr && !t_reached) a.converged[row] = 0;
+            } else {
+                if (a.samples != nullptr) a.samples[row] = samples;
+                if (a.tops0 != nullptr) a.tops0[row] = tops0;
+                if (a.steps_done != nullptr) a.steps_done[row] = sd;
+                if (a.converged != nullptr) a.converged[row] = t_reached != 0;
+            }
+        }
+    }
+    if (a.write_states && a.states != nullptr) {
+        uint8_t *dst = a.states + (ladder * NC + slot) * (uint64_t)nq;                   // slot order
+        const uint32_t sidc = (fin[slot] >> 16) & 0xFFu;
+        for (int q = lane; q < nq; q += 64) dst[q] = (uint8_t)((st[sidc * W + (q >> 4)] >> ((q & 15) * 2)) & 3u);
+    }
+    if (a.flags != nullptr && lane == 0) a.flags[ladder * NC + slot] = (uint8_t)(fin[slot] >> 31);
+}
+
+hipError_t launch_ladder_colour(const LadderArgs &a, hipStream_t stream)
+{
+    if (a.phase_tab == nullptr || a.n_phases == 0 || a.noise != 0 || a.conv_mode != 0 || a.resume) return hipErrorInvalidValue;
+    const void *fn = a.code == kCodeToric ? (const void *)ladder_colour_kernel<kCodeToric>
+                   : a.code == kCodeXzzx ? (const void *)ladder_colour_kernel<kCodeXzzx>
+                   : a.code == kCodeRotated ? (const void *)ladder_colour_kernel<kCodeRotated>
+                   : a.code == kCodePlanar ? (const void *)ladder_colour_kernel<kCodePlanar> : nullptr;
+    if (!fn) return hipErrorInvalidValue;
+    const size_t lds = sizeof(uint32_t) * ((size_t)a.Nc * a.W + 4 * (size_t)a.Nc + (size_t)a.ncls);
+    void *kargs[] = {const_cast<LadderArgs *>(&a)};
+    hipError_t e = hipLaunchKernel(fn, dim3((unsigned)a.N), dim3((unsigned)a.Nc * 64u), kargs, lds, stream);
+    if (e != hipSuccess) return e;
+    return hipGetLastError();
+}
+
+}  // namespace qecmc

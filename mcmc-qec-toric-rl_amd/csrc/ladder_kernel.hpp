@@ -2014,5 +2014,6 @@ hipError_t launch_ladder_sweep(const LadderArgs &a, hipStream_t stream);      //
 hipError_t launch_ladder_surf(const LadderArgs &a, hipStream_t stream);       // ladder_surf.hip: xzzx / rotated / planar, depolarizing, random scan
 hipError_t launch_ladder_biased(const LadderArgs &a, hipStream_t stream);     // ladder_biased.hip: biased and alpha rules
 hipError_t launch_ladder_uset(const LadderArgs &a, hipStream_t stream);       // ladder_uset.hip: the unique-chain estimators' set insertion
+hipError_t launch_ladder_colour(const LadderArgs &a, hipStream_t stream);     // ladder_colour.hip: scan = 2, one workgroup per ladder, colour-parallel phases
 
 }  // namespace qecmc

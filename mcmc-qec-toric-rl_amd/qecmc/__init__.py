@@ -1,7 +1,7 @@
 """qecmc -- MI355X-native MCMC equivalence-class sampler (host-side mirror of the
 reference's Toric_code / Chain / Ladder / PTEQ API over the libqecmc C-ABI)."""
 from ._lib import QecmcError, device_count, lib, dev_flags, use_library
-from ._lib import TORIC, XZZX, ROTATED, PLANAR
+from ._lib import TORIC, XZZX, ROTATED, PLANAR, SCANS
 from .toric_model import Toric_code
 from .xzzx_model import xzzx_code
 from .rotated_surface_model import RotSurCode

@@ -24,7 +24,9 @@ def pteq_batch(init, p, Nc=None, steps=1000, iters=10, tops_burn=2, p_logical=0.
     init: uint8[N, 2, L, L] (toric, code=PLANAR) or uint8[N, L, L] (code=XZZX / ROTATED) seed configurations, one per
     syndrome; eta selects the biased chain of src/mcmc_biased.py (PTEQ_biased), alpha the "alpha" noise ladder of
     src/mcmc_alpha.py (PTEQ_alpha; `p` is then pz_tilde); scan="random" is the reference's
-    chain, scan="sweep" the systematic generator sweep (same stationary law, faster).  conv_criteria None runs exactly
+    chain, scan="sweep" the systematic generator sweep (same stationary law), scan="colour" the latency layout for few
+    syndromes: one workgroup per ladder, a whole colour phase of mutually disjoint generators per wavefront pass (`iters` counts
+    phases; steps_done / converged report the first step with tops0 >= TOPS; depolarizing rule, fixed-length runs).  conv_criteria None runs exactly
     `steps` ladder steps; 'error_based' stops each syndrome by the reference's criterion (:74-105).
     replicas=R > 1 runs R independent ladders per syndrome (Philox index first_syndrome + s*R + r) and sums their class
     counts, samples and tops0 on the device (steps_done: the slowest ladder; converged: all of them) -- the droplets
@@ -47,7 +49,7 @@ def pteq_batch(init, p, Nc=None, steps=1000, iters=10, tops_burn=2, p_logical=0.
                         conv_mode=L_.CONV_ERROR_BASED if conv_criteria else L_.CONV_NONE,
                         noise=L_.NOISE_ALPHA if alpha is not None else L_.NOISE_DEPOLARIZING if eta is None else L_.NOISE_BIASED,
                         eta=0.0 if eta is None else float(eta), alpha=0.0 if alpha is None else float(alpha),
-                        scan={"random": L_.SCAN_RANDOM, "sweep": L_.SCAN_SWEEP}[scan], replicas=int(replicas), flags=int(flags))
+                        scan=L_.SCANS[scan], replicas=int(replicas), flags=int(flags))
     R = max(int(replicas), 1)
     counts = np.zeros((N, ncls), dtype=np.uint32)
     samples = np.zeros(N, dtype=np.uint32)

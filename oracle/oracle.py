@@ -105,6 +105,7 @@ def lib():
         _LIB.orc_planar_syndrome.argtypes = [C.c_int, u8p, u8p, u8p]
         _LIB.orc_planar_syndrome.restype = None
         _LIB.orc_surf_ngen.argtypes = [C.c_int, C.c_int]; _LIB.orc_surf_ngen.restype = C.c_int
+        _LIB.orc_colour_phases.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]; _LIB.orc_colour_phases.restype = C.c_int
         _LIB.orc_surf_gen_rco.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         _LIB.orc_surf_gen_rco.restype = None
         _LIB.orc_chain_update.argtypes = [mp, u8p, C.c_double, C.c_double, C.c_uint64, C.POINTER(_Rng), C.c_uint32,
@@ -331,6 +332,15 @@ def planar_syndrome(m):
     v = np.zeros((L - 1, L), dtype=np.uint8); q = np.zeros((L, L - 1), dtype=np.uint8)
     lib().orc_planar_syndrome(L, _u8(m), _u8(v), _u8(q))
     return v.astype(bool), q.astype(bool)
+
+
+def colour_phases(code, L):
+    """scan = 2: int32[n_phases, 64] generator indices of the colour phases (-1 = none), the oracle's own statement of the rule"""
+    buf = np.full(64 * 64, -1, dtype=np.int32)
+    n = int(lib().orc_colour_phases(code, L, buf.ctypes.data_as(C.POINTER(C.c_int)), buf.size))
+    if n < 0 or n > 64:
+        raise RuntimeError("colour_phases: %d" % n)
+    return buf[:n * 64].reshape(n, 64).copy()
 
 
 def surf_ngen(code, L):

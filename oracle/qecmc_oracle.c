@@ -446,6 +446,106 @@ static void chain_update_sweep(const orc_model *m, uint8_t *state, double p, dou
     }
 }
 
+/* scan = 2 ("colour"): the generators are cut into PHASES of mutually disjoint generators (no shared qubit), and a chain
+ * advances one whole phase at a time -- on the GPU one wavefront pass, here the members one after the other, which is the same
+ * thing because they commute and their tests do not see each other.  The phases, stated here independently of the library:
+ * greedy colouring in sweep order (colour(g) = the smallest colour that no earlier generator sharing a qubit with g has), then
+ * every colour class, in increasing g, in consecutive chunks of at most 64.  tab[phase][i] = generator, -1 = none. */
+typedef struct { int code, L, n_phases; int *tab; } colour_phases_t;
+static colour_phases_t g_phases[16];
+static int g_n_phases_cached = 0;
+
+static const colour_phases_t *colour_phases(const orc_model *m)
+{
+    const colour_phases_t *hit = NULL;
+#pragma omp critical(orc_colour_phases)
+    {
+        for (int i = 0; i < g_n_phases_cached; ++i)
+            if (g_phases[i].code == m->code && g_phases[i].L == m->L) hit = &g_phases[i];
+        if (!hit && g_n_phases_cached < 16) {
+            const int L = m->L, nq = orc_nq(m->code, L);
+            const int G = m->code == ORC_TORIC ? 2 * L * L : orc_surf_ngen(m->code, L);
+            uint8_t *zero = calloc((size_t)nq, 1), *pat = malloc((size_t)G * nq);
+            int *colour = malloc(sizeof(int) * (size_t)G), n_colours = 0;
+            for (int g = 0; g < G; ++g) model_sweep_stabilizer(m, zero, pat + (size_t)g * nq, (uint64_t)g);   /* the generator's own Paulis */
+            for (int g = 0; g < G; ++g) {
+                int c = 0, again = 1;
+                while (again) {
+                    again = 0;
+                    for (int h = 0; h < g && !again; ++h) {
+                        if (colour[h] != c) continue;
+                        for (int q = 0; q < nq; ++q)
+                            if (pat[(size_t)g * nq + q] && pat[(size_t)h * nq + q]) { again = 1; break; }
+                    }
+                    if (again) ++c;
+                }
+                colour[g] = c;
+                if (c + 1 > n_colours) n_colours = c + 1;
+            }
+            int n_ph = 0;
+            for (int c = 0; c < n_colours; ++c) {
+                int members = 0;
+                for (int g = 0; g < G; ++g) members += colour[g] == c;
+                n_ph += (members + 63) / 64;
+            }
+            colour_phases_t *e = &g_phases[g_n_phases_cached];
+            e->code = m->code; e->L = L; e->n_phases = n_ph; e->tab = malloc(sizeof(int) * (size_t)n_ph * 64);
+            for (int i = 0; i < n_ph * 64; ++i) e->tab[i] = -1;
+            int ph = -1;
+            for (int c = 0; c < n_colours; ++c) {
+                int fill = 64;
+                for (int g = 0; g < G; ++g) {
+                    if (colour[g] != c) continue;
+                    if (fill == 64) { ++ph; fill = 0; }
+                    e->tab[ph * 64 + fill++] = g;
+                }
+            }
+            free(zero); free(pat); free(colour);
+            ++g_n_phases_cached;
+            hit = e;
+        }
+    }
+    return hit;
+}
+
+int orc_colour_phases(int code, int L, int *tab_out, int cap)
+{
+    orc_model m = {code, L, ORC_NOISE_DEPOLARIZING, 0.0, 0.0, 2, 0, {0.0, 0.0, 0.0}};
+    const colour_phases_t *ph = colour_phases(&m);
+    if (!ph) return -1;
+    for (int i = 0; i < ph->n_phases * 64 && i < cap; ++i) tab_out[i] = ph->tab[i];
+    return ph->n_phases;
+}
+
+/* Colour-parallel Metropolis (scan = 2; `iters` counts phases, k = phase index of the chain).  Top chain with logical moves (it
+ * must accept every move, p >= 0.75): before the phase, with probability p_logical (word 0 of block (k, 0)), one uniformly random
+ * logical operator drawn from words 1-3 of that block as in the other scans.  Then every generator of phase k mod P, member i
+ * drawing u = word i & 3 of block (k, 8 + (i >> 2)): a chain with f < 1 accepts iff u < f^dE (mcmc.py:42); a chain with f >= 1 --
+ * where a coin-less sweep would compose to the identity -- applies the generator iff u >= 1/2. */
+static void chain_update_colour(const orc_model *m, uint8_t *state, double p, double p_logical, uint64_t iters,
+                                orc_rng *rng, uint32_t slot, uint64_t k0, uint8_t *scratch)
+{
+    const size_t nq = (size_t)orc_nq(m->code, m->L);
+    const double factor = (p / 3.0) / (1.0 - p);
+    const colour_phases_t *ph = colour_phases(m);
+    if (!ph) abort();
+    for (uint64_t j = 0; j < iters; ++j) {
+        const uint64_t k = k0 + j;
+        if (p_logical != 0 && orc_draw(rng, slot, k, 0, 0) < p_logical) {
+            model_random_logical(m, state, scratch, rng, slot, k);
+            memcpy(state, scratch, nq);
+        }
+        const int *members = ph->tab + (size_t)(k % (uint64_t)ph->n_phases) * 64;
+        for (int i = 0; i < 64; ++i) {
+            if (members[i] < 0) continue;
+            const int dE = model_sweep_stabilizer(m, state, scratch, (uint64_t)members[i]);
+            const double u = orc_draw(rng, slot, k, 8u + (uint32_t)(i >> 2), i & 3);
+            const int acc = factor >= 1.0 ? u >= 0.5 : (dE <= 0 || u < pow(factor, (double)dE));
+            if (acc) memcpy(state, scratch, nq);
+        }
+    }
+}
+
 /* p_x^nx p_y^ny p_z^nz p_I^(num-nx-ny-nz), mcmc_biased.py:31,43 (left-to-right products of pow()) */
 static double biased_weight(const uint8_t *s, int nq, double px, double py, double pz)
 {
@@ -524,6 +624,10 @@ void orc_chain_update(const orc_model *m, uint8_t *state, double p, double p_log
     const size_t nq = (size_t)orc_nq(m->code, m->L);
     if (m->scan == 1 && m->noise == ORC_NOISE_DEPOLARIZING) {
         chain_update_sweep(m, state, p, p_logical, iters, rng, slot, k0, scratch);
+        return;
+    }
+    if (m->scan == 2 && m->noise == ORC_NOISE_DEPOLARIZING) {
+        chain_update_colour(m, state, p, p_logical, iters, rng, slot, k0, scratch);
         return;
     }
     if (m->noise == ORC_NOISE_BIASED) {

@@ -70,7 +70,8 @@ typedef struct orc_model {
     int det_pow;   /* alpha swap test: 0 = libm pow as the reference (mcmc_alpha.py:123); 1 = the deterministic
                       exp(e*ln(base)) the GPU uses (same decision unless u falls within ~1e-16 of the threshold) */
     int scan;      /* 0: the reference's random scan; 1: systematic sweep over the generators (NOT the reference's
-                      chain: the deterministic-scan variant the GPU offers as scan=1, same stationary law) */
+                      chain: the deterministic-scan variant the GPU offers as scan=1, same stationary law); 2: the same idea one
+                      colour phase -- a set of mutually disjoint generators -- at a time (the GPU's latency layout, scan=2) */
     double pxyz[3]; /* ORC_NOISE_XYZ: Chain_xyz's (p_x, p_y, p_z), src/mcmc.py:106-114 -- a single chain without logical
                       moves whose proposals are accepted with prod_i (p_i / (1 - sum p))^(change of n_i), :162-173 */
 } orc_model;
@@ -86,6 +87,7 @@ int  orc_surf_apply_logical(int code, int L, const uint8_t *in, uint8_t *out, in
 int  orc_surf_eq_class(int code, int L, const uint8_t *m);
 void orc_surf_syndrome(int code, int L, const uint8_t *in, uint8_t *defects /*[L+1][L+1]*/);
 /* number of generators, and generator g in the order the sweep / the one-word pick use (-> row, col, op) */
+int  orc_colour_phases(int code, int L, int *tab_out, int cap);   /* scan = 2: [n_phases][64] generator indices, -1 = none; returns n_phases */
 int  orc_surf_ngen(int code, int L);
 void orc_surf_gen_rco(int code, int L, int g, int *row, int *col, int *op);
 /* Planar_code.syndrom, planar_model.py:134-153: vertex_defects uint8[L-1][L] then plaquette_defects uint8[L][L-1] */

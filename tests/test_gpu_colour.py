@@ -1,0 +1,92 @@
+"""scan = "colour" (QECMC_SCAN_COLOUR, csrc/ladder_colour.hip): the latency layout -- one workgroup per
+ladder, one wavefront per rung, a whole colour phase of mutually disjoint generators per wavefront pass.  Not the reference's
+Markov chain (a systematic scan), so it is validated like scan = "sweep": bit for bit against the oracle's own restatement of the
+rule (orc_model.scan = 2: the same phases, built independently, applied one generator after the other), and statistically
+against exact enumeration (tests/test_gpu_stats.py runs its L = 3 cases with this scan too)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def q():
+    import qecmc
+    assert qecmc.device_count() >= 1
+    return qecmc
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+def _rand(rng, shape, p):
+    return (rng.integers(1, 4, size=shape) * (rng.random(shape) < p)).astype(np.uint8)
+
+
+CASES = [  # name, L, Nc, N, steps, iters, p, p_logical, replicas
+    ("toric", 3, 3, 5, 400, 10, 0.10, 0.5, 1), ("toric", 5, 5, 9, 300, 10, 0.10, 0.5, 1), ("toric", 9, 8, 6, 200, 10, 0.15, 0.5, 1),
+    ("toric", 15, 8, 3, 60, 10, 0.18, 0.5, 1),          # 450 generators: colour classes of more than 64 are cut into two passes
+    ("toric", 4, 4, 4, 150, 7, 0.12, 0.5, 1), ("toric", 9, 16, 2, 50, 3, 0.15, 0.25, 1), ("toric", 5, 1, 4, 200, 10, 0.10, 0.0, 1),
+    ("toric", 5, 5, 3, 120, 1, 0.10, 1.0, 3),            # replicas: ladder l = s R + r, summed per syndrome
+    ("xzzx", 9, 8, 5, 150, 10, 0.15, 0.5, 1), ("rotated", 7, 7, 4, 150, 10, 0.17, 0.5, 1), ("rotated", 21, 8, 2, 30, 10, 0.17, 0.5, 1),
+    ("planar", 5, 5, 4, 150, 10, 0.12, 0.5, 1), ("xzzx", 3, 2, 7, 300, 5, 0.2, 0.5, 2)]
+
+
+@pytest.mark.parametrize("name,L,Nc,N,steps,iters,p,p_logical,R", CASES)
+def test_colour_scan_bit_exact(q, orc, name, L, Nc, N, steps, iters, p, p_logical, R):
+    rng = np.random.default_rng(L * 7 + Nc + N)
+    code, ocode = {"toric": (q.TORIC, orc.TORIC), "xzzx": (q.XZZX, orc.XZZX), "rotated": (q.ROTATED, orc.ROTATED), "planar": (q.PLANAR, orc.PLANAR)}[name]
+    shape = (N, 2, L, L) if name in ("toric", "planar") else (N, L, L)
+    init = _rand(rng, shape, p)
+    if name == "planar":
+        init[:, 1, -1, :] = 0; init[:, 1, :, -1] = 0
+    kw = dict(steps=steps, iters=iters, tops_burn=1, seed=77, first_syndrome=11)
+    got = q.pteq_batch(init, p, Nc=Nc, code=code, scan="colour", p_logical=p_logical, return_states=True, TOPS=2, replicas=R, **kw)
+    # the oracle's ladder takes p_logical = 0.5 in its batch call (decoders.py:52): drive its Ladder directly for the other values
+    ncls = 16 if name == "toric" else 4
+    counts = np.zeros((N * R, ncls), np.uint32); samples = np.zeros(N * R, np.uint64); tops0 = np.zeros(N * R, np.uint64)
+    reached = np.zeros(N * R, np.uint64)
+    states = np.zeros((N * R, Nc) + shape[1:], np.uint8)
+    for l in range(N * R):
+        ld = orc.Ladder(ocode, init[l // R], p, Nc, p_logical, scan=2)
+        r = orc.Rng.philox(77, 11 + l)
+        for t in range(steps):
+            ld.step(iters, r)
+            if ld.tops0 >= 1:
+                counts[l, orc.surf_eq_class(ocode, ld.states[0]) if name != "toric" else orc.toric_eq_class(ld.states[0])] += 1
+                samples[l] += 1
+            if not reached[l] and ld.tops0 >= 2:
+                reached[l] = t + 1
+        tops0[l] = ld.tops0
+        states[l] = ld.states
+    assert np.array_equal(got["states"], states)
+    assert np.array_equal(got["counts"], counts.reshape(N, R, ncls).sum(axis=1))
+    assert np.array_equal(got["samples"], samples.reshape(N, R).sum(axis=1).astype(np.uint32))
+    assert np.array_equal(got["tops0"], tops0.reshape(N, R).sum(axis=1).astype(np.uint32))
+    want_done = np.where(reached > 0, reached, steps).reshape(N, R).max(axis=1)
+    assert np.array_equal(got["steps_done"], want_done.astype(np.uint32))                 # the first step with tops0 >= TOPS
+    assert np.array_equal(got["converged"], (reached > 0).reshape(N, R).all(axis=1))
+
+
+def test_colour_scan_conserves_the_syndrome(q):
+    from qecmc import toric_model as tm
+    rng = np.random.default_rng(3)
+    init = _rand(rng, (8, 2, 9, 9), 0.15)
+    got = q.pteq_batch(init, 0.15, Nc=8, steps=500, scan="colour", return_states=True, seed=5)
+    for s in range(8):
+        ref = tm.syndrome(init[s])
+        for c in range(8):
+            assert np.array_equal(tm.syndrome(got["states"][s, c]), ref)
+
+
+def test_colour_scan_rejects_what_it_does_not_do(q):
+    init = np.zeros((1, 2, 5, 5), np.uint8)
+    with pytest.raises(q.QecmcError):
+        q.pteq_batch(init, 0.1, Nc=5, steps=100, scan="colour", conv_criteria="error_based")
+    with pytest.raises(q.QecmcError):
+        q.pteq_batch(np.zeros((1, 5, 5), np.uint8), 0.1, Nc=5, steps=100, scan="colour", code=q.XZZX, eta=10.0)
+    with pytest.raises(q.QecmcError):
+        q.pteq_batch(init, 0.1, Nc=1, steps=100, scan="colour", p_logical=0.5)          # a 1-rung ladder's top sits below p = 0.75

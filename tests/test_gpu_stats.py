@@ -28,7 +28,7 @@ def _rand_state(seed, L, p):
     return m
 
 
-@pytest.mark.parametrize("scan", ["random", "sweep"])
+@pytest.mark.parametrize("scan", ["random", "sweep", "colour"])
 @pytest.mark.parametrize("seed,p,Nc", [(1, 0.10, 3), (2, 0.15, 4), (3, 0.12, 4), (4, 0.20, 5)])
 def test_exact_enumeration_L3(q, seed, p, Nc, scan):
     from qecmc import toric_model as tm
@@ -183,14 +183,15 @@ def _class_fractions(res, ok):
     return frac.mean(axis=0), frac.std(axis=0, ddof=1) / np.sqrt(ok.sum())
 
 
+@pytest.mark.parametrize("scan", ["random", "colour"])
 @pytest.mark.parametrize("name,seed,p,Nc", [("xzzx", 11, 0.20, 3), ("xzzx", 13, 0.15, 4), ("rotated", 12, 0.25, 4), ("rotated", 14, 0.17, 3)])
-def test_plaquette_depolarizing_exact_L3(q, name, seed, p, Nc):
+def test_plaquette_depolarizing_exact_L3(q, name, seed, p, Nc, scan):
     from util_exact import SurfEnumeration, depolarizing_weight
     code = {"xzzx": q.XZZX, "rotated": q.ROTATED}[name]
     init = _rand_surf(seed)
     P = SurfEnumeration(code, init, _surf_api(q)).class_probabilities(depolarizing_weight(p))
     R, steps = 4096, 4000
-    res = q.pteq_batch(np.broadcast_to(init, (R,) + init.shape).copy(), p, Nc=Nc, steps=steps, iters=10, tops_burn=5, seed=2000 + seed, code=code)
+    res = q.pteq_batch(np.broadcast_to(init, (R,) + init.shape).copy(), p, Nc=Nc, steps=steps, iters=10, tops_burn=5, seed=2000 + seed, code=code, scan=scan)
     ok = res["samples"] > steps // 2
     assert ok.mean() > 0.97
     mean, sem = _class_fractions(res, ok)

@@ -225,3 +225,37 @@ def test_oracle_biased_chain_q3_law_L3_iters10(code, seed, p, eta):
     assert (res["samples"] == steps - 499).all()
     mean, sem = _check_classes(res["counts"] / res["samples"][:, None].astype(np.float64), Q)
     assert np.abs(mean - P).max() > 10 * sem.max()                # ... and measurably not on the biased law
+
+
+@pytest.mark.parametrize("code,seed,p,Nc", [(orc.TORIC, 1, 0.10, 3), (orc.XZZX, 11, 0.20, 3)])
+def test_oracle_colour_scan_matches_exact_enumeration_L3(code, seed, p, Nc):
+    """scan = 2 (one colour phase of mutually disjoint generators at a time, the GPU's latency layout): the same stationary law"""
+    if code == orc.TORIC:
+        init = _rand_state(seed, 3, 0.15)
+        P = toric_class_probabilities(init, p, orc.toric_apply_stabilizer, orc.toric_to_class)
+    else:
+        init = _rand_surf(seed)
+        P = SurfEnumeration(code, init, ORC_API).class_probabilities(depolarizing_weight(p))
+    R, steps = 96, 6000
+    res = orc.pteq_batch(code, np.broadcast_to(init, (R,) + init.shape).copy(), p, Nc, steps, iters=10, tops_burn=5, seed=600 + seed, n_threads=8, scan=2)
+    assert (res["samples"] > steps // 2).all()
+    _check_classes(res["counts"] / res["samples"][:, None].astype(np.float64), P)
+
+
+@pytest.mark.parametrize("code,L", [(orc.TORIC, 3), (orc.TORIC, 4), (orc.TORIC, 9), (orc.XZZX, 5), (orc.ROTATED, 7), (orc.PLANAR, 5)])
+def test_oracle_colour_phases_partition_the_generators_into_disjoint_sets(code, L):
+    ph = orc.colour_phases(code, L)
+    G = 2 * L * L if code == orc.TORIC else orc.surf_ngen(code, L)
+    members = ph[ph >= 0]
+    assert sorted(members.tolist()) == list(range(G))                    # every generator exactly once
+    zero = np.zeros((2, L, L) if code in (orc.TORIC, orc.PLANAR) else (L, L), np.uint8)
+    for row in ph:
+        seen = np.zeros(zero.size, bool)
+        for g in row[row >= 0]:
+            if code == orc.TORIC:
+                pat = orc.toric_apply_stabilizer(zero, (g % (L * L)) // L, g % L, 1 if g < L * L else 3)[0]
+            else:
+                pat = orc.surf_apply_stabilizer(code, zero, *orc.surf_gen_rco(code, L, int(g)))[0]
+            q = pat.ravel() != 0
+            assert not (seen & q).any()                                  # no qubit is touched twice within a phase
+            seen |= q
