@@ -166,7 +166,9 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
         // runs that stop by the convergence criterion: a persistent grid (what one launch keeps resident) fed from a counter
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, p->device));
-        const size_t per_cu_lds = (160 * 1024) / pl->lds_bytes, per_cu_waves = (size_t)(Nc * 64 <= 512 ? 32 : 16) / (size_t)Nc;
+        // (waves per CU: 8 per SIMD for the 512-thread depolarizing kernels, 4 for the 1024-thread ones and for the biased / alpha
+        // queue kernels, which run at 128 VGPRs: ladder_biased.hip)
+        const size_t per_cu_lds = (160 * 1024) / pl->lds_bytes, per_cu_waves = (size_t)((Nc * 64 <= 512 && !p->noise) ? 32 : 16) / (size_t)Nc;
         size_t per_cu = per_cu_lds < per_cu_waves ? per_cu_lds : per_cu_waves;
         if (per_cu < 1) per_cu = 1;
         pl->queue_grid = (uint32_t)(per_cu * (size_t)prop.multiProcessorCount);
@@ -208,6 +210,9 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
         HIP_TRY(hipMemcpy(pl->phases.p, ph.data(), ph.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
         a.phase_tab = pl->phases.as<uint16_t>();
         a.n_phases = (uint32_t)n_phases;
+        pl->lds_bytes = sizeof(uint32_t) * colour_lds_dwords(Nc, W, ncls, a.n_phases, (uint32_t)(gt.size() / 2), L, nq, a.swap_fast_ok != 0);
+        if (pl->lds_bytes > 160 * 1024)
+            return fail(QECMC_ERR_UNSUPPORTED, "scan = colour: L=%d Nc=%d needs %zu B of LDS per workgroup (> 160 KiB)", L, Nc, pl->lds_bytes);
         if (p->p_logical > 0.0 && !((a.acc_all_mask >> (Nc - 1)) & 1u))
             return fail(QECMC_ERR_UNSUPPORTED, "scan = colour needs a top rung that accepts every move (p_top = 0.75) when logical moves are on");
     }
@@ -699,7 +704,7 @@ int qecmc_pteq_batch_stats(const qecmc_params *params, const uint8_t *init, uint
     if (pl->queue_grid && !swap_accepts_out && !nerr_sums_out && !final_states_out && pl->prm.steps > 0) {
         // the work-queue kernels log one column per lane of the persistent grid, not per ladder
         const uint64_t cols = std::min<uint64_t>((N * R + 63) / 64 * 64, (uint64_t)pl->queue_grid * 64u);
-        ws_bytes = 2ull * cols * pl->prm.steps;
+        ws_bytes = (pl->prm.noise == QECMC_NOISE_ALPHA ? 4ull : 2ull) * cols * pl->prm.steps;   // (alpha noise logs the two counts behind n_eff)
     }
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));

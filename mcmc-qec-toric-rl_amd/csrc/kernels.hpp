@@ -125,10 +125,21 @@ inline int ladder_gen_dwords(int code, int noise, int scan, uint32_t n_gen, int 
 }
 // the shapes the work-queue kernels exist for: depolarizing rule, random scan, error_based criterion, the framed top chain
 // (toric L <= 16, plaquette codes L <= 32; a top rung at p = 0.75, i.e. Nc >= 2, with logical moves)
+// ... and the biased / alpha rules on the xzzx / rotated codes (any L, Nc: no framed top chain there)
 inline bool ladder_uses_queue(int code, int noise, int scan, int conv_mode, int L, int Nc, double p_logical)
 {
-    return noise == 0 && scan == 0 && conv_mode != 0 && L <= (code == 0 ? 16 : 32) && Nc >= 2 && p_logical > 0.0;
+    if (noise != 0) return scan == 0 && conv_mode != 0 && (code == 1 || code == 2);
+    return scan == 0 && conv_mode != 0 && L <= (code == 0 ? 16 : 32) && Nc >= 2 && p_logical > 0.0;
 }
+// LDS of one workgroup (dwords): states, records, swap uniforms, histogram, then the tables every phase reads -- the phase
+// table, the generator table, the logical masks, the swap thresholds (32-bit where they fit) -- so that the serial path of a
+// step never waits for global memory
+inline size_t colour_lds_dwords(int Nc, int W, int ncls, uint32_t n_phases, uint32_t n_gen, int L, int nq, bool swap32)
+{
+    return (size_t)Nc * W + 4 * (size_t)Nc + ncls + 32u * n_phases + 2u * n_gen + 4u * (L + 1) * W +
+           (swap32 ? 1u : 2u) * (size_t)(Nc > 1 ? Nc - 1 : 0) * (nq + 1) + 4;
+}
+
 hipError_t launch_ladder_rs_toric(const LadderArgs &a, hipStream_t stream);
 
 // byte-state primitive kernels (primitives.hip); all pointers are device pointers

@@ -9,7 +9,7 @@
 // stream; a sweep is n_phases of those (7 at toric L = 9) instead of 162 proposals.
 //
 // This is NOT the reference's Markov chain (a systematic scan, like scan = 1): every single-generator Metropolis kernel keeps
-// the rung's stationary law, hence so does their composition.  The rule, which the oracle restates (orc_model.scan = 2):
+// the rung's stationary law, hence so does their composition.  The rule, which the CPU oracle restates (scan = 2 of its model):
 //   * the plan cuts the generators into phases (tables.hpp colour_phases: greedy colouring in table order, chunks of <= 64);
 //     phase index K of a rung counts from prop0 = step0 * iters; a ladder step = `iters` phases of every rung, phase K uses
 //     phase (K mod n_phases) of the table;
@@ -34,7 +34,16 @@ __device__ __forceinline__ int wave_sum(int v)
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
-
+// sum over the accepted lanes of dE in [-4, 4]: four ballots of the bits of dE + 4 and one of the accepted lanes -- scalar
+// popcounts instead of six cross-lane round trips on the step's serial path
+__device__ __forceinline__ int wave_sum_dE(bool acc, int dE)
+{
+    const uint32_t v = (uint32_t)(dE + 4);
+    int s = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) s += __popcll(__ballot(acc && ((v >> b) & 1u))) << b;
+    return s - 4 * __popcll(__ballot(acc));
+}
 template <int CODE>
 __global__ __launch_bounds__(1024) void ladder_colour_kernel(const LadderArgs a)
 {
@@ -46,6 +55,11 @@ __global__ __launch_bounds__(1024) void ladder_colour_kernel(const LadderArgs a)
     uint32_t *rec = st + NC * W;                         // [2][NC]   slot records by step parity (pack_info)
     uint32_t *swu = rec + 2 * NC;                        // [2][NC]   swap uniforms by step parity
     uint32_t *hist = swu + 2 * NC;                       // [ncls]
+    uint16_t *ptab = reinterpret_cast<uint16_t *>(hist + ncls);                       // [n_phases][64]
+    uint2 *gtab = reinterpret_cast<uint2 *>(hist + ncls + 32 * a.n_phases + ((ncls + 32 * a.n_phases + NC * W + 4 * NC) & 1));   // [n_gen], 8-byte aligned
+    uint32_t *lml = reinterpret_cast<uint32_t *>(gtab + a.n_gen);                      // [4][L+1][W]
+    uint32_t *swt = lml + 4 * (a.L + 1) * W;                                          // [NC-1][nq+1] swap thresholds (u32, or u64 as two dwords)
+    const bool swap32 = a.swap_fast_ok != 0;
     const uint32_t R = a.replicas;
     const uint64_t ladder = blockIdx.x;                  // one workgroup per ladder
     if (ladder >= a.N) return;
@@ -65,6 +79,13 @@ __global__ __launch_bounds__(1024) void ladder_colour_kernel(const LadderArgs a)
         cnt0 += (int)nnz2(word);
     }
     for (int c = tid; c < ncls; c += NC * 64) hist[c] = 0;
+    for (int i = tid; i < (int)a.n_phases * 64; i += NC * 64) ptab[i] = a.phase_tab[i];
+    for (int i = tid; i < (int)a.n_gen; i += NC * 64) gtab[i] = a.gen[i];
+    for (int i = tid; i < 4 * (L + 1) * W; i += NC * 64) lml[i] = a.lmask[i];
+    for (int i = tid; i < (NC - 1) * (nq + 1); i += NC * 64) {
+        if (swap32) swt[i] = (uint32_t)a.swap_thr[i];      // (entry d = 0 -- 2^32 -- is never looked up: d <= 0 always swaps)
+        else { swt[2 * i] = (uint32_t)a.swap_thr[i]; swt[2 * i + 1] = (uint32_t)(a.swap_thr[i] >> 32); }
+    }
     __syncthreads();
     // wave-uniform slot state: error count, state id, class, flag (Chain.flag, mcmc.py:75)
     uint32_t n = (uint32_t)wave_sum(cnt0), sid = slot, flag = slot == (uint32_t)(NC - 1);
@@ -108,14 +129,26 @@ __global__ __launch_bounds__(1024) void ladder_colour_kernel(const LadderArgs a)
     // accept iff u <= thr[dE + 4] (dE <= 0 or f >= 1: always -- a rung with f >= 1 takes the coin instead)
     const uint32_t thr1 = a.acc_thr[slot][0] - 1u, thr2 = a.acc_thr[slot][1] - 1u, thr3 = a.acc_thr[slot][2] - 1u, thr4 = a.acc_thr[slot][3] - 1u;
     const uint32_t iters = a.iters, P = a.n_phases;
-    const uint32_t *lmask = a.lmask;
+    const uint32_t *lmask = lml;
     const int LW = (L + 1) * W;
 
+    // running indices instead of 64-bit remainders on the serial path: the phase of the table (K mod P) and the diagonal stream's
+    // offset ((slot + step) mod Nc); the generator entry of the NEXT phase is fetched while the current one is tested -- it does
+    // not depend on the state -- which takes two of the three LDS round trips of a phase off the critical path
+    uint32_t ph = (uint32_t)(a.prop0 % (uint64_t)P), dg = (uint32_t)(((uint64_t)slot + a.step0) % (uint64_t)NC);
+    uint2 e_next;
+    bool act_next;
+    {
+        const uint32_t g0 = ptab[ph * 64u + (uint32_t)lane];
+        act_next = g0 != 0xFFFFu;
+        e_next = gtab[act_next ? g0 : 0u];
+    }
     for (uint64_t t = 0; t < a.nsteps; ++t) {
         uint32_t *sb = st + sid * W;
         bool recount = false;
         // the rung's Philox stream at this step: the slot's own for the top rule, the diagonal one otherwise (philox.hpp)
-        const uint32_t strm = top_logical ? slot : kDiagStream + (uint32_t)(((uint64_t)slot + a.step0 + t) % (uint64_t)NC);
+        const uint32_t strm = top_logical ? slot : kDiagStream + dg;
+        dg = dg + 1u == (uint32_t)NC ? 0u : dg + 1u;
         for (uint32_t j = 0; j < iters; ++j) {
             const uint64_t K = a.prop0 + t * iters + j;
             if (top_logical) {
@@ -145,9 +178,14 @@ __global__ __launch_bounds__(1024) void ladder_colour_kernel(const LadderArgs a)
                 }
             }
             // ---- one phase: every lane its generator
-            const uint32_t gid = a.phase_tab[(size_t)(K % P) * 64 + lane];
-            const bool active = gid != 0xFFFFu;
-            const uint2 e = a.gen[active ? gid : 0u];                         // 4 x (site << 2 | pauli), 0 = no site
+            const bool active = act_next;
+            const uint2 e = e_next;                                           // 4 x (site << 2 | pauli), 0 = no site
+            ph = ph + 1u == P ? 0u : ph + 1u;
+            {
+                const uint32_t gn = ptab[ph * 64u + (uint32_t)lane];
+                act_next = gn != 0xFFFFu;
+                e_next = gtab[act_next ? gn : 0u];
+            }
             const uint32_t ent[4] = {e.x & 0xFFFFu, e.x >> 16, e.y & 0xFFFFu, e.y >> 16};
             uint32_t *ad[4];
             uint32_t sh[4], F = 0, OPS = 0;
@@ -169,7 +207,7 @@ __global__ __launch_bounds__(1024) void ladder_colour_kernel(const LadderArgs a)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) lds_xor(ad[i], (ent[i] & 3u) << sh[i]);     // (same-word updates of different lanes: LDS atomics)
             }
-            n = (uint32_t)((int)n + __builtin_amdgcn_readfirstlane(wave_sum(acc ? dE : 0)));
+            n = (uint32_t)((int)n + wave_sum_dE(acc, dE));
         }
         if (recount) {                                                        // the logical operators moved O(L) sites
             int c = 0;
@@ -188,7 +226,8 @@ __global__ __launch_bounds__(1024) void ladder_colour_kernel(const LadderArgs a)
         for (int i = NC - 2; i >= 0; --i) {
             const uint32_t lo = cur[i], xi = sx[i];
             const int d = (int)(car & 0xFFFFu) - (int)(lo & 0xFFFFu);                  // ne_hi - ne_lo, _r_flip mcmc.py:146-149
-            const bool flip = d <= 0 || (uint64_t)xi < a.swap_thr[(size_t)i * (nq + 1) + d];
+            const int e = i * (nq + 1) + (d > 0 ? d : 0);
+            const bool flip = d <= 0 || (swap32 ? xi < swt[e] : (uint64_t)xi < (((uint64_t)swt[2 * e + 1] << 32) | swt[2 * e]));
             const uint32_t into = flip ? lo : car;
             car = flip ? car : lo;
             if ((int)slot == i + 1) mine = into;
@@ -249,7 +288,12 @@ hipError_t launch_ladder_colour(const LadderArgs &a, hipStream_t stream)
                    : a.code == kCodeRotated ? (const void *)ladder_colour_kernel<kCodeRotated>
                    : a.code == kCodePlanar ? (const void *)ladder_colour_kernel<kCodePlanar> : nullptr;
     if (!fn) return hipErrorInvalidValue;
-    const size_t lds = sizeof(uint32_t) * ((size_t)a.Nc * a.W + 4 * (size_t)a.Nc + (size_t)a.ncls);
+    const size_t lds = sizeof(uint32_t) * colour_lds_dwords(a.Nc, a.W, a.ncls, a.n_phases, a.n_gen, a.L, a.nq, a.swap_fast_ok != 0);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
     void *kargs[] = {const_cast<LadderArgs *>(&a)};
     hipError_t e = hipLaunchKernel(fn, dim3((unsigned)a.N), dim3((unsigned)a.Nc * 64u), kargs, lds, stream);
     if (e != hipSuccess) return e;

@@ -858,7 +858,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
                                               : ratio12_packed(Nn, entry_counts());
                         const bool acc = test12(e, xw, Nn, [&]() -> uint32_t {
                             constexpr int WI = decltype(wsel)::value;
-                            const u32x4 r = philox_block(kb, kSubRefine, syn, strm, a.seed_lo, a.seed_hi);
+                            const u32x4 r = philox_block(kb - (kq >> 2), kSubRefine, syn, strm, a.seed_lo, a.seed_hi);
                             return WI == 0 ? r.x : WI == 1 ? r.y : WI == 2 ? r.z : r.w;
                         });
                         if (acc) {
@@ -872,7 +872,8 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
                     // dynamic word select); the current block lives in `carry`, so the one a step ends in is still there for the next step
                     uint64_t kb = kbase >> 2;
                     for (int jb = -(int)((uint32_t)kbase & 3u); jb < (int)iters; jb += 4, ++kb) {
-                        if (kb != carry_kb) { carry = philox_block(kb, 1, syn, strm, a.seed_lo, a.seed_hi); carry_kb = kb; }
+                        // (QUEUE: a ladder's proposal indices count from the step it started at, kq = t0 * iters, a multiple of 4)
+                        if (kb != carry_kb) { carry = philox_block(kb - (kq >> 2), 1, syn, strm, a.seed_lo, a.seed_hi); carry_kb = kb; }
                         if ((uint32_t)jb < iters) one(carry.x, kb, std::integral_constant<int, 0>{});
                         if ((uint32_t)(jb + 1) < iters) one(carry.y, kb, std::integral_constant<int, 1>{});
                         if ((uint32_t)(jb + 2) < iters) one(carry.z, kb, std::integral_constant<int, 2>{});
@@ -947,7 +948,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
                         }
                         const bool acc = test12(ratio12_packed(Nn, Nb), B, Nn, [&]() -> uint32_t {
                             constexpr int WI = decltype(wsel)::value;               // 1 or 3: the word B's index
-                            const u32x4 r = philox_block(kb, kSubRefine, syn, strm, a.seed_lo, a.seed_hi);
+                            const u32x4 r = philox_block(kb - (kq >> 1), kSubRefine, syn, strm, a.seed_lo, a.seed_hi);
                             return WI == 1 ? r.y : r.w;
                         });
                         if (acc) {
@@ -980,11 +981,12 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
                     };
                     // the packed blocks that overlap [kbase, kbase + iters): the first may start at its second proposal, the last may
                     // end at its first (wave-uniform)
+                    // (QUEUE: the block index is reduced by the ladder's own start, kq >> 1, where the block is drawn)
                     const uint64_t b0 = kbase >> 1;
                     const bool skip_first = (kbase & 1) != 0, skip_last = ((kbase + iters) & 1) != 0;
                     const uint32_t nblk = (uint32_t)(((kbase + iters - 1) >> 1) - b0) + 1u;
                     for (uint32_t bi = 0; bi < nblk; ++bi) {
-                        const u32x4 x = philox_block(b0 + bi, kSubTopPair, syn, strm, a.seed_lo, a.seed_hi);
+                        const u32x4 x = philox_block(b0 + bi - (kq >> 1), kSubTopPair, syn, strm, a.seed_lo, a.seed_hi);
                         if (!(skip_first && bi == 0)) one(x.x, x.y, b0 + bi, std::integral_constant<int, 1>{});
                         if (!(skip_last && bi == nblk - 1)) one(x.z, x.w, b0 + bi, std::integral_constant<int, 3>{});
                     }
@@ -1683,16 +1685,18 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
                     if (CONV && BIASED && alpha_noise) {
                         // nbr_errors_bottom_chain[since_burn] = chains[0].n_eff (decoders_biasednoise.py:204): slot 0's
                         // attribute, logged as its two counts; the window sums stay exact integers
-                        if (lane_t < cnt) {
+                        if (QUEUE ? !q_dead : lane_t < cnt) {
+                            // (QUEUE: one log column per lane of the persistent grid, rows = the ladder's own steps)
+                            const size_t lN = QUEUE ? (size_t)gridDim.x * 64u : (size_t)a.N;
                             uint32_t *mylog = reinterpret_cast<uint32_t *>(a.nlog) + (s0 + lane_t);
                             const uint32_t v0 = neffb[(t & 1) * NC * 64 + lane_t];
-                            mylog[(size_t)t * a.N] = v0;
+                            mylog[(size_t)(t - t0) * lN] = v0;
                             const uint32_t l = samples, lo1 = l - 1;
                             const uint32_t a0 = lo1 >> 2, b0 = lo1 >> 1, c0 = (3u * lo1) >> 2, a1 = l >> 2, b1 = l >> 1, c1 = (3u * l) >> 2;
                             sumB += v0 & 0xFFFFu; sumBxy += v0 >> 16;
-                            if (c1 != c0) { const uint32_t v = mylog[(size_t)(burn + c0) * a.N]; sumB -= v & 0xFFFFu; sumBxy -= v >> 16; }
-                            if (b1 != b0) { const uint32_t v = mylog[(size_t)(burn + b0) * a.N]; sumA += v & 0xFFFFu; sumAxy += v >> 16; }
-                            if (a1 != a0) { const uint32_t v = mylog[(size_t)(burn + a0) * a.N]; sumA -= v & 0xFFFFu; sumAxy -= v >> 16; }
+                            if (c1 != c0) { const uint32_t v = mylog[(size_t)(burn + c0) * lN]; sumB -= v & 0xFFFFu; sumBxy -= v >> 16; }
+                            if (b1 != b0) { const uint32_t v = mylog[(size_t)(burn + b0) * lN]; sumA += v & 0xFFFFu; sumAxy += v >> 16; }
+                            if (a1 != a0) { const uint32_t v = mylog[(size_t)(burn + a0) * lN]; sumA -= v & 0xFFFFu; sumAxy -= v >> 16; }
                         }
                     } else
                     if (CONV && (QUEUE ? !q_dead : lane_t < cnt)) {
@@ -1880,9 +1884,21 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
                         sid = slot_u; n = cn; flag = slot_u == (uint32_t)(NC - 1);
                         if constexpr (CODE == kCodeToric) cls = toric_class_packed(st + dbase, W, LL);
                         else cls = surf_class_packed(CODE, st + dbase, L);
+                        if constexpr (BIASED) {
+                            // the packed counts of the fresh state and, for alpha noise, the slot's n_eff record of both parities
+                            // (Chain_alpha.__init__, mcmc_alpha.py:18-22)
+                            int nx = 0, ny = 0, nz = 0;
+                            for (int w = 0; w < W; ++w) count_xyz(st[dbase + w * 64], nx, ny, nz);
+                            xyc[sid * 64 + lane_t] = (uint32_t)nx | ((uint32_t)nz << 10) | ((uint32_t)(nx + ny) << 20);
+                            if (alpha_noise) {
+                                const uint32_t v = (uint32_t)nz | ((uint32_t)(nx + ny) << 16);
+                                neffb[slot_u * 64 + lane_t] = v;
+                                neffb[(NC + slot_u) * 64 + lane_t] = v;
+                            }
+                        }
                         if (wave_u == 0) {
                             tops0 = 0; samples = 0; burn = 0; conv_start = 0; conv_streak = 0; done = 0; steps_done = 0; conv_ok = 0;
-                            sumA = 0; sumB = 0; q_flushed = false;
+                            sumA = 0; sumB = 0; sumAxy = 0; sumBxy = 0; q_flushed = false;
                         }
                     }
                 }

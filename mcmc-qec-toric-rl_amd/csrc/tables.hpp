@@ -2,7 +2,7 @@
 // ladder temperatures, power tables of the biased / alpha rules, stabilizer-generator tables, logical-operator masks, the
 // count-change table, the colour phases of scan = 2.  Pure host C++ (no HIP call): capi.hip includes it, and
 // tables_test_api.cpp builds it alone with -fsanitize=address,undefined so that tests/test_host_tables.py can check every
-// table against values the oracle computes ("-fsanitize=address on host lib").
+// table against values the CPU oracle computes ("-fsanitize=address on host lib").
 #pragma once
 #include "../../include/qecmc.h"
 
@@ -201,7 +201,7 @@ inline std::vector<uint64_t> swap_thresholds(const std::vector<double> &pdiff, i
 // scan = 2 (QECMC_SCAN_COLOUR): the generators cut into PHASES of mutually disjoint generators (no shared qubit), which one
 // wavefront proposes at once.  Greedy colouring in table order -- colour(g) = the smallest colour no earlier generator sharing
 // a qubit with g has -- then every colour class, in increasing g, in consecutive chunks of at most 64 (one lane each).
-// Returns [n_phases][64] generator indices, 0xFFFF = idle lane.  (The oracle states the same rule on its own.)
+// Returns [n_phases][64] generator indices, 0xFFFF = idle lane.  (The CPU oracle states the same rule on its own.)
 inline std::vector<uint16_t> colour_phases(const std::vector<uint32_t> &gt, int &n_phases)
 {
     const size_t G = gt.size() / 2;

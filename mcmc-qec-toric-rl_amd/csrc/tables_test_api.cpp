@@ -1,6 +1,6 @@
 // C test API over the host-side table builders (tables.hpp), compiled ALONE by g++ -- no HIP runtime, no device -- with
 // -fsanitize=address,undefined (make tables_asan) or plainly (make tables): tests/test_host_tables.py checks every table the
-// plan precomputes for the kernels against values the oracle computes, on the CPU.  Not part of libqecmc.so.
+// plan precomputes for the kernels against values the CPU oracle computes.  Not part of libqecmc.so.
 #include "tables.hpp"
 
 #include <cstring>

@@ -345,6 +345,28 @@ def test_work_queue_plaquette_codes_bit_exact(q, orc, name, L, Nc, N, steps, ite
     assert got["converged"].any() or L == 7          # (the three-rung L = 7 ladders all run to the horizon: refills by horizon only)
 
 
+@pytest.mark.parametrize("name,L,Nc,N,steps,iters,eta,alpha", [
+    ("xzzx", 5, 5, 200, 3000, 10, 100.0, None), ("rotated", 5, 4, 150, 2000, 8, 10.0, None), ("xzzx", 7, 3, 100, 1500, 5, 30.0, None),
+    ("xzzx", 5, 5, 200, 3000, 10, None, 1.7), ("rotated", 5, 4, 140, 2500, 10, None, 2.5), ("xzzx", 3, 2, 90, 1200, 6, None, 1.2)])
+def test_work_queue_biased_and_alpha_bit_exact(q, orc, name, L, Nc, N, steps, iters, eta, alpha):
+    """The work queue under the biased and alpha rules (what generate_data.py:142-150 routes biased noise to: PTEQ_alpha with the
+    error_based criterion): the grid forced to one workgroup, every lane runs several ladders; each must come out as the oracle's
+    single run -- counts, samples, tops0, stopping step, flag."""
+    rng = np.random.default_rng(L * 13 + N)
+    code, ocode = {"rotated": (q.ROTATED, orc.ROTATED), "xzzx": (q.XZZX, orc.XZZX)}[name]
+    init = rand_plaq(rng, N, L, 0.12)
+    kw = dict(steps=steps, iters=iters, tops_burn=1, seed=23, first_syndrome=7, conv_criteria="error_based", SEQ=1, TOPS=4, eps=0.5)
+    p = 0.12 if eta is not None else 0.1
+    noise = dict(eta=eta) if eta is not None else dict(alpha=alpha)
+    got = q.pteq_batch(init, p, Nc=Nc, code=code, flags=q.dev_flags(queue_grid=1), **noise, **kw)
+    okw = dict(noise=orc.BIASED, eta=eta) if eta is not None else dict(noise=orc.ALPHA, alpha=alpha, det_pow=1)
+    ref = orc.pteq_batch(ocode, init, p, Nc, kw.pop("steps"), **okw, **kw)
+    for k in ("converged", "steps_done", "samples", "tops0"):
+        assert np.array_equal(got[k], ref[k].astype(got[k].dtype)), k
+    assert np.array_equal(got["counts"], ref["counts"])
+    assert got["converged"].any() and np.unique(got["steps_done"]).size > 5
+
+
 # ------------------------------------------------------------------ syndrome generation on the device (row f1)
 @pytest.mark.parametrize("name,L,rates,N,first", [("toric", 9, (0.05, 0.05, 0.05), 1000, 0), ("toric", 4, (0.1, 0.1, 0.1), 77, 4000),
                                                   ("xzzx", 9, (7.4257e-4, 7.4257e-4, 0.148515), 600, 12), ("rotated", 21, (0.17 / 3,) * 3, 65, 1),

@@ -1,6 +1,10 @@
-"""Runs that stop by the reference's convergence criterion (decoders.py:74-82): the work-queue kernel against one ladder per
-lane (QECMC_QUEUE_GRID huge = every ladder gets its own lane from the start, i.e. the round-1 behaviour with early exit per
-workgroup).  Toric L=5 p=0.10 Nc=5, default criterion (SEQ=2, TOPS=10, eps=0.1), horizon 2^17 steps."""
+"""Runs that stop by the reference's convergence criterion (decoders.py:74-82): the work-queue kernels against one ladder per
+lane (persistent grid at its maximum = every ladder gets its own lane from the start, i.e. early exit per workgroup only).
+
+    python tools/bench_conv.py toric L p Nc N H              depolarizing, default criterion (SEQ=2, TOPS=10, eps=0.1), horizon H
+    python tools/bench_conv.py alpha L p eta Nc N H          the route generate_data.py:142-150 takes for biased noise: PTEQ_alpha on
+                                                             the xzzx code with (pz_tilde, alpha) derived from (p, eta)
+Writes gpurun_out/r03_conv_queue_<tag>.json."""
 import json
 import os
 import sys
@@ -8,20 +12,36 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, "mcmc-qec-toric-rl_amd")
-sys.path.insert(0, ".")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "mcmc-qec-toric-rl_amd"))
+sys.path.insert(0, ROOT)
 import qecmc
 import bench
+from qecmc import harness
 
-L, p, Nc, N, H = (int(sys.argv[1]), float(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (5, 0.10, 5, 1 << 18, 1 << 16)
-init = bench.synth_batch(N, L, p, 7)
+mode = sys.argv[1] if len(sys.argv) > 1 else "toric"
+if mode == "toric":
+    L, p, Nc, N, H = (int(sys.argv[2]), float(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])) if len(sys.argv) > 6 else (5, 0.10, 5, 1 << 18, 1 << 16)
+    init = bench.synth_batch(N, L, p, 7)
+    kw = dict(code=qecmc.TORIC)
+    p_dec = p
+    tag = "toric_L%d" % L
+    workload = "toric L=%d p=%g Nc=%d" % (L, p, Nc)
+else:
+    L, p, eta, Nc, N, H = int(sys.argv[2]), float(sys.argv[3]), float(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7])
+    rng = np.random.default_rng(7)
+    raw = harness.draw_errors(qecmc.XZZX, L, N, p, rng, eta=eta)
+    init = harness.hide_class(qecmc.XZZX, raw, rng)
+    p_dec, a = harness.biased_as_alpha(p, eta)                  # generate_data.py:142-150
+    kw = dict(code=qecmc.XZZX, alpha=float(a))
+    tag = "alpha_L%d" % L
+    workload = "xzzx L=%d, errors at p=%g eta=%g, decoded by PTEQ_alpha (pz_tilde=%.6g, alpha=%.6g), Nc=%d" % (L, p, eta, p_dec, a, Nc)
 out = {}
-for name, grid in (("queue", None), ("one_ladder_per_lane", str(1 << 30))):
-    if grid: os.environ["QECMC_QUEUE_GRID"] = grid
-    else: os.environ.pop("QECMC_QUEUE_GRID", None)
-    for rep in range(1 if L > 5 else 2):
+for name, grid in (("queue", 0), ("one_ladder_per_lane", 65535)):
+    for rep in range(2):
         t0 = time.time()
-        r = qecmc.pteq_batch(init, p, Nc=Nc, steps=H, iters=10, tops_burn=2, seed=3, conv_criteria="error_based", return_stats=True)
+        r = qecmc.pteq_batch(init, p_dec, Nc=Nc, steps=H, iters=10, tops_burn=2, seed=3, conv_criteria="error_based", return_stats=True,
+                             flags=qecmc.dev_flags(queue_grid=grid), **kw)
         dt = time.time() - t0
     steps = r["steps_done"].astype(np.float64)
     out[name] = dict(kernel_ms=r["stats"]["kernel_ms"], wall_s=dt, converged_frac=float(r["converged"].mean()), mean_steps=float(steps.mean()),
@@ -30,6 +50,8 @@ for name, grid in (("queue", None), ("one_ladder_per_lane", str(1 << 30))):
                      checksum=int(r["counts"].astype(np.uint64).sum()))
     print(name, json.dumps(out[name]), flush=True)
 out["speedup"] = out["one_ladder_per_lane"]["kernel_ms"] / out["queue"]["kernel_ms"]
-out["workload"] = "toric L=%d p=%g Nc=%d, %d syndromes, error_based criterion (SEQ=2, TOPS=10, eps=0.1), horizon %d ladder steps" % (L, p, Nc, N, H)
-json.dump(out, open("gpurun_out/r02_conv_queue_L%d.json" % L, "w"), indent=1)
+out["identical_class_counts"] = out["queue"]["checksum"] == out["one_ladder_per_lane"]["checksum"]
+out["workload"] = "%s, %d syndromes, error_based criterion (SEQ=2, TOPS=10, eps=0.1), horizon %d ladder steps" % (workload, N, H)
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(out, open("gpurun_out/r03_conv_queue_%s.json" % tag, "w"), indent=1)
 print("speedup", out["speedup"])

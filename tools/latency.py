@@ -45,15 +45,18 @@ def default_stop(init, p, Nc, **kw):
 out = {"note": "one syndrome per call; lane-per-chain layout = the reference's random scan (scan=random); times include the "
                "host-pointer boundary (H2D, launch, D2H) in wall_ms and the kernel alone in kernel_ms"}
 q.pteq_batch(bench.synth_batch(1, 5, 0.1, 1), 0.1, Nc=5, steps=10)          # load the library, warm the context
+ONLY_COLOUR = "--only-colour" in sys.argv          # (the lane-per-chain rows take minutes: profiles/r03_latency.json keeps them)
 for name, L, p, Nc in (("toric L=9 p=0.15 Nc=8", 9, 0.15, 8), ("toric L=15 p=0.18 Nc=8", 15, 0.18, 8)):
     rows = []
     for s in range(4 if L == 9 else 2):
         init, raw = bench.synth_batch(1, L, p, 100 + s, return_raw=True)
         row = {"syndrome_seed": 100 + s}
-        for R in (1, 64):
+        for R in (() if ONLY_COLOUR else (1, 64)):
             kw = dict(replicas=R) if R > 1 else {}
             row["replicas_%d" % R] = {"to_tops0_ge_10": first_step_with_tops(init, p, Nc, 10, **kw), "default_stop": default_stop(init, p, Nc, **kw)}
         if "colour" in getattr(q, "SCANS", ()):
+            # (iters = 10 PHASES per step here: 10 / n_phases sweeps of every rung between swap sweeps, against 10 / G in the
+            # lane-per-chain layout)
             row["colour_parallel"] = {"to_tops0_ge_10": first_step_with_tops(init, p, Nc, 10, scan="colour")}
         rows.append(row)
         print(name, json.dumps(row), file=sys.stderr, flush=True)
