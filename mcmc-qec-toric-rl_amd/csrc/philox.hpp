@@ -29,8 +29,11 @@ __host__ __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32
 __host__ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                                         uint32_t k0, uint32_t k1)
 {
+#ifndef QECMC_PHILOX_ROUNDS
+#define QECMC_PHILOX_ROUNDS 10      // Philox4x32-10, the Random123 default (tools/ builds a 7-round library for the ceiling analysis of DESIGN.md only)
+#endif
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < QECMC_PHILOX_ROUNDS; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
         const uint32_t n0 = xor3((uint32_t)(p1 >> 32), c1, k0);
