@@ -194,9 +194,11 @@ int qecmc_ladder_step_alpha(const qecmc_params *params, uint64_t N, uint8_t *sta
  * (nullable); final_states_out uint8[N][Nc][nq] in slot order (nullable; only
  * meaningful with conv_mode NONE); stats nullable.
  * conv_mode ERROR_BASED needs device workspace for the per-step bottom-chain error counts the criterion averages
- * (decoders.py:68,93-105): 2*N*steps bytes, or -- toric depolarizing ladders, which run on a persistent grid with a work queue
- * (a lane whose ladder has stopped takes the next one of the batch in place) -- 2*min(N, grid*64)*steps.  A plan's queue counter
- * is its own: one launch of a conv_mode plan at a time. */
+ * (decoders.py:68,93-105): 2*N*steps bytes (alpha noise: 4, the two counts behind n_eff), or -- for the ladders that run on a
+ * persistent grid with a work queue (a lane whose ladder has stopped takes the next one of the batch in place: the depolarizing
+ * random-scan ladders of every code with a top rung at p = 0.75, toric L <= 16 and the others L <= 32, and the biased / alpha rules
+ * on the xzzx / rotated codes) -- the same per min(N, grid*64) columns.  A plan's queue counter is its own: one launch of a
+ * conv_mode plan at a time. */
 int qecmc_pteq_batch(const qecmc_params *params, const uint8_t *init, uint64_t N, uint32_t *counts_out,
                      uint32_t *samples_out, uint32_t *tops0_out, uint32_t *steps_done_out,
                      uint8_t *converged_out, uint8_t *final_states_out, qecmc_stats *stats_out);

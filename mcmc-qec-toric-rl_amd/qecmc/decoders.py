@@ -85,7 +85,7 @@ PTEQ_REPLICAS = 1
 
 
 def PTEQ(init_code, p, Nc=None, SEQ=2, TOPS=10, tops_burn=2, eps=0.1, steps=50000000, iters=10,
-         conv_criteria='error_based', seed=None, replicas=None):
+         conv_criteria='error_based', seed=None, replicas=None, scan="random"):
     """Drop-in for decoders.PTEQ (decoders.py:25): same arguments, returns the uint8 percent vector of
     the equivalence classes.  With the convergence criterion the run is issued with a growing horizon (65 536
     ladder steps, x4 until it converges or `steps` is reached) so that the default `steps = 5e7` never allocates
@@ -97,16 +97,18 @@ def PTEQ(init_code, p, Nc=None, SEQ=2, TOPS=10, tops_burn=2, eps=0.1, steps=5000
     reference's bookkeeping and, if asked for, its own convergence stop -- in the lanes that would otherwise idle, and forms the
     percent vector from their summed class counts: the "droplets" pattern the reference itself uses for its other estimators
     (decoders.py:215-225).  R = 64 fills the wavefronts at the price of one; it is a different (lower-variance) estimator
-    whose run ends when the slowest of the R ladders has converged, so it is opt-in."""
-    return _pteq(init_code, p, None, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, conv_criteria, seed, replicas=replicas)
+    whose run ends when the slowest of the R ladders has converged, so it is opt-in.
+    scan="colour" (with conv_criteria=None) decodes the one syndrome in the latency layout: a workgroup per ladder, a colour
+    phase of generators per wavefront pass -- 10-20 x sooner at tops0 >= 10 than the lane-per-chain layout (profiles/r03_latency.json)."""
+    return _pteq(init_code, p, None, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, conv_criteria, seed, replicas=replicas, scan=scan)
 
 
-def _pteq(init_code, p, eta, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, conv_criteria, seed, alpha=None, replicas=None):
+def _pteq(init_code, p, eta, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, conv_criteria, seed, alpha=None, replicas=None, scan="random"):
     if tops_burn >= TOPS:
         print('tops_burn has to be smaller than TOPS')
     seed = _fresh_seed() if seed is None else seed
     kw = dict(Nc=Nc or init_code.system_size, iters=iters, tops_burn=tops_burn, p_logical=0.5, seed=seed,
-              code=_code_id(init_code), eta=eta, alpha=alpha, replicas=PTEQ_REPLICAS if replicas is None else int(replicas))
+              code=_code_id(init_code), eta=eta, alpha=alpha, replicas=PTEQ_REPLICAS if replicas is None else int(replicas), scan=scan)
     if conv_criteria is None:
         return pteq_batch(init_code.qubit_matrix, p, steps=steps, **kw)["percent"][0]
     horizon = min(int(steps), 1 << 16)

@@ -34,8 +34,9 @@ def draw_case(rng):
     noise = "depolarizing"
     if code in ("xzzx", "rotated") and nq <= 400 and rng.random() < 0.35:
         noise = rng.choice(["biased", "alpha"])
-    scan = "sweep" if (noise == "depolarizing" and rng.random() < 0.15) else "random"
-    conv = noise != "alpha" and rng.random() < 0.3
+    u = rng.random()
+    scan = "random" if noise != "depolarizing" else "sweep" if u < 0.15 else "colour" if (u < 0.3 and Nc >= 2) else "random"
+    conv = scan != "colour" and rng.random() < 0.3        # (round 3: the alpha rule's criterion runs take the work queue too)
     iters = int(rng.choice([1, 2, 3, 5, 7, 8, 10, 10, 10, 12, 13, 25]))
     work = Nc * iters * nq                                                 # ~ oracle cost per ladder step (the stencil copies nq bytes)
     steps = int(max(3, min(400 if not conv else 2500, 6e6 // work)))
@@ -69,7 +70,7 @@ def run_case(c, rng):
     if c["conv"]:
         kw.update(conv_criteria="error_based", SEQ=1, TOPS=3, eps=0.6)
     gk = dict(kw, code=qcode, Nc=c["Nc"], scan=c["scan"], return_states=not c["conv"])
-    ok = dict(kw, return_states=not c["conv"], scan=1 if c["scan"] == "sweep" else 0)
+    ok = dict(kw, return_states=not c["conv"], scan={"random": 0, "sweep": 1, "colour": 2}[c["scan"]])
     p = c["p"]
     if c["noise"] == "biased":
         gk["eta"] = c["eta"]; ok.update(noise=orc.BIASED, eta=c["eta"])
@@ -98,7 +99,8 @@ def run_case(c, rng):
                    tops0=ref["tops0"].reshape(c["N"], c["R"]).sum(axis=1), steps_done=ref["steps_done"].reshape(c["N"], c["R"]).max(axis=1),
                    converged=ref["converged"].reshape(c["N"], c["R"]).all(axis=1))
     bad = []
-    for key in ("counts", "samples", "tops0", "steps_done", "converged"):
+    # (scan = colour reports the first step with tops0 >= TOPS in steps_done / converged: tests/test_gpu_colour.py checks those)
+    for key in ("counts", "samples", "tops0") + (() if c["scan"] == "colour" else ("steps_done", "converged")):
         if not np.array_equal(np.asarray(got[key]).astype(np.uint64), np.asarray(ref[key]).astype(np.uint64)):
             bad.append(key)
     if not c["conv"] and not np.array_equal(got["states"], ref["states"]):
