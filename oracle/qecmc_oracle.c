@@ -452,7 +452,7 @@ static void chain_update_sweep(const orc_model *m, uint8_t *state, double p, dou
  * greedy colouring in sweep order (colour(g) = the smallest colour that no earlier generator sharing a qubit with g has), then
  * every colour class, in increasing g, in consecutive chunks of at most 64.  tab[phase][i] = generator, -1 = none. */
 typedef struct { int code, L, n_phases; int *tab; } colour_phases_t;
-static colour_phases_t g_phases[16];
+static colour_phases_t g_phases[4 * 65];            /* one entry per (code, L): four codes, L <= 64 */
 static int g_n_phases_cached = 0;
 
 static const colour_phases_t *colour_phases(const orc_model *m)
@@ -462,7 +462,7 @@ static const colour_phases_t *colour_phases(const orc_model *m)
     {
         for (int i = 0; i < g_n_phases_cached; ++i)
             if (g_phases[i].code == m->code && g_phases[i].L == m->L) hit = &g_phases[i];
-        if (!hit && g_n_phases_cached < 16) {
+        if (!hit && g_n_phases_cached < (int)(sizeof g_phases / sizeof g_phases[0])) {
             const int L = m->L, nq = orc_nq(m->code, L);
             const int G = m->code == ORC_TORIC ? 2 * L * L : orc_surf_ngen(m->code, L);
             uint8_t *zero = calloc((size_t)nq, 1), *pat = malloc((size_t)G * nq);

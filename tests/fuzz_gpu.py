@@ -213,6 +213,8 @@ def main():
     failures, done, kinds = [], 0, {}
     for i in range(cases):
         c = draw_case(rng)
+        if os.environ.get("QECMC_FUZZ_TRACE"):
+            print("case %d %s" % (i, json.dumps(c)), flush=True)           # (what was running when a launch took the process down)
         try:
             bad = run_case(c, rng)
         except q.QecmcError as e:                                          # a shape the library refuses (LDS, table size): said so, fine
