@@ -107,7 +107,6 @@ int validate_params(const qecmc_params *p)
     if (p->scan != QECMC_SCAN_RANDOM && p->scan != QECMC_SCAN_SWEEP && p->scan != QECMC_SCAN_COLOUR) return fail(QECMC_ERR_INVALID, "scan mode %d unknown", p->scan);
     if (p->scan != QECMC_SCAN_RANDOM && p->noise != QECMC_NOISE_DEPOLARIZING) return fail(QECMC_ERR_UNSUPPORTED, "the systematic scans (sweep, colour) are built for the depolarizing rule only");
     if (p->scan == QECMC_SCAN_COLOUR) {
-        if (p->conv_mode != QECMC_CONV_NONE) return fail(QECMC_ERR_UNSUPPORTED, "scan = colour runs fixed-length ladders (steps_done reports the first step with tops0 >= TOPS)");
         if (p->p_logical > 0.0 && p->Nc < 2) return fail(QECMC_ERR_UNSUPPORTED, "scan = colour needs the top rung at p = 0.75 (Nc >= 2) when logical moves are on");
     }
     if (p->conv_mode != QECMC_CONV_NONE && p->conv_mode != QECMC_CONV_ERROR_BASED) return fail(QECMC_ERR_INVALID, "conv_mode %d unknown", p->conv_mode);

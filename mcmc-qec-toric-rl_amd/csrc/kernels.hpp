@@ -137,7 +137,7 @@ inline bool ladder_uses_queue(int code, int noise, int scan, int conv_mode, int 
 inline size_t colour_lds_dwords(int Nc, int W, int ncls, uint32_t n_phases, uint32_t n_gen, int L, int nq, bool swap32)
 {
     return (size_t)Nc * W + 4 * (size_t)Nc + ncls + 32u * n_phases + 2u * n_gen + 4u * (L + 1) * W +
-           (swap32 ? 1u : 2u) * (size_t)(Nc > 1 ? Nc - 1 : 0) * (nq + 1) + 4;
+           (swap32 ? 1u : 2u) * (size_t)(Nc > 1 ? Nc - 1 : 0) * (nq + 1) + 2 + 4;   // (+ 2: the stop flag by step parity)
 }
 
 hipError_t launch_ladder_rs_toric(const LadderArgs &a, hipStream_t stream);

@@ -22,8 +22,9 @@
 //     coin-less sweep would compose to the identity) applies the generator iff the top bit of u is set;
 //   * swap sweep, tops0 / class histogram bookkeeping: mcmc.py:94-103 and decoders.py:60-68 unchanged (swap uniforms: word i & 3
 //     of block (t, i >> 2) of the swap stream, as in the other scans).
-// steps_done (no convergence criterion in this layout) reports the first ladder step after which tops0 >= TOPS (or `steps`),
-// converged whether it was reached: the "time to tops0 >= 10" the latency table of profiles/ quotes.
+// conv_mode = error_based runs the reference's criterion on wave 0 (the workgroup leaves when its ladder has converged).  In
+// fixed-length runs steps_done reports the first ladder step after which tops0 >= TOPS (or `steps`), converged whether it was
+// reached: the "time to tops0 >= 10" the latency table of profiles/ quotes.
 #include "ladder_kernel.hpp"
 
 namespace qecmc {
@@ -44,7 +45,9 @@ __device__ __forceinline__ int wave_sum_dE(bool acc, int dE)
     for (int b = 0; b < 4; ++b) s += __popcll(__ballot(acc && ((v >> b) & 1u))) << b;
     return s - 4 * __popcll(__ballot(acc));
 }
-template <int CODE>
+// CONV: the error_based convergence criterion of decoders.py:74-82,93-105 on wave 0 (one ladder per workgroup: the workgroup leaves when
+// its ladder has converged); steps_done / converged are then the criterion's, as in the other scans.
+template <int CODE, bool CONV>
 __global__ __launch_bounds__(1024) void ladder_colour_kernel(const LadderArgs a)
 {
     extern __shared__ uint32_t lds[];
@@ -60,6 +63,7 @@ __global__ __launch_bounds__(1024) void ladder_colour_kernel(const LadderArgs a)
     uint32_t *lml = reinterpret_cast<uint32_t *>(gtab + a.n_gen);                      // [4][L+1][W]
     uint32_t *swt = lml + 4 * (a.L + 1) * W;                                          // [NC-1][nq+1] swap thresholds (u32, or u64 as two dwords)
     const bool swap32 = a.swap_fast_ok != 0;
+    volatile uint32_t *stopf = swt + (swap32 ? 1 : 2) * (NC > 1 ? NC - 1 : 0) * (a.nq + 1);   // [2] "the ladder has converged", by step parity
     const uint32_t R = a.replicas;
     const uint64_t ladder = blockIdx.x;                  // one workgroup per ladder
     if (ladder >= a.N) return;
@@ -79,6 +83,7 @@ __global__ __launch_bounds__(1024) void ladder_colour_kernel(const LadderArgs a)
         cnt0 += (int)nnz2(word);
     }
     for (int c = tid; c < ncls; c += NC * 64) hist[c] = 0;
+    if (tid < 2) stopf[tid] = 0;
     for (int i = tid; i < (int)a.n_phases * 64; i += NC * 64) ptab[i] = a.phase_tab[i];
     for (int i = tid; i < (int)a.n_gen; i += NC * 64) gtab[i] = a.gen[i];
     for (int i = tid; i < 4 * (L + 1) * W; i += NC * 64) lml[i] = a.lmask[i];
@@ -123,6 +128,8 @@ __global__ __launch_bounds__(1024) void ladder_colour_kernel(const LadderArgs a)
     }
     n = (uint32_t)__builtin_amdgcn_readfirstlane((int)n);
     uint32_t tops0 = 0, samples = 0, t_reached = 0;     // wave 0's bookkeeping (uniform)
+    [[maybe_unused]] uint32_t burn = 0, conv_start = 0, conv_streak = 0, done = 0, steps_done = 0;   // decoders.py:37-48
+    [[maybe_unused]] uint64_t sumA = 0, sumB = 0;       // window sums of the logged bottom-chain error counts: Q2 = series[l/4 : l/2], Q4 = series[3l/4 : l]
     const bool acc_all = (a.acc_all_mask >> slot) & 1u;
     const bool top_logical = slot == (uint32_t)(NC - 1) && a.thr_logical != 0;
     const uint32_t thrL1 = (uint32_t)(a.thr_logical - 1);
@@ -222,6 +229,7 @@ __global__ __launch_bounds__(1024) void ladder_colour_kernel(const LadderArgs a)
             if (lane < 4 && (int)slot * 4 + lane < NC - 1) sx[slot * 4 + lane] = sel4(b, lane);
         }
         __syncthreads();
+        if constexpr (CONV) { if (stopf[t & 1]) break; }                                 // (set by wave 0 one step earlier: uniform for the workgroup)
         uint32_t car = cur[NC - 1], mine = car;
         for (int i = NC - 2; i >= 0; --i) {
             const uint32_t lo = cur[i], xi = sx[i];
@@ -236,15 +244,46 @@ __global__ __launch_bounds__(1024) void ladder_colour_kernel(const LadderArgs a)
         mine = (uint32_t)__builtin_amdgcn_readfirstlane((int)mine);
         n = mine & 0xFFFFu; sid = (mine >> 16) & 0xFFu; cls = (mine >> 24) & 0x3Fu; flag = mine >> 31;
         if ((int)slot == NC - 1) flag = 1;                                               // mcmc.py:100
-        if (slot == 0) {
+        if (slot == 0 && !done) {
             tops0 += (NC == 1) | flag;                                                   // :101-102
-            flag = 0;                                                                    // :103
             if (a.counts != nullptr && tops0 >= a.tops_burn) {                           // decoders.py:60-67
                 if (lane == 0) hist[CODE == kCodeXzzx ? (cls ^ (cls >> 1)) : cls] += 1;
                 samples++;
+                if constexpr (CONV) {
+                    // nbr_errors_bottom_chain[since_burn] = count_errors (:68): logged in HBM, series index i in row burn + i; the three
+                    // entries that leave / enter the windows are independent loads (one round trip on wave 0's path per step)
+                    uint16_t *mylog = a.nlog + ladder;
+                    const size_t lN = (size_t)a.N;
+                    mylog[(size_t)t * lN] = (uint16_t)n;
+                    const uint32_t l = samples, lo1 = l - 1;
+                    const uint32_t a0 = lo1 >> 2, b0 = lo1 >> 1, c0 = (3u * lo1) >> 2, a1 = l >> 2, b1 = l >> 1, c1 = (3u * l) >> 2;
+                    sumB += n;
+                    if (c1 != c0) sumB -= mylog[(size_t)(burn + c0) * lN];
+                    if (b1 != b0) sumA += mylog[(size_t)(burn + b0) * lN];
+                    if (a1 != a0) sumA -= mylog[(size_t)(burn + a0) * lN];
+                }
+            } else {
+                burn++;                                                                  // resulting_burn_in, :71
             }
             if (!t_reached && tops0 >= a.TOPS) t_reached = (uint32_t)t + 1u;
+            if constexpr (CONV) {
+                if (tops0 >= a.TOPS) {                                                   // :74
+                    const uint32_t l = samples ? samples : 1u;
+                    const uint32_t den2 = (l >> 1) - (l >> 2), den4 = l - ((3u * l) >> 2);
+                    bool accept = false;                                                 // empty slice -> nan -> not accepted
+                    if (samples && den2 && den4) accept = fabs((double)sumA / (double)den2 - (double)sumB / (double)den4) < a.eps;   // :96-102
+                    if (accept) {
+                        if (conv_streak >= a.SEQ) { done = 1; steps_done = (uint32_t)t + 1u; }   // :77-78
+                        else conv_streak = tops0 - conv_start;                           // :79
+                    } else {
+                        conv_streak = 0;                                                 // :81-82
+                        conv_start = tops0;
+                    }
+                }
+                if (done && lane == 0) stopf[(t + 1) & 1] = 1;
+            }
         }
+        if (slot == 0) flag = 0;                                                         // :103
     }
     __syncthreads();
     // ---- results
@@ -258,17 +297,19 @@ __global__ __launch_bounds__(1024) void ladder_colour_kernel(const LadderArgs a)
                 else a.counts[row * ncls + c] = hist[c];
             }
         if (lane == 0) {
-            const uint32_t sd = t_reached ? t_reached : (uint32_t)a.nsteps;
+            // steps_done / converged: the criterion's; without it, the first step with tops0 >= TOPS
+            const uint32_t sd = CONV ? (done ? steps_done : (uint32_t)a.nsteps) : (t_reached ? t_reached : (uint32_t)a.nsteps);
+            const bool reached = CONV ? done != 0 : t_reached != 0;
             if (R > 1) {
                 if (a.samples != nullptr) atomicAdd(a.samples + row, samples);
                 if (a.tops0 != nullptr) atomicAdd(a.tops0 + row, tops0);
                 if (a.steps_done != nullptr) atomicMax(a.steps_done + row, sd);
-                if (a.converged != nullptr && !t_reached) a.converged[row] = 0;
+                if (a.converged != nullptr && !reached) a.converged[row] = 0;
             } else {
                 if (a.samples != nullptr) a.samples[row] = samples;
                 if (a.tops0 != nullptr) a.tops0[row] = tops0;
                 if (a.steps_done != nullptr) a.steps_done[row] = sd;
-                if (a.converged != nullptr) a.converged[row] = t_reached != 0;
+                if (a.converged != nullptr) a.converged[row] = reached;
             }
         }
     }
@@ -282,11 +323,13 @@ __global__ __launch_bounds__(1024) void ladder_colour_kernel(const LadderArgs a)
 
 hipError_t launch_ladder_colour(const LadderArgs &a, hipStream_t stream)
 {
-    if (a.phase_tab == nullptr || a.n_phases == 0 || a.noise != 0 || a.conv_mode != 0 || a.resume) return hipErrorInvalidValue;
-    const void *fn = a.code == kCodeToric ? (const void *)ladder_colour_kernel<kCodeToric>
-                   : a.code == kCodeXzzx ? (const void *)ladder_colour_kernel<kCodeXzzx>
-                   : a.code == kCodeRotated ? (const void *)ladder_colour_kernel<kCodeRotated>
-                   : a.code == kCodePlanar ? (const void *)ladder_colour_kernel<kCodePlanar> : nullptr;
+    if (a.phase_tab == nullptr || a.n_phases == 0 || a.noise != 0 || a.resume) return hipErrorInvalidValue;
+    if (a.conv_mode != 0 && a.nlog == nullptr) return hipErrorInvalidValue;
+    const bool conv = a.conv_mode != 0;
+#define QECMC_KC(code) (conv ? (const void *)ladder_colour_kernel<code, true> : (const void *)ladder_colour_kernel<code, false>)
+    const void *fn = a.code == kCodeToric ? QECMC_KC(kCodeToric) : a.code == kCodeXzzx ? QECMC_KC(kCodeXzzx)
+                   : a.code == kCodeRotated ? QECMC_KC(kCodeRotated) : a.code == kCodePlanar ? QECMC_KC(kCodePlanar) : nullptr;
+#undef QECMC_KC
     if (!fn) return hipErrorInvalidValue;
     const size_t lds = sizeof(uint32_t) * colour_lds_dwords(a.Nc, a.W, a.ncls, a.n_phases, a.n_gen, a.L, a.nq, a.swap_fast_ok != 0);
     if (lds > 160 * 1024) return hipErrorInvalidValue;

@@ -438,9 +438,9 @@ class Ladder:
 
 
 def pteq(code, init, p, Nc=None, SEQ=2, TOPS=10, tops_burn=2, eps=0.1, steps=1000, iters=10, conv_criteria=None,
-         rng=None, noise=DEPOLARIZING, eta=0.0, alpha=0.0, det_pow=0):
+         rng=None, noise=DEPOLARIZING, eta=0.0, alpha=0.0, det_pow=0, scan=0):
     init = _m(init); Nc = Nc or _size(code, init)
-    mod = _model(code, _size(code, init), noise, eta, 0, alpha, det_pow)
+    mod = _model(code, _size(code, init), noise, eta, scan, alpha, det_pow)
     res = PteqResult()
     fin = np.empty((Nc,) + init.shape, dtype=np.uint8)
     lib().orc_pteq(C.byref(mod), _u8(init), p, Nc, SEQ, TOPS, tops_burn, eps, steps, iters,

@@ -36,7 +36,7 @@ def draw_case(rng):
         noise = rng.choice(["biased", "alpha"])
     u = rng.random()
     scan = "random" if noise != "depolarizing" else "sweep" if u < 0.15 else "colour" if (u < 0.3 and Nc >= 2) else "random"
-    conv = scan != "colour" and rng.random() < 0.3        # (round 3: the alpha rule's criterion runs take the work queue too)
+    conv = rng.random() < 0.3                             # (round 3: the alpha rule's criterion runs take the work queue too)
     iters = int(rng.choice([1, 2, 3, 5, 7, 8, 10, 10, 10, 12, 13, 25]))
     work = Nc * iters * nq                                                 # ~ oracle cost per ladder step (the stencil copies nq bytes)
     steps = int(max(3, min(400 if not conv else 2500, 6e6 // work)))
@@ -45,7 +45,7 @@ def draw_case(rng):
     p = float(rng.choice([0.05, 0.1, 0.15, 0.18, 0.3]))
     # runs that stop by the criterion: a persistent grid of one or two workgroups makes finished lanes take new ladders from the
     # queue; fixed-length random-scan runs: sometimes cut into chunks continued from device-resident state (harness.LadderRun)
-    grid = str(rng.choice(["", "1", "2"])) if conv else ""
+    grid = str(rng.choice(["", "1", "2"])) if (conv and scan != "colour") else ""
     chunks = noise != "alpha" and scan == "random" and not conv and rng.random() < 0.25
     # replica ladders (R per syndrome, results summed on the device) in some of the one-launch fixed-length runs
     R = int(rng.choice([2, 3, 5])) if (not conv and not chunks and noise != "alpha" and rng.random() < 0.2) else 1
@@ -100,7 +100,7 @@ def run_case(c, rng):
                    converged=ref["converged"].reshape(c["N"], c["R"]).all(axis=1))
     bad = []
     # (scan = colour reports the first step with tops0 >= TOPS in steps_done / converged: tests/test_gpu_colour.py checks those)
-    for key in ("counts", "samples", "tops0") + (() if c["scan"] == "colour" else ("steps_done", "converged")):
+    for key in ("counts", "samples", "tops0") + (() if (c["scan"] == "colour" and not c["conv"]) else ("steps_done", "converged")):
         if not np.array_equal(np.asarray(got[key]).astype(np.uint64), np.asarray(ref[key]).astype(np.uint64)):
             bad.append(key)
     if not c["conv"] and not np.array_equal(got["states"], ref["states"]):

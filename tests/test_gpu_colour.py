@@ -71,6 +71,40 @@ def test_colour_scan_bit_exact(q, orc, name, L, Nc, N, steps, iters, p, p_logica
     assert np.array_equal(got["converged"], (reached > 0).reshape(N, R).all(axis=1))
 
 
+@pytest.mark.parametrize("name,L,Nc,N,steps,iters,R", [("toric", 3, 3, 40, 3000, 10, 1), ("toric", 5, 5, 30, 4000, 10, 1), ("rotated", 5, 4, 25, 3000, 7, 1),
+                                                    ("xzzx", 5, 5, 20, 3000, 10, 3), ("planar", 4, 4, 10, 2000, 5, 1)])
+def test_colour_scan_with_the_convergence_criterion_bit_exact(q, orc, name, L, Nc, N, steps, iters, R):
+    """conv_criteria = 'error_based' (decoders.py:74-105) in the latency layout: the criterion runs on wave 0 of the ladder's workgroup,
+    which leaves when it fires.  Stopping step, flag, class counts, samples and tops0 are the oracle's (its PTEQ loop around scan = 2)."""
+    rng = np.random.default_rng(L * 5 + N)
+    code, ocode = {"toric": (q.TORIC, orc.TORIC), "xzzx": (q.XZZX, orc.XZZX), "rotated": (q.ROTATED, orc.ROTATED), "planar": (q.PLANAR, orc.PLANAR)}[name]
+    shape = (N, 2, L, L) if name in ("toric", "planar") else (N, L, L)
+    init = _rand(rng, shape, 0.1)
+    if name == "planar":
+        init[:, 1, -1, :] = 0; init[:, 1, :, -1] = 0
+    kw = dict(steps=steps, iters=iters, tops_burn=1, seed=41, first_syndrome=3, conv_criteria="error_based", SEQ=1, TOPS=4, eps=0.5)
+    got = q.pteq_batch(init, 0.1, Nc=Nc, code=code, scan="colour", replicas=R, **kw)
+    ref = orc.pteq_batch(ocode, np.repeat(init, R, axis=0), 0.1, Nc, kw.pop("steps"), scan=2, **kw)
+    ncls = ref["counts"].shape[1]
+    assert np.array_equal(got["counts"], ref["counts"].reshape(N, R, ncls).sum(axis=1))
+    assert np.array_equal(got["samples"], ref["samples"].reshape(N, R).sum(axis=1).astype(np.uint32))
+    assert np.array_equal(got["tops0"], ref["tops0"].reshape(N, R).sum(axis=1).astype(np.uint32))
+    assert np.array_equal(got["steps_done"], ref["steps_done"].reshape(N, R).max(axis=1).astype(np.uint32))
+    assert np.array_equal(got["converged"], ref["converged"].reshape(N, R).all(axis=1))
+    assert got["converged"].any() and np.unique(got["steps_done"]).size > 3
+
+
+def test_pteq_dropin_in_the_latency_layout(q, orc):
+    """decoders.PTEQ(code, p, scan="colour") with the reference's default criterion: one syndrome, one workgroup"""
+    from qecmc import decoders
+    rng = np.random.default_rng(8)
+    code = q.Toric_code(5)
+    code.qubit_matrix = _rand(rng, (2, 5, 5), 0.1)
+    pct = q.PTEQ(code, 0.1, seed=19, scan="colour")
+    ref = orc.pteq(orc.TORIC, code.qubit_matrix, 0.1, Nc=5, steps=1 << 22, conv_criteria="error_based", rng=orc.Rng.philox(19, 0), scan=2)
+    assert ref["converged"] and np.array_equal(pct, ref["percent"])
+
+
 def test_colour_scan_conserves_the_syndrome(q):
     from qecmc import toric_model as tm
     rng = np.random.default_rng(3)
@@ -84,8 +118,6 @@ def test_colour_scan_conserves_the_syndrome(q):
 
 def test_colour_scan_rejects_what_it_does_not_do(q):
     init = np.zeros((1, 2, 5, 5), np.uint8)
-    with pytest.raises(q.QecmcError):
-        q.pteq_batch(init, 0.1, Nc=5, steps=100, scan="colour", conv_criteria="error_based")
     with pytest.raises(q.QecmcError):
         q.pteq_batch(np.zeros((1, 5, 5), np.uint8), 0.1, Nc=5, steps=100, scan="colour", code=q.XZZX, eta=10.0)
     with pytest.raises(q.QecmcError):

@@ -57,7 +57,8 @@ for name, L, p, Nc in (("toric L=9 p=0.15 Nc=8", 9, 0.15, 8), ("toric L=15 p=0.1
         if "colour" in getattr(q, "SCANS", ()):
             # (iters = 10 PHASES per step here: 10 / n_phases sweeps of every rung between swap sweeps, against 10 / G in the
             # lane-per-chain layout)
-            row["colour_parallel"] = {"to_tops0_ge_10": first_step_with_tops(init, p, Nc, 10, scan="colour")}
+            row["colour_parallel"] = {"to_tops0_ge_10": first_step_with_tops(init, p, Nc, 10, scan="colour"),
+                                      "default_stop": default_stop(init, p, Nc, scan="colour")}
         rows.append(row)
         print(name, json.dumps(row), file=sys.stderr, flush=True)
     out[name] = rows
