@@ -50,7 +50,8 @@ typedef enum qecmc_code { QECMC_TORIC = 0, QECMC_XZZX = 1, QECMC_ROTATED = 2, QE
 /* COLOUR: the latency layout -- one workgroup per ladder, one wavefront per rung, the lanes of a wavefront = the generators of
  * one colour phase (mutually disjoint, so their Metropolis tests are independent), proposed at once: a sweep is n_phases wavefront
  * passes instead of G sequential proposals.  A systematic scan like SWEEP (same stationary law, not the reference's chain);
- * depolarizing rule, fixed-length runs; `iters` counts phases; steps_done = the first step with tops0 >= TOPS. */
+ * depolarizing rule; `iters` counts phases; fixed-length runs report the first step with tops0 >= TOPS in steps_done / converged,
+ * conv_mode error_based runs the reference's criterion. */
 typedef enum qecmc_scan { QECMC_SCAN_RANDOM = 0, QECMC_SCAN_SWEEP = 1, QECMC_SCAN_COLOUR = 2 } qecmc_scan;
 typedef enum qecmc_noise { QECMC_NOISE_DEPOLARIZING = 0, QECMC_NOISE_BIASED = 1, QECMC_NOISE_ALPHA = 2 } qecmc_noise;
 typedef enum qecmc_conv { QECMC_CONV_NONE = 0, QECMC_CONV_ERROR_BASED = 1 } qecmc_conv;
