@@ -553,7 +553,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
         // dozen LDS addresses derived from it (records, swap uniforms, histogram rows, count tables ...) are formed where a step
         // uses them -- one add each -- instead of being hoisted out of the step loop into registers the 64-VGPR cap then spills.
         int lane_t = lane;
-        if constexpr (kLaunderLane) asm volatile("" : "+v"(lane_t));
+        if constexpr (kLaunderLane) { lane_t = (int)__lane_id(); asm volatile("" : "+v"(lane_t)); }   // (v_mbcnt: nothing derived from threadIdx stays live)
         // Issue arbitration between co-resident workgroups is oldest-first, which lets the first one
         // race ahead and leaves the last one alone (latency-bound, 2 waves per SIMD) at the end of a
         // launch.  Lowering a workgroup's priority as it advances (cyclically, every 8 steps) narrows
@@ -807,12 +807,15 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
                 // a12 + 2 <= e, above when a12 - 1 > e (for an integer i, i <= floor(e) <=> i <= e: the comparisons stay in floating
                 // point, exact on 12-bit integers).  In between (3 cells in 4096) the reference's expression decides, and only a true
                 // 12-bit tie draws w = refine(), the proposal's word of the refinement block.
-                auto test12 = [&](float e, uint32_t word, uint32_t Nn, auto &&refine) -> bool {
+                // (Both margins come from ONE subtraction: e - a12 is exact -- a12 is a multiple of e's ulp whenever e < 2^24 -- except when e is
+                // far below a12, where its rounding moves the difference by < 1e-3 of a unit around -1: inside the 0.3 of a unit the
+                // exponent's error budget leaves.  The proposal's packed counts are formed only where the exact expression needs them.)
+                auto test12 = [&](float e, uint32_t word, auto &&counts, auto &&refine) -> bool {
                     const uint32_t a12 = word & 0xFFFu;
-                    const float af = (float)a12;
-                    bool acc = af + 2.0f <= e;
-                    if (!acc && af - 1.0f <= e) {
-                        const double ratio = weight(Nn) / weight(entry_counts());   // mcmc_biased.py:44-46 (p_b's table addresses stay out of the hot loop)
+                    const float dm = e - (float)a12;
+                    bool acc = dm >= 2.0f;
+                    if (!acc && dm >= -1.0f) {
+                        const double ratio = weight(counts()) / weight(entry_counts());   // mcmc_biased.py:44-46 (p_b's table addresses stay out of the hot loop)
                         const double ulo = (double)a12 * (1.0 / 4096.0);
                         acc = ulo + (1.0 / 4096.0) <= ratio;
                         if (!acc && ulo < ratio) {
@@ -852,18 +855,17 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
                         uint32_t ssh[4];
                         const uint32_t F = sites(ev, sad, ssh);
                         const uint2 d = xlut[(ev.y & 0xF00u) | F];                  // pattern id << 8 | old fields -> the count change
-                        const uint32_t Nn = Np + d.x;
                         const half2_t pD = Dh + __builtin_bit_cast(half2_t, d.y);
                         const float e = f32ok ? __builtin_amdgcn_exp2f(__builtin_fmaf((float)pD.x, lxyf, __builtin_fmaf((float)pD.y, lzf, 12.0f)))
-                                              : ratio12_packed(Nn, entry_counts());
-                        const bool acc = test12(e, xw, Nn, [&]() -> uint32_t {
+                                              : ratio12_packed(Np + d.x, entry_counts());
+                        const bool acc = test12(e, xw, [&]() -> uint32_t { return Np + d.x; }, [&]() -> uint32_t {
                             constexpr int WI = decltype(wsel)::value;
                             const u32x4 r = philox_block(kb - (kq >> 2), kSubRefine, syn, strm, a.seed_lo, a.seed_hi);
                             return WI == 0 ? r.x : WI == 1 ? r.y : WI == 2 ? r.z : r.w;
                         });
                         if (acc) {
                             apply_gen(sad, ssh);
-                            Np = Nn;
+                            Np += d.x;
                             Dh = pD;
                             any_acc = true;
                         }
@@ -946,7 +948,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
                             const uint32_t F = sites(ev, sad, ssh);
                             Nn = Np + xlut[(ev.y & 0xF00u) | F].x;
                         }
-                        const bool acc = test12(ratio12_packed(Nn, Nb), B, Nn, [&]() -> uint32_t {
+                        const bool acc = test12(ratio12_packed(Nn, Nb), B, [&]() -> uint32_t { return Nn; }, [&]() -> uint32_t {
                             constexpr int WI = decltype(wsel)::value;               // 1 or 3: the word B's index
                             const u32x4 r = philox_block(kb - (kq >> 1), kSubRefine, syn, strm, a.seed_lo, a.seed_hi);
                             return WI == 1 ? r.y : r.w;
@@ -1909,20 +1911,23 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
     if (a.dbg && threadIdx.x == 0) a.dbg[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
 #endif
     // (the epilogue's addresses are formed here, not carried through the step loop)
+    const int tid_e0 = tid;
+    const int slot_e = kLaunderLane ? (int)wave_u : slot;        // (the wave's index, from the scalar copy)
     int lane_e = lane;
-    if constexpr (kLaunderLane) asm volatile("" : "+v"(lane_e));
+    if constexpr (kLaunderLane) { lane_e = (int)__lane_id(); asm volatile("" : "+v"(lane_e)); }
+    const int tid_e = kLaunderLane ? (int)(wave_u * 64u) + lane_e : tid_e0;
     uint32_t *fin = info + (a.nsteps & 1) * NC * 64;
     fin[slot_u * 64 + lane_e] = pack_info(n, sid, cls, flag);
     __syncthreads();
     if constexpr (kLdsCounters) {
-        if (slot == 0) { tops0 = ctrT[lane_e]; samples = ctrS[lane_e]; }
+        if (slot_e == 0) { tops0 = ctrT[lane_e]; samples = ctrS[lane_e]; }
     }
 
     // ---- results: coalesced stores ---------------------------------------------------
     if constexpr (QUEUE) return;                  // (every ladder wrote its results when it finished)
     if (a.counts != nullptr)
 #pragma unroll 1
-        for (int i = tid; i < cnt * ncls; i += nthreads) {
+        for (int i = tid_e; i < cnt * ncls; i += nthreads) {
             const int j = i / ncls, c = i - j * ncls;
             const uint32_t v = hist[c * 64 + j];
             if (R > 1) { if (v) atomicAdd(a.counts + ((s0 + (uint64_t)j) / R) * ncls + c, v); }   // the syndrome's R ladders, summed
@@ -1931,20 +1936,20 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
         }
     if (a.swap_acc != nullptr) {
 #pragma unroll 1
-        for (int i = tid; i < cnt * (2 * NC - 1); i += nthreads) {
+        for (int i = tid_e; i < cnt * (2 * NC - 1); i += nthreads) {
             const int j = i / (2 * NC - 1), c = i - j * (2 * NC - 1);
             if (c < NC - 1) a.swap_acc[(s0 + j) * (NC - 1) + c] = lds_all[gdw + c * 64 + j];
             else if (a.nerr_sum != nullptr) a.nerr_sum[(s0 + j) * NC + (c - (NC - 1))] = lds_all[gdw + (NC + c - (NC - 1)) * 64 + j];
         }
     }
-    if (slot == 0 && lane_e < cnt && R > 1) {
+    if (slot_e == 0 && lane_e < cnt && R > 1) {
         const uint64_t row = (s0 + lane_e) / R;
         if (a.samples != nullptr) atomicAdd(a.samples + row, samples);
         if (a.tops0 != nullptr) atomicAdd(a.tops0 + row, tops0);
         if (a.steps_done != nullptr) atomicMax(a.steps_done + row, done ? steps_done : (uint32_t)a.nsteps);
         if (a.converged != nullptr && !conv_ok) a.converged[row] = 0;               // the caller presets 1: all R ladders converged
     } else
-    if (slot == 0 && lane_e < cnt) {
+    if (slot_e == 0 && lane_e < cnt) {
         if (a.samples != nullptr) a.samples[s0 + lane_e] = a.accumulate ? a.samples[s0 + lane_e] + samples : samples;
         if (a.steps_done != nullptr) a.steps_done[s0 + lane_e] = USET ? (cm_done ? cm_steps : (uint32_t)a.nsteps) : done ? steps_done : (uint32_t)a.nsteps;
         if (a.converged != nullptr) a.converged[s0 + lane_e] = (uint8_t)conv_ok;
@@ -1954,13 +1959,13 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
     }
     if constexpr (BIASED) {
         if (alpha_noise && a.neff != nullptr && lane_e < cnt)
-            a.neff[(s0 + lane_e) * NC + slot] = neffb[((((uint32_t)a.nsteps & 1u) ^ 1u) * NC + slot) * 64 + lane_e];
+            a.neff[(s0 + lane_e) * NC + slot_e] = neffb[((((uint32_t)a.nsteps & 1u) ^ 1u) * NC + slot_e) * 64 + lane_e];
     }
     if (a.write_states && a.states != nullptr) {
         uint8_t *dst = a.states + s0 * (uint64_t)NC * nq;
         const int per = NC * nq, total = cnt * per;
 #pragma unroll 1      // (unrolled, its index divisions spill a register of the whole kernel to scratch)
-        for (int o = tid; o < total; o += nthreads) {
+        for (int o = tid_e; o < total; o += nthreads) {
             const int j = o / per, rem = o - j * per, c = rem / nq, q = rem - c * nq;
             const uint32_t sidc = (fin[c * 64 + j] >> 16) & 0xFFu;
             dst[o] = (uint8_t)((st[(sidc * W + (q >> 4)) * 64 + j] >> ((q & 15) * 2)) & 3u);

@@ -17,41 +17,43 @@ ALLOWED_SCRATCH = {
     "k_chain_update": 32,
     "k_syndrome": 32,
     "ladder<1024,4,rotated: conv|biased|gentop|alpha|queue>": 36,
-    "ladder<1024,4,xzzx: conv|biased|gentop|alpha|queue>": 28,
+    "ladder<1024,4,xzzx: conv|biased|gentop|alpha|queue>": 32,
     "ladder<512,4,rotated: conv|biased|gentop|alpha|queue>": 36,
-    "ladder<512,4,xzzx: conv|biased|gentop|alpha|queue>": 28,
-    "ladder<512,8,planar: conv|gentop>": 16,
-    "ladder<512,8,planar: conv|gentop|delut>": 16,
+    "ladder<512,4,xzzx: conv|biased|gentop|alpha|queue>": 32,
+    "ladder<512,8,planar: conv|gentop>": 28,
+    "ladder<512,8,planar: conv|gentop|delut>": 20,
     "ladder<512,8,planar: conv|gentop|queue>": 40,
     "ladder<512,8,planar: conv|scan|gentop>": 8,
     "ladder<512,8,planar: gsplit|uset>": 60,
     "ladder<512,8,planar: uset>": 60,
+    "ladder<512,8,rotated: biased|gentop>": 12,
     "ladder<512,8,rotated: biased|gentop|alpha>": 88,
     "ladder<512,8,rotated: biased|gentop|alpha|ssw>": 88,
-    "ladder<512,8,rotated: biased|gentop|ssw>": 12,
+    "ladder<512,8,rotated: biased|gentop|ssw>": 20,
     "ladder<512,8,rotated: conv|biased|gentop>": 96,
-    "ladder<512,8,rotated: conv|biased|gentop|alpha>": 196,
-    "ladder<512,8,rotated: conv|gentop>": 16,
-    "ladder<512,8,rotated: conv|gentop|delut>": 16,
+    "ladder<512,8,rotated: conv|biased|gentop|alpha>": 184,
+    "ladder<512,8,rotated: conv|gentop>": 12,
+    "ladder<512,8,rotated: conv|gentop|delut>": 12,
     "ladder<512,8,rotated: conv|gentop|queue>": 40,
     "ladder<512,8,rotated: conv|scan|gentop>": 8,
-    "ladder<512,8,rotated: gsplit|uset>": 60,
-    "ladder<512,8,rotated: uset>": 60,
-    "ladder<512,8,toric: conv|gentop>": 56,
-    "ladder<512,8,toric: conv|gsplit|gentop>": 56,
+    "ladder<512,8,rotated: gsplit|uset>": 52,
+    "ladder<512,8,rotated: uset>": 52,
+    "ladder<512,8,toric: conv|gentop>": 64,
+    "ladder<512,8,toric: conv|gsplit|gentop>": 64,
     "ladder<512,8,toric: conv|gsplit|queue>": 12,
     "ladder<512,8,toric: conv|queue>": 12,
-    "ladder<512,8,toric: conv|scan|gentop>": 56,
-    "ladder<512,8,xzzx: biased|gentop|alpha>": 84,
+    "ladder<512,8,toric: conv|scan|gentop>": 72,
+    "ladder<512,8,xzzx: biased|gentop>": 20,
+    "ladder<512,8,xzzx: biased|gentop|alpha>": 68,
     "ladder<512,8,xzzx: biased|gentop|alpha|ssw>": 80,
-    "ladder<512,8,xzzx: conv|biased|gentop>": 80,
-    "ladder<512,8,xzzx: conv|biased|gentop|alpha>": 184,
-    "ladder<512,8,xzzx: conv|gentop>": 16,
+    "ladder<512,8,xzzx: conv|biased|gentop>": 96,
+    "ladder<512,8,xzzx: conv|biased|gentop|alpha>": 176,
+    "ladder<512,8,xzzx: conv|gentop>": 12,
     "ladder<512,8,xzzx: conv|gentop|delut>": 12,
     "ladder<512,8,xzzx: conv|gentop|queue>": 44,
     "ladder<512,8,xzzx: conv|scan|gentop>": 8,
-    "ladder<512,8,xzzx: gsplit|uset>": 48,
-    "ladder<512,8,xzzx: uset>": 48,
+    "ladder<512,8,xzzx: gsplit|uset>": 52,
+    "ladder<512,8,xzzx: uset>": 52,
 }
 # the kernels BASELINE configurations 2-5 launch at their bench shapes (bench.py --config N): never on the list
 BASELINE_KERNELS = ["ladder<512,8,toric: gsplit|delut|ssw>", "ladder<512,4,toric: pre|delut>", "ladder<512,8,xzzx: biased|gentop|ssw>",
