@@ -12,6 +12,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -53,10 +55,58 @@ int use_device(int dev)
     return 0;
 }
 
+// Small device blocks are recycled: the drop-in entry points (one chain or one ladder per call, mcmc.py:81-103 driven from a Python loop)
+// would otherwise spend most of a call in hipMalloc / hipFree -- hipFree also waits for the device.  Blocks up to kPoolBlock bytes are
+// rounded up to a power of two and kept, per device, until kPoolBytes are cached; larger ones (the batched calls) go to the runtime as before.
+// Nothing here is zero-filled, exactly like hipMalloc: every user writes its buffer before a kernel reads it.
+class DevPool {
+public:
+    static constexpr size_t kPoolBlock = size_t(1) << 20, kPoolBytes = size_t(32) << 20;
+    static DevPool &get() { static DevPool *pool = new DevPool; return *pool; }   // (never destroyed: the HIP runtime may be gone before static destructors run)
+    hipError_t take(size_t bytes, void **p, size_t *cap, int *dev)
+    {
+        *cap = 0;
+        if (bytes > kPoolBlock) return hipMalloc(p, bytes);
+        size_t want = 256;
+        while (want < bytes) want <<= 1;
+        if (hipError_t e = hipGetDevice(dev)) return e;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            for (size_t i = 0; i < free_.size(); ++i)
+                if (free_[i].cap == want && free_[i].dev == *dev) {
+                    *p = free_[i].p; *cap = want;
+                    cached_ -= want;
+                    free_[i] = free_.back(); free_.pop_back();
+                    return hipSuccess;
+                }
+        }
+        *cap = want;
+        return hipMalloc(p, want);
+    }
+    void give(void *p, size_t cap, int dev)
+    {
+        if (cap) {
+            std::lock_guard<std::mutex> g(mu_);
+            if (cached_ + cap <= kPoolBytes) { free_.push_back({p, cap, dev}); cached_ += cap; return; }
+        }
+        (void)hipFree(p);
+    }
+private:
+    struct Blk { void *p; size_t cap; int dev; };
+    std::mutex mu_;
+    std::vector<Blk> free_;
+    size_t cached_ = 0;
+};
+
 struct DevBuf {
     void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    size_t cap = 0;          // pooled block size (0: straight from hipMalloc)
+    int dev = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { if (p) DevPool::get().give(p, cap, dev); }
+    hipError_t alloc(size_t bytes) { return DevPool::get().take(bytes ? bytes : 1, &p, &cap, &dev); }
     template <class T> T *as() const { return static_cast<T *>(p); }
 };
 
@@ -444,6 +494,13 @@ int qecmc_generate_syndromes(int code, int L, uint64_t N, double p_x, double p_y
 }
 
 // ---------------------------------------------------------------- chain / ladder
+// (the drop-in calls gather their small buffers into one host block -- per thread, kept between calls -- and move it with one copy each way)
+static std::vector<uint8_t> &staging()
+{
+    static thread_local std::vector<uint8_t> h;
+    return h;
+}
+
 static int chain_update_impl(int code, int L, uint64_t N, uint8_t *states_inout, double p, double eta, int noise,
                              double p_logical, uint64_t iters, uint64_t seed, uint32_t first_syndrome, uint32_t slot, uint64_t k0,
                              uint8_t *accepted_out = nullptr)
@@ -467,21 +524,32 @@ static int chain_update_impl(int code, int L, uint64_t N, uint8_t *states_inout,
     for (size_t d = 1; d <= nq && !noise; ++d) tbl[d] = thr32(std::pow(f, (double)d));
     for (int d = 1; d <= 4 && !noise; ++d) a.acc44[d] = thr44(std::pow(f, (double)d));
     const std::vector<double> bt = noise == QECMC_NOISE_ALPHA ? alpha_tables(p, eta, nq) : bias_tables(p, noise ? eta : 1.0, nq);
-    DevBuf ds, dt, db, dacc;
-    HIP_TRY(ds.alloc(N * nq)); HIP_TRY(dt.alloc(tbl.size() * 4)); HIP_TRY(db.alloc(bt.size() * 8));
-    if (accepted_out) { HIP_TRY(dacc.alloc(N)); a.accepted = dacc.as<uint8_t>(); }
-    HIP_TRY(hipMemcpy(ds.p, states_inout, N * nq, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dt.p, tbl.data(), tbl.size() * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(db.p, bt.data(), bt.size() * 8, hipMemcpyHostToDevice));
-    a.states = ds.as<uint8_t>(); a.N = N; a.iters = iters; a.k0 = k0;
+    // one device block, one copy each way: [bias table | acceptance table | states | accepted]
+    auto up = [](size_t v) { return (v + 255) & ~size_t(255); };     // (every part on a 256-byte boundary, as hipMalloc would place it)
+    const size_t o_tbl = up(bt.size() * 8), o_st = o_tbl + up(tbl.size() * 4), o_acc = o_st + up(N * nq), total = o_acc + (accepted_out ? N : 0);
+    std::vector<uint8_t> &h = staging();
+    h.resize(o_acc);
+    std::memcpy(h.data(), bt.data(), bt.size() * 8);
+    std::memcpy(h.data() + o_tbl, tbl.data(), tbl.size() * 4);
+    std::memcpy(h.data() + o_st, states_inout, N * nq);
+    DevBuf d;
+    HIP_TRY(d.alloc(total));
+    HIP_TRY(hipMemcpy(d.p, h.data(), o_acc, hipMemcpyHostToDevice));
+    if (accepted_out) a.accepted = d.as<uint8_t>() + o_acc;
+    a.states = d.as<uint8_t>() + o_st; a.N = N; a.iters = iters; a.k0 = k0;
     a.thr_logical = p_logical > 0 ? thr64(p_logical) : 0;
-    a.acc_tbl = dt.as<uint32_t>(); a.acc_all = !noise && f >= 1.0;
+    a.acc_tbl = reinterpret_cast<uint32_t *>(d.as<uint8_t>() + o_tbl); a.acc_all = !noise && f >= 1.0;
     a.first_syndrome = first_syndrome; a.slot = slot;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.L = L;
-    a.code = code; a.noise = noise; a.bias_tbl = db.as<double>();
+    a.code = code; a.noise = noise; a.bias_tbl = d.as<double>();
     HIP_TRY(launch_chain_update(a, 0));
-    HIP_TRY(hipMemcpy(states_inout, ds.p, N * nq, hipMemcpyDeviceToHost));
-    if (accepted_out) HIP_TRY(hipMemcpy(accepted_out, dacc.p, N, hipMemcpyDeviceToHost));
+    if (accepted_out) {
+        h.resize(total - o_st);
+        HIP_TRY(hipMemcpy(h.data(), d.as<uint8_t>() + o_st, total - o_st, hipMemcpyDeviceToHost));
+        std::memcpy(states_inout, h.data(), N * nq);
+        std::memcpy(accepted_out, h.data() + (o_acc - o_st), N);
+    } else
+        HIP_TRY(hipMemcpy(states_inout, d.as<uint8_t>() + o_st, N * nq, hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -503,6 +571,35 @@ int qecmc_chain_update_alpha(int code, int L, uint64_t N, uint8_t *states_inout,
     return chain_update_impl(code, L, N, states_inout, pz_tilde, alpha, QECMC_NOISE_ALPHA, p_logical, iters, seed, first_syndrome, slot, k0, accepted_out);
 }
 
+// The step entry points' plan cache: keyed by the whole parameter block (the fields a plan does not depend on -- seed, first_syndrome,
+// steps -- are constant for one ladder anyway), a handful of entries, least recently used out first.  Plans are immutable once
+// built (a launch works on a copy of `args`), so concurrent callers may share one.
+static int cached_plan(const qecmc_params &p, std::shared_ptr<const qecmc_plan> *out)
+{
+    struct Entry { qecmc_params key; std::shared_ptr<const qecmc_plan> plan; uint64_t used; };
+    static std::mutex mu;
+    static std::vector<Entry> *cache = new std::vector<Entry>;     // (never destroyed, like the block pool)
+    static uint64_t tick = 0;
+    constexpr size_t kEntries = 8;
+    {
+        std::lock_guard<std::mutex> g(mu);
+        for (Entry &e : *cache)
+            if (std::memcmp(&e.key, &p, sizeof p) == 0) { e.used = ++tick; *out = e.plan; return 0; }
+    }
+    auto pl = std::make_shared<qecmc_plan>();
+    if (int rc = build_plan(&p, pl.get())) return rc;
+    *out = pl;
+    std::lock_guard<std::mutex> g(mu);
+    if (cache->size() >= kEntries) {
+        size_t lru = 0;
+        for (size_t i = 1; i < cache->size(); ++i) if ((*cache)[i].used < (*cache)[lru].used) lru = i;
+        // (its tables are freed when the last caller still stepping with it returns; every such call ends with a blocking copy)
+        (*cache)[lru] = Entry{p, pl, ++tick};
+    } else
+        cache->push_back(Entry{p, pl, ++tick});
+    return 0;
+}
+
 static int ladder_step_impl(const qecmc_params *params, uint64_t N, uint8_t *states_inout, uint8_t *flags_inout,
                             uint32_t *tops0_inout, uint16_t *neff_inout, uint64_t iters, uint64_t nsteps, uint64_t step0, uint64_t prop0)
 {
@@ -518,29 +615,34 @@ static int ladder_step_impl(const qecmc_params *params, uint64_t N, uint8_t *sta
         return fail(QECMC_ERR_INVALID, "alpha-noise ladders step through qecmc_ladder_step_alpha (which carries the slots' n_eff), the others through qecmc_ladder_step");
     if (int rc = use_device(p.device)) return rc;
     if (N == 0) return 0;
-    qecmc_plan pl;
-    if (int rc = build_plan(&p, &pl)) return rc;
+    // a Python loop over Ladder.step presents the same parameters every call: the tables of the last few plans are kept
+    std::shared_ptr<const qecmc_plan> plan;
+    if (int rc = cached_plan(p, &plan)) return rc;
+    const qecmc_plan &pl = *plan;
     const size_t nq = pl.args.nq, Nc = pl.args.Nc;
-    DevBuf ds, df, dt;
-    HIP_TRY(ds.alloc(N * Nc * nq)); HIP_TRY(df.alloc(N * Nc)); HIP_TRY(dt.alloc(N * 4));
-    HIP_TRY(hipMemcpy(ds.p, states_inout, N * Nc * nq, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(df.p, flags_inout, N * Nc, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dt.p, tops0_inout, N * 4, hipMemcpyHostToDevice));
+    // one device block, one copy each way: [n_eff records | tops0 | states | flags]
+    auto up = [](size_t v) { return (v + 255) & ~size_t(255); };     // (every part on a 256-byte boundary, as hipMalloc would place it)
+    const size_t o_t0 = neff_inout ? up(N * Nc * 4) : 0, o_st = o_t0 + up(N * 4), o_fl = o_st + up(N * Nc * nq), total = o_fl + N * Nc;
+    std::vector<uint8_t> &h = staging();
+    h.resize(total);
+    if (neff_inout) std::memcpy(h.data(), neff_inout, N * Nc * 4);
+    std::memcpy(h.data() + o_t0, tops0_inout, N * 4);
+    std::memcpy(h.data() + o_st, states_inout, N * Nc * nq);
+    std::memcpy(h.data() + o_fl, flags_inout, N * Nc);
+    DevBuf d;
+    HIP_TRY(d.alloc(total));
+    HIP_TRY(hipMemcpy(d.p, h.data(), total, hipMemcpyHostToDevice));
     LadderArgs a = pl.args;
-    DevBuf dn;
-    if (neff_inout) {
-        HIP_TRY(dn.alloc(N * Nc * 4));
-        HIP_TRY(hipMemcpy(dn.p, neff_inout, N * Nc * 4, hipMemcpyHostToDevice));
-        a.neff = dn.as<uint32_t>();
-    }
-    a.states = ds.as<uint8_t>(); a.flags = df.as<uint8_t>(); a.tops0 = dt.as<uint32_t>();
+    if (neff_inout) a.neff = d.as<uint32_t>();
+    a.states = d.as<uint8_t>() + o_st; a.flags = d.as<uint8_t>() + o_fl; a.tops0 = reinterpret_cast<uint32_t *>(d.as<uint8_t>() + o_t0);
     a.N = N; a.first_syndrome = p.first_syndrome; a.step0 = step0; a.prop0 = prop0; a.nsteps = nsteps;
     a.resume = 1; a.write_states = 1;
     HIP_TRY(launch_ladder_rs_toric(a, 0));
-    HIP_TRY(hipMemcpy(states_inout, ds.p, N * Nc * nq, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(flags_inout, df.p, N * Nc, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(tops0_inout, dt.p, N * 4, hipMemcpyDeviceToHost));
-    if (neff_inout) HIP_TRY(hipMemcpy(neff_inout, dn.p, N * Nc * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h.data(), d.p, total, hipMemcpyDeviceToHost));
+    if (neff_inout) std::memcpy(neff_inout, h.data(), N * Nc * 4);
+    std::memcpy(tops0_inout, h.data() + o_t0, N * 4);
+    std::memcpy(states_inout, h.data() + o_st, N * Nc * nq);
+    std::memcpy(flags_inout, h.data() + o_fl, N * Nc);
     return 0;
 }
 
@@ -574,6 +676,8 @@ int qecmc_plan_create(const qecmc_params *params, qecmc_plan **plan_out)
 
 int qecmc_plan_destroy(qecmc_plan *plan)
 {
+    // the plan's tables may go back to the block pool and on to another call: wait for the launches that read them (what hipFree used to do)
+    if (plan) { (void)hipSetDevice(plan->prm.device); (void)hipDeviceSynchronize(); }
     delete plan;
     return 0;
 }

@@ -116,6 +116,63 @@ def test_ladder_step_bit_exact(q, orc, L, p, Nc, iters, nstep):
         assert ld.tops0 == ref.tops0
 
 
+def test_interleaved_ladders_share_the_plan_cache_and_block_pool(q, orc):
+    """The step entry points keep the tables of the last 8 parameter sets and recycle their small device blocks: 11 ladders of
+    different shapes stepped in turn (so entries are evicted and rebuilt, blocks change hands) must each stay on its own trajectory."""
+    rng = np.random.default_rng(77)
+    shapes = [(3, 0.30, 4), (5, 0.10, 5), (5, 0.12, 5), (7, 0.15, 8), (3, 0.05, 2), (5, 0.20, 3), (9, 0.15, 8), (5, 0.10, 6), (7, 0.10, 3),
+              (3, 0.20, 3), (5, 0.15, 5)]
+    lads, refs, rngs = [], [], []
+    for i, (L, p, Nc) in enumerate(shapes):
+        m = rand_states(rng, 1, L, 0.15)[0]
+        code = q.Toric_code(L)
+        code.qubit_matrix = m.copy()
+        lads.append(q.Ladder(p, code, Nc, 0.5, seed=1000 + i, stream=i))
+        refs.append(orc.ToricLadder(m, p, Nc, 0.5))
+        rngs.append(orc.Rng.philox(1000 + i, i))
+    for rnd in range(4):
+        for ld, ref, r in zip(lads, refs, rngs):
+            ld.step(10, nsteps=1 + rnd)
+            for _ in range(1 + rnd):
+                ref.step(10, r)
+    for ld, ref in zip(lads, refs):
+        assert np.array_equal(np.stack([c.code.qubit_matrix for c in ld.chains]), ref.states)
+        assert [c.flag for c in ld.chains] == ref.flags.tolist() and ld.tops0 == ref.tops0
+
+
+def test_ladders_stepped_from_concurrent_threads(q, orc):
+    """ctypes releases the GIL around a call: four threads stepping their own ladders (two of them with identical parameters,
+    i.e. sharing one cached plan) through the pooled blocks must reproduce the oracle's trajectories."""
+    import threading
+    rng = np.random.default_rng(78)
+    shapes = [(5, 0.10, 5, 7), (5, 0.10, 5, 7), (7, 0.15, 8, 8), (3, 0.30, 4, 9)]
+    lads, inits = [], []
+    for i, (L, p, Nc, seed) in enumerate(shapes):
+        m = rand_states(rng, 1, L, 0.15)[0]
+        code = q.Toric_code(L)
+        code.qubit_matrix = m.copy()
+        lads.append(q.Ladder(p, code, Nc, 0.5, seed=seed, stream=3))
+        inits.append(m)
+    errs = []
+
+    def run(ld):
+        try:
+            for _ in range(60):
+                ld.step(10)
+        except Exception as e:           # noqa: BLE001 -- reported below, in the main thread
+            errs.append(e)
+    th = [threading.Thread(target=run, args=(ld,)) for ld in lads]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    for (L, p, Nc, seed), m, ld in zip(shapes, inits, lads):
+        ref, r = orc.ToricLadder(m, p, Nc, 0.5), orc.Rng.philox(seed, 3)
+        for _ in range(60):
+            ref.step(10, r)
+        assert np.array_equal(np.stack([c.code.qubit_matrix for c in ld.chains]), ref.states)
+        assert ld.tops0 == ref.tops0
+
+
 # ------------------------------------------------------------------ PTEQ batch vs oracle
 @pytest.mark.parametrize("L,p,Nc,N,steps,tops_burn", [
     (3, 0.10, 3, 1, 300, 2), (3, 0.10, 2, 63, 200, 0), (5, 0.10, 5, 65, 200, 1), (5, 0.10, 5, 130, 150, 2),
