@@ -79,8 +79,8 @@ struct LadderArgs {
     float swap_inv_log2[kMaxNc];   // 1 / log2(p_diff[i]): first guess of the largest d with u < p_diff[i]^d (the table decides)
     int32_t swap_fast_ok;          // every swap threshold with d >= 1 fits 32 bits (false only if two rungs coincide)
     int L, Nc, W, nq, ncls;
-#ifdef QECMC_TIMELINE
-    uint64_t *dbg;            // [grid][4] diagnostic stamps (tools/timeline.hip only)
+#if defined(QECMC_TIMELINE) || defined(QECMC_STEPTRACE)
+    uint64_t *dbg;            // [grid][4] diagnostic stamps (tools/timeline.hip, tools/steptrace.hip only)
 #endif
     int resume;               // 0: replicate init into every slot (mcmc.py:72); 1: load states/flags/tops0
     int write_states;

@@ -259,6 +259,18 @@ enum LadderFlag : uint32_t {
     kPre = 1u << 7, kDelut = 1u << 8, kQueue = 1u << 9, kSsw = 1u << 10,
 };
 
+// Diagnostic build only (tools/steptrace.hip): shader-clock stamps of one workgroup's waves at the phase boundaries of 32 ladder steps,
+// behind the per-workgroup stamps of QECMC_TIMELINE in a.dbg.
+#ifdef QECMC_STEPTRACE
+#define QECMC_STAMP(k)                                                                                                         \
+    do {                                                                                                                       \
+        if (a.dbg && blockIdx.x == gridDim.x / 2 && t >= 2000 && t < 2032 && (threadIdx.x & 63) == 0)                          \
+            a.dbg[(size_t)gridDim.x * 4 + (((t - 2000) * 16 + (threadIdx.x >> 6)) * 8 + (k))] = (k) == 5 ? (uint64_t)slot_u : (uint64_t)clock64(); \
+    } while (0)
+#else
+#define QECMC_STAMP(k) ((void)0)
+#endif
+
 template <int MAXT, int MINW, int CODE, uint32_t FLAGS>
 __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
 {
@@ -326,7 +338,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
         }
     };
 
-#ifdef QECMC_TIMELINE   // diagnostic build only (tools/timeline.hip): per-workgroup start/end stamps and placement
+#if defined(QECMC_TIMELINE) || defined(QECMC_STEPTRACE)   // diagnostic build only (tools/timeline.hip, tools/steptrace.hip): per-workgroup start/end stamps and placement
     if (a.dbg && threadIdx.x == 0) {
         a.dbg[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memrealtime();
         a.dbg[blockIdx.x * 4 + 1] = ((uint64_t)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) |   // XCC_ID
@@ -565,6 +577,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
             case 2: __builtin_amdgcn_s_setprio(2); break;
             default: __builtin_amdgcn_s_setprio(3); break;
         }
+        QECMC_STAMP(5); QECMC_STAMP(0);
         // ---------------- Chain.update_chain(iters) on every slot (mcmc.py:81-83) -----------
         uint32_t *stw = st + sid * W * 64 + lane_t;
         const uint64_t kbase = a.prop0 + t * iters;
@@ -1537,6 +1550,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
 
         // ---------------- swap sweep, Ladder.step mcmc.py:96-103 --------------------------------
         // (double-buffered by step parity: a fast wave may publish step t+1 while a slow one still reads step t)
+        QECMC_STAMP(1);
         uint32_t *cur = info + (t & 1) * NC * 64 + lane_t, *sx = swx + (t & 1) * NC * 64 + lane_t;
         cur[slot_u * 64] = pack_info(n, sid, cls, flag);
         if constexpr (PRE) {
@@ -1597,7 +1611,9 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
             if (left > 2) p[128] = r2;
             if (left > 3) p[192] = r3;
         }
+        QECMC_STAMP(2);
         __syncthreads();
+        QECMC_STAMP(3);
         [[maybe_unused]] bool q_refill = false;
         if (CONV || USET) {                                 // flags set one step earlier: uniform for the workgroup
             volatile uint32_t *f0 = lds_all + (NC * W * 64 + 4 * NC * 64 + ncls * 64 + NC * 9 + NC * kSwapFast);
@@ -1675,6 +1691,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
             }   // !SSW
             if (!SSW && slot_u == 0) mine = car;
             n = mine & 0xFFFFu; sid = (mine >> 16) & 0xFFu; cls = (mine >> 24) & 0x3Fu; flag = mine >> 31;
+            QECMC_STAMP(4);
             if ((int)slot_u == NC - 1) flag = 1;                                    // chains[-1].flag = 1, mcmc.py:100
             if (wave_u == 0 && !done) {                                             // ladder + PTEQ bookkeeping on slot 0's new state
                 if constexpr (kLdsCounters) { tops0 = ctrT[lane_t]; samples = ctrS[lane_t]; }
@@ -1907,7 +1924,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
             }
         }
     }
-#ifdef QECMC_TIMELINE
+#if defined(QECMC_TIMELINE) || defined(QECMC_STEPTRACE)
     if (a.dbg && threadIdx.x == 0) a.dbg[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
 #endif
     // (the epilogue's addresses are formed here, not carried through the step loop)

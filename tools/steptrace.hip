@@ -1,0 +1,81 @@
+// Diagnostic (not part of the product): where a ladder step's time goes, wave by wave.  Unity build of the library sources with
+// QECMC_STEPTRACE defined: the waves of the middle workgroup of a launch stamp the shader clock at the phase boundaries of ladder steps
+// 2000 .. 2031 (step begin | proposals done | records and swap bounds published | past the barrier | cascade done).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/steptrace tools/steptrace.hip
+//   tools/steptrace toric 15 0.18 8 131072        (config 3)        tools/steptrace rotated 21 0.17 8 32768   (config 5)
+#define QECMC_STEPTRACE 1
+#include "../mcmc-qec-toric-rl_amd/csrc/capi.hip"
+#include "../mcmc-qec-toric-rl_amd/csrc/ladder_rs.hip"
+#include "../mcmc-qec-toric-rl_amd/csrc/ladder_toric.hip"
+#include "../mcmc-qec-toric-rl_amd/csrc/ladder_surf.hip"
+#include "../mcmc-qec-toric-rl_amd/csrc/primitives.hip"
+namespace qecmc {   // the families this tool does not trace
+hipError_t launch_ladder_sweep(const LadderArgs &, hipStream_t) { return hipErrorInvalidValue; }
+hipError_t launch_ladder_biased(const LadderArgs &, hipStream_t) { return hipErrorInvalidValue; }
+hipError_t launch_ladder_uset(const LadderArgs &, hipStream_t) { return hipErrorInvalidValue; }
+hipError_t launch_ladder_colour(const LadderArgs &, hipStream_t) { return hipErrorInvalidValue; }
+}
+#include <algorithm>
+
+int main(int argc, char **argv)
+{
+    const char *cname = argc > 1 ? argv[1] : "toric";
+    const int L = argc > 2 ? atoi(argv[2]) : 15;
+    const double perr = argc > 3 ? atof(argv[3]) : 0.18;
+    const int Nc = argc > 4 ? atoi(argv[4]) : 8;
+    const uint64_t N = argc > 5 ? atoll(argv[5]) : 131072;
+    const int steps = 3000;
+    const int code = !strcmp(cname, "toric") ? QECMC_TORIC : !strcmp(cname, "xzzx") ? QECMC_XZZX : !strcmp(cname, "rotated") ? QECMC_ROTATED : QECMC_PLANAR;
+    qecmc_params p; memset(&p, 0, sizeof p);
+    p.abi_size = sizeof p; p.code = code; p.L = L; p.Nc = Nc; p.p = perr; p.p_logical = 0.5; p.iters = argc > 6 ? atoi(argv[6]) : 10;
+    p.steps = steps; p.tops_burn = 2; p.seed = 1;
+    qecmc_plan *pl = nullptr;
+    if (qecmc_plan_create(&p, &pl)) { printf("plan: %s\n", qecmc_last_error()); return 1; }
+    const size_t nq = pl->args.nq;
+    std::vector<uint8_t> init(N * nq, 0);     // the trivial syndrome: what a step costs does not depend on it
+    uint8_t *di; uint32_t *dc, *ds, *dt; uint64_t *dbg;
+    const unsigned grid = (unsigned)((N + 63) / 64);
+    const size_t ndbg = (size_t)grid * 4 + 32 * 16 * 8;
+    hipMalloc(&di, N * nq); hipMalloc(&dc, N * 64); hipMalloc(&ds, N * 4); hipMalloc(&dt, N * 4); hipMalloc(&dbg, ndbg * 8);
+    hipMemcpy(di, init.data(), N * nq, hipMemcpyHostToDevice);
+    for (int rep = 0; rep < 2; ++rep) {
+        LadderArgs a = pl->args;
+        a.init = di; a.counts = dc; a.samples = ds; a.tops0 = dt; a.states = nullptr; a.write_states = 0; a.N = N;
+        a.nsteps = steps; a.dbg = dbg;
+        hipMemset(dbg, 0, ndbg * 8);
+        hipError_t e = launch_ladder_rs_toric(a, 0);
+        if (e != hipSuccess) { printf("launch: %s\n", hipGetErrorString(e)); return 1; }
+        if (hipDeviceSynchronize() != hipSuccess) { printf("sync failed\n"); return 1; }
+    }
+    std::vector<uint64_t> h(ndbg);
+    hipMemcpy(h.data(), dbg, ndbg * 8, hipMemcpyDeviceToHost);
+    const uint64_t *tr = h.data() + (size_t)grid * 4;
+    auto at = [&](int t, int w, int k) { return tr[((size_t)t * 16 + w) * 8 + k]; };
+    // per step: the workgroup's period (first wave's step begin to the next step's), and per wave the share of each phase
+    double sum_period = 0, ph[5] = {0, 0, 0, 0, 0}, role[16][5];
+    int rolen[16];
+    memset(role, 0, sizeof role); memset(rolen, 0, sizeof rolen);
+    printf("%s L=%d p=%g Nc=%d N=%llu iters=%llu: cycles per phase (shader clock), mean over steps 2000..2030 and the %d waves\n", cname, L, perr, Nc,
+           (unsigned long long)N, (unsigned long long)p.iters, Nc);
+    for (int t = 0; t < 31; ++t) {
+        uint64_t b0 = ~0ull, b1 = ~0ull;
+        for (int w = 0; w < Nc; ++w) { b0 = std::min(b0, at(t, w, 0)); b1 = std::min(b1, at(t + 1, w, 0)); }
+        sum_period += (double)(b1 - b0);
+        for (int w = 0; w < Nc; ++w) {
+            const double d[5] = {(double)(at(t, w, 1) - at(t, w, 0)), (double)(at(t, w, 2) - at(t, w, 1)), (double)(at(t, w, 3) - at(t, w, 2)),
+                                 (double)(at(t, w, 4) - at(t, w, 3)), (double)(at(t + 1, w, 0) - at(t, w, 4))};
+            const int s = (int)at(t, w, 5);
+            for (int k = 0; k < 5; ++k) { ph[k] += d[k]; role[s][k] += d[k]; }
+            rolen[s]++;
+        }
+    }
+    const double nw = 31.0 * Nc;
+    printf("step period %.0f cycles\n", sum_period / 31);
+    printf("all waves : proposals %.0f | publish+bounds %.0f | barrier wait %.0f | cascade %.0f | bookkeeping+loop %.0f\n", ph[0] / nw, ph[1] / nw, ph[2] / nw,
+           ph[3] / nw, ph[4] / nw);
+    for (int s = 0; s < Nc; ++s)
+        if (rolen[s])
+            printf("slot %2d   : proposals %.0f | publish+bounds %.0f | barrier wait %.0f | cascade %.0f | bookkeeping+loop %.0f\n", s, role[s][0] / rolen[s],
+                   role[s][1] / rolen[s], role[s][2] / rolen[s], role[s][3] / rolen[s], role[s][4] / rolen[s]);
+    return 0;
+}
