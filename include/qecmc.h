@@ -79,7 +79,8 @@ typedef struct qecmc_params {
     double   p;             /* bottom-chain error rate (mcmc.py:50 p_bottom); pz_tilde_bottom for alpha noise (mcmc_alpha.py:76) */
     double   eta;           /* bias (mcmc_biased.py:11); unused otherwise */
     double   alpha;         /* alpha noise exponent (mcmc_alpha.py:11, decoders_biasednoise.py:175); unused otherwise */
-    double   p_logical;     /* top-chain logical proposal rate (decoders.py:52 passes 0.5) */
+    double   p_logical;     /* top-chain logical proposal rate (decoders.py:52 passes 0.5); the ladder kernels' random scan selects with
+                               16 bits, i.e. acts as ceil(p_logical * 2^16) / 2^16 (exact for 0.5; the CPU oracle does the same) */
     uint64_t seed;          /* Philox key */
     uint32_t first_syndrome;/* global index of syndrome 0 of this call: results do not
                                depend on how a batch is sharded over GPUs */
