@@ -61,7 +61,10 @@ typedef enum qecmc_conv { QECMC_CONV_NONE = 0, QECMC_CONV_ERROR_BASED = 1 } qecm
 typedef struct qecmc_params {
     uint32_t abi_size;
     int32_t  code;          /* qecmc_code */
-    int32_t  L;             /* system_size (toric_model.py:10) */
+    int32_t  L;             /* system_size (toric_model.py:10).  The ladder calls keep every rung's state, the generator table and the
+                               acceptance tables in one workgroup's LDS, and refuse (QECMC_ERR_UNSUPPORTED, with the numbers) what does not fit:
+                               Nc * ceil(nq / 16) * 256 B of states + tables <= 160 KiB (toric L = 20 at Nc = 8, L = 31 at Nc = 2), at most 2048
+                               generators (toric L <= 32, xzzx / rotated L <= 45), nq <= 511 for the biased / alpha rules (L <= 21) */
     int32_t  Nc;            /* number of chains in the ladder (decoders.py:30; Q7: default L) */
     int32_t  noise;         /* qecmc_noise */
     int32_t  scan;          /* qecmc_scan: RANDOM = the reference's chain (src/mcmc.py:19-43) */

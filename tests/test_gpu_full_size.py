@@ -61,3 +61,29 @@ def test_full_size_properties(q, orc, name, L, p, Nc, N, eta):
                              return_states=True, noise=orc.BIASED if eta else orc.DEPOLARIZING, eta=eta or 0.0)
         assert np.array_equal(one["counts"][s], ref["counts"][0]) and int(one["tops0"][s]) == int(ref["tops0"][0])
         assert np.array_equal(one["states"][s], ref["states"][0])
+
+
+# ------------------------------------------------------------------ the largest shapes the LDS holds, and what lies beyond
+@pytest.mark.parametrize("name,L,Nc,eta", [("toric", 20, 8, None), ("toric", 31, 2, None), ("toric", 32, 1, None), ("rotated", 33, 4, None),
+                                          ("xzzx", 21, 4, 30.0)])
+def test_largest_shapes_bit_exact(q, orc, name, L, Nc, eta):
+    rng = np.random.default_rng(L + Nc)
+    cid = {"toric": q.TORIC, "xzzx": q.XZZX, "rotated": q.ROTATED}[name]
+    oid = {"toric": orc.TORIC, "xzzx": orc.XZZX, "rotated": orc.ROTATED}[name]
+    N = 5
+    shape = (N, 2, L, L) if name == "toric" else (N, L, L)
+    init = (rng.integers(1, 4, size=shape) * (rng.random(shape) < 0.12)).astype(np.uint8)
+    got = q.pteq_batch(init, 0.12, Nc=Nc, steps=12, iters=10, tops_burn=0, seed=3, first_syndrome=2, code=cid, eta=eta, return_states=True)
+    ref = orc.pteq_batch(oid, init, 0.12, Nc, 12, iters=10, tops_burn=0, seed=3, first_syndrome=2, return_states=True,
+                         noise=orc.BIASED if eta else orc.DEPOLARIZING, eta=eta or 0.0)
+    assert np.array_equal(got["counts"], ref["counts"]) and np.array_equal(got["tops0"], ref["tops0"].astype(np.uint32))
+    assert np.array_equal(got["states"], ref["states"])
+
+
+@pytest.mark.parametrize("name,L,Nc,eta,what", [("toric", 24, 8, None, "of LDS per workgroup"), ("toric", 40, 2, None, "generators exceed"),
+                                               ("rotated", 41, 8, None, "of LDS per workgroup"), ("xzzx", 23, 4, 10.0, "10-bit fields")])
+def test_shapes_beyond_the_lds_are_refused_with_the_reason(q, name, L, Nc, eta, what):
+    cid = {"toric": q.TORIC, "xzzx": q.XZZX, "rotated": q.ROTATED}[name]
+    init = np.zeros((2, 2, L, L) if name == "toric" else (2, L, L), dtype=np.uint8)
+    with pytest.raises(q.QecmcError, match=what):
+        q.pteq_batch(init, 0.1, Nc=Nc, steps=5, code=cid, eta=eta)
