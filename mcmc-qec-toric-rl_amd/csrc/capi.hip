@@ -500,6 +500,10 @@ static std::vector<uint8_t> &staging()
     static thread_local std::vector<uint8_t> h;
     return h;
 }
+// (a large batch through these entry points must not leave its host copy behind in the thread)
+struct StagingTrim {
+    ~StagingTrim() { std::vector<uint8_t> &h = staging(); if (h.capacity() > (size_t(8) << 20)) std::vector<uint8_t>().swap(h); }
+};
 
 static int chain_update_impl(int code, int L, uint64_t N, uint8_t *states_inout, double p, double eta, int noise,
                              double p_logical, uint64_t iters, uint64_t seed, uint32_t first_syndrome, uint32_t slot, uint64_t k0,
@@ -527,6 +531,7 @@ static int chain_update_impl(int code, int L, uint64_t N, uint8_t *states_inout,
     // one device block, one copy each way: [bias table | acceptance table | states | accepted]
     auto up = [](size_t v) { return (v + 255) & ~size_t(255); };     // (every part on a 256-byte boundary, as hipMalloc would place it)
     const size_t o_tbl = up(bt.size() * 8), o_st = o_tbl + up(tbl.size() * 4), o_acc = o_st + up(N * nq), total = o_acc + (accepted_out ? N : 0);
+    StagingTrim trim;
     std::vector<uint8_t> &h = staging();
     h.resize(o_acc);
     std::memcpy(h.data(), bt.data(), bt.size() * 8);
@@ -623,6 +628,7 @@ static int ladder_step_impl(const qecmc_params *params, uint64_t N, uint8_t *sta
     // one device block, one copy each way: [n_eff records | tops0 | states | flags]
     auto up = [](size_t v) { return (v + 255) & ~size_t(255); };     // (every part on a 256-byte boundary, as hipMalloc would place it)
     const size_t o_t0 = neff_inout ? up(N * Nc * 4) : 0, o_st = o_t0 + up(N * 4), o_fl = o_st + up(N * Nc * nq), total = o_fl + N * Nc;
+    StagingTrim trim;
     std::vector<uint8_t> &h = staging();
     h.resize(total);
     if (neff_inout) std::memcpy(h.data(), neff_inout, N * Nc * 4);
