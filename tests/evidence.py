@@ -182,6 +182,10 @@ def threshold(a):
                                       conv_criteria="error_based", device_generation=True)
         rec["curves"]["L%d" % L] = dict(success_rate=[float(x) for x in out["success_rate"]], err=[float(x) for x in out["err"]],
                                         converged_frac=[float(x) for x in out["converged_frac"]],
+                                        # among the syndromes whose ladder got past the burn-in at all (the reference returns the all-zero
+                                        # vector -> class 0 for the others, decoders.py:63,89: the raw rate at low p measures that trap too)
+                                        success_rate_sampled=[float(x) for x in out["success_rate_sampled"]],
+                                        err_sampled=[float(x) for x in out["err_sampled"]], frac_sampled=[float(x) for x in out["frac_sampled"]],
                                         mean_steps=[float(m["mean_steps"]) if m and "mean_steps" in m else None for m in out["metrics"]],
                                         wall_s=time.time() - t0)
         say("threshold: L=%d done in %.1f s: " % (L, time.time() - t0) + " ".join("%.3f" % x for x in out["success_rate"]))
@@ -195,7 +199,7 @@ def main():
     ap.add_argument("--oracle", type=int, default=1024)
     ap.add_argument("--sweeps", type=float, default=1e5)
     ap.add_argument("--syndromes", type=int, default=32768)
-    ap.add_argument("--tag", default="r02")
+    ap.add_argument("--tag", default="r03")
     a = ap.parse_args()
     if a.steps is None:
         a.steps = 100000 if a.what == "headline" else 10000
