@@ -296,6 +296,8 @@ def main():
 
     for _ in range(args.warmup):
         sh.launch(stream); sh.gather()
+    if use_dist and args.warmup == 0:
+        sh.gather()                                             # (untimed: RCCL sets up its point-to-point channels at the first exchange)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
