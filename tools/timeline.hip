@@ -4,7 +4,15 @@
 #define QECMC_TIMELINE 1
 #include "../mcmc-qec-toric-rl_amd/csrc/capi.hip"
 #include "../mcmc-qec-toric-rl_amd/csrc/ladder_rs.hip"
+#include "../mcmc-qec-toric-rl_amd/csrc/ladder_toric.hip"
 #include "../mcmc-qec-toric-rl_amd/csrc/primitives.hip"
+namespace qecmc {   // the families this tool does not launch
+hipError_t launch_ladder_surf(const LadderArgs &, hipStream_t) { return hipErrorInvalidValue; }
+hipError_t launch_ladder_sweep(const LadderArgs &, hipStream_t) { return hipErrorInvalidValue; }
+hipError_t launch_ladder_biased(const LadderArgs &, hipStream_t) { return hipErrorInvalidValue; }
+hipError_t launch_ladder_uset(const LadderArgs &, hipStream_t) { return hipErrorInvalidValue; }
+hipError_t launch_ladder_colour(const LadderArgs &, hipStream_t) { return hipErrorInvalidValue; }
+}
 #include <map>
 #include <algorithm>
 
