@@ -16,7 +16,7 @@
 //   * top rung (slot Nc - 1, p_logical > 0; it sits at p = 0.75 where every move is accepted, mcmc.py:30): before the phase, with
 //     probability p_logical (word 0 of block (K, 0) < ceil(p_logical 2^32)) one uniformly random logical operator drawn from
 //     words 1-3 of that block exactly as scan = 1 draws it (toric_model.py:228-253 / xzzx_model.py:340-357);
-//   * generator i of the phase draws u = word (i & 3) of block (K, 8 + (i >> 2)) of the rung's stream (the slot's own for the
+//   * generator i of the phase draws u = word (K & 3) of block (K >> 2, 8 + i) of the rung's stream (the slot's own for the
 //     top rule, the diagonal stream kDiagStream + (slot + step) mod Nc otherwise, as in the other scans);
 //     a rung with f < 1 accepts iff u < ceil(f^dE 2^32) (dE <= 0: always; mcmc.py:42); a rung with f >= 1 (where a
 //     coin-less sweep would compose to the identity) applies the generator iff the top bit of u is set;
@@ -35,18 +35,19 @@ __device__ __forceinline__ int wave_sum(int v)
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
-// sum over the accepted lanes of dE in [-4, 4]: four ballots of the bits of dE + 4 and one of the accepted lanes -- scalar
-// popcounts instead of six cross-lane round trips on the step's serial path
-__device__ __forceinline__ int wave_sum_dE(bool acc, int dE)
-{
-    const uint32_t v = (uint32_t)(dE + 4);
-    int s = 0;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) s += __popcll(__ballot(acc && ((v >> b) & 1u))) << b;
-    return s - 4 * __popcll(__ballot(acc));
-}
 // CONV: the error_based convergence criterion of decoders.py:74-82,93-105 on wave 0 (one ladder per workgroup: the workgroup leaves when
 // its ladder has converged); steps_done / converged are then the criterion's, as in the other scans.
+// Diagnostic build only (tools/steptrace.hip): shader-clock stamps of workgroup 0's waves at the phase boundaries of ladder steps 2000 .. 2031
+#ifdef QECMC_STEPTRACE
+#define QECMC_CSTAMP(k)                                                                                                        \
+    do {                                                                                                                       \
+        if (a.dbg && blockIdx.x == 0 && t >= 2000 && t < 2032 && lane == 0)                                                    \
+            a.dbg[(size_t)gridDim.x * 4 + (((t - 2000) * 16 + slot) * 8 + (k))] = (k) == 5 ? (uint64_t)slot : (uint64_t)clock64(); \
+    } while (0)
+#else
+#define QECMC_CSTAMP(k) ((void)0)
+#endif
+
 template <int CODE, bool CONV>
 __global__ __launch_bounds__(1024) void ladder_colour_kernel(const LadderArgs a)
 {
@@ -143,23 +144,64 @@ __global__ __launch_bounds__(1024) void ladder_colour_kernel(const LadderArgs a)
     // offset ((slot + step) mod Nc); the generator entry of the NEXT phase is fetched while the current one is tested -- it does
     // not depend on the state -- which takes two of the three LDS round trips of a phase off the critical path
     uint32_t ph = (uint32_t)(a.prop0 % (uint64_t)P), dg = (uint32_t)(((uint64_t)slot + a.step0) % (uint64_t)NC);
-    uint2 e_next;
+    // ... and so does everything else about a phase except the four state words: word indices, bit shifts, the values to xor in, the
+    // Pauli pattern, and -- the uniform being known before dE is -- the largest dE the lane would accept (thresholds fall with dE; a rung
+    // with f >= 1 takes the coin: every dE or none).  All of it is prepared one phase ahead, in the shadow of the current phase's chain
+    // state words -> fields -> dE -> compare -> xor, which is what a lone workgroup's step time is made of.
+    struct Prepared { bool act; uint32_t wi[4], sh[4], xv[4], ops; int dmax; };
+    uint2 e_next;                                                             // the entry of the phase after the prepared one
     bool act_next;
-    {
-        const uint32_t g0 = ptab[ph * 64u + (uint32_t)lane];
-        act_next = g0 != 0xFFFFu;
-        e_next = gtab[act_next ? g0 : 0u];
-    }
+    u32x4 ub{0, 0, 0, 0};                                                     // this lane's block of uniforms (four consecutive phases)
+    auto fetch_entry = [&]() {
+        const uint32_t gn = ptab[ph * 64u + (uint32_t)lane];
+        ph = ph + 1u == P ? 0u : ph + 1u;
+        act_next = gn != 0xFFFFu;
+        e_next = gtab[act_next ? gn : 0u];
+    };
+    // prepare phase Kn of a step on stream strm_n from the entry fetched last (and fetch the one after it)
+    auto prepare = [&](uint64_t Kn, uint32_t strm_n, bool first_of_step) -> Prepared {
+        Prepared q;
+        q.act = act_next;
+        const uint2 e = e_next;                                               // 4 x (site << 2 | pauli), 0 = no site
+        fetch_entry();
+        const uint32_t ent[4] = {e.x & 0xFFFFu, e.x >> 16, e.y & 0xFFFFu, e.y >> 16};
+        q.ops = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t qb = ent[i] >> 2;
+            q.wi[i] = qb >> 4;
+            q.sh[i] = (qb & 15u) * 2u;
+            q.xv[i] = (ent[i] & 3u) << q.sh[i];
+            q.ops |= (ent[i] & 3u) << (2 * i);                                // (an unused entry reads site 0 into both and cancels)
+        }
+        // (a member's block serves four consecutive phases of a step: drawn at the step's first phase -- the stream is the step's -- and
+        // whenever the phase index enters a new group of four)
+        if (first_of_step || (Kn & 3u) == 0) ub = philox_block(Kn >> 2, 8u + (uint32_t)lane, syn, strm_n, a.seed_lo, a.seed_hi);
+        const uint32_t u = sel4(ub, (int)(Kn & 3u));
+        // mcmc.py:42 / :30 with the coin: accept iff dE <= dmax
+        q.dmax = acc_all ? ((u >> 31) != 0u ? 127 : -127) : (int)(u <= thr1) + (int)(u <= thr2) + (int)(u <= thr3) + (int)(u <= thr4);
+        return q;
+    };
+    fetch_entry();
+    Prepared nxt = prepare(a.prop0, top_logical ? slot : kDiagStream + dg, true);
     for (uint64_t t = 0; t < a.nsteps; ++t) {
+        QECMC_CSTAMP(5); QECMC_CSTAMP(0);
         uint32_t *sb = st + sid * W;
         bool recount = false;
         // the rung's Philox stream at this step: the slot's own for the top rule, the diagonal one otherwise (philox.hpp)
         const uint32_t strm = top_logical ? slot : kDiagStream + dg;
         dg = dg + 1u == (uint32_t)NC ? 0u : dg + 1u;
+        [[maybe_unused]] u32x4 topb{0, 0, 0, 0};
+        int dn = 0;                                                           // this lane's accepted dE of the step
         for (uint32_t j = 0; j < iters; ++j) {
             const uint64_t K = a.prop0 + t * iters + j;
             if (top_logical) {
-                const u32x4 x = philox_block(K, 0, syn, strm, a.seed_lo, a.seed_hi);     // (wave-uniform)
+                // the top rule's blocks (K, 0) are wave-uniform: lane l draws the one of phase j + l, 64 phases at a time, and the phase
+                // that needs it reads that lane -- one Philox evaluation per step instead of one per phase on the ladder's longest wave
+                if ((j & 63u) == 0) topb = philox_block(K + (uint64_t)lane, 0, syn, strm, a.seed_lo, a.seed_hi);
+                const int jl = (int)(j & 63u);
+                const u32x4 x{(uint32_t)__builtin_amdgcn_readlane((int)topb.x, jl), (uint32_t)__builtin_amdgcn_readlane((int)topb.y, jl),
+                              (uint32_t)__builtin_amdgcn_readlane((int)topb.z, jl), (uint32_t)__builtin_amdgcn_readlane((int)topb.w, jl)};
                 if (x.x <= thrL1) {
                     const uint32_t *m0 = lmask + L * W, *m1 = m0, *m2 = m0, *m3 = m0;    // identity rows
                     uint32_t cdelta;
@@ -184,42 +226,43 @@ __global__ __launch_bounds__(1024) void ladder_colour_kernel(const LadderArgs a)
                     recount = true;
                 }
             }
-            // ---- one phase: every lane its generator
-            const bool active = act_next;
-            const uint2 e = e_next;                                           // 4 x (site << 2 | pauli), 0 = no site
-            ph = ph + 1u == P ? 0u : ph + 1u;
+            // ---- one phase: every lane its generator (prepared during the phase before)
+            const Prepared cu = nxt;
             {
-                const uint32_t gn = ptab[ph * 64u + (uint32_t)lane];
-                act_next = gn != 0xFFFFu;
-                e_next = gtab[act_next ? gn : 0u];
+                // the next phase: of this step, or the first of the next one (whose stream is the next diagonal)
+                const bool last = j + 1u == iters;
+                nxt = prepare(K + 1u, top_logical ? slot : (last ? kDiagStream + dg : strm), last);
             }
-            const uint32_t ent[4] = {e.x & 0xFFFFu, e.x >> 16, e.y & 0xFFFFu, e.y >> 16};
             uint32_t *ad[4];
-            uint32_t sh[4], F = 0, OPS = 0;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t q = ent[i] >> 2;
-                ad[i] = sb + (q >> 4);
-                sh[i] = (q & 15u) * 2u;
-                F |= ((*ad[i] >> sh[i]) & 3u) << (2 * i);                     // (an unused entry reads site 0 into both and cancels)
-                OPS |= (ent[i] & 3u) << (2 * i);
+            for (int i = 0; i < 4; ++i) ad[i] = sb + cu.wi[i];
+            int dE = 0;
+            bool acc;
+            if (acc_all) {
+                // a rung with f >= 1 is blind: the coin decides, the state is not read, and the error count is taken again at the step's end
+                acc = cu.act && cu.dmax > 0;
+                recount = true;
+            } else {
+                uint32_t F = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) F |= ((*ad[i] >> cu.sh[i]) & 3u) << (2 * i);
+                const uint32_t G = F ^ cu.ops;
+                dE = (int)__popc((G | (G >> 1)) & 0x55u) - (int)__popc((F | (F >> 1)) & 0x55u);            // toric_model.py:275-282
+                acc = cu.act && dE <= cu.dmax;
             }
-            const uint32_t G = F ^ OPS;
-            const int dE = (int)__popc((G | (G >> 1)) & 0x55u) - (int)__popc((F | (F >> 1)) & 0x55u);      // toric_model.py:275-282
-            const u32x4 xb = philox_block(K, 8u + ((uint32_t)lane >> 2), syn, strm, a.seed_lo, a.seed_hi);
-            const uint32_t u = sel4(xb, lane & 3);
-            const uint32_t thr = dE == 1 ? thr1 : dE == 2 ? thr2 : dE == 3 ? thr3 : thr4;
-            const bool acc = active && (acc_all ? (u >> 31) != 0u : (dE <= 0 || u <= thr));   // mcmc.py:42 / :30 with the coin
             if (acc) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) lds_xor(ad[i], (ent[i] & 3u) << sh[i]);     // (same-word updates of different lanes: LDS atomics)
+                for (int i = 0; i < 4; ++i) lds_xor(ad[i], cu.xv[i]);                   // (same-word updates of different lanes: LDS atomics)
             }
-            n = (uint32_t)((int)n + wave_sum_dE(acc, dE));
+            dn += acc ? dE : 0;                                                 // (the rule never reads n inside a step: summed over the wave once, below)
         }
+        QECMC_CSTAMP(1);
         if (recount) {                                                        // the logical operators moved O(L) sites
             int c = 0;
             for (int w = lane; w < W; w += 64) c += (int)nnz2(sb[w]);
             n = (uint32_t)__builtin_amdgcn_readfirstlane(wave_sum(c));
+        } else {
+            n = (uint32_t)((int)n + __builtin_amdgcn_readfirstlane(wave_sum(dn)));
         }
         // ---- Ladder.step's swap sweep (mcmc.py:96-103): records and uniforms out, one barrier, every wave replays the cascade
         uint32_t *cur = rec + (t & 1) * NC, *sx = swu + (t & 1) * NC;
@@ -228,22 +271,42 @@ __global__ __launch_bounds__(1024) void ladder_colour_kernel(const LadderArgs a)
             const u32x4 b = philox_block(a.step0 + t, slot, syn, kSwapStream, a.seed_lo, a.seed_hi);
             if (lane < 4 && (int)slot * 4 + lane < NC - 1) sx[slot * 4 + lane] = sel4(b, lane);
         }
+        QECMC_CSTAMP(2);
         __syncthreads();
+        QECMC_CSTAMP(3);
         if constexpr (CONV) { if (stopf[t & 1]) break; }                                 // (set by wave 0 one step earlier: uniform for the workgroup)
-        uint32_t car = cur[NC - 1], mine = car;
-        for (int i = NC - 2; i >= 0; --i) {
-            const uint32_t lo = cur[i], xi = sx[i];
-            const int d = (int)(car & 0xFFFFu) - (int)(lo & 0xFFFFu);                  // ne_hi - ne_lo, _r_flip mcmc.py:146-149
-            const int e = i * (nq + 1) + (d > 0 ? d : 0);
+        // The cascade (mcmc.py:96-99) carries one record down the rungs: which one depends on every decision above.  Its decisions do
+        // not: the record carried into rung pair i is one of those of slots i+1 .. NC-1, so lane (c, i) tests "record c against slot i" for
+        // every pair at once (one threshold look-up each, NC^2 <= 256 tests in at most four passes) and the serial part walks a bit table
+        // with scalar instructions -- a lone workgroup has nobody to hide seven dependent look-ups behind.
+        uint64_t fm[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            const int c0 = ch * 64;
+            if (c0 >= NC * NC) break;
+            const int c = c0 + lane, ca = c / NC, ci = c - ca * NC;
+            const bool valid = ca < NC && ci < NC - 1 && ca > ci;
+            const uint32_t hi = cur[valid ? ca : 0], lo = cur[valid ? ci : 0], xi = sx[valid ? ci : 0];
+            const int d = (int)(hi & 0xFFFFu) - (int)(lo & 0xFFFFu);                   // ne_hi - ne_lo, _r_flip mcmc.py:146-149
+            const int e = (valid ? ci : 0) * (nq + 1) + (d > 0 ? d : 0);
             const bool flip = d <= 0 || (swap32 ? xi < swt[e] : (uint64_t)xi < (((uint64_t)swt[2 * e + 1] << 32) | swt[2 * e]));
-            const uint32_t into = flip ? lo : car;
-            car = flip ? car : lo;
-            if ((int)slot == i + 1) mine = into;
+            fm[ch] = __ballot(valid && flip);
         }
-        if (slot == 0) mine = car;
+        int carried = NC - 1, mine_s = NC - 1;                                         // slots whose step-t records are carried / end up here
+        for (int i = NC - 2; i >= 0; --i) {
+            const int b = carried * NC + i;
+            const uint64_t w = b < 64 ? fm[0] : b < 128 ? fm[1] : b < 192 ? fm[2] : fm[3];
+            const bool flip = (w >> (b & 63)) & 1ull;
+            const int into = flip ? i : carried;                                       // what slot i+1 now holds (:98-99)
+            carried = flip ? carried : i;
+            if ((int)slot == i + 1) mine_s = into;
+        }
+        if (slot == 0) mine_s = carried;
+        uint32_t mine = cur[mine_s];
         mine = (uint32_t)__builtin_amdgcn_readfirstlane((int)mine);
         n = mine & 0xFFFFu; sid = (mine >> 16) & 0xFFu; cls = (mine >> 24) & 0x3Fu; flag = mine >> 31;
         if ((int)slot == NC - 1) flag = 1;                                               // mcmc.py:100
+        QECMC_CSTAMP(4);
         if (slot == 0 && !done) {
             tops0 += (NC == 1) | flag;                                                   // :101-102
             if (a.counts != nullptr && tops0 >= a.tops_burn) {                           // decoders.py:60-67

@@ -520,7 +520,8 @@ int orc_colour_phases(int code, int L, int *tab_out, int cap)
 /* Colour-parallel Metropolis (scan = 2; `iters` counts phases, k = phase index of the chain).  Top chain with logical moves (it
  * must accept every move, p >= 0.75): before the phase, with probability p_logical (word 0 of block (k, 0)), one uniformly random
  * logical operator drawn from words 1-3 of that block as in the other scans.  Then every generator of phase k mod P, member i
- * drawing u = word i & 3 of block (k, 8 + (i >> 2)): a chain with f < 1 accepts iff u < f^dE (mcmc.py:42); a chain with f >= 1 --
+ * drawing u = word k & 3 of block (k >> 2, 8 + i) -- a member's block serves four consecutive phases --: a chain with f < 1 accepts iff
+ * u < f^dE (mcmc.py:42); a chain with f >= 1 --
  * where a coin-less sweep would compose to the identity -- applies the generator iff u >= 1/2. */
 static void chain_update_colour(const orc_model *m, uint8_t *state, double p, double p_logical, uint64_t iters,
                                 orc_rng *rng, uint32_t slot, uint64_t k0, uint8_t *scratch)
@@ -539,7 +540,7 @@ static void chain_update_colour(const orc_model *m, uint8_t *state, double p, do
         for (int i = 0; i < 64; ++i) {
             if (members[i] < 0) continue;
             const int dE = model_sweep_stabilizer(m, state, scratch, (uint64_t)members[i]);
-            const double u = orc_draw(rng, slot, k, 8u + (uint32_t)(i >> 2), i & 3);
+            const double u = orc_draw(rng, slot, k >> 2, 8u + (uint32_t)i, (int)(k & 3));
             const int acc = factor >= 1.0 ? u >= 0.5 : (dE <= 0 || u < pow(factor, (double)dE));
             if (acc) memcpy(state, scratch, nq);
         }

@@ -3,17 +3,18 @@
 // 2000 .. 2031 (step begin | proposals done | records and swap bounds published | past the barrier | cascade done).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/steptrace tools/steptrace.hip
 //   tools/steptrace toric 15 0.18 8 131072        (config 3)        tools/steptrace rotated 21 0.17 8 32768   (config 5)
+//   tools/steptrace toric 9 0.15 8 1 10 colour    (the colour-parallel layout, one ladder: waves do not rotate, slot = wave)
 #define QECMC_STEPTRACE 1
 #include "../mcmc-qec-toric-rl_amd/csrc/capi.hip"
 #include "../mcmc-qec-toric-rl_amd/csrc/ladder_rs.hip"
 #include "../mcmc-qec-toric-rl_amd/csrc/ladder_toric.hip"
 #include "../mcmc-qec-toric-rl_amd/csrc/ladder_surf.hip"
+#include "../mcmc-qec-toric-rl_amd/csrc/ladder_colour.hip"
 #include "../mcmc-qec-toric-rl_amd/csrc/primitives.hip"
 namespace qecmc {   // the families this tool does not trace
 hipError_t launch_ladder_sweep(const LadderArgs &, hipStream_t) { return hipErrorInvalidValue; }
 hipError_t launch_ladder_biased(const LadderArgs &, hipStream_t) { return hipErrorInvalidValue; }
 hipError_t launch_ladder_uset(const LadderArgs &, hipStream_t) { return hipErrorInvalidValue; }
-hipError_t launch_ladder_colour(const LadderArgs &, hipStream_t) { return hipErrorInvalidValue; }
 }
 #include <algorithm>
 
@@ -29,6 +30,7 @@ int main(int argc, char **argv)
     qecmc_params p; memset(&p, 0, sizeof p);
     p.abi_size = sizeof p; p.code = code; p.L = L; p.Nc = Nc; p.p = perr; p.p_logical = 0.5; p.iters = argc > 6 ? atoi(argv[6]) : 10;
     p.steps = steps; p.tops_burn = 2; p.seed = 1;
+    if (argc > 7 && !strcmp(argv[7], "colour")) p.scan = QECMC_SCAN_COLOUR;
     qecmc_plan *pl = nullptr;
     if (qecmc_plan_create(&p, &pl)) { printf("plan: %s\n", qecmc_last_error()); return 1; }
     const size_t nq = pl->args.nq;
