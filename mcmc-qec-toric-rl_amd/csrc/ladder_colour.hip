@@ -280,6 +280,7 @@ __global__ __launch_bounds__(1024) void ladder_colour_kernel(const LadderArgs a)
         // every pair at once (one threshold look-up each, NC^2 <= 256 tests in at most four passes) and the serial part walks a bit table
         // with scalar instructions -- a lone workgroup has nobody to hide seven dependent look-ups behind.
         uint64_t fm[4] = {0, 0, 0, 0};
+        const uint32_t rec_l = cur[lane < NC ? lane : 0];                              // lane l: slot l's record (read back by the walk's result)
 #pragma unroll
         for (int ch = 0; ch < 4; ++ch) {
             const int c0 = ch * 64;
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(1024) void ladder_colour_kernel(const LadderArgs a)
             if ((int)slot == i + 1) mine_s = into;
         }
         if (slot == 0) mine_s = carried;
-        uint32_t mine = cur[mine_s];
+        uint32_t mine = (uint32_t)__builtin_amdgcn_readlane((int)rec_l, mine_s);
         mine = (uint32_t)__builtin_amdgcn_readfirstlane((int)mine);
         n = mine & 0xFFFFu; sid = (mine >> 16) & 0xFFu; cls = (mine >> 24) & 0x3Fu; flag = mine >> 31;
         if ((int)slot == NC - 1) flag = 1;                                               // mcmc.py:100
