@@ -151,12 +151,10 @@ def cpu_model():
 
 def oracle_batch(args, init, steps, n_threads, first=0, states=False):
     from oracle import oracle as orc
-    if args.code == "toric":
-        return orc.toric_pteq_batch(init, args.p, args.Nc, steps, iters=args.iters, tops_burn=2, seed=args.seed,
-                                    first_syndrome=first, n_threads=n_threads, return_states=states)
-    code = {"xzzx": orc.XZZX, "rotated": orc.ROTATED, "planar": orc.PLANAR}[args.code]
+    code = {"toric": orc.TORIC, "xzzx": orc.XZZX, "rotated": orc.ROTATED, "planar": orc.PLANAR}[args.code]
     return orc.pteq_batch(code, init, args.p, args.Nc, steps, iters=args.iters, tops_burn=2, seed=args.seed, first_syndrome=first,
-                          n_threads=n_threads, noise=orc.DEPOLARIZING if args.eta is None else orc.BIASED, eta=args.eta or 0.0, return_states=states)
+                          n_threads=n_threads, noise=orc.DEPOLARIZING if args.eta is None else orc.BIASED, eta=args.eta or 0.0, return_states=states,
+                          scan=3 if args.scan == "wave" else 0)
 
 
 def cpu_baseline(args, init, n_gen, target_s=12.0):
@@ -205,8 +203,9 @@ def parse_args(argv=None):
     ap.add_argument("--p-logical", type=float, default=0.5, help="top-chain logical rate (decoders.py:52 uses 0.5)")
     ap.add_argument("--code", default=None, choices=["toric", "xzzx", "rotated", "planar"])
     ap.add_argument("--eta", type=float, default=None, help="bias: selects the mcmc_biased chain (config 4)")
-    ap.add_argument("--scan", default="random", choices=["random", "sweep"],
-                    help="random = the reference's random-scan chain; sweep = systematic generator sweep (scan=1)")
+    ap.add_argument("--scan", default="random", choices=["random", "sweep", "wave"],
+                    help="random = the reference's random-scan chain; wave = the same chain per syndrome with a generator pick shared by the 64 "
+                         "ladders of a wavefront (scan=3); sweep = systematic generator sweep (scan=1: not the reference's chain)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--library", default=None, help="time another build of libqecmc.so (same ABI) instead of the in-tree one: A/B runs on one box")
     ap.add_argument("--flags", type=lambda v: int(v, 0), default=0, help="qecmc_params.flags: developer switches between equivalent kernel variants (include/qecmc.h)")
@@ -248,7 +247,7 @@ def main():
     proposals_per_pass = N * Nc * args.iters * args.ladder_steps      # per GPU
     workload = ("%s; %s L=%d p=%g%s, %d syndromes per GPU, Nc=%d parallel tempering, iters=%d, %d ladder steps per pass, scan=%s"
                 % (CONFIGS[args.config]["name"], args.code, L, args.p, "" if args.eta is None else " eta=%g" % args.eta, N, Nc,
-                   args.iters, args.ladder_steps, "random (the reference's chain)" if args.scan == "random" else "sweep"))
+                   args.iters, args.ladder_steps, {"random": "random (the reference's chain)", "wave": "wave (the reference's chain per syndrome; one generator pick per wavefront)", "sweep": "sweep"}[args.scan]))
 
     if args.dry_run:
         # launcher + exchange rehearsal (CPU, gloo): every rank fills its records with a rank-dependent pattern, rank 0 checks
@@ -289,7 +288,7 @@ def main():
     sh = PteqShard(init_h, args.p, first, n_total=N * world, code=code_id, Nc=Nc, p_logical=args.p_logical, iters=args.iters,
                    steps=args.ladder_steps, tops_burn=2, seed=args.seed,
                    noise=L_.NOISE_DEPOLARIZING if args.eta is None else L_.NOISE_BIASED, eta=args.eta or 0.0,
-                   scan=L_.SCAN_RANDOM if args.scan == "random" else L_.SCAN_SWEEP, flags=args.flags)
+                   scan=L_.SCANS[args.scan], flags=args.flags)
     lds, threads, spb = C.c_uint32(), C.c_uint32(), C.c_uint32()
     L_.check(L_.lib().qecmc_plan_info(sh.plan, lds, threads, spb))
     stream = torch.cuda.current_stream()
@@ -377,7 +376,7 @@ def main():
             "mixing": {"frac_syndromes_past_burn_in": float(np.mean(samples > 0)),
                        "mean_tops0": float(np.mean(tops0)), "frac_tops0_ge_10": float(np.mean(tops0 >= 10))},
         }
-        if world == 1 and not args.no_cpu_baseline and args.scan == "random":
+        if world == 1 and not args.no_cpu_baseline and args.scan in ("random", "wave"):
             out["cpu_baseline"] = cpu_baseline(args, init_h, n_gen)
             if args.p_logical == 0.5:
                 # the metric's "eq-class histogram match": the oracle (the checker, on the same Philox streams) must give the
@@ -393,7 +392,7 @@ def main():
                 # pass of the same ladders through the host-pointer entry point -- every rung's final configuration
                 import qecmc
                 again = qecmc.pteq_batch(init_h[:n_chk], args.p, Nc=Nc, steps=args.ladder_steps, iters=args.iters, tops_burn=2, seed=args.seed,
-                                         first_syndrome=first, code=code_id, eta=args.eta, return_states=True, flags=args.flags)
+                                         first_syndrome=first, code=code_id, eta=args.eta, return_states=True, flags=args.flags, scan=args.scan)
                 out["histogram_match"] = {"syndromes_checked": n_chk, "ladder_steps": args.ladder_steps,
                                           "syndromes_with_samples": with_samples,
                                           # (null: no ladder of the sample got past the burn-in, the counts are all zero on both sides)

@@ -52,7 +52,13 @@ typedef enum qecmc_code { QECMC_TORIC = 0, QECMC_XZZX = 1, QECMC_ROTATED = 2, QE
  * passes instead of G sequential proposals.  A systematic scan like SWEEP (same stationary law, not the reference's chain);
  * depolarizing rule; `iters` counts phases; fixed-length runs report the first step with tops0 >= TOPS in steps_done / converged,
  * conv_mode error_based runs the reference's criterion. */
-typedef enum qecmc_scan { QECMC_SCAN_RANDOM = 0, QECMC_SCAN_SWEEP = 1, QECMC_SCAN_COLOUR = 2 } qecmc_scan;
+/* WAVE: the reference's random scan (src/mcmc.py:19-43) with ONE generator pick per proposal shared by the 64 ladders of a wavefront
+ * (global ladder indices that agree above bit 6), every ladder keeping its own acceptance uniform.  toric_model.py:287-296 picks the
+ * generator independently of the state and syndromes never interact, so each ladder's chain has exactly the reference's law -- unlike
+ * SWEEP / COLOUR this IS the reference's Markov chain per syndrome; only the noise of different syndromes is correlated.  What it buys:
+ * a proposal's sites are wave-uniform, so the rungs' states live in registers.  Depolarizing rule, a top rung at
+ * p = 0.75 (Nc >= 2), first_syndrome a multiple of 64, toric L <= 16 / xzzx, rotated L <= 22. */
+typedef enum qecmc_scan { QECMC_SCAN_RANDOM = 0, QECMC_SCAN_SWEEP = 1, QECMC_SCAN_COLOUR = 2, QECMC_SCAN_WAVE = 3 } qecmc_scan;
 typedef enum qecmc_noise { QECMC_NOISE_DEPOLARIZING = 0, QECMC_NOISE_BIASED = 1, QECMC_NOISE_ALPHA = 2 } qecmc_noise;
 typedef enum qecmc_conv { QECMC_CONV_NONE = 0, QECMC_CONV_ERROR_BASED = 1 } qecmc_conv;
 

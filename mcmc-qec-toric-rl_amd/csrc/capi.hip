@@ -127,7 +127,7 @@ inline size_t code_nq(int code, int L) { return (size_t)code_nq_of(code, L); }
 struct qecmc_plan {
     qecmc_params prm;
     LadderArgs args;
-    DevBuf swap_thr, lmask, acc_top, gen, bias, lnb, xyz_lut, gen_type, queue, phases;
+    DevBuf swap_thr, lmask, acc_top, gen, bias, lnb, xyz_lut, gen_type, queue, phases, wu_desc;
     uint32_t queue_grid = 0;                                   // persistent grid of the work-queue kernels (0: not a queue plan)
     size_t lds_bytes;
     uint32_t *d_swap_acc = nullptr, *d_nerr_sum = nullptr;   // qecmc_plan_set_stats (caller-owned)
@@ -154,8 +154,12 @@ int validate_params(const qecmc_params *p)
         if (p->code == QECMC_TORIC || p->code == QECMC_PLANAR) return fail(QECMC_ERR_UNSUPPORTED, "biased noise is built for the xzzx and rotated codes (BASELINE config 4)");
     } else if (!(p->p > 0.0) || !(p->p <= 0.75)) return fail(QECMC_ERR_INVALID, "p=%g must be in (0, 0.75]", p->p);
     if (!(p->p_logical >= 0.0) || !(p->p_logical <= 1.0)) return fail(QECMC_ERR_INVALID, "p_logical=%g must be in [0,1]", p->p_logical);
-    if (p->scan != QECMC_SCAN_RANDOM && p->scan != QECMC_SCAN_SWEEP && p->scan != QECMC_SCAN_COLOUR) return fail(QECMC_ERR_INVALID, "scan mode %d unknown", p->scan);
-    if (p->scan != QECMC_SCAN_RANDOM && p->noise != QECMC_NOISE_DEPOLARIZING) return fail(QECMC_ERR_UNSUPPORTED, "the systematic scans (sweep, colour) are built for the depolarizing rule only");
+    if (p->scan != QECMC_SCAN_RANDOM && p->scan != QECMC_SCAN_SWEEP && p->scan != QECMC_SCAN_COLOUR && p->scan != QECMC_SCAN_WAVE) return fail(QECMC_ERR_INVALID, "scan mode %d unknown", p->scan);
+    if (p->scan != QECMC_SCAN_RANDOM && p->noise != QECMC_NOISE_DEPOLARIZING) return fail(QECMC_ERR_UNSUPPORTED, "the sweep, colour and wave scans are built for the depolarizing rule only");
+    if (p->scan == QECMC_SCAN_WAVE) {
+        if (p->Nc < 2) return fail(QECMC_ERR_UNSUPPORTED, "scan = wave needs a ladder whose top rung sits at p = 0.75 (Nc >= 2)");
+        if (p->first_syndrome & 63u) return fail(QECMC_ERR_INVALID, "scan = wave shares a generator pick among the 64 ladders of a wavefront: first_syndrome=%u must be a multiple of 64", p->first_syndrome);
+    }
     if (p->scan == QECMC_SCAN_COLOUR) {
         if (p->p_logical > 0.0 && p->Nc < 2) return fail(QECMC_ERR_UNSUPPORTED, "scan = colour needs the top rung at p = 0.75 (Nc >= 2) when logical moves are on");
     }
@@ -208,6 +212,7 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
         xyz_lut = count_change_table(patterns);
     }
     pl->lds_bytes = p->scan == QECMC_SCAN_COLOUR ? sizeof(uint32_t) * ((size_t)Nc * W + 4 * (size_t)Nc + (size_t)ncls)   // (ladder_colour.hip: one ladder per workgroup)
+                  : p->scan == QECMC_SCAN_WAVE ? wu_lds_bytes(Nc, W, ncls, L)
                                                  : ladder_lds_bytes(L, Nc, W, ncls, ladder_gen_dwords(p->code, p->noise, p->scan, n_gen, Nc, nq, a.n_types));
     if (pl->lds_bytes > 160 * 1024)
         return fail(QECMC_ERR_UNSUPPORTED, "L=%d Nc=%d needs %zu B of LDS per workgroup (> 160 KiB)", L, Nc, pl->lds_bytes);
@@ -237,6 +242,7 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
         for (int d = 1; d <= 4; ++d) {
             a.acc_thr[c][d - 1] = thr32(std::pow(f, (double)d));                     // mcmc.py:42
             a.acc_thr44[c][d - 1] = thr44(std::pow(f, (double)d));
+            a.acc_thr48[c][d - 1] = thr48(std::pow(f, (double)d));
         }
     }
     std::vector<uint32_t> top_tbl(nq + 1, 0u);                             // mcmc.py:34 for a top chain below p = 0.75
@@ -264,6 +270,18 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
             return fail(QECMC_ERR_UNSUPPORTED, "scan = colour: L=%d Nc=%d needs %zu B of LDS per workgroup (> 160 KiB)", L, Nc, pl->lds_bytes);
         if (p->p_logical > 0.0 && !((a.acc_all_mask >> (Nc - 1)) & 1u))
             return fail(QECMC_ERR_UNSUPPORTED, "scan = colour needs a top rung that accepts every move (p_top = 0.75) when logical moves are on");
+    }
+    if (p->scan == QECMC_SCAN_WAVE) {
+        // the wave-uniform random scan (ladder_wu.hpp): one scalar-loadable descriptor per generator; states in registers
+        const std::vector<uint32_t> wd = wave_descriptors(gt);
+        a.n_gen = (uint32_t)(gt.size() / 2);
+        pl->lds_bytes = wu_lds_bytes(Nc, W, ncls, L);
+        if (wd.empty() || !wu_supported(a) || pl->lds_bytes > 160 * 1024)
+            return fail(QECMC_ERR_UNSUPPORTED, "scan = wave: L=%d Nc=%d p=%g is outside what it is built for (a top rung that accepts every move, at most "
+                        "32 packed state words per rung -- toric L <= 16, xzzx / rotated L <= 22 --, %zu B of LDS)", L, Nc, p->p, pl->lds_bytes);
+        HIP_TRY(pl->wu_desc.alloc(wd.size() * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpy(pl->wu_desc.p, wd.data(), wd.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        a.wu_desc = pl->wu_desc.as<uint32_t>();
     }
     {
         a.n_gen = (uint32_t)(gt.size() / 2);
@@ -716,6 +734,8 @@ int qecmc_pteq_launch_dev(qecmc_plan *plan, const void *d_init, uint64_t N, uint
     if (!d_init || !d_counts || !d_samples) return fail(QECMC_ERR_INVALID, "NULL device buffer");
     const uint64_t R = plan->args.replicas, M = N * R;              // ladders
     if (M + first_syndrome > 0xFFFFFFFFull) return fail(QECMC_ERR_INVALID, "global ladder index (first_syndrome + N * replicas) exceeds 32 bits");
+    if (plan->args.scan == QECMC_SCAN_WAVE && (first_syndrome & 63u))
+        return fail(QECMC_ERR_INVALID, "scan = wave: first_syndrome=%u must be a multiple of 64 (a wavefront shares its generator picks)", first_syndrome);
     if (plan->prm.conv_mode == QECMC_CONV_ERROR_BASED && !d_workspace)
         return fail(QECMC_ERR_INVALID, "conv_mode error_based needs the workspace of qecmc_plan_workspace_bytes()");
     if (R > 1 && (plan->d_swap_acc || plan->d_nerr_sum)) return fail(QECMC_ERR_INVALID, "qecmc_plan_set_stats is per ladder: not with replicas > 1");
@@ -759,7 +779,7 @@ int qecmc_plan_set_stats(qecmc_plan *plan, void *d_swap_accepts, void *d_nerr_su
     if (!plan) return fail(QECMC_ERR_INVALID, "plan is NULL");
     if (d_nerr_sums && !d_swap_accepts) return fail(QECMC_ERR_INVALID, "d_nerr_sums needs d_swap_accepts");
     if (d_swap_accepts && plan->args.Nc < 2) return fail(QECMC_ERR_INVALID, "swap statistics need Nc >= 2");
-    if (d_swap_accepts && plan->args.scan == QECMC_SCAN_COLOUR) return fail(QECMC_ERR_UNSUPPORTED, "swap statistics are not collected by the scan = colour kernel");
+    if (d_swap_accepts && (plan->args.scan == QECMC_SCAN_COLOUR || plan->args.scan == QECMC_SCAN_WAVE)) return fail(QECMC_ERR_UNSUPPORTED, "swap statistics are not collected by the scan = colour / wave kernels");
     if (d_swap_accepts && plan->lds_bytes + ladder_stats_lds_bytes(plan->args.Nc) > 160 * 1024)
         return fail(QECMC_ERR_UNSUPPORTED, "no LDS left for the statistics counters at this L / Nc");
     plan->d_swap_acc = static_cast<uint32_t *>(d_swap_accepts);
@@ -779,6 +799,8 @@ int qecmc_pteq_resume_dev(qecmc_plan *plan, void *d_states, void *d_flags, void 
     if (plan->args.noise == QECMC_NOISE_ALPHA) return fail(QECMC_ERR_UNSUPPORTED, "alpha-noise ladders carry n_eff: continue them with qecmc_ladder_step_alpha");
     if (plan->args.scan == QECMC_SCAN_COLOUR) return fail(QECMC_ERR_UNSUPPORTED, "scan = colour starts its ladders from seed configurations: no chunked continuation");
     if (N + first_syndrome > 0xFFFFFFFFull) return fail(QECMC_ERR_INVALID, "global syndrome index exceeds 32 bits");
+    if (plan->args.scan == QECMC_SCAN_WAVE && (first_syndrome & 63u))
+        return fail(QECMC_ERR_INVALID, "scan = wave: first_syndrome=%u must be a multiple of 64 (a wavefront shares its generator picks)", first_syndrome);
     LadderArgs a = plan->args;
     a.states = static_cast<uint8_t *>(d_states); a.flags = static_cast<uint8_t *>(d_flags); a.tops0 = static_cast<uint32_t *>(d_tops0);
     a.counts = static_cast<uint32_t *>(d_counts); a.samples = static_cast<uint32_t *>(d_samples);

@@ -2053,5 +2053,6 @@ hipError_t launch_ladder_surf(const LadderArgs &a, hipStream_t stream);       //
 hipError_t launch_ladder_biased(const LadderArgs &a, hipStream_t stream);     // ladder_biased.hip: biased and alpha rules
 hipError_t launch_ladder_uset(const LadderArgs &a, hipStream_t stream);       // ladder_uset.hip: the unique-chain estimators' set insertion
 hipError_t launch_ladder_colour(const LadderArgs &a, hipStream_t stream);     // ladder_colour.hip: scan = 2, one workgroup per ladder, colour-parallel phases
+hipError_t launch_ladder_wu(const LadderArgs &a, hipStream_t stream);         // ladder_wu.hip: scan = 3, wave-uniform generator picks, states in registers
 
 }  // namespace qecmc

@@ -16,6 +16,7 @@ hipError_t launch_ladder_rs_toric(const LadderArgs &a, hipStream_t stream)
     // One 64-syndrome group (Nc waves) per workgroup.  (Two groups per workgroup, sharing only the barrier, paid off while a
     // one-round grid ended in a long tail; with the current proposal loop the 8-wave workgroups are faster at every batch
     // size: +1.6 % at 65 536 syndromes, +5 % at 262 144.)
+    if (a.scan == 3) return launch_ladder_wu(a, stream);
     if (a.scan == 2) return a.uset_tab != nullptr ? hipErrorInvalidValue : launch_ladder_colour(a, stream);
     if (a.uset_tab != nullptr) return launch_ladder_uset(a, stream);
     if (a.noise) return a.scan ? hipErrorInvalidValue : launch_ladder_biased(a, stream);   // the sweep is built for the depolarizing rule only

@@ -61,6 +61,13 @@ inline uint64_t thr44(double v)
     if (!(v > 0.0)) return 0;
     return (uint64_t)std::ceil(v * 17592186044416.0);
 }
+// ceil(v * 2^48): scan = 3's acceptance uniform (16 bits, completed by a 32-bit word when they tie with the threshold's)
+inline uint64_t thr48(double v)
+{
+    if (!(v < 1.0)) return 1ull << 48;
+    if (!(v > 0.0)) return 0;
+    return (uint64_t)std::ceil(v * 281474976710656.0);
+}
 inline uint32_t thr32(double v)
 {
     const uint64_t t = thr64(v);
@@ -196,6 +203,51 @@ inline std::vector<uint64_t> swap_thresholds(const std::vector<double> &pdiff, i
     for (size_t i = 0; i < pdiff.size(); ++i)
         for (int d = 0; d <= nq; ++d) sw[i * (size_t)(nq + 1) + d] = thr64(std::pow(pdiff[i], (double)d));
     return sw;
+}
+
+// scan = 3 (QECMC_SCAN_WAVE, ladder_wu.hpp): one 48-byte descriptor per generator, read with scalar loads by a wavefront whose
+// 64 ladders test that generator together.  dwords 0-3: site i as (state word) | (bit shift) << 8; 4-7: the value to xor into
+// that word (Pauli << shift; a site that does not exist: 0, on word 0); 8, 9: the error-count change of a site as a 4-entry byte
+// table indexed by its old 2-bit field, 4 (1 + change) -- 8 for an identity, 0 for the generator's own Pauli, else 4 -- for the
+// generator's first Pauli (dword 8) and its second one, if any (dword 9); 10, 11: per site the byte or-ed into / and-ed with the old
+// field to form the table index (4: second table; a missing site: index of a "no change" entry, field masked away).
+// Empty if some generator carries three different Paulis (none of the four code models does).
+inline std::vector<uint32_t> wave_descriptors(const std::vector<uint32_t> &gt)
+{
+    const size_t G = gt.size() / 2;
+    std::vector<uint32_t> d(12 * G, 0u);
+    auto table = [](uint32_t P) { uint32_t t = 0; for (uint32_t f = 0; f < 4; ++f) t |= (f == 0 ? 8u : f == P ? 0u : 4u) << (8 * f); return t; };
+    for (size_t g = 0; g < G; ++g) {
+        uint32_t pa = 0, pb = 0;
+        uint32_t e[4];
+        for (int u = 0; u < 4; ++u) {
+            e[u] = (u < 2 ? gt[2 * g] >> (16 * u) : gt[2 * g + 1] >> (16 * (u - 2))) & 0xFFFFu;
+            const uint32_t P = e[u] & 3u;
+            if (!P) continue;
+            if (!pa || pa == P) pa = P;
+            else if (!pb || pb == P) pb = P;
+            else return {};
+        }
+        if (!pa) return {};
+        const uint32_t neutral = pa == 1u ? 2u : 1u;            // a field value that is neither the identity nor Pauli pa: table entry 4
+        uint32_t omask = 0, amask = 0;
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t P = e[u] & 3u, q = e[u] >> 2;
+            if (P) {
+                d[12 * g + u] = (q >> 4) | (((q & 15u) * 2u) << 8);
+                d[12 * g + 4 + u] = P << ((q & 15u) * 2u);
+                amask |= 3u << (8 * u);
+                if (P != pa) omask |= 4u << (8 * u);
+            } else {
+                omask |= neutral << (8 * u);
+            }
+        }
+        d[12 * g + 8] = table(pa);
+        d[12 * g + 9] = pb ? table(pb) : table(pa);
+        d[12 * g + 10] = omask;
+        d[12 * g + 11] = amask;
+    }
+    return d;
 }
 
 // scan = 2 (QECMC_SCAN_COLOUR): the generators cut into PHASES of mutually disjoint generators (no shared qubit), which one

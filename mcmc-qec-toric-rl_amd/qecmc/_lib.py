@@ -28,8 +28,8 @@ def use_library(path):
     LIB_PATH = os.path.abspath(path)
 
 TORIC, XZZX, ROTATED, PLANAR = 0, 1, 2, 3
-SCAN_RANDOM, SCAN_SWEEP, SCAN_COLOUR = 0, 1, 2
-SCANS = {"random": SCAN_RANDOM, "sweep": SCAN_SWEEP, "colour": SCAN_COLOUR}
+SCAN_RANDOM, SCAN_SWEEP, SCAN_COLOUR, SCAN_WAVE = 0, 1, 2, 3
+SCANS = {"random": SCAN_RANDOM, "sweep": SCAN_SWEEP, "colour": SCAN_COLOUR, "wave": SCAN_WAVE}
 NOISE_DEPOLARIZING, NOISE_BIASED, NOISE_ALPHA = 0, 1, 2
 CONV_NONE, CONV_ERROR_BASED = 0, 1
 PTDC_INIT_PER_DROPLET, PTDC_SET_PER_RUNG = 1, 2

@@ -547,6 +547,81 @@ static void chain_update_colour(const orc_model *m, uint8_t *state, double p, do
     }
 }
 
+/* scan = 3 ("wave"): the reference's random-scan chain (mcmc.py:19-43) with a generator pick SHARED by the 64 ladders whose global
+ * indices agree above bit 6 (a GPU wavefront): the pick does not depend on the state (toric_model.py:287-296) and ladders of different
+ * syndromes never interact, so every ladder keeps exactly the reference's law; only the noise of different syndromes is correlated.
+ * Philox addressing, slot c, proposal k (the ladder's streams are its slots': no diagonal streams here):
+ *   pick    words A, B = 2 (k & 1), 2 (k & 1) + 1 of block (k >> 1, sub 9) with ctr[2] = syndrome >> 6, stream 0x800 + c:
+ *           g = floor(B G / 2^32).  Top chain (p_logical != 0; it must accept every move, p >= 0.75): logical iff
+ *           A[31:16] < p_logical 2^16, the operator's fields cut from A[15:0] and B as in the packed layout of scan = 0;
+ *   accept  a16 = half (k & 1) (low half first) of word (k & 7) >> 1 of block (k >> 3, sub 10) of the ladder's own index, stream c;
+ *           w32 = word k & 3 of block (k >> 2, sub 11); u = (a16 2^32 + w32) 2^-48 < f^dE (mcmc.py:42). */
+static void wave_block(const orc_rng *rng, uint32_t synd_word, uint32_t stream, uint64_t k, uint32_t sub, uint32_t out[4])
+{
+    const uint32_t ctr[4] = {(uint32_t)k, (uint32_t)((k >> 32) & 0xFFFFu) | (sub << 16), synd_word, stream};
+    const uint32_t key[2] = {(uint32_t)rng->seed, (uint32_t)(rng->seed >> 32)};
+    orc_philox4x32_10(ctr, key, out);
+}
+
+/* _apply_random_logical (toric_model.py:228-253, xzzx_model.py:340-357) from the two words of a packed top-chain proposal */
+static int logical_from_words(const orc_model *m, const uint8_t *in, uint8_t *out, uint32_t A, uint32_t B)
+{
+    const int L = m->L;
+#define FLD(word, shl, nbits) ((uint32_t)((word) << (shl)) >> (32 - (nbits)))
+    if (m->code == ORC_TORIC) {
+        /* A = select[31:16] | op0[15:14] | op1[13:12] | X_pos0[11:0];  B = Z_pos0[31:21] | X_pos1[20:10] | Z_pos1[9:0] */
+        const int ops[2] = {(int)FLD(A, 16, 2), (int)FLD(A, 18, 2)};
+        int dE = 0;
+        if (out != in) memcpy(out, in, (size_t)2 * L * L);
+        for (int layer = 0; layer < 2; ++layer) {
+            const int op = ops[layer];
+            int xpos = 0, zpos = 0;
+            if (op == 1 || op == 2) xpos = layer == 0 ? (int)((FLD(A, 20, 12) * (uint32_t)L) >> 12) : (int)((FLD(B, 11, 11) * (uint32_t)L) >> 11);
+            if (op == 3 || op == 2) zpos = layer == 0 ? (int)((FLD(B, 0, 11) * (uint32_t)L) >> 11) : (int)((FLD(B, 22, 10) * (uint32_t)L) >> 10);
+            dE += orc_toric_apply_logical(L, out, out, op, layer, xpos, zpos);
+        }
+        return dE;
+    }
+    /* plaquette codes: A = select[31:16] | op[15:14] | X_pos[13:0], Z_pos = B[31:16] */
+    const int op = (int)FLD(A, 16, 2);
+    int xpos = 0, zpos = 0;
+    if (op == 1 || op == 2) xpos = (int)((FLD(A, 18, 14) * (uint32_t)L) >> 14);
+    if (op == 3 || op == 2) zpos = (int)((FLD(B, 0, 16) * (uint32_t)L) >> 16);
+#undef FLD
+    return orc_surf_apply_logical(m->code, L, in, out, op, xpos, zpos);
+}
+
+static void chain_update_wave(const orc_model *m, uint8_t *state, double p, double p_logical, uint64_t iters,
+                              orc_rng *rng, uint32_t slot, uint64_t k0, uint8_t *scratch)
+{
+    const size_t nq = (size_t)orc_nq(m->code, m->L);
+    const double factor = (p / 3.0) / (1.0 - p);
+    const int G = m->code == ORC_TORIC ? 2 * m->L * m->L : orc_surf_ngen(m->code, m->L);
+    if (rng->mode == 0) abort();                       /* a Philox-mode rule */
+    if (p_logical != 0 && !(p >= 0.75)) abort();       /* the top chain of scan = 3 accepts every move */
+    for (uint64_t j = 0; j < iters; ++j) {
+        const uint64_t k = k0 + j;
+        uint32_t pw[4];
+        wave_block(rng, rng->syndrome >> 6, 0x800u + slot, k >> 1, 9u, pw);
+        const uint32_t A = pw[2 * (k & 1)], B = pw[2 * (k & 1) + 1];
+        const int g = (int)(((uint64_t)B * (uint32_t)G) >> 32);
+        rng->consumed += 2;
+        if (p_logical != 0) {                                      /* mcmc.py:20-31 at p >= 0.75 */
+            if ((double)(A >> 16) / 65536.0 < p_logical) logical_from_words(m, state, scratch, A, B);
+            else model_sweep_stabilizer(m, state, scratch, (uint64_t)g);
+            memcpy(state, scratch, nq);
+            continue;
+        }
+        const int dE = model_sweep_stabilizer(m, state, scratch, (uint64_t)g);   /* :38-40 */
+        uint32_t aw[4], rw[4];
+        wave_block(rng, rng->syndrome, slot, k >> 3, 10u, aw);
+        wave_block(rng, rng->syndrome, slot, k >> 2, 11u, rw);
+        const uint32_t word = aw[(k & 7) >> 1], a16 = (k & 1) ? word >> 16 : word & 0xFFFFu;
+        const double u = ((double)a16 * 4294967296.0 + (double)rw[k & 3]) / 281474976710656.0;   /* 48 bits: exact */
+        if (u < pow(factor, (double)dE)) memcpy(state, scratch, nq);                               /* :42 */
+    }
+}
+
 /* p_x^nx p_y^ny p_z^nz p_I^(num-nx-ny-nz), mcmc_biased.py:31,43 (left-to-right products of pow()) */
 static double biased_weight(const uint8_t *s, int nq, double px, double py, double pz)
 {
@@ -629,6 +704,10 @@ void orc_chain_update(const orc_model *m, uint8_t *state, double p, double p_log
     }
     if (m->scan == 2 && m->noise == ORC_NOISE_DEPOLARIZING) {
         chain_update_colour(m, state, p, p_logical, iters, rng, slot, k0, scratch);
+        return;
+    }
+    if (m->scan == 3 && m->noise == ORC_NOISE_DEPOLARIZING) {
+        chain_update_wave(m, state, p, p_logical, iters, rng, slot, k0, scratch);
         return;
     }
     if (m->noise == ORC_NOISE_BIASED) {
@@ -775,7 +854,7 @@ void orc_ladder_step(orc_ladder *ld, uint64_t iters, orc_rng *rng)
     const int is_alpha = ld->model.noise == ORC_NOISE_ALPHA;
     for (int c = 0; c < Nc; ++c) {                                  /* update_ladder :81-83 */
         const double pl = c == Nc - 1 ? ld->p_logical : 0.0;
-        const uint32_t strm = pl != 0 ? (uint32_t)c : ORC_DIAG_STREAM + (uint32_t)(((uint64_t)c + ld->step_index) % (uint64_t)Nc);
+        const uint32_t strm = (pl != 0 || ld->model.scan == 3) ? (uint32_t)c : ORC_DIAG_STREAM + (uint32_t)(((uint64_t)c + ld->step_index) % (uint64_t)Nc);
         if (is_alpha) {
             if (orc_chain_update_alpha(&ld->model, ld->states + (size_t)c * nq, ld->p_ladder[c], pl,
                                        iters, rng, strm, k0, ld->scratch, &ld->n_eff[c])) {

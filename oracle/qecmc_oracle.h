@@ -71,7 +71,9 @@ typedef struct orc_model {
                       exp(e*ln(base)) the GPU uses (same decision unless u falls within ~1e-16 of the threshold) */
     int scan;      /* 0: the reference's random scan; 1: systematic sweep over the generators (NOT the reference's
                       chain: the deterministic-scan variant the GPU offers as scan=1, same stationary law); 2: the same idea one
-                      colour phase -- a set of mutually disjoint generators -- at a time (the GPU's latency layout, scan=2) */
+                      colour phase -- a set of mutually disjoint generators -- at a time (the GPU's latency layout, scan=2);
+                      3: the reference's random scan again, with a generator pick shared by the 64 ladders of a GPU wavefront (scan=3:
+                      every ladder keeps the reference's law; chain_update_wave in qecmc_oracle.c states the Philox addressing) */
     double pxyz[3]; /* ORC_NOISE_XYZ: Chain_xyz's (p_x, p_y, p_z), src/mcmc.py:106-114 -- a single chain without logical
                       moves whose proposals are accepted with prod_i (p_i / (1 - sum p))^(change of n_i), :162-173 */
 } orc_model;

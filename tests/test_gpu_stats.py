@@ -28,7 +28,17 @@ def _rand_state(seed, L, p):
     return m
 
 
-@pytest.mark.parametrize("scan", ["random", "sweep", "colour"])
+def _mean_sem(frac, ok, scan):
+    """mean and standard error over the replicas; scan = "wave": the 64 replicas of a wavefront share their generator picks, so the
+    error is taken over the 64 wavefront means (valid whatever the correlation inside a wavefront)"""
+    if scan != "wave":
+        f = frac[ok]
+        return f.mean(axis=0), f.std(axis=0, ddof=1) / np.sqrt(ok.sum())
+    g = np.array([frac[i:i + 64][ok[i:i + 64]].mean(axis=0) for i in range(0, len(frac), 64) if ok[i:i + 64].any()])
+    return frac[ok].mean(axis=0), g.std(axis=0, ddof=1) / np.sqrt(len(g))
+
+
+@pytest.mark.parametrize("scan", ["random", "sweep", "colour", "wave"])
 @pytest.mark.parametrize("seed,p,Nc", [(1, 0.10, 3), (2, 0.15, 4), (3, 0.12, 4), (4, 0.20, 5)])
 def test_exact_enumeration_L3(q, seed, p, Nc, scan):
     from qecmc import toric_model as tm
@@ -39,8 +49,7 @@ def test_exact_enumeration_L3(q, seed, p, Nc, scan):
                        seed=1000 + seed, scan=scan)
     ok = res["samples"] > steps // 2                  # replicas whose burn-in (tops0 >= 5) ended in the first half
     assert ok.mean() > 0.97
-    frac = res["counts"][ok] / res["samples"][ok, None].astype(np.float64)
-    mean, sem = frac.mean(axis=0), frac.std(axis=0, ddof=1) / np.sqrt(ok.sum())
+    mean, sem = _mean_sem(res["counts"] / np.maximum(res["samples"], 1)[:, None].astype(np.float64), ok, scan)
     # within Monte-Carlo error of the exact answer (4096 replicas: sem ~ 1e-3); the 2e-4 floor absorbs the
     # residual burn-in transient of a finite run
     assert np.all(np.abs(mean - P) <= 5 * sem + 2e-4), (mean, P, sem)
@@ -183,7 +192,7 @@ def _class_fractions(res, ok):
     return frac.mean(axis=0), frac.std(axis=0, ddof=1) / np.sqrt(ok.sum())
 
 
-@pytest.mark.parametrize("scan", ["random", "colour"])
+@pytest.mark.parametrize("scan", ["random", "colour", "wave"])
 @pytest.mark.parametrize("name,seed,p,Nc", [("xzzx", 11, 0.20, 3), ("xzzx", 13, 0.15, 4), ("rotated", 12, 0.25, 4), ("rotated", 14, 0.17, 3)])
 def test_plaquette_depolarizing_exact_L3(q, name, seed, p, Nc, scan):
     from util_exact import SurfEnumeration, depolarizing_weight
@@ -194,7 +203,7 @@ def test_plaquette_depolarizing_exact_L3(q, name, seed, p, Nc, scan):
     res = q.pteq_batch(np.broadcast_to(init, (R,) + init.shape).copy(), p, Nc=Nc, steps=steps, iters=10, tops_burn=5, seed=2000 + seed, code=code, scan=scan)
     ok = res["samples"] > steps // 2
     assert ok.mean() > 0.97
-    mean, sem = _class_fractions(res, ok)
+    mean, sem = _mean_sem(res["counts"] / np.maximum(res["samples"], 1)[:, None].astype(np.float64), ok, scan)
     assert np.all(np.abs(mean - P) <= 5 * sem + 2e-4), (mean, P, sem)
     if np.sort(P)[-1] - np.sort(P)[-2] > 0.01:        # (seed 13 draws the empty lattice at L = 3: the four classes tie exactly)
         assert mean.argmax() == P.argmax()

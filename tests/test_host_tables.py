@@ -31,6 +31,7 @@ def T():
     lib = C.CDLL(path)
     lib.qt_thr64.restype = C.c_uint64; lib.qt_thr64.argtypes = [C.c_double]
     lib.qt_thr44.restype = C.c_uint64; lib.qt_thr44.argtypes = [C.c_double]
+    lib.qt_thr48.restype = C.c_uint64; lib.qt_thr48.argtypes = [C.c_double]
     lib.qt_thr32.restype = C.c_uint32; lib.qt_thr32.argtypes = [C.c_double]
     lib.qt_chain_factor.restype = C.c_double; lib.qt_chain_factor.argtypes = [C.c_double]
     return lib
@@ -178,6 +179,58 @@ def test_colour_phases_equal_the_oracles(T, code, L):
 
 
 @pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+@pytest.mark.parametrize("code,L", SHAPES + [(TORIC, 16), (XZZX, 21)])
+def test_wave_descriptors_are_the_oracles_stencil(T, code, L):
+    """scan = 3's per-generator descriptors (csrc/tables.hpp wave_descriptors), interpreted the way csrc/ladder_wu.hpp does -- fields
+    by word / shift, the byte table behind v_perm_b32, the sum of its bytes, the xor values -- against the oracle's stabilizer on
+    random packed states: new configuration and error-count change."""
+    nq = _nq(code, L)
+    W = (nq + 15) // 16
+    buf = np.zeros(12 * 4096, np.uint32)
+    n = T.qt_wave_descriptors(code, L, _ptr(buf, C.c_uint32), buf.size)
+    G = 2 * L * L if code == TORIC else orc.surf_ngen(ORC_CODE[code], L)
+    assert n == 12 * G
+    d = buf[:n].reshape(G, 12)
+    rng = np.random.default_rng(L * 5 + code)
+    for g in rng.permutation(G)[:40]:
+        m = rng.integers(0, 4, size=_zero(code, L).shape).astype(np.uint8)
+        if code == PLANAR:
+            m[1, -1, :] = 0; m[1, :, -1] = 0
+        flat = m.ravel()
+        words = np.zeros(W, np.uint64)
+        for q in range(nq):
+            words[q >> 4] |= np.uint64(int(flat[q]) << (2 * (q & 15)))
+        e = d[g]
+        sel = 0
+        for i in range(4):
+            wi, sh = int(e[i]) & 0xFF, (int(e[i]) >> 8) & 31
+            assert wi < W
+            sel |= ((int(words[wi]) >> sh) & 0xFF) << (8 * i)              # v_lshrrev_b32_sdwa: a byte, junk above the field
+        sel = (sel & int(e[11])) | int(e[10]) if code != TORIC else sel & 0x03030303
+        tab = int(e[8]).to_bytes(4, "little") + int(e[9]).to_bytes(4, "little")   # v_perm_b32: selectors 0-3 -> dword 8, 4-7 -> dword 9
+        if code == TORIC:
+            assert e[8] == e[9]
+        dE4 = sum(tab[(sel >> (8 * i)) & 0xFF] for i in range(4))          # v_sad_u8: 4 (dE + 4)
+        for i in range(4):
+            words[int(e[i]) & 0xFF] ^= np.uint64(int(e[4 + i]))
+        new = np.array([(int(words[q >> 4]) >> (2 * (q & 15))) & 3 for q in range(nq)], np.uint8).reshape(m.shape)
+        if code == TORIC:
+            ref, dE = orc.toric_apply_stabilizer(m, (int(g) % (L * L)) // L, int(g) % L, 1 if g < L * L else 3)
+        else:
+            ref, dE = orc.surf_apply_stabilizer(ORC_CODE[code], m, *orc.surf_gen_rco(ORC_CODE[code], L, int(g)))
+        assert np.array_equal(new, ref)
+        assert dE4 == 4 * (dE + 4)
+
+
+def test_thr48_decides_like_the_floating_point_test(T):
+    rng = np.random.default_rng(4)
+    for v in list(rng.random(200)) + [1e-9, 2.0 ** -48, 0.999999999, 1.0, 1.5, 0.0]:
+        t = T.qt_thr48(float(v))
+        for x in (t - 1, t, t + 1):
+            if 0 <= x < (1 << 48):
+                assert (x < t) == (x / 2.0 ** 48 < v)
+
+
 def test_host_tables_under_asan_ubsan():
     if os.environ.get("QECMC_TABLES_LIB"):
         pytest.skip("already the sanitizer child")

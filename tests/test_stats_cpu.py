@@ -259,3 +259,71 @@ def test_oracle_colour_phases_partition_the_generators_into_disjoint_sets(code, 
             q = pat.ravel() != 0
             assert not (seen & q).any()                                  # no qubit is touched twice within a phase
             seen |= q
+
+
+# ---- scan = 3 ("wave"): the reference's random scan with a generator pick shared by the 64 ladders of a GPU wavefront ----------
+@pytest.mark.parametrize("code,seed,p,Nc", [(orc.TORIC, 1, 0.10, 3), (orc.XZZX, 11, 0.20, 3), (orc.ROTATED, 12, 0.25, 4)])
+def test_oracle_wave_scan_matches_exact_enumeration_L3(code, seed, p, Nc):
+    """Every ladder of scan = 3 is the reference's chain: its class histogram sits on the exact law.  The replicas get a pick group
+    of their own each (first_syndrome = 64 r), so that they are independent and the standard error over them means what it says."""
+    if code == orc.TORIC:
+        init = _rand_state(seed, 3, 0.15)
+        P = toric_class_probabilities(init, p, orc.toric_apply_stabilizer, orc.toric_to_class)
+    else:
+        init = _rand_surf(seed)
+        P = SurfEnumeration(code, init, ORC_API).class_probabilities(depolarizing_weight(p))
+    R, steps = 96, 6000
+    counts, samples = [], []
+    for r in range(R):
+        res = orc.pteq_batch(code, init[None].copy(), p, Nc, steps, iters=10, tops_burn=5, seed=700 + seed, first_syndrome=64 * r, n_threads=1, scan=3)
+        counts.append(res["counts"][0]); samples.append(res["samples"][0])
+    counts, samples = np.array(counts), np.array(samples)
+    assert (samples > steps // 2).all()
+    _check_classes(counts / samples[:, None].astype(np.float64), P)
+
+
+def test_oracle_wave_scan_shares_its_picks_within_a_group_of_64_only():
+    """A chain at f = 1 accepts every proposal (mcmc.py:42 with factor 1), so its trajectory IS its sequence of generator picks: the
+    same for two ladders of one group of 64, different across groups and across slots; and every generator comes up equally often."""
+    L, iters = 5, 4000
+    zero = np.zeros((2, L, L), np.uint8)
+    def run(syndrome, slot):
+        m = zero.copy()
+        return orc.chain_update(orc.TORIC, m, 0.75, 0.0, iters, orc.Rng.philox(5, syndrome), slot=slot, k0=0, scan=3)
+    a, b, c, d = run(64, 0), run(127, 0), run(128, 0), run(64, 1)
+    assert np.array_equal(a, b) and not np.array_equal(a, c) and not np.array_equal(a, d)
+    # uniform over the 2 L^2 generators: apply one proposal at a time from the empty lattice and identify the generator
+    G = 2 * L * L
+    hits = np.zeros(G, np.int64)
+    pats = {}
+    for g in range(G):
+        pats[orc.toric_apply_stabilizer(zero, (g % (L * L)) // L, g % L, 1 if g < L * L else 3)[0].tobytes()] = g
+    n = 20000
+    for k in range(n):
+        hits[pats[orc.chain_update(orc.TORIC, zero.copy(), 0.75, 0.0, 1, orc.Rng.philox(9, 0), slot=2, k0=k, scan=3).tobytes()]] += 1
+    exp = n / G
+    assert np.abs(hits - exp).max() < 5 * np.sqrt(exp)
+
+
+def test_oracle_wave_scan_acceptance_uniform_is_48_bits_against_the_reference_rule():
+    """One proposal of a cold chain: accepted iff a16 2^32 + w32 < ceil(f^dE 2^48) -- checked against a direct evaluation of
+    mcmc.py:42 on the same Philox words for a few thousand (syndrome, k)."""
+    L, p = 3, 0.2
+    f = (p / 3.0) / (1.0 - p)
+    rng = np.random.default_rng(3)
+    init = (rng.integers(1, 4, size=(2, L, L)) * (rng.random((2, L, L)) < 0.3)).astype(np.uint8)
+    n_acc = 0
+    for k in range(3000):
+        syn = int(rng.integers(0, 1 << 20))
+        out = orc.chain_update(orc.TORIC, init.copy(), p, 0.0, 1, orc.Rng.philox(21, syn), slot=1, k0=k, scan=3)
+        pw = orc.philox4x32_10([k >> 1, 9 << 16, syn >> 6, 0x800 + 1], [21, 0])
+        g = (int(pw[2 * (k & 1) + 1]) * 2 * L * L) >> 32
+        new, dE = orc.toric_apply_stabilizer(init, (g % (L * L)) // L, g % L, 1 if g < L * L else 3)
+        aw = orc.philox4x32_10([k >> 3, 10 << 16, syn, 1], [21, 0]); rw = orc.philox4x32_10([k >> 2, 11 << 16, syn, 1], [21, 0])
+        word = int(aw[(k & 7) >> 1]); a16 = (word >> 16) if (k & 1) else (word & 0xFFFF)
+        x = (a16 << 32) + int(rw[k & 3])
+        thr = (1 << 48) if f ** dE >= 1 else int(np.ceil((f ** dE) * 2.0 ** 48))
+        acc = x < thr
+        n_acc += acc
+        assert np.array_equal(out, new if acc else init)
+    assert 0 < n_acc < 3000

@@ -1,0 +1,26 @@
+#!/bin/bash
+# One parametrised GPU-box script (replaces the numbered gpu_call*.sh of earlier rounds): `tools/gpu_run.sh <what> [args]`, run as
+#   gpurun --timeout S -- 'bash tools/gpu_run.sh <what> ...'
+# Everything it writes goes under gpurun_out/ (merged back by gpurun).  Steps are joined with && : a failed GPU step ends the call.
+set -o pipefail
+mkdir -p gpurun_out
+cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+b() {  # b <tag> <bench args...>: one bench line, condensed
+    tag=$1; shift
+    timeout -k 10 300 python bench.py --no-cpu-baseline --steps 3 "$@" 2> gpurun_out/bench_$tag.err | tee gpurun_out/bench_$tag.json | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('$tag', '%.3e prop/s' % d['proposals_per_s'], 'frac %.3f' % d['roofline']['frac'], '%.2f ms' % d['kernel_ms_per_launch'], 'lds', d['config']['lds_bytes_per_workgroup'])"
+}
+case "$1" in
+  wave-first)   # first contact of the scan = wave kernel: its parity tests, then A/B against the random scan on the headline shape
+    timeout -k 10 900 python -m pytest tests/test_gpu_wave.py -x -q > gpurun_out/wave_tests.log 2>&1; rc=$?; tail -15 gpurun_out/wave_tests.log
+    [ $rc -eq 0 ] && b cfg2_random --config 2 && b cfg2_wave --config 2 --scan wave && b cfg2_random_b --config 2 && b cfg2_wave_b --config 2 --scan wave
+    ;;
+  tests)        # tests [pytest args]: the GPU suite (or part of it)
+    shift
+    timeout -k 10 1100 python -m pytest tests -m gpu -q "$@" > gpurun_out/gpu_tests.log 2>&1; echo "tests rc=$?"; tail -12 gpurun_out/gpu_tests.log
+    ;;
+  bench)        # bench <tag> <bench args>
+    shift; b "$@"
+    ;;
+  *) echo "unknown step $1"; exit 2 ;;
+esac
