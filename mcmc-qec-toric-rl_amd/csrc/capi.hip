@@ -242,7 +242,6 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
         for (int d = 1; d <= 4; ++d) {
             a.acc_thr[c][d - 1] = thr32(std::pow(f, (double)d));                     // mcmc.py:42
             a.acc_thr44[c][d - 1] = thr44(std::pow(f, (double)d));
-            a.acc_thr48[c][d - 1] = thr48(std::pow(f, (double)d));
         }
     }
     std::vector<uint32_t> top_tbl(nq + 1, 0u);                             // mcmc.py:34 for a top chain below p = 0.75

@@ -76,8 +76,7 @@ struct LadderArgs {
     uint32_t acc_all_mask;    // bit c: slot c accepts every proposal (f >= 1, mcmc.py:30)
     uint32_t acc_thr[kMaxNc][4];   // ceil(f_c^dE * 2^32), dE = 1..4 (sweep mode: one 32-bit word per acceptance)
     uint64_t acc_thr44[kMaxNc][4]; // ceil(f_c^dE * 2^44): random scan, the 44-bit acceptance uniform of a non-top proposal
-    uint64_t acc_thr48[kMaxNc][4]; // ceil(f_c^dE * 2^48): scan = 3 (ladder_wu.hip), a 16-bit uniform completed by a 32-bit word on a tie
-    const uint32_t *wu_desc;       // scan = 3: [n_gen][12] generator descriptors (tables.hpp wave_descriptors)
+    const uint32_t *wu_desc;       // scan = 3: [n_gen][16] generator descriptors (tables.hpp wave_descriptors)
     float swap_inv_log2[kMaxNc];   // 1 / log2(p_diff[i]): first guess of the largest d with u < p_diff[i]^d (the table decides)
     int32_t swap_fast_ok;          // every swap threshold with d >= 1 fits 32 bits (false only if two rungs coincide)
     int L, Nc, W, nq, ncls;

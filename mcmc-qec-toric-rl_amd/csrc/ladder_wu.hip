@@ -6,11 +6,12 @@ namespace qecmc {
 size_t wu_lds_bytes(int Nc, int W, int ncls, int L) { return sizeof(uint32_t) * (size_t)wu_lds(Nc, W, ncls, L).total; }
 
 // the shapes scan = 3 is built for: depolarizing rule, a ladder whose top rung accepts every move (Nc >= 2, p_top = 0.75), up to
-// 32 state words per ladder rung (toric L <= 16, xzzx / rotated L <= 22), descriptor offsets that fit 16 bits
+// 32 state words per ladder rung (toric L <= 16, xzzx / rotated L <= 22), descriptor offsets that fit 16 bits, 1 <= iters <= 128,
+// rungs at distinct temperatures (32-bit swap thresholds)
 bool wu_supported(const LadderArgs &a)
 {
     return a.noise == 0 && a.Nc >= 2 && ((a.acc_all_mask >> (a.Nc - 1)) & 1u) && !(a.acc_all_mask & ((1u << (a.Nc - 1)) - 1u)) &&
-           a.W <= 32 && a.n_gen * 48u <= 65535u && a.uset_tab == nullptr && a.swap_acc == nullptr && a.queue == nullptr &&
+           a.W <= 32 && a.n_gen <= 1023u && a.iters >= 1u && a.iters <= 128u && a.swap_fast_ok != 0 && a.uset_tab == nullptr && a.swap_acc == nullptr && a.queue == nullptr &&
            wu_lds_bytes(a.Nc, a.W, a.ncls, a.L) <= 160 * 1024;
 }
 

@@ -10,21 +10,24 @@
 //     no LDS traffic, no per-lane table gathers, no address arithmetic in the proposal loop;
 //   * dE from the four old fields by one v_perm_b32 (a four-entry table per Pauli, applied to the four bytes at once) and one
 //     v_sad_u8, which also adds the rung's threshold-row address: 4 (dE + 4) + base in a single instruction;
-//   * the pick costs one Philox block per TWO proposals per wavefront (lane j draws the block of proposals 2j, 2j + 1 of a
-//     128-proposal window), the per-ladder acceptance uniform 16 bits: one block per EIGHT proposals per lane; the 48-bit
-//     uniform is completed (a 32-bit refinement word) only when a lane's 16 bits tie with its threshold's;
+//   * the pick costs one Philox block per TWO proposals per wavefront (lane l draws the block of proposals 2l, 2l + 1 of a
+//     window of up to 128 proposals), the per-ladder acceptance uniform 12 bits: one block per TEN proposals per lane; the 44-bit
+//     uniform is completed (a 32-bit refinement word) only when a lane's 12 bits tie with its threshold's;
 //   * the top rung (p = 0.75: every move is accepted, mcmc.py:30) applies its stabilizers blindly and collects its logical
 //     operators -- wave-uniform now -- in one frame that is applied once per step.
 // States move through LDS once per ladder step, when the swap sweep (mcmc.py:94-103) has decided who goes where: every wave
 // writes its rung's W words, and after the cascade reads the W words of the rung whose state it receives.
 //
-// RNG addressing of scan = 3 (the CPU oracle restates it independently, as its scan = 3), slot c, proposal k:
-//   pick      words A, B = 2 (k & 1), 2 (k & 1) + 1 of block (k >> 1, sub 9) with ctr[2] = (global ladder index) >> 6 and stream
-//             0x800 + c:  g = floor(B G / 2^32); top rung: logical iff A[31:16] < ceil(p_logical 2^16), its fields cut from
-//             A[15:0] and B as in the packed layout of scan = 0 (philox.hpp)
-//   accept    a16 = half (k & 1) of word (k & 7) >> 1 of block (k >> 3, sub 10) of the ladder's own index, stream c;
-//             w32 = word k & 3 of block (k >> 2, sub 11);  accept iff a16 2^32 + w32 < ceil(f^dE 2^48)
-//   swaps     as in the other scans (block (t, i >> 2) of stream 0x100)
+// RNG addressing of scan = 3 (the CPU oracle restates it independently, as its scan = 3): by ladder step T and proposal j of the step
+// (1 <= iters <= 128), slot c:
+//   pick      S = 128 / iters steps share a window: w = T / S, P = (T % S) iters + j; words A, B = 2 (P & 1), 2 (P & 1) + 1 of block
+//             (64 w + (P >> 1), sub 9) with ctr[2] = (global ladder index) >> 6 and stream 0x800 + c -- lane P >> 1 of the wavefront draws
+//             it --:  g = floor(B G / 2^32); top rung: logical iff A[31:16] < ceil(p_logical 2^16), its fields cut from A[15:0] and B as
+//             in the packed layout of scan = 0 (philox.hpp)
+//   accept    ten proposals share block (T ceil(iters / 10) + j / 10, sub 10) of the ladder's own index, stream c: a12 = field j % 10
+//             (wu_field below); w32 = word j & 3 of block (T ceil(iters / 4) + (j >> 2), sub 11);
+//             accept iff a12 2^32 + w32 < ceil(f^dE 2^44)
+//   swaps     as in the other scans (block (T, i >> 2) of stream 0x100)
 // Batches must start on a multiple of 64 (first_syndrome & 63 == 0) so that a wavefront is one pick group.
 #pragma once
 #include "ladder_kernel.hpp"
@@ -165,7 +168,7 @@ __host__ __device__ inline WuLds wu_lds(int Nc, int W, int ncls, int L)
     o.rec = o.xbuf + Nc * W * 64;
     o.swd = o.rec + Nc * 64;
     o.hist = o.swd + Nc * 64;
-    o.thr = o.hist + ncls * 64;               // [Nc][2][9]: high 17 / low 32 bits of ceil(f^dE 2^48), dE + 4 = 0 .. 8
+    o.thr = o.hist + ncls * 64;               // [Nc][2][9]: high 13 / low 32 bits of ceil(f^dE 2^44), dE + 4 = 0 .. 8
     o.swapT = o.thr + Nc * 18;
     o.lml = o.swapT + Nc * kSwapFast;
     o.stop = o.lml + 4 * (L + 1) * W + 64;
@@ -193,11 +196,24 @@ struct WuEnv {
     uint64_t s0;
 };
 
-// the step loop of one wave: TOP = the rung that accepts every move (its stabilizers unseen, its logical operators through a frame)
-template <int CODE, int WV, bool CONV, bool TOP>
+// field f (0 .. 9) of an acceptance block: twelve leading bits of a 44-bit uniform each -- two per word in bits 0-23, the last two
+// gathered from the four top bytes
+__device__ __forceinline__ uint32_t wu_field(const u32x4 &b, int f)
+{
+    if (f < 8) {
+        const uint32_t w = sel4(b, f >> 1);
+        return (f & 1) ? __builtin_amdgcn_ubfe(w, 12u, 12u) : (w & 0xFFFu);
+    }
+    const uint32_t lo = f == 8 ? b.x : b.z, hi = f == 8 ? b.y : b.w;
+    return __builtin_amdgcn_perm(hi, lo, 0x0C0C0703u) & 0xFFFu;      // byte 3 of lo | byte 3 of hi << 8
+}
+
+// the step loop of one wave: TOP = the rung that accepts every move (its stabilizers unseen, its logical operators through a frame);
+// IT = 10: `iters` known at compile time (decoders.py:25 iters=10), the proposal loop unrolled without guards; IT = 0: any 1 <= iters <= 128
+template <int CODE, int WV, bool CONV, bool TOP, int IT>
 __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::type &st, WuCtx &cx, const WuEnv &ev)
 {
-    const int NC = a.Nc, L = a.L, nq = a.nq;
+    const int L = a.L;
     uint32_t *const lml = ev.lml;
     const uint32_t lds0 = ev.lds0, slot = ev.slot, syn = ev.syn, grp = ev.grp;
     const int lane = ev.lane;
@@ -205,57 +221,51 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
     const bool live = lane < ev.cnt;
     constexpr bool top = TOP;
     const uint32_t G = a.n_gen;
-    const bool swap_fast = a.swap_fast_ok != 0;
     const uint32_t m55 = 0x55555555u;
     uint32_t n4 = cx.n4, cls = cx.cls, flag = cx.flag, tops0 = cx.tops0, samples = cx.samples;
     [[maybe_unused]] uint32_t burn = 0, conv_start = 0, conv_streak = 0, done = 0, conv_ok = 0, steps_done = 0;
     [[maybe_unused]] uint64_t sumA = 0, sumB = 0;
     const wu_const_ptr desc = (wu_const_ptr)a.wu_desc;
-    const uint32_t iters = a.iters;
+    const uint32_t iters = IT ? (uint32_t)IT : a.iters;
+    const uint32_t nch = (iters + 9u) / 10u, nc4 = (iters + 3u) / 4u;             // acceptance / refinement blocks per step
+    const uint32_t S = 128u / iters;                                              // ladder steps per pick window (iters <= 128)
     const uint32_t thr16 = (uint32_t)((a.thr_logical + 65535u) >> 16);            // logical iff A[31:16] < thr16
-    const uint32_t thr_base = lds0 + ev.thr_off;    // LDS byte address of this rung's threshold row
+    const uint32_t thr_base = lds0 + ev.thr_off;                                  // LDS byte address of this rung's threshold row
     const uint32_t nbias = 0u - (thr_base + 16u);
-    uint32_t pk = 0;                                                              // packed descriptor offsets of a 128-proposal window
+    uint32_t pk = 0;                                                              // packed descriptor offsets of a pick window
     [[maybe_unused]] uint32_t pa0 = 0, pa1 = 0, pb0 = 0, pb1 = 0;                 // top rung: the window's words A, B
-    u32x4 ab{0, 0, 0, 0};                                                         // this ladder's block of eight 16-bit acceptance uniforms
-    // (the seed is laundered in the cold paths -- window refresh, tie refinement -- so that their Philox key schedules are not kept
-    // in scalar registers across the proposal loop)
-    auto refresh = [&](uint64_t kwin) {
-        const u32x4 b = wu_philox((kwin >> 1) + (uint64_t)lane, kSubWuPick, grp, kWuPickStream + slot, a.seed_lo, a.seed_hi);
+    uint32_t ws = (uint32_t)(a.step0 % S);                                        // this step's index within its pick window
+    uint64_t wi = a.step0 / S;                                                    // ... and the window's
+    auto refresh = [&]() {
+        // lane l: the picks of proposals 2l, 2l + 1 of the window (one Philox block), as descriptor offsets
+        const u32x4 b = wu_philox(wi * 64u + (uint64_t)lane, kSubWuPick, grp, kWuPickStream + slot, a.seed_lo, a.seed_hi);
         const uint32_t g0 = scale_u32(b.y, G), g1 = scale_u32(b.w, G);
-        pk = (g0 * 48u) | ((g1 * 48u) << 16);
+        pk = (g0 << 6) | (g1 << 22);
         if (top) { pa0 = b.x; pb0 = b.y; pa1 = b.z; pb1 = b.w; }
     };
-    const uint64_t kfirst = a.prop0;
-    refresh(kfirst & ~127ull);
-    bool fresh = true;                                                            // the acceptance block of the first proposal is not in registers yet
+    refresh();
 
     for (uint64_t t = 0; t < a.nsteps; ++t) {
-        uint64_t k = a.prop0 + t * (uint64_t)iters;
-        const uint64_t kend = k + iters;
+        const uint64_t T = a.step0 + t;
         [[maybe_unused]] uint32_t maskv = 0, cdelta = 0;                           // top rung: the step's frame of logical operators (lane w: word w), class change
-        while (k < kend) {
-            const uint64_t kb = k & ~7ull;
-            const uint32_t f0 = (uint32_t)(k & 7u);
-            uint32_t frem = (uint32_t)((kend - kb) < 8u ? (kend - kb) : 8u);
-            asm volatile("" : "+s"(frem));                                       // (a 32-bit bound: the guards below stay scalar compares)
-            const uint32_t fend = frem;                                            // fields f0 .. fend-1 of this block
-            if (!top && (f0 == 0 || fresh)) ab = wu_philox(kb >> 3, kSubWuAcc, syn, slot, a.seed_lo, a.seed_hi);
-            fresh = false;
-            const uint32_t lbase = (uint32_t)((kb >> 1) & 63u);
+        const uint32_t pbase = ws * iters;                                         // the step's first proposal within the window
+        for (uint32_t c = 0; c < nch; ++c) {
+            [[maybe_unused]] u32x4 ab{0, 0, 0, 0};                                 // this ladder's block of ten 12-bit acceptance uniforms
+            if (!top) ab = wu_philox(T * nch + c, kSubWuAcc, syn, slot, a.seed_lo, a.seed_hi);
+            uint32_t left = iters - c * 10u;
+            if constexpr (IT == 0) asm volatile("" : "+s"(left));                  // (a scalar bound for the guards below)
 #pragma unroll
-            for (int f = 0; f < 8; ++f) {
-                if ((uint32_t)f < f0 || (uint32_t)f >= fend) continue;
-                if (f == 0 && (kb & 127u) == 0 && kb != (kfirst & ~127ull)) refresh(kb);
-                const uint32_t li = lbase + (uint32_t)(f >> 1);
-                const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)pk, (int)li);
-                const uint32_t off = (f & 1) ? r >> 16 : r & 0xFFFFu;
+            for (int f = 0; f < 10; ++f) {
+                if constexpr (IT == 0) { if ((uint32_t)f >= left) break; }
+                const uint32_t P = pbase + c * 10u + (uint32_t)f;                  // proposal of the window: lane P >> 1, half P & 1
+                const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)pk, (int)(P >> 1));
+                const uint32_t off = (P & 1u) ? r >> 16 : r & 0xFFFFu;
                 const wu_const_ptr e = desc + (off >> 2);
-                if (top) {
-                    const uint32_t A = (uint32_t)__builtin_amdgcn_readlane((int)((f & 1) ? pa1 : pa0), (int)li);
+                if constexpr (top) {
+                    const uint32_t A = (uint32_t)__builtin_amdgcn_readlane((int)((P & 1u) ? pa1 : pa0), (int)(P >> 1));
                     if (thr16 != 0 && (A >> 16) < thr16) {
                         // a logical operator (mcmc.py:23-24; toric_model.py:228-253, xzzx_model.py:340-357): into the frame
-                        const uint32_t B = (uint32_t)__builtin_amdgcn_readlane((int)((f & 1) ? pb1 : pb0), (int)li);
+                        const uint32_t B = (uint32_t)__builtin_amdgcn_readlane((int)((P & 1u) ? pb1 : pb0), (int)(P >> 1));
                         const int LW = (L + 1) * WV;
                         if constexpr (CODE == kCodeToric) {
                             const uint32_t op0 = (A >> 14) & 3u, op1 = (A >> 12) & 3u;
@@ -292,15 +302,14 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
                     }
                     const uint32_t addr = __builtin_amdgcn_sad_u8(pv, 0u, thr_base); // LDS address of this rung's threshold for dE
                     const uint32_t Th = *(wu_lds_ptr)(uintptr_t)addr;
-                    const uint32_t w = sel4(ab, f >> 1);
-                    const uint32_t a16 = (f & 1) ? w >> 16 : w & 0xFFFFu;
-                    bool acc = a16 < Th;
-                    if (__builtin_amdgcn_uicmp(a16, Th, 32) != 0) {
-                        // the 16 leading bits tie with the threshold's in some lane: the refinement word decides there
-                        const uint64_t kk = kb + (uint64_t)f;
-                        const u32x4 rb = wu_philox(kk >> 2, kSubWuRefine, syn, slot, a.seed_lo, a.seed_hi);
+                    const uint32_t a12 = wu_field(ab, f);
+                    bool acc = a12 < Th;
+                    if (__builtin_amdgcn_uicmp(a12, Th, 32) != 0) {
+                        // the 12 leading bits tie with the threshold's in some lane: the refinement word decides there
+                        const uint32_t j = c * 10u + (uint32_t)f;
+                        const u32x4 rb = wu_philox(T * nc4 + (j >> 2), kSubWuRefine, syn, slot, a.seed_lo, a.seed_hi);
                         const uint32_t Tl = *(wu_lds_ptr)(uintptr_t)(addr + 36u);
-                        if (a16 == Th) acc = sel4(rb, (int)(kk & 3u)) < Tl;
+                        if (a12 == Th) acc = sel4(rb, (int)(j & 3u)) < Tl;
                     }
                     if (acc) {
                         wu_xor<WV>(st, d0, d1, d2, d3, x0, x1, x2, x3);
@@ -308,7 +317,6 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
                     }
                 }
             }
-            k = kb + fend;
         }
         if (top) {
             // the step's logical operators at once, then the error count (the blind moves did not keep it)
@@ -323,9 +331,10 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
 #undef QECMC_WU_FLUSH
             n4 <<= 2;
         }
+        // the next step's pick window (state-independent; before the barrier, where the other waves are still busy)
+        if (++ws == S) { ws = 0; ++wi; refresh(); }
 
         // ---- Ladder.step's swap sweep (mcmc.py:96-103)
-        __syncthreads();                                   // (everybody has read the exchange buffer of the step before)
         // (per-step work: its table addresses are formed here, from laundered copies of the shape, instead of being hoisted out of the
         // step loop and kept -- spilled -- in scalar registers across the proposal loop, which runs at 8 waves per SIMD on ~80 SGPRs)
         int NCl = a.Nc, nql = a.nq, ncl = a.ncls, Ll = a.L;
@@ -338,44 +347,24 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
         uint32_t *const rec = ldsl + ol.rec, *const swd = ldsl + ol.swd, *const hist = ldsl + ol.hist, *const swapT = ldsl + ol.swapT;
         volatile uint32_t *const stopf = ldsl + ol.stop;
         const uint32_t xaddr = lds0l + (uint32_t)lane * 4u;
+        const int swb = NC - 1 - (int)slot;                 // the top rungs draw the swap uniforms: block swb = pairs 4 swb .. 4 swb + 3
+        u32x4 sb{0, 0, 0, 0};
+        const bool duty = swb >= 0 && swb < 4 && swb * 4 < NC - 1;
+        if (duty) sb = wu_philox(T, (uint32_t)swb, syn, kSwapStream, a.seed_lo, a.seed_hi);
+        __syncthreads();                                   // (everybody has read the exchange buffer and the swap uniforms of the step before)
         {
             const uint32_t xo = xaddr + slot * (uint32_t)(WV * 256);
 #define QECMC_WU_PUT(w) if constexpr (w < WV) wu_ds_write<WV, w>(st, xo);
             WU_EACH(QECMC_WU_PUT)
             rec[slot * 64u + (uint32_t)lane] = pack_info(n4 >> 2, slot, cls, flag);
-        }
-        const int swb = NC - 1 - (int)slot;                 // the top rungs draw the swap uniforms: block swb = pairs 4 swb .. 4 swb + 3
-        if (swb >= 0 && swb < 4 && swb * 4 < NC - 1) {
-            const u32x4 b = wu_philox(a.step0 + t, (uint32_t)swb, syn, kSwapStream, a.seed_lo, a.seed_hi);
-            const int left = NC - 1 - swb * 4;
-            // u < p_diff[i]^d (mcmc.py:149) reads d <= dmax: thresholds fall with d, dmax = the largest d whose threshold exceeds x
-            auto swap_dmax = [&](uint32_t x, int i) -> uint32_t {
-                auto below = [&](int dd) -> bool {
-                    return (swap_fast && dd < kSwapFast) ? x < swapT[i * kSwapFast + dd] : (uint64_t)x < a.swap_thr[(size_t)i * (nq + 1) + dd];
-                };
-                const float inv = a.swap_inv_log2[i];
-                int d = inv == 0.0f ? nq : (int)((__log2f((float)x + 0.5f) - 32.0f) * inv);
-                d = d < 0 ? 0 : d > nq ? nq : d;
-                if (swap_fast && d + 2 < kSwapFast) {
-                    const int w0 = d > 1 ? d - 1 : 1;
-                    const uint32_t *T = swapT + i * kSwapFast + w0;
-                    const int c = (int)(x < T[0]) + (int)(x < T[1]) + (int)(x < T[2]) + (int)(x < T[3]);
-                    d = w0 - 1 + c;
-                    if (c < 4 && (c > 0 || w0 == 1)) return (uint32_t)d;
-                }
-                while (d < nq && below(d + 1)) ++d;
-                while (d > 0 && !below(d)) --d;
-                return (uint32_t)d;
-            };
-            uint32_t *p = swd + (uint32_t)(swb * 4) * 64u + (uint32_t)lane;
-            const uint32_t r0 = swap_dmax(b.x, swb * 4);
-            const uint32_t r1 = left > 1 ? swap_dmax(b.y, swb * 4 + 1) : 0u;
-            const uint32_t r2 = left > 2 ? swap_dmax(b.z, swb * 4 + 2) : 0u;
-            const uint32_t r3 = left > 3 ? swap_dmax(b.w, swb * 4 + 3) : 0u;
-            p[0] = r0;
-            if (left > 1) p[64] = r1;
-            if (left > 2) p[128] = r2;
-            if (left > 3) p[192] = r3;
+            if (duty) {
+                uint32_t *p = swd + (uint32_t)(swb * 4) * 64u + (uint32_t)lane;
+                const int left = NC - 1 - swb * 4;
+                p[0] = sb.x;
+                if (left > 1) p[64] = sb.y;
+                if (left > 2) p[128] = sb.z;
+                if (left > 3) p[192] = sb.w;
+            }
         }
         wu_ds_wait<WV>(st);                                 // (the asm stores of the exchange are not in the compiler's count)
         __syncthreads();
@@ -386,9 +375,13 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
             uint32_t car = cur[(NC - 1) * 64], mine = car;
             const int i_stop = slot == 0 ? 0 : (int)slot - 1;
             for (int i = NC - 2; i >= i_stop; --i) {                                 // mcmc.py:96
-                const uint32_t lo = cur[i * 64], xi = sx[i * 64];
+                const uint32_t lo = cur[i * 64], x = sx[i * 64];
                 const int d = (int)(car & 0xFFFFu) - (int)(lo & 0xFFFFu);            // ne_hi - ne_lo, _r_flip :146-149
-                const bool flip = d <= (int)xi;
+                // x < ceil(p_diff[i]^d 2^32): the LDS table for d < 64 (entry 0 never passes: d <= 0 flips anyway), else the plan's
+                const int dd = d < 1 ? 1 : d;
+                bool lt = x < swapT[i * kSwapFast + (dd < kSwapFast ? dd : 0)];
+                if (dd >= kSwapFast) lt = (uint64_t)x < a.swap_thr[(size_t)i * (nq + 1) + dd];
+                const bool flip = d <= 0 || lt;
                 const uint32_t into = flip ? lo : car;                               // what slot i+1 now holds (:98-99)
                 car = flip ? car : lo;
                 if ((int)slot == i + 1) mine = into;
@@ -440,7 +433,6 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
             if (slot == 0) flag = 0;                                                 // :103
         }
     }
-
     cx.n4 = n4; cx.cls = cls; cx.flag = flag; cx.tops0 = tops0; cx.samples = samples; cx.done = done; cx.conv_ok = conv_ok; cx.steps_done = steps_done;
 }
 
@@ -471,9 +463,9 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_wu_kernel(const LadderArgs 
     if (tid < 4) stopf[tid] = 0;
     for (int i = tid; i < NC * 18; i += nthreads) {
         const int c = i / 18, r = i - c * 18, hi = r < 9, idx = hi ? r : r - 9;
-        // dE <= 0 (idx <= 4): always accepted -- a high part no 16-bit uniform reaches; dE = 1..4: ceil(f^dE 2^48)
-        const uint64_t t48 = idx <= 4 ? (1ull << 48) : a.acc_thr48[c][idx - 5];
-        thrT[i] = hi ? (uint32_t)(t48 >> 32) : (uint32_t)t48;
+        // dE <= 0 (idx <= 4): always accepted -- a high part no 12-bit uniform reaches; dE = 1..4: ceil(f^dE 2^44)
+        const uint64_t t44 = idx <= 4 ? (1ull << 44) : a.acc_thr44[c][idx - 5];
+        thrT[i] = hi ? (uint32_t)(t44 >> 32) : (uint32_t)t44;
     }
     for (int i = tid; i < (NC - 1) * kSwapFast; i += nthreads) {
         const int pr = i / kSwapFast, d = i - pr * kSwapFast;
@@ -520,8 +512,13 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_wu_kernel(const LadderArgs 
     ev.lds0 = lds0; ev.thr_off = (uint32_t)((o.thr + (int)slot * 18) * 4); ev.slot = slot; ev.syn = syn; ev.grp = grp;
     ev.lane = lane; ev.cnt = cnt; ev.s0 = s0;
     // (the two roles are separate loops: they meet at the step's barriers)
-    if (top) wu_run<CODE, WV, CONV, true>(a, st, cx, ev);
-    else wu_run<CODE, WV, CONV, false>(a, st, cx, ev);
+    if (a.iters == 10u) {
+        if (top) wu_run<CODE, WV, CONV, true, 10>(a, st, cx, ev);
+        else wu_run<CODE, WV, CONV, false, 10>(a, st, cx, ev);
+    } else {
+        if (top) wu_run<CODE, WV, CONV, true, 0>(a, st, cx, ev);
+        else wu_run<CODE, WV, CONV, false, 0>(a, st, cx, ev);
+    }
     n4 = cx.n4; cls = cx.cls; flag = cx.flag; tops0 = cx.tops0; samples = cx.samples;
     const uint32_t done = cx.done, conv_ok = cx.conv_ok, steps_done = cx.steps_done;
     const uint32_t xaddr = lds0 + (uint32_t)lane * 4u;

@@ -61,13 +61,6 @@ inline uint64_t thr44(double v)
     if (!(v > 0.0)) return 0;
     return (uint64_t)std::ceil(v * 17592186044416.0);
 }
-// ceil(v * 2^48): scan = 3's acceptance uniform (16 bits, completed by a 32-bit word when they tie with the threshold's)
-inline uint64_t thr48(double v)
-{
-    if (!(v < 1.0)) return 1ull << 48;
-    if (!(v > 0.0)) return 0;
-    return (uint64_t)std::ceil(v * 281474976710656.0);
-}
 inline uint32_t thr32(double v)
 {
     const uint64_t t = thr64(v);
@@ -205,7 +198,7 @@ inline std::vector<uint64_t> swap_thresholds(const std::vector<double> &pdiff, i
     return sw;
 }
 
-// scan = 3 (QECMC_SCAN_WAVE, ladder_wu.hpp): one 48-byte descriptor per generator, read with scalar loads by a wavefront whose
+// scan = 3 (QECMC_SCAN_WAVE, ladder_wu.hpp): one 64-byte descriptor per generator (one cache line; 12 dwords used), read with scalar loads by a wavefront whose
 // 64 ladders test that generator together.  dwords 0-3: site i as (state word) | (bit shift) << 8; 4-7: the value to xor into
 // that word (Pauli << shift; a site that does not exist: 0, on word 0); 8, 9: the error-count change of a site as a 4-entry byte
 // table indexed by its old 2-bit field, 4 (1 + change) -- 8 for an identity, 0 for the generator's own Pauli, else 4 -- for the
@@ -215,7 +208,7 @@ inline std::vector<uint64_t> swap_thresholds(const std::vector<double> &pdiff, i
 inline std::vector<uint32_t> wave_descriptors(const std::vector<uint32_t> &gt)
 {
     const size_t G = gt.size() / 2;
-    std::vector<uint32_t> d(12 * G, 0u);
+    std::vector<uint32_t> d(16 * G, 0u);
     auto table = [](uint32_t P) { uint32_t t = 0; for (uint32_t f = 0; f < 4; ++f) t |= (f == 0 ? 8u : f == P ? 0u : 4u) << (8 * f); return t; };
     for (size_t g = 0; g < G; ++g) {
         uint32_t pa = 0, pb = 0;
@@ -234,18 +227,18 @@ inline std::vector<uint32_t> wave_descriptors(const std::vector<uint32_t> &gt)
         for (int u = 0; u < 4; ++u) {
             const uint32_t P = e[u] & 3u, q = e[u] >> 2;
             if (P) {
-                d[12 * g + u] = (q >> 4) | (((q & 15u) * 2u) << 8);
-                d[12 * g + 4 + u] = P << ((q & 15u) * 2u);
+                d[16 * g + u] = (q >> 4) | (((q & 15u) * 2u) << 8);
+                d[16 * g + 4 + u] = P << ((q & 15u) * 2u);
                 amask |= 3u << (8 * u);
                 if (P != pa) omask |= 4u << (8 * u);
             } else {
                 omask |= neutral << (8 * u);
             }
         }
-        d[12 * g + 8] = table(pa);
-        d[12 * g + 9] = pb ? table(pb) : table(pa);
-        d[12 * g + 10] = omask;
-        d[12 * g + 11] = amask;
+        d[16 * g + 8] = table(pa);
+        d[16 * g + 9] = pb ? table(pb) : table(pa);
+        d[16 * g + 10] = omask;
+        d[16 * g + 11] = amask;
     }
     return d;
 }

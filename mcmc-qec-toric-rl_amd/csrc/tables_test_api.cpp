@@ -25,7 +25,6 @@ int qt_logical_masks(int code, int L, int W, uint32_t *out, int cap)
     return put(code == QECMC_TORIC ? toric_logical_masks(L, W) : surf_logical_masks(code, L, W), out, cap);
 }
 int qt_wave_descriptors(int code, int L, uint32_t *out, int cap) { return put(wave_descriptors(gen_table(code, L)), out, cap); }
-uint64_t qt_thr48(double v) { return thr48(v); }
 uint64_t qt_thr64(double v) { return thr64(v); }
 uint64_t qt_thr44(double v) { return thr44(v); }
 uint32_t qt_thr32(double v) { return thr32(v); }

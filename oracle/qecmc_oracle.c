@@ -550,12 +550,16 @@ static void chain_update_colour(const orc_model *m, uint8_t *state, double p, do
 /* scan = 3 ("wave"): the reference's random-scan chain (mcmc.py:19-43) with a generator pick SHARED by the 64 ladders whose global
  * indices agree above bit 6 (a GPU wavefront): the pick does not depend on the state (toric_model.py:287-296) and ladders of different
  * syndromes never interact, so every ladder keeps exactly the reference's law; only the noise of different syndromes is correlated.
- * Philox addressing, slot c, proposal k (the ladder's streams are its slots': no diagonal streams here):
- *   pick    words A, B = 2 (k & 1), 2 (k & 1) + 1 of block (k >> 1, sub 9) with ctr[2] = syndrome >> 6, stream 0x800 + c:
- *           g = floor(B G / 2^32).  Top chain (p_logical != 0; it must accept every move, p >= 0.75): logical iff
- *           A[31:16] < p_logical 2^16, the operator's fields cut from A[15:0] and B as in the packed layout of scan = 0;
- *   accept  a16 = half (k & 1) (low half first) of word (k & 7) >> 1 of block (k >> 3, sub 10) of the ladder's own index, stream c;
- *           w32 = word k & 3 of block (k >> 2, sub 11); u = (a16 2^32 + w32) 2^-48 < f^dE (mcmc.py:42). */
+ * Philox addressing by ladder step T = k0 / iters and proposal j of the step (1 <= iters <= 128; the ladder's streams are its
+ * slots': no diagonal streams here), slot c:
+ *   pick    S = 128 / iters steps share a window: w = T / S, P = (T % S) iters + j; words A, B = 2 (P & 1), 2 (P & 1) + 1 of block
+ *           (64 w + (P >> 1), sub 9) with ctr[2] = syndrome >> 6, stream 0x800 + c:  g = floor(B G / 2^32).  Top chain (p_logical != 0;
+ *           it must accept every move, p >= 0.75): logical iff A[31:16] < p_logical 2^16, the operator's fields cut from A[15:0]
+ *           and B as in the packed layout of scan = 0;
+ *   accept  ten proposals share block (T ceil(iters / 10) + j / 10, sub 10) of the ladder's own index, stream c: field f = j % 10 is
+ *           a12 = bits 12 (f & 1) .. + 11 of word f >> 1 (f < 8), byte 3 of word 0 | low nibble of byte 3 of word 1 << 8 (f = 8), the
+ *           same of words 2, 3 (f = 9); w32 = word j & 3 of block (T ceil(iters / 4) + (j >> 2), sub 11);
+ *           u = (a12 2^32 + w32) 2^-44 < f^dE (mcmc.py:42). */
 static void wave_block(const orc_rng *rng, uint32_t synd_word, uint32_t stream, uint64_t k, uint32_t sub, uint32_t out[4])
 {
     const uint32_t ctr[4] = {(uint32_t)k, (uint32_t)((k >> 32) & 0xFFFFu) | (sub << 16), synd_word, stream};
@@ -599,11 +603,13 @@ static void chain_update_wave(const orc_model *m, uint8_t *state, double p, doub
     const int G = m->code == ORC_TORIC ? 2 * m->L * m->L : orc_surf_ngen(m->code, m->L);
     if (rng->mode == 0) abort();                       /* a Philox-mode rule */
     if (p_logical != 0 && !(p >= 0.75)) abort();       /* the top chain of scan = 3 accepts every move */
+    if (iters < 1 || iters > 128) abort();
+    const uint64_t T = k0 / iters, S = 128 / iters, nch = (iters + 9) / 10, nc4 = (iters + 3) / 4;
     for (uint64_t j = 0; j < iters; ++j) {
-        const uint64_t k = k0 + j;
+        const uint64_t P = (T % S) * iters + j;
         uint32_t pw[4];
-        wave_block(rng, rng->syndrome >> 6, 0x800u + slot, k >> 1, 9u, pw);
-        const uint32_t A = pw[2 * (k & 1)], B = pw[2 * (k & 1) + 1];
+        wave_block(rng, rng->syndrome >> 6, 0x800u + slot, (T / S) * 64 + (P >> 1), 9u, pw);
+        const uint32_t A = pw[2 * (P & 1)], B = pw[2 * (P & 1) + 1];
         const int g = (int)(((uint64_t)B * (uint32_t)G) >> 32);
         rng->consumed += 2;
         if (p_logical != 0) {                                      /* mcmc.py:20-31 at p >= 0.75 */
@@ -614,11 +620,13 @@ static void chain_update_wave(const orc_model *m, uint8_t *state, double p, doub
         }
         const int dE = model_sweep_stabilizer(m, state, scratch, (uint64_t)g);   /* :38-40 */
         uint32_t aw[4], rw[4];
-        wave_block(rng, rng->syndrome, slot, k >> 3, 10u, aw);
-        wave_block(rng, rng->syndrome, slot, k >> 2, 11u, rw);
-        const uint32_t word = aw[(k & 7) >> 1], a16 = (k & 1) ? word >> 16 : word & 0xFFFFu;
-        const double u = ((double)a16 * 4294967296.0 + (double)rw[k & 3]) / 281474976710656.0;   /* 48 bits: exact */
-        if (u < pow(factor, (double)dE)) memcpy(state, scratch, nq);                               /* :42 */
+        wave_block(rng, rng->syndrome, slot, T * nch + j / 10, 10u, aw);
+        wave_block(rng, rng->syndrome, slot, T * nc4 + (j >> 2), 11u, rw);
+        const int f = (int)(j % 10);
+        const uint32_t a12 = f < 8 ? (aw[f >> 1] >> (12 * (f & 1))) & 0xFFFu
+                                   : ((aw[f == 8 ? 0 : 2] >> 24) | (((aw[f == 8 ? 1 : 3] >> 24) & 0xFu) << 8));
+        const double u = ((double)a12 * 4294967296.0 + (double)rw[j & 3]) / 17592186044416.0;   /* 44 bits: exact */
+        if (u < pow(factor, (double)dE)) memcpy(state, scratch, nq);                              /* :42 */
     }
 }
 

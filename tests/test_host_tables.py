@@ -31,7 +31,6 @@ def T():
     lib = C.CDLL(path)
     lib.qt_thr64.restype = C.c_uint64; lib.qt_thr64.argtypes = [C.c_double]
     lib.qt_thr44.restype = C.c_uint64; lib.qt_thr44.argtypes = [C.c_double]
-    lib.qt_thr48.restype = C.c_uint64; lib.qt_thr48.argtypes = [C.c_double]
     lib.qt_thr32.restype = C.c_uint32; lib.qt_thr32.argtypes = [C.c_double]
     lib.qt_chain_factor.restype = C.c_double; lib.qt_chain_factor.argtypes = [C.c_double]
     return lib
@@ -186,11 +185,11 @@ def test_wave_descriptors_are_the_oracles_stencil(T, code, L):
     random packed states: new configuration and error-count change."""
     nq = _nq(code, L)
     W = (nq + 15) // 16
-    buf = np.zeros(12 * 4096, np.uint32)
+    buf = np.zeros(16 * 4096, np.uint32)
     n = T.qt_wave_descriptors(code, L, _ptr(buf, C.c_uint32), buf.size)
     G = 2 * L * L if code == TORIC else orc.surf_ngen(ORC_CODE[code], L)
-    assert n == 12 * G
-    d = buf[:n].reshape(G, 12)
+    assert n == 16 * G
+    d = buf[:n].reshape(G, 16)
     rng = np.random.default_rng(L * 5 + code)
     for g in rng.permutation(G)[:40]:
         m = rng.integers(0, 4, size=_zero(code, L).shape).astype(np.uint8)
@@ -220,15 +219,6 @@ def test_wave_descriptors_are_the_oracles_stencil(T, code, L):
             ref, dE = orc.surf_apply_stabilizer(ORC_CODE[code], m, *orc.surf_gen_rco(ORC_CODE[code], L, int(g)))
         assert np.array_equal(new, ref)
         assert dE4 == 4 * (dE + 4)
-
-
-def test_thr48_decides_like_the_floating_point_test(T):
-    rng = np.random.default_rng(4)
-    for v in list(rng.random(200)) + [1e-9, 2.0 ** -48, 0.999999999, 1.0, 1.5, 0.0]:
-        t = T.qt_thr48(float(v))
-        for x in (t - 1, t, t + 1):
-            if 0 <= x < (1 << 48):
-                assert (x < t) == (x / 2.0 ** 48 < v)
 
 
 def test_host_tables_under_asan_ubsan():

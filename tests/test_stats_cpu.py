@@ -285,11 +285,13 @@ def test_oracle_wave_scan_matches_exact_enumeration_L3(code, seed, p, Nc):
 def test_oracle_wave_scan_shares_its_picks_within_a_group_of_64_only():
     """A chain at f = 1 accepts every proposal (mcmc.py:42 with factor 1), so its trajectory IS its sequence of generator picks: the
     same for two ladders of one group of 64, different across groups and across slots; and every generator comes up equally often."""
-    L, iters = 5, 4000
+    L, iters, steps = 5, 10, 300
     zero = np.zeros((2, L, L), np.uint8)
     def run(syndrome, slot):
         m = zero.copy()
-        return orc.chain_update(orc.TORIC, m, 0.75, 0.0, iters, orc.Rng.philox(5, syndrome), slot=slot, k0=0, scan=3)
+        for T in range(steps):
+            m = orc.chain_update(orc.TORIC, m, 0.75, 0.0, iters, orc.Rng.philox(5, syndrome), slot=slot, k0=T * iters, scan=3)
+        return m
     a, b, c, d = run(64, 0), run(127, 0), run(128, 0), run(64, 1)
     assert np.array_equal(a, b) and not np.array_equal(a, c) and not np.array_equal(a, d)
     # uniform over the 2 L^2 generators: apply one proposal at a time from the empty lattice and identify the generator
@@ -305,25 +307,33 @@ def test_oracle_wave_scan_shares_its_picks_within_a_group_of_64_only():
     assert np.abs(hits - exp).max() < 5 * np.sqrt(exp)
 
 
-def test_oracle_wave_scan_acceptance_uniform_is_48_bits_against_the_reference_rule():
-    """One proposal of a cold chain: accepted iff a16 2^32 + w32 < ceil(f^dE 2^48) -- checked against a direct evaluation of
-    mcmc.py:42 on the same Philox words for a few thousand (syndrome, k)."""
+def test_oracle_wave_scan_acceptance_uniform_is_44_bits_against_the_reference_rule():
+    """One ladder step of a cold chain, proposal by proposal: accepted iff a12 2^32 + w32 < ceil(f^dE 2^44) -- checked against a direct
+    evaluation of mcmc.py:42 on the same Philox words for a few hundred (syndrome, step) and two values of iters."""
     L, p = 3, 0.2
     f = (p / 3.0) / (1.0 - p)
     rng = np.random.default_rng(3)
-    init = (rng.integers(1, 4, size=(2, L, L)) * (rng.random((2, L, L)) < 0.3)).astype(np.uint8)
-    n_acc = 0
-    for k in range(3000):
-        syn = int(rng.integers(0, 1 << 20))
-        out = orc.chain_update(orc.TORIC, init.copy(), p, 0.0, 1, orc.Rng.philox(21, syn), slot=1, k0=k, scan=3)
-        pw = orc.philox4x32_10([k >> 1, 9 << 16, syn >> 6, 0x800 + 1], [21, 0])
-        g = (int(pw[2 * (k & 1) + 1]) * 2 * L * L) >> 32
-        new, dE = orc.toric_apply_stabilizer(init, (g % (L * L)) // L, g % L, 1 if g < L * L else 3)
-        aw = orc.philox4x32_10([k >> 3, 10 << 16, syn, 1], [21, 0]); rw = orc.philox4x32_10([k >> 2, 11 << 16, syn, 1], [21, 0])
-        word = int(aw[(k & 7) >> 1]); a16 = (word >> 16) if (k & 1) else (word & 0xFFFF)
-        x = (a16 << 32) + int(rw[k & 3])
-        thr = (1 << 48) if f ** dE >= 1 else int(np.ceil((f ** dE) * 2.0 ** 48))
-        acc = x < thr
-        n_acc += acc
-        assert np.array_equal(out, new if acc else init)
-    assert 0 < n_acc < 3000
+    n_acc = n_all = 0
+    for it in range(300):
+        iters = (10, 7)[it & 1]
+        init = (rng.integers(1, 4, size=(2, L, L)) * (rng.random((2, L, L)) < 0.3)).astype(np.uint8)
+        syn, T = int(rng.integers(0, 1 << 20)), int(rng.integers(0, 5000))
+        out = orc.chain_update(orc.TORIC, init.copy(), p, 0.0, iters, orc.Rng.philox(21, syn), slot=1, k0=T * iters, scan=3)
+        S, nch, nc4 = 128 // iters, (iters + 9) // 10, (iters + 3) // 4
+        cur = init
+        for j in range(iters):
+            P = (T % S) * iters + j
+            pw = orc.philox4x32_10([(T // S) * 64 + (P >> 1), 9 << 16, syn >> 6, 0x800 + 1], [21, 0])
+            g = (int(pw[2 * (P & 1) + 1]) * 2 * L * L) >> 32
+            new, dE = orc.toric_apply_stabilizer(cur, (g % (L * L)) // L, g % L, 1 if g < L * L else 3)
+            aw = orc.philox4x32_10([T * nch + j // 10, 10 << 16, syn, 1], [21, 0]); rw = orc.philox4x32_10([T * nc4 + (j >> 2), 11 << 16, syn, 1], [21, 0])
+            fld = j % 10
+            a12 = (aw[fld >> 1] >> (12 * (fld & 1))) & 0xFFF if fld < 8 else (aw[0 if fld == 8 else 2] >> 24) | (((aw[1 if fld == 8 else 3] >> 24) & 0xF) << 8)
+            x = (a12 << 32) + int(rw[j & 3])
+            thr = (1 << 44) if f ** dE >= 1 else int(np.ceil((f ** dE) * 2.0 ** 44))
+            acc = x < thr
+            n_acc += acc; n_all += 1
+            if acc:
+                cur = new
+        assert np.array_equal(out, cur)
+    assert 0 < n_acc < n_all
