@@ -100,18 +100,20 @@ def profile_counters(args):
     written by tools/profile_round.sh around this same command): HBM bytes per launch and the issue / LDS utilisation.
     None when the workload differs from the profiled one."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cfg%d_pmc_summary.json" % args.config)))
-    if not files or args.scan != "random":
+    if not files:
         return None
     d = json.load(open(files[-1]))
     w = d.get("_workload", {})
-    same = all(w.get(k) == getattr(args, k) for k in ("code", "L", "Nc", "iters", "syndromes", "ladder_steps")) and w.get("p_logical", 0.5) == args.p_logical
+    same = (all(w.get(k) == getattr(args, k) for k in ("code", "L", "Nc", "iters", "syndromes", "ladder_steps")) and w.get("p_logical", 0.5) == args.p_logical
+            and w.get("scan", "random") == args.scan)
     if not same or "SQ_INSTS_VALU" not in d:
         return None
     wave_props = args.syndromes / 64 * args.Nc * args.iters * args.ladder_steps         # wave-proposals per launch
     cyc = d.get("GRBM_GUI_ACTIVE", 0) / 8.0                                              # per-XCD active cycles of the launch
     out = {"source": os.path.basename(files[-1]),
-           # 1-byte-per-lane loads (64 B per wave instruction): no x2 FETCH_SIZE correction applies, see profiles/README.md
-           "traffic": (d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0 if "FETCH_SIZE" in d and "WRITE_SIZE" in d else None,
+           # gfx950 counts FETCH_SIZE in units of 64 B where the counter's documentation says 32 B (MI355X_MICROARCH.md, HBM / rocprofv3
+           # section): the raw value times 2; WRITE_SIZE as reported.  (Round 3 printed the uncorrected sum, which sat below the compulsory bytes.)
+           "traffic": (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0 if "FETCH_SIZE" in d and "WRITE_SIZE" in d else None,
            "insts_per_wave_proposal": {"valu": d["SQ_INSTS_VALU"] / wave_props, "salu": d["SQ_INSTS_SALU"] / wave_props,
                                        "lds": d["SQ_INSTS_LDS"] / wave_props}}
     if cyc and "SQ_ACTIVE_INST_VALU" in d:
@@ -149,12 +151,14 @@ def cpu_model():
     return "unknown"
 
 
-def oracle_batch(args, init, steps, n_threads, first=0, states=False):
+def oracle_batch(args, init, steps, n_threads, first=0, states=False, scan=None):
+    """the CPU oracle on a sample of the batch: the checker of the timed pass (its scan) or the timed CPU baseline (scan = 0: the
+    reference's own loop, one pick per ladder -- a CPU has no wavefront to share a pick with)"""
     from oracle import oracle as orc
     code = {"toric": orc.TORIC, "xzzx": orc.XZZX, "rotated": orc.ROTATED, "planar": orc.PLANAR}[args.code]
     return orc.pteq_batch(code, init, args.p, args.Nc, steps, iters=args.iters, tops_burn=2, seed=args.seed, first_syndrome=first,
                           n_threads=n_threads, noise=orc.DEPOLARIZING if args.eta is None else orc.BIASED, eta=args.eta or 0.0, return_states=states,
-                          scan=3 if args.scan == "wave" else 0)
+                          scan=(3 if args.scan == "wave" else 0) if scan is None else scan)
 
 
 def cpu_baseline(args, init, n_gen, target_s=12.0):
@@ -162,13 +166,13 @@ def cpu_baseline(args, init, n_gen, target_s=12.0):
     box's host cores on a bounded sample of the same workload."""
     cores = os.cpu_count() or 1
     n_syn = min(init.shape[0], 4 * cores)
-    oracle_batch(args, init[:n_syn], 100, cores)                    # spin the threads up
+    oracle_batch(args, init[:n_syn], 100, cores, scan=0)            # spin the threads up
     t0 = time.perf_counter()
-    oracle_batch(args, init[:n_syn], 500, cores)                    # calibration
+    oracle_batch(args, init[:n_syn], 500, cores, scan=0)            # calibration
     dt = max(time.perf_counter() - t0, 1e-4)
     steps = int(max(500, min(200000, 500 * target_s / dt)))
     t0 = time.perf_counter()
-    oracle_batch(args, init[:n_syn], steps, cores)
+    oracle_batch(args, init[:n_syn], steps, cores, scan=0)
     dt = time.perf_counter() - t0
     proposals = n_syn * args.Nc * args.iters * steps
     return {"value": proposals / n_gen / dt, "unit": "chain-sweeps/s", "cores": cores, "cpu_model": cpu_model(), "kind": "port",
@@ -203,9 +207,10 @@ def parse_args(argv=None):
     ap.add_argument("--p-logical", type=float, default=0.5, help="top-chain logical rate (decoders.py:52 uses 0.5)")
     ap.add_argument("--code", default=None, choices=["toric", "xzzx", "rotated", "planar"])
     ap.add_argument("--eta", type=float, default=None, help="bias: selects the mcmc_biased chain (config 4)")
-    ap.add_argument("--scan", default="random", choices=["random", "sweep", "wave"],
-                    help="random = the reference's random-scan chain; wave = the same chain per syndrome with a generator pick shared by the 64 "
-                         "ladders of a wavefront (scan=3); sweep = systematic generator sweep (scan=1: not the reference's chain)")
+    ap.add_argument("--scan", default="auto", choices=["auto", "random", "sweep", "wave"],
+                    help="random = the reference's random-scan chain (scan=0); wave = the same chain per syndrome with a generator pick shared by the 64 "
+                         "ladders of a wavefront, states in registers (scan=3); auto = wave where it is built and the faster one (depolarizing rule, "
+                         "at most 16 packed state words per rung: toric L <= 11), else random; sweep = systematic generator sweep (scan=1: not the reference's chain)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--library", default=None, help="time another build of libqecmc.so (same ABI) instead of the in-tree one: A/B runs on one box")
     ap.add_argument("--flags", type=lambda v: int(v, 0), default=0, help="qecmc_params.flags: developer switches between equivalent kernel variants (include/qecmc.h)")
@@ -217,6 +222,10 @@ def parse_args(argv=None):
     for k in ("code", "L", "p", "Nc", "syndromes", "eta"):
         if getattr(args, k) is None:
             setattr(args, k, cfg[k])
+    if args.scan == "auto":
+        nq = (2 if args.code in ("toric", "planar") else 1) * args.L * args.L
+        # scan = wave where same-box A/B runs have it ahead (profiles/r04_wave_ab.json): rung states of at most 16 words keep 8 waves per SIMD
+        args.scan = "wave" if (args.eta is None and args.Nc >= 2 and (nq + 15) // 16 <= 16 and args.iters <= 128 and args.syndromes % 64 == 0) else "random"
     return args
 
 
@@ -366,13 +375,14 @@ def main():
                               % (init_h.nbytes / 1e6, sh.rec.numel() * 4 / 1e6),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pc.get("traffic"),
-                         "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE+WRITE_SIZE, profiles/)",
+                         "traffic_unit": "bytes per launch (rocprofv3 2 x FETCH_SIZE + WRITE_SIZE: the gfx950 correction of MI355X_MICROARCH.md; profiles/)",
+                         "compulsory_bytes_per_launch": N * (nq + 4 * ncls + 8),
                          "algorithmic_bytes_per_launch": algo_bytes,
                          # what actually binds (instruction issue and the LDS array), from the committed PMC passes of this workload
                          "counters": {k: v for k, v in pc.items() if k != "traffic"} or None,
-                         "note": "algorithmic bytes = 8 B/proposal + N*(nq+4*ncls) (SURVEY.md 8d); the state is "
-                                 "LDS-resident so real HBM traffic is ~N*(nq+4*ncls+8) B per launch and the binding "
-                                 "resource is instruction issue (Philox) with the LDS array close behind, see DESIGN.md"},
+                         "note": "algorithmic bytes = 8 B/proposal + N*(nq+4*ncls) (SURVEY.md 8d); the states are on-chip (registers / LDS), "
+                                 "so real HBM traffic is the compulsory N*(nq+4*ncls+8) B per launch and the binding resource is instruction "
+                                 "issue, see DESIGN.md"},
             "mixing": {"frac_syndromes_past_burn_in": float(np.mean(samples > 0)),
                        "mean_tops0": float(np.mean(tops0)), "frac_tops0_ge_10": float(np.mean(tops0 >= 10))},
         }
@@ -402,6 +412,27 @@ def main():
                                                                                            np.array_equal(again["counts"], ref["counts"])),
                                           "match": bool(same and np.array_equal(tops0[:n_chk].astype(np.uint64), ref["tops0"].astype(np.uint64)) and
                                                         np.array_equal(again["states"], ref["states"]))}
+        if world == 1 and args.scan == "wave":
+            # the same batch through the scan = 0 kernel (the chain pinned draw for draw to the reference's injected-stream fixtures), for the record
+            pr0 = L_.make_params(code=code_id, L=L, Nc=Nc, p=args.p, p_logical=args.p_logical, iters=args.iters, steps=args.ladder_steps, tops_burn=2,
+                                 seed=args.seed, device=local_rank, scan=L_.SCAN_RANDOM, flags=args.flags)
+            plan0 = C.c_void_p()
+            L_.check(L_.lib().qecmc_plan_create(pr0, C.byref(plan0)))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ms0 = []
+            for rep in range(3):
+                e0.record(stream)
+                L_.check(L_.lib().qecmc_pteq_launch_dev(plan0, sh.d_init.data_ptr(), N, first, d_counts.data_ptr(), d_samples.data_ptr(), d_tops0.data_ptr(),
+                                                        None, None, None, None, 0, C.c_void_p(stream.cuda_stream)))
+                e1.record(stream)
+                torch.cuda.synchronize()
+                ms0.append(e0.elapsed_time(e1))
+            L_.lib().qecmc_plan_destroy(plan0)
+            m0 = float(np.mean(ms0[1:]))
+            out["random_scan"] = {"note": "scan = 0 on the same batch: one generator pick per ladder and proposal, states in LDS (the kernel of rounds 1-3)",
+                                  "kernel_ms_per_launch": m0, "proposals_per_s": proposals_per_pass / (m0 * 1e-3),
+                                  "chain_sweeps_per_s": proposals_per_pass / n_gen / (m0 * 1e-3),
+                                  "roofline_frac": algo_bytes / (m0 * 1e-3) / 1e9 / HBM_PEAK_GBS}
         if world == 1 and toric and args.scan == "random" and args.eta is None and args.sweep:
             # the library's second scan mode on the same batch, for the record (`value` above is the reference's chain)
             pr2 = L_.make_params(code=code_id, L=L, Nc=Nc, p=args.p, p_logical=args.p_logical, iters=args.iters,
@@ -413,7 +444,7 @@ def main():
             for rep in range(2):
                 e0.record(stream)
                 L_.check(L_.lib().qecmc_pteq_launch_dev(plan2, sh.d_init.data_ptr(), N, first, d_counts.data_ptr(),
-                                                        d_samples.data_ptr(), d_tops0.data_ptr(), None, None, None, None,
+                                                        d_samples.data_ptr(), d_tops0.data_ptr(), None, None, None, None, 0,
                                                         C.c_void_p(stream.cuda_stream)))
                 e1.record(stream)
                 torch.cuda.synchronize()

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define QECMC_ABI_VERSION 3
+#define QECMC_ABI_VERSION 4
 
 typedef enum qecmc_status {
     QECMC_OK = 0,
@@ -57,7 +57,11 @@ typedef enum qecmc_code { QECMC_TORIC = 0, QECMC_XZZX = 1, QECMC_ROTATED = 2, QE
  * generator independently of the state and syndromes never interact, so each ladder's chain has exactly the reference's law -- unlike
  * SWEEP / COLOUR this IS the reference's Markov chain per syndrome; only the noise of different syndromes is correlated.  What it buys:
  * a proposal's sites are wave-uniform, so the rungs' states live in registers.  Depolarizing rule, a top rung at
- * p = 0.75 (Nc >= 2), first_syndrome a multiple of 64, toric L <= 16 / xzzx, rotated L <= 22. */
+ * p = 0.75 (Nc >= 2), first_syndrome a multiple of 64, at most 16 packed state words per rung (toric / planar L <= 11, xzzx / rotated
+ * L <= 16: beyond, the RANDOM kernels are as fast), 1 <= iters <= 128.  With conv_mode error_based the launch runs on a persistent grid
+ * whose workgroups own contiguous shares of the batch and reuse the lane of a stopped ladder for the next one of their share: the
+ * generator picks then belong to the lane's position in the grid, so results are reproducible for a given (batch size, grid,
+ * first_syndrome) and equal to the one-ladder-per-lane layout whenever the batch fits the grid; no final states in that mode. */
 typedef enum qecmc_scan { QECMC_SCAN_RANDOM = 0, QECMC_SCAN_SWEEP = 1, QECMC_SCAN_COLOUR = 2, QECMC_SCAN_WAVE = 3 } qecmc_scan;
 typedef enum qecmc_noise { QECMC_NOISE_DEPOLARIZING = 0, QECMC_NOISE_BIASED = 1, QECMC_NOISE_ALPHA = 2 } qecmc_noise;
 typedef enum qecmc_conv { QECMC_CONV_NONE = 0, QECMC_CONV_ERROR_BASED = 1 } qecmc_conv;
@@ -265,7 +269,9 @@ int qecmc_ptdc_batch_xyz(const qecmc_params *params, const uint8_t *init, uint64
 
 /* Plan + device-pointer form: build once (validates, uploads threshold tables),
  * then launch asynchronously on a caller stream with buffers already in HBM.
- * d_workspace: qecmc_plan_workspace_bytes() bytes (0 for conv_mode NONE, then NULL is fine). */
+ * d_workspace / workspace_bytes: the criterion runs' log (decoders.py:68: nbr_errors_bottom_chain), qecmc_plan_workspace_bytes() bytes
+ * -- 0 for conv_mode NONE, then NULL / 0 is fine.  ABI 4: the size travels with the pointer and a buffer smaller than the launch
+ * needs is refused (QECMC_ERR_INVALID) before anything is enqueued; the library has ONE formula for it (capi.hip workspace_need). */
 typedef struct qecmc_plan qecmc_plan;
 int qecmc_plan_create(const qecmc_params *params, qecmc_plan **plan_out);
 int qecmc_plan_destroy(qecmc_plan *plan);
@@ -273,7 +279,8 @@ int qecmc_plan_workspace_bytes(const qecmc_plan *plan, uint64_t N, uint64_t *byt
 int qecmc_pteq_launch_dev(qecmc_plan *plan, const void *d_init, uint64_t N, uint32_t first_syndrome,
                           void *d_counts, void *d_samples, void *d_tops0 /*nullable*/,
                           void *d_steps_done /*nullable*/, void *d_converged /*nullable*/,
-                          void *d_final_states /*nullable*/, void *d_workspace /*nullable*/, void *hip_stream);
+                          void *d_final_states /*nullable*/, void *d_workspace /*nullable*/, uint64_t workspace_bytes,
+                          void *hip_stream);
 /* Optional per-syndrome equilibrium observables of the following launches of `plan` (device pointers, either nullable;
  * NULL, NULL switches them off again):
  *   d_swap_accepts uint32[N][Nc-1]: accepted swap tests of rung pair (i, i+1) (Ladder.step's r_flip, src/mcmc.py:96-99);

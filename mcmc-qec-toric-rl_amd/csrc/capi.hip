@@ -212,23 +212,25 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
         xyz_lut = count_change_table(patterns);
     }
     pl->lds_bytes = p->scan == QECMC_SCAN_COLOUR ? sizeof(uint32_t) * ((size_t)Nc * W + 4 * (size_t)Nc + (size_t)ncls)   // (ladder_colour.hip: one ladder per workgroup)
-                  : p->scan == QECMC_SCAN_WAVE ? wu_lds_bytes(Nc, W, ncls, L)
+                  : p->scan == QECMC_SCAN_WAVE ? wu_lds_bytes(Nc, W, ncls, L, p->conv_mode != 0)
                                                  : ladder_lds_bytes(L, Nc, W, ncls, ladder_gen_dwords(p->code, p->noise, p->scan, n_gen, Nc, nq, a.n_types));
     if (pl->lds_bytes > 160 * 1024)
         return fail(QECMC_ERR_UNSUPPORTED, "L=%d Nc=%d needs %zu B of LDS per workgroup (> 160 KiB)", L, Nc, pl->lds_bytes);
-    if (ladder_uses_queue(p->code, p->noise, p->scan, p->conv_mode, L, Nc, p->p_logical)) {
+    const bool wave_queue = p->scan == QECMC_SCAN_WAVE && p->conv_mode != 0;      // (ladder_wu.hpp: the workgroups' own work queues)
+    if (ladder_uses_queue(p->code, p->noise, p->scan, p->conv_mode, L, Nc, p->p_logical) || wave_queue) {
         // runs that stop by the convergence criterion: a persistent grid (what one launch keeps resident) fed from a counter
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, p->device));
         // (waves per CU: 8 per SIMD for the 512-thread depolarizing kernels, 4 for the 1024-thread ones and for the biased / alpha
         // queue kernels, which run at 128 VGPRs: ladder_biased.hip)
-        const size_t per_cu_lds = (160 * 1024) / pl->lds_bytes, per_cu_waves = (size_t)((Nc * 64 <= 512 && !p->noise) ? 32 : 16) / (size_t)Nc;
+        const size_t per_cu_lds = (160 * 1024) / pl->lds_bytes,
+                     per_cu_waves = (size_t)((Nc * 64 <= 512 && !p->noise && !(wave_queue && W > 16)) ? 32 : 16) / (size_t)Nc;
         size_t per_cu = per_cu_lds < per_cu_waves ? per_cu_lds : per_cu_waves;
         if (per_cu < 1) per_cu = 1;
         pl->queue_grid = (uint32_t)(per_cu * (size_t)prop.multiProcessorCount);
         if (p->flags >> 16) pl->queue_grid = p->flags >> 16;   // tests: force refills on small batches
         if (pl->queue_grid == 0) pl->queue_grid = 1;
-        HIP_TRY(pl->queue.alloc(sizeof(uint32_t)));
+        if (!wave_queue) HIP_TRY(pl->queue.alloc(sizeof(uint32_t)));
     }
 
     std::vector<double> pladder, pdiff;
@@ -274,10 +276,11 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
         // the wave-uniform random scan (ladder_wu.hpp): one scalar-loadable descriptor per generator; states in registers
         const std::vector<uint32_t> wd = wave_descriptors(gt);
         a.n_gen = (uint32_t)(gt.size() / 2);
-        pl->lds_bytes = wu_lds_bytes(Nc, W, ncls, L);
+        pl->lds_bytes = wu_lds_bytes(Nc, W, ncls, L, p->conv_mode != 0);
+        a.conv_mode = p->conv_mode;
         if (wd.empty() || !wu_supported(a) || pl->lds_bytes > 160 * 1024)
             return fail(QECMC_ERR_UNSUPPORTED, "scan = wave: L=%d Nc=%d p=%g is outside what it is built for (a top rung that accepts every move, at most "
-                        "32 packed state words per rung -- toric L <= 16, xzzx / rotated L <= 22 --, %zu B of LDS)", L, Nc, p->p, pl->lds_bytes);
+                        "16 packed state words per rung -- toric / planar L <= 11, xzzx / rotated L <= 16 --, %zu B of LDS)", L, Nc, p->p, pl->lds_bytes);
         HIP_TRY(pl->wu_desc.alloc(wd.size() * sizeof(uint32_t)));
         HIP_TRY(hipMemcpy(pl->wu_desc.p, wd.data(), wd.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         a.wu_desc = pl->wu_desc.as<uint32_t>();
@@ -714,19 +717,48 @@ int qecmc_plan_info(const qecmc_plan *plan, uint32_t *lds_bytes, uint32_t *block
     return 0;
 }
 
+// THE workspace formula of the criterion runs (the one place it lives): one log entry per (ladder step, column) -- the bottom chain's
+// error count (u16), or for alpha noise the two counts behind n_eff (2 x u16) -- with one column per ladder (rounded up to whole
+// 64-lane groups), or, when the launch runs on the plan's persistent grid with a work queue, one per lane of that grid.
+static bool launch_takes_queue(const qecmc_plan *plan, bool wants_states_or_stats)
+{
+    return plan->queue_grid != 0 && !wants_states_or_stats && plan->prm.steps > 0;
+}
+// the persistent grid a scan = wave criterion launch of M ladders runs on, and the ladders each of its workgroups owns
+static void wave_queue_shape(const qecmc_plan *plan, uint64_t M, uint32_t *grid, uint32_t *chunk)
+{
+    // (whole groups of 64 per workgroup: a batch that gives every ladder a lane of its own is laid out like a launch without the queue,
+    // ladder l in lane l & 63 of workgroup l >> 6, and gives the same results whatever the grid)
+    const uint64_t groups = (M + 63) / 64, g = std::max<uint64_t>(1, std::min<uint64_t>(plan->queue_grid, groups)), c = ((M + g - 1) / g + 63) / 64 * 64;
+    *chunk = (uint32_t)c;
+    *grid = (uint32_t)((M + c - 1) / c);
+}
+static uint64_t workspace_need(const qecmc_plan *plan, uint64_t N, bool queue)
+{
+    if (plan->prm.conv_mode != QECMC_CONV_ERROR_BASED) return 0;
+    const uint64_t M = N * plan->args.replicas;
+    uint64_t cols = (M + 63) / 64 * 64;
+    if (queue && plan->args.scan == QECMC_SCAN_WAVE) {
+        uint32_t grid, chunk;
+        wave_queue_shape(plan, M, &grid, &chunk);
+        cols = (uint64_t)grid * 64u;
+    } else if (queue) {
+        cols = std::min<uint64_t>(cols, (uint64_t)plan->queue_grid * 64u);
+    }
+    return (plan->prm.noise == QECMC_NOISE_ALPHA ? 4ull : 2ull) * cols * plan->prm.steps;
+}
+
 int qecmc_plan_workspace_bytes(const qecmc_plan *plan, uint64_t N, uint64_t *bytes_out)
 {
     if (!plan || !bytes_out) return fail(QECMC_ERR_INVALID, "NULL argument");
-    // one log entry per (ladder step, syndrome): the bottom chain's error count (u16), or for alpha noise the two counts behind n_eff (2 x u16)
-    // (rounded up to whole 64-lane groups: the work-queue kernels keep one column per lane of their grid)
-    const uint64_t cols = (N * plan->args.replicas + 63) / 64 * 64;
-    *bytes_out = plan->prm.conv_mode == QECMC_CONV_ERROR_BASED ? (plan->prm.noise == QECMC_NOISE_ALPHA ? 4ull : 2ull) * cols * plan->prm.steps : 0ull;
+    // (enough for any launch of N syndromes with this plan: a launch that takes the work queue uses fewer columns)
+    *bytes_out = workspace_need(plan, N, false);
     return 0;
 }
 
 int qecmc_pteq_launch_dev(qecmc_plan *plan, const void *d_init, uint64_t N, uint32_t first_syndrome, void *d_counts,
                           void *d_samples, void *d_tops0, void *d_steps_done, void *d_converged, void *d_final_states,
-                          void *d_workspace, void *hip_stream)
+                          void *d_workspace, uint64_t workspace_bytes, void *hip_stream)
 {
     if (!plan) return fail(QECMC_ERR_INVALID, "plan is NULL");
     if (N == 0) return 0;
@@ -735,8 +767,14 @@ int qecmc_pteq_launch_dev(qecmc_plan *plan, const void *d_init, uint64_t N, uint
     if (M + first_syndrome > 0xFFFFFFFFull) return fail(QECMC_ERR_INVALID, "global ladder index (first_syndrome + N * replicas) exceeds 32 bits");
     if (plan->args.scan == QECMC_SCAN_WAVE && (first_syndrome & 63u))
         return fail(QECMC_ERR_INVALID, "scan = wave: first_syndrome=%u must be a multiple of 64 (a wavefront shares its generator picks)", first_syndrome);
-    if (plan->prm.conv_mode == QECMC_CONV_ERROR_BASED && !d_workspace)
-        return fail(QECMC_ERR_INVALID, "conv_mode error_based needs the workspace of qecmc_plan_workspace_bytes()");
+    const bool takes_queue = launch_takes_queue(plan, plan->d_swap_acc != nullptr || d_final_states != nullptr);
+    {
+        const uint64_t need = workspace_need(plan, N, takes_queue);
+        if (need && !d_workspace) return fail(QECMC_ERR_INVALID, "conv_mode error_based needs the workspace of qecmc_plan_workspace_bytes()");
+        if (workspace_bytes < need)
+            return fail(QECMC_ERR_INVALID, "workspace of %llu bytes, this launch logs %llu (qecmc_plan_workspace_bytes: 2 or 4 bytes per ladder step and column)",
+                        (unsigned long long)workspace_bytes, (unsigned long long)need);
+    }
     if (R > 1 && (plan->d_swap_acc || plan->d_nerr_sum)) return fail(QECMC_ERR_INVALID, "qecmc_plan_set_stats is per ladder: not with replicas > 1");
     if ((plan->d_swap_acc || plan->d_nerr_sum) && (uint64_t)plan->args.nq * plan->prm.steps > 0xFFFFFFFFull)
         return fail(QECMC_ERR_INVALID, "qecmc_plan_set_stats: nq * steps exceeds the 32-bit error-count sums");
@@ -763,7 +801,13 @@ int qecmc_pteq_launch_dev(qecmc_plan *plan, const void *d_init, uint64_t N, uint
     a.write_states = d_final_states != nullptr;
     a.N = M; a.first_syndrome = first_syndrome;
     a.step0 = 0; a.prop0 = 0; a.nsteps = plan->prm.steps; a.resume = 0;
-    if (plan->queue_grid && !a.swap_acc && !d_final_states && plan->prm.steps > 0) {
+    if (plan->args.scan == QECMC_SCAN_WAVE && plan->prm.conv_mode != QECMC_CONV_NONE && !takes_queue)
+        return fail(QECMC_ERR_UNSUPPORTED, "scan = wave runs the criterion on its persistent grid, where a ladder's lane is reused when it has stopped: no final "
+                    "states or per-ladder statistics with conv_mode error_based (and steps must be > 0)");
+    if (takes_queue && plan->args.scan == QECMC_SCAN_WAVE) {
+        // (the workgroups of the persistent grid own contiguous shares of the batch: no global counter)
+        wave_queue_shape(plan, M, &a.grid_cap, &a.wu_chunk);
+    } else if (takes_queue) {
         // (one launch at a time per plan: the counter belongs to the plan)
         HIP_TRY(hipMemsetAsync(plan->queue.p, 0, sizeof(uint32_t), strm));
         a.queue = plan->queue.as<uint32_t>();
@@ -829,13 +873,8 @@ int qecmc_pteq_batch_stats(const qecmc_params *params, const uint8_t *init, uint
     if (N == 0) return 0;
     if (!init || !counts_out || !samples_out) return fail(QECMC_ERR_INVALID, "NULL buffer");
     const size_t nq = pl->args.nq, Nc = pl->args.Nc, ncls = pl->args.ncls, R = pl->args.replicas;
-    uint64_t ws_bytes = 0;
-    qecmc_plan_workspace_bytes(pl, N, &ws_bytes);
-    if (pl->queue_grid && !swap_accepts_out && !nerr_sums_out && !final_states_out && pl->prm.steps > 0) {
-        // the work-queue kernels log one column per lane of the persistent grid, not per ladder
-        const uint64_t cols = std::min<uint64_t>((N * R + 63) / 64 * 64, (uint64_t)pl->queue_grid * 64u);
-        ws_bytes = (pl->prm.noise == QECMC_NOISE_ALPHA ? 4ull : 2ull) * cols * pl->prm.steps;   // (alpha noise logs the two counts behind n_eff)
-    }
+    // (the work-queue kernels log one column per lane of the persistent grid, not per ladder: workspace_need knows)
+    const uint64_t ws_bytes = workspace_need(pl, N, launch_takes_queue(pl, swap_accepts_out || nerr_sums_out || final_states_out));
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     if (ws_bytes > free_b / 2)
@@ -857,7 +896,7 @@ int qecmc_pteq_batch_stats(const qecmc_params *params, const uint8_t *init, uint
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, 0));
     int rc = qecmc_pteq_launch_dev(pl, di.p, N, params->first_syndrome, dc.p, ds.p, dt.p, dsd.p, dcv.p,
-                                   final_states_out ? df.p : nullptr, ws_bytes ? dw.p : nullptr, nullptr);
+                                   final_states_out ? df.p : nullptr, ws_bytes ? dw.p : nullptr, ws_bytes, nullptr);
     if (rc) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
     HIP_TRY(hipEventRecord(e1, 0));
     HIP_TRY(hipEventSynchronize(e1));

@@ -77,6 +77,7 @@ struct LadderArgs {
     uint32_t acc_thr[kMaxNc][4];   // ceil(f_c^dE * 2^32), dE = 1..4 (sweep mode: one 32-bit word per acceptance)
     uint64_t acc_thr44[kMaxNc][4]; // ceil(f_c^dE * 2^44): random scan, the 44-bit acceptance uniform of a non-top proposal
     const uint32_t *wu_desc;       // scan = 3: [n_gen][16] generator descriptors (tables.hpp wave_descriptors)
+    uint32_t wu_chunk;             // scan = 3, criterion runs on a persistent grid: ladders per workgroup (a multiple of 64; 0: one ladder per lane, no queue)
     float swap_inv_log2[kMaxNc];   // 1 / log2(p_diff[i]): first guess of the largest d with u < p_diff[i]^d (the table decides)
     int32_t swap_fast_ok;          // every swap threshold with d >= 1 fits 32 bits (false only if two rungs coincide)
     int L, Nc, W, nq, ncls;
@@ -144,7 +145,7 @@ inline size_t colour_lds_dwords(int Nc, int W, int ncls, uint32_t n_phases, uint
 hipError_t launch_ladder_rs_toric(const LadderArgs &a, hipStream_t stream);
 // scan = 3 (ladder_wu.hip): what it is built for, and the LDS of one workgroup
 bool wu_supported(const LadderArgs &a);
-size_t wu_lds_bytes(int Nc, int W, int ncls, int L);
+size_t wu_lds_bytes(int Nc, int W, int ncls, int L, bool conv);
 
 // byte-state primitive kernels (primitives.hip); all pointers are device pointers
 hipError_t launch_apply_stabilizer(int code, int L, uint64_t N, const uint8_t *in, uint8_t *out, const int32_t *rows,

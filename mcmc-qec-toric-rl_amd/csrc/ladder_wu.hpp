@@ -42,18 +42,16 @@ template <> struct WuVec<4> { typedef uint32_t type __attribute__((ext_vector_ty
 template <> struct WuVec<8> { typedef uint32_t type __attribute__((ext_vector_type(8))); };
 template <> struct WuVec<12> { typedef uint32_t type __attribute__((ext_vector_type(12))); };
 template <> struct WuVec<16> { typedef uint32_t type __attribute__((ext_vector_type(16))); };
-template <> struct WuVec<32> { typedef uint32_t type __attribute__((ext_vector_type(32))); };
 
 // The state registers are PINNED (the index mode addresses v[base + M0]) -- WV dwords ending at v63 (64-VGPR kernels) or at v127 --
 // and every access to them is an asm statement that names the pinned tuple as an operand: the compiler then keeps the value where
 // it is (any C++-level element access makes it a value of its own that is copied in and out of the pinned registers around every
 // statement).  An "i" operand gives the register number of a static element, v[%c[r]].
-template <int WV> constexpr int wu_base() { return WV == 32 ? 96 : 64 - WV; }
+template <int WV> constexpr int wu_base() { return 64 - WV; }
 #define WU_BY_WV(M)                                                                                                            \
     if constexpr (WV == 4) { M("{v[60:63]}") } else if constexpr (WV == 8) { M("{v[56:63]}") }                                 \
-    else if constexpr (WV == 12) { M("{v[52:63]}") } else if constexpr (WV == 16) { M("{v[48:63]}") } else { M("{v[96:127]}") }
-#define WU_EACH(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) M(16) M(17) M(18) M(19) \
-    M(20) M(21) M(22) M(23) M(24) M(25) M(26) M(27) M(28) M(29) M(30) M(31)
+    else if constexpr (WV == 12) { M("{v[52:63]}") } else { static_assert(WV == 16, "state widths: 4, 8, 12, 16 words"); M("{v[48:63]}") }
+#define WU_EACH(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
 
 template <int WV> __device__ __forceinline__ void wu_def(typename WuVec<WV>::type &st)
 {
@@ -156,13 +154,17 @@ __device__ __forceinline__ void wu_xor(typename WuVec<WV>::type &st, uint32_t d0
 #undef M
 }
 
-// LDS carve-up of one workgroup (dwords): the exchange buffer, records, swap bounds, histogram, acceptance rows, swap rows,
-// logical masks (+ 64: the frame reads a row with all 64 lanes), stop flag
-struct WuLds { int xbuf, rec, swd, hist, thr, swapT, lml, stop, total; };
-__host__ __device__ inline int wu_words(int W) { return W <= 4 ? 4 : W <= 8 ? 8 : W <= 12 ? 12 : W <= 16 ? 16 : 32; }   // WV: state words per rung, padded
-__host__ __device__ inline WuLds wu_lds(int Nc, int W, int ncls, int L)
+// LDS carve-up of one workgroup (dwords): the exchange buffer (W words per rung), records, swap uniforms, histogram, acceptance rows,
+// swap rows, logical masks (rows padded to WV words, + 64: the frame reads a row with all 64 lanes), stop / refill flags, and -- the
+// criterion kernels -- wave 0's per-ladder bookkeeping [kWuBk][64] and the refill mailbox [2][64]
+struct WuLds { int xbuf, rec, swd, hist, thr, swapT, lml, stop, bk, mail, bot, total; };
+constexpr int kWuBk = 13;      // tops0, samples, burn, conv_start, conv_streak, sumA lo / hi, sumB lo / hi, state (done | pending << 1 | has << 3),
+                               // steps_done, converged, the lane's ladder (QUEUE)
+__host__ __device__ inline int wu_words(int W) { return W <= 4 ? 4 : W <= 8 ? 8 : W <= 12 ? 12 : 16; }   // WV: state words per rung, padded
+__host__ __device__ inline int wu_words_min(int WV) { return WV == 4 ? 1 : WV - 3; }                     // the narrowest W a WV-word kernel serves
+__host__ __device__ inline WuLds wu_lds(int Nc, int W, int ncls, int L, bool conv)
 {
-    W = wu_words(W);               // (the kernel moves and masks whole WV-word states: the padding words stay zero)
+    const int WV = wu_words(W);
     WuLds o;
     o.xbuf = 0;
     o.rec = o.xbuf + Nc * W * 64;
@@ -171,8 +173,11 @@ __host__ __device__ inline WuLds wu_lds(int Nc, int W, int ncls, int L)
     o.thr = o.hist + ncls * 64;               // [Nc][2][9]: high 13 / low 32 bits of ceil(f^dE 2^44), dE + 4 = 0 .. 8
     o.swapT = o.thr + Nc * 18;
     o.lml = o.swapT + Nc * kSwapFast;
-    o.stop = o.lml + 4 * (L + 1) * W + 64;
-    o.total = o.stop + 4;
+    o.stop = o.lml + 4 * (L + 1) * WV + 64;
+    o.bk = o.stop + 4;
+    o.mail = o.bk + (conv ? kWuBk * 64 : 0);                 // [2][64] refill orders by step parity
+    o.bot = o.mail + (conv ? 2 * 64 : 0);                    // [2][64] the record that landed in rung 0, by step parity
+    o.total = o.bot + (conv ? 2 * 64 : 0);
     return o;
 }
 
@@ -186,14 +191,15 @@ __device__ __forceinline__ u32x4 wu_philox(uint64_t k, uint32_t sub, uint32_t sy
 
 typedef const uint32_t __attribute__((address_space(4))) *wu_const_ptr;
 typedef const uint32_t __attribute__((address_space(3))) *wu_lds_ptr;
+typedef uint32_t __attribute__((address_space(3))) *wu_lds_rw;
+
+constexpr uint32_t kWuDead = 0xFFFFFFFFu, kWuKeep = 0xFFFFFFFEu;      // refill mailbox: no ladder left for the lane / the lane keeps its ladder
 
 struct WuCtx { uint32_t n4, cls, flag, tops0, samples, done, conv_ok, steps_done; };
 struct WuEnv {
-    uint32_t *xbuf, *rec, *swd, *hist, *swapT, *lml;
-    volatile uint32_t *stopf;
-    uint32_t lds0, thr_off, slot, syn, grp;
-    int lane, cnt;
-    uint64_t s0;
+    uint32_t lds0, thr_off, lml_off, slot, grp, lad;    // lad: the lane's first ladder of this launch (kWuDead: none)
+    int lane;
+    uint64_t chunk_hi;                                  // QUEUE: end of the workgroup's share of the batch
 };
 
 // field f (0 .. 9) of an acceptance block: twelve leading bits of a 44-bit uniform each -- two per word in bits 0-23, the last two
@@ -208,32 +214,88 @@ __device__ __forceinline__ uint32_t wu_field(const u32x4 &b, int f)
     return __builtin_amdgcn_perm(hi, lo, 0x0C0C0703u) & 0xFFFu;      // byte 3 of lo | byte 3 of hi << 8
 }
 
+// one Metropolis proposal of a rung below the top (mcmc.py:38-42) on the 64 ladders of the wave: the generator of descriptor e[0..11],
+// a12 = the lanes' leading acceptance bits.  The 12 bits decide unless they tie with the threshold's in some lane (once in 4096 per lane).
+template <int CODE, int WV>
+__device__ __forceinline__ void wu_propose(typename WuVec<WV>::type &st, uint32_t &n4, uint32_t a12, uint32_t thr_base, uint32_t nbias,
+                                           uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3,
+                                           uint32_t tlo, uint32_t thi, uint32_t omask, uint32_t amask,
+                                           uint64_t refine_k, uint32_t refine_w, uint32_t syn, uint32_t slot, uint32_t seed_lo, uint32_t seed_hi)
+{
+    const uint32_t F = wu_read<WV>(st, d0, d1, d2, d3);
+    uint32_t pv;
+    if constexpr (CODE == kCodeToric) pv = __builtin_amdgcn_perm(tlo, tlo, F & 0x03030303u);   // byte i: 4 (1 + change of the error count at site i)
+    else pv = __builtin_amdgcn_perm(thi, tlo, (F & amask) | omask);                            // (null sites and the second Pauli's half of the table)
+    const uint32_t addr = __builtin_amdgcn_sad_u8(pv, 0u, thr_base);                           // LDS address of this rung's threshold for dE
+    const uint32_t Th = *(wu_lds_ptr)(uintptr_t)addr;
+    bool acc = a12 < Th;
+    if (__builtin_amdgcn_uicmp(a12, Th, 32) != 0) {
+        const u32x4 rb = wu_philox(refine_k, kSubWuRefine, syn, slot, seed_lo, seed_hi);
+        const uint32_t Tl = *(wu_lds_ptr)(uintptr_t)(addr + 36u);
+        if (a12 == Th) acc = sel4(rb, (int)refine_w) < Tl;
+    }
+    if (acc) {
+        wu_xor<WV>(st, d0, d1, d2, d3, x0, x1, x2, x3);
+        n4 = n4 + addr + nbias;                                                                 // n += dE
+    }
+}
+
+// this rung's seed configuration of ladder `lad`, packed 2 bits per qubit, into the lane's column of the rung's rows of the exchange
+// buffer (Ladder.__init__ copies the seed into every rung, mcmc.py:72; resume: the rung's own state) -- a short runtime loop; the caller
+// then takes the words into its state registers with the exchange's own static reads.  Returns 4 x the error count and the class.
+template <int CODE>
+__device__ __forceinline__ void wu_stage_lds(const LadderArgs &a, uint64_t lad, uint32_t slot, wu_lds_rw xrow, uint32_t &n4, uint32_t &cls)
+{
+    const int NC = a.Nc, W = a.W, L = a.L, nq = a.nq;
+    const uint8_t *src = a.resume ? a.states + (lad * NC + slot) * (uint64_t)nq : a.init + (lad / a.replicas) * (uint64_t)nq;
+    uint32_t cnt = 0;
+#pragma unroll 1
+    for (int w = 0; w < W; ++w) {
+        uint32_t word = 0;
+#pragma unroll 4
+        for (int b = 0; b < 16; ++b) {
+            const int q = w * 16 + b;
+            if (q < nq) word |= (uint32_t)(src[q] & 3u) << (2 * b);
+        }
+        xrow[w * 64] = word;
+        cnt += nnz2(word);
+    }
+    n4 = 4u * cnt;
+    cls = (uint32_t)(CODE == kCodeToric ? toric_eq_class_b(L, src) : surf_eq_class_b(CODE, L, src));
+    if (CODE == kCodeXzzx) cls = cls == 0 ? 0u : cls == 1 ? 1u : cls == 2 ? 3u : 2u;   // the internal value v with class = v ^ (v >> 1)
+}
+
 // the step loop of one wave: TOP = the rung that accepts every move (its stabilizers unseen, its logical operators through a frame);
-// IT = 10: `iters` known at compile time (decoders.py:25 iters=10), the proposal loop unrolled without guards; IT = 0: any 1 <= iters <= 128
-template <int CODE, int WV, bool CONV, bool TOP, int IT>
+// IT = 10: `iters` known at compile time (decoders.py:25 iters=10), the proposal loop unrolled without guards; IT = 0: any 1 <= iters <= 128.
+// QUEUE (with CONV): a persistent grid; a lane whose ladder has ended takes the next one of its workgroup's share of the batch (in lane
+// order among the lanes that end together, so the assignment does not depend on timing): the acceptance and swap uniforms follow
+// the ladder (its index, its own step), the generator picks the lane's position (group, workgroup step).
+template <int CODE, int WV, bool CONV, bool QUEUE, bool TOP, int IT>
 __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::type &st, WuCtx &cx, const WuEnv &ev)
 {
+    static_assert(!QUEUE || CONV, "the work queue serves the runs that stop by the criterion");
     const int L = a.L;
-    uint32_t *const lml = ev.lml;
-    const uint32_t lds0 = ev.lds0, slot = ev.slot, syn = ev.syn, grp = ev.grp;
+    wu_lds_ptr const lml = (wu_lds_ptr)(uintptr_t)(ev.lds0 + ev.lml_off);
+    const uint32_t lds0 = ev.lds0, slot = ev.slot, grp = ev.grp;
     const int lane = ev.lane;
-    const uint64_t s0 = ev.s0;
-    const bool live = lane < ev.cnt;
     constexpr bool top = TOP;
     const uint32_t G = a.n_gen;
     const uint32_t m55 = 0x55555555u;
-    uint32_t n4 = cx.n4, cls = cx.cls, flag = cx.flag, tops0 = cx.tops0, samples = cx.samples;
-    [[maybe_unused]] uint32_t burn = 0, conv_start = 0, conv_streak = 0, done = 0, conv_ok = 0, steps_done = 0;
-    [[maybe_unused]] uint64_t sumA = 0, sumB = 0;
+    uint32_t n4 = cx.n4, cls = cx.cls, flag = cx.flag;
+    uint32_t syn = a.first_syndrome + ev.lad;                                     // Philox ctr[2] of the lane's ladder
+    [[maybe_unused]] uint32_t t0 = 0;                                             // QUEUE: the workgroup step the lane's ladder started at
+    [[maybe_unused]] uint32_t tops0 = cx.tops0, samples = 0;                      // wave 0 of the fixed-length kernels: in registers
     const wu_const_ptr desc = (wu_const_ptr)a.wu_desc;
     const uint32_t iters = IT ? (uint32_t)IT : a.iters;
     const uint32_t nch = (iters + 9u) / 10u, nc4 = (iters + 3u) / 4u;             // acceptance / refinement blocks per step
     const uint32_t S = 128u / iters;                                              // ladder steps per pick window (iters <= 128)
     const uint32_t thr16 = (uint32_t)((a.thr_logical + 65535u) >> 16);            // logical iff A[31:16] < thr16
     const uint32_t thr_base = lds0 + ev.thr_off;                                  // LDS byte address of this rung's threshold row
-    const uint32_t nbias = 0u - (thr_base + 16u);
+    uint32_t nbias = 0u - (thr_base + 16u);
+    asm volatile("" : "+s"(nbias));                                               // (one v_add3_u32 per accepted move: n4 + address + nbias)
     uint32_t pk = 0;                                                              // packed descriptor offsets of a pick window
     [[maybe_unused]] uint32_t pa0 = 0, pa1 = 0, pb0 = 0, pb1 = 0;                 // top rung: the window's words A, B
+    [[maybe_unused]] uint32_t pf_a = 0, pf_b = 0, pf_c = 0, pf_l = 0;             // the booking wave: log entries fetched ahead, for sample pf_l
     uint32_t ws = (uint32_t)(a.step0 % S);                                        // this step's index within its pick window
     uint64_t wi = a.step0 / S;                                                    // ... and the window's
     auto refresh = [&]() {
@@ -245,8 +307,10 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
     };
     refresh();
 
-    for (uint64_t t = 0; t < a.nsteps; ++t) {
-        const uint64_t T = a.step0 + t;
+    // (the criterion kernels book a step behind the barrier of the next one: without the queue one more, unbooked, step follows the last)
+    for (uint64_t t = 0; QUEUE || t < a.nsteps + (CONV ? 1u : 0u); ++t) {
+        // the ladder's own step: what addresses its acceptance and swap uniforms
+        const uint64_t T = QUEUE ? (uint64_t)((uint32_t)t - t0) : a.step0 + t;
         [[maybe_unused]] uint32_t maskv = 0, cdelta = 0;                           // top rung: the step's frame of logical operators (lane w: word w), class change
         const uint32_t pbase = ws * iters;                                         // the step's first proposal within the window
         for (uint32_t c = 0; c < nch; ++c) {
@@ -258,6 +322,7 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
             for (int f = 0; f < 10; ++f) {
                 if constexpr (IT == 0) { if ((uint32_t)f >= left) break; }
                 const uint32_t P = pbase + c * 10u + (uint32_t)f;                  // proposal of the window: lane P >> 1, half P & 1
+                if constexpr (!top && IT == 10) { if (f & 1) continue; }           // (done with its pair)
                 const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)pk, (int)(P >> 1));
                 const uint32_t off = (P & 1u) ? r >> 16 : r & 0xFFFFu;
                 const wu_const_ptr e = desc + (off >> 2);
@@ -290,30 +355,27 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
                         wu_xor<WV>(st, d0, d1, d2, d3, x0, x1, x2, x3);
                     }
                 } else {
-                    const uint32_t d0 = e[0], d1 = e[1], d2 = e[2], d3 = e[3], x0 = e[4], x1 = e[5], x2 = e[6], x3 = e[7];
-                    const uint32_t F = wu_read<WV>(st, d0, d1, d2, d3);
-                    uint32_t pv;
-                    if constexpr (CODE == kCodeToric) {
-                        const uint32_t tlo = e[8];
-                        pv = __builtin_amdgcn_perm(tlo, tlo, F & 0x03030303u);      // byte i: 4 (1 + change of the error count at site i)
+                    const uint32_t j = c * 10u + (uint32_t)f;
+                    if constexpr (IT == 10) {
+                        // (iters even: proposal parity = field parity; a lane of the window holds a pair: one readlane, both descriptors
+                        // fetched together, the second one's latency hidden behind the first proposal)
+                        if ((f & 1) == 0) {
+                            const wu_const_ptr eb = desc + ((r >> 16) >> 2);
+                            const uint32_t d0 = e[0], d1 = e[1], d2 = e[2], d3 = e[3], x0 = e[4], x1 = e[5], x2 = e[6], x3 = e[7], tlo = e[8];
+                            const uint32_t thi = CODE == kCodeToric ? 0u : e[9], om = CODE == kCodeToric ? 0u : e[10], am = CODE == kCodeToric ? 0u : e[11];
+                            const uint32_t b0 = eb[0], b1 = eb[1], b2 = eb[2], b3 = eb[3], y0 = eb[4], y1 = eb[5], y2 = eb[6], y3 = eb[7], ulo = eb[8];
+                            const uint32_t uhi = CODE == kCodeToric ? 0u : eb[9], on = CODE == kCodeToric ? 0u : eb[10], an = CODE == kCodeToric ? 0u : eb[11];
+                            __builtin_amdgcn_sched_barrier(0);
+                            wu_propose<CODE, WV>(st, n4, wu_field(ab, f), thr_base, nbias, d0, d1, d2, d3, x0, x1, x2, x3, tlo, thi, om, am,
+                                                 T * nc4 + (j >> 2), j & 3u, syn, slot, a.seed_lo, a.seed_hi);
+                            wu_propose<CODE, WV>(st, n4, wu_field(ab, f + 1), thr_base, nbias, b0, b1, b2, b3, y0, y1, y2, y3, ulo, uhi, on, an,
+                                                 T * nc4 + ((j + 1u) >> 2), (j + 1u) & 3u, syn, slot, a.seed_lo, a.seed_hi);
+                        }
                     } else {
-                        const uint32_t tlo = e[8], thi = e[9];
-                        pv = __builtin_amdgcn_perm(thi, tlo, (F & e[11]) | e[10]);  // (null sites and the second Pauli's half of the table)
-                    }
-                    const uint32_t addr = __builtin_amdgcn_sad_u8(pv, 0u, thr_base); // LDS address of this rung's threshold for dE
-                    const uint32_t Th = *(wu_lds_ptr)(uintptr_t)addr;
-                    const uint32_t a12 = wu_field(ab, f);
-                    bool acc = a12 < Th;
-                    if (__builtin_amdgcn_uicmp(a12, Th, 32) != 0) {
-                        // the 12 leading bits tie with the threshold's in some lane: the refinement word decides there
-                        const uint32_t j = c * 10u + (uint32_t)f;
-                        const u32x4 rb = wu_philox(T * nc4 + (j >> 2), kSubWuRefine, syn, slot, a.seed_lo, a.seed_hi);
-                        const uint32_t Tl = *(wu_lds_ptr)(uintptr_t)(addr + 36u);
-                        if (a12 == Th) acc = sel4(rb, (int)(j & 3u)) < Tl;
-                    }
-                    if (acc) {
-                        wu_xor<WV>(st, d0, d1, d2, d3, x0, x1, x2, x3);
-                        n4 = n4 + addr + nbias;                                     // n += dE
+                        const uint32_t d0 = e[0], d1 = e[1], d2 = e[2], d3 = e[3], x0 = e[4], x1 = e[5], x2 = e[6], x3 = e[7], tlo = e[8];
+                        const uint32_t thi = CODE == kCodeToric ? 0u : e[9], om = CODE == kCodeToric ? 0u : e[10], am = CODE == kCodeToric ? 0u : e[11];
+                        wu_propose<CODE, WV>(st, n4, wu_field(ab, f), thr_base, nbias, d0, d1, d2, d3, x0, x1, x2, x3, tlo, thi, om, am,
+                                             T * nc4 + (j >> 2), j & 3u, syn, slot, a.seed_lo, a.seed_hi);
                     }
                 }
             }
@@ -337,28 +399,31 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
         // ---- Ladder.step's swap sweep (mcmc.py:96-103)
         // (per-step work: its table addresses are formed here, from laundered copies of the shape, instead of being hoisted out of the
         // step loop and kept -- spilled -- in scalar registers across the proposal loop, which runs at 8 waves per SIMD on ~80 SGPRs)
-        int NCl = a.Nc, nql = a.nq, ncl = a.ncls, Ll = a.L;
+        int NCl = a.Nc, nql = a.nq, ncl = a.ncls, Ll = a.L, Wl = a.W;
         uint32_t slotl = ev.slot, lds0l = ev.lds0;
-        uint32_t *ldsl = ev.xbuf;
-        asm volatile("" : "+s"(NCl), "+s"(nql), "+s"(ncl), "+s"(Ll), "+s"(slotl), "+s"(lds0l), "+s"(ldsl));
-        const int NC = NCl, nq = nql;
+        asm volatile("" : "+s"(NCl), "+s"(nql), "+s"(ncl), "+s"(Ll), "+s"(slotl), "+s"(lds0l), "+s"(Wl));
+        const int NC = NCl, nq = nql, ncls = ncl;
         const uint32_t slot = slotl;
-        const WuLds ol = wu_lds(NC, WV, ncl, Ll);
-        uint32_t *const rec = ldsl + ol.rec, *const swd = ldsl + ol.swd, *const hist = ldsl + ol.hist, *const swapT = ldsl + ol.swapT;
-        volatile uint32_t *const stopf = ldsl + ol.stop;
+        const WuLds ol = wu_lds(NC, Wl, ncls, Ll, CONV);
+        // (LDS pointers by address space: a laundered generic pointer would turn every access below into a flat load)
+        wu_lds_rw const ldsl = (wu_lds_rw)(uintptr_t)lds0l;
+        wu_lds_rw const rec = ldsl + ol.rec, swd = ldsl + ol.swd, hist = ldsl + ol.hist, swapT = ldsl + ol.swapT;
+        volatile __attribute__((address_space(3))) uint32_t *const stopf = ldsl + ol.stop;
+        [[maybe_unused]] wu_lds_rw const bk = ldsl + ol.bk + (uint32_t)lane, mail = ldsl + ol.mail, bot = ldsl + ol.bot;
         const uint32_t xaddr = lds0l + (uint32_t)lane * 4u;
+        const uint32_t xstride = (uint32_t)Wl * 256u;                               // bytes of one rung in the exchange buffer
         const int swb = NC - 1 - (int)slot;                 // the top rungs draw the swap uniforms: block swb = pairs 4 swb .. 4 swb + 3
         u32x4 sb{0, 0, 0, 0};
         const bool duty = swb >= 0 && swb < 4 && swb * 4 < NC - 1;
         if (duty) sb = wu_philox(T, (uint32_t)swb, syn, kSwapStream, a.seed_lo, a.seed_hi);
         __syncthreads();                                   // (everybody has read the exchange buffer and the swap uniforms of the step before)
         {
-            const uint32_t xo = xaddr + slot * (uint32_t)(WV * 256);
-#define QECMC_WU_PUT(w) if constexpr (w < WV) wu_ds_write<WV, w>(st, xo);
+            const uint32_t xo = xaddr + slot * xstride;
+#define QECMC_WU_PUT(w) if constexpr (w < WV) { if (w < wu_words_min(WV) || w < Wl) wu_ds_write<WV, w>(st, xo); }
             WU_EACH(QECMC_WU_PUT)
             rec[slot * 64u + (uint32_t)lane] = pack_info(n4 >> 2, slot, cls, flag);
             if (duty) {
-                uint32_t *p = swd + (uint32_t)(swb * 4) * 64u + (uint32_t)lane;
+                wu_lds_rw p = swd + (uint32_t)(swb * 4) * 64u + (uint32_t)lane;
                 const int left = NC - 1 - swb * 4;
                 p[0] = sb.x;
                 if (left > 1) p[64] = sb.y;
@@ -371,7 +436,7 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
         if constexpr (CONV) { if (stopf[t & 1]) break; }    // (written by wave 0 during the step before: uniform for the workgroup)
         {
             // every wave replays the top-down cascade on the published records down to the rung that fills its own slot
-            const uint32_t *cur = rec + (uint32_t)lane, *sx = swd + (uint32_t)lane;
+            wu_lds_ptr cur = rec + (uint32_t)lane, sx = swd + (uint32_t)lane;
             uint32_t car = cur[(NC - 1) * 64], mine = car;
             const int i_stop = slot == 0 ? 0 : (int)slot - 1;
             for (int i = NC - 2; i >= i_stop; --i) {                                 // mcmc.py:96
@@ -388,55 +453,165 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
             }
             if (slot == 0) mine = car;
             // this rung's new state: the W words of the rung it comes from
-            const uint32_t xin = xaddr + ((mine >> 16) & 0xFFu) * (uint32_t)(WV * 256);
-#define QECMC_WU_TAKE(w) if constexpr (w < WV) wu_ds_read<WV, w>(st, xin);
+            const uint32_t xin = xaddr + ((mine >> 16) & 0xFFu) * xstride;
+#define QECMC_WU_TAKE(w) if constexpr (w < WV) { if (w < wu_words_min(WV) || w < Wl) wu_ds_read<WV, w>(st, xin); }
             WU_EACH(QECMC_WU_TAKE)
             wu_ds_wait<WV>(st);
             n4 = (mine & 0xFFFFu) << 2; cls = (mine >> 24) & 0x3Fu; flag = mine >> 31;
             if (top) flag = 1;                                                       // chains[-1].flag = 1, mcmc.py:100
-            if (slot == 0 && !done) {                                                // ladder + PTEQ bookkeeping on rung 0's new state
-                tops0 += (NC == 1) | flag;                                           // :101-102
-                const uint32_t n0 = mine & 0xFFFFu;
-                if (a.counts != nullptr && tops0 >= a.tops_burn) {                   // decoders.py:60-67
-                    hist[(CODE == kCodeXzzx ? (cls ^ (cls >> 1)) : cls) * 64 + lane] += 1;
-                    samples++;
-                    if (CONV && live) {
-                        // nbr_errors_bottom_chain[since_burn] = count_errors (:68), logged in HBM: series index i in row burn + i
-                        const size_t lN = (size_t)a.N;
-                        uint16_t *mylog = a.nlog + (s0 + lane);
-                        mylog[(size_t)t * lN] = (uint16_t)n0;
-                        const uint32_t l = samples, lo1 = l - 1;
-                        const uint32_t a0 = lo1 >> 2, b0 = lo1 >> 1, c0 = (3u * lo1) >> 2, a1 = l >> 2, b1 = l >> 1, c1 = (3u * l) >> 2;
-                        sumB += n0;
-                        if (c1 != c0) sumB -= mylog[(size_t)(burn + c0) * lN];
-                        if (b1 != b0) sumA += mylog[(size_t)(burn + b0) * lN];
-                        if (a1 != a0) sumA -= mylog[(size_t)(burn + a0) * lN];
+            if constexpr (!CONV) {
+                if (slot == 0) {                                                     // ladder + PTEQ bookkeeping on rung 0's new state
+                    tops0 += (NC == 1) | flag;                                       // :101-102
+                    if (a.counts != nullptr && tops0 >= a.tops_burn) {               // decoders.py:60-67
+                        hist[(CODE == kCodeXzzx ? (cls ^ (cls >> 1)) : cls) * 64 + lane] += 1;
+                        samples++;
+                    }
+                }
+            } else if (slot == 0) {
+                bot[((uint32_t)t & 1u) * 64u + (uint32_t)lane] = mine;              // (booked by the top rung's wave behind the next step's barrier)
+            }
+            if constexpr (CONV && TOP) {
+                // ---- ladder + PTEQ bookkeeping with the error_based criterion (decoders.py:60-82,93-105), by the wave of the TOP rung -- the
+                // one with the shortest step -- and one step behind: rung 0's wave leaves the record that landed in rung 0 at step tb in LDS
+                // (by step parity), and this wave books it behind the barrier of step tb + 1, off the critical path of the workgroup.  The
+                // per-ladder state lives in LDS between steps.
+                auto book = [&](uint64_t tb, uint64_t Tb) {
+                    const uint32_t recw = bot[((uint32_t)tb & 1u) * 64u + (uint32_t)lane];
+            // the same with the error_based criterion (decoders.py:74-82,93-105); the per-ladder state lives in LDS between steps
+            uint32_t b_tops0 = bk[0], b_samples = bk[64], b_burn = bk[128], b_cstart = bk[192], b_cstreak = bk[256], b_state = bk[576];
+            uint64_t sumA = (uint64_t)bk[320] | ((uint64_t)bk[384] << 32), sumB = (uint64_t)bk[448] | ((uint64_t)bk[512] << 32);
+            uint32_t has = (b_state >> 3) & 1u, pending = (b_state >> 1) & 3u, done = b_state & 1u;
+            const uint32_t Town = (uint32_t)Tb;                                  // the ladder's own step (of the step being booked)
+            bool ended = false;
+            uint32_t conv_ok = 0;
+            if (has && !done && !pending) {
+                b_tops0 += (NC == 1) | (recw >> 31);                                     // :101-102
+                const uint32_t n0 = recw & 0xFFFFu, cls0 = (recw >> 24) & 0x3Fu;
+                if (a.counts != nullptr && b_tops0 >= a.tops_burn) {             // decoders.py:60-67
+                    hist[(CODE == kCodeXzzx ? (cls0 ^ (cls0 >> 1)) : cls0) * 64 + lane] += 1;
+                    b_samples++;
+                    // nbr_errors_bottom_chain[since_burn] = count_errors (:68), logged in HBM: series index i in row burn + i of the
+                    // lane's column (QUEUE: a column per lane of the grid, rows = the ladder's own steps)
+                    const size_t lN = QUEUE ? (size_t)gridDim.x * 64u : (size_t)a.N;
+                    uint16_t *mylog = a.nlog + ((size_t)blockIdx.x * 64u + (size_t)lane);
+                    mylog[(size_t)Town * lN] = (uint16_t)n0;
+                    const uint32_t l = b_samples, lo1 = l - 1;
+                    const uint32_t a0 = lo1 >> 2, b0 = lo1 >> 1, c0 = (3u * lo1) >> 2, a1 = l >> 2, b1 = l >> 1, c1 = (3u * l) >> 2;
+                    // the (up to three) entries that leave / enter the windows Q2 = series[l/4 : l/2], Q4 = series[3l/4 : l]: old rows of the
+                    // log, i.e. HBM round trips -- fetched one sample ahead (below), so that they travel during the proposals of a step
+                    // instead of standing on this wave's path (samples below 8 read them in place: their rows are only just written)
+                    const bool ahead = pf_l == l && l >= 8u;
+                    uint32_t vc = pf_c, vb = pf_b, va = pf_a;
+                    if (!ahead) {
+                        vc = c1 != c0 ? mylog[(size_t)(b_burn + c0) * lN] : 0u;
+                        vb = b1 != b0 ? mylog[(size_t)(b_burn + b0) * lN] : 0u;
+                        va = a1 != a0 ? mylog[(size_t)(b_burn + a0) * lN] : 0u;
+                    }
+                    sumB += n0;
+                    sumB -= vc;
+                    sumA += vb;
+                    sumA -= va;
+                    {   // ... and the next sample's (the burn-in is over: its offset stays)
+                        const uint32_t l2 = l + 1u;
+                        const uint32_t a2 = l2 >> 2, b2 = l2 >> 1, c2 = (3u * l2) >> 2;
+                        pf_c = c2 != c1 ? mylog[(size_t)(b_burn + c1) * lN] : 0u;
+                        pf_b = b2 != b1 ? mylog[(size_t)(b_burn + b1) * lN] : 0u;
+                        pf_a = a2 != a1 ? mylog[(size_t)(b_burn + a1) * lN] : 0u;
+                        pf_l = l2;
                     }
                 } else {
-                    burn++;                                                          // resulting_burn_in, :71
+                    b_burn++;                                                    // resulting_burn_in, :71
                 }
-                if (CONV && tops0 >= a.TOPS) {                                       // :74
-                    const uint32_t l = samples ? samples : 1u;
+                if (b_tops0 >= a.TOPS) {                                         // :74
+                    const uint32_t l = b_samples ? b_samples : 1u;
                     const uint32_t den2 = (l >> 1) - (l >> 2), den4 = l - ((3u * l) >> 2);
-                    bool accept = false;                                             // empty slice -> nan -> not accepted
-                    if (samples && den2 && den4) accept = fabs((double)sumA / (double)den2 - (double)sumB / (double)den4) < a.eps;   // :96-102
+                    bool accept = false;                                         // empty slice -> nan -> not accepted
+                    if (b_samples && den2 && den4) accept = fabs((double)sumA / (double)den2 - (double)sumB / (double)den4) < a.eps;   // :96-102
                     if (accept) {
-                        if (conv_streak >= a.SEQ) { done = 1; conv_ok = 1; steps_done = (uint32_t)t + 1; }   // :77-78
-                        else conv_streak = tops0 - conv_start;                       // :79
+                        if (b_cstreak >= a.SEQ) { ended = true; conv_ok = 1; }   // :77-78
+                        else b_cstreak = b_tops0 - b_cstart;                     // :79
                     } else {
-                        conv_streak = 0;                                             // :81-82
-                        conv_start = tops0;
+                        b_cstreak = 0;                                           // :81-82
+                        b_cstart = b_tops0;
+                    }
+                }
+                if (QUEUE && !ended && (uint64_t)Town + 1u >= a.nsteps) ended = true;   // the horizon: `steps` of the ladder's own steps
+            }
+            if constexpr (QUEUE) {
+                if (pending) pending -= 1;                                       // (a lane between two ladders: the steps it idles are not booked)
+                uint32_t give = kWuKeep;
+                const uint64_t em = __ballot(ended);
+                if (ended) {
+                    // ---- a ladder that ended writes its results at once; its lane takes the workgroup's next one -- in lane order
+                    // among the lanes that end at the same step, so the assignment does not depend on timing
+                    const uint64_t row = (uint64_t)bk[768] / a.replicas;
+                    for (int cc = 0; cc < ncls; ++cc) {
+                        const uint32_t v = hist[cc * 64 + lane];
+                        hist[cc * 64 + lane] = 0;
+                        if (a.replicas > 1) { if (v) atomicAdd(a.counts + row * ncls + cc, v); }
+                        else a.counts[row * ncls + cc] = v;
+                    }
+                    const uint32_t sd = Town + 1u;
+                    if (a.replicas > 1) {
+                        atomicAdd(a.samples + row, b_samples);
+                        if (a.tops0 != nullptr) atomicAdd(a.tops0 + row, b_tops0);
+                        if (a.steps_done != nullptr) atomicMax(a.steps_done + row, sd);
+                        if (a.converged != nullptr && !conv_ok) a.converged[row] = 0;
+                    } else {
+                        a.samples[row] = b_samples;
+                        if (a.tops0 != nullptr) a.tops0[row] = b_tops0;
+                        if (a.steps_done != nullptr) a.steps_done[row] = sd;
+                        if (a.converged != nullptr) a.converged[row] = (uint8_t)conv_ok;
+                    }
+                    b_tops0 = b_samples = b_burn = b_cstart = b_cstreak = 0; sumA = sumB = 0;
+                    const uint32_t cand = (uint32_t)stopf[2] + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
+                    give = (uint64_t)cand < ev.chunk_hi ? cand : kWuDead;
+                    if (give == kWuDead) has = 0; else { pending = 2; bk[768] = give; }
+                }
+                // this step's orders: read by every wave behind the NEXT step's barrier (mailbox and flag by step parity)
+                mail[((uint32_t)tb & 1u) * 64u + (uint32_t)lane] = give;
+                if (lane == 0) { stopf[2] = (uint32_t)stopf[2] + (uint32_t)__popcll(em); }
+                if (__all(!has)) stopf[(tb + 2) & 1] = 1;
+            } else {
+                if (ended) { done = 1; bk[640] = Town + 1u; bk[704] = conv_ok; }   // steps_done, converged
+                if (__all(done || !has)) stopf[(tb + 2) & 1] = 1;
+            }
+            bk[0] = b_tops0; bk[64] = b_samples; bk[128] = b_burn; bk[192] = b_cstart; bk[256] = b_cstreak;
+            bk[320] = (uint32_t)sumA; bk[384] = (uint32_t)(sumA >> 32); bk[448] = (uint32_t)sumB; bk[512] = (uint32_t)(sumB >> 32);
+            bk[576] = done | (pending << 1) | (has << 3);
+                };
+                if (t > 0) book(t - 1, QUEUE ? (uint64_t)((uint32_t)(t - 1) - t0) : a.step0 + t - 1);
+            }
+
+            if (slot == 0) flag = 0;                                                 // :103
+        }
+        if constexpr (QUEUE) {
+            // ---- refill: the orders wave 0 wrote during the step before take effect here, behind this step's barrier: every wave stages
+            // its own rung of the lane's new ladder (the lane idled this step; its ladder's first step is the next one)
+            if (t > 1) {
+                const uint32_t give = mail[((uint32_t)t & 1u) * 64u + (uint32_t)lane];          // (the orders of the booking of step t - 2)
+                if (__builtin_amdgcn_uicmp(give, kWuKeep, 36) != 0) {                // (some lane has an order: give < kWuKeep -- ICMP_ULT)
+                    if (give < kWuKeep) {
+                        // (through the lane's own column of this rung's rows of the exchange buffer: whoever still reads that column reads it
+                        // for the same lane, whose state is being replaced in every wave)
+                        syn = a.first_syndrome + give;
+                        t0 = (uint32_t)t + 1u;
+                        wu_stage_lds<CODE>(a, (uint64_t)give, slot, ldsl + (slot * (uint32_t)Wl) * 64u + (uint32_t)lane, n4, cls);
+                        const uint32_t xme = xaddr + slot * xstride;
+#define QECMC_WU_MINE(w) if constexpr (w < WV) { if (w < wu_words_min(WV) || w < Wl) wu_ds_read<WV, w>(st, xme); }
+                        WU_EACH(QECMC_WU_MINE)
+#undef QECMC_WU_MINE
+                        wu_ds_wait<WV>(st);
+                        flag = top ? 1u : 0u;
                     }
                 }
             }
-            if (CONV && slot == 0 && __all(done || !live)) stopf[(t + 1) & 1] = 1;
-            if (slot == 0) flag = 0;                                                 // :103
         }
     }
-    cx.n4 = n4; cx.cls = cls; cx.flag = flag; cx.tops0 = tops0; cx.samples = samples; cx.done = done; cx.conv_ok = conv_ok; cx.steps_done = steps_done;
+    cx.n4 = n4; cx.cls = cls; cx.flag = flag; cx.tops0 = tops0; cx.samples = samples;
 }
 
-template <int MAXT, int MINW, int CODE, int WV, bool CONV>
+template <int MAXT, int MINW, int CODE, int WV, bool CONV, bool QUEUE, int IT>
 __global__ __launch_bounds__(MAXT, MINW) void ladder_wu_kernel(const LadderArgs a)
 {
     typedef typename WuVec<WV>::type vec_t;
@@ -445,22 +620,30 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_wu_kernel(const LadderArgs 
     const int nthreads = NC * 64;
     const int tid = (int)threadIdx.x, lane = tid & 63;
     const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);      // this wave's rung (fixed: states move)
-    const WuLds o = wu_lds(NC, W, ncls, L);
-    uint32_t *xbuf = lds + o.xbuf, *rec = lds + o.rec, *swd = lds + o.swd, *hist = lds + o.hist, *thrT = lds + o.thr;
+    const WuLds o = wu_lds(NC, W, ncls, L, CONV);
+    uint32_t *xbuf = lds + o.xbuf, *rec = lds + o.rec, *hist = lds + o.hist, *thrT = lds + o.thr;
     uint32_t *swapT = lds + o.swapT, *lml = lds + o.lml;
     volatile uint32_t *stopf = lds + o.stop;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(wu_lds_ptr)lds;                    // LDS byte address of the dynamic segment
     const uint32_t R = a.replicas;
-    const uint64_t s0 = (uint64_t)blockIdx.x * 64u;
-    const int cnt = a.N > s0 ? (int)((a.N - s0) < 64u ? (a.N - s0) : 64u) : 0;
-    const uint32_t syn = a.first_syndrome + (uint32_t)s0 + (uint32_t)lane;        // Philox ctr[2] of this ladder
-    const uint32_t grp = (a.first_syndrome + (uint32_t)s0) >> 6;                  // ... of the wavefront's shared picks
+    // the workgroup's share of the batch: 64 ladders, or -- QUEUE -- a.wu_chunk of them, taken 64 at a time
+    const uint64_t s0 = (uint64_t)blockIdx.x * (QUEUE ? (uint64_t)a.wu_chunk : 64u);
+    const uint64_t s1 = QUEUE ? (s0 + a.wu_chunk < a.N ? s0 + a.wu_chunk : a.N) : a.N;
+    const int cnt = s1 > s0 ? (int)((s1 - s0) < 64u ? (s1 - s0) : 64u) : 0;
     const bool live = lane < cnt;
     const bool top = slot == (uint32_t)(NC - 1);                                  // (the launcher guarantees that this rung accepts every move)
 
     // ---- tables
     for (int i = tid; i < ncls * 64; i += nthreads) hist[i] = 0;
-    if (tid < 4) stopf[tid] = 0;
+    if (tid < 4) stopf[tid] = tid == 2 ? (uint32_t)s0 + 64u : 0u;   // [0], [1]: stop, by step parity; [2]: the workgroup's queue (next unassigned ladder)
+    if constexpr (CONV) {
+        uint32_t *bk = lds + o.bk, *mail = lds + o.mail;
+        for (int i = tid; i < kWuBk * 64; i += nthreads) {
+            const int row = i >> 6, l = i & 63;
+            bk[i] = row == 9 ? (l < cnt ? 8u : 0u) : row == 12 ? (uint32_t)s0 + (uint32_t)l : 0u;                   // state: has; the lane's ladder
+        }
+        for (int i = tid; i < 128; i += nthreads) mail[i] = kWuKeep;
+    }
     for (int i = tid; i < NC * 18; i += nthreads) {
         const int c = i / 18, r = i - c * 18, hi = r < 9, idx = hi ? r : r - 9;
         // dE <= 0 (idx <= 4): always accepted -- a high part no 12-bit uniform reaches; dE = 1..4: ceil(f^dE 2^44)
@@ -480,52 +663,46 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_wu_kernel(const LadderArgs 
     vec_t st;
     wu_def<WV>(st);
     uint32_t n4 = 0, cls = 0, flag = top ? 1u : 0u;
-    {
-        const uint64_t ladder = s0 + (uint64_t)(live ? lane : 0);
-        const uint8_t *src = cnt > 0 ? (a.resume ? a.states + (ladder * NC + slot) * (uint64_t)nq : a.init + (ladder / R) * (uint64_t)nq) : nullptr;
-#define QECMC_WU_STAGE(w)                                                                                    \
-        if constexpr (w < WV) {                                                                              \
-            uint32_t word = 0;                                                                               \
-            if (w < W && cnt > 0)                                                                            \
-                for (int b = 0; b < 16; ++b) {                                                               \
-                    const int q = w * 16 + b;                                                                \
-                    if (q < nq) word |= (uint32_t)(src[q] & 3u) << (2 * b);                                  \
-                }                                                                                            \
-            wu_set<WV, w>(st, word);                                                                         \
-            n4 += 4u * nnz2(word);                                                                           \
-        }
-        WU_EACH(QECMC_WU_STAGE)
-#undef QECMC_WU_STAGE
-        if (cnt > 0) {
-            cls = (uint32_t)(CODE == kCodeToric ? toric_eq_class_b(L, src) : surf_eq_class_b(CODE, L, src));
-            if (CODE == kCodeXzzx) cls = cls == 0 ? 0u : cls == 1 ? 1u : cls == 2 ? 3u : 2u;   // the internal value v with class = v ^ (v >> 1)
-            if (a.resume) flag = a.flags[ladder * NC + slot];
-        }
+    const uint64_t ladder = s0 + (uint64_t)(live ? lane : 0);
+#define QECMC_WU_ZERO(w) if constexpr (w < WV) wu_set<WV, w>(st, 0u);
+    WU_EACH(QECMC_WU_ZERO)
+#undef QECMC_WU_ZERO
+    if (cnt > 0) {
+        wu_stage_lds<CODE>(a, ladder, slot, (wu_lds_rw)(uintptr_t)lds0 + (slot * (uint32_t)W) * 64u + (uint32_t)lane, n4, cls);
+        const uint32_t xme = lds0 + (uint32_t)lane * 4u + slot * (uint32_t)(W * 256);
+        const int Wl = W;
+#define QECMC_WU_MINE(w) if constexpr (w < WV) { if (w < wu_words_min(WV) || w < Wl) wu_ds_read<WV, w>(st, xme); }
+        WU_EACH(QECMC_WU_MINE)
+#undef QECMC_WU_MINE
+        wu_ds_wait<WV>(st);
+        if (a.resume) flag = a.flags[ladder * NC + slot];
     }
-    uint32_t tops0 = 0, samples = 0;                                  // wave 0's per-ladder bookkeeping
+    uint32_t tops0 = 0;                                               // wave 0's per-ladder bookkeeping (the criterion kernels: in LDS)
     if (slot == 0 && a.resume && live) tops0 = a.tops0[s0 + lane];
     __syncthreads();
 
-    WuCtx cx{n4, cls, flag, tops0, samples, 0u, 0u, 0u};
+    WuCtx cx{n4, cls, flag, tops0, 0u, 0u, 0u, 0u};
     WuEnv ev;
-    ev.xbuf = xbuf; ev.rec = rec; ev.swd = swd; ev.hist = hist; ev.swapT = swapT; ev.lml = lml; ev.stopf = stopf;
-    ev.lds0 = lds0; ev.thr_off = (uint32_t)((o.thr + (int)slot * 18) * 4); ev.slot = slot; ev.syn = syn; ev.grp = grp;
-    ev.lane = lane; ev.cnt = cnt; ev.s0 = s0;
+    ev.lds0 = lds0; ev.thr_off = (uint32_t)((o.thr + (int)slot * 18) * 4); ev.lml_off = (uint32_t)(o.lml * 4); ev.slot = slot;
+    ev.grp = (a.first_syndrome >> 6) + (uint32_t)blockIdx.x;         // the wavefront's shared picks: its position in the grid
+    ev.lad = live ? (uint32_t)ladder : kWuDead;
+    ev.lane = lane; ev.chunk_hi = s1;
     // (the two roles are separate loops: they meet at the step's barriers)
-    if (a.iters == 10u) {
-        if (top) wu_run<CODE, WV, CONV, true, 10>(a, st, cx, ev);
-        else wu_run<CODE, WV, CONV, false, 10>(a, st, cx, ev);
-    } else {
-        if (top) wu_run<CODE, WV, CONV, true, 0>(a, st, cx, ev);
-        else wu_run<CODE, WV, CONV, false, 0>(a, st, cx, ev);
-    }
-    n4 = cx.n4; cls = cx.cls; flag = cx.flag; tops0 = cx.tops0; samples = cx.samples;
-    const uint32_t done = cx.done, conv_ok = cx.conv_ok, steps_done = cx.steps_done;
+    if (top) wu_run<CODE, WV, CONV, QUEUE, true, IT>(a, st, cx, ev);
+    else wu_run<CODE, WV, CONV, QUEUE, false, IT>(a, st, cx, ev);
+    if constexpr (QUEUE) return;                                      // (every ladder wrote its results when it ended)
+    n4 = cx.n4; cls = cx.cls; flag = cx.flag; tops0 = cx.tops0;
+    uint32_t samples = cx.samples, done = 0, conv_ok = 0, steps_done = 0;
     const uint32_t xaddr = lds0 + (uint32_t)lane * 4u;
     // ---- results
     __syncthreads();
+    if constexpr (CONV) {
+        const uint32_t *bk = lds + o.bk + lane;
+        tops0 = bk[0]; samples = bk[64]; done = bk[576] & 1u; steps_done = bk[640]; conv_ok = bk[704];
+    }
     {
-        const uint32_t xo = xaddr + slot * (uint32_t)(WV * 256);
+        const int Wl = W;
+        const uint32_t xo = xaddr + slot * (uint32_t)(W * 256);
         WU_EACH(QECMC_WU_PUT)
         wu_ds_wait<WV>(st);
         rec[slot * 64u + (uint32_t)lane] = pack_info(n4 >> 2, slot, cls, flag);
@@ -562,28 +739,52 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_wu_kernel(const LadderArgs 
 #pragma unroll 1
         for (int i = tid; i < total; i += nthreads) {
             const int j = i / per, rem = i - j * per, c = rem / nq, q = rem - c * nq;
-            dst[i] = (uint8_t)((xbuf[(c * WV + (q >> 4)) * 64 + j] >> ((q & 15) * 2)) & 3u);
+            dst[i] = (uint8_t)((xbuf[(c * W + (q >> 4)) * 64 + j] >> ((q & 15) * 2)) & 3u);
         }
     }
 }
 
-template <int CODE, bool CONV>
-inline const void *wu_pick(int Nc, int W)
+// the kernel for a shape: the padded state width (4, 8, 12 or 16 words: toric L <= 11, the one-layer codes L <= 16), 8 waves per SIMD up
+// to 8 rungs and 4 beyond; IT = 10: the unrolled proposal loop of `iters` = 10 (decoders.py:25), built for the toric code (the BASELINE
+// shapes); QUEUE: the criterion runs (every criterion launch takes the queue kernel: a batch no larger than the grid gives each ladder
+// a lane of its own)
+template <int CODE, bool CONV, bool QUEUE, int IT>
+inline const void *wu_pick_it(int Nc, int W)
 {
     const bool big = Nc * 64 > 512;
 #ifdef QECMC_WU_DEV     // development builds: the headline shape only
-    return (!big && W > 8 && W <= 12) ? (const void *)ladder_wu_kernel<512, 8, CODE, 12, CONV> : nullptr;
+    return (!big && W > 8 && W <= 12) ? (const void *)ladder_wu_kernel<512, 8, CODE, 12, CONV, QUEUE, IT> : nullptr;
 #else
-    if (W <= 4) return big ? (const void *)ladder_wu_kernel<1024, 4, CODE, 4, CONV> : (const void *)ladder_wu_kernel<512, 8, CODE, 4, CONV>;
-    if (W <= 8) return big ? (const void *)ladder_wu_kernel<1024, 4, CODE, 8, CONV> : (const void *)ladder_wu_kernel<512, 8, CODE, 8, CONV>;
-    if (W <= 12) return big ? (const void *)ladder_wu_kernel<1024, 4, CODE, 12, CONV> : (const void *)ladder_wu_kernel<512, 8, CODE, 12, CONV>;
-    if (W <= 16) return big ? (const void *)ladder_wu_kernel<1024, 4, CODE, 16, CONV> : (const void *)ladder_wu_kernel<512, 8, CODE, 16, CONV>;
-    return big ? (const void *)ladder_wu_kernel<1024, 4, CODE, 32, CONV> : (const void *)ladder_wu_kernel<512, 4, CODE, 32, CONV>;
+    if constexpr (IT == 10) {
+        if (big) return nullptr;
+        if (W <= 4) return (const void *)ladder_wu_kernel<512, 8, CODE, 4, CONV, QUEUE, IT>;
+        if (W <= 8) return (const void *)ladder_wu_kernel<512, 8, CODE, 8, CONV, QUEUE, IT>;
+        if (W <= 12) return (const void *)ladder_wu_kernel<512, 8, CODE, 12, CONV, QUEUE, IT>;
+        return (const void *)ladder_wu_kernel<512, 6, CODE, 16, CONV, QUEUE, IT>;      // (45 KB of LDS: three workgroups per CU anyway)
+    } else {
+        if (W <= 4) return big ? (const void *)ladder_wu_kernel<1024, 4, CODE, 4, CONV, QUEUE, IT> : (const void *)ladder_wu_kernel<512, 8, CODE, 4, CONV, QUEUE, IT>;
+        if (W <= 8) return big ? (const void *)ladder_wu_kernel<1024, 4, CODE, 8, CONV, QUEUE, IT> : (const void *)ladder_wu_kernel<512, 8, CODE, 8, CONV, QUEUE, IT>;
+        if (W <= 12) return big ? (const void *)ladder_wu_kernel<1024, 4, CODE, 12, CONV, QUEUE, IT> : (const void *)ladder_wu_kernel<512, 8, CODE, 12, CONV, QUEUE, IT>;
+        return big ? (const void *)ladder_wu_kernel<1024, 4, CODE, 16, CONV, QUEUE, IT> : (const void *)ladder_wu_kernel<512, 6, CODE, 16, CONV, QUEUE, IT>;
+    }
 #endif
+}
+// variant: 0 fixed length, 2 criterion on the persistent grid
+template <int CODE>
+inline const void *wu_pick(int variant, int Nc, int W, uint32_t iters)
+{
+    if (W > 16 || (variant != 0 && variant != 2)) return nullptr;
+    const bool it10 = CODE == kCodeToric && iters == 10u && Nc * 64 <= 512;
+    if constexpr (CODE == kCodeToric) {
+        if (it10) return variant == 2 ? wu_pick_it<CODE, true, true, 10>(Nc, W) : wu_pick_it<CODE, false, false, 10>(Nc, W);
+    }
+    return variant == 2 ? wu_pick_it<CODE, true, true, 0>(Nc, W) : wu_pick_it<CODE, false, false, 0>(Nc, W);
 }
 
 // one translation unit per code family (parallel builds)
-const void *wu_kernel_toric(bool conv, int Nc, int W);       // ladder_wu.hip
-const void *wu_kernel_surf(int code, bool conv, int Nc, int W);   // ladder_wu_surf.hip
+const void *wu_kernel_toric(int variant, int Nc, int W, uint32_t iters);            // ladder_wu.hip
+const void *wu_kernel_xzzx(int variant, int Nc, int W, uint32_t iters);             // ladder_wu_xzzx.hip
+const void *wu_kernel_rotated(int variant, int Nc, int W, uint32_t iters);          // ladder_wu_rotated.hip
+const void *wu_kernel_planar(int variant, int Nc, int W, uint32_t iters);           // ladder_wu_planar.hip
 
 }  // namespace qecmc

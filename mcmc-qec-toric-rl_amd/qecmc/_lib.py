@@ -102,7 +102,7 @@ SIGNATURES = {
     "qecmc_plan_destroy": (C.c_int, [C.c_void_p]),
     "qecmc_plan_info": (C.c_int, [C.c_void_p, _u32p, _u32p, _u32p]),
     "qecmc_pteq_launch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
-                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
 }
 
 _lib = None
@@ -136,7 +136,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
-        if L.qecmc_abi_version() != 3:
+        if L.qecmc_abi_version() != 4:
             raise QecmcError("libqecmc ABI version mismatch")
         _lib = L
     return _lib

@@ -150,7 +150,7 @@ class PteqShard:
         counts, samples, tops0 = self.views()
         if self.n:
             L_.check(L_.lib().qecmc_pteq_launch_dev(self.plan, self.d_init.data_ptr(), self.n, self.first, counts.data_ptr(),
-                                                    samples.data_ptr(), tops0.data_ptr(), None, None, None, None,
+                                                    samples.data_ptr(), tops0.data_ptr(), None, None, None, None, 0,
                                                     C.c_void_p(stream.cuda_stream)))
 
     def gather(self):

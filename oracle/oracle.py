@@ -26,7 +26,8 @@ class _Rng(C.Structure):
                 ("len", C.c_uint64), ("consumed", C.c_uint64), ("seed", C.c_uint64),
                 ("syndrome", C.c_uint32), ("c_stream", C.c_uint32), ("c_sub", C.c_uint32),
                 ("c_k", C.c_uint64), ("c_valid", C.c_int), ("c_w", C.c_uint32 * 4),
-                ("c2_stream", C.c_uint32), ("c2_sub", C.c_uint32), ("c2_k", C.c_uint64), ("c2_valid", C.c_int), ("c2_w", C.c_uint32 * 4)]
+                ("c2_stream", C.c_uint32), ("c2_sub", C.c_uint32), ("c2_k", C.c_uint64), ("c2_valid", C.c_int), ("c2_w", C.c_uint32 * 4),
+                ("wave_override", C.c_int), ("wave_group", C.c_uint32), ("wave_t0", C.c_uint64)]
 
 
 class Model(C.Structure):
@@ -134,6 +135,11 @@ def lib():
                                         C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                         C.POINTER(C.c_uint64), u8p, u8p]
         _LIB.orc_pteq_batch.restype = None
+        _LIB.orc_pteq_wave_queue.argtypes = [mp, u8p, C.c_uint64, C.c_uint32, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int,
+                                             C.c_double, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int,
+                                             C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                             C.POINTER(C.c_uint64), u8p]
+        _LIB.orc_pteq_wave_queue.restype = None
     return _LIB
 
 
@@ -471,6 +477,21 @@ def pteq_batch(code, init, p, Nc, steps, iters=10, tops_burn=2, seed=0, first_sy
     if return_states:
         out["states"] = fin
     return out
+
+
+def pteq_wave_queue(code, init, p, Nc, steps, grid, iters=10, tops_burn=2, seed=0, first_syndrome=0, n_threads=0, SEQ=2, TOPS=10, eps=0.1):
+    """scan = 3 with the error_based criterion on a persistent grid of `grid` workgroups: the deterministic work queue of the GPU
+    kernel, restated (orc_pteq_wave_queue)"""
+    init = _m(init); N = init.shape[0]
+    mod = _model(code, init.shape[-1], DEPOLARIZING, 0.0, 3)
+    counts = np.zeros((N, 16), dtype=np.uint32)
+    samples = np.zeros(N, dtype=np.uint64); tops0 = np.zeros(N, dtype=np.uint64)
+    steps_done = np.zeros(N, dtype=np.uint64); converged = np.zeros(N, dtype=np.uint8)
+    lib().orc_pteq_wave_queue(C.byref(mod), _u8(init), N, first_syndrome, p, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, seed, grid, n_threads,
+                              counts.ctypes.data_as(C.POINTER(C.c_uint32)), samples.ctypes.data_as(C.POINTER(C.c_uint64)),
+                              tops0.ctypes.data_as(C.POINTER(C.c_uint64)), steps_done.ctypes.data_as(C.POINTER(C.c_uint64)), _u8(converged))
+    ncls = 16 if code == TORIC else 4
+    return dict(counts=counts[:, :ncls].copy(), samples=samples, tops0=tops0, steps_done=steps_done, converged=converged.astype(bool))
 
 
 # ---- unique-chain estimators (decoders.py:138-233) ---------------------------------------------------------------

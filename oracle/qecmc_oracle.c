@@ -595,6 +595,8 @@ static int logical_from_words(const orc_model *m, const uint8_t *in, uint8_t *ou
     return orc_surf_apply_logical(m->code, L, in, out, op, xpos, zpos);
 }
 
+/* (work-queue runs, orc_pteq_wave_queue below: the pick belongs to the lane's POSITION -- group rng->wave_group, the workgroup's own
+ *  step counter = the ladder's step + rng->wave_t0 -- while the acceptance uniforms stay the ladder's own) */
 static void chain_update_wave(const orc_model *m, uint8_t *state, double p, double p_logical, uint64_t iters,
                               orc_rng *rng, uint32_t slot, uint64_t k0, uint8_t *scratch)
 {
@@ -605,10 +607,12 @@ static void chain_update_wave(const orc_model *m, uint8_t *state, double p, doub
     if (p_logical != 0 && !(p >= 0.75)) abort();       /* the top chain of scan = 3 accepts every move */
     if (iters < 1 || iters > 128) abort();
     const uint64_t T = k0 / iters, S = 128 / iters, nch = (iters + 9) / 10, nc4 = (iters + 3) / 4;
+    const uint64_t Tp = T + (rng->wave_override ? rng->wave_t0 : 0);                 /* the step that addresses the pick */
+    const uint32_t group = rng->wave_override ? rng->wave_group : rng->syndrome >> 6;
     for (uint64_t j = 0; j < iters; ++j) {
-        const uint64_t P = (T % S) * iters + j;
+        const uint64_t P = (Tp % S) * iters + j;
         uint32_t pw[4];
-        wave_block(rng, rng->syndrome >> 6, 0x800u + slot, (T / S) * 64 + (P >> 1), 9u, pw);
+        wave_block(rng, group, 0x800u + slot, (Tp / S) * 64 + (P >> 1), 9u, pw);
         const uint32_t A = pw[2 * (P & 1)], B = pw[2 * (P & 1) + 1];
         const int g = (int)(((uint64_t)B * (uint32_t)G) >> 32);
         rng->consumed += 2;
@@ -928,66 +932,166 @@ static double sum_range(const double *a, uint64_t lo, uint64_t hi)
     return s;
 }
 
+/* decoders.PTEQ's loop (decoders.py:55-82) one ladder step at a time: what orc_pteq runs to the end, and what the work-queue
+ * restatement (orc_pteq_wave_queue) interleaves over the 64 lanes of a workgroup */
+typedef struct pteq_run {
+    orc_ladder *ld;
+    const orc_model *m;
+    int ncls, SEQ, TOPS, tops_burn, conv_mode, det_series, converged;
+    double eps;
+    uint64_t steps, iters, step, since_burn, resulting_burn_in, recorded, conv_start, conv_streak;
+    uint32_t eq[16];
+    double *series, *series_z, *series_xy;
+} pteq_run;
+
+static void pteq_run_init(pteq_run *r, const orc_model *m, const uint8_t *init, double p, int Nc, int SEQ, int TOPS, int tops_burn,
+                          double eps, uint64_t steps, uint64_t iters, int conv_mode)
+{
+    memset(r, 0, sizeof *r);
+    r->ld = orc_ladder_new(m, init, p, Nc, 0.5);                    /* decoders.py:52 */
+    r->m = m; r->ncls = orc_ncls(m->code); r->SEQ = SEQ; r->TOPS = TOPS; r->tops_burn = tops_burn; r->conv_mode = conv_mode;
+    r->eps = eps; r->steps = steps; r->iters = iters;
+    r->series = conv_mode ? (double *)calloc((size_t)steps, sizeof(double)) : NULL;
+    /* det_pow: the GPU's form of the alpha series means, (sum n_z + alpha sum n_xy) / len from exact integer sums */
+    r->det_series = conv_mode && m->noise == ORC_NOISE_ALPHA && m->det_pow;
+    r->series_z = r->det_series ? (double *)calloc((size_t)steps, sizeof(double)) : NULL;
+    r->series_xy = r->det_series ? (double *)calloc((size_t)steps, sizeof(double)) : NULL;
+}
+
+/* one iteration of the loop of decoders.py:55; returns 1 when the run has ended (criterion or `steps`) */
+static int pteq_run_step(pteq_run *r, orc_rng *rng)
+{
+    orc_ladder *ld = r->ld;
+    const orc_model *m = r->m;
+    const uint64_t step = r->step;
+    orc_ladder_step(ld, r->iters, rng);                             /* :57 */
+    int cur = orc_eq_class(m->code, m->L, ld->states);              /* :60 */
+    if (ld->tops0 >= (uint64_t)r->tops_burn) {                      /* :63 */
+        r->since_burn = step - r->resulting_burn_in;
+        r->eq[cur] += 1;                                            /* :66-67 (running row) */
+        r->recorded = r->since_burn + 1;
+        if (r->series) r->series[r->since_burn] = m->noise == ORC_NOISE_ALPHA ? ld->n_eff[0]     /* decoders_biasednoise.py:204 */
+                                                                           : (double)orc_count_errors((size_t)ld->nq, ld->states);
+        if (r->det_series) { r->series_z[r->since_burn] = ld->n_eff_cnt[0]; r->series_xy[r->since_burn] = ld->n_eff_cnt[1]; }
+    } else {
+        r->resulting_burn_in += 1;                                  /* :71 */
+    }
+    r->step = step + 1;
+    if (r->conv_mode == 1 && ld->tops0 >= (uint64_t)r->TOPS) {      /* :74 */
+        uint64_t l = r->since_burn + 1;
+        double q2 = mean_range(r->series, l / 4, l / 2);
+        double q4 = mean_range(r->series, 3 * l / 4, l);
+        if (r->det_series) {
+            const double n2 = (double)(l / 2 - l / 4), n4 = (double)(l - 3 * l / 4);
+            q2 = n2 > 0 ? (sum_range(r->series_z, l / 4, l / 2) + m->alpha * sum_range(r->series_xy, l / 4, l / 2)) / n2 : NAN;
+            q4 = n4 > 0 ? (sum_range(r->series_z, 3 * l / 4, l) + m->alpha * sum_range(r->series_xy, 3 * l / 4, l)) / n4 : NAN;
+        }
+        double err = fabs(q2 - q4);
+        if (err < r->eps) {                                         /* :102 */
+            if (r->conv_streak >= (uint64_t)r->SEQ) { r->converged = 1; return 1; }
+            r->conv_streak = ld->tops0 - r->conv_start;             /* :79 */
+        } else {
+            r->conv_streak = 0;                                     /* :81-82 */
+            r->conv_start = ld->tops0;
+        }
+    }
+    return r->step >= r->steps;
+}
+
+static void pteq_run_finish(pteq_run *r, orc_pteq_result *res, uint8_t *final_states)
+{
+    memcpy(res->counts, r->eq, sizeof r->eq);
+    res->samples = r->recorded;
+    res->tops0 = r->ld->tops0;
+    res->steps_done = r->step;
+    res->converged = r->converged;
+    memset(res->percent, 0, sizeof res->percent);
+    for (int i = 0; i < r->ncls; ++i)                               /* :89 */
+        res->percent[i] = (uint8_t)((double)r->eq[i] / (double)(r->since_burn + 1) * 100.0);
+    if (final_states) memcpy(final_states, r->ld->states, (size_t)r->ld->Nc * r->ld->nq);
+    free(r->series); free(r->series_z); free(r->series_xy);
+    orc_ladder_free(r->ld);
+    r->ld = NULL;
+}
+
 void orc_pteq(const orc_model *m, const uint8_t *init, double p, int Nc, int SEQ, int TOPS, int tops_burn,
               double eps, uint64_t steps, uint64_t iters, int conv_mode, orc_rng *rng,
               orc_pteq_result *res, uint8_t *final_states)
 {
-    orc_ladder *ld = orc_ladder_new(m, init, p, Nc, 0.5);           /* decoders.py:52 */
-    const int ncls = orc_ncls(m->code);
-    uint64_t since_burn = 0, resulting_burn_in = 0, recorded = 0;
-    uint64_t conv_start = 0, conv_streak = 0;
-    uint32_t eq[16];
-    memset(eq, 0, sizeof eq);
-    double *series = conv_mode ? (double *)calloc((size_t)steps, sizeof(double)) : NULL;
-    /* det_pow: the GPU's form of the alpha series means, (sum n_z + alpha sum n_xy) / len from exact integer sums */
-    const int det_series = conv_mode && m->noise == ORC_NOISE_ALPHA && m->det_pow;
-    double *series_z = det_series ? (double *)calloc((size_t)steps, sizeof(double)) : NULL;
-    double *series_xy = det_series ? (double *)calloc((size_t)steps, sizeof(double)) : NULL;
-    int converged = 0;
-    uint64_t step;
-    for (step = 0; step < steps; ++step) {                          /* :55 */
-        orc_ladder_step(ld, iters, rng);                            /* :57 */
-        int cur = orc_eq_class(m->code, m->L, ld->states);          /* :60 */
-        if (ld->tops0 >= (uint64_t)tops_burn) {                     /* :63 */
-            since_burn = step - resulting_burn_in;
-            eq[cur] += 1;                                           /* :66-67 (running row) */
-            recorded = since_burn + 1;
-            if (series) series[since_burn] = m->noise == ORC_NOISE_ALPHA ? ld->n_eff[0]     /* decoders_biasednoise.py:204 */
-                                                                         : (double)orc_count_errors((size_t)ld->nq, ld->states);
-            if (det_series) { series_z[since_burn] = ld->n_eff_cnt[0]; series_xy[since_burn] = ld->n_eff_cnt[1]; }
-        } else {
-            resulting_burn_in += 1;                                 /* :71 */
+    pteq_run r;
+    pteq_run_init(&r, m, init, p, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, conv_mode);
+    while (r.step < steps)
+        if (pteq_run_step(&r, rng)) break;
+    pteq_run_finish(&r, res, final_states);
+}
+
+/* The criterion-stopped runs of scan = 3 on a persistent grid (the GPU's work queue, restated): workgroup g of `grid` owns the
+ * ladders [g C, min(N, (g+1) C)), C = ceil(N / grid) rounded up to a multiple of 64; its 64 lanes start on the first 64 of them and run in lockstep, one ladder step
+ * per workgroup step t.  A lane whose ladder ends at workgroup step t (criterion, or `steps` of its own steps) idles during steps
+ * t + 1 and t + 2 (the GPU books a step behind the next one's barrier and restages behind the one after) and starts the workgroup's
+ * next unassigned ladder at step t + 3 -- lanes that end together take them in lane order.  A
+ * ladder's acceptance and swap uniforms are addressed by its own index and its own step; the generator picks belong to the lane's
+ * position: group (first_syndrome >> 6) + g, workgroup step t.  Deterministic for a given (N, grid, first_syndrome); every ladder
+ * has the reference's law. */
+void orc_pteq_wave_queue(const orc_model *m, const uint8_t *init, uint64_t N, uint32_t first_syndrome, double p, int Nc, int SEQ,
+                         int TOPS, int tops_burn, double eps, uint64_t steps, uint64_t iters, uint64_t seed, uint32_t grid, int n_threads,
+                         uint32_t *counts_out, uint64_t *samples_out, uint64_t *tops0_out, uint64_t *steps_done_out, uint8_t *converged_out)
+{
+    const size_t nq = (size_t)orc_nq(m->code, m->L);
+    const uint64_t C = ((N + grid - 1) / grid + 63) / 64 * 64;        /* whole groups of 64 per workgroup */
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#else
+    (void)n_threads;
+#endif
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t g = 0; g < (int64_t)grid; ++g) {
+        const uint64_t lo = (uint64_t)g * C, hi = lo + C < N ? lo + C : N;
+        if (lo >= N) continue;
+        pteq_run run[64];
+        orc_rng rng[64];
+        int64_t lad[64];                      /* the lane's ladder, -1: none */
+        uint64_t start[64];                   /* workgroup step a waiting lane starts its next ladder at */
+        uint64_t next = lo + 64;              /* the workgroup's queue */
+        int alive = 0;
+        for (int l = 0; l < 64; ++l) {
+            lad[l] = lo + (uint64_t)l < hi ? (int64_t)(lo + (uint64_t)l) : -1;
+            start[l] = 0;
+            if (lad[l] >= 0) ++alive;
         }
-        if (conv_mode == 1 && ld->tops0 >= (uint64_t)TOPS) {        /* :74 */
-            uint64_t l = since_burn + 1;
-            double q2 = mean_range(series, l / 4, l / 2);
-            double q4 = mean_range(series, 3 * l / 4, l);
-            if (det_series) {
-                const double n2 = (double)(l / 2 - l / 4), n4 = (double)(l - 3 * l / 4);
-                q2 = n2 > 0 ? (sum_range(series_z, l / 4, l / 2) + m->alpha * sum_range(series_xy, l / 4, l / 2)) / n2 : NAN;
-                q4 = n4 > 0 ? (sum_range(series_z, 3 * l / 4, l) + m->alpha * sum_range(series_xy, 3 * l / 4, l)) / n4 : NAN;
+        int running[64];
+        memset(running, 0, sizeof running);
+        for (uint64_t t = 0; alive > 0; ++t) {
+            for (int l = 0; l < 64; ++l) {
+                if (lad[l] < 0) continue;
+                if (!running[l]) {
+                    if (t < start[l]) continue;
+                    pteq_run_init(&run[l], m, init + (size_t)lad[l] * nq, p, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, 1);
+                    orc_rng_init_philox(&rng[l], seed, first_syndrome + (uint32_t)lad[l]);
+                    rng[l].wave_override = 1;
+                    rng[l].wave_group = (first_syndrome >> 6) + (uint32_t)g;
+                    rng[l].wave_t0 = t;
+                    running[l] = 1;
+                }
+                if (pteq_run_step(&run[l], &rng[l])) {
+                    orc_pteq_result res;
+                    pteq_run_finish(&run[l], &res, NULL);
+                    const size_t s = (size_t)lad[l];
+                    memcpy(counts_out + s * 16, res.counts, sizeof res.counts);
+                    samples_out[s] = res.samples; tops0_out[s] = res.tops0;
+                    if (steps_done_out) steps_done_out[s] = res.steps_done;
+                    if (converged_out) converged_out[s] = (uint8_t)res.converged;
+                    running[l] = 0;
+                    lad[l] = -2;                                      /* ended at this step: takes a new ladder below */
+                }
             }
-            double err = fabs(q2 - q4);
-            if (err < eps) {                                        /* :102 */
-                if (conv_streak >= (uint64_t)SEQ) { converged = 1; step++; break; }
-                conv_streak = ld->tops0 - conv_start;               /* :79 */
-            } else {
-                conv_streak = 0;                                    /* :81-82 */
-                conv_start = ld->tops0;
+            for (int l = 0; l < 64; ++l) {                            /* lanes that ended at step t, in lane order */
+                if (lad[l] != -2) continue;
+                if (next < hi) { lad[l] = (int64_t)next++; start[l] = t + 3; }
+                else { lad[l] = -1; --alive; }
             }
         }
     }
-    memcpy(res->counts, eq, sizeof eq);
-    res->samples = recorded;
-    res->tops0 = ld->tops0;
-    res->steps_done = step;
-    res->converged = converged;
-    memset(res->percent, 0, sizeof res->percent);
-    for (int i = 0; i < ncls; ++i)                                  /* :89 */
-        res->percent[i] = (uint8_t)((double)eq[i] / (double)(since_burn + 1) * 100.0);
-    if (final_states) memcpy(final_states, ld->states, (size_t)Nc * ld->nq);
-    free(series); free(series_z); free(series_xy);
-    orc_ladder_free(ld);
 }
 
 void orc_toric_pteq(int L, const uint8_t *init, double p, int Nc, int SEQ, int TOPS, int tops_burn,

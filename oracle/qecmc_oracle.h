@@ -50,6 +50,10 @@ typedef struct orc_rng {
     uint64_t c2_k;
     int c2_valid;
     uint32_t c2_w[4];
+    /* scan = 3 work-queue runs: the generator picks are addressed by the lane's position (group, workgroup step = ladder step + t0) */
+    int wave_override;
+    uint32_t wave_group;
+    uint64_t wave_t0;
 } orc_rng;
 
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
@@ -147,6 +151,12 @@ typedef struct orc_pteq_result {
 void orc_toric_pteq(int L, const uint8_t *init, double p, int Nc, int SEQ, int TOPS, int tops_burn,
                     double eps, uint64_t steps, uint64_t iters, int conv_mode, orc_rng *rng,
                     orc_pteq_result *res, uint8_t *final_states);
+
+/* scan = 3 with the error_based criterion on a persistent grid of `grid` workgroups (the GPU's deterministic work queue, restated in
+ * qecmc_oracle.c): counts_out [N][16], the other outputs [N] */
+void orc_pteq_wave_queue(const orc_model *m, const uint8_t *init, uint64_t N, uint32_t first_syndrome, double p, int Nc, int SEQ,
+                         int TOPS, int tops_burn, double eps, uint64_t steps, uint64_t iters, uint64_t seed, uint32_t grid, int n_threads,
+                         uint32_t *counts_out, uint64_t *samples_out, uint64_t *tops0_out, uint64_t *steps_done_out, uint8_t *converged_out);
 
 /* code / noise generic forms of the above */
 void orc_chain_update(const orc_model *m, uint8_t *state, double p, double p_logical, uint64_t iters,

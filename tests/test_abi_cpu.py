@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/qecmc.h but not exported"
     assert set(names) == set(L_.SIGNATURES), "ctypes binding and header disagree"
-    assert lib.qecmc_abi_version() == 3
+    assert lib.qecmc_abi_version() == 4
 
 
 def test_params_struct_matches_the_c_layout():

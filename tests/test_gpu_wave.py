@@ -41,12 +41,12 @@ def _init(rng, name, N, L, p):
 
 CASES = [  # name, L, Nc, N, steps, iters, p, p_logical, replicas, first_syndrome
     ("toric", 3, 3, 5, 400, 10, 0.10, 0.5, 1, 0), ("toric", 5, 5, 70, 200, 10, 0.10, 0.5, 1, 128),     # 70: two workgroups, the second ragged
-    ("toric", 9, 8, 6, 200, 10, 0.15, 0.5, 1, 64), ("toric", 15, 8, 3, 60, 10, 0.18, 0.5, 1, 0),      # W = 11 -> 12 / 29 -> 32 state words
+    ("toric", 9, 8, 6, 200, 10, 0.15, 0.5, 1, 64), ("toric", 11, 8, 3, 60, 10, 0.18, 0.5, 1, 0),      # W = 11 -> 12 words / 16 words exactly
     ("toric", 4, 4, 4, 150, 7, 0.12, 0.5, 1, 0), ("toric", 9, 16, 2, 50, 3, 0.15, 0.25, 1, 0),         # odd iters: blocks of 8 cut anywhere; 16 rungs
     ("toric", 7, 2, 4, 200, 10, 0.10, 0.5, 1, 0), ("toric", 5, 5, 4, 120, 1, 0.02, 1.0, 3, 192),       # p = 0.02: thresholds below 2^-16
     ("toric", 5, 5, 3, 300, 10, 0.10, 0.0, 1, 0),                                                     # no logical moves (PTDC's ladders)
-    ("toric", 16, 4, 2, 40, 25, 0.15, 0.5, 1, 0), ("toric", 9, 9, 3, 80, 10, 0.15, 0.5, 1, 0),        # 32 words exactly; 9 rungs: 1024-thread groups
-    ("xzzx", 9, 8, 5, 150, 10, 0.15, 0.5, 1, 0), ("rotated", 7, 7, 4, 150, 10, 0.17, 0.5, 1, 0), ("rotated", 21, 8, 2, 30, 10, 0.17, 0.5, 1, 0),
+    ("toric", 10, 4, 2, 40, 25, 0.15, 0.5, 1, 0), ("toric", 9, 9, 3, 80, 10, 0.15, 0.5, 1, 0),        # 13 of 16 words; 9 rungs: 1024-thread groups
+    ("xzzx", 9, 8, 5, 150, 10, 0.15, 0.5, 1, 0), ("rotated", 7, 7, 4, 150, 10, 0.17, 0.5, 1, 0), ("rotated", 15, 8, 2, 30, 10, 0.17, 0.5, 1, 0),
     ("planar", 5, 5, 4, 150, 10, 0.12, 0.5, 1, 0), ("xzzx", 3, 2, 7, 300, 5, 0.2, 0.5, 2, 64), ("planar", 9, 8, 3, 100, 10, 0.12, 0.5, 1, 0)]
 
 
@@ -96,6 +96,32 @@ def test_wave_scan_with_the_convergence_criterion_bit_exact(q, orc, name, L, Nc,
     assert np.array_equal(got["converged"], ref["converged"].reshape(N, R).all(axis=1))
 
 
+@pytest.mark.parametrize("name,L,Nc,N,steps,iters,grid,R", [("toric", 3, 3, 300, 2500, 10, 1, 1), ("toric", 5, 5, 400, 3000, 10, 2, 1), ("toric", 5, 4, 200, 2000, 7, 3, 1),
+                                                         ("rotated", 5, 4, 150, 2500, 10, 1, 1), ("xzzx", 5, 5, 100, 2000, 10, 1, 2), ("planar", 4, 4, 130, 1500, 5, 2, 1),
+                                                         ("toric", 9, 8, 140, 1200, 10, 1, 1)])
+def test_wave_scan_work_queue_bit_exact(q, orc, name, L, Nc, N, steps, iters, grid, R):
+    """The criterion runs on a persistent grid (forced down to 1-3 workgroups here, so that every lane runs several ladders): a lane whose
+    ladder has ended takes the next one of its workgroup's share of the batch, in lane order among the lanes that end together.  The
+    oracle restates the rule (orc_pteq_wave_queue); class counts, samples, tops0, the stopping step and the flag of every ladder are
+    its -- ladders stopped by the criterion and ladders that reach the horizon of `steps` of their own steps alike."""
+    rng = np.random.default_rng(L + 17 * Nc + N)
+    code, ocode = _codes(q, orc, name)
+    init = _init(rng, name, N, L, 0.1)
+    kw = dict(iters=iters, tops_burn=2, seed=9, first_syndrome=128, SEQ=2, TOPS=4, eps=0.3)
+    got = q.pteq_batch(init, 0.1, Nc=Nc, code=code, scan="wave", replicas=R, steps=steps, conv_criteria="error_based", flags=q.dev_flags(queue_grid=grid), **kw)
+    M = N * R
+    g_eff = max(1, min(grid, (M + 63) // 64))
+    ref = orc.pteq_wave_queue(ocode, np.repeat(init, R, axis=0), 0.1, Nc, steps, g_eff, **kw)
+    ncls = ref["counts"].shape[1]
+    if name == "toric" and L <= 5 and iters == 10:
+        assert ref["converged"].any() and not ref["converged"].all()                  # both ways of ending occur
+    assert np.array_equal(got["counts"], ref["counts"].reshape(N, R, ncls).sum(axis=1))
+    assert np.array_equal(got["samples"], ref["samples"].reshape(N, R).sum(axis=1).astype(np.uint32))
+    assert np.array_equal(got["tops0"], ref["tops0"].reshape(N, R).sum(axis=1).astype(np.uint32))
+    assert np.array_equal(got["steps_done"], ref["steps_done"].reshape(N, R).max(axis=1).astype(np.uint32))
+    assert np.array_equal(got["converged"], ref["converged"].reshape(N, R).all(axis=1))
+
+
 def test_wave_scan_sharded_equals_whole(q):
     """Results depend on the global ladder index only: a batch cut at a multiple of 64 gives the rows of the whole batch."""
     rng = np.random.default_rng(8)
@@ -128,3 +154,50 @@ def test_wave_scan_rejects_what_it_does_not_do(q):
         q.pteq_batch(init, 0.1, Nc=1, steps=100, scan="wave", p_logical=0.5)          # a 1-rung ladder's top sits below p = 0.75
     with pytest.raises(q.QecmcError):
         q.pteq_batch(init, 0.1, Nc=5, steps=100, scan="wave", first_syndrome=7)       # a wavefront is one pick group
+    with pytest.raises(q.QecmcError):
+        q.pteq_batch(np.zeros((2, 2, 15, 15), np.uint8), 0.18, Nc=8, steps=10, scan="wave")   # 29 words per rung: the scan = 0 kernels' ground
+    with pytest.raises(q.QecmcError):                                                  # the criterion runs reuse lanes: no final states
+        q.pteq_batch(init, 0.1, Nc=5, steps=100, scan="wave", conv_criteria="error_based", return_states=True)
+
+
+@pytest.mark.parametrize("kind", ["depolarizing", "wave", "biased", "alpha"])
+def test_launch_dev_refuses_an_undersized_workspace(q, kind):
+    """ABI 4: qecmc_pteq_launch_dev takes the size of the criterion runs' log next to its pointer and refuses a buffer
+    smaller than the launch needs -- QECMC_ERR_INVALID before anything is enqueued -- for the depolarizing, biased and alpha criterion
+    plans alike; the size comes from qecmc_plan_workspace_bytes, the one place the formula lives."""
+    import ctypes as C
+    import torch
+    from qecmc import _lib as L_
+    N, L, Nc, steps = 200, 5, 5, 500
+    kw = dict(L=L, Nc=Nc, p=0.1, p_logical=0.5, iters=10, steps=steps, tops_burn=0, TOPS=4, SEQ=2, eps=0.3, seed=1, conv_mode=L_.CONV_ERROR_BASED)
+    if kind == "depolarizing":
+        pr, nq, ncls = L_.make_params(code=L_.TORIC, **kw), 50, 16
+    elif kind == "wave":
+        pr, nq, ncls = L_.make_params(code=L_.TORIC, scan=L_.SCAN_WAVE, **kw), 50, 16
+    elif kind == "biased":
+        pr, nq, ncls = L_.make_params(code=L_.XZZX, noise=L_.NOISE_BIASED, eta=10.0, **kw), 25, 4
+    else:
+        pr, nq, ncls = L_.make_params(code=L_.XZZX, noise=L_.NOISE_ALPHA, alpha=2.0, **kw), 25, 4
+    plan = C.c_void_p()
+    L_.check(L_.lib().qecmc_plan_create(pr, C.byref(plan)))
+    try:
+        need = C.c_uint64()
+        L_.check(L_.lib().qecmc_plan_workspace_bytes(plan, N, C.byref(need)))
+        assert need.value == (4 if kind == "alpha" else 2) * 256 * steps          # one column per ladder, whole groups of 64
+        dev = torch.device("cuda", 0)
+        init = torch.zeros(N * nq, dtype=torch.uint8, device=dev)
+        counts = torch.zeros(N * ncls, dtype=torch.int32, device=dev)
+        samples = torch.zeros(N, dtype=torch.int32, device=dev)
+        ws = torch.zeros(need.value, dtype=torch.uint8, device=dev)
+        stream = torch.cuda.current_stream()
+        args = (plan, init.data_ptr(), N, 0, counts.data_ptr(), samples.data_ptr(), None, None, None, None)
+        # one ladder per lane here (the persistent grid is larger than the batch), so the launch needs all of it
+        rc = L_.lib().qecmc_pteq_launch_dev(*args, ws.data_ptr(), need.value - 1, C.c_void_p(stream.cuda_stream))
+        assert rc == -1 and b"workspace" in L_.lib().qecmc_last_error()
+        rc = L_.lib().qecmc_pteq_launch_dev(*args, None, 0, C.c_void_p(stream.cuda_stream))
+        assert rc == -1
+        L_.check(L_.lib().qecmc_pteq_launch_dev(*args, ws.data_ptr(), need.value, C.c_void_p(stream.cuda_stream)))
+        torch.cuda.synchronize()
+        assert int(samples.sum().item()) > 0
+    finally:
+        L_.lib().qecmc_plan_destroy(plan)

@@ -37,11 +37,12 @@ else:
     tag = "alpha_L%d" % L
     workload = "xzzx L=%d, errors at p=%g eta=%g, decoded by PTEQ_alpha (pz_tilde=%.6g, alpha=%.6g), Nc=%d" % (L, p, eta, p_dec, a, Nc)
 out = {}
-for name, grid in (("queue", 0), ("one_ladder_per_lane", 65535)):
+SCAN = os.environ.get("QECMC_BENCH_SCAN", "random")       # "wave": the scan = 3 kernel (no work queue yet: one ladder per lane)
+for name, grid in ((("queue", 0), ("one_ladder_per_lane", 65535)) if SCAN == "random" else (("wave_one_ladder_per_lane", 0),)):
     for rep in range(2):
         t0 = time.time()
         r = qecmc.pteq_batch(init, p_dec, Nc=Nc, steps=H, iters=10, tops_burn=2, seed=3, conv_criteria="error_based", return_stats=True,
-                             flags=qecmc.dev_flags(queue_grid=grid), **kw)
+                             flags=qecmc.dev_flags(queue_grid=grid), scan=SCAN, **kw)
         dt = time.time() - t0
     steps = r["steps_done"].astype(np.float64)
     out[name] = dict(kernel_ms=r["stats"]["kernel_ms"], wall_s=dt, converged_frac=float(r["converged"].mean()), mean_steps=float(steps.mean()),
@@ -49,9 +50,10 @@ for name, grid in (("queue", 0), ("one_ladder_per_lane", 65535)):
                      useful_proposals_per_s=float(steps.sum() * Nc * 10 / (r["stats"]["kernel_ms"] * 1e-3)),
                      checksum=int(r["counts"].astype(np.uint64).sum()))
     print(name, json.dumps(out[name]), flush=True)
-out["speedup"] = out["one_ladder_per_lane"]["kernel_ms"] / out["queue"]["kernel_ms"]
-out["identical_class_counts"] = out["queue"]["checksum"] == out["one_ladder_per_lane"]["checksum"]
+if SCAN == "random":
+    out["speedup"] = out["one_ladder_per_lane"]["kernel_ms"] / out["queue"]["kernel_ms"]
+    out["identical_class_counts"] = out["queue"]["checksum"] == out["one_ladder_per_lane"]["checksum"]
 out["workload"] = "%s, %d syndromes, error_based criterion (SEQ=2, TOPS=10, eps=0.1), horizon %d ladder steps" % (workload, N, H)
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(out, open("gpurun_out/r03_conv_queue_%s.json" % tag, "w"), indent=1)
-print("speedup", out["speedup"])
+json.dump(out, open("gpurun_out/r04_conv_%s_%s.json" % (SCAN, tag), "w"), indent=1)
+print("speedup", out.get("speedup"))

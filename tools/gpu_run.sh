@@ -15,6 +15,10 @@ case "$1" in
     timeout -k 10 900 python -m pytest tests/test_gpu_wave.py -x -q > gpurun_out/wave_tests.log 2>&1; rc=$?; tail -15 gpurun_out/wave_tests.log
     [ $rc -eq 0 ] && b cfg2_random --config 2 && b cfg2_wave --config 2 --scan wave && b cfg2_random_b --config 2 && b cfg2_wave_b --config 2 --scan wave
     ;;
+  wave-cfgs)    # scan = wave against the random scan on BASELINE configurations 2, 3, 5 (same box, alternating)
+    timeout -k 10 900 python -m pytest tests/test_gpu_wave.py -x -q > gpurun_out/wave_tests.log 2>&1; rc=$?; tail -5 gpurun_out/wave_tests.log
+    [ $rc -eq 0 ] && for c in 2 3 5; do b cfg${c}_random --config $c && b cfg${c}_wave --config $c --scan wave || exit 1; done
+    ;;
   tests)        # tests [pytest args]: the GPU suite (or part of it)
     shift
     timeout -k 10 1100 python -m pytest tests -m gpu -q "$@" > gpurun_out/gpu_tests.log 2>&1; echo "tests rc=$?"; tail -12 gpurun_out/gpu_tests.log
