@@ -181,6 +181,121 @@ def cpu_baseline(args, init, n_gen, target_s=12.0):
             "proposals_per_s": proposals / dt}
 
 
+def criterion_bench(args, L_, PteqShard, torch, dist, use_dist, world, rank, local_rank, dev, init_h, first, code_id, nq, ncls, n_gen, workload):
+    """--criterion: the reference's default route (decoders.py:25,74-105).  One step = one launch of the batch through the criterion
+    kernels on their persistent grid; `value` = chain-sweeps the ladders actually ran / wall time (a ladder that stops early stops
+    counting); roofline on the same 8 B / proposal convention, useful proposals only."""
+    N, L, Nc = args.syndromes, args.L, args.Nc
+    crit = dict(conv_mode=L_.CONV_ERROR_BASED, SEQ=2, TOPS=10, eps=0.1)                 # decoders.py:25
+    common = dict(code=code_id, Nc=Nc, p_logical=args.p_logical, iters=args.iters, tops_burn=2, seed=args.seed,
+                  noise=L_.NOISE_DEPOLARIZING if args.eta is None else L_.NOISE_BIASED, eta=args.eta or 0.0, scan=L_.SCANS[args.scan], flags=args.flags)
+    sh = PteqShard(init_h, args.p, first, n_total=N * world, steps=args.ladder_steps, **common, **crit)
+    lds, threads, spb = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    L_.check(L_.lib().qecmc_plan_info(sh.plan, lds, threads, spb))
+    stream = torch.cuda.current_stream()
+    for _ in range(args.warmup):
+        sh.launch(stream); sh.gather()
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record(stream); sh.launch(stream); b.record(stream)
+        sh.gather()
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = [a.elapsed_time(b) for a, b in ev]
+    useful_steps = torch.tensor([float(sh.steps_done.to(torch.float64).sum().item())], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if use_dist:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(useful_steps, op=dist.ReduceOp.SUM)
+    elapsed = float(t.item())
+    props = torch.cuda.get_device_properties(dev)
+    ranks = rank_records(dist, use_dist, world, rank, props.name, str(getattr(props, "uuid", "")) or None, float(np.mean(kernel_ms)), first)
+    if rank == 0:
+        k_ms = float(np.mean(kernel_ms))
+        sd = sh.steps_done.cpu().numpy().astype(np.float64)
+        conv = sh.converged.cpu().numpy().astype(bool)
+        useful_props_launch = float(sd.sum()) * Nc * args.iters                          # this rank's launch
+        useful_total = float(useful_steps.item()) * Nc * args.iters * args.steps          # all ranks, all timed launches
+        algo_bytes = useful_props_launch * ALGO_BYTES_PER_PROPOSAL + N * (nq + 4 * ncls)
+        achieved = algo_bytes / (k_ms * 1e-3) / 1e9
+        # the same kernel family at fixed length on the first 65 536 syndromes: what a ladder step costs without the criterion, the queue
+        # and its tail (time after a workgroup's queue ran dry)
+        n_fix = min(N, 65536)
+        shf = PteqShard(init_h[:n_fix], args.p, first, n_total=n_fix, steps=10000, **common)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fix_ms = []
+        for rep in range(3):
+            e0.record(stream); shf.launch(stream); e1.record(stream)
+            torch.cuda.synchronize()
+            fix_ms.append(e0.elapsed_time(e1))
+        shf.close()
+        fixed_rate = n_fix * Nc * args.iters * 10000 / (float(np.mean(fix_ms[1:])) * 1e-3)
+        out = {
+            "metric": metric_name(args) + " -- criterion-stopped (decoders.py:25 conv_criteria='error_based', SEQ=2, TOPS=10, eps=0.1)",
+            "value": useful_total / n_gen / elapsed,
+            "unit": "chain-sweeps/s of the steps the ladders ran (1 sweep = %d Metropolis proposals on one chain)" % n_gen,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": workload + "; every ladder stopped by the error_based criterion or at the horizon of %d of its own steps" % args.ladder_steps,
+                       "baseline_config": args.config, "syndromes_per_gpu": N, "code": args.code, "L": L, "p": args.p, "eta": args.eta, "Nc": Nc,
+                       "iters": args.iters, "horizon_ladder_steps": args.ladder_steps, "SEQ": 2, "TOPS": 10, "eps": 0.1, "tops_burn": 2, "seed": args.seed,
+                       "scan": args.scan, "lds_bytes_per_workgroup": lds.value, "threads_per_workgroup": threads.value,
+                       "workspace_bytes": sh.ws_bytes, "parallelism": "syndrome shards x%d, RCCL gather of class counts" % world},
+            "useful_proposals_per_launch": useful_props_launch,
+            "useful_proposals_per_s": useful_total / elapsed,
+            "kernel_ms_per_launch": k_ms,
+            "stopping": {"converged_frac": float(conv.mean()), "mean_steps": float(sd.mean()), "median_steps": float(np.median(sd)),
+                         "p99_steps": float(np.percentile(sd, 99)), "max_steps": float(sd.max())},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": algo_bytes,
+                         "note": "8 B per USEFUL proposal (SURVEY.md 8d convention): steps a ladder ran before it stopped; idle lanes, the two "
+                                 "steps a lane waits between ladders and the tail after a workgroup's queue ran dry are time, not work"},
+            # useful rate / the fixed-length rate of the same kernel family on this box: what the criterion, the queue and its tail cost together
+            "efficiency_vs_fixed_length": (useful_props_launch / (k_ms * 1e-3)) / fixed_rate,
+            "fixed_length_proposals_per_s": fixed_rate,
+            "comm": {"backend": (dist.get_backend() + " (RCCL)") if use_dist else None, "world": dist.get_world_size() if use_dist else 1},
+            "ranks": ranks,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle as orc
+            ocode = {"toric": orc.TORIC, "xzzx": orc.XZZX, "rotated": orc.ROTATED, "planar": orc.PLANAR}[args.code]
+            cores = os.cpu_count() or 1
+            n_cpu = min(N, cores)
+            okw = dict(iters=args.iters, tops_burn=2, seed=args.seed, n_threads=cores, conv_criteria="error_based", SEQ=2, TOPS=10, eps=0.1,
+                       noise=orc.DEPOLARIZING if args.eta is None else orc.BIASED, eta=args.eta or 0.0)
+            t1 = time.perf_counter()
+            ref0 = orc.pteq_batch(ocode, init_h[:n_cpu], args.p, Nc, args.ladder_steps, first_syndrome=first, scan=0, **okw)   # the reference's own loop
+            dt = time.perf_counter() - t1
+            cpu_props = float(ref0["steps_done"].sum()) * Nc * args.iters
+            out["cpu_baseline"] = {"value": cpu_props / n_gen / dt, "unit": "chain-sweeps/s", "cores": cores, "cpu_model": cpu_model(), "kind": "port",
+                                   "sample": f"{n_cpu} syndromes, one per thread, each run to its criterion stop or the horizon ({cpu_props:.3g} proposals, {dt:.1f} s)",
+                                   "proposals_per_s": cpu_props / dt}
+            # the metric's histogram match on the criterion route: 64 ladders (one workgroup, a lane each) through the same entry point and
+            # kernel, against the oracle's restatement of the rule -- class counts, samples, tops0, stopping step and flag, bit for bit
+            import qecmc
+            n_chk = min(N, 64)
+            got = qecmc.pteq_batch(init_h[:n_chk], args.p, Nc=Nc, steps=args.ladder_steps, iters=args.iters, tops_burn=2, seed=args.seed, first_syndrome=first,
+                                   code=code_id, eta=args.eta, conv_criteria="error_based", SEQ=2, TOPS=10, eps=0.1, scan=args.scan, flags=args.flags)
+            ref = orc.pteq_batch(ocode, init_h[:n_chk], args.p, Nc, args.ladder_steps, first_syndrome=first, scan=3 if args.scan == "wave" else 0, **okw)
+            same = all(np.array_equal(np.asarray(got[k]).astype(np.uint64), np.asarray(ref[k]).astype(np.uint64)) for k in ("counts", "samples", "tops0", "steps_done"))
+            out["histogram_match"] = {"syndromes_checked": n_chk, "horizon": args.ladder_steps,
+                                      "class_counts_samples_tops0_stopping_step_bit_identical_to_cpu_oracle": bool(same),
+                                      "converged_flags_identical": bool(np.array_equal(got["converged"], ref["converged"])),
+                                      "match": bool(same and np.array_equal(got["converged"], ref["converged"]))}
+        print(json.dumps(out))
+    sh.close()
+    if use_dist:
+        dist.destroy_process_group()
+
+
 def spawn_ranks(n, argv):
     """`bench.py --gpus N` outside a launcher: start N ranks (one per GPU) as children of this process, which has not
     touched the GPU, wait, and hand their exit code on.  The same command line the driver uses."""
@@ -211,6 +326,10 @@ def parse_args(argv=None):
                     help="random = the reference's random-scan chain (scan=0); wave = the same chain per syndrome with a generator pick shared by the 64 "
                          "ladders of a wavefront, states in registers (scan=3); auto = wave where it is built and the faster one (depolarizing rule, "
                          "at most 16 packed state words per rung: toric L <= 11), else random; sweep = systematic generator sweep (scan=1: not the reference's chain)")
+    ap.add_argument("--criterion", action="store_true",
+                    help="time the route the reference runs by default (decoders.py:25 conv_criteria='error_based', SEQ=2, TOPS=10, eps=0.1): every "
+                         "ladder stops by the criterion or at the horizon of --ladder-steps of its own steps; `value` counts the steps the ladders "
+                         "actually ran.  Defaults: 8 ladders per lane of the persistent grid (--syndromes 524288), horizon 262144, one launch per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--library", default=None, help="time another build of libqecmc.so (same ABI) instead of the in-tree one: A/B runs on one box")
     ap.add_argument("--flags", type=lambda v: int(v, 0), default=0, help="qecmc_params.flags: developer switches between equivalent kernel variants (include/qecmc.h)")
@@ -219,6 +338,15 @@ def parse_args(argv=None):
                     help="launcher / exchange rehearsal without a GPU: gloo, no kernel, zero throughput (tests/test_bench_launcher.py)")
     args = ap.parse_args(argv)
     cfg = CONFIGS[args.config]
+    if args.criterion:
+        # N >= 8 ladders per lane of the persistent grid (256 CUs x 4 workgroups x 64 lanes at the config-2 shape); the horizon bounds the
+        # log workspace (2 B per lane of the grid and ladder step) and censors a quarter of the L = 9, p = 0.15 ladders
+        if args.syndromes is None:
+            args.syndromes = 8 * cfg["syndromes"]
+        if args.ladder_steps == 10000:
+            args.ladder_steps = 262144
+        if args.steps == 5 and args.warmup == 1:      # (a launch runs for seconds: two timed ones, the first launch of the process among them)
+            args.steps, args.warmup = 2, 0
     for k in ("code", "L", "p", "Nc", "syndromes", "eta"):
         if getattr(args, k) is None:
             setattr(args, k, cfg[k])
@@ -294,6 +422,8 @@ def main():
         dist.init_process_group("nccl", device_id=dev)   # RCCL
 
     init_h = make_batch(args, rank)
+    if args.criterion:
+        return criterion_bench(args, L_, PteqShard, torch, dist, use_dist, world, rank, local_rank, dev, init_h, first, code_id, nq, ncls, n_gen, workload)
     sh = PteqShard(init_h, args.p, first, n_total=N * world, code=code_id, Nc=Nc, p_logical=args.p_logical, iters=args.iters,
                    steps=args.ladder_steps, tops_burn=2, seed=args.seed,
                    noise=L_.NOISE_DEPOLARIZING if args.eta is None else L_.NOISE_BIASED, eta=args.eta or 0.0,

@@ -275,7 +275,10 @@ int qecmc_ptdc_batch_xyz(const qecmc_params *params, const uint8_t *init, uint64
 typedef struct qecmc_plan qecmc_plan;
 int qecmc_plan_create(const qecmc_params *params, qecmc_plan **plan_out);
 int qecmc_plan_destroy(qecmc_plan *plan);
-int qecmc_plan_workspace_bytes(const qecmc_plan *plan, uint64_t N, uint64_t *bytes_out);
+/* the workspace a launch of N syndromes needs: with_final_states != 0 for a launch that passes d_final_states (one log column per ladder:
+ * 2 N steps bytes, 4 for alpha noise); 0 for one that does not -- the plans with a work queue then log one column per lane of their
+ * persistent grid, however large the batch */
+int qecmc_plan_workspace_bytes(const qecmc_plan *plan, uint64_t N, int with_final_states, uint64_t *bytes_out);
 int qecmc_pteq_launch_dev(qecmc_plan *plan, const void *d_init, uint64_t N, uint32_t first_syndrome,
                           void *d_counts, void *d_samples, void *d_tops0 /*nullable*/,
                           void *d_steps_done /*nullable*/, void *d_converged /*nullable*/,

@@ -748,11 +748,12 @@ static uint64_t workspace_need(const qecmc_plan *plan, uint64_t N, bool queue)
     return (plan->prm.noise == QECMC_NOISE_ALPHA ? 4ull : 2ull) * cols * plan->prm.steps;
 }
 
-int qecmc_plan_workspace_bytes(const qecmc_plan *plan, uint64_t N, uint64_t *bytes_out)
+int qecmc_plan_workspace_bytes(const qecmc_plan *plan, uint64_t N, int with_final_states, uint64_t *bytes_out)
 {
     if (!plan || !bytes_out) return fail(QECMC_ERR_INVALID, "NULL argument");
-    // (enough for any launch of N syndromes with this plan: a launch that takes the work queue uses fewer columns)
-    *bytes_out = workspace_need(plan, N, false);
+    // what qecmc_pteq_launch_dev(plan, N syndromes, d_final_states given or not) will ask for: a launch that may take the plan's work
+    // queue logs one column per lane of the persistent grid, any other one column per ladder
+    *bytes_out = workspace_need(plan, N, launch_takes_queue(plan, with_final_states != 0 || plan->d_swap_acc != nullptr));
     return 0;
 }
 

@@ -97,7 +97,7 @@ SIGNATURES = {
     "qecmc_plan_set_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "qecmc_pteq_resume_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64,
                                         C.c_void_p, C.c_void_p, C.c_void_p]),
-    "qecmc_plan_workspace_bytes": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "qecmc_plan_workspace_bytes": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]),
     "qecmc_plan_create": (C.c_int, [C.POINTER(Params), C.POINTER(C.c_void_p)]),
     "qecmc_plan_destroy": (C.c_int, [C.c_void_p]),
     "qecmc_plan_info": (C.c_int, [C.c_void_p, _u32p, _u32p, _u32p]),

@@ -137,6 +137,16 @@ class PteqShard:
         self.rec = torch.zeros(self.max_rows * (self.ncls + 2), dtype=torch.int32, device=self.dev)
         self.gathered = ([torch.empty_like(self.rec) for _ in range(self.world)]
                          if (self.dist_on and self.rank == dst) else None)
+        # runs that stop by the criterion (decoders.py:74-82): the log workspace, and where every ladder stopped
+        self.ws = self.steps_done = self.converged = None
+        self.ws_bytes = 0
+        if params.get("conv_mode", L_.CONV_NONE) != L_.CONV_NONE:
+            need = C.c_uint64()
+            L_.check(L_.lib().qecmc_plan_workspace_bytes(self.plan, self.n, 0, C.byref(need)))
+            self.ws_bytes = int(need.value)
+            self.ws = torch.empty(max(self.ws_bytes, 1), dtype=torch.uint8, device=self.dev)
+            self.steps_done = torch.zeros(self.n, dtype=torch.int32, device=self.dev)
+            self.converged = torch.zeros(self.n, dtype=torch.uint8, device=self.dev)
 
     def views(self, rec=None, n=None):
         rec = self.rec if rec is None else rec
@@ -150,7 +160,10 @@ class PteqShard:
         counts, samples, tops0 = self.views()
         if self.n:
             L_.check(L_.lib().qecmc_pteq_launch_dev(self.plan, self.d_init.data_ptr(), self.n, self.first, counts.data_ptr(),
-                                                    samples.data_ptr(), tops0.data_ptr(), None, None, None, None, 0,
+                                                    samples.data_ptr(), tops0.data_ptr(),
+                                                    None if self.steps_done is None else self.steps_done.data_ptr(),
+                                                    None if self.converged is None else self.converged.data_ptr(), None,
+                                                    None if self.ws is None else self.ws.data_ptr(), self.ws_bytes,
                                                     C.c_void_p(stream.cuda_stream)))
 
     def gather(self):

@@ -182,7 +182,7 @@ def test_launch_dev_refuses_an_undersized_workspace(q, kind):
     L_.check(L_.lib().qecmc_plan_create(pr, C.byref(plan)))
     try:
         need = C.c_uint64()
-        L_.check(L_.lib().qecmc_plan_workspace_bytes(plan, N, C.byref(need)))
+        L_.check(L_.lib().qecmc_plan_workspace_bytes(plan, N, 0, C.byref(need)))
         assert need.value == (4 if kind == "alpha" else 2) * 256 * steps          # one column per ladder, whole groups of 64
         dev = torch.device("cuda", 0)
         init = torch.zeros(N * nq, dtype=torch.uint8, device=dev)

@@ -34,7 +34,7 @@ for f in glob.glob(out + "/pmc_*/*/*_counter_collection.csv"):
 summ = {k: sum(v) / len(v) for k, v in acc.items()}
 summ['_launches_averaged'] = {k: len(v) for k, v in acc.items()}
 summ['_kernel'] = meta
-summ['_workload'] = {k: getattr(a, k) for k in ("code", "L", "p", "eta", "Nc", "iters", "syndromes", "ladder_steps", "p_logical")}
+summ['_workload'] = {k: getattr(a, k) for k in ("code", "L", "p", "eta", "Nc", "iters", "syndromes", "ladder_steps", "p_logical", "scan", "criterion")}
 json.dump(summ, open(out + "/pmc_summary.json", "w"), indent=1, sort_keys=True)
 print(json.dumps(summ, sort_keys=True)[:1500])
 PY
