@@ -24,11 +24,17 @@ sys.argv = ["bench.py", "--config", str(cfg)] + sys.argv[3:]
 sys.path.insert(0, ".")
 import bench
 a = bench.parse_args(sys.argv[1:])
+# the DOMINANT ladder kernel of the run (bench.py also launches companions: the scan = 0 kernel beside a scan = wave headline, the
+# fixed-length kernel beside a criterion run): the one the kernel trace gives the largest total time
+dominant = None
+for r in csv.DictReader(open(out + "/kernel_stats.csv")):
+    if 'ladder' in r['Name'] and (dominant is None or float(r['TotalDurationNs']) > dominant[1]):
+        dominant = (r['Name'], float(r['TotalDurationNs']))
 acc = collections.defaultdict(list)
 meta = {}
 for f in glob.glob(out + "/pmc_*/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if 'ladder' in r['Kernel_Name']:
+        if r['Kernel_Name'] == dominant[0]:
             acc[r['Counter_Name']].append(float(r['Counter_Value']))
             meta = {k: r[k] for k in ('Kernel_Name', 'Grid_Size', 'Workgroup_Size', 'LDS_Block_Size', 'VGPR_Count', 'SGPR_Count', 'Scratch_Size')}
 summ = {k: sum(v) / len(v) for k, v in acc.items()}
