@@ -151,12 +151,12 @@ def cpu_model():
     return "unknown"
 
 
-def oracle_batch(args, init, steps, n_threads, first=0, states=False, scan=None):
+def oracle_batch(args, init, steps, n_threads, first=0, states=False, scan=None, tops_burn=2):
     """the CPU oracle on a sample of the batch: the checker of the timed pass (its scan) or the timed CPU baseline (scan = 0: the
     reference's own loop, one pick per ladder -- a CPU has no wavefront to share a pick with)"""
     from oracle import oracle as orc
     code = {"toric": orc.TORIC, "xzzx": orc.XZZX, "rotated": orc.ROTATED, "planar": orc.PLANAR}[args.code]
-    return orc.pteq_batch(code, init, args.p, args.Nc, steps, iters=args.iters, tops_burn=2, seed=args.seed, first_syndrome=first,
+    return orc.pteq_batch(code, init, args.p, args.Nc, steps, iters=args.iters, tops_burn=tops_burn, seed=args.seed, first_syndrome=first,
                           n_threads=n_threads, noise=orc.DEPOLARIZING if args.eta is None else orc.BIASED, eta=args.eta or 0.0, return_states=states,
                           scan=(3 if args.scan == "wave" else 0) if scan is None else scan)
 
@@ -530,17 +530,21 @@ def main():
                 # state-dependent outputs that are non-zero whatever the burn-in did (the long-lattice configurations pass
                 # tops_burn = 2 for few or none of their ladders in 10 000 steps): tops0 of the timed pass, and -- from one more
                 # pass of the same ladders through the host-pointer entry point -- every rung's final configuration
+                # That second pass runs with tops_burn = 0 (every step is a sample), so that the class histogram itself is compared on
+                # every configuration: same trajectories, non-zero counts whatever the burn-in did.
                 import qecmc
-                again = qecmc.pteq_batch(init_h[:n_chk], args.p, Nc=Nc, steps=args.ladder_steps, iters=args.iters, tops_burn=2, seed=args.seed,
+                again = qecmc.pteq_batch(init_h[:n_chk], args.p, Nc=Nc, steps=args.ladder_steps, iters=args.iters, tops_burn=0, seed=args.seed,
                                          first_syndrome=first, code=code_id, eta=args.eta, return_states=True, flags=args.flags, scan=args.scan)
+                ref0 = oracle_batch(args, init_h[:n_chk], args.ladder_steps, os.cpu_count() or 1, tops_burn=0)
+                hist0 = bool(np.array_equal(again["counts"], ref0["counts"]) and int(again["counts"].sum()) == n_chk * args.ladder_steps)
                 out["histogram_match"] = {"syndromes_checked": n_chk, "ladder_steps": args.ladder_steps,
                                           "syndromes_with_samples": with_samples,
                                           # (null: no ladder of the sample got past the burn-in, the counts are all zero on both sides)
                                           "class_counts_bit_identical_to_cpu_oracle": same if with_samples else None,
+                                          "class_histogram_of_every_step_bit_identical_to_cpu_oracle": hist0,
                                           "tops0_bit_identical_to_cpu_oracle": bool(np.array_equal(tops0[:n_chk].astype(np.uint64), ref["tops0"].astype(np.uint64))),
-                                          "final_states_bit_identical_to_cpu_oracle": bool(np.array_equal(again["states"], ref["states"]) and
-                                                                                           np.array_equal(again["counts"], ref["counts"])),
-                                          "match": bool(same and np.array_equal(tops0[:n_chk].astype(np.uint64), ref["tops0"].astype(np.uint64)) and
+                                          "final_states_bit_identical_to_cpu_oracle": bool(np.array_equal(again["states"], ref["states"])),
+                                          "match": bool(same and hist0 and np.array_equal(tops0[:n_chk].astype(np.uint64), ref["tops0"].astype(np.uint64)) and
                                                         np.array_equal(again["states"], ref["states"]))}
         if world == 1 and args.scan == "wave":
             # the same batch through the scan = 0 kernel (the chain pinned draw for draw to the reference's injected-stream fixtures), for the record

@@ -87,3 +87,21 @@ def test_sharding_launch_propagates_failure():
     from qecmc.sharding import launch
     with pytest.raises(RuntimeError):
         launch(2, _failing, backend="gloo", timeout=60)
+
+
+@pytest.mark.gpu
+def test_bench_under_torchrun_initialises_rccl_and_gathers():
+    """The driver's launcher form on the GPU box, world 1, as a FRESH child process: RCCL initialises, the gather
+    path runs, the line certifies its communicator and its rank's shard."""
+    from qecmc.sharding import free_port
+    e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        e.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+           "--ladder-steps", "500"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=e)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert "nccl" in out["comm"]["backend"] and out["comm"]["world"] == 1
+    assert out["ranks"][0]["first_syndrome"] == 0 and out["n_gpus"] == 1 and out["value"] > 0

@@ -73,7 +73,7 @@ def test_stencil_argument_errors(q):
 
 
 # ------------------------------------------------------------------ Chain.update_chain vs oracle (same Philox stream)
-@pytest.mark.parametrize("L,p,p_logical,iters", [(3, 0.5, 0.0, 50), (5, 0.10, 0.0, 1000), (9, 0.15, 0.0, 2000),
+@pytest.mark.parametrize("L,p,p_logical,iters", [(3, 0.5, 0.0, 50), (5, 0.10, 0.0, 1000), (5, 0.10, 0.0, 10000), (9, 0.15, 0.0, 2000),   # (5, 0.1, 0, 10000): BASELINE config 1 at its stated length
                                                  (9, 0.75, 0.5, 1000), (5, 0.30, 0.5, 1000), (9, 0.20, 0.25, 800),
                                                  (15, 0.18, 0.0, 500), (4, 0.6, 1.0, 300)])
 def test_chain_update_bit_exact(q, orc, L, p, p_logical, iters):
