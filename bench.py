@@ -496,6 +496,7 @@ def main():
                        "lds_bytes_per_workgroup": lds.value, "threads_per_workgroup": threads.value,
                        "parallelism": "syndrome shards x%d, RCCL gather of class counts" % world},
             "proposals_per_s": total_proposals / elapsed,
+            "library_path": L_.library_path(),
             "comm": {"backend": (dist.get_backend() + " (RCCL)") if use_dist else None, "world": dist.get_world_size() if use_dist else 1},
             "ranks": ranks,
             "ladder_sweeps_per_s": sweeps_per_s / Nc,

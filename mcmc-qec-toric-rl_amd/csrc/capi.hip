@@ -599,8 +599,20 @@ int qecmc_chain_update_alpha(int code, int L, uint64_t N, uint8_t *states_inout,
 // The step entry points' plan cache: keyed by the whole parameter block (the fields a plan does not depend on -- seed, first_syndrome,
 // steps -- are constant for one ladder anyway), a handful of entries, least recently used out first.  Plans are immutable once
 // built (a launch works on a copy of `args`), so concurrent callers may share one.
-static int cached_plan(const qecmc_params &p, std::shared_ptr<const qecmc_plan> *out)
+// (the key: exactly the fields build_plan reads, in a zeroed struct -- not the caller's block with its padding, seed, first_syndrome
+// and step count, which would make a cache miss of every ladder with its own seed)
+static qecmc_params plan_key(const qecmc_params &p)
 {
+    qecmc_params k;
+    std::memset(&k, 0, sizeof k);
+    k.abi_size = p.abi_size; k.code = p.code; k.L = p.L; k.Nc = p.Nc; k.noise = p.noise; k.scan = p.scan; k.conv_mode = p.conv_mode; k.device = p.device;
+    k.iters = p.iters; k.tops_burn = p.tops_burn; k.TOPS = p.TOPS; k.SEQ = p.SEQ; k.replicas = p.replicas; k.eps = p.eps; k.p = p.p; k.eta = p.eta;
+    k.alpha = p.alpha; k.p_logical = p.p_logical; k.flags = p.flags;
+    return k;
+}
+static int cached_plan(const qecmc_params &pin, std::shared_ptr<const qecmc_plan> *out)
+{
+    const qecmc_params p = plan_key(pin);
     struct Entry { qecmc_params key; std::shared_ptr<const qecmc_plan> plan; uint64_t used; };
     static std::mutex mu;
     static std::vector<Entry> *cache = new std::vector<Entry>;     // (never destroyed, like the block pool)
@@ -612,7 +624,7 @@ static int cached_plan(const qecmc_params &p, std::shared_ptr<const qecmc_plan> 
             if (std::memcmp(&e.key, &p, sizeof p) == 0) { e.used = ++tick; *out = e.plan; return 0; }
     }
     auto pl = std::make_shared<qecmc_plan>();
-    if (int rc = build_plan(&p, pl.get())) return rc;
+    if (int rc = build_plan(&pin, pl.get())) return rc;
     *out = pl;
     std::lock_guard<std::mutex> g(mu);
     if (cache->size() >= kEntries) {
@@ -662,6 +674,7 @@ static int ladder_step_impl(const qecmc_params *params, uint64_t N, uint8_t *sta
     if (neff_inout) a.neff = d.as<uint32_t>();
     a.states = d.as<uint8_t>() + o_st; a.flags = d.as<uint8_t>() + o_fl; a.tops0 = reinterpret_cast<uint32_t *>(d.as<uint8_t>() + o_t0);
     a.N = N; a.first_syndrome = p.first_syndrome; a.step0 = step0; a.prop0 = prop0; a.nsteps = nsteps;
+    a.seed_lo = (uint32_t)p.seed; a.seed_hi = (uint32_t)(p.seed >> 32);      // (the cached tables do not depend on the seed: patched per call)
     a.resume = 1; a.write_states = 1;
     HIP_TRY(launch_ladder_rs_toric(a, 0));
     HIP_TRY(hipMemcpy(h.data(), d.p, total, hipMemcpyDeviceToHost));
@@ -702,8 +715,15 @@ int qecmc_plan_create(const qecmc_params *params, qecmc_plan **plan_out)
 
 int qecmc_plan_destroy(qecmc_plan *plan)
 {
-    // the plan's tables may go back to the block pool and on to another call: wait for the launches that read them (what hipFree used to do)
-    if (plan) { (void)hipSetDevice(plan->prm.device); (void)hipDeviceSynchronize(); }
+    // the plan's tables may go back to the block pool and on to another call: wait for the launches that read them (what hipFree used
+    // to do) -- on the plan's device, leaving the caller's current device as it was
+    if (plan) {
+        int cur = -1;
+        const bool have = hipGetDevice(&cur) == hipSuccess;
+        (void)hipSetDevice(plan->prm.device);
+        (void)hipDeviceSynchronize();
+        if (have && cur != plan->prm.device) (void)hipSetDevice(cur);
+    }
     delete plan;
     return 0;
 }
@@ -870,7 +890,7 @@ int qecmc_pteq_batch_stats(const qecmc_params *params, const uint8_t *init, uint
     const auto t0 = std::chrono::steady_clock::now();
     qecmc_plan *pl = nullptr;
     if (int rc = qecmc_plan_create(params, &pl)) return rc;
-    struct Guard { qecmc_plan *p; ~Guard() { delete p; } } guard{pl};
+    struct Guard { qecmc_plan *p; ~Guard() { qecmc_plan_destroy(p); } } guard{pl};   // (synchronises: an error return may leave the launch running)
     if (N == 0) return 0;
     if (!init || !counts_out || !samples_out) return fail(QECMC_ERR_INVALID, "NULL buffer");
     const size_t nq = pl->args.nq, Nc = pl->args.Nc, ncls = pl->args.ncls, R = pl->args.replicas;
@@ -974,7 +994,7 @@ int qecmc_ptdc_batch_xyz(const qecmc_params *params, const uint8_t *init, uint64
     const bool init_per_droplet = flags & QECMC_PTDC_INIT_PER_DROPLET, per_rung = flags & QECMC_PTDC_SET_PER_RUNG;
     qecmc_plan *pl = nullptr;
     if (int rc = qecmc_plan_create(&p, &pl)) return rc;
-    struct Guard { qecmc_plan *p; ~Guard() { delete p; } } guard{pl};
+    struct Guard { qecmc_plan *p; ~Guard() { qecmc_plan_destroy(p); } } guard{pl};   // (synchronises: an error return may leave the launch running)
     if (N == 0) return 0;
     if (!init || !hist_out) return fail(QECMC_ERR_INVALID, "NULL buffer");
     const size_t nq = pl->args.nq, Nc = pl->args.Nc, ncls = pl->args.ncls, D = (size_t)droplets;

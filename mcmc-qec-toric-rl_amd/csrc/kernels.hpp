@@ -90,7 +90,7 @@ struct LadderArgs {
     // and tops0 to the outputs of syndrome l / R (atomics; the caller zeroes them) -- decoders.py:215-225 "droplets"
     uint32_t *queue;          // QUEUE kernels: the batch's counter of ladders handed out after launch (zeroed by the caller)
     uint32_t grid_cap;        // ... the persistent grid: at most this many workgroups (0: one per 64 ladders)
-    uint32_t tune;            // development knobs (QECMC_TUNE; 0 in production): bit 1 = no PRE instantiations, bit 2 = no dE table, bit 3 = no SSW instantiations
+    uint32_t tune;            // development knobs (qecmc_params.flags bits 0-15, include/qecmc.h qecmc_flag; 0 in production): bit 1 = no PRE instantiations, bit 2 = no dE table, bit 3 = no SSW instantiations
     uint32_t replicas;
     int accumulate;           // counts / samples are added to (qecmc_pteq_resume_dev)
     // equilibrium observables (qecmc_plan_set_stats; nullable): accepted swaps per rung pair, sum of error counts per rung

@@ -667,8 +667,8 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
         // ONE Philox word per proposal (word k&3 of block (k>>2, 1), so a block feeds four): its top 20 bits pick the
         // generator, g = floor(x20 * G / 2^20) (the G generators as equally likely as 20 bits allow: G 2^-20; the proposal stays
         // symmetric, so the stationary law is untouched) and its low 12 bits lead the 44-bit acceptance uniform.  Word k&3 of
-        // the refinement block (k>>2, kSubRefine) supplies the other 32 bits, and is computed only when some lane_t's 12 bits
-        // tie with its threshold's (once in 4096 proposals per lane_t).
+        // the refinement block (k>>2, kSubRefine) supplies the other 32 bits, and is computed only when some lane's 12 bits
+        // tie with its threshold's (once in 4096 proposals per lane).
         [[maybe_unused]] auto random_scan_loop = [&]() {
             int ni = DELUT ? (int)(4u * n) : (int)n;
             const uint32_t *myF = thrF + slot_u * 4 - 5;                            // indexed by dE + 4 = 5..8
@@ -693,7 +693,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
                     const uint32_t v = delut[(ev.z & 0xF00u) | F];
                     const uint32_t a12 = xw & 0xFFFu, tI = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(myT - 4) + v);
                     bool acc = a12 < tI;                                            // mcmc.py:42 (dE <= 0: tI = 4096)
-                    if (a12 == tI) {                                                // rare (a lane_t in 4096): the next 32 bits decide
+                    if (a12 == tI) {                                                // rare (a lane in 4096): the next 32 bits decide
                         constexpr int WI = decltype(wsel)::value;
                         const u32x4 r = philox_block(kb - (kq >> 2), kSubRefine, syn, strm, a.seed_lo, a.seed_hi);
                         acc = (WI == 0 ? r.x : WI == 1 ? r.y : WI == 2 ? r.z : r.w) < *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(myF) + v);
@@ -716,7 +716,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
                 const uint32_t dE16 = __popc(__builtin_amdgcn_bitop3_b32(uF, F, nzG, 0xAB));   // ~(uF | F) | nzG;  = dE + 16
                 const uint32_t a12 = xw & 0xFFFu, tI = (myT - 16)[dE16];
                 bool acc = a12 < tI;                                                // mcmc.py:42 (dE <= 0: tI = 4096)
-                if (a12 == tI) {                                                    // rare (a lane_t in 4096): the next 32 bits decide
+                if (a12 == tI) {                                                    // rare (a lane in 4096): the next 32 bits decide
                     constexpr int WI = decltype(wsel)::value;
                     const u32x4 r = philox_block(kb - (kq >> 2), kSubRefine, syn, strm, a.seed_lo, a.seed_hi);
                     acc = (WI == 0 ? r.x : WI == 1 ? r.y : WI == 2 ? r.z : r.w) < (myF - 12)[dE16];
@@ -939,7 +939,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
                         uint32_t Nn, idx0 = 0, mw = 0;
                         [[maybe_unused]] const uint32_t *m0 = lml + L * W, *m1 = m0;   // identity rows (LDS copy of the plan's masks)
                         if constexpr (CODE == kCodeXzzx) {
-                            // branch-free: every lane_t reads its generator (harmless where the proposal is a logical operator)
+                            // branch-free: every lane reads its generator (harmless where the proposal is a logical operator)
                             const uint4 ev = gen_entry(gi);
                             mw = mtab[gi];
                             const uint32_t F = sites(ev, sad, ssh);
@@ -1067,7 +1067,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
                 blind_sweep_tables();
             } else if (top && acc_all) {
                 // random scan, top chain at f = 1 (mcmc.py:30): every proposal is applied blindly, n recounted once.  With a row
-                // of the lattice inside one word (L <= 16) the logical operators are collected in a per-lane_t frame and applied
+                // of the lattice inside one word (L <= 16) the logical operators are collected in a per-lane frame and applied
                 // once per step, as on the toric code: xzzx -- parities of the (position-independent) anti-diagonal X and
                 // diagonal Z; rotated -- the set of X columns and of Z rows; planar -- the X rows and Z columns of layer 0.
                 uint32_t cdelta = 0, frX = 0, frZ = 0;
@@ -1081,7 +1081,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
                             frX ^= CODE == kCodeXzzx ? ax : ax << xp;
                             frZ ^= CODE == kCodeXzzx ? az : az << zp;
                         } else {
-                            // the operator's L + L sites, generated on the fly (per-lane_t positions would make the plan's mask rows
+                            // the operator's L + L sites, generated on the fly (per-lane positions would make the plan's mask rows
                             // 2 W scattered global loads per proposal): xzzx -- X on the anti-diagonal, Z on the diagonal
                             // (xzzx_model.py:291-311); rotated -- X on column X_pos, Z on row Z_pos (rotated_surface_model.py:260-280);
                             // planar -- X on row X_pos, Z on column Z_pos of layer 0 (planar_model.py:264-268)
@@ -1385,7 +1385,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
         } else if (acc_all && L <= 16) {
             // Top chain at p = 0.75: every proposal is accepted (mcmc.py:30), so moves are blind
             // XORs and commute.  Stabilizers go straight to LDS; logical operators are collected
-            // in a per-lane_t frame (which rows / columns carry an operator) and flushed once.
+            // in a per-lane frame (which rows / columns carry an operator) and flushed once.
             //   fr0: bit r      = X on row r of layer 0      bit 16+c = Z on column c of layer 0
             //   fr1: bit c      = X on column c of layer 1   bit 16+r = Z on row r of layer 1
             uint32_t fr0 = 0, fr1 = 0, cdelta = 0;
@@ -1720,7 +1720,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
                     } else
                     if (CONV && (QUEUE ? !q_dead : lane_t < cnt)) {
                         // nbr_errors_bottom_chain[since_burn] = count_errors (:68); series index i lives in log row burn+i
-                        // (QUEUE: one log column per lane_t of the persistent grid, rows = the ladder's own steps)
+                        // (QUEUE: one log column per lane of the persistent grid, rows = the ladder's own steps)
                         const size_t lN = QUEUE ? (size_t)gridDim.x * 64u : (size_t)a.N;
                         uint16_t *mylog = a.nlog + (s0 + lane_t);
                         mylog[(size_t)(t - t0) * lN] = (uint16_t)n0;
@@ -1756,7 +1756,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_kernel(const LadderArgs a)
             }
             if (a.swap_acc != nullptr && wave_u == 0) {
                 // equilibrium observables (qecmc_plan_set_stats): the cascade once more, with every rung's decision and the error
-                // count each rung ends the step with added to per-lane_t LDS counters (off the hot path: one scalar branch when off)
+                // count each rung ends the step with added to per-lane LDS counters (off the hot path: one scalar branch when off)
                 uint32_t *sacc = lds_all + gdw + lane_t, *nsum = sacc + NC * 64;
                 uint32_t c2 = cur[(NC - 1) * 64];
                 for (int i = NC - 2; i >= 0; --i) {

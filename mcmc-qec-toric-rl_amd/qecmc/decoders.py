@@ -99,7 +99,12 @@ def PTEQ(init_code, p, Nc=None, SEQ=2, TOPS=10, tops_burn=2, eps=0.1, steps=5000
     (decoders.py:215-225).  R = 64 fills the wavefronts at the price of one; it is a different (lower-variance) estimator
     whose run ends when the slowest of the R ladders has converged, so it is opt-in.
     scan="colour" (with conv_criteria=None) decodes the one syndrome in the latency layout: a workgroup per ladder, a colour
-    phase of generators per wavefront pass -- 10-20 x sooner at tops0 >= 10 than the lane-per-chain layout (profiles/r03_latency.json)."""
+    phase of generators per wavefront pass.  A ladder step of `iters` = 10 there is 10 PHASES -- about 1.4 sweeps of every rung
+    at toric L = 9 -- against 10 proposals (0.06 sweep) in the lane-per-chain layout, at 1.3 x the time per step; that work
+    ratio is why it reaches tops0 >= 10 in 17-41 ms instead of 187-366 ms (profiles/r03_latency.json).  The stop itself
+    (tops0 >= 10, or the eps = 0.1 heuristic) is the reference's and says nothing about decoding quality at equal wall time.
+    scan="wave": the reference's own chain per syndrome with a generator pick shared by the 64 ladders of a wavefront (the
+    batched throughput layout, qecmc.pteq_batch; a one-syndrome call gains nothing from it)."""
     return _pteq(init_code, p, None, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, conv_criteria, seed, replicas=replicas, scan=scan)
 
 

@@ -26,5 +26,21 @@ case "$1" in
   bench)        # bench <tag> <bench args>
     shift; b "$@"
     ;;
+  ab)           # ab <other libqecmc.so> <bench args>: this build against another one of the same ABI, alternating on one box (bench.py --library)
+    shift; other=$1; shift
+    for i in 1 2; do b this_$i "$@" && b other_$i --library "$other" "$@" || exit 1; done
+    ;;
+  profiles)     # profiles <tag> <config ...>: tools/profile_round.sh (kernel trace + separate PMC passes + bench) for BASELINE configurations
+    shift; tag=$1; shift
+    for c in "$@"; do bash tools/profile_round.sh $tag $c > gpurun_out/prof_${tag}_cfg$c.log 2>&1 || exit 1; tail -2 gpurun_out/prof_${tag}_cfg$c.log; done
+    ;;
+  criterion)    # criterion [bench args]: the reference's default route (bench.py --criterion), the line kept under gpurun_out/
+    shift
+    timeout -k 10 1000 python bench.py --criterion "$@" > gpurun_out/criterion_bench.json 2> gpurun_out/criterion_bench.err; tail -c 1500 gpurun_out/criterion_bench.json
+    ;;
+  round-end)    # the driver's round-end sequence rehearsed: GPU tests, smoke(), the default bench line
+    timeout -k 10 1000 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests.log 2>&1; rc=$?; tail -4 gpurun_out/gpu_tests.log
+    [ $rc -eq 0 ] && python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" && python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err && tail -c 600 gpurun_out/bench_default.json
+    ;;
   *) echo "unknown step $1"; exit 2 ;;
 esac

@@ -36,7 +36,8 @@ int main(int argc, char **argv)
     const size_t nq = pl->args.nq;
     std::vector<uint8_t> init(N * nq, 0);     // the trivial syndrome: what a step costs does not depend on it
     uint8_t *di; uint32_t *dc, *ds, *dt; uint64_t *dbg;
-    const unsigned grid = (unsigned)((N + 63) / 64);
+    // (the colour kernel launches one workgroup per ladder and stamps behind gridDim.x * 4 entries: size the buffer for ITS grid)
+    const unsigned grid = p.scan == QECMC_SCAN_COLOUR ? (unsigned)N : (unsigned)((N + 63) / 64);
     const size_t ndbg = (size_t)grid * 4 + 32 * 16 * 8;
     hipMalloc(&di, N * nq); hipMalloc(&dc, N * 64); hipMalloc(&ds, N * 4); hipMalloc(&dt, N * 4); hipMalloc(&dbg, ndbg * 8);
     hipMemcpy(di, init.data(), N * nq, hipMemcpyHostToDevice);
