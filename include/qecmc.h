@@ -181,6 +181,11 @@ int qecmc_chain_update_alpha(int code, int L, uint64_t N, uint8_t *states_inout,
                              double p_logical, uint64_t iters, uint64_t seed, uint32_t first_syndrome,
                              uint32_t slot, uint64_t k0, uint8_t *accepted_out);
 
+/* Chain_xyz.update_chain_fast(iters), src/mcmc.py:106-114,162-173 (what decoders.py:352,442 sample STDC_general_noise with): a
+ * generator proposal accepted with probability prod_i (p_i / (1 - p_x - p_y - p_z))^(change of n_i), i = x, y, z; p_xyz double[3]. */
+int qecmc_chain_update_xyz(int code, int L, uint64_t N, uint8_t *states_inout, const double *p_xyz, uint64_t iters,
+                           uint64_t seed, uint32_t first_syndrome, uint32_t slot, uint64_t k0);
+
 /* Ladder.step(iters) x nsteps, src/mcmc.py:94-103, on N ladders in slot order.
  * states uint8[N][Nc][nq], flags uint8[N][Nc], tops0 uint32[N]; step0 / prop0 =
  * ladder steps / proposals per slot already done (Philox addressing: at ladder step T the top chain draws from

@@ -596,6 +596,37 @@ int qecmc_chain_update_alpha(int code, int L, uint64_t N, uint8_t *states_inout,
     return chain_update_impl(code, L, N, states_inout, pz_tilde, alpha, QECMC_NOISE_ALPHA, p_logical, iters, seed, first_syndrome, slot, k0, accepted_out);
 }
 
+// Chain_xyz.update_chain_fast(iters), src/mcmc.py:106-114,162-173, on N independent chains: a stabilizer generator is proposed
+// (planar_model._apply_random_stabilizer in the reference, the code's own here) and accepted with probability
+// prod_i (p_i / (1 - sum p))^(change of n_i), i = x, y, z.  Draws as the non-top rule of qecmc_chain_update.
+int qecmc_chain_update_xyz(int code, int L, uint64_t N, uint8_t *states_inout, const double *p_xyz, uint64_t iters, uint64_t seed,
+                           uint32_t first_syndrome, uint32_t slot, uint64_t k0)
+{
+    PRIM_PROLOGUE();
+    if (!states_inout || !p_xyz) return fail(QECMC_ERR_INVALID, "NULL buffer");
+    const double tot = (p_xyz[0] + p_xyz[1]) + p_xyz[2];
+    if (!(p_xyz[0] > 0) || !(p_xyz[1] > 0) || !(p_xyz[2] > 0) || !(tot < 1.0)) return fail(QECMC_ERR_INVALID, "p_xyz=(%g,%g,%g) must be positive with a sum below 1", p_xyz[0], p_xyz[1], p_xyz[2]);
+    if (slot >= 0x100u) return fail(QECMC_ERR_INVALID, "slot %u collides with the swap stream id", slot);
+    const double f[3] = {p_xyz[0] / (1.0 - tot), p_xyz[1] / (1.0 - tot), p_xyz[2] / (1.0 - tot)};          // mcmc.py:110
+    std::vector<uint64_t> thr(729);
+    for (int dx = -4; dx <= 4; ++dx)
+        for (int dy = -4; dy <= 4; ++dy)
+            for (int dz = -4; dz <= 4; ++dz)
+                thr[((dx + 4) * 9 + (dy + 4)) * 9 + (dz + 4)] = thr44((std::pow(f[0], (double)dx) * std::pow(f[1], (double)dy)) * std::pow(f[2], (double)dz));   // :170
+    ChainArgs a;
+    std::memset(&a, 0, sizeof a);
+    DevBuf dthr, dst;
+    HIP_TRY(dthr.alloc(729 * 8)); HIP_TRY(dst.alloc(N * nq));
+    HIP_TRY(hipMemcpy(dthr.p, thr.data(), 729 * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dst.p, states_inout, N * nq, hipMemcpyHostToDevice));
+    a.states = dst.as<uint8_t>(); a.N = N; a.iters = iters; a.k0 = k0; a.first_syndrome = first_syndrome; a.slot = slot;
+    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.L = L; a.code = code; a.noise = 0;
+    a.xyz_thr = dthr.as<uint64_t>();
+    HIP_TRY(launch_chain_update(a, 0));
+    HIP_TRY(hipMemcpy(states_inout, dst.p, N * nq, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 // The step entry points' plan cache: keyed by the whole parameter block (the fields a plan does not depend on -- seed, first_syndrome,
 // steps -- are constant for one ladder anyway), a handful of entries, least recently used out first.  Plans are immutable once
 // built (a launch works on a copy of `args`), so concurrent callers may share one.

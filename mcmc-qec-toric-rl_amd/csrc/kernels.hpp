@@ -171,6 +171,7 @@ struct ChainArgs {
     int noise;                // 0 depolarizing (mcmc.py), 1 biased (mcmc_biased.py), 2 alpha (mcmc_alpha.py; same rule, other table)
     uint8_t *accepted;        // [N] out (nullable): 1 iff at least one proposal was accepted (Chain_alpha refreshes n_eff then)
     const double *bias_tbl;   // [4][nq+1] px^n, py^n, pz^n, pI^n (biased noise)
+    const uint64_t *xyz_thr;  // [9][9][9] ceil(w 2^44), w = prod_i (p_i / (1 - sum p))^(change of n_i): Chain_xyz (mcmc.py:106-114,162-173); nullable
 };
 hipError_t launch_chain_update(const ChainArgs &a, hipStream_t s);
 

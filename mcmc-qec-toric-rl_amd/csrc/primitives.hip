@@ -104,7 +104,10 @@ __global__ void k_chain_update(const ChainArgs a)
     const uint32_t syn = a.first_syndrome + (uint32_t)i;
     auto thr = [&](int dE) { return a.acc_tbl[dE]; };       // ceil(f^dE * 2^32), dE in [1, nq]
     const bool top = a.thr_logical != 0;
-    const double pb = a.noise ? biased_weight_b(a.bias_tbl, nq, m) : 0.0;       // mcmc_biased.py:28-31 (never refreshed: Q3)
+    const bool xyz = a.xyz_thr != nullptr;                                      // Chain_xyz (mcmc.py:106-114,162-173): acceptance by the change of (n_x, n_y, n_z)
+    const double pb = (a.noise && !xyz) ? biased_weight_b(a.bias_tbl, nq, m) : 0.0;       // mcmc_biased.py:28-31 (never refreshed: Q3)
+    int cx = 0, cy = 0, cz = 0;                                                 // qubit_errors of the chain (:111), carried like the reference does (:172)
+    if (xyz) for (int q = 0; q < nq; ++q) { cx += m[q] == 1; cy += m[q] == 2; cz += m[q] == 3; }
     bool any_acc = false;
     for (uint64_t j = 0; j < a.iters; ++j) {
         const uint64_t k = a.k0 + j;
@@ -156,6 +159,12 @@ __global__ void k_chain_update(const ChainArgs a)
         }
         // ---- accept?
         bool acc;
+        int nx = 0, ny = 0, nz = 0;
+        if (xyz) {                                                                  // mcmc.py:166-170: u < (factors ** change).prod()
+            for (int q = 0; q < nq; ++q) { nx += m[q] == 1; ny += m[q] == 2; nz += m[q] == 3; }     // _count_errors_xyz of the proposal
+            acc = v44 < a.xyz_thr[((nx - cx + 4) * 9 + (ny - cy + 4)) * 9 + (nz - cz + 4)];
+            if (acc) { cx = nx; cy = ny; cz = nz; }
+        } else
         if (a.noise) {                                                              // mcmc_biased.py:40-46 / :53-59
             const double u = (double)v44 * (1.0 / 17592186044416.0);               // 2^-44, exact
             acc = u < biased_weight_b(a.bias_tbl, nq, m) / pb;

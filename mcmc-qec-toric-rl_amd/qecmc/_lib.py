@@ -81,6 +81,8 @@ SIGNATURES = {
                                             C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64]),
     "qecmc_chain_update_alpha": (C.c_int, [C.c_int, C.c_int, C.c_uint64, _u8p, C.c_double, C.c_double, C.c_double,
                                            C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, _u8p]),
+    "qecmc_chain_update_xyz": (C.c_int, [C.c_int, C.c_int, C.c_uint64, _u8p, C.POINTER(C.c_double), C.c_uint64, C.c_uint64, C.c_uint32,
+                                         C.c_uint32, C.c_uint64]),
     "qecmc_ladder_step": (C.c_int, [C.POINTER(Params), C.c_uint64, _u8p, _u8p, _u32p, C.c_uint64, C.c_uint64,
                                     C.c_uint64, C.c_uint64]),
     "qecmc_ladder_step_alpha": (C.c_int, [C.POINTER(Params), C.c_uint64, _u8p, _u8p, _u32p, _u16p, C.c_uint64,

@@ -108,6 +108,19 @@ def PTEQ(init_code, p, Nc=None, SEQ=2, TOPS=10, tops_burn=2, eps=0.1, steps=5000
     return _pteq(init_code, p, None, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, conv_criteria, seed, replicas=replicas, scan=scan)
 
 
+def conv_crit_error_based_PT(nbr_errors_bottom_chain, since_burn, tops_accepted, SEQ, eps):
+    """decoders.py:93-105 (the host form of the criterion the kernels run in place): |mean of the 2nd quarter - mean of the 4th| < eps on
+    the bottom chain's error-count series of length since_burn + 1 -> (accept, converged = tops_accepted >= SEQ)"""
+    l = since_burn + 1
+    with np.errstate(invalid="ignore"), __import__("warnings").catch_warnings():
+        __import__("warnings").simplefilter("ignore")
+        q2 = np.average(nbr_errors_bottom_chain[(l // 4): (l // 2)])
+        q4 = np.average(nbr_errors_bottom_chain[(3 * l // 4): l])
+    if abs(q2 - q4) < eps:
+        return True, tops_accepted >= SEQ
+    return False, False
+
+
 def _pteq(init_code, p, eta, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, conv_criteria, seed, alpha=None, replicas=None, scan="random"):
     if tops_burn >= TOPS:
         print('tops_burn has to be smaller than TOPS')

@@ -74,3 +74,8 @@ def PTEQ_alpha_with_shortest(init_code, pz_tilde, alpha=1, Nc=None, SEQ=2, TOPS=
     from .mcmc_alpha import Ladder_alpha
     ladder = Ladder_alpha(pz_tilde, init_code, alpha, Nc or init_code.system_size, 0.5, seed=seed)     # :109
     return _shortest_loop(ladder, pz_tilde, SEQ, TOPS, tops_burn, eps, steps, iters, conv_criteria)
+
+
+# decoders_biasednoise.py:79-90 / :226-237: the same criterion under two more names
+from .decoders import conv_crit_error_based_PT as conv_crit_error_based_PT_biased     # noqa: E402
+from .decoders import conv_crit_error_based_PT as conv_crit_error_based_PT_alpha      # noqa: E402

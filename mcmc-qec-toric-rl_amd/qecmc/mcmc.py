@@ -68,6 +68,33 @@ class Chain:
             self.p_logical = p_logical
 
 
+class Chain_xyz:
+    """src/mcmc.py:106-114: a single chain at general noise (p_x, p_y, p_z) -- what decoders.py:352,442 sample STDC_general_noise
+    with.  `update_chain_fast(iters)` (:112-114 -> :162-173) is one kernel launch (qecmc_chain_update_xyz): a generator proposal of the
+    code's own stencil, accepted with probability prod_i (p_i / (1 - sum p))^(change of n_i); `qubit_errors` follows the chain."""
+
+    def __init__(self, p_xyz, code, seed=None, stream=0):
+        self.code = code
+        self.p_xyz = np.asarray(p_xyz, dtype=np.float64)
+        self.factors = self.p_xyz / (1.0 - self.p_xyz.sum())
+        self.qubit_errors = code.count_errors_xyz()
+        self.seed = _fresh_seed() if seed is None else seed
+        self.stream = stream
+        self.slot = 0
+        self.proposals_done = 0
+
+    def update_chain_fast(self, iters):
+        import ctypes as C
+        m, _ = L_.as_states(self.code.qubit_matrix, self.code.qubit_matrix.ndim)
+        m = m.copy()
+        pxyz = (C.c_double * 3)(*[float(v) for v in self.p_xyz])
+        L_.check(L_.lib().qecmc_chain_update_xyz(_code_id(self.code), self.code.system_size, 1, L_.u8(m), pxyz, int(iters), self.seed,
+                                                 self.stream, self.slot, self.proposals_done))
+        self.proposals_done += int(iters)
+        self.code.qubit_matrix = m[0]
+        self.qubit_errors = self.code.count_errors_xyz()
+
+
 class Ladder:
     _eta = None           # Ladder_biased sets the bias
     _chain_cls = None
@@ -107,6 +134,15 @@ class Ladder:
             ch.proposals_done = self.proposals_done
             ch.update_chain(iters)
         self.proposals_done += int(iters)
+
+    def r_flip(self, ind_lo):
+        """src/mcmc.py:86-92 with _r_flip (:144-149) -- mcmc_biased.py:107-113 likewise: should rungs ind_lo / ind_lo + 1 be swapped?
+        (Host-side, on Python's `random` like the reference; `step` runs the whole sweep on the GPU and does not call it.)"""
+        ne_lo = self.chains[ind_lo].code.count_errors()
+        ne_hi = self.chains[ind_lo + 1].code.count_errors()
+        if ne_hi < ne_lo and self._eta is None:
+            return True
+        return rand.random() < self.p_diff[ind_lo] ** (ne_hi - ne_lo)
 
     def step(self, iters, nsteps=1):
         """`nsteps` x Ladder.step(iters) (src/mcmc.py:94-103) in one kernel launch."""

@@ -47,6 +47,11 @@ class Chain_alpha:
             self._nz, self._nxy = _counts(m[0])
 
 
+    def update_chain_fast(self, iters):
+        # mcmc_alpha.py:73-74 reads `self.factor`, which Chain_alpha never sets: the reference raises here too
+        raise AttributeError("'Chain_alpha' object has no attribute 'factor'")
+
+
 class Ladder_alpha:
     def __init__(self, pz_tilde_bottom, init_code, alpha, Nc, p_logical=0, seed=None, stream=0):
         self.alpha = alpha
@@ -74,6 +79,12 @@ class Ladder_alpha:
             ch.proposals_done = self.proposals_done
             ch.update_chain(iters)
         self.proposals_done += int(iters)
+
+    def r_flip(self, ind_lo):
+        """mcmc_alpha.py:117-123: the slots' n_eff attributes (quirk Q4) and the ratio of their pz_tilde's; always draws"""
+        import random as rand
+        lo, hi = self.chains[ind_lo], self.chains[ind_lo + 1]
+        return rand.random() < (lo.pz_tilde / hi.pz_tilde) ** (hi.n_eff - lo.n_eff)
 
     def step(self, iters, nsteps=1):
         """`nsteps` x Ladder_alpha.step(iters) (src/mcmc_alpha.py:127-137) in one kernel launch."""

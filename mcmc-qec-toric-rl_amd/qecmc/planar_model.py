@@ -82,6 +82,49 @@ class Planar_code:
         self.qubit_matrix[1, :, -1] = 0
         self.syndrom()
 
+    def generate_general_noise_error(self, p_xyz):
+        # planar_model.py:43-59: one NumPy uniform per cell cut at p_x, p_x + p_y, p_x + p_y + p_z (general noise: STDC_general_noise's input)
+        size = self.system_size
+        p_xyz = np.asarray(p_xyz, dtype=np.float64)
+        u = np.random.uniform(0, 1, size=(2, size, size))
+        m = np.zeros((2, size, size), dtype=np.uint8)
+        m[u < p_xyz.sum()] = 3
+        m[u < p_xyz[0:2].sum()] = 2
+        m[u < p_xyz[0]] = 1
+        m[1, -1, :] = 0
+        m[1, :, -1] = 0
+        self.qubit_matrix = m
+        self.syndrom()
+
+    def _fill_rows(self, p_x, p_y, p_z):
+        # planar_model.py:66-77 / :88-99 index the (2, L, L) array with [i, j] for i, j < L: each draw sets a whole ROW of layer i, and
+        # i = 2 is out of bounds -- the loops of the one-layer models pasted onto the two-layer one.  Mirrored as written: only
+        # size = 2 runs through; any larger lattice raises the reference's IndexError.
+        size = self.system_size
+        for i in range(size):
+            for j in range(size):
+                q = 0
+                r = rand.random()
+                if r < p_z:
+                    q = 3
+                elif p_z < r < (p_z + p_x):
+                    q = 1
+                elif (p_z + p_x) < r < (p_z + p_x + p_y):
+                    q = 2
+                self.qubit_matrix[i, j] = q
+
+    def generate_biased_error(self, p_error, eta):
+        p_z = p_error * eta / (eta + 1)                                    # planar_model.py:61-65
+        p_x = p_error / (2 * (eta + 1))
+        self._fill_rows(p_x, p_x, p_z)
+
+    def generate_alpha_error(self, p_error, alpha):
+        from scipy import optimize                                         # planar_model.py:79-86
+        p_tilde = p_error / (1 + p_error)
+        pz_tilde = optimize.fsolve(lambda x: x + 2 * x ** alpha - p_tilde, 0.5)[0]
+        px_tilde = pz_tilde ** alpha
+        self._fill_rows(px_tilde * (1 - p_error), px_tilde * (1 - p_error), pz_tilde * (1 - p_error))
+
     def chain_lengths(self):
         m = self.qubit_matrix
         return int((m == 1).sum()), int((m == 2).sum()), int((m == 3).sum())

@@ -366,10 +366,10 @@ def surf_syndrome(code, m):
     return out
 
 
-def chain_update(code, m, p, p_logical, iters, rng, slot=0, k0=0, noise=DEPOLARIZING, eta=0.0, scan=0):
+def chain_update(code, m, p, p_logical, iters, rng, slot=0, k0=0, noise=DEPOLARIZING, eta=0.0, scan=0, pxyz=None):
     m = _m(m).copy()
     scratch = np.empty_like(m)
-    mod = _model(code, _size(code, m), noise, eta, scan)
+    mod = _model(code, _size(code, m), XYZ if pxyz is not None else noise, eta, scan, pxyz=pxyz)
     lib().orc_chain_update(C.byref(mod), _u8(m), p, p_logical, iters, C.byref(rng.c), slot, k0, _u8(scratch))
     return m
 

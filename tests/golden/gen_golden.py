@@ -26,6 +26,7 @@ Fixtures
   f_xyz.npz                   STDC_droplet_general_noise / STDC_general_noise(_shortest) on the planar code (decoders.py:325-507), with
                               Chain and Chain_xyz (mcmc.py:106-114,162-173) sampling
   f_nalpha.npz                STDC_droplet_alpha / STDC_Nall_n_alpha (decoders.py:510-581) on the xzzx and rotated codes
+  f_api_surface.npz           what decoders.py / decoders_biasednoise.py touch on the sampler path's classes: names, call shapes, result kinds (--only api)
   f_planar.npz                Planar_code stencil KATs and Chain (incl. update_chain_fast) / Ladder / PTEQ trajectories
 """
 import argparse
@@ -960,6 +961,191 @@ def gen_f4(tm, mc):
     print("f4_config1.npz count", ch.code.count_errors(), "class", ch.code.define_equivalence_class())
 
 
+# ---- API surface: what the reference's callers touch ---------------------------------------------------------------------------
+class _Rec:
+    """recording proxy around one of the reference's own objects: every attribute its CALLER (decoders.py, decoders_biasednoise.py,
+    generate_data.py) reads, sets or calls goes into `log` as (class, attribute, kind, positional arguments, keywords, result)."""
+    log = set()
+    classes = ()
+
+    def __init__(self, obj):
+        object.__setattr__(self, "_o", obj)
+
+    @staticmethod
+    def describe(v):
+        if isinstance(v, _Rec):
+            v = object.__getattribute__(v, "_o")
+        if isinstance(v, np.ndarray):
+            return "ndarray%d:%s" % (v.ndim, v.dtype)
+        if isinstance(v, tuple):
+            return "tuple(" + ",".join(_Rec.describe(x) for x in v) + ")"
+        if isinstance(v, (list,)):
+            return "list"
+        if isinstance(v, (bool, np.bool_)):
+            return "bool"
+        if isinstance(v, (int, np.integer)):
+            return "int"
+        if isinstance(v, (float, np.floating)):
+            return "float"
+        return type(v).__name__
+
+    @staticmethod
+    def wrap(v):
+        if isinstance(v, _Rec.classes):
+            return _Rec(v)
+        if isinstance(v, list) and v and isinstance(v[0], _Rec.classes):
+            return [_Rec(x) for x in v]
+        return v
+
+    @staticmethod
+    def unwrap(v):
+        if isinstance(v, _Rec):
+            return object.__getattribute__(v, "_o")
+        if isinstance(v, (list, tuple)):
+            return type(v)(_Rec.unwrap(x) for x in v)
+        return v
+
+    def __getattr__(self, name):
+        o = object.__getattribute__(self, "_o")
+        v = getattr(o, name)
+        cls = type(o).__name__
+        if callable(v) and not isinstance(v, type):
+            def call(*a, **k):
+                r = v(*_Rec.unwrap(a), **{kk: _Rec.unwrap(vv) for kk, vv in k.items()})
+                _Rec.log.add((cls, name, "call", len(a), ",".join(sorted(k)), _Rec.describe(r)))
+                return _Rec.wrap(r)
+            return call
+        _Rec.log.add((cls, name, "get", 0, "", _Rec.describe(v)))
+        return _Rec.wrap(v)
+
+    def __setattr__(self, name, val):
+        o = object.__getattribute__(self, "_o")
+        _Rec.log.add((type(o).__name__, name, "set", 0, "", _Rec.describe(val)))
+        setattr(o, name, _Rec.unwrap(val))
+
+    def __deepcopy__(self, memo):
+        import copy
+        return _Rec(copy.deepcopy(object.__getattribute__(self, "_o"), memo))
+
+
+class _SerialPool:
+    """multiprocessing.Pool stand-in of the recording run: same calls, this process (the workers would take the proxies' logs with them)"""
+    def __init__(self, *a, **k): pass
+    def __enter__(self): return self
+    def __exit__(self, *a): return False
+    def starmap(self, fn, args): return [fn(*x) for x in args]
+    def map(self, fn, args): return [fn(x) for x in args]
+
+
+def gen_api(tm, mc, dec):
+    """f_api_surface.npz: the names, call shapes and result kinds the reference's decoders use on the sampler path's classes -- recorded
+    by running decoders.PTEQ / PTDC / PTRC / STDC / STRC / STDC_general_noise(_shortest) / STDC_Nall_n_alpha / single_temp and
+    decoders_biasednoise.PTEQ_biased / PTEQ_alpha / PTEQ_alpha_with_shortest for a few steps on recording proxies of the
+    reference's own objects -- plus the names those modules take from `src.*` by import.  tests/test_api_surface.py holds the
+    qecmc mirrors to it."""
+    import inspect
+    import src.planar_model as pm
+    import src.xzzx_model as xm
+    import src.rotated_surface_model as rm
+    import src.mcmc_alpha as ma
+    import src.mcmc_biased as mb
+    import decoders_biasednoise as decb
+    _Rec.log = set()
+    _Rec.classes = (mc.Chain, mc.Ladder, mc.Chain_xyz, ma.Chain_alpha, ma.Ladder_alpha, mb.Chain_biased, mb.Ladder_biased,
+                    tm.Toric_code, pm.Planar_code, xm.xzzx_code, rm.RotSurCode)
+    ctor = set()
+
+    def factory(real):
+        def make(*a, **k):
+            ctor.add((real.__name__, len(a), ",".join(sorted(k))))
+            return _Rec(real(*_Rec.unwrap(a), **{kk: _Rec.unwrap(vv) for kk, vv in k.items()}))
+        make.__name__ = real.__name__
+        return make
+    saved = []
+    for mod in (dec, decb):
+        for name, val in list(vars(mod).items()):
+            if isinstance(val, type) and val in _Rec.classes:
+                saved.append((mod, name, val))
+                setattr(mod, name, factory(val))
+        if hasattr(mod, "Pool"):
+            saved.append((mod, "Pool", mod.Pool))
+            mod.Pool = _SerialPool
+    rng = np.random.default_rng(4242)
+    random.seed(77); np.random.seed(77)
+    try:
+        def toric(L=3, p=0.15):
+            c = tm.Toric_code(L); c.qubit_matrix = rand_matrix(rng, L, p); return _Rec(c)
+        def planar(L=3, p=0.15):
+            c = pm.Planar_code(L); c.qubit_matrix = rand_planar(rng, L, p); return _Rec(c)
+        def surf(cls, L=3, p=0.2):
+            c = cls(L); c.qubit_matrix = rand_matrix2(rng, L, p); return _Rec(c)
+        def class_list(make, n):
+            out = []
+            base = make()
+            for eq in range(n):
+                c = _Rec(__import__("copy").deepcopy(_Rec.unwrap(base)))
+                out.append(c)
+            return out
+        dec.PTEQ(toric(), 0.1, Nc=3, steps=60, conv_criteria=None)
+        dec.PTEQ(toric(), 0.1, Nc=3, steps=400, TOPS=2, tops_burn=1, eps=5.0)
+        dec.PTEQ(planar(), 0.1, Nc=3, steps=60, conv_criteria=None)
+        dec.PTEQ(surf(xm.xzzx_code), 0.1, Nc=3, steps=60, conv_criteria=None)
+        dec.single_temp(toric(), 0.1, 20)
+        dec.PTDC(toric(), 0.1, droplets=1, Nc=2, steps=40)
+        def toric_classes():
+            base = _Rec.unwrap(toric())
+            out = []
+            for eq in range(16):
+                c = tm.Toric_code(3); c.qubit_matrix = base.to_class(eq); out.append(_Rec(c))
+            return out
+        def planar_classes():
+            m = rand_planar(rng, 3, 0.15)
+            out = []
+            for op in range(4):
+                c = pm.Planar_code(3); c.qubit_matrix, _ = pm._apply_logical(m.copy(), op, 0, 0); out.append(c)
+            out.sort(key=lambda c: c.define_equivalence_class())
+            return [_Rec(c) for c in out]
+        dec.PTRC(toric_classes(), 0.1, droplets=1, Nc=2, steps=40)
+        dec.STDC(toric(), 0.1, droplets=1, steps=40)
+        dec.STDC(planar_classes(), 0.1, droplets=1, steps=40)
+        dec.STRC(planar_classes(), 0.1, droplets=1, steps=40)
+        p_xyz = np.array([0.05, 0.03, 0.04])
+        inits = planar_classes()
+        dec.STDC_general_noise(inits, p_xyz, p_sampling=None, droplets=1, steps=40)
+        dec.STDC_general_noise(inits, p_xyz, p_sampling=np.array([0.08, 0.06, 0.07]), droplets=1, steps=40)
+        dec.STDC_general_noise_shortest(inits, p_xyz, p_sampling=None, droplets=1, steps=40)
+        dec.STDC_Nall_n_alpha([surf(xm.xzzx_code) for _ in range(4)], pz_tilde_sampling=np.float64(0.3), alpha=2.0, pz_tilde=0.2, steps=40)
+        decb.PTEQ_biased(surf(xm.xzzx_code), 0.1, eta=10, Nc=3, steps=60, conv_criteria=None)
+        decb.PTEQ_biased(surf(rm.RotSurCode), 0.1, eta=10, Nc=3, steps=300, TOPS=2, tops_burn=1, eps=5.0)
+        decb.PTEQ_alpha(surf(xm.xzzx_code), 0.1, alpha=2.0, Nc=3, steps=60, conv_criteria=None)
+        decb.PTEQ_alpha(surf(rm.RotSurCode), 0.1, alpha=2.0, Nc=3, steps=300, TOPS=2, tops_burn=1, eps=5.0)
+        decb.PTEQ_alpha_with_shortest(surf(xm.xzzx_code), 0.1, alpha=2.0, Nc=3, steps=60, conv_criteria=None)
+    finally:
+        for mod, name, val in saved:
+            setattr(mod, name, val)
+    # what the caller modules take from src.* by import and actually use (co_names of their functions)
+    imports = set()
+    for mod in (dec, decb):
+        used = set()
+        for fn in vars(mod).values():
+            if inspect.isfunction(fn) and fn.__module__ == mod.__name__:
+                used |= set(fn.__code__.co_names)
+        for name, val in vars(mod).items():
+            m = getattr(val, "__module__", "") or ""
+            if name in used and m.startswith("src.") and not m.endswith("mwpm"):
+                imports.add((mod.__name__, m, name))
+    # generate_data.py (pandas, MWPM: not run here) as text: the attributes it reads / calls on its code object `init_code`
+    import ast
+    gd = set()
+    for node in ast.walk(ast.parse(open(os.path.join(REF, "generate_data.py")).read())):
+        if isinstance(node, ast.Attribute) and isinstance(node.value, ast.Name) and node.value.id == "init_code":
+            gd.add(node.attr)
+    recs = sorted("|".join(str(x) for x in r) for r in _Rec.log)
+    np.savez(os.path.join(HERE, "f_api_surface.npz"), records=np.array(recs), constructors=np.array(sorted("|".join(str(x) for x in c) for c in ctor)),
+             imports=np.array(sorted("|".join(i) for i in imports)), generate_data_code_attrs=np.array(sorted(gd)))
+    print("f_api_surface.npz: %d attribute records, %d constructor shapes, %d imported names" % (len(recs), len(ctor), len(imports)))
+
+
 def main():
     if not os.path.isdir(REF):
         print("reference not present; nothing to do")
@@ -971,6 +1157,7 @@ def main():
     if "f1" in only: gen_f1(tm)
     if "f2" in only: gen_f2(tm, mc, dec)
     if "f4" in only: gen_f4(tm, mc)
+    if "api" in only: gen_api(tm, mc, dec)
     if "fp" in only or "fd" in only or "fc" in only or "fg" in only:
         import src.planar_model as pm
         if "fc" in only: gen_convmult(tm, pm, mc, dec)

@@ -62,6 +62,22 @@ def test_planar_stencils_on_device(q, t):
         code.apply_stabilizer(0, L - 1, 3)
 
 
+@pytest.mark.parametrize("L,pxyz,iters", [(3, (0.05, 0.03, 0.04), 200), (5, (0.02, 0.10, 0.01), 1000), (7, (0.10, 0.10, 0.10), 800), (5, (0.30, 0.001, 0.05), 1500)])
+def test_chain_xyz_update_bit_exact(q, orc, L, pxyz, iters):
+    """src/mcmc.py:106-114 (Chain_xyz, the chain decoders.py:352,442 run STDC_general_noise on): planar code, general (p_x, p_y, p_z)"""
+    code = q.Planar_code(L)
+    code.qubit_matrix = rand_states(np.random.default_rng(L * 7 + iters), 1, L, 0.2)[0]
+    m0 = code.qubit_matrix.copy()
+    seed, stream = 0xABCDEF12345, 11
+    ch = q.mcmc.Chain_xyz(np.array(pxyz), code, seed=seed, stream=stream)
+    assert ch.qubit_errors.shape == (3,)
+    for part in (iters // 3, iters - iters // 3):          # two calls continue one proposal stream (k0 carries)
+        ch.update_chain_fast(part)
+    ref = orc.chain_update(orc.PLANAR, m0, 0.0, 0.0, iters, orc.Rng.philox(seed, stream), pxyz=pxyz)
+    assert np.array_equal(ch.code.qubit_matrix, ref) and not np.array_equal(ref, m0)
+    assert np.array_equal(ch.qubit_errors, [np.sum(ref == k) for k in (1, 2, 3)])
+
+
 @pytest.mark.parametrize("L,p,p_logical,iters,fast", [(5, 0.15, 0.0, 800, False), (7, 0.3, 0.5, 600, False), (4, 0.2, 0.0, 500, True),
                                                        (12, 0.1, 0.0, 400, True), (9, 0.75, 0.5, 500, False)])
 def test_chain_bit_exact(q, orc, L, p, p_logical, iters, fast):
