@@ -144,6 +144,11 @@ def lib():
     return _lib
 
 
+def library_path():
+    """the libqecmc.so this process binds (QECMC_LIBRARY or the in-tree build): bench lines carry it, so an A/B names its builds"""
+    return os.path.abspath(LIB_PATH)
+
+
 def check(rc):
     if rc != 0:
         raise QecmcError(f"libqecmc error {rc}: {lib().qecmc_last_error().decode()}")
