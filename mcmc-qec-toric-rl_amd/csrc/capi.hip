@@ -155,7 +155,8 @@ int validate_params(const qecmc_params *p)
     } else if (!(p->p > 0.0) || !(p->p <= 0.75)) return fail(QECMC_ERR_INVALID, "p=%g must be in (0, 0.75]", p->p);
     if (!(p->p_logical >= 0.0) || !(p->p_logical <= 1.0)) return fail(QECMC_ERR_INVALID, "p_logical=%g must be in [0,1]", p->p_logical);
     if (p->scan != QECMC_SCAN_RANDOM && p->scan != QECMC_SCAN_SWEEP && p->scan != QECMC_SCAN_COLOUR && p->scan != QECMC_SCAN_WAVE) return fail(QECMC_ERR_INVALID, "scan mode %d unknown", p->scan);
-    if (p->scan != QECMC_SCAN_RANDOM && p->noise != QECMC_NOISE_DEPOLARIZING) return fail(QECMC_ERR_UNSUPPORTED, "the sweep, colour and wave scans are built for the depolarizing rule only");
+    if (p->scan != QECMC_SCAN_RANDOM && p->noise != QECMC_NOISE_DEPOLARIZING && !(p->scan == QECMC_SCAN_WAVE && p->noise == QECMC_NOISE_ALPHA))
+        return fail(QECMC_ERR_UNSUPPORTED, "the sweep and colour scans are built for the depolarizing rule only, the wave scan for the depolarizing and alpha rules");
     if (p->scan == QECMC_SCAN_WAVE) {
         if (p->Nc < 2) return fail(QECMC_ERR_UNSUPPORTED, "scan = wave needs a ladder whose top rung sits at p = 0.75 (Nc >= 2)");
         if (p->first_syndrome & 63u) return fail(QECMC_ERR_INVALID, "scan = wave shares a generator pick among the 64 ladders of a wavefront: first_syndrome=%u must be a multiple of 64", p->first_syndrome);
@@ -212,7 +213,7 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
         xyz_lut = count_change_table(patterns);
     }
     pl->lds_bytes = p->scan == QECMC_SCAN_COLOUR ? sizeof(uint32_t) * ((size_t)Nc * W + 4 * (size_t)Nc + (size_t)ncls)   // (ladder_colour.hip: one ladder per workgroup)
-                  : p->scan == QECMC_SCAN_WAVE ? wu_lds_bytes(Nc, W, ncls, L, p->conv_mode != 0)
+                  : p->scan == QECMC_SCAN_WAVE ? wu_lds_bytes(Nc, W, ncls, L, p->conv_mode != 0, alpha)
                                                  : ladder_lds_bytes(L, Nc, W, ncls, ladder_gen_dwords(p->code, p->noise, p->scan, n_gen, Nc, nq, a.n_types));
     if (pl->lds_bytes > 160 * 1024)
         return fail(QECMC_ERR_UNSUPPORTED, "L=%d Nc=%d needs %zu B of LDS per workgroup (> 160 KiB)", L, Nc, pl->lds_bytes);
@@ -224,7 +225,7 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
         // (waves per CU: 8 per SIMD for the 512-thread depolarizing kernels, 4 for the 1024-thread ones and for the biased / alpha
         // queue kernels, which run at 128 VGPRs: ladder_biased.hip)
         const size_t per_cu_lds = (160 * 1024) / pl->lds_bytes,
-                     per_cu_waves = (size_t)((Nc * 64 <= 512 && !p->noise && !(wave_queue && W > 16)) ? 32 : 16) / (size_t)Nc;
+                     per_cu_waves = (size_t)((Nc * 64 <= 512 && (!p->noise || wave_queue) && !(wave_queue && W > 16)) ? 32 : 16) / (size_t)Nc;
         size_t per_cu = per_cu_lds < per_cu_waves ? per_cu_lds : per_cu_waves;
         if (per_cu < 1) per_cu = 1;
         pl->queue_grid = (uint32_t)(per_cu * (size_t)prop.multiProcessorCount);
@@ -276,11 +277,9 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
         // the wave-uniform random scan (ladder_wu.hpp): one scalar-loadable descriptor per generator; states in registers
         const std::vector<uint32_t> wd = wave_descriptors(gt);
         a.n_gen = (uint32_t)(gt.size() / 2);
-        pl->lds_bytes = wu_lds_bytes(Nc, W, ncls, L, p->conv_mode != 0);
+        pl->lds_bytes = wu_lds_bytes(Nc, W, ncls, L, p->conv_mode != 0, alpha);
         a.conv_mode = p->conv_mode;
-        if (wd.empty() || !wu_supported(a) || pl->lds_bytes > 160 * 1024)
-            return fail(QECMC_ERR_UNSUPPORTED, "scan = wave: L=%d Nc=%d p=%g is outside what it is built for (a top rung that accepts every move, at most "
-                        "16 packed state words per rung -- toric / planar L <= 11, xzzx / rotated L <= 16 --, %zu B of LDS)", L, Nc, p->p, pl->lds_bytes);
+        if (wd.empty()) return fail(QECMC_ERR_UNSUPPORTED, "scan = wave: a generator with three different Paulis");
         HIP_TRY(pl->wu_desc.alloc(wd.size() * sizeof(uint32_t)));
         HIP_TRY(hipMemcpy(pl->wu_desc.p, wd.data(), wd.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         a.wu_desc = pl->wu_desc.as<uint32_t>();
@@ -337,6 +336,10 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
     a.acc_tbl_top = pl->acc_top.as<uint32_t>();
     a.swap_thr = pl->swap_thr.as<uint64_t>();
     a.lmask = pl->lmask.as<uint32_t>();
+    if (p->scan == QECMC_SCAN_WAVE && (!wu_supported(a) || pl->lds_bytes > 160 * 1024))
+        return fail(QECMC_ERR_UNSUPPORTED, "scan = wave: L=%d Nc=%d p=%g is outside what it is built for (depolarizing rule: a top rung that accepts every move, at most "
+                    "16 packed state words per rung -- toric / planar L <= 11, xzzx / rotated L <= 16; alpha rule: xzzx / rotated L <= 11, Nc <= 8, "
+                    "4 iters max|log2 ratio| <= 2000 --, %zu B of LDS)", L, Nc, p->p, pl->lds_bytes);
     return 0;
 }
 

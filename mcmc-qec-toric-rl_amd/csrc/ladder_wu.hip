@@ -3,17 +3,24 @@
 
 namespace qecmc {
 
-size_t wu_lds_bytes(int Nc, int W, int ncls, int L, bool conv) { return sizeof(uint32_t) * (size_t)wu_lds(Nc, W, ncls, L, conv).total; }
+size_t wu_lds_bytes(int Nc, int W, int ncls, int L, bool conv, bool alpha) { return sizeof(uint32_t) * (size_t)wu_lds(Nc, W, ncls, L, conv, alpha).total; }
 
 // the shapes scan = 3 is built for: depolarizing rule, a ladder whose top rung accepts every move (Nc >= 2, p_top = 0.75), up to
 // 16 state words per ladder rung (toric / planar L <= 11, xzzx / rotated L <= 16: where the states fit the registers of 8 waves per
 // SIMD -- beyond that the scan = 0 kernels are as fast, profiles/r04_wave_ab.json), 1 <= iters <= 128, rungs at distinct temperatures
 // (32-bit swap thresholds)
+// ... and the alpha noise model's ladder (noise = 2, whose top rung sits at pz_tilde = 1 and accepts every move) on the xzzx / rotated codes up to
+// 8 state words and 8 rungs, where the plan allows the single-precision estimate of the acceptance ratio on every rung below the top
 bool wu_supported(const LadderArgs &a)
 {
+    if (a.noise == 2)
+        return (a.code == kCodeXzzx || a.code == kCodeRotated) && a.Nc >= 2 && a.Nc <= 8 && a.W <= 8 && a.n_gen <= 1023u && a.iters >= 1u && a.iters <= 128u &&
+               (a.bias_f32ok & ((1u << (a.Nc - 1)) - 1u)) == ((1u << (a.Nc - 1)) - 1u) && a.bias_tbl != nullptr && a.alpha_lnb != nullptr &&
+               a.uset_tab == nullptr && a.swap_acc == nullptr && !a.resume && a.neff == nullptr &&
+               wu_lds_bytes(a.Nc, a.W, a.ncls, a.L, a.conv_mode != 0, true) <= 160 * 1024;
     return a.noise == 0 && a.Nc >= 2 && ((a.acc_all_mask >> (a.Nc - 1)) & 1u) && !(a.acc_all_mask & ((1u << (a.Nc - 1)) - 1u)) &&
            a.W <= 16 && a.n_gen <= 1023u && a.iters >= 1u && a.iters <= 128u && a.swap_fast_ok != 0 &&
-           a.uset_tab == nullptr && a.swap_acc == nullptr && wu_lds_bytes(a.Nc, a.W, a.ncls, a.L, a.conv_mode != 0) <= 160 * 1024;
+           a.uset_tab == nullptr && a.swap_acc == nullptr && wu_lds_bytes(a.Nc, a.W, a.ncls, a.L, a.conv_mode != 0, false) <= 160 * 1024;
 }
 
 const void *wu_kernel_toric(int variant, int Nc, int W, uint32_t iters) { return wu_pick<kCodeToric>(variant, Nc, W, iters); }
@@ -26,10 +33,10 @@ hipError_t launch_ladder_wu(const LadderArgs &a, hipStream_t stream)
     const bool queue = a.conv_mode != 0;
     if (queue && (a.resume || a.write_states || a.wu_chunk < 64u || (a.wu_chunk & 63u))) return hipErrorInvalidValue;
     const int variant = queue ? 2 : 0;
-    const void *fn = a.code == kCodeToric ? wu_kernel_toric(variant, a.Nc, a.W, a.iters) : a.code == kCodeXzzx ? wu_kernel_xzzx(variant, a.Nc, a.W, a.iters)
+    const void *fn = a.noise == 2 ? wu_kernel_alpha(a.code, variant, a.Nc, a.W, a.iters) : a.code == kCodeToric ? wu_kernel_toric(variant, a.Nc, a.W, a.iters) : a.code == kCodeXzzx ? wu_kernel_xzzx(variant, a.Nc, a.W, a.iters)
                    : a.code == kCodeRotated ? wu_kernel_rotated(variant, a.Nc, a.W, a.iters) : a.code == kCodePlanar ? wu_kernel_planar(variant, a.Nc, a.W, a.iters) : nullptr;
     if (!fn) return hipErrorInvalidValue;
-    const size_t lds = wu_lds_bytes(a.Nc, a.W, a.ncls, a.L, a.conv_mode != 0);
+    const size_t lds = wu_lds_bytes(a.Nc, a.W, a.ncls, a.L, a.conv_mode != 0, a.noise == 2);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;

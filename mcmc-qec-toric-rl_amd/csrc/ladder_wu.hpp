@@ -157,12 +157,15 @@ __device__ __forceinline__ void wu_xor(typename WuVec<WV>::type &st, uint32_t d0
 // LDS carve-up of one workgroup (dwords): the exchange buffer (W words per rung), records, swap uniforms, histogram, acceptance rows,
 // swap rows, logical masks (rows padded to WV words, + 64: the frame reads a row with all 64 lanes), stop / refill flags, and -- the
 // criterion kernels -- wave 0's per-ladder bookkeeping [kWuBk][64] and the refill mailbox [2][64]
-struct WuLds { int xbuf, rec, swd, hist, thr, swapT, lml, stop, bk, mail, bot, total; };
+struct WuLds { int xbuf, rec, swd, hist, thr, swapT, lml, stop, bk, mail, bot, cht, nef, lnb, bot2, total; };
 constexpr int kWuBk = 13;      // tops0, samples, burn, conv_start, conv_streak, sumA lo / hi, sumB lo / hi, state (done | pending << 1 | has << 3),
                                // steps_done, converged, the lane's ladder (QUEUE)
+constexpr int kWuBkAlpha = 17; // ... and the alpha rule's second pair of window sums (n_x + n_y): sumAxy lo / hi, sumBxy lo / hi
 __host__ __device__ inline int wu_words(int W) { return W <= 4 ? 4 : W <= 8 ? 8 : W <= 12 ? 12 : 16; }   // WV: state words per rung, padded
 __host__ __device__ inline int wu_words_min(int WV) { return WV == 4 ? 1 : WV - 3; }                     // the narrowest W a WV-word kernel serves
-__host__ __device__ inline WuLds wu_lds(int Nc, int W, int ncls, int L, bool conv)
+// (alpha rule: the 9 x 9 table of a proposal's count change as two fp16 numbers, the slots' n_eff attributes as doubles [Nc][64], ln(pz_i / pz_i+1),
+// and -- criterion runs -- slot 0's n_eff record by step parity)
+__host__ __device__ inline WuLds wu_lds(int Nc, int W, int ncls, int L, bool conv, bool alpha = false)
 {
     const int WV = wu_words(W);
     WuLds o;
@@ -175,9 +178,13 @@ __host__ __device__ inline WuLds wu_lds(int Nc, int W, int ncls, int L, bool con
     o.lml = o.swapT + Nc * kSwapFast;
     o.stop = o.lml + 4 * (L + 1) * WV + 64;
     o.bk = o.stop + 4;
-    o.mail = o.bk + (conv ? kWuBk * 64 : 0);                 // [2][64] refill orders by step parity
+    o.mail = o.bk + (conv ? (alpha ? kWuBkAlpha : kWuBk) * 64 : 0);   // [2][64] refill orders by step parity
     o.bot = o.mail + (conv ? 2 * 64 : 0);                    // [2][64] the record that landed in rung 0, by step parity
-    o.total = o.bot + (conv ? 2 * 64 : 0);
+    o.cht = o.bot + (conv ? 2 * 64 : 0);
+    o.nef = (o.cht + (alpha ? 84 : 0) + 1) & ~1;             // (doubles: 8-byte aligned)
+    o.lnb = o.nef + (alpha ? Nc * 128 : 0);
+    o.bot2 = o.lnb + (alpha ? 2 * Nc : 0);
+    o.total = o.bot2 + (alpha && conv ? 2 * 64 : 0);
     return o;
 }
 
@@ -195,9 +202,9 @@ typedef uint32_t __attribute__((address_space(3))) *wu_lds_rw;
 
 constexpr uint32_t kWuDead = 0xFFFFFFFFu, kWuKeep = 0xFFFFFFFEu;      // refill mailbox: no ladder left for the lane / the lane keeps its ladder
 
-struct WuCtx { uint32_t n4, cls, flag, tops0, samples, done, conv_ok, steps_done; };
+struct WuCtx { uint32_t n4, cls, flag, tops0, samples, done, conv_ok, steps_done, nef; };
 struct WuEnv {
-    uint32_t lds0, thr_off, lml_off, slot, grp, lad;    // lad: the lane's first ladder of this launch (kWuDead: none)
+    uint32_t lds0, thr_off, lml_off, cht_off, slot, grp, lad;    // lad: the lane's first ladder of this launch (kWuDead: none)
     int lane;
     uint64_t chunk_hi;                                  // QUEUE: end of the workgroup's share of the batch
 };
@@ -240,6 +247,127 @@ __device__ __forceinline__ void wu_propose(typename WuVec<WV>::type &st, uint32_
     }
 }
 
+// ---- the alpha rule (src/mcmc_alpha.py) -----------------------------------------------------------------------------------------
+typedef _Float16 wu_half2 __attribute__((ext_vector_type(2)));
+typedef const double __attribute__((address_space(3))) *wu_lds_dptr;
+typedef double __attribute__((address_space(3))) *wu_lds_drw;
+
+// nx / nz / nxy += the fields of word w that are 1 / 3 / 1 or 2 (Chain_alpha.__init__, mcmc_alpha.py:18-22, on the packed word)
+template <int WV, int w> __device__ __forceinline__ void wu_count3(typename WuVec<WV>::type &st, uint32_t &nx, uint32_t &nz, uint32_t &nxy, uint32_t m55)
+{
+    uint32_t t, u;
+#define M(PIN)                                                                                                                 \
+    asm volatile("v_lshrrev_b32 %[t], 1, v[%c[r]]\n\t"                                                                         \
+                 "v_bitop3_b32 %[u], %[t], v[%c[r]], %[m] bitop3:0x08\n\t"                                                     \
+                 "v_bcnt_u32_b32 %[nx], %[u], %[nx]\n\t"                                                                       \
+                 "v_bitop3_b32 %[u], %[t], v[%c[r]], %[m] bitop3:0x80\n\t"                                                     \
+                 "v_bcnt_u32_b32 %[nz], %[u], %[nz]\n\t"                                                                       \
+                 "v_bitop3_b32 %[u], %[t], v[%c[r]], %[m] bitop3:0x28\n\t"                                                     \
+                 "v_bcnt_u32_b32 %[nxy], %[u], %[nxy]"                                                                         \
+                 : [t] "=&v"(t), [u] "=&v"(u), [nx] "+v"(nx), [nz] "+v"(nz), [nxy] "+v"(nxy), "+" PIN(st)                      \
+                 : [r] "i"(wu_base<WV>() + w), [m] "s"(m55));
+    WU_BY_WV(M)
+#undef M
+}
+template <int WV, int w> __device__ __forceinline__ void wu_count_x(typename WuVec<WV>::type &st, uint32_t &nx, uint32_t m55)
+{
+    uint32_t t;
+#define M(PIN)                                                                                                                 \
+    asm volatile("v_lshrrev_b32 %[t], 1, v[%c[r]]\n\t"                                                                         \
+                 "v_bitop3_b32 %[t], %[t], v[%c[r]], %[m] bitop3:0x08\n\t"                                                     \
+                 "v_bcnt_u32_b32 %[nx], %[t], %[nx]"                                                                           \
+                 : [t] "=&v"(t), [nx] "+v"(nx), "+" PIN(st) : [r] "i"(wu_base<WV>() + w), [m] "s"(m55));
+    WU_BY_WV(M)
+#undef M
+}
+// the state's counts, packed n_x | n_z << 10 | (n_x + n_y) << 20
+template <int WV> __device__ __forceinline__ uint32_t wu_counts_packed(typename WuVec<WV>::type &st, uint32_t m55)
+{
+    uint32_t nx = 0, nz = 0, nxy = 0;
+#define QECMC_WU_C3(w) if constexpr (w < WV) wu_count3<WV, w>(st, nx, nz, nxy, m55);
+    WU_EACH(QECMC_WU_C3)
+#undef QECMC_WU_C3
+    return nx | (nz << 10) | (nxy << 20);
+}
+// n_eff = n_z + alpha (n_x + n_y) as Chain_alpha forms it (mcmc_alpha.py:22,58) from the record n_z | n_xy << 16
+__device__ __forceinline__ double wu_neff(uint32_t rec, double alpha)
+{
+#pragma clang fp contract(off)
+    return (double)(rec & 0xFFFFu) + alpha * (double)(rec >> 16);
+}
+// Ladder_alpha.r_flip (mcmc_alpha.py:118-123) on the slots' attributes: u < (pz_lo / pz_hi) ** (n_eff_hi - n_eff_lo), the power as
+// det_exp(e ln b) like the oracle -- behind a single-precision estimate of 2^32 times it that settles all but ~6e-5 of the tests
+// (the estimate's relative error stays below 5e-6: the exponent is rounded to a float of magnitude <= 32 wherever the outcome is open)
+__device__ __forceinline__ bool wu_alpha_flip(uint32_t x, double ne_hi, double ne_lo, double lnb)
+{
+#pragma clang fp contract(off)
+    const double e = ne_hi - ne_lo;
+    const double y = e * lnb;
+    if (!(y < 0.0)) return true;                                       // (det_exp returns 1: every u passes)
+    const float ef = __builtin_amdgcn_exp2f(__builtin_fmaf((float)y, 1.44269504f, 32.0f));
+    const float xf = (float)x, band = __builtin_fmaf(ef, 3.0e-5f, 2.0f);
+    if (xf < ef - band) return true;
+    if (xf > ef + band) return false;
+    return (double)x * (1.0 / 4294967296.0) < det_exp(y);
+}
+
+struct WuAl { uint32_t Dh, any, Nb; };     // the counts' change since the step began (D_xy | D_z << 16, fp16 integers), "a move was accepted", the counts then
+
+// one proposal of a rung below the top under the alpha rule (mcmc_alpha.py:61-70): accept iff u < p_n / p_b with p_b frozen when the step
+// began (Q3).  log2 of the ratio is lxy D_xy + lz D_z with D the count change since then, so two fmas and a v_exp_f32 give 2^12 p_n / p_b to
+// well within a unit (the plan has checked 4 iters max|l| <= 2000: ladder_kernel.hpp, the same estimate), and only a lane whose twelve
+// leading uniform bits lie within a cell or two of it evaluates the reference's expression -- on the power tables, in its order.
+template <int CODE, int WV>
+__device__ __forceinline__ void wu_propose_alpha(const LadderArgs &a, typename WuVec<WV>::type &st, WuAl &al, uint32_t a12, uint32_t cht_addr,
+                                                 float lxy, float lz, uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3,
+                                                 uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t tlo, uint32_t thi, uint32_t omask, uint32_t amask,
+                                                 uint64_t refine_k, uint32_t refine_w, uint32_t syn, uint32_t slot, uint32_t m55)
+{
+    const uint32_t F = wu_read<WV>(st, d0, d1, d2, d3);
+    const uint32_t pv = __builtin_amdgcn_perm(thi, tlo, (F & amask) | omask);      // byte i: 4 ((dz + 1) + 9 (dxy + 1)) of site i (a missing site: 0)
+    const uint32_t addr = __builtin_amdgcn_sad_u8(pv, 0u, cht_addr);               // LDS address of the proposal's (D_xy, D_z)
+    const uint32_t dch = *(wu_lds_ptr)(uintptr_t)addr;
+    const wu_half2 pD = __builtin_bit_cast(wu_half2, al.Dh) + __builtin_bit_cast(wu_half2, dch);
+    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf((float)pD.x, lxy, __builtin_fmaf((float)pD.y, lz, 12.0f)));
+    const float dm = e - (float)a12;
+    bool acc = dm >= 2.0f;
+    if (!acc && dm >= -1.0f) {
+        // the reference's expression (mcmc_alpha.py:64-68): counts of the proposal and of the state the step began with
+        const int nq = a.nq, T1 = nq + 1;
+        const double *bt = a.bias_tbl + (size_t)slot * 4 * T1;
+        uint32_t nxc = 0;
+#define QECMC_WU_CX(w) if constexpr (w < WV) wu_count_x<WV, w>(st, nxc, m55);
+        WU_EACH(QECMC_WU_CX)
+#undef QECMC_WU_CX
+        int dx = 0;
+        {
+            const uint32_t P0 = x0 >> ((d0 >> 8) & 31u), P1 = x1 >> ((d1 >> 8) & 31u), P2 = x2 >> ((d2 >> 8) & 31u), P3 = x3 >> ((d3 >> 8) & 31u);
+            const uint32_t f0 = F & 3u, f1 = (F >> 8) & 3u, f2 = (F >> 16) & 3u, f3 = (F >> 24) & 3u;
+            dx += (int)((f0 ^ P0) == 1u) - (int)(f0 == 1u);
+            dx += (int)((f1 ^ P1) == 1u) - (int)(f1 == 1u);
+            dx += (int)((f2 ^ P2) == 1u) - (int)(f2 == 1u);
+            dx += (int)((f3 ^ P3) == 1u) - (int)(f3 == 1u);
+        }
+        const int bx = (int)(al.Nb & 1023u), bz = (int)((al.Nb >> 10) & 1023u), bxy = (int)(al.Nb >> 20);
+        const int cx = (int)nxc + dx, cz = bz + (int)(float)pD.y, cxy = bxy + (int)(float)pD.x;
+        const double pn = bt[cx] * bt[T1 + (cxy - cx)] * bt[2 * T1 + cz] * bt[3 * T1 + (nq - cxy - cz)];
+        const double pb = bt[bx] * bt[T1 + (bxy - bx)] * bt[2 * T1 + bz] * bt[3 * T1 + (nq - bxy - bz)];
+        const double ratio = pn / pb;
+        const double ulo = (double)a12 * (1.0 / 4096.0);
+        acc = ulo + (1.0 / 4096.0) <= ratio;
+        if (!acc && ulo < ratio) {
+            const u32x4 rb = wu_philox(refine_k, kSubWuRefine, syn, slot, a.seed_lo, a.seed_hi);
+            const uint64_t v44 = ((uint64_t)a12 << 32) | sel4(rb, (int)refine_w);
+            acc = (double)v44 * (1.0 / 17592186044416.0) < ratio;
+        }
+    }
+    if (acc) {
+        wu_xor<WV>(st, d0, d1, d2, d3, x0, x1, x2, x3);
+        al.Dh = __builtin_bit_cast(uint32_t, pD);
+        al.any = 1u;
+    }
+}
+
 // this rung's seed configuration of ladder `lad`, packed 2 bits per qubit, into the lane's column of the rung's rows of the exchange
 // buffer (Ladder.__init__ copies the seed into every rung, mcmc.py:72; resume: the rung's own state) -- a short runtime loop; the caller
 // then takes the words into its state registers with the exchange's own static reads.  Returns 4 x the error count and the class.
@@ -270,10 +398,13 @@ __device__ __forceinline__ void wu_stage_lds(const LadderArgs &a, uint64_t lad, 
 // QUEUE (with CONV): a persistent grid; a lane whose ladder has ended takes the next one of its workgroup's share of the batch (in lane
 // order among the lanes that end together, so the assignment does not depend on timing): the acceptance and swap uniforms follow
 // the ladder (its index, its own step), the generator picks the lane's position (group, workgroup step).
-template <int CODE, int WV, bool CONV, bool QUEUE, bool TOP, int IT>
+// ALPHA: the alpha noise model's ladder (src/mcmc_alpha.py; xzzx / rotated codes): wu_propose_alpha, slot-bound n_eff attributes (Q4) -- a wave IS
+// a slot here, so its attribute is a register --, the floating-point swap test, the criterion on the logged count pairs.
+template <int CODE, int WV, bool CONV, bool QUEUE, bool TOP, int IT, bool ALPHA>
 __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::type &st, WuCtx &cx, const WuEnv &ev)
 {
     static_assert(!QUEUE || CONV, "the work queue serves the runs that stop by the criterion");
+    static_assert(!ALPHA || CODE != kCodeToric, "the alpha rule: xzzx / rotated codes");
     const int L = a.L;
     wu_lds_ptr const lml = (wu_lds_ptr)(uintptr_t)(ev.lds0 + ev.lml_off);
     const uint32_t lds0 = ev.lds0, slot = ev.slot, grp = ev.grp;
@@ -282,6 +413,10 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
     const uint32_t G = a.n_gen;
     const uint32_t m55 = 0x55555555u;
     uint32_t n4 = cx.n4, cls = cx.cls, flag = cx.flag;
+    [[maybe_unused]] uint32_t nef = cx.nef;                                       // ALPHA: this slot's n_eff attribute as n_z | (n_x + n_y) << 16
+    [[maybe_unused]] float lxyf = 0.0f, lzf = 0.0f;
+    if constexpr (ALPHA) { lxyf = a.bias_l2f[ev.slot][0]; lzf = a.bias_l2f[ev.slot][1]; }
+    [[maybe_unused]] const uint32_t cht_base = ev.lds0 + ev.cht_off;
     uint32_t syn = a.first_syndrome + ev.lad;                                     // Philox ctr[2] of the lane's ladder
     [[maybe_unused]] uint32_t t0 = 0;                                             // QUEUE: the workgroup step the lane's ladder started at
     [[maybe_unused]] uint32_t tops0 = cx.tops0, samples = 0;                      // wave 0 of the fixed-length kernels: in registers
@@ -313,6 +448,8 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
         const uint64_t T = QUEUE ? (uint64_t)((uint32_t)t - t0) : a.step0 + t;
         [[maybe_unused]] uint32_t maskv = 0, cdelta = 0;                           // top rung: the step's frame of logical operators (lane w: word w), class change
         const uint32_t pbase = ws * iters;                                         // the step's first proposal within the window
+        [[maybe_unused]] WuAl al{0u, 0u, 0u};
+        if constexpr (ALPHA && !top) al.Nb = wu_counts_packed<WV>(st, m55);        // p_b's counts (mcmc_alpha.py:38-41)
         for (uint32_t c = 0; c < nch; ++c) {
             [[maybe_unused]] u32x4 ab{0, 0, 0, 0};                                 // this ladder's block of ten 12-bit acceptance uniforms
             if (!top) ab = wu_philox(T * nch + c, kSubWuAcc, syn, slot, a.seed_lo, a.seed_hi);
@@ -359,6 +496,20 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
                     if constexpr (IT == 10) {
                         // (iters even: proposal parity = field parity; a lane of the window holds a pair: one readlane, both descriptors
                         // fetched together, the second one's latency hidden behind the first proposal)
+                        if constexpr (ALPHA) {
+                          if ((f & 1) == 0) {
+                            const wu_const_ptr eb = desc + ((r >> 16) >> 2);
+                            const uint32_t d0 = e[0], d1 = e[1], d2 = e[2], d3 = e[3], x0 = e[4], x1 = e[5], x2 = e[6], x3 = e[7];
+                            const uint32_t am = e[11], tlo = e[12], thi = e[13], om = e[14], coff = e[15];
+                            const uint32_t b0 = eb[0], b1 = eb[1], b2 = eb[2], b3 = eb[3], y0 = eb[4], y1 = eb[5], y2 = eb[6], y3 = eb[7];
+                            const uint32_t an = eb[11], ulo = eb[12], uhi = eb[13], on = eb[14], cofn = eb[15];
+                            __builtin_amdgcn_sched_barrier(0);
+                            wu_propose_alpha<CODE, WV>(a, st, al, wu_field(ab, f), cht_base + coff, lxyf, lzf, d0, d1, d2, d3, x0, x1, x2, x3, tlo, thi, om, am,
+                                                       T * nc4 + (j >> 2), j & 3u, syn, slot, m55);
+                            wu_propose_alpha<CODE, WV>(a, st, al, wu_field(ab, f + 1), cht_base + cofn, lxyf, lzf, b0, b1, b2, b3, y0, y1, y2, y3, ulo, uhi, on, an,
+                                                       T * nc4 + ((j + 1u) >> 2), (j + 1u) & 3u, syn, slot, m55);
+                          }
+                        } else
                         if ((f & 1) == 0) {
                             const wu_const_ptr eb = desc + ((r >> 16) >> 2);
                             const uint32_t d0 = e[0], d1 = e[1], d2 = e[2], d3 = e[3], x0 = e[4], x1 = e[5], x2 = e[6], x3 = e[7], tlo = e[8];
@@ -371,6 +522,11 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
                             wu_propose<CODE, WV>(st, n4, wu_field(ab, f + 1), thr_base, nbias, b0, b1, b2, b3, y0, y1, y2, y3, ulo, uhi, on, an,
                                                  T * nc4 + ((j + 1u) >> 2), (j + 1u) & 3u, syn, slot, a.seed_lo, a.seed_hi);
                         }
+                    } else if constexpr (ALPHA) {
+                        const uint32_t d0 = e[0], d1 = e[1], d2 = e[2], d3 = e[3], x0 = e[4], x1 = e[5], x2 = e[6], x3 = e[7];
+                        const uint32_t am = e[11], tlo = e[12], thi = e[13], om = e[14], coff = e[15];
+                        wu_propose_alpha<CODE, WV>(a, st, al, wu_field(ab, f), cht_base + coff, lxyf, lzf, d0, d1, d2, d3, x0, x1, x2, x3, tlo, thi, om, am,
+                                                   T * nc4 + (j >> 2), j & 3u, syn, slot, m55);
                     } else {
                         const uint32_t d0 = e[0], d1 = e[1], d2 = e[2], d3 = e[3], x0 = e[4], x1 = e[5], x2 = e[6], x3 = e[7], tlo = e[8];
                         const uint32_t thi = CODE == kCodeToric ? 0u : e[9], om = CODE == kCodeToric ? 0u : e[10], am = CODE == kCodeToric ? 0u : e[11];
@@ -384,14 +540,23 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
             // the step's logical operators at once, then the error count (the blind moves did not keep it)
             cls ^= cdelta;
             n4 = 0;
+            [[maybe_unused]] uint32_t tx = 0, tz = 0, txy = 0;
 #define QECMC_WU_FLUSH(w)                                                                                    \
             if constexpr (w < WV) {                                                                          \
                 wu_xor_s<WV, w>(st, (uint32_t)__builtin_amdgcn_readlane((int)maskv, w));                     \
-                wu_count<WV, w>(st, n4, m55);                                                                \
+                if constexpr (ALPHA) wu_count3<WV, w>(st, tx, tz, txy, m55);                                 \
+                else wu_count<WV, w>(st, n4, m55);                                                           \
             }
             WU_EACH(QECMC_WU_FLUSH)
 #undef QECMC_WU_FLUSH
+            if constexpr (ALPHA) { n4 = tz + txy; nef = tz | (txy << 16); }           // (every move of this rung is accepted: the attribute follows, :58)
             n4 <<= 2;
+        } else if constexpr (ALPHA) {
+            // the counts the step ends with; the slot's attribute follows them if a move was accepted (mcmc_alpha.py:70)
+            const wu_half2 D = __builtin_bit_cast(wu_half2, al.Dh);
+            const uint32_t ez = (uint32_t)((int)((al.Nb >> 10) & 1023u) + (int)(float)D.y), exy = (uint32_t)((int)(al.Nb >> 20) + (int)(float)D.x);
+            n4 = (ez + exy) << 2;
+            if (al.any) nef = ez | (exy << 16);
         }
         // the next step's pick window (state-independent; before the barrier, where the other waves are still busy)
         if (++ws == S) { ws = 0; ++wi; refresh(); }
@@ -404,12 +569,14 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
         asm volatile("" : "+s"(NCl), "+s"(nql), "+s"(ncl), "+s"(Ll), "+s"(slotl), "+s"(lds0l), "+s"(Wl));
         const int NC = NCl, nq = nql, ncls = ncl;
         const uint32_t slot = slotl;
-        const WuLds ol = wu_lds(NC, Wl, ncls, Ll, CONV);
+        const WuLds ol = wu_lds(NC, Wl, ncls, Ll, CONV, ALPHA);
         // (LDS pointers by address space: a laundered generic pointer would turn every access below into a flat load)
         wu_lds_rw const ldsl = (wu_lds_rw)(uintptr_t)lds0l;
         wu_lds_rw const rec = ldsl + ol.rec, swd = ldsl + ol.swd, hist = ldsl + ol.hist, swapT = ldsl + ol.swapT;
         volatile __attribute__((address_space(3))) uint32_t *const stopf = ldsl + ol.stop;
-        [[maybe_unused]] wu_lds_rw const bk = ldsl + ol.bk + (uint32_t)lane, mail = ldsl + ol.mail, bot = ldsl + ol.bot;
+        [[maybe_unused]] wu_lds_rw const bk = ldsl + ol.bk + (uint32_t)lane, mail = ldsl + ol.mail, bot = ldsl + ol.bot, bot2 = ldsl + ol.bot2;
+        [[maybe_unused]] wu_lds_drw const nefd = (wu_lds_drw)(ldsl + ol.nef) + (uint32_t)lane;
+        [[maybe_unused]] wu_lds_dptr const lnbd = (wu_lds_dptr)(ldsl + ol.lnb);
         const uint32_t xaddr = lds0l + (uint32_t)lane * 4u;
         const uint32_t xstride = (uint32_t)Wl * 256u;                               // bytes of one rung in the exchange buffer
         const int swb = NC - 1 - (int)slot;                 // the top rungs draw the swap uniforms: block swb = pairs 4 swb .. 4 swb + 3
@@ -422,6 +589,7 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
 #define QECMC_WU_PUT(w) if constexpr (w < WV) { if (w < wu_words_min(WV) || w < Wl) wu_ds_write<WV, w>(st, xo); }
             WU_EACH(QECMC_WU_PUT)
             rec[slot * 64u + (uint32_t)lane] = pack_info(n4 >> 2, slot, cls, flag);
+            if constexpr (ALPHA) nefd[slot * 64u] = wu_neff(nef, a.alpha);
             if (duty) {
                 wu_lds_rw p = swd + (uint32_t)(swb * 4) * 64u + (uint32_t)lane;
                 const int left = NC - 1 - swb * 4;
@@ -441,12 +609,17 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
             const int i_stop = slot == 0 ? 0 : (int)slot - 1;
             for (int i = NC - 2; i >= i_stop; --i) {                                 // mcmc.py:96
                 const uint32_t lo = cur[i * 64], x = sx[i * 64];
+                bool flip;
+                if constexpr (ALPHA) {
+                    flip = wu_alpha_flip(x, nefd[(i + 1) * 64], nefd[i * 64], lnbd[i]);   // the slots' attributes: they stay where they are (Q4)
+                } else {
                 const int d = (int)(car & 0xFFFFu) - (int)(lo & 0xFFFFu);            // ne_hi - ne_lo, _r_flip :146-149
                 // x < ceil(p_diff[i]^d 2^32): the LDS table for d < 64 (entry 0 never passes: d <= 0 flips anyway), else the plan's
                 const int dd = d < 1 ? 1 : d;
                 bool lt = x < swapT[i * kSwapFast + (dd < kSwapFast ? dd : 0)];
                 if (dd >= kSwapFast) lt = (uint64_t)x < a.swap_thr[(size_t)i * (nq + 1) + dd];
-                const bool flip = d <= 0 || lt;
+                flip = d <= 0 || lt;
+                }
                 const uint32_t into = flip ? lo : car;                               // what slot i+1 now holds (:98-99)
                 car = flip ? car : lo;
                 if ((int)slot == i + 1) mine = into;
@@ -469,6 +642,7 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
                 }
             } else if (slot == 0) {
                 bot[((uint32_t)t & 1u) * 64u + (uint32_t)lane] = mine;              // (booked by the top rung's wave behind the next step's barrier)
+                if constexpr (ALPHA) bot2[((uint32_t)t & 1u) * 64u + (uint32_t)lane] = nef;   // chains[0].n_eff, decoders_biasednoise.py:204
             }
             if constexpr (CONV && TOP) {
                 // ---- ladder + PTEQ bookkeeping with the error_based criterion (decoders.py:60-82,93-105), by the wave of the TOP rung -- the
@@ -480,6 +654,8 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
             // the same with the error_based criterion (decoders.py:74-82,93-105); the per-ladder state lives in LDS between steps
             uint32_t b_tops0 = bk[0], b_samples = bk[64], b_burn = bk[128], b_cstart = bk[192], b_cstreak = bk[256], b_state = bk[576];
             uint64_t sumA = (uint64_t)bk[320] | ((uint64_t)bk[384] << 32), sumB = (uint64_t)bk[448] | ((uint64_t)bk[512] << 32);
+            [[maybe_unused]] uint64_t sumAxy = 0, sumBxy = 0;
+            if constexpr (ALPHA) { sumAxy = (uint64_t)bk[832] | ((uint64_t)bk[896] << 32); sumBxy = (uint64_t)bk[960] | ((uint64_t)bk[1024] << 32); }
             uint32_t has = (b_state >> 3) & 1u, pending = (b_state >> 1) & 3u, done = b_state & 1u;
             const uint32_t Town = (uint32_t)Tb;                                  // the ladder's own step (of the step being booked)
             bool ended = false;
@@ -493,8 +669,11 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
                     // nbr_errors_bottom_chain[since_burn] = count_errors (:68), logged in HBM: series index i in row burn + i of the
                     // lane's column (QUEUE: a column per lane of the grid, rows = the ladder's own steps)
                     const size_t lN = QUEUE ? (size_t)gridDim.x * 64u : (size_t)a.N;
-                    uint16_t *mylog = a.nlog + ((size_t)blockIdx.x * 64u + (size_t)lane);
-                    mylog[(size_t)Town * lN] = (uint16_t)n0;
+                    // (ALPHA: chains[0].n_eff -- slot 0's attribute, decoders_biasednoise.py:204 -- logged as its two counts, 4 B)
+                    typedef typename std::conditional<ALPHA, uint32_t, uint16_t>::type log_t;
+                    log_t *mylog = reinterpret_cast<log_t *>(a.nlog) + ((size_t)blockIdx.x * 64u + (size_t)lane);
+                    const uint32_t v0 = ALPHA ? bot2[((uint32_t)tb & 1u) * 64u + (uint32_t)lane] : n0;
+                    mylog[(size_t)Town * lN] = (log_t)v0;
                     const uint32_t l = b_samples, lo1 = l - 1;
                     const uint32_t a0 = lo1 >> 2, b0 = lo1 >> 1, c0 = (3u * lo1) >> 2, a1 = l >> 2, b1 = l >> 1, c1 = (3u * l) >> 2;
                     // the (up to three) entries that leave / enter the windows Q2 = series[l/4 : l/2], Q4 = series[3l/4 : l]: old rows of the
@@ -507,10 +686,17 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
                         vb = b1 != b0 ? mylog[(size_t)(b_burn + b0) * lN] : 0u;
                         va = a1 != a0 ? mylog[(size_t)(b_burn + a0) * lN] : 0u;
                     }
+                    if constexpr (ALPHA) {
+                        sumB += v0 & 0xFFFFu; sumBxy += v0 >> 16;
+                        sumB -= vc & 0xFFFFu; sumBxy -= vc >> 16;
+                        sumA += vb & 0xFFFFu; sumAxy += vb >> 16;
+                        sumA -= va & 0xFFFFu; sumAxy -= va >> 16;
+                    } else {
                     sumB += n0;
                     sumB -= vc;
                     sumA += vb;
                     sumA -= va;
+                    }
                     {   // ... and the next sample's (the burn-in is over: its offset stays)
                         const uint32_t l2 = l + 1u;
                         const uint32_t a2 = l2 >> 2, b2 = l2 >> 1, c2 = (3u * l2) >> 2;
@@ -526,7 +712,10 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
                     const uint32_t l = b_samples ? b_samples : 1u;
                     const uint32_t den2 = (l >> 1) - (l >> 2), den4 = l - ((3u * l) >> 2);
                     bool accept = false;                                         // empty slice -> nan -> not accepted
-                    if (b_samples && den2 && den4) accept = fabs((double)sumA / (double)den2 - (double)sumB / (double)den4) < a.eps;   // :96-102
+                    if (b_samples && den2 && den4) {
+                        if constexpr (ALPHA) accept = alpha_series_close(sumA, sumAxy, den2, sumB, sumBxy, den4, a.alpha, a.eps);   // decoders_biasednoise.py:229-238
+                        else accept = fabs((double)sumA / (double)den2 - (double)sumB / (double)den4) < a.eps;   // :96-102
+                    }
                     if (accept) {
                         if (b_cstreak >= a.SEQ) { ended = true; conv_ok = 1; }   // :77-78
                         else b_cstreak = b_tops0 - b_cstart;                     // :79
@@ -563,7 +752,7 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
                         if (a.steps_done != nullptr) a.steps_done[row] = sd;
                         if (a.converged != nullptr) a.converged[row] = (uint8_t)conv_ok;
                     }
-                    b_tops0 = b_samples = b_burn = b_cstart = b_cstreak = 0; sumA = sumB = 0;
+                    b_tops0 = b_samples = b_burn = b_cstart = b_cstreak = 0; sumA = sumB = 0; sumAxy = sumBxy = 0;
                     const uint32_t cand = (uint32_t)stopf[2] + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
                     give = (uint64_t)cand < ev.chunk_hi ? cand : kWuDead;
                     if (give == kWuDead) has = 0; else { pending = 2; bk[768] = give; }
@@ -579,6 +768,7 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
             bk[0] = b_tops0; bk[64] = b_samples; bk[128] = b_burn; bk[192] = b_cstart; bk[256] = b_cstreak;
             bk[320] = (uint32_t)sumA; bk[384] = (uint32_t)(sumA >> 32); bk[448] = (uint32_t)sumB; bk[512] = (uint32_t)(sumB >> 32);
             bk[576] = done | (pending << 1) | (has << 3);
+            if constexpr (ALPHA) { bk[832] = (uint32_t)sumAxy; bk[896] = (uint32_t)(sumAxy >> 32); bk[960] = (uint32_t)sumBxy; bk[1024] = (uint32_t)(sumBxy >> 32); }
                 };
                 if (t > 0) book(t - 1, QUEUE ? (uint64_t)((uint32_t)(t - 1) - t0) : a.step0 + t - 1);
             }
@@ -603,15 +793,17 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
 #undef QECMC_WU_MINE
                         wu_ds_wait<WV>(st);
                         flag = top ? 1u : 0u;
+                        if constexpr (ALPHA) { const uint32_t c3 = wu_counts_packed<WV>(st, m55); nef = ((c3 >> 10) & 1023u) | ((c3 >> 20) << 16); }   // Chain_alpha.__init__
                     }
                 }
             }
         }
     }
     cx.n4 = n4; cx.cls = cls; cx.flag = flag; cx.tops0 = tops0; cx.samples = samples;
+    if constexpr (ALPHA) cx.nef = nef;
 }
 
-template <int MAXT, int MINW, int CODE, int WV, bool CONV, bool QUEUE, int IT>
+template <int MAXT, int MINW, int CODE, int WV, bool CONV, bool QUEUE, int IT, bool ALPHA = false>
 __global__ __launch_bounds__(MAXT, MINW) void ladder_wu_kernel(const LadderArgs a)
 {
     typedef typename WuVec<WV>::type vec_t;
@@ -620,7 +812,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_wu_kernel(const LadderArgs 
     const int nthreads = NC * 64;
     const int tid = (int)threadIdx.x, lane = tid & 63;
     const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);      // this wave's rung (fixed: states move)
-    const WuLds o = wu_lds(NC, W, ncls, L, CONV);
+    const WuLds o = wu_lds(NC, W, ncls, L, CONV, ALPHA);
     uint32_t *xbuf = lds + o.xbuf, *rec = lds + o.rec, *hist = lds + o.hist, *thrT = lds + o.thr;
     uint32_t *swapT = lds + o.swapT, *lml = lds + o.lml;
     volatile uint32_t *stopf = lds + o.stop;
@@ -638,19 +830,27 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_wu_kernel(const LadderArgs 
     if (tid < 4) stopf[tid] = tid == 2 ? (uint32_t)s0 + 64u : 0u;   // [0], [1]: stop, by step parity; [2]: the workgroup's queue (next unassigned ladder)
     if constexpr (CONV) {
         uint32_t *bk = lds + o.bk, *mail = lds + o.mail;
-        for (int i = tid; i < kWuBk * 64; i += nthreads) {
+        for (int i = tid; i < (ALPHA ? kWuBkAlpha : kWuBk) * 64; i += nthreads) {
             const int row = i >> 6, l = i & 63;
             bk[i] = row == 9 ? (l < cnt ? 8u : 0u) : row == 12 ? (uint32_t)s0 + (uint32_t)l : 0u;                   // state: has; the lane's ladder
         }
         for (int i = tid; i < 128; i += nthreads) mail[i] = kWuKeep;
     }
-    for (int i = tid; i < NC * 18; i += nthreads) {
+    if constexpr (ALPHA) {
+        // (D_xy, D_z) of a proposal as two fp16 integers, at byte offset 4 ((D_z + 4) + 9 (D_xy + 4)); ln(pz_i / pz_i+1) of the rung pairs
+        for (int i = tid; i < 81; i += nthreads) {
+            const wu_half2 h = {(_Float16)(float)(i / 9 - 4), (_Float16)(float)(i % 9 - 4)};
+            lds[o.cht + i] = __builtin_bit_cast(uint32_t, h);
+        }
+        for (int i = tid; i < NC - 1; i += nthreads) reinterpret_cast<double *>(lds + o.lnb)[i] = a.alpha_lnb[i];
+    }
+    for (int i = tid; i < NC * 18 && !ALPHA; i += nthreads) {
         const int c = i / 18, r = i - c * 18, hi = r < 9, idx = hi ? r : r - 9;
         // dE <= 0 (idx <= 4): always accepted -- a high part no 12-bit uniform reaches; dE = 1..4: ceil(f^dE 2^44)
         const uint64_t t44 = idx <= 4 ? (1ull << 44) : a.acc_thr44[c][idx - 5];
         thrT[i] = hi ? (uint32_t)(t44 >> 32) : (uint32_t)t44;
     }
-    for (int i = tid; i < (NC - 1) * kSwapFast; i += nthreads) {
+    for (int i = tid; i < (NC - 1) * kSwapFast && !ALPHA; i += nthreads) {
         const int pr = i / kSwapFast, d = i - pr * kSwapFast;
         swapT[i] = (d >= 1 && d <= nq) ? (uint32_t)a.swap_thr[(size_t)pr * (nq + 1) + d] : 0u;
     }
@@ -681,15 +881,17 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_wu_kernel(const LadderArgs 
     if (slot == 0 && a.resume && live) tops0 = a.tops0[s0 + lane];
     __syncthreads();
 
-    WuCtx cx{n4, cls, flag, tops0, 0u, 0u, 0u, 0u};
+    uint32_t nef0 = 0;
+    if constexpr (ALPHA) { const uint32_t c3 = wu_counts_packed<WV>(st, 0x55555555u); nef0 = ((c3 >> 10) & 1023u) | ((c3 >> 20) << 16); }   // Chain_alpha.__init__, mcmc_alpha.py:18-22
+    WuCtx cx{n4, cls, flag, tops0, 0u, 0u, 0u, 0u, nef0};
     WuEnv ev;
-    ev.lds0 = lds0; ev.thr_off = (uint32_t)((o.thr + (int)slot * 18) * 4); ev.lml_off = (uint32_t)(o.lml * 4); ev.slot = slot;
+    ev.lds0 = lds0; ev.thr_off = (uint32_t)((o.thr + (int)slot * 18) * 4); ev.lml_off = (uint32_t)(o.lml * 4); ev.cht_off = (uint32_t)(o.cht * 4); ev.slot = slot;
     ev.grp = (a.first_syndrome >> 6) + (uint32_t)blockIdx.x;         // the wavefront's shared picks: its position in the grid
     ev.lad = live ? (uint32_t)ladder : kWuDead;
     ev.lane = lane; ev.chunk_hi = s1;
     // (the two roles are separate loops: they meet at the step's barriers)
-    if (top) wu_run<CODE, WV, CONV, QUEUE, true, IT>(a, st, cx, ev);
-    else wu_run<CODE, WV, CONV, QUEUE, false, IT>(a, st, cx, ev);
+    if (top) wu_run<CODE, WV, CONV, QUEUE, true, IT, ALPHA>(a, st, cx, ev);
+    else wu_run<CODE, WV, CONV, QUEUE, false, IT, ALPHA>(a, st, cx, ev);
     if constexpr (QUEUE) return;                                      // (every ladder wrote its results when it ended)
     n4 = cx.n4; cls = cx.cls; flag = cx.flag; tops0 = cx.tops0;
     uint32_t samples = cx.samples, done = 0, conv_ok = 0, steps_done = 0;
@@ -781,10 +983,22 @@ inline const void *wu_pick(int variant, int Nc, int W, uint32_t iters)
     return variant == 2 ? wu_pick_it<CODE, true, true, 0>(Nc, W) : wu_pick_it<CODE, false, false, 0>(Nc, W);
 }
 
+// the alpha rule's kernels: xzzx / rotated codes up to 8 state words per rung (L <= 11) and 8 rungs
+// (IT = 10: PTEQ_alpha's default iters, decoders_biasednoise.py:175)
+template <int CODE, int IT>
+inline const void *wu_pick_alpha(int variant, int Nc, int W)
+{
+    if (W > 8 || Nc * 64 > 512 || (variant != 0 && variant != 2)) return nullptr;
+    if (variant == 2)
+        return W <= 4 ? (const void *)ladder_wu_kernel<512, 8, CODE, 4, true, true, IT, true> : (const void *)ladder_wu_kernel<512, 8, CODE, 8, true, true, IT, true>;
+    return W <= 4 ? (const void *)ladder_wu_kernel<512, 8, CODE, 4, false, false, IT, true> : (const void *)ladder_wu_kernel<512, 8, CODE, 8, false, false, IT, true>;
+}
+
 // one translation unit per code family (parallel builds)
 const void *wu_kernel_toric(int variant, int Nc, int W, uint32_t iters);            // ladder_wu.hip
 const void *wu_kernel_xzzx(int variant, int Nc, int W, uint32_t iters);             // ladder_wu_xzzx.hip
 const void *wu_kernel_rotated(int variant, int Nc, int W, uint32_t iters);          // ladder_wu_rotated.hip
 const void *wu_kernel_planar(int variant, int Nc, int W, uint32_t iters);           // ladder_wu_planar.hip
+const void *wu_kernel_alpha(int code, int variant, int Nc, int W, uint32_t iters);   // ladder_wu_alpha.hip
 
 }  // namespace qecmc

@@ -204,7 +204,7 @@ inline std::vector<uint64_t> swap_thresholds(const std::vector<double> &pdiff, i
 // table indexed by its old 2-bit field, 4 (1 + change) -- 8 for an identity, 0 for the generator's own Pauli, else 4 -- for the
 // generator's first Pauli (dword 8) and its second one, if any (dword 9); 10, 11: per site the byte or-ed into / and-ed with the old
 // field to form the table index (4: second table; a missing site: index of a "no change" entry, field masked away).
-// Empty if some generator carries three different Paulis (none of the four code models does).
+// 12-15: the same for the alpha rule (below).  Empty if some generator carries three different Paulis (none of the four code models does).
 inline std::vector<uint32_t> wave_descriptors(const std::vector<uint32_t> &gt)
 {
     const size_t G = gt.size() / 2;
@@ -239,6 +239,28 @@ inline std::vector<uint32_t> wave_descriptors(const std::vector<uint32_t> &gt)
         d[16 * g + 9] = pb ? table(pb) : table(pa);
         d[16 * g + 10] = omask;
         d[16 * g + 11] = amask;
+        // the alpha rule (mcmc_alpha.py:31-36 weighs n_z and n_x + n_y): per Pauli the byte 4 ((dz + 1) + 9 (dxy + 1)) of applying it to old field f;
+        // the four bytes add up to the byte offset of (D_xy, D_z) in the kernel's 9 x 9 table, a missing site (selector 0x0C: the constant 0)
+        // is made up for by the offset in dword 15
+        auto atable = [](uint32_t P) {
+            uint32_t t = 0;
+            for (uint32_t f = 0; f < 4; ++f) {
+                const uint32_t fn = f ^ P;
+                const int dz = (int)(fn == 3u) - (int)(f == 3u), dxy = (int)(fn == 1u || fn == 2u) - (int)(f == 1u || f == 2u);
+                t |= (uint32_t)(4 * ((dz + 1) + 9 * (dxy + 1))) << (8 * f);
+            }
+            return t;
+        };
+        uint32_t omask_a = 0, n_real = 0;
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t P = e[u] & 3u;
+            if (P) { ++n_real; if (P != pa) omask_a |= 4u << (8 * u); }
+            else omask_a |= 0x0Cu << (8 * u);
+        }
+        d[16 * g + 12] = atable(pa);
+        d[16 * g + 13] = pb ? atable(pb) : atable(pa);
+        d[16 * g + 14] = omask_a;
+        d[16 * g + 15] = (4u - n_real) * 40u;
     }
     return d;
 }

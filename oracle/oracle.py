@@ -479,11 +479,12 @@ def pteq_batch(code, init, p, Nc, steps, iters=10, tops_burn=2, seed=0, first_sy
     return out
 
 
-def pteq_wave_queue(code, init, p, Nc, steps, grid, iters=10, tops_burn=2, seed=0, first_syndrome=0, n_threads=0, SEQ=2, TOPS=10, eps=0.1):
+def pteq_wave_queue(code, init, p, Nc, steps, grid, iters=10, tops_burn=2, seed=0, first_syndrome=0, n_threads=0, SEQ=2, TOPS=10, eps=0.1,
+                    noise=DEPOLARIZING, alpha=0.0, det_pow=0):
     """scan = 3 with the error_based criterion on a persistent grid of `grid` workgroups: the deterministic work queue of the GPU
     kernel, restated (orc_pteq_wave_queue)"""
     init = _m(init); N = init.shape[0]
-    mod = _model(code, init.shape[-1], DEPOLARIZING, 0.0, 3)
+    mod = _model(code, init.shape[-1], noise, 0.0, 3, alpha, det_pow)
     counts = np.zeros((N, 16), dtype=np.uint32)
     samples = np.zeros(N, dtype=np.uint64); tops0 = np.zeros(N, dtype=np.uint64)
     steps_done = np.zeros(N, dtype=np.uint64); converged = np.zeros(N, dtype=np.uint8)

@@ -672,6 +672,56 @@ double orc_det_exp(double y)
     return q * sc.d;
 }
 
+/* scan = 3 under the alpha rule (mcmc_alpha.py:27-70): the picks of chain_update_wave -- shared by the 64 ladders of a wavefront --, the
+ * ladder's own 44-bit acceptance uniform against p_n / p_b with p_b frozen at loop entry (Q3); the top rung (pz_tilde = 1: every weight
+ * is 0.25^num, the ratio exactly 1) accepts every move.  Returns whether a move was accepted; *n_eff follows (:58,:70). */
+static int chain_update_wave_alpha(const orc_model *m, uint8_t *state, double pz_tilde, double p_logical, uint64_t iters,
+                                   orc_rng *rng, uint32_t slot, uint64_t k0, uint8_t *scratch, double *n_eff)
+{
+    const size_t nq = (size_t)orc_nq(m->code, m->L);
+    const double alpha = m->alpha;
+    const double p_tilde = pz_tilde + 2 * pow(pz_tilde, alpha);
+    const double p = p_tilde / (1 + p_tilde);
+    const double pz = pz_tilde * (1 - p), px = pow(pz_tilde, alpha) * (1 - p), py = px;
+    const double pb = biased_weight(state, (int)nq, px, py, pz);
+    const int G = orc_surf_ngen(m->code, m->L);
+    if (rng->mode == 0 || m->code == ORC_TORIC) abort();
+    if (p_logical != 0 && !(pz_tilde >= 1.0)) abort();
+    if (iters < 1 || iters > 128) abort();
+    const uint64_t T = k0 / iters, S = 128 / iters, nch = (iters + 9) / 10, nc4 = (iters + 3) / 4;
+    const uint64_t Tp = T + (rng->wave_override ? rng->wave_t0 : 0);
+    const uint32_t group = rng->wave_override ? rng->wave_group : rng->syndrome >> 6;
+    int accepted = 0;
+    for (uint64_t j = 0; j < iters; ++j) {
+        const uint64_t P = (Tp % S) * iters + j;
+        uint32_t pw[4];
+        wave_block(rng, group, 0x800u + slot, (Tp / S) * 64 + (P >> 1), 9u, pw);
+        const uint32_t A = pw[2 * (P & 1)], B = pw[2 * (P & 1) + 1];
+        const int g = (int)(((uint64_t)B * (uint32_t)G) >> 32);
+        rng->consumed += 2;
+        double u = 0.0;                                                       /* (the top rung: any u < 1) */
+        if (p_logical != 0 && (double)(A >> 16) / 65536.0 < p_logical) logical_from_words(m, state, scratch, A, B);
+        else model_sweep_stabilizer(m, state, scratch, (uint64_t)g);
+        if (p_logical == 0) {
+            uint32_t aw[4], rw[4];
+            wave_block(rng, rng->syndrome, slot, T * nch + j / 10, 10u, aw);
+            wave_block(rng, rng->syndrome, slot, T * nc4 + (j >> 2), 11u, rw);
+            const int f = (int)(j % 10);
+            const uint32_t a12 = f < 8 ? (aw[f >> 1] >> (12 * (f & 1))) & 0xFFFu
+                                       : ((aw[f == 8 ? 0 : 2] >> 24) | (((aw[f == 8 ? 1 : 3] >> 24) & 0xFu) << 8));
+            u = ((double)a12 * 4294967296.0 + (double)rw[j & 3]) / 17592186044416.0;
+        }
+        if (u < biased_weight(scratch, (int)nq, px, py, pz) / pb) {
+            memcpy(state, scratch, nq);
+            int nx = 0, ny = 0, nz = 0;
+            for (size_t i = 0; i < nq; ++i) { nx += state[i] == 1; ny += state[i] == 2; nz += state[i] == 3; }
+            *n_eff = nz + alpha * (nx + ny);
+            accepted = 1;
+        }
+    }
+    return accepted;
+}
+
 /* Chain_alpha.update_chain, mcmc_alpha.py:27-70: the biased rule with (p_x, p_y, p_z) derived from (pz_tilde, alpha),
  * p_b frozen at loop entry (Q3), and n_eff = n_z + alpha (n_x + n_y) refreshed on every accepted move (:58,:70). */
 int orc_chain_update_alpha(const orc_model *m, uint8_t *state, double pz_tilde, double p_logical, uint64_t iters,
@@ -682,6 +732,7 @@ int orc_chain_update_alpha(const orc_model *m, uint8_t *state, double pz_tilde, 
     const double p_tilde = pz_tilde + 2 * pow(pz_tilde, alpha);                         /* :32 */
     const double p = p_tilde / (1 + p_tilde);                                           /* :34 */
     const double pz = pz_tilde * (1 - p), px = pow(pz_tilde, alpha) * (1 - p), py = px; /* :35-36 */
+    if (m->scan == 3) return chain_update_wave_alpha(m, state, pz_tilde, p_logical, iters, rng, slot, k0, scratch, n_eff);
     const double pb = biased_weight(state, (int)nq, px, py, pz);                        /* :38-41 */
     int accepted = 0;
     for (uint64_t j = 0; j < iters; ++j) {

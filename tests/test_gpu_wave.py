@@ -201,3 +201,45 @@ def test_launch_dev_refuses_an_undersized_workspace(q, kind):
         assert int(samples.sum().item()) > 0
     finally:
         L_.lib().qecmc_plan_destroy(plan)
+
+
+# ---- scan = wave under the alpha noise model (src/mcmc_alpha.py; what generate_data.py:142-150 routes biased noise to) --------------------
+ALPHA_CASES = [  # name, L, Nc, N, steps, iters, pz_tilde, alpha, replicas
+    ("xzzx", 3, 3, 5, 300, 10, 0.20, 2.0, 1), ("xzzx", 5, 5, 70, 200, 10, 0.175, 4.04, 1), ("rotated", 5, 4, 6, 200, 7, 0.15, 3.0, 1),
+    ("xzzx", 7, 7, 4, 150, 10, 0.12, 4.04, 1), ("rotated", 7, 8, 3, 100, 10, 0.2, 1.3, 2), ("xzzx", 9, 8, 3, 80, 10, 0.15, 2.5, 1),
+    ("xzzx", 11, 5, 2, 40, 25, 0.1, 6.0, 1), ("xzzx", 5, 2, 4, 200, 1, 0.3, 1.0, 1), ("rotated", 9, 6, 3, 60, 3, 0.25, 2.0, 1)]
+
+
+@pytest.mark.parametrize("name,L,Nc,N,steps,iters,pzt,alpha,R", ALPHA_CASES)
+def test_wave_scan_alpha_bit_exact(q, orc, name, L, Nc, N, steps, iters, pzt, alpha, R):
+    """Ladder_alpha (mcmc_alpha.py:75-137) with the generator pick shared by a wavefront: p_b frozen at the step's start (Q3), slot-bound n_eff
+    attributes in the swap test (Q4), the top rung at pz_tilde = 1 -- class counts, tops0 and every rung's final configuration equal the oracle's."""
+    rng = np.random.default_rng(L * 5 + Nc + N)
+    code, ocode = _codes(q, orc, name)
+    init = _init(rng, name, N, L, 0.12)
+    kw = dict(steps=steps, iters=iters, tops_burn=0, seed=31, first_syndrome=64)
+    got = q.pteq_batch(init, pzt, Nc=Nc, code=code, alpha=alpha, scan="wave", return_states=True, replicas=R, **kw)
+    ref = orc.pteq_batch(ocode, np.repeat(init, R, axis=0), pzt, Nc, kw.pop("steps"), return_states=True, noise=orc.ALPHA, alpha=alpha, det_pow=1, scan=3, **kw)
+    assert np.array_equal(got["counts"], ref["counts"].reshape(N, R, 4).sum(axis=1))
+    assert np.array_equal(got["tops0"], ref["tops0"].reshape(N, R).sum(axis=1).astype(np.uint32))
+    assert np.array_equal(got["samples"], ref["samples"].reshape(N, R).sum(axis=1).astype(np.uint32))
+    if R == 1:
+        assert np.array_equal(got["states"], ref["states"])
+    assert got["counts"].sum() > 0 and not np.array_equal(got["states"][:, 0], init)
+
+
+@pytest.mark.parametrize("name,L,Nc,N,steps,iters,grid,pzt,alpha", [("xzzx", 3, 3, 200, 2500, 10, 1, 0.2, 2.0), ("xzzx", 5, 5, 300, 3000, 10, 2, 0.175, 4.04),
+                                                                  ("rotated", 5, 4, 150, 2500, 7, 1, 0.15, 3.0), ("xzzx", 7, 7, 100, 1500, 10, 1, 0.15, 4.04)])
+def test_wave_scan_alpha_work_queue_bit_exact(q, orc, name, L, Nc, N, steps, iters, grid, pzt, alpha):
+    """PTEQ_alpha's default route (decoders_biasednoise.py:175-238: error_based on chains[0].n_eff) on the deterministic work queue"""
+    rng = np.random.default_rng(L + 19 * Nc + N)
+    code, ocode = _codes(q, orc, name)
+    init = _init(rng, name, N, L, 0.1)
+    kw = dict(iters=iters, tops_burn=2, seed=13, first_syndrome=0, SEQ=2, TOPS=4, eps=0.3)
+    got = q.pteq_batch(init, pzt, Nc=Nc, code=code, alpha=alpha, scan="wave", steps=steps, conv_criteria="error_based", flags=q.dev_flags(queue_grid=grid), **kw)
+    g_eff = max(1, min(grid, (N + 63) // 64))
+    ref = orc.pteq_wave_queue(ocode, init, pzt, Nc, steps, g_eff, noise=orc.ALPHA, alpha=alpha, det_pow=1, **kw)
+    for k in ("counts", "samples", "tops0", "steps_done"):
+        assert np.array_equal(got[k], ref[k].astype(got[k].dtype)), k
+    assert np.array_equal(got["converged"], ref["converged"])
+    assert ref["converged"].any()

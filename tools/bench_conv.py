@@ -37,8 +37,8 @@ else:
     tag = "alpha_L%d" % L
     workload = "xzzx L=%d, errors at p=%g eta=%g, decoded by PTEQ_alpha (pz_tilde=%.6g, alpha=%.6g), Nc=%d" % (L, p, eta, p_dec, a, Nc)
 out = {}
-SCAN = os.environ.get("QECMC_BENCH_SCAN", "random")       # "wave": the scan = 3 kernel (no work queue yet: one ladder per lane)
-for name, grid in ((("queue", 0), ("one_ladder_per_lane", 65535)) if SCAN == "random" else (("wave_one_ladder_per_lane", 0),)):
+SCAN = os.environ.get("QECMC_BENCH_SCAN", "random")       # "wave": the scan = 3 kernel on its deterministic work queue
+for name, grid in ((("queue", 0), ("one_ladder_per_lane", 65535)) if SCAN == "random" else (("wave_queue", 0),)):
     for rep in range(2):
         t0 = time.time()
         r = qecmc.pteq_batch(init, p_dec, Nc=Nc, steps=H, iters=10, tops_burn=2, seed=3, conv_criteria="error_based", return_stats=True,
@@ -48,6 +48,7 @@ for name, grid in ((("queue", 0), ("one_ladder_per_lane", 65535)) if SCAN == "ra
     out[name] = dict(kernel_ms=r["stats"]["kernel_ms"], wall_s=dt, converged_frac=float(r["converged"].mean()), mean_steps=float(steps.mean()),
                      median_steps=float(np.median(steps)), p99_steps=float(np.percentile(steps, 99)), max_steps=float(steps.max()),
                      useful_proposals_per_s=float(steps.sum() * Nc * 10 / (r["stats"]["kernel_ms"] * 1e-3)),
+                     roofline_frac=float(steps.sum() * Nc * 10 / (r["stats"]["kernel_ms"] * 1e-3)) * 8 / 8e12,
                      checksum=int(r["counts"].astype(np.uint64).sum()))
     print(name, json.dumps(out[name]), flush=True)
 if SCAN == "random":
