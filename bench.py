@@ -99,13 +99,13 @@ def profile_counters(args):
     """What the committed rocprofv3 passes of this exact workload say binds the kernel (profiles/rNN_cfgC_pmc_summary.json,
     written by tools/profile_round.sh around this same command): HBM bytes per launch and the issue / LDS utilisation.
     None when the workload differs from the profiled one."""
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cfg%d_pmc_summary.json" % args.config)))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", ("r*_alpha_pmc_summary.json" if getattr(args, "alpha_route", False) else "r*_cfg%d_pmc_summary.json" % args.config))))
     if not files:
         return None
     d = json.load(open(files[-1]))
     w = d.get("_workload", {})
     same = (all(w.get(k) == getattr(args, k) for k in ("code", "L", "Nc", "iters", "syndromes", "ladder_steps")) and w.get("p_logical", 0.5) == args.p_logical
-            and w.get("scan", "random") == args.scan)
+            and w.get("scan", "random") == args.scan and bool(w.get("alpha_route", False)) == bool(getattr(args, "alpha_route", False)))
     if not same or "SQ_INSTS_VALU" not in d:
         return None
     wave_props = args.syndromes / 64 * args.Nc * args.iters * args.ladder_steps         # wave-proposals per launch
@@ -126,8 +126,37 @@ def profile_counters(args):
 
 def metric_name(args):
     """BASELINE.json's metric, named after the workload that was run (config 2 gives BASELINE's own string)"""
-    return "MCMC sweeps/sec (whole node), L=%d %s p=%g%s; eq-class histogram match" % (
-        args.L, args.code, args.p, "" if args.eta is None else " eta=%g" % args.eta)
+    return "MCMC sweeps/sec (whole node), L=%d %s p=%g%s%s; eq-class histogram match" % (
+        args.L, args.code, args.p, "" if args.eta is None else " eta=%g" % args.eta,
+        " decoded by PTEQ_alpha(pz_tilde=%.4g, alpha=%.4g)" % rule(args) if getattr(args, "alpha_route", False) else "")
+
+
+def rule(args):
+    """What the decoder is handed: (p, keyword arguments of the rule) for the library (`lib=True`: noise ids of qecmc._lib) and the oracle.
+    --alpha-route: errors drawn at (p, eta), decoded by PTEQ_alpha(pz_tilde, alpha) -- generate_data.py:142-150's route for biased noise."""
+    if getattr(args, "alpha_route", False):
+        pz_tilde = (args.p / (1 + 1 / args.eta)) / (1 - args.p)                          # generate_data.py:145
+        return float(pz_tilde), float(np.log(pz_tilde / (2 * args.eta)) / np.log(pz_tilde))   # :146
+    return args.p, None
+
+
+def lib_rule(args, L_):
+    p_dec, a = rule(args)
+    if a is not None:
+        return p_dec, dict(noise=L_.NOISE_ALPHA, eta=0.0, alpha=a)
+    return p_dec, dict(noise=L_.NOISE_DEPOLARIZING if args.eta is None else L_.NOISE_BIASED, eta=args.eta or 0.0)
+
+
+def orc_rule(args, orc):
+    p_dec, a = rule(args)
+    if a is not None:
+        return p_dec, dict(noise=orc.ALPHA, alpha=a, det_pow=1)
+    return p_dec, dict(noise=orc.DEPOLARIZING if args.eta is None else orc.BIASED, eta=args.eta or 0.0)
+
+
+def api_rule(args):
+    p_dec, a = rule(args)
+    return p_dec, (dict(alpha=a) if a is not None else dict(eta=args.eta))
 
 
 def rank_records(dist, use_dist, world, rank, device_name, device_uuid, kernel_ms, first):
@@ -156,9 +185,9 @@ def oracle_batch(args, init, steps, n_threads, first=0, states=False, scan=None,
     reference's own loop, one pick per ladder -- a CPU has no wavefront to share a pick with)"""
     from oracle import oracle as orc
     code = {"toric": orc.TORIC, "xzzx": orc.XZZX, "rotated": orc.ROTATED, "planar": orc.PLANAR}[args.code]
-    return orc.pteq_batch(code, init, args.p, args.Nc, steps, iters=args.iters, tops_burn=tops_burn, seed=args.seed, first_syndrome=first,
-                          n_threads=n_threads, noise=orc.DEPOLARIZING if args.eta is None else orc.BIASED, eta=args.eta or 0.0, return_states=states,
-                          scan=(3 if args.scan == "wave" else 0) if scan is None else scan)
+    p_dec, okw = orc_rule(args, orc)
+    return orc.pteq_batch(code, init, p_dec, args.Nc, steps, iters=args.iters, tops_burn=tops_burn, seed=args.seed, first_syndrome=first,
+                          n_threads=n_threads, return_states=states, scan=(3 if args.scan == "wave" else 0) if scan is None else scan, **okw)
 
 
 def cpu_baseline(args, init, n_gen, target_s=12.0):
@@ -187,9 +216,9 @@ def criterion_bench(args, L_, PteqShard, torch, dist, use_dist, world, rank, loc
     counting); roofline on the same 8 B / proposal convention, useful proposals only."""
     N, L, Nc = args.syndromes, args.L, args.Nc
     crit = dict(conv_mode=L_.CONV_ERROR_BASED, SEQ=2, TOPS=10, eps=0.1)                 # decoders.py:25
-    common = dict(code=code_id, Nc=Nc, p_logical=args.p_logical, iters=args.iters, tops_burn=2, seed=args.seed,
-                  noise=L_.NOISE_DEPOLARIZING if args.eta is None else L_.NOISE_BIASED, eta=args.eta or 0.0, scan=L_.SCANS[args.scan], flags=args.flags)
-    sh = PteqShard(init_h, args.p, first, n_total=N * world, steps=args.ladder_steps, **common, **crit)
+    p_dec, rkw = lib_rule(args, L_)
+    common = dict(code=code_id, Nc=Nc, p_logical=args.p_logical, iters=args.iters, tops_burn=2, seed=args.seed, scan=L_.SCANS[args.scan], flags=args.flags, **rkw)
+    sh = PteqShard(init_h, p_dec, first, n_total=N * world, steps=args.ladder_steps, **common, **crit)
     lds, threads, spb = C.c_uint32(), C.c_uint32(), C.c_uint32()
     L_.check(L_.lib().qecmc_plan_info(sh.plan, lds, threads, spb))
     stream = torch.cuda.current_stream()
@@ -229,7 +258,7 @@ def criterion_bench(args, L_, PteqShard, torch, dist, use_dist, world, rank, loc
         # the same kernel family at fixed length on the first 65 536 syndromes: what a ladder step costs without the criterion, the queue
         # and its tail (time after a workgroup's queue ran dry)
         n_fix = min(N, 65536)
-        shf = PteqShard(init_h[:n_fix], args.p, first, n_total=n_fix, steps=10000, **common)
+        shf = PteqShard(init_h[:n_fix], p_dec, first, n_total=n_fix, steps=10000, **common)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         fix_ms = []
         for rep in range(3):
@@ -246,6 +275,7 @@ def criterion_bench(args, L_, PteqShard, torch, dist, use_dist, world, rank, loc
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": workload + "; every ladder stopped by the error_based criterion or at the horizon of %d of its own steps" % args.ladder_steps,
                        "baseline_config": args.config, "syndromes_per_gpu": N, "code": args.code, "L": L, "p": args.p, "eta": args.eta, "Nc": Nc,
+                       "decoder": ("PTEQ_alpha(pz_tilde=%.6g, alpha=%.6g), generate_data.py:142-150" % rule(args)) if args.alpha_route else "PTEQ_biased" if args.eta is not None else "PTEQ",
                        "iters": args.iters, "horizon_ladder_steps": args.ladder_steps, "SEQ": 2, "TOPS": 10, "eps": 0.1, "tops_burn": 2, "seed": args.seed,
                        "scan": args.scan, "lds_bytes_per_workgroup": lds.value, "threads_per_workgroup": threads.value,
                        "workspace_bytes": sh.ws_bytes, "parallelism": "syndrome shards x%d, RCCL gather of class counts" % world},
@@ -269,10 +299,9 @@ def criterion_bench(args, L_, PteqShard, torch, dist, use_dist, world, rank, loc
             ocode = {"toric": orc.TORIC, "xzzx": orc.XZZX, "rotated": orc.ROTATED, "planar": orc.PLANAR}[args.code]
             cores = os.cpu_count() or 1
             n_cpu = min(N, cores)
-            okw = dict(iters=args.iters, tops_burn=2, seed=args.seed, n_threads=cores, conv_criteria="error_based", SEQ=2, TOPS=10, eps=0.1,
-                       noise=orc.DEPOLARIZING if args.eta is None else orc.BIASED, eta=args.eta or 0.0)
+            okw = dict(iters=args.iters, tops_burn=2, seed=args.seed, n_threads=cores, conv_criteria="error_based", SEQ=2, TOPS=10, eps=0.1, **orc_rule(args, orc)[1])
             t1 = time.perf_counter()
-            ref0 = orc.pteq_batch(ocode, init_h[:n_cpu], args.p, Nc, args.ladder_steps, first_syndrome=first, scan=0, **okw)   # the reference's own loop
+            ref0 = orc.pteq_batch(ocode, init_h[:n_cpu], p_dec, Nc, args.ladder_steps, first_syndrome=first, scan=0, **okw)   # the reference's own loop
             dt = time.perf_counter() - t1
             cpu_props = float(ref0["steps_done"].sum()) * Nc * args.iters
             out["cpu_baseline"] = {"value": cpu_props / n_gen / dt, "unit": "chain-sweeps/s", "cores": cores, "cpu_model": cpu_model(), "kind": "port",
@@ -282,9 +311,9 @@ def criterion_bench(args, L_, PteqShard, torch, dist, use_dist, world, rank, loc
             # kernel, against the oracle's restatement of the rule -- class counts, samples, tops0, stopping step and flag, bit for bit
             import qecmc
             n_chk = min(N, 64)
-            got = qecmc.pteq_batch(init_h[:n_chk], args.p, Nc=Nc, steps=args.ladder_steps, iters=args.iters, tops_burn=2, seed=args.seed, first_syndrome=first,
-                                   code=code_id, eta=args.eta, conv_criteria="error_based", SEQ=2, TOPS=10, eps=0.1, scan=args.scan, flags=args.flags)
-            ref = orc.pteq_batch(ocode, init_h[:n_chk], args.p, Nc, args.ladder_steps, first_syndrome=first, scan=3 if args.scan == "wave" else 0, **okw)
+            got = qecmc.pteq_batch(init_h[:n_chk], p_dec, Nc=Nc, steps=args.ladder_steps, iters=args.iters, tops_burn=2, seed=args.seed, first_syndrome=first,
+                                   code=code_id, conv_criteria="error_based", SEQ=2, TOPS=10, eps=0.1, scan=args.scan, flags=args.flags, **api_rule(args)[1])
+            ref = orc.pteq_batch(ocode, init_h[:n_chk], p_dec, Nc, args.ladder_steps, first_syndrome=first, scan=3 if args.scan == "wave" else 0, **okw)
             same = all(np.array_equal(np.asarray(got[k]).astype(np.uint64), np.asarray(ref[k]).astype(np.uint64)) for k in ("counts", "samples", "tops0", "steps_done"))
             out["histogram_match"] = {"syndromes_checked": n_chk, "horizon": args.ladder_steps,
                                       "class_counts_samples_tops0_stopping_step_bit_identical_to_cpu_oracle": bool(same),
@@ -322,6 +351,9 @@ def parse_args(argv=None):
     ap.add_argument("--p-logical", type=float, default=0.5, help="top-chain logical rate (decoders.py:52 uses 0.5)")
     ap.add_argument("--code", default=None, choices=["toric", "xzzx", "rotated", "planar"])
     ap.add_argument("--eta", type=float, default=None, help="bias: selects the mcmc_biased chain (config 4)")
+    ap.add_argument("--alpha-route", action="store_true",
+                    help="the route generate_data.py:142-150 takes for biased noise: errors drawn at (p, eta) on the xzzx code (defaults L=5, p=0.15, "
+                         "eta=100, Nc=5), decoded by PTEQ_alpha with (pz_tilde, alpha) derived from them (src/mcmc_alpha.py)")
     ap.add_argument("--scan", default="auto", choices=["auto", "random", "sweep", "wave"],
                     help="random = the reference's random-scan chain (scan=0); wave = the same chain per syndrome with a generator pick shared by the 64 "
                          "ladders of a wavefront, states in registers (scan=3); auto = wave where it is built and the faster one (depolarizing rule, "
@@ -337,12 +369,18 @@ def parse_args(argv=None):
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / exchange rehearsal without a GPU: gloo, no kernel, zero throughput (tests/test_bench_launcher.py)")
     args = ap.parse_args(argv)
-    cfg = CONFIGS[args.config]
+    cfg = dict(CONFIGS[args.config])
+    if args.alpha_route:
+        cfg.update(name="generate_data.py:142-150: biased noise decoded by PTEQ_alpha", code="xzzx", L=5, p=0.15, eta=100.0, Nc=5, syndromes=98304)
+        if args.criterion and args.ladder_steps == 10000:
+            args.ladder_steps = 65536
     if args.criterion:
         # N >= 8 ladders per lane of the persistent grid (256 CUs x 4 workgroups x 64 lanes at the config-2 shape); the horizon bounds the
         # log workspace (2 B per lane of the grid and ladder step) and censors a quarter of the L = 9, p = 0.15 ladders
         if args.syndromes is None:
-            args.syndromes = 8 * cfg["syndromes"]
+            # (the alpha route's ladders are short and heavy-tailed -- mean 13 000 steps, horizon 65 536 --: 16 per lane keep the tail of a
+            # workgroup's queue, the time its last ladders run alone, to a quarter of the launch)
+            args.syndromes = (16 if args.alpha_route else 8) * cfg["syndromes"]
         if args.ladder_steps == 10000:
             args.ladder_steps = 262144
         if args.steps == 5 and args.warmup == 1:      # (a launch runs for seconds: two timed ones, the first launch of the process among them)
@@ -353,7 +391,9 @@ def parse_args(argv=None):
     if args.scan == "auto":
         nq = (2 if args.code in ("toric", "planar") else 1) * args.L * args.L
         # scan = wave where same-box A/B runs have it ahead (profiles/r04_wave_ab.json): rung states of at most 16 words keep 8 waves per SIMD
-        args.scan = "wave" if (args.eta is None and args.Nc >= 2 and (nq + 15) // 16 <= 16 and args.iters <= 128 and args.syndromes % 64 == 0) else "random"
+        W = (nq + 15) // 16
+        ok = W <= 8 and args.Nc <= 8 and args.code in ("xzzx", "rotated") if args.alpha_route else (args.eta is None and W <= 16)
+        args.scan = "wave" if (ok and args.Nc >= 2 and args.iters <= 128 and args.syndromes % 64 == 0) else "random"
     return args
 
 
@@ -383,7 +423,7 @@ def main():
     first = rank * N                                    # global syndrome index of this shard
     proposals_per_pass = N * Nc * args.iters * args.ladder_steps      # per GPU
     workload = ("%s; %s L=%d p=%g%s, %d syndromes per GPU, Nc=%d parallel tempering, iters=%d, %d ladder steps per pass, scan=%s"
-                % (CONFIGS[args.config]["name"], args.code, L, args.p, "" if args.eta is None else " eta=%g" % args.eta, N, Nc,
+                % ("generate_data.py:142-150: biased noise decoded by PTEQ_alpha (pz_tilde=%.4g, alpha=%.4g)" % rule(args) if args.alpha_route else CONFIGS[args.config]["name"], args.code, L, args.p, "" if args.eta is None else " eta=%g" % args.eta, N, Nc,
                    args.iters, args.ladder_steps, {"random": "random (the reference's chain)", "wave": "wave (the reference's chain per syndrome; one generator pick per wavefront)", "sweep": "sweep"}[args.scan]))
 
     if args.dry_run:
@@ -424,10 +464,9 @@ def main():
     init_h = make_batch(args, rank)
     if args.criterion:
         return criterion_bench(args, L_, PteqShard, torch, dist, use_dist, world, rank, local_rank, dev, init_h, first, code_id, nq, ncls, n_gen, workload)
-    sh = PteqShard(init_h, args.p, first, n_total=N * world, code=code_id, Nc=Nc, p_logical=args.p_logical, iters=args.iters,
-                   steps=args.ladder_steps, tops_burn=2, seed=args.seed,
-                   noise=L_.NOISE_DEPOLARIZING if args.eta is None else L_.NOISE_BIASED, eta=args.eta or 0.0,
-                   scan=L_.SCANS[args.scan], flags=args.flags)
+    p_dec, rkw = lib_rule(args, L_)
+    sh = PteqShard(init_h, p_dec, first, n_total=N * world, code=code_id, Nc=Nc, p_logical=args.p_logical, iters=args.iters,
+                   steps=args.ladder_steps, tops_burn=2, seed=args.seed, scan=L_.SCANS[args.scan], flags=args.flags, **rkw)
     lds, threads, spb = C.c_uint32(), C.c_uint32(), C.c_uint32()
     L_.check(L_.lib().qecmc_plan_info(sh.plan, lds, threads, spb))
     stream = torch.cuda.current_stream()
@@ -534,8 +573,8 @@ def main():
                 # That second pass runs with tops_burn = 0 (every step is a sample), so that the class histogram itself is compared on
                 # every configuration: same trajectories, non-zero counts whatever the burn-in did.
                 import qecmc
-                again = qecmc.pteq_batch(init_h[:n_chk], args.p, Nc=Nc, steps=args.ladder_steps, iters=args.iters, tops_burn=0, seed=args.seed,
-                                         first_syndrome=first, code=code_id, eta=args.eta, return_states=True, flags=args.flags, scan=args.scan)
+                again = qecmc.pteq_batch(init_h[:n_chk], p_dec, Nc=Nc, steps=args.ladder_steps, iters=args.iters, tops_burn=0, seed=args.seed,
+                                         first_syndrome=first, code=code_id, return_states=True, flags=args.flags, scan=args.scan, **api_rule(args)[1])
                 ref0 = oracle_batch(args, init_h[:n_chk], args.ladder_steps, os.cpu_count() or 1, tops_burn=0)
                 hist0 = bool(np.array_equal(again["counts"], ref0["counts"]) and int(again["counts"].sum()) == n_chk * args.ladder_steps)
                 out["histogram_match"] = {"syndromes_checked": n_chk, "ladder_steps": args.ladder_steps,
@@ -549,8 +588,8 @@ def main():
                                                         np.array_equal(again["states"], ref["states"]))}
         if world == 1 and args.scan == "wave":
             # the same batch through the scan = 0 kernel (the chain pinned draw for draw to the reference's injected-stream fixtures), for the record
-            pr0 = L_.make_params(code=code_id, L=L, Nc=Nc, p=args.p, p_logical=args.p_logical, iters=args.iters, steps=args.ladder_steps, tops_burn=2,
-                                 seed=args.seed, device=local_rank, scan=L_.SCAN_RANDOM, flags=args.flags)
+            pr0 = L_.make_params(code=code_id, L=L, Nc=Nc, p=p_dec, p_logical=args.p_logical, iters=args.iters, steps=args.ladder_steps, tops_burn=2,
+                                 seed=args.seed, device=local_rank, scan=L_.SCAN_RANDOM, flags=args.flags, **rkw)
             plan0 = C.c_void_p()
             L_.check(L_.lib().qecmc_plan_create(pr0, C.byref(plan0)))
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -281,10 +281,11 @@ template <int WV, int w> __device__ __forceinline__ void wu_count_x(typename WuV
 #undef M
 }
 // the state's counts, packed n_x | n_z << 10 | (n_x + n_y) << 20
-template <int WV> __device__ __forceinline__ uint32_t wu_counts_packed(typename WuVec<WV>::type &st, uint32_t m55)
+// (W: the words in use -- wave-uniform; the padding words of a WV-word kernel are zero and need not be looked at)
+template <int WV> __device__ __forceinline__ uint32_t wu_counts_packed(typename WuVec<WV>::type &st, uint32_t m55, int W = WV)
 {
     uint32_t nx = 0, nz = 0, nxy = 0;
-#define QECMC_WU_C3(w) if constexpr (w < WV) wu_count3<WV, w>(st, nx, nz, nxy, m55);
+#define QECMC_WU_C3(w) if constexpr (w < WV) { if (w < wu_words_min(WV) || w < W) wu_count3<WV, w>(st, nx, nz, nxy, m55); }
     WU_EACH(QECMC_WU_C3)
 #undef QECMC_WU_C3
     return nx | (nz << 10) | (nxy << 20);
@@ -296,7 +297,7 @@ __device__ __forceinline__ double wu_neff(uint32_t rec, double alpha)
     return (double)(rec & 0xFFFFu) + alpha * (double)(rec >> 16);
 }
 // Ladder_alpha.r_flip (mcmc_alpha.py:118-123) on the slots' attributes: u < (pz_lo / pz_hi) ** (n_eff_hi - n_eff_lo), the power as
-// det_exp(e ln b) like the oracle -- behind a single-precision estimate of 2^32 times it that settles all but ~6e-5 of the tests
+// det_exp(e ln b) like the CPU oracle -- behind a single-precision estimate of 2^32 times it that settles all but ~6e-5 of the tests
 // (the estimate's relative error stays below 5e-6: the exponent is rounded to a float of magnitude <= 32 wherever the outcome is open)
 __device__ __forceinline__ bool wu_alpha_flip(uint32_t x, double ne_hi, double ne_lo, double lnb)
 {
@@ -449,7 +450,7 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
         [[maybe_unused]] uint32_t maskv = 0, cdelta = 0;                           // top rung: the step's frame of logical operators (lane w: word w), class change
         const uint32_t pbase = ws * iters;                                         // the step's first proposal within the window
         [[maybe_unused]] WuAl al{0u, 0u, 0u};
-        if constexpr (ALPHA && !top) al.Nb = wu_counts_packed<WV>(st, m55);        // p_b's counts (mcmc_alpha.py:38-41)
+        if constexpr (ALPHA && !top) al.Nb = wu_counts_packed<WV>(st, m55, a.W);   // p_b's counts (mcmc_alpha.py:38-41)
         for (uint32_t c = 0; c < nch; ++c) {
             [[maybe_unused]] u32x4 ab{0, 0, 0, 0};                                 // this ladder's block of ten 12-bit acceptance uniforms
             if (!top) ab = wu_philox(T * nch + c, kSubWuAcc, syn, slot, a.seed_lo, a.seed_hi);

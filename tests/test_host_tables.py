@@ -205,6 +205,7 @@ def test_wave_descriptors_are_the_oracles_stencil(T, code, L):
             wi, sh = int(e[i]) & 0xFF, (int(e[i]) >> 8) & 31
             assert wi < W
             sel |= ((int(words[wi]) >> sh) & 0xFF) << (8 * i)              # v_lshrrev_b32_sdwa: a byte, junk above the field
+        sel0 = sel
         sel = (sel & int(e[11])) | int(e[10]) if code != TORIC else sel & 0x03030303
         tab = int(e[8]).to_bytes(4, "little") + int(e[9]).to_bytes(4, "little")   # v_perm_b32: selectors 0-3 -> dword 8, 4-7 -> dword 9
         if code == TORIC:
@@ -219,6 +220,17 @@ def test_wave_descriptors_are_the_oracles_stencil(T, code, L):
             ref, dE = orc.surf_apply_stabilizer(ORC_CODE[code], m, *orc.surf_gen_rco(ORC_CODE[code], L, int(g)))
         assert np.array_equal(new, ref)
         assert dE4 == 4 * (dE + 4)
+        # dwords 12-15, the alpha rule: the same selector with the missing sites' bytes 0x0C (the constant 0), the byte tables of
+        # 4 ((dz + 1) + 9 (dxy + 1)); their sum + dword 15 = the byte offset of (D_xy, D_z) in the kernel's 9 x 9 table
+        sel_a = (sel0 & int(e[11])) | int(e[14])
+        tab_a = int(e[12]).to_bytes(4, "little") + int(e[13]).to_bytes(4, "little")
+        off = int(e[15])
+        for i in range(4):
+            b = (sel_a >> (8 * i)) & 0xFF
+            off += 0 if b == 0x0C else tab_a[b]
+        dz = int(np.sum(ref == 3)) - int(np.sum(m == 3))
+        dxy = int(np.sum((ref == 1) | (ref == 2))) - int(np.sum((m == 1) | (m == 2)))
+        assert off == 4 * ((dz + 4) + 9 * (dxy + 4))
 
 
 def test_host_tables_under_asan_ubsan():

@@ -16,10 +16,11 @@ CODES = ["toric", "xzzx", "rotated", "planar"]
 
 def kernel_label(mangled):
     """ladder_kernel<MAXT, MINW, CODE, FLAGS> -> 'ladder<512,8,toric: gsplit|delut|ssw>'; other kernels by name."""
-    w = re.search(r"ladder_wu_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELb([01])ELi(\d+)E", mangled)
-    if w:   # ladder_wu_kernel<MAXT, MINW, CODE, WV, CONV, QUEUE, IT> -> 'wave<512,8,toric: 12 words, conv, queue, iters 10>'
-        maxt, minw, code, wv, conv, queue, it = (int(x) for x in w.groups())
-        return "wave<%d,%d,%s: %d words%s%s%s>" % (maxt, minw, CODES[code], wv, ", conv" if conv else "", ", queue" if queue else "", ", iters %d" % it if it else "")
+    w = re.search(r"ladder_wu_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELb([01])ELi(\d+)ELb([01])E", mangled)
+    if w:   # ladder_wu_kernel<MAXT, MINW, CODE, WV, CONV, QUEUE, IT, ALPHA> -> 'wave<512,8,toric: 12 words, conv, queue, iters 10>'
+        maxt, minw, code, wv, conv, queue, it, alpha = (int(x) for x in w.groups())
+        return "wave<%d,%d,%s: %d words%s%s%s%s>" % (maxt, minw, CODES[code], wv, ", conv" if conv else "", ", queue" if queue else "", ", alpha" if alpha else "",
+                                                   ", iters %d" % it if it else "")
     m = re.search(r"ladder_kernelILi(\d+)ELi(\d+)ELi(\d+)ELj(\d+)E", mangled)
     if not m:
         m2 = re.match(r"_ZN5qecmc\d+([A-Za-z_0-9]+?)(?:I|E)", mangled)

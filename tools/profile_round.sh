@@ -25,10 +25,10 @@ sys.path.insert(0, ".")
 import bench
 a = bench.parse_args(sys.argv[1:])
 # the DOMINANT ladder kernel of the run (bench.py also launches companions: the scan = 0 kernel beside a scan = wave headline, the
-# fixed-length kernel beside a criterion run): the one the kernel trace gives the largest total time
+# fixed-length kernel beside a criterion run): the one of the line's own scan that the kernel trace gives the largest total time
 dominant = None
 for r in csv.DictReader(open(out + "/kernel_stats.csv")):
-    if 'ladder' in r['Name'] and (dominant is None or float(r['TotalDurationNs']) > dominant[1]):
+    if ('ladder_wu_kernel' if a.scan == "wave" else 'ladder') in r['Name'] and (dominant is None or float(r['TotalDurationNs']) > dominant[1]):
         dominant = (r['Name'], float(r['TotalDurationNs']))
 acc = collections.defaultdict(list)
 meta = {}
@@ -40,7 +40,7 @@ for f in glob.glob(out + "/pmc_*/*/*_counter_collection.csv"):
 summ = {k: sum(v) / len(v) for k, v in acc.items()}
 summ['_launches_averaged'] = {k: len(v) for k, v in acc.items()}
 summ['_kernel'] = meta
-summ['_workload'] = {k: getattr(a, k) for k in ("code", "L", "p", "eta", "Nc", "iters", "syndromes", "ladder_steps", "p_logical", "scan", "criterion")}
+summ['_workload'] = {k: getattr(a, k) for k in ("code", "L", "p", "eta", "Nc", "iters", "syndromes", "ladder_steps", "p_logical", "scan", "criterion", "alpha_route")}
 json.dump(summ, open(out + "/pmc_summary.json", "w"), indent=1, sort_keys=True)
 print(json.dumps(summ, sort_keys=True)[:1500])
 PY
