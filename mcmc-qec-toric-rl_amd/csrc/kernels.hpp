@@ -146,6 +146,7 @@ hipError_t launch_ladder_rs_toric(const LadderArgs &a, hipStream_t stream);
 // scan = 3 (ladder_wu.hip): what it is built for, and the LDS of one workgroup
 bool wu_supported(const LadderArgs &a);
 size_t wu_lds_bytes(int Nc, int W, int ncls, int L, bool conv, bool alpha);
+constexpr int kWuAlphaQueueWaves = 6;   // waves per SIMD the alpha rule's criterion kernels of scan = 3 are built for (ladder_wu.hpp wu_pick_alpha): sizes their persistent grid
 
 // byte-state primitive kernels (primitives.hip); all pointers are device pointers
 hipError_t launch_apply_stabilizer(int code, int L, uint64_t N, const uint8_t *in, uint8_t *out, const int32_t *rows,

@@ -990,8 +990,13 @@ template <int CODE, int IT>
 inline const void *wu_pick_alpha(int variant, int Nc, int W)
 {
     if (W > 8 || Nc * 64 > 512 || (variant != 0 && variant != 2)) return nullptr;
+    // (the criterion kernels of the alpha rule at 6 waves per SIMD -- 80 VGPRs, 102 SGPRs --: 96-120 B of scratch reloaded every step at 8, 28-40 B at 6,
+    // and 4 % faster on the PTEQ_alpha route, same-box A/B; kWuAlphaQueueWaves tells the plan how many workgroups a CU then holds)
+#ifndef QECMC_WU_ALPHA_CONV_MINW
+#define QECMC_WU_ALPHA_CONV_MINW kWuAlphaQueueWaves
+#endif
     if (variant == 2)
-        return W <= 4 ? (const void *)ladder_wu_kernel<512, 8, CODE, 4, true, true, IT, true> : (const void *)ladder_wu_kernel<512, 8, CODE, 8, true, true, IT, true>;
+        return W <= 4 ? (const void *)ladder_wu_kernel<512, QECMC_WU_ALPHA_CONV_MINW, CODE, 4, true, true, IT, true> : (const void *)ladder_wu_kernel<512, QECMC_WU_ALPHA_CONV_MINW, CODE, 8, true, true, IT, true>;
     return W <= 4 ? (const void *)ladder_wu_kernel<512, 8, CODE, 4, false, false, IT, true> : (const void *)ladder_wu_kernel<512, 8, CODE, 8, false, false, IT, true>;
 }
 

@@ -105,7 +105,10 @@ def test_harness_generate_decodes_low_noise(q, tmp_path):
                        ({"code": "planar", "size": 5, "p_error": 0.03, "noise": "depolarizing"},
                         dict(steps=3000, conv_criteria=None, tops_burn=0)),
                        ({"code": "rotated", "size": 5, "p_error": 0.04, "noise": "alpha", "alpha": 2.0},
-                        dict(steps=200000))):                                   # PTEQ_alpha's default error_based criterion
+                        dict(steps=200000)),                                    # PTEQ_alpha's default error_based criterion
+                       ({"code": "xzzx", "size": 5, "p_error": 0.05, "noise": "biased", "eta": 10},
+                        dict(steps=200000, scan="wave")),                       # ... on the scan = wave kernels and their work queue
+                       ({"code": "toric", "size": 5, "p_error": 0.08, "noise": "depolarizing"}, dict(steps=200000, scan="wave"))):
         f = tmp_path / (params["code"] + ".npz")
         out = harness.generate(params, 256, seed=3, file_path=str(f), **kw)
         assert out["distr"].shape == (256, 16 if params["code"] == "toric" else 4)
@@ -227,6 +230,30 @@ def test_biased_ladder_exact_L3_iters1(q, name, seed, p, eta):
     mean, sem = _class_fractions(res, ok)
     assert np.all(np.abs(mean - P) <= 5 * sem + 2e-4), (mean, P, sem)
     assert mean.argmax() == P.argmax()
+
+
+@pytest.mark.parametrize("name,L,seed,pzt,alpha,Nc", [("xzzx", 3, 41, 0.30, 2.0, 3), ("rotated", 3, 42, 0.25, 3.0, 4), ("xzzx", 5, 43, 0.175, 4.04, 5)])
+def test_alpha_ladder_wave_scan_has_the_random_scans_law(q, name, L, seed, pzt, alpha, Nc):
+    """Ladder_alpha has no closed-form law to pin (its swap test reads attributes that lag behind the codes, Q4), but whatever law the
+    reference's chain has, scan = wave has it per syndrome: the pick is independent of the state, so sharing it among the ladders of a
+    wavefront changes no ladder's transition kernel.  4 096 replicas of one syndrome under both scans: class fractions and the bottom rung's
+    mean n_z, n_x + n_y agree within Monte-Carlo error (wave: the error over the 64 wavefront means)."""
+    code = {"xzzx": q.XZZX, "rotated": q.ROTATED}[name]
+    init = _rand_surf(seed, L, 0.2)
+    R, steps = 4096, 3000
+    out = {}
+    for scan in ("random", "wave"):
+        res = q.pteq_batch(np.broadcast_to(init, (R,) + init.shape).copy(), pzt, Nc=Nc, steps=steps, iters=10, tops_burn=5, seed=5000 + seed, code=code,
+                           alpha=alpha, scan=scan, return_states=True)
+        ok = res["samples"] > steps // 2
+        assert ok.mean() > 0.9
+        frac = res["counts"] / np.maximum(res["samples"], 1)[:, None].astype(np.float64)
+        bottom = res["states"][:, 0].reshape(R, -1)
+        obs = np.concatenate([frac, (bottom == 3).sum(1, keepdims=True), ((bottom == 1) | (bottom == 2)).sum(1, keepdims=True)], axis=1)
+        out[scan] = _mean_sem(obs, ok, scan)
+    (m0, s0), (m1, s1) = out["random"], out["wave"]
+    assert np.all(np.abs(m0 - m1) <= 5 * np.sqrt(s0 ** 2 + s1 ** 2) + 2e-4), (m0, m1, s0, s1)
+    assert m0[:4].argmax() == m1[:4].argmax()
 
 
 @pytest.mark.parametrize("name,seed,p,eta", [("xzzx", 31, 0.25, 3.0), ("rotated", 32, 0.30, 10.0)])

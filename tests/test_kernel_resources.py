@@ -71,11 +71,11 @@ ALLOWED_SCRATCH = {
     # proposal loop itself reads no scratch (`hipcc -S`: 14 scratch instructions, none between the step's first proposal and its first barrier)
     "wave<512,8,xzzx: 4 words, alpha, iters 10>": 48, "wave<512,8,xzzx: 8 words, alpha, iters 10>": 84,
     "wave<512,8,rotated: 4 words, alpha, iters 10>": 48, "wave<512,8,rotated: 8 words, alpha, iters 10>": 84,
-    "wave<512,8,xzzx: 4 words, conv, queue, alpha, iters 10>": 96, "wave<512,8,xzzx: 8 words, conv, queue, alpha, iters 10>": 120,
-    "wave<512,8,rotated: 4 words, conv, queue, alpha, iters 10>": 96, "wave<512,8,rotated: 8 words, conv, queue, alpha, iters 10>": 120,
+    "wave<512,6,xzzx: 4 words, conv, queue, alpha, iters 10>": 28, "wave<512,6,xzzx: 8 words, conv, queue, alpha, iters 10>": 40,
+    "wave<512,6,rotated: 4 words, conv, queue, alpha, iters 10>": 28, "wave<512,6,rotated: 8 words, conv, queue, alpha, iters 10>": 44,
     "wave<512,8,xzzx: 4 words, alpha>": 84, "wave<512,8,xzzx: 8 words, alpha>": 144, "wave<512,8,rotated: 4 words, alpha>": 84, "wave<512,8,rotated: 8 words, alpha>": 144,
-    "wave<512,8,xzzx: 4 words, conv, queue, alpha>": 116, "wave<512,8,xzzx: 8 words, conv, queue, alpha>": 220,
-    "wave<512,8,rotated: 4 words, conv, queue, alpha>": 116, "wave<512,8,rotated: 8 words, conv, queue, alpha>": 220,
+    "wave<512,6,xzzx: 4 words, conv, queue, alpha>": 32, "wave<512,6,xzzx: 8 words, conv, queue, alpha>": 76,
+    "wave<512,6,rotated: 4 words, conv, queue, alpha>": 32, "wave<512,6,rotated: 8 words, conv, queue, alpha>": 76,
 }
 # the kernels BASELINE configurations 2-5 launch at their bench shapes (bench.py --config N): never on the list
 BASELINE_KERNELS = ["wave<512,8,toric: 12 words, iters 10>", "ladder<512,8,toric: gsplit|delut|ssw>", "ladder<512,4,toric: pre|delut>", "ladder<512,8,xzzx: biased|gentop|ssw>",

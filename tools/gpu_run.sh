@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 b() {  # b <tag> <bench args...>: one bench line, condensed
     tag=$1; shift
     timeout -k 10 300 python bench.py --no-cpu-baseline --steps 3 "$@" 2> gpurun_out/bench_$tag.err | tee gpurun_out/bench_$tag.json | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('$tag', '%.3e prop/s' % d['proposals_per_s'], 'frac %.3f' % d['roofline']['frac'], '%.2f ms' % d['kernel_ms_per_launch'], 'lds', d['config']['lds_bytes_per_workgroup'])"
+import json,sys; d=json.loads(sys.stdin.read()); print('$tag', '%.3e prop/s' % d.get('proposals_per_s', d.get('useful_proposals_per_s', 0.0)), 'frac %.3f' % d['roofline']['frac'], '%.2f ms' % d['kernel_ms_per_launch'], 'lds', d['config']['lds_bytes_per_workgroup'])"
 }
 case "$1" in
   wave-first)   # first contact of the scan = wave kernel: its parity tests, then A/B against the random scan on the headline shape
