@@ -956,7 +956,10 @@ inline const void *wu_pick_it(int Nc, int W)
 {
     const bool big = Nc * 64 > 512;
 #ifdef QECMC_WU_DEV     // development builds: the headline shape only
-    return (!big && W > 8 && W <= 12) ? (const void *)ladder_wu_kernel<512, 8, CODE, 12, CONV, QUEUE, IT> : nullptr;
+#ifndef QECMC_WU_DEV_QUEUE_MINW
+#define QECMC_WU_DEV_QUEUE_MINW 8
+#endif
+    return (!big && W > 8 && W <= 12) ? (const void *)ladder_wu_kernel<512, (QUEUE ? QECMC_WU_DEV_QUEUE_MINW : 8), CODE, 12, CONV, QUEUE, IT> : nullptr;
 #else
     if constexpr (IT == 10) {
         if (big) return nullptr;

@@ -36,6 +36,10 @@ def draw_case(rng):
         noise = rng.choice(["biased", "alpha"])
     u = rng.random()
     scan = "random" if noise != "depolarizing" else "sweep" if u < 0.15 else "colour" if (u < 0.3 and Nc >= 2) else "random"
+    # (round 4) scan = wave where it is built: the depolarizing rule up to 16 state words per rung, the alpha rule up to 8 words and 8 rungs
+    W = (nq + 15) // 16
+    if Nc >= 2 and ((noise == "depolarizing" and W <= 16) or (noise == "alpha" and W <= 8 and Nc <= 8)) and rng.random() < (0.6 if noise == "alpha" else 0.3):
+        scan = "wave"
     conv = rng.random() < 0.3                             # (round 3: the alpha rule's criterion runs take the work queue too)
     iters = int(rng.choice([1, 2, 3, 5, 7, 8, 10, 10, 10, 12, 13, 25]))
     work = Nc * iters * nq                                                 # ~ oracle cost per ladder step (the stencil copies nq bytes)
@@ -52,7 +56,7 @@ def draw_case(rng):
     if R > 1:
         N = max(1, N // R)
     return dict(code=code, L=L, Nc=Nc, noise=noise, scan=scan, conv=conv, iters=iters, steps=steps, N=N, p=p, grid=grid, chunks=bool(chunks), R=R,
-                tops_burn=int(rng.choice([0, 1, 2])), seed=int(rng.integers(1, 1 << 30)), first=int(rng.integers(0, 1000)),
+                tops_burn=int(rng.choice([0, 1, 2])), seed=int(rng.integers(1, 1 << 30)), first=int(rng.integers(0, 1000)) * (64 if scan == "wave" else 1),
                 eta=float(rng.choice([3.0, 10.0, 100.0])), alpha=float(rng.choice([1.3, 2.0, 3.1])))
 
 
@@ -70,7 +74,7 @@ def run_case(c, rng):
     if c["conv"]:
         kw.update(conv_criteria="error_based", SEQ=1, TOPS=3, eps=0.6)
     gk = dict(kw, code=qcode, Nc=c["Nc"], scan=c["scan"], return_states=not c["conv"])
-    ok = dict(kw, return_states=not c["conv"], scan={"random": 0, "sweep": 1, "colour": 2}[c["scan"]])
+    ok = dict(kw, return_states=not c["conv"], scan={"random": 0, "sweep": 1, "colour": 2, "wave": 3}[c["scan"]])
     p = c["p"]
     if c["noise"] == "biased":
         gk["eta"] = c["eta"]; ok.update(noise=orc.BIASED, eta=c["eta"])
@@ -92,7 +96,14 @@ def run_case(c, rng):
         run.close()
     else:
         got = q.pteq_batch(init, p, **gk, **({"replicas": c["R"]} if c["R"] > 1 else {}))
-    ref = orc.pteq_batch(ocode, np.repeat(init, c["R"], axis=0), p, c["Nc"], steps, **ok)
+    if c["scan"] == "wave" and c["conv"]:
+        # the criterion runs of scan = wave take the deterministic per-workgroup queue: the oracle's restatement of it, on the grid the launch uses
+        groups = (c["N"] + 63) // 64
+        g_eff = max(1, min(int(c["grid"]) if c["grid"] else groups, groups))
+        wk = {k: v for k, v in ok.items() if k not in ("return_states", "scan", "conv_criteria")}
+        ref = orc.pteq_wave_queue(ocode, init, p, c["Nc"], steps, g_eff, **wk)
+    else:
+        ref = orc.pteq_batch(ocode, np.repeat(init, c["R"], axis=0), p, c["Nc"], steps, **ok)
     if c["R"] > 1:                                                          # ladder l = s R + r: Philox index first + l, summed per syndrome
         ncls = ref["counts"].shape[1]
         ref = dict(ref, counts=ref["counts"].reshape(c["N"], c["R"], ncls).sum(axis=1), samples=ref["samples"].reshape(c["N"], c["R"]).sum(axis=1),
