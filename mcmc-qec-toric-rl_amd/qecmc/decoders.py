@@ -82,15 +82,20 @@ def pteq_batch(init, p, Nc=None, steps=1000, iters=10, tops_burn=2, p_logical=0.
 # gives a lower-variance estimate (summed class counts; `converged` then means all 64 have converged, so the run ends with the
 # slowest of them): opt in per call (replicas=64) or for a whole script (decoders.PTEQ_REPLICAS = 64).
 PTEQ_REPLICAS = 1
+# The criterion runs of the one-syndrome drop-ins: first horizon (ladder steps) and its growth when a ladder outlasts it (see _pteq)
+PTEQ_FIRST_HORIZON = 1 << 20
+PTEQ_HORIZON_GROWTH = 16
+LAST_RUN = {}
 
 
 def PTEQ(init_code, p, Nc=None, SEQ=2, TOPS=10, tops_burn=2, eps=0.1, steps=50000000, iters=10,
          conv_criteria='error_based', seed=None, replicas=None, scan="random"):
     """Drop-in for decoders.PTEQ (decoders.py:25): same arguments, returns the uint8 percent vector of
-    the equivalence classes.  With the convergence criterion the run is issued with a growing horizon (65 536
-    ladder steps, x4 until it converges or `steps` is reached) so that the default `steps = 5e7` never allocates
+    the equivalence classes.  With the convergence criterion the run is issued with a growing horizon (2^20
+    ladder steps, x16 until it converges or `steps` is reached) so that the default `steps = 5e7` never allocates
     a 5e7-entry error-count log up front.  Philox is counter-based, so a longer horizon replays the same
-    trajectory: the answer equals that of a single run with the full `steps`.
+    trajectory: the answer equals that of a single run with the full `steps`; a ladder that stops within the first
+    horizon -- every default-criterion run measured -- is one launch with no repeated step (decoders.LAST_RUN).
 
     The reference decodes ONE syndrome per call (generate_data.py:136) with one ladder, which occupies one lane of each of the
     Nc wavefronts; that is the default here too (PTEQ_REPLICAS = 1).  `replicas=R` runs R independent ladders -- each with the
@@ -129,13 +134,21 @@ def _pteq(init_code, p, eta, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, conv_c
               code=_code_id(init_code), eta=eta, alpha=alpha, replicas=PTEQ_REPLICAS if replicas is None else int(replicas), scan=scan)
     if conv_criteria is None:
         return pteq_batch(init_code.qubit_matrix, p, steps=steps, **kw)["percent"][0]
-    horizon = min(int(steps), 1 << 16)
+    # The horizon only sizes the error-count log (2 B -- alpha rule 4 B -- per ladder and step of it; a converged ladder ends its launch at
+    # once), so it starts at 2^20 steps -- beyond where the reference's defaults stop at every lattice size measured (L = 9: 3e4 ... 3.4e5
+    # steps, profiles/r03_latency.json) -- and grows x16: a run that does outlast it replays at most 1/15 of its steps (round 3: 65 536 and
+    # x4, up to a third).  LAST_RUN tells what happened.
+    horizon = min(int(steps), PTEQ_FIRST_HORIZON)
+    launches = replayed = 0
     while True:
         res = pteq_batch(init_code.qubit_matrix, p, steps=horizon, conv_criteria=conv_criteria, SEQ=SEQ, TOPS=TOPS,
                          eps=eps, **kw)
+        launches += 1
         if res["converged"][0] or horizon >= int(steps):
             break
-        horizon = min(int(steps), horizon * 4)
+        replayed += horizon
+        horizon = min(int(steps), horizon * PTEQ_HORIZON_GROWTH)
+    LAST_RUN.update(launches=launches, horizon=horizon, steps_done=int(res["steps_done"][0]), replayed_steps=replayed)
     if not res["converged"][0]:
         print('\n\nWARNING: PTEQ hit max number of steps before convergence:\t', horizon, '\n\n')
     return res["percent"][0]

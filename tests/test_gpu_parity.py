@@ -269,6 +269,18 @@ def test_pteq_dropin_default_criterion(q, orc):
     assert ref["converged"][0]
     exp = (np.divide(ref["counts"][0], ref["samples"][0]) * 100).astype(np.uint8)
     assert np.array_equal(pct, exp) and 96 <= int(pct.sum()) <= 100
+    # one launch, no step run twice: the ladder stopped inside the first horizon
+    from qecmc import decoders
+    assert decoders.LAST_RUN["launches"] == 1 and decoders.LAST_RUN["replayed_steps"] == 0 and decoders.LAST_RUN["steps_done"] == int(ref["steps_done"][0])
+    # ... and a ladder that outlasts a (shrunk) first horizon gives the same answer through the growing horizons, replaying at most 1/15
+    old = decoders.PTEQ_FIRST_HORIZON
+    try:
+        decoders.PTEQ_FIRST_HORIZON = max(16, int(ref["steps_done"][0]) // 40)
+        pct2 = q.PTEQ(code, 0.1, seed=5, replicas=1)
+    finally:
+        decoders.PTEQ_FIRST_HORIZON = old
+    assert np.array_equal(pct2, exp) and decoders.LAST_RUN["launches"] >= 2
+    assert decoders.LAST_RUN["replayed_steps"] < decoders.LAST_RUN["horizon"] / 14
 
 
 # ------------------------------------------------------------------ scan = sweep (systematic generator sweep)
