@@ -7,8 +7,8 @@ size_t wu_lds_bytes(int Nc, int W, int ncls, int L, bool conv, bool alpha) { ret
 
 // the shapes scan = 3 is built for: depolarizing rule, a ladder whose top rung accepts every move (Nc >= 2, p_top = 0.75), up to
 // 16 state words per ladder rung (toric / planar L <= 11, xzzx / rotated L <= 16: where the states fit the registers of 8 waves per
-// SIMD -- beyond that the scan = 0 kernels are as fast, profiles/r04_wave_ab.json), 1 <= iters <= 128, rungs at distinct temperatures
-// (32-bit swap thresholds)
+// SIMD), fixed-length runs of up to 8 rungs also up to 32 words (toric L <= 16, xzzx / rotated L <= 22: 6 waves per SIMD, the exchange in two
+// halves), 1 <= iters <= 128, rungs at distinct temperatures (32-bit swap thresholds)
 // ... and the alpha noise model's ladder (noise = 2, whose top rung sits at pz_tilde = 1 and accepts every move) on the xzzx / rotated codes up to
 // 8 state words and 8 rungs, where the plan allows the single-precision estimate of the acceptance ratio on every rung below the top
 bool wu_supported(const LadderArgs &a)
@@ -19,7 +19,7 @@ bool wu_supported(const LadderArgs &a)
                a.uset_tab == nullptr && a.swap_acc == nullptr && !a.resume && a.neff == nullptr &&
                wu_lds_bytes(a.Nc, a.W, a.ncls, a.L, a.conv_mode != 0, true) <= 160 * 1024;
     return a.noise == 0 && a.Nc >= 2 && ((a.acc_all_mask >> (a.Nc - 1)) & 1u) && !(a.acc_all_mask & ((1u << (a.Nc - 1)) - 1u)) &&
-           a.W <= 16 && a.n_gen <= 1023u && a.iters >= 1u && a.iters <= 128u && a.swap_fast_ok != 0 &&
+           (a.W <= 16 || (a.W <= 32 && a.conv_mode == 0 && a.Nc <= 8 && a.code != kCodePlanar)) && a.n_gen <= 1023u && a.iters >= 1u && a.iters <= 128u && a.swap_fast_ok != 0 &&
            a.uset_tab == nullptr && a.swap_acc == nullptr && wu_lds_bytes(a.Nc, a.W, a.ncls, a.L, a.conv_mode != 0, false) <= 160 * 1024;
 }
 

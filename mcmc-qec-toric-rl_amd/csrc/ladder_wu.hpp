@@ -42,16 +42,20 @@ template <> struct WuVec<4> { typedef uint32_t type __attribute__((ext_vector_ty
 template <> struct WuVec<8> { typedef uint32_t type __attribute__((ext_vector_type(8))); };
 template <> struct WuVec<12> { typedef uint32_t type __attribute__((ext_vector_type(12))); };
 template <> struct WuVec<16> { typedef uint32_t type __attribute__((ext_vector_type(16))); };
+template <> struct WuVec<32> { typedef uint32_t type __attribute__((ext_vector_type(32))); };
 
 // The state registers are PINNED (the index mode addresses v[base + M0]) -- WV dwords ending at v63 (64-VGPR kernels) or at v127 --
 // and every access to them is an asm statement that names the pinned tuple as an operand: the compiler then keeps the value where
 // it is (any C++-level element access makes it a value of its own that is copied in and out of the pinned registers around every
 // statement).  An "i" operand gives the register number of a static element, v[%c[r]].
-template <int WV> constexpr int wu_base() { return 64 - WV; }
+// (32 words -- toric L <= 16, the one-layer codes L <= 22 --: v48 .. v79 of an 80-VGPR kernel, 6 waves per SIMD)
+template <int WV> constexpr int wu_base() { return WV == 32 ? 48 : 64 - WV; }
 #define WU_BY_WV(M)                                                                                                            \
     if constexpr (WV == 4) { M("{v[60:63]}") } else if constexpr (WV == 8) { M("{v[56:63]}") }                                 \
-    else if constexpr (WV == 12) { M("{v[52:63]}") } else { static_assert(WV == 16, "state widths: 4, 8, 12, 16 words"); M("{v[48:63]}") }
-#define WU_EACH(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
+    else if constexpr (WV == 12) { M("{v[52:63]}") } else if constexpr (WV == 16) { M("{v[48:63]}") }                          \
+    else { static_assert(WV == 32, "state widths: 4, 8, 12, 16, 32 words"); M("{v[48:79]}") }
+#define WU_EACH(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) \
+                   M(16) M(17) M(18) M(19) M(20) M(21) M(22) M(23) M(24) M(25) M(26) M(27) M(28) M(29) M(30) M(31)
 
 template <int WV> __device__ __forceinline__ void wu_def(typename WuVec<WV>::type &st)
 {
@@ -92,15 +96,17 @@ template <int WV, int w> __device__ __forceinline__ void wu_count(typename WuVec
     WU_BY_WV(M)
 #undef M
 }
-template <int WV, int w> __device__ __forceinline__ void wu_ds_write(typename WuVec<WV>::type &st, uint32_t addr)
+// (row: the word's row of the rung's region in the exchange buffer -- w itself, or w - 16 for the upper half of a 32-word state, which
+// passes through the buffer in two halves)
+template <int WV, int w, int row = w> __device__ __forceinline__ void wu_ds_write(typename WuVec<WV>::type &st, uint32_t addr)
 {
-#define M(PIN) asm volatile("ds_write_b32 %[a], v[%c[r]] offset:%c[o]" : "+" PIN(st) : [a] "v"(addr), [r] "i"(wu_base<WV>() + w), [o] "i"(w * 256) : "memory");
+#define M(PIN) asm volatile("ds_write_b32 %[a], v[%c[r]] offset:%c[o]" : "+" PIN(st) : [a] "v"(addr), [r] "i"(wu_base<WV>() + w), [o] "i"(row * 256) : "memory");
     WU_BY_WV(M)
 #undef M
 }
-template <int WV, int w> __device__ __forceinline__ void wu_ds_read(typename WuVec<WV>::type &st, uint32_t addr)
+template <int WV, int w, int row = w> __device__ __forceinline__ void wu_ds_read(typename WuVec<WV>::type &st, uint32_t addr)
 {
-#define M(PIN) asm volatile("ds_read_b32 v[%c[r]], %[a] offset:%c[o]" : "+" PIN(st) : [a] "v"(addr), [r] "i"(wu_base<WV>() + w), [o] "i"(w * 256) : "memory");
+#define M(PIN) asm volatile("ds_read_b32 v[%c[r]], %[a] offset:%c[o]" : "+" PIN(st) : [a] "v"(addr), [r] "i"(wu_base<WV>() + w), [o] "i"(row * 256) : "memory");
     WU_BY_WV(M)
 #undef M
 }
@@ -161,8 +167,10 @@ struct WuLds { int xbuf, rec, swd, hist, thr, swapT, lml, stop, bk, mail, bot, c
 constexpr int kWuBk = 13;      // tops0, samples, burn, conv_start, conv_streak, sumA lo / hi, sumB lo / hi, state (done | pending << 1 | has << 3),
                                // steps_done, converged, the lane's ladder (QUEUE)
 constexpr int kWuBkAlpha = 17; // ... and the alpha rule's second pair of window sums (n_x + n_y): sumAxy lo / hi, sumBxy lo / hi
-__host__ __device__ inline int wu_words(int W) { return W <= 4 ? 4 : W <= 8 ? 8 : W <= 12 ? 12 : 16; }   // WV: state words per rung, padded
-__host__ __device__ inline int wu_words_min(int WV) { return WV == 4 ? 1 : WV - 3; }                     // the narrowest W a WV-word kernel serves
+__host__ __device__ inline int wu_words(int W) { return W <= 4 ? 4 : W <= 8 ? 8 : W <= 12 ? 12 : W <= 16 ? 16 : 32; }   // WV: state words per rung, padded
+__host__ __device__ inline int wu_words_min(int WV) { return WV == 4 ? 1 : WV == 32 ? 17 : WV - 3; }      // the narrowest W a WV-word kernel serves
+constexpr int kWuHalf = 16;                                                                               // rows per rung of a 32-word kernel's exchange buffer
+__host__ __device__ inline int wu_rows(int W) { return W > 16 ? kWuHalf : W; }                            // rows per rung of the exchange buffer
 // (alpha rule: the 9 x 9 table of a proposal's count change as two fp16 numbers, the slots' n_eff attributes as doubles [Nc][64], ln(pz_i / pz_i+1),
 // and -- criterion runs -- slot 0's n_eff record by step parity)
 __host__ __device__ inline WuLds wu_lds(int Nc, int W, int ncls, int L, bool conv, bool alpha = false)
@@ -170,7 +178,7 @@ __host__ __device__ inline WuLds wu_lds(int Nc, int W, int ncls, int L, bool con
     const int WV = wu_words(W);
     WuLds o;
     o.xbuf = 0;
-    o.rec = o.xbuf + Nc * W * 64;
+    o.rec = o.xbuf + Nc * wu_rows(W) * 64;
     o.swd = o.rec + Nc * 64;
     o.hist = o.swd + Nc * 64;
     o.thr = o.hist + ncls * 64;               // [Nc][2][9]: high 13 / low 32 bits of ceil(f^dE 2^44), dE + 4 = 0 .. 8
@@ -372,23 +380,26 @@ __device__ __forceinline__ void wu_propose_alpha(const LadderArgs &a, typename W
 // this rung's seed configuration of ladder `lad`, packed 2 bits per qubit, into the lane's column of the rung's rows of the exchange
 // buffer (Ladder.__init__ copies the seed into every rung, mcmc.py:72; resume: the rung's own state) -- a short runtime loop; the caller
 // then takes the words into its state registers with the exchange's own static reads.  Returns 4 x the error count and the class.
+// (a 32-word kernel stages words [w0, w1) = [0, 16) and [16, W) in two calls, each into rows 0 .. of the rung's region; the class comes with the first)
 template <int CODE>
-__device__ __forceinline__ void wu_stage_lds(const LadderArgs &a, uint64_t lad, uint32_t slot, wu_lds_rw xrow, uint32_t &n4, uint32_t &cls)
+__device__ __forceinline__ void wu_stage_lds(const LadderArgs &a, uint64_t lad, uint32_t slot, wu_lds_rw xrow, uint32_t &n4, uint32_t &cls, int w0 = 0, int w1 = -1)
 {
     const int NC = a.Nc, W = a.W, L = a.L, nq = a.nq;
     const uint8_t *src = a.resume ? a.states + (lad * NC + slot) * (uint64_t)nq : a.init + (lad / a.replicas) * (uint64_t)nq;
     uint32_t cnt = 0;
+    if (w1 < 0) w1 = W;
 #pragma unroll 1
-    for (int w = 0; w < W; ++w) {
+    for (int w = w0; w < w1; ++w) {
         uint32_t word = 0;
 #pragma unroll 4
         for (int b = 0; b < 16; ++b) {
             const int q = w * 16 + b;
             if (q < nq) word |= (uint32_t)(src[q] & 3u) << (2 * b);
         }
-        xrow[w * 64] = word;
+        xrow[(w - w0) * 64] = word;
         cnt += nnz2(word);
     }
+    if (w0 != 0) { n4 += 4u * cnt; return; }
     n4 = 4u * cnt;
     cls = (uint32_t)(CODE == kCodeToric ? toric_eq_class_b(L, src) : surf_eq_class_b(CODE, L, src));
     if (CODE == kCodeXzzx) cls = cls == 0 ? 0u : cls == 1 ? 1u : cls == 2 ? 3u : 2u;   // the internal value v with class = v ^ (v >> 1)
@@ -579,7 +590,7 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
         [[maybe_unused]] wu_lds_drw const nefd = (wu_lds_drw)(ldsl + ol.nef) + (uint32_t)lane;
         [[maybe_unused]] wu_lds_dptr const lnbd = (wu_lds_dptr)(ldsl + ol.lnb);
         const uint32_t xaddr = lds0l + (uint32_t)lane * 4u;
-        const uint32_t xstride = (uint32_t)Wl * 256u;                               // bytes of one rung in the exchange buffer
+        const uint32_t xstride = (uint32_t)(WV == 32 ? kWuHalf : Wl) * 256u;          // bytes of one rung in the exchange buffer
         const int swb = NC - 1 - (int)slot;                 // the top rungs draw the swap uniforms: block swb = pairs 4 swb .. 4 swb + 3
         u32x4 sb{0, 0, 0, 0};
         const bool duty = swb >= 0 && swb < 4 && swb * 4 < NC - 1;
@@ -587,7 +598,9 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
         __syncthreads();                                   // (everybody has read the exchange buffer and the swap uniforms of the step before)
         {
             const uint32_t xo = xaddr + slot * xstride;
-#define QECMC_WU_PUT(w) if constexpr (w < WV) { if (w < wu_words_min(WV) || w < Wl) wu_ds_write<WV, w>(st, xo); }
+            // (a 32-word state passes through the buffer in two halves: words 0-15 here, the rest behind two more barriers below)
+#define QECMC_WU_PUT(w) if constexpr (w < WV && w < kWuHalf) { if (w < wu_words_min(WV) || w < Wl) wu_ds_write<WV, w>(st, xo); }
+#define QECMC_WU_PUT_HI(w) if constexpr (w < WV && w >= kWuHalf) { if (w < wu_words_min(WV) || w < Wl) wu_ds_write<WV, w, w - kWuHalf>(st, xo); }
             WU_EACH(QECMC_WU_PUT)
             rec[slot * 64u + (uint32_t)lane] = pack_info(n4 >> 2, slot, cls, flag);
             if constexpr (ALPHA) nefd[slot * 64u] = wu_neff(nef, a.alpha);
@@ -628,9 +641,20 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
             if (slot == 0) mine = car;
             // this rung's new state: the W words of the rung it comes from
             const uint32_t xin = xaddr + ((mine >> 16) & 0xFFu) * xstride;
-#define QECMC_WU_TAKE(w) if constexpr (w < WV) { if (w < wu_words_min(WV) || w < Wl) wu_ds_read<WV, w>(st, xin); }
+#define QECMC_WU_TAKE(w) if constexpr (w < WV && w < kWuHalf) { if (w < wu_words_min(WV) || w < Wl) wu_ds_read<WV, w>(st, xin); }
+#define QECMC_WU_TAKE_HI(w) if constexpr (w < WV && w >= kWuHalf) { if (w < wu_words_min(WV) || w < Wl) wu_ds_read<WV, w, w - kWuHalf>(st, xin); }
             WU_EACH(QECMC_WU_TAKE)
             wu_ds_wait<WV>(st);
+            if constexpr (WV == 32) {
+                static_assert(WV != 32 || (!CONV && !QUEUE), "the 32-word kernels: fixed-length runs");
+                const uint32_t xo = xaddr + slot * xstride;
+                __syncthreads();                               // (every wave has taken the lower half of its new state)
+                WU_EACH(QECMC_WU_PUT_HI)
+                wu_ds_wait<WV>(st);
+                __syncthreads();
+                WU_EACH(QECMC_WU_TAKE_HI)
+                wu_ds_wait<WV>(st);
+            }
             n4 = (mine & 0xFFFFu) << 2; cls = (mine >> 24) & 0x3Fu; flag = mine >> 31;
             if (top) flag = 1;                                                       // chains[-1].flag = 1, mcmc.py:100
             if constexpr (!CONV) {
@@ -869,13 +893,23 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_wu_kernel(const LadderArgs 
     WU_EACH(QECMC_WU_ZERO)
 #undef QECMC_WU_ZERO
     if (cnt > 0) {
-        wu_stage_lds<CODE>(a, ladder, slot, (wu_lds_rw)(uintptr_t)lds0 + (slot * (uint32_t)W) * 64u + (uint32_t)lane, n4, cls);
-        const uint32_t xme = lds0 + (uint32_t)lane * 4u + slot * (uint32_t)(W * 256);
+        const int rows = wu_rows(W);                                  // rows of a rung's region of the exchange buffer
+        const wu_lds_rw xcol = (wu_lds_rw)(uintptr_t)lds0 + (slot * (uint32_t)rows) * 64u + (uint32_t)lane;
+        wu_stage_lds<CODE>(a, ladder, slot, xcol, n4, cls, 0, WV == 32 ? kWuHalf : W);
+        const uint32_t xme = lds0 + (uint32_t)lane * 4u + slot * (uint32_t)(rows * 256);
         const int Wl = W;
-#define QECMC_WU_MINE(w) if constexpr (w < WV) { if (w < wu_words_min(WV) || w < Wl) wu_ds_read<WV, w>(st, xme); }
+#define QECMC_WU_MINE(w) if constexpr (w < WV && w < kWuHalf) { if (w < wu_words_min(WV) || w < Wl) wu_ds_read<WV, w>(st, xme); }
         WU_EACH(QECMC_WU_MINE)
 #undef QECMC_WU_MINE
         wu_ds_wait<WV>(st);
+        if constexpr (WV == 32) {
+            // (the upper half through the same rows: this lane's own column, which nobody else reads)
+            wu_stage_lds<CODE>(a, ladder, slot, xcol, n4, cls, kWuHalf, W);
+#define QECMC_WU_MINE_HI(w) if constexpr (w < WV && w >= kWuHalf) { if (w < wu_words_min(WV) || w < Wl) wu_ds_read<WV, w, w - kWuHalf>(st, xme); }
+            WU_EACH(QECMC_WU_MINE_HI)
+#undef QECMC_WU_MINE_HI
+            wu_ds_wait<WV>(st);
+        }
         if (a.resume) flag = a.flags[ladder * NC + slot];
     }
     uint32_t tops0 = 0;                                               // wave 0's per-ladder bookkeeping (the criterion kernels: in LDS)
@@ -903,15 +937,14 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_wu_kernel(const LadderArgs 
         const uint32_t *bk = lds + o.bk + lane;
         tops0 = bk[0]; samples = bk[64]; done = bk[576] & 1u; steps_done = bk[640]; conv_ok = bk[704];
     }
+    const int rows = wu_rows(W);
     {
         const int Wl = W;
-        const uint32_t xo = xaddr + slot * (uint32_t)(W * 256);
+        const uint32_t xo = xaddr + slot * (uint32_t)(rows * 256);
         WU_EACH(QECMC_WU_PUT)
         wu_ds_wait<WV>(st);
         rec[slot * 64u + (uint32_t)lane] = pack_info(n4 >> 2, slot, cls, flag);
     }
-#undef QECMC_WU_PUT
-#undef QECMC_WU_TAKE
     __syncthreads();
     if (a.counts != nullptr)
 #pragma unroll 1
@@ -937,14 +970,31 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_wu_kernel(const LadderArgs 
             for (int c = 0; c < NC; ++c) a.flags[(s0 + lane) * NC + c] = (uint8_t)(rec[c * 64 + lane] >> 31);
     }
     if (a.write_states && a.states != nullptr) {
+        // (the words the exchange buffer holds: all of them, or -- 32-word kernels -- the lower half, then the upper one)
         uint8_t *dst = a.states + s0 * (uint64_t)NC * nq;
         const int per = NC * nq, total = cnt * per;
+        auto copy = [&](int w_lo, int w_hi) {
 #pragma unroll 1
-        for (int i = tid; i < total; i += nthreads) {
-            const int j = i / per, rem = i - j * per, c = rem / nq, q = rem - c * nq;
-            dst[i] = (uint8_t)((xbuf[(c * W + (q >> 4)) * 64 + j] >> ((q & 15) * 2)) & 3u);
+            for (int i = tid; i < total; i += nthreads) {
+                const int j = i / per, rem = i - j * per, c = rem / nq, q = rem - c * nq, w = q >> 4;
+                if (w >= w_lo && w < w_hi) dst[i] = (uint8_t)((xbuf[(c * rows + (w - w_lo)) * 64 + j] >> ((q & 15) * 2)) & 3u);
+            }
+        };
+        copy(0, rows);
+        if constexpr (WV == 32) {
+            const int Wl = W;
+            const uint32_t xo = xaddr + slot * (uint32_t)(rows * 256);
+            __syncthreads();
+            WU_EACH(QECMC_WU_PUT_HI)
+            wu_ds_wait<WV>(st);
+            __syncthreads();
+            copy(kWuHalf, W);
         }
     }
+#undef QECMC_WU_PUT
+#undef QECMC_WU_TAKE
+#undef QECMC_WU_PUT_HI
+#undef QECMC_WU_TAKE_HI
 }
 
 // the kernel for a shape: the padded state width (4, 8, 12 or 16 words: toric L <= 11, the one-layer codes L <= 16), 8 waves per SIMD up
@@ -966,12 +1016,18 @@ inline const void *wu_pick_it(int Nc, int W)
         if (W <= 4) return (const void *)ladder_wu_kernel<512, 8, CODE, 4, CONV, QUEUE, IT>;
         if (W <= 8) return (const void *)ladder_wu_kernel<512, 8, CODE, 8, CONV, QUEUE, IT>;
         if (W <= 12) return (const void *)ladder_wu_kernel<512, 8, CODE, 12, CONV, QUEUE, IT>;
-        return (const void *)ladder_wu_kernel<512, 6, CODE, 16, CONV, QUEUE, IT>;      // (45 KB of LDS: three workgroups per CU anyway)
+        if (W <= 16) return (const void *)ladder_wu_kernel<512, 6, CODE, 16, CONV, QUEUE, IT>;      // (45 KB of LDS: three workgroups per CU anyway)
+        if constexpr (!CONV && !QUEUE) return (const void *)ladder_wu_kernel<512, 6, CODE, 32, false, false, IT>;   // (toric L = 12 .. 16: BASELINE config 3)
+        return nullptr;
     } else {
         if (W <= 4) return big ? (const void *)ladder_wu_kernel<1024, 4, CODE, 4, CONV, QUEUE, IT> : (const void *)ladder_wu_kernel<512, 8, CODE, 4, CONV, QUEUE, IT>;
         if (W <= 8) return big ? (const void *)ladder_wu_kernel<1024, 4, CODE, 8, CONV, QUEUE, IT> : (const void *)ladder_wu_kernel<512, 8, CODE, 8, CONV, QUEUE, IT>;
         if (W <= 12) return big ? (const void *)ladder_wu_kernel<1024, 4, CODE, 12, CONV, QUEUE, IT> : (const void *)ladder_wu_kernel<512, 8, CODE, 12, CONV, QUEUE, IT>;
-        return big ? (const void *)ladder_wu_kernel<1024, 4, CODE, 16, CONV, QUEUE, IT> : (const void *)ladder_wu_kernel<512, 6, CODE, 16, CONV, QUEUE, IT>;
+        if (W <= 16) return big ? (const void *)ladder_wu_kernel<1024, 4, CODE, 16, CONV, QUEUE, IT> : (const void *)ladder_wu_kernel<512, 6, CODE, 16, CONV, QUEUE, IT>;
+        // 17 .. 32 words (toric L <= 16, the one-layer codes L <= 22): fixed-length runs of up to 8 rungs, 80 VGPRs at 6 waves per SIMD, the state
+        // through the exchange buffer in two halves (52 KB of LDS: three workgroups per CU); not built for the planar code
+        if constexpr (!CONV && !QUEUE && CODE != kCodePlanar) { if (!big) return (const void *)ladder_wu_kernel<512, 6, CODE, 32, false, false, IT>; }
+        return nullptr;
     }
 #endif
 }
@@ -979,7 +1035,7 @@ inline const void *wu_pick_it(int Nc, int W)
 template <int CODE>
 inline const void *wu_pick(int variant, int Nc, int W, uint32_t iters)
 {
-    if (W > 16 || (variant != 0 && variant != 2)) return nullptr;
+    if (W > 32 || (variant != 0 && variant != 2)) return nullptr;
     const bool it10 = CODE == kCodeToric && iters == 10u && Nc * 64 <= 512;
     if constexpr (CODE == kCodeToric) {
         if (it10) return variant == 2 ? wu_pick_it<CODE, true, true, 10>(Nc, W) : wu_pick_it<CODE, false, false, 10>(Nc, W);
