@@ -356,8 +356,8 @@ def parse_args(argv=None):
                          "eta=100, Nc=5), decoded by PTEQ_alpha with (pz_tilde, alpha) derived from them (src/mcmc_alpha.py)")
     ap.add_argument("--scan", default="auto", choices=["auto", "random", "sweep", "wave"],
                     help="random = the reference's random-scan chain (scan=0); wave = the same chain per syndrome with a generator pick shared by the 64 "
-                         "ladders of a wavefront, states in registers (scan=3); auto = wave where it is built and the faster one (depolarizing rule, "
-                         "at most 16 packed state words per rung: toric L <= 11), else random; sweep = systematic generator sweep (scan=1: not the reference's chain)")
+                         "ladders of a wavefront, states in registers (scan=3); auto = wave where it is built and measured faster (toric code, depolarizing "
+                         "rule, L <= 11 -- fixed-length runs L <= 16 --, and the alpha route), else random; sweep = systematic generator sweep (scan=1: not the reference's chain)")
     ap.add_argument("--criterion", action="store_true",
                     help="time the route the reference runs by default (decoders.py:25 conv_criteria='error_based', SEQ=2, TOPS=10, eps=0.1): every "
                          "ladder stops by the criterion or at the horizon of --ladder-steps of its own steps; `value` counts the steps the ladders "
@@ -392,7 +392,11 @@ def parse_args(argv=None):
         nq = (2 if args.code in ("toric", "planar") else 1) * args.L * args.L
         # scan = wave where same-box A/B runs have it ahead (profiles/r04_wave_ab.json): rung states of at most 16 words keep 8 waves per SIMD
         W = (nq + 15) // 16
-        ok = W <= 8 and args.Nc <= 8 and args.code in ("xzzx", "rotated") if args.alpha_route else (args.eta is None and W <= 16)
+        # where same-box A/B runs have scan = wave ahead (profiles/r04_wave_ab.json): the toric code -- up to 16 state words per rung at 8 waves per
+        # SIMD, fixed-length runs of up to 32 words (L <= 16) at 6 -- and the alpha rule; on the one-layer codes and the planar code the
+        # random scan's kernels are (L = 9: 0.72-0.74 against 0.61; rotated L = 21 at BASELINE's 32 768 syndromes 0.51 against 0.46)
+        ok = W <= 8 and args.Nc <= 8 and args.code in ("xzzx", "rotated") if args.alpha_route else (
+            args.eta is None and args.code == "toric" and (W <= 16 or (W <= 32 and args.Nc <= 8 and not args.criterion)))
         args.scan = "wave" if (ok and args.Nc >= 2 and args.iters <= 128 and args.syndromes % 64 == 0) else "random"
     return args
 

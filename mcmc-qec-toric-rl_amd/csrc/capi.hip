@@ -127,7 +127,7 @@ inline size_t code_nq(int code, int L) { return (size_t)code_nq_of(code, L); }
 struct qecmc_plan {
     qecmc_params prm;
     LadderArgs args;
-    DevBuf swap_thr, lmask, acc_top, gen, bias, lnb, xyz_lut, gen_type, queue, phases, wu_desc;
+    DevBuf swap_thr, lmask, acc_top, gen, bias, lnb, xyz_lut, gen_type, queue, phases, wu_desc, col_thr;
     uint32_t queue_grid = 0;                                   // persistent grid of the work-queue kernels (0: not a queue plan)
     size_t lds_bytes;
     uint32_t *d_swap_acc = nullptr, *d_nerr_sum = nullptr;   // qecmc_plan_set_stats (caller-owned)
@@ -155,14 +155,14 @@ int validate_params(const qecmc_params *p)
     } else if (!(p->p > 0.0) || !(p->p <= 0.75)) return fail(QECMC_ERR_INVALID, "p=%g must be in (0, 0.75]", p->p);
     if (!(p->p_logical >= 0.0) || !(p->p_logical <= 1.0)) return fail(QECMC_ERR_INVALID, "p_logical=%g must be in [0,1]", p->p_logical);
     if (p->scan != QECMC_SCAN_RANDOM && p->scan != QECMC_SCAN_SWEEP && p->scan != QECMC_SCAN_COLOUR && p->scan != QECMC_SCAN_WAVE) return fail(QECMC_ERR_INVALID, "scan mode %d unknown", p->scan);
-    if (p->scan != QECMC_SCAN_RANDOM && p->noise != QECMC_NOISE_DEPOLARIZING && !(p->scan == QECMC_SCAN_WAVE && p->noise == QECMC_NOISE_ALPHA))
-        return fail(QECMC_ERR_UNSUPPORTED, "the sweep and colour scans are built for the depolarizing rule only, the wave scan for the depolarizing and alpha rules");
+    if (p->scan != QECMC_SCAN_RANDOM && p->noise != QECMC_NOISE_DEPOLARIZING && !(p->scan == QECMC_SCAN_WAVE && p->noise == QECMC_NOISE_ALPHA) && p->scan != QECMC_SCAN_COLOUR)
+        return fail(QECMC_ERR_UNSUPPORTED, "the sweep scan is built for the depolarizing rule only, the wave scan for the depolarizing and alpha rules");
     if (p->scan == QECMC_SCAN_WAVE) {
         if (p->Nc < 2) return fail(QECMC_ERR_UNSUPPORTED, "scan = wave needs a ladder whose top rung sits at p = 0.75 (Nc >= 2)");
         if (p->first_syndrome & 63u) return fail(QECMC_ERR_INVALID, "scan = wave shares a generator pick among the 64 ladders of a wavefront: first_syndrome=%u must be a multiple of 64", p->first_syndrome);
     }
     if (p->scan == QECMC_SCAN_COLOUR) {
-        if (p->p_logical > 0.0 && p->Nc < 2) return fail(QECMC_ERR_UNSUPPORTED, "scan = colour needs the top rung at p = 0.75 (Nc >= 2) when logical moves are on");
+        if (p->p_logical > 0.0 && p->Nc < 2 && p->noise != QECMC_NOISE_BIASED) return fail(QECMC_ERR_UNSUPPORTED, "scan = colour needs the top rung at p = 0.75 (Nc >= 2) when logical moves are on");
     }
     if (p->conv_mode != QECMC_CONV_NONE && p->conv_mode != QECMC_CONV_ERROR_BASED) return fail(QECMC_ERR_INVALID, "conv_mode %d unknown", p->conv_mode);
     if (p->conv_mode == QECMC_CONV_ERROR_BASED && (p->TOPS < 0 || p->SEQ < 0 || !(p->eps >= 0))) return fail(QECMC_ERR_INVALID, "TOPS, SEQ and eps must be non-negative");
@@ -267,10 +267,12 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
         HIP_TRY(hipMemcpy(pl->phases.p, ph.data(), ph.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
         a.phase_tab = pl->phases.as<uint16_t>();
         a.n_phases = (uint32_t)n_phases;
-        pl->lds_bytes = sizeof(uint32_t) * colour_lds_dwords(Nc, W, ncls, a.n_phases, (uint32_t)(gt.size() / 2), L, nq, a.swap_fast_ok != 0);
+        // Ladder_alpha's top rung sits at pz_tilde = 1 (mcmc_alpha.py:94): every weight ratio is 1, it takes the coin like the depolarizing top rung
+        if (alpha && Nc >= 2) a.acc_all_mask |= 1u << (Nc - 1);
+        pl->lds_bytes = sizeof(uint32_t) * colour_lds_dwords(Nc, W, ncls, a.n_phases, (uint32_t)(gt.size() / 2), L, nq, a.swap_fast_ok != 0, p->noise);
         if (pl->lds_bytes > 160 * 1024)
             return fail(QECMC_ERR_UNSUPPORTED, "scan = colour: L=%d Nc=%d needs %zu B of LDS per workgroup (> 160 KiB)", L, Nc, pl->lds_bytes);
-        if (p->p_logical > 0.0 && !((a.acc_all_mask >> (Nc - 1)) & 1u))
+        if (p->p_logical > 0.0 && p->noise != QECMC_NOISE_BIASED && !((a.acc_all_mask >> (Nc - 1)) & 1u))
             return fail(QECMC_ERR_UNSUPPORTED, "scan = colour needs a top rung that accepts every move (p_top = 0.75) when logical moves are on");
     }
     if (p->scan == QECMC_SCAN_WAVE) {
@@ -311,6 +313,24 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
             if (a.iters <= 512u && 4.0 * (double)a.iters * std::max(std::fabs(a.bias_l2[c][0]), std::fabs(a.bias_l2[c][1])) <= 2000.0)
                 a.bias_f32ok |= 1u << c;
         }
+        if (p->scan == QECMC_SCAN_COLOUR) {
+            // scan = 2 under these rules (ladder_colour.hip): a generator is a Metropolis move for the model's own weight, accepted iff
+            // u < (px / pI)^dxy (pz / pI)^dz -- as integers, u <= ceil(ratio 2^32) - 1 -- for its changes (dz, dxy) of n_z and n_x + n_y
+            std::vector<uint32_t> ct((size_t)Nc * 81);
+            for (int c = 0; c < Nc; ++c) {
+                const double *t = &bt[(size_t)c * 4 * (nq + 1)];
+                const double fxy = t[1] / t[3 * (nq + 1) + 1], fz = t[2 * (nq + 1) + 1] / t[3 * (nq + 1) + 1];
+                for (int dz = -4; dz <= 4; ++dz)
+                    for (int dxy = -4; dxy <= 4; ++dxy) {
+                        const uint64_t th = thr64(std::pow(fxy, (double)dxy) * std::pow(fz, (double)dz));
+                        if (th == 0) return fail(QECMC_ERR_UNSUPPORTED, "scan = colour: an acceptance ratio of rung %d underflows", c);
+                        ct[(size_t)c * 81 + 9 * (dz + 4) + (dxy + 4)] = (uint32_t)(th - 1);
+                    }
+            }
+            HIP_TRY(pl->col_thr.alloc(ct.size() * sizeof(uint32_t)));
+            HIP_TRY(hipMemcpy(pl->col_thr.p, ct.data(), ct.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            a.col_thr = pl->col_thr.as<uint32_t>();
+        }
         HIP_TRY(pl->xyz_lut.alloc(xyz_lut.size() * sizeof(uint32_t)));
         HIP_TRY(hipMemcpy(pl->xyz_lut.p, xyz_lut.data(), xyz_lut.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         a.xyz_lut = pl->xyz_lut.as<uint32_t>();
@@ -338,7 +358,7 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
     a.lmask = pl->lmask.as<uint32_t>();
     if (p->scan == QECMC_SCAN_WAVE && (!wu_supported(a) || pl->lds_bytes > 160 * 1024))
         return fail(QECMC_ERR_UNSUPPORTED, "scan = wave: L=%d Nc=%d p=%g is outside what it is built for (depolarizing rule: a top rung that accepts every move, at most "
-                    "16 packed state words per rung -- toric / planar L <= 11, xzzx / rotated L <= 16; alpha rule: xzzx / rotated L <= 11, Nc <= 8, "
+                    "16 packed state words per rung -- toric / planar L <= 11, xzzx / rotated L <= 16 --, fixed-length runs of up to 8 rungs 32 words -- toric L <= 16, xzzx / rotated L <= 22; alpha rule: xzzx / rotated L <= 11, Nc <= 8, "
                     "4 iters max|log2 ratio| <= 2000 --, %zu B of LDS)", L, Nc, p->p, pl->lds_bytes);
     return 0;
 }

@@ -76,6 +76,7 @@ struct LadderArgs {
     uint32_t acc_all_mask;    // bit c: slot c accepts every proposal (f >= 1, mcmc.py:30)
     uint32_t acc_thr[kMaxNc][4];   // ceil(f_c^dE * 2^32), dE = 1..4 (sweep mode: one 32-bit word per acceptance)
     uint64_t acc_thr44[kMaxNc][4]; // ceil(f_c^dE * 2^44): random scan, the 44-bit acceptance uniform of a non-top proposal
+    const uint32_t *col_thr;  // [Nc][81]           scan = 2 under the biased / alpha rules: accept iff u <= col_thr[c][9 (dz + 4) + dxy + 4] (capi.hip)
     const uint32_t *wu_desc;       // scan = 3: [n_gen][16] generator descriptors (tables.hpp wave_descriptors)
     uint32_t wu_chunk;             // scan = 3, criterion runs on a persistent grid: ladders per workgroup (a multiple of 64; 0: one ladder per lane, no queue)
     float swap_inv_log2[kMaxNc];   // 1 / log2(p_diff[i]): first guess of the largest d with u < p_diff[i]^d (the table decides)
@@ -136,10 +137,12 @@ inline bool ladder_uses_queue(int code, int noise, int scan, int conv_mode, int 
 // LDS of one workgroup (dwords): states, records, swap uniforms, histogram, then the tables every phase reads -- the phase
 // table, the generator table, the logical masks, the swap thresholds (32-bit where they fit) -- so that the serial path of a
 // step never waits for global memory
-inline size_t colour_lds_dwords(int Nc, int W, int ncls, uint32_t n_phases, uint32_t n_gen, int L, int nq, bool swap32)
+// (noise != 0: the rule's 81 thresholds per rung; the alpha rule's n_eff records by step parity)
+inline size_t colour_lds_dwords(int Nc, int W, int ncls, uint32_t n_phases, uint32_t n_gen, int L, int nq, bool swap32, int noise = 0)
 {
     return (size_t)Nc * W + 4 * (size_t)Nc + ncls + 32u * n_phases + 2u * n_gen + 4u * (L + 1) * W +
-           (swap32 ? 1u : 2u) * (size_t)(Nc > 1 ? Nc - 1 : 0) * (nq + 1) + 2 + 4;   // (+ 2: the stop flag by step parity)
+           (swap32 ? 1u : 2u) * (size_t)(Nc > 1 ? Nc - 1 : 0) * (nq + 1) + 2 + 4 +   // (+ 2: the stop flag by step parity)
+           (noise ? (size_t)Nc * 81 + 2 * (size_t)Nc : 0);
 }
 
 hipError_t launch_ladder_rs_toric(const LadderArgs &a, hipStream_t stream);

@@ -25,6 +25,16 @@
 // conv_mode = error_based runs the reference's criterion on wave 0 (the workgroup leaves when its ladder has converged).  In
 // fixed-length runs steps_done reports the first ladder step after which tops0 >= TOPS (or `steps`), converged whether it was
 // reached: the "time to tops0 >= 10" the latency table of profiles/ quotes.
+//
+// RULE = 1 / 2: the biased (src/mcmc_biased.py) and alpha (src/mcmc_alpha.py) noise models on the xzzx / rotated codes.  The members of
+// a phase are tested at once, so Q3's frozen p_b cannot be carried (a member's ratio would depend on what the members before it did):
+// every generator is a Metropolis move for the model's own weight, u < (px / pI)^dxy (pz / pI)^dz with (dxy, dz) the change of
+// n_x + n_y and n_z of that generator alone -- an 81-entry threshold table per rung (a.col_thr) --, the law the reference's rule has at
+// iters = 1.  The biased top rung is not uniform: it runs the same rule and tests its logical operators (word 0 of block (K, 1) against
+// the ratio of the power tables' products, the reference's expression); Ladder_alpha's top rung (pz_tilde = 1: every ratio is 1) takes
+// the coin and its logical operators unseen, like the depolarizing one.  RULE = 2 also: the swap test on the slots' n_eff attributes
+// (mcmc_alpha.py:118-123), which stay with the slot (Q4: a wave IS a slot here, the attribute is a scalar of the wave) and follow the
+// counts only when a move was accepted (:58,:70); the criterion on the logged attribute of slot 0 (decoders_biasednoise.py:204,229-238).
 #include "ladder_kernel.hpp"
 
 namespace qecmc {
@@ -48,9 +58,10 @@ __device__ __forceinline__ int wave_sum(int v)
 #define QECMC_CSTAMP(k) ((void)0)
 #endif
 
-template <int CODE, bool CONV>
+template <int CODE, bool CONV, int RULE = 0>
 __global__ __launch_bounds__(1024) void ladder_colour_kernel(const LadderArgs a)
 {
+    static_assert(RULE == 0 || CODE == kCodeXzzx || CODE == kCodeRotated, "the biased / alpha rules: xzzx and rotated codes");
     extern __shared__ uint32_t lds[];
     const int NC = a.Nc, W = a.W, L = a.L, LL = L * L, nq = a.nq, ncls = a.ncls;
     const int tid = (int)threadIdx.x, lane = tid & 63;
@@ -65,6 +76,8 @@ __global__ __launch_bounds__(1024) void ladder_colour_kernel(const LadderArgs a)
     uint32_t *swt = lml + 4 * (a.L + 1) * W;                                          // [NC-1][nq+1] swap thresholds (u32, or u64 as two dwords)
     const bool swap32 = a.swap_fast_ok != 0;
     volatile uint32_t *stopf = swt + (swap32 ? 1 : 2) * (NC > 1 ? NC - 1 : 0) * (a.nq + 1);   // [2] "the ladder has converged", by step parity
+    [[maybe_unused]] uint32_t *cthr = const_cast<uint32_t *>(stopf) + 2;                  // RULE != 0: [NC][81] accept iff u <= cthr[9 (dz + 4) + dxy + 4]
+    [[maybe_unused]] uint32_t *nefr = cthr + (RULE ? NC * 81 : 0);                          // RULE == 2: [2][NC] the slots' n_eff records (n_z | n_xy << 16) by step parity
     const uint32_t R = a.replicas;
     const uint64_t ladder = blockIdx.x;                  // one workgroup per ladder
     if (ladder >= a.N) return;
@@ -88,6 +101,7 @@ __global__ __launch_bounds__(1024) void ladder_colour_kernel(const LadderArgs a)
     for (int i = tid; i < (int)a.n_phases * 64; i += NC * 64) ptab[i] = a.phase_tab[i];
     for (int i = tid; i < (int)a.n_gen; i += NC * 64) gtab[i] = a.gen[i];
     for (int i = tid; i < 4 * (L + 1) * W; i += NC * 64) lml[i] = a.lmask[i];
+    if constexpr (RULE != 0) { for (int i = tid; i < NC * 81; i += NC * 64) cthr[i] = a.col_thr[i]; }
     for (int i = tid; i < (NC - 1) * (nq + 1); i += NC * 64) {
         if (swap32) swt[i] = (uint32_t)a.swap_thr[i];      // (entry d = 0 -- 2^32 -- is never looked up: d <= 0 always swaps)
         else { swt[2 * i] = (uint32_t)a.swap_thr[i]; swt[2 * i + 1] = (uint32_t)(a.swap_thr[i] >> 32); }
@@ -128,6 +142,19 @@ __global__ __launch_bounds__(1024) void ladder_colour_kernel(const LadderArgs a)
         cls = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
     }
     n = (uint32_t)__builtin_amdgcn_readfirstlane((int)n);
+    // RULE == 2: n_z | n_xy << 16 of a state (wave-parallel over its words), and this slot's n_eff attribute as those counts (Chain_alpha.__init__)
+    [[maybe_unused]] auto counts_zxy = [&](const uint32_t *sbw) -> uint32_t {
+        int cz = 0, cxy = 0;
+        for (int w = lane; w < W; w += 64) {
+            const uint32_t x = sbw[w];
+            cz += __popc(x & (x >> 1) & 0x55555555u);
+            cxy += __popc((x ^ (x >> 1)) & 0x55555555u);
+        }
+        return (uint32_t)__builtin_amdgcn_readfirstlane(wave_sum(cz)) | ((uint32_t)__builtin_amdgcn_readfirstlane(wave_sum(cxy)) << 16);
+    };
+    [[maybe_unused]] uint32_t nef = 0;
+    if constexpr (RULE == 2) nef = counts_zxy(st + slot * W);
+    [[maybe_unused]] uint64_t sumAxy = 0, sumBxy = 0;
     uint32_t tops0 = 0, samples = 0, t_reached = 0;     // wave 0's bookkeeping (uniform)
     [[maybe_unused]] uint32_t burn = 0, conv_start = 0, conv_streak = 0, done = 0, steps_done = 0;   // decoders.py:37-48
     [[maybe_unused]] uint64_t sumA = 0, sumB = 0;       // window sums of the logged bottom-chain error counts: Q2 = series[l/4 : l/2], Q4 = series[3l/4 : l]
@@ -136,6 +163,7 @@ __global__ __launch_bounds__(1024) void ladder_colour_kernel(const LadderArgs a)
     const uint32_t thrL1 = (uint32_t)(a.thr_logical - 1);
     // accept iff u <= thr[dE + 4] (dE <= 0 or f >= 1: always -- a rung with f >= 1 takes the coin instead)
     const uint32_t thr1 = a.acc_thr[slot][0] - 1u, thr2 = a.acc_thr[slot][1] - 1u, thr3 = a.acc_thr[slot][2] - 1u, thr4 = a.acc_thr[slot][3] - 1u;
+    [[maybe_unused]] const uint32_t *mythr = cthr + slot * 81u;
     const uint32_t iters = a.iters, P = a.n_phases;
     const uint32_t *lmask = lml;
     const int LW = (L + 1) * W;
@@ -148,7 +176,7 @@ __global__ __launch_bounds__(1024) void ladder_colour_kernel(const LadderArgs a)
     // Pauli pattern, and -- the uniform being known before dE is -- the largest dE the lane would accept (thresholds fall with dE; a rung
     // with f >= 1 takes the coin: every dE or none).  All of it is prepared one phase ahead, in the shadow of the current phase's chain
     // state words -> fields -> dE -> compare -> xor, which is what a lone workgroup's step time is made of.
-    struct Prepared { bool act; uint32_t wi[4], sh[4], xv[4], ops; int dmax; };
+    struct Prepared { bool act; uint32_t wi[4], sh[4], xv[4], ops, u; int dmax; };
     uint2 e_next;                                                             // the entry of the phase after the prepared one
     bool act_next;
     u32x4 ub{0, 0, 0, 0};                                                     // this lane's block of uniforms (four consecutive phases)
@@ -178,6 +206,7 @@ __global__ __launch_bounds__(1024) void ladder_colour_kernel(const LadderArgs a)
         // whenever the phase index enters a new group of four)
         if (first_of_step || (Kn & 3u) == 0) ub = philox_block(Kn >> 2, 8u + (uint32_t)lane, syn, strm_n, a.seed_lo, a.seed_hi);
         const uint32_t u = sel4(ub, (int)(Kn & 3u));
+        q.u = u;
         // mcmc.py:42 / :30 with the coin: accept iff dE <= dmax
         q.dmax = acc_all ? ((u >> 31) != 0u ? 127 : -127) : (int)(u <= thr1) + (int)(u <= thr2) + (int)(u <= thr3) + (int)(u <= thr4);
         return q;
@@ -193,6 +222,7 @@ __global__ __launch_bounds__(1024) void ladder_colour_kernel(const LadderArgs a)
         dg = dg + 1u == (uint32_t)NC ? 0u : dg + 1u;
         [[maybe_unused]] u32x4 topb{0, 0, 0, 0};
         int dn = 0;                                                           // this lane's accepted dE of the step
+        [[maybe_unused]] bool any_acc = false, any_lane = false;              // RULE == 2: a move was accepted this step (wave-uniform / this lane's)
         for (uint32_t j = 0; j < iters; ++j) {
             const uint64_t K = a.prop0 + t * iters + j;
             if (top_logical) {
@@ -221,9 +251,31 @@ __global__ __launch_bounds__(1024) void ladder_colour_kernel(const LadderArgs a)
                         if (az) m1 = lmask + LW + zp * W;
                         cdelta = ax | (az << 1);
                     }
-                    for (int w = lane; w < W; w += 64) sb[w] ^= m0[w] ^ m1[w] ^ m2[w] ^ m3[w];
-                    cls ^= cdelta;
-                    recount = true;
+                    bool take = true;
+                    if constexpr (RULE == 1) {
+                        // the biased top rung tests the operator like every move (mcmc_biased.py:32-46): u < w(new) / w(old), the power
+                        // tables' products in the reference's order; u = word 0 of block (K, 1)
+                        int ox = 0, oz = 0, oxy = 0, qx = 0, qz = 0, qxy = 0;
+                        for (int w = lane; w < W; w += 64) {
+                            const uint32_t xo = sb[w], xn = xo ^ m0[w] ^ m1[w] ^ m2[w] ^ m3[w];
+                            ox += __popc(xo & ~(xo >> 1) & 0x55555555u); oz += __popc(xo & (xo >> 1) & 0x55555555u); oxy += __popc((xo ^ (xo >> 1)) & 0x55555555u);
+                            qx += __popc(xn & ~(xn >> 1) & 0x55555555u); qz += __popc(xn & (xn >> 1) & 0x55555555u); qxy += __popc((xn ^ (xn >> 1)) & 0x55555555u);
+                        }
+                        ox = wave_sum(ox); oz = wave_sum(oz); oxy = wave_sum(oxy); qx = wave_sum(qx); qz = wave_sum(qz); qxy = wave_sum(qxy);
+                        const int T1 = nq + 1;
+                        const double *bt = a.bias_tbl + (size_t)slot * 4 * T1;
+                        const double wn = bt[qx] * bt[T1 + (qxy - qx)] * bt[2 * T1 + qz] * bt[3 * T1 + (nq - qxy - qz)];
+                        const double wo = bt[ox] * bt[T1 + (oxy - ox)] * bt[2 * T1 + oz] * bt[3 * T1 + (nq - oxy - oz)];
+                        const u32x4 ab = philox_block(K, 1u, syn, strm, a.seed_lo, a.seed_hi);
+                        take = (double)ab.x * (1.0 / 4294967296.0) < wn / wo;
+                        take = __builtin_amdgcn_readfirstlane((int)take) != 0;
+                    }
+                    if (take) {
+                        for (int w = lane; w < W; w += 64) sb[w] ^= m0[w] ^ m1[w] ^ m2[w] ^ m3[w];
+                        cls ^= cdelta;
+                        recount = true;
+                        any_acc = true;
+                    }
                 }
             }
             // ---- one phase: every lane its generator (prepared during the phase before)
@@ -248,6 +300,12 @@ __global__ __launch_bounds__(1024) void ladder_colour_kernel(const LadderArgs a)
                 for (int i = 0; i < 4; ++i) F |= ((*ad[i] >> cu.sh[i]) & 3u) << (2 * i);
                 const uint32_t G = F ^ cu.ops;
                 dE = (int)__popc((G | (G >> 1)) & 0x55u) - (int)__popc((F | (F >> 1)) & 0x55u);            // toric_model.py:275-282
+                if constexpr (RULE != 0) {
+                    // the model's own weight ratio for this generator: the changes of n_z (fields = 3) and n_x + n_y (fields 1, 2)
+                    const int dz = (int)__popc(G & (G >> 1) & 0x55u) - (int)__popc(F & (F >> 1) & 0x55u);
+                    const int dxy = (int)__popc((G ^ (G >> 1)) & 0x55u) - (int)__popc((F ^ (F >> 1)) & 0x55u);
+                    acc = cu.act && cu.u <= mythr[9 * (dz + 4) + (dxy + 4)];
+                } else
                 acc = cu.act && dE <= cu.dmax;
             }
             if (acc) {
@@ -255,6 +313,7 @@ __global__ __launch_bounds__(1024) void ladder_colour_kernel(const LadderArgs a)
                 for (int i = 0; i < 4; ++i) lds_xor(ad[i], cu.xv[i]);                   // (same-word updates of different lanes: LDS atomics)
             }
             dn += acc ? dE : 0;                                                 // (the rule never reads n inside a step: summed over the wave once, below)
+            if constexpr (RULE == 2) any_lane |= acc;
         }
         QECMC_CSTAMP(1);
         if (recount) {                                                        // the logical operators moved O(L) sites
@@ -267,6 +326,11 @@ __global__ __launch_bounds__(1024) void ladder_colour_kernel(const LadderArgs a)
         // ---- Ladder.step's swap sweep (mcmc.py:96-103): records and uniforms out, one barrier, every wave replays the cascade
         uint32_t *cur = rec + (t & 1) * NC, *sx = swu + (t & 1) * NC;
         if (lane == 0) cur[slot] = pack_info(n, sid, cls, flag);
+        if constexpr (RULE == 2) {
+            // the slot's attribute follows its chain's counts if a move was accepted this step (mcmc_alpha.py:58,:70)
+            if (any_acc || __any(any_lane)) nef = counts_zxy(sb);
+            if (lane == 0) nefr[(t & 1) * NC + slot] = nef;
+        }
         if ((int)slot * 4 < NC - 1) {
             const u32x4 b = philox_block(a.step0 + t, slot, syn, kSwapStream, a.seed_lo, a.seed_hi);
             if (lane < 4 && (int)slot * 4 + lane < NC - 1) sx[slot * 4 + lane] = sel4(b, lane);
@@ -281,6 +345,12 @@ __global__ __launch_bounds__(1024) void ladder_colour_kernel(const LadderArgs a)
         // with scalar instructions -- a lone workgroup has nobody to hide seven dependent look-ups behind.
         uint64_t fm[4] = {0, 0, 0, 0};
         const uint32_t rec_l = cur[lane < NC ? lane : 0];                              // lane l: slot l's record (read back by the walk's result)
+        [[maybe_unused]] uint64_t fa = 0;                                              // RULE == 2: bit i = rung pair i flips (the attributes stay put: Q4)
+        if constexpr (RULE == 2) {
+            const uint32_t *ne = nefr + (t & 1) * NC;
+            const int i = lane < NC - 1 ? lane : 0;
+            fa = __ballot(lane < NC - 1 && alpha_flip(sx[i], ne[i + 1], ne[i], a.alpha, a.alpha_lnb[i]));
+        } else
 #pragma unroll
         for (int ch = 0; ch < 4; ++ch) {
             const int c0 = ch * 64;
@@ -297,7 +367,7 @@ __global__ __launch_bounds__(1024) void ladder_colour_kernel(const LadderArgs a)
         for (int i = NC - 2; i >= 0; --i) {
             const int b = carried * NC + i;
             const uint64_t w = b < 64 ? fm[0] : b < 128 ? fm[1] : b < 192 ? fm[2] : fm[3];
-            const bool flip = (w >> (b & 63)) & 1ull;
+            const bool flip = RULE == 2 ? ((fa >> i) & 1ull) != 0 : ((w >> (b & 63)) & 1ull) != 0;
             const int into = flip ? i : carried;                                       // what slot i+1 now holds (:98-99)
             carried = flip ? carried : i;
             if ((int)slot == i + 1) mine_s = into;
@@ -316,15 +386,25 @@ __global__ __launch_bounds__(1024) void ladder_colour_kernel(const LadderArgs a)
                 if constexpr (CONV) {
                     // nbr_errors_bottom_chain[since_burn] = count_errors (:68): logged in HBM, series index i in row burn + i; the three
                     // entries that leave / enter the windows are independent loads (one round trip on wave 0's path per step)
-                    uint16_t *mylog = a.nlog + ladder;
                     const size_t lN = (size_t)a.N;
-                    mylog[(size_t)t * lN] = (uint16_t)n;
                     const uint32_t l = samples, lo1 = l - 1;
                     const uint32_t a0 = lo1 >> 2, b0 = lo1 >> 1, c0 = (3u * lo1) >> 2, a1 = l >> 2, b1 = l >> 1, c1 = (3u * l) >> 2;
+                    if constexpr (RULE == 2) {
+                        // chains[0].n_eff (decoders_biasednoise.py:204): slot 0's attribute -- this wave's -- logged as its two counts
+                        uint32_t *mylog = reinterpret_cast<uint32_t *>(a.nlog) + ladder;
+                        mylog[(size_t)t * lN] = nef;
+                        sumB += nef & 0xFFFFu; sumBxy += nef >> 16;
+                        if (c1 != c0) { const uint32_t v = mylog[(size_t)(burn + c0) * lN]; sumB -= v & 0xFFFFu; sumBxy -= v >> 16; }
+                        if (b1 != b0) { const uint32_t v = mylog[(size_t)(burn + b0) * lN]; sumA += v & 0xFFFFu; sumAxy += v >> 16; }
+                        if (a1 != a0) { const uint32_t v = mylog[(size_t)(burn + a0) * lN]; sumA -= v & 0xFFFFu; sumAxy -= v >> 16; }
+                    } else {
+                    uint16_t *mylog = a.nlog + ladder;
+                    mylog[(size_t)t * lN] = (uint16_t)n;
                     sumB += n;
                     if (c1 != c0) sumB -= mylog[(size_t)(burn + c0) * lN];
                     if (b1 != b0) sumA += mylog[(size_t)(burn + b0) * lN];
                     if (a1 != a0) sumA -= mylog[(size_t)(burn + a0) * lN];
+                    }
                 }
             } else {
                 burn++;                                                                  // resulting_burn_in, :71
@@ -335,7 +415,10 @@ __global__ __launch_bounds__(1024) void ladder_colour_kernel(const LadderArgs a)
                     const uint32_t l = samples ? samples : 1u;
                     const uint32_t den2 = (l >> 1) - (l >> 2), den4 = l - ((3u * l) >> 2);
                     bool accept = false;                                                 // empty slice -> nan -> not accepted
-                    if (samples && den2 && den4) accept = fabs((double)sumA / (double)den2 - (double)sumB / (double)den4) < a.eps;   // :96-102
+                    if (samples && den2 && den4) {
+                        if constexpr (RULE == 2) accept = alpha_series_close(sumA, sumAxy, den2, sumB, sumBxy, den4, a.alpha, a.eps);   // decoders_biasednoise.py:229-238
+                        else accept = fabs((double)sumA / (double)den2 - (double)sumB / (double)den4) < a.eps;   // :96-102
+                    }
                     if (accept) {
                         if (conv_streak >= a.SEQ) { done = 1; steps_done = (uint32_t)t + 1u; }   // :77-78
                         else conv_streak = tops0 - conv_start;                           // :79
@@ -387,15 +470,21 @@ __global__ __launch_bounds__(1024) void ladder_colour_kernel(const LadderArgs a)
 
 hipError_t launch_ladder_colour(const LadderArgs &a, hipStream_t stream)
 {
-    if (a.phase_tab == nullptr || a.n_phases == 0 || a.noise != 0 || a.resume) return hipErrorInvalidValue;
+    if (a.phase_tab == nullptr || a.n_phases == 0 || a.noise < 0 || a.noise > 2 || a.resume) return hipErrorInvalidValue;
     if (a.conv_mode != 0 && a.nlog == nullptr) return hipErrorInvalidValue;
+    if (a.noise != 0 && (a.col_thr == nullptr || a.bias_tbl == nullptr || (a.code != kCodeXzzx && a.code != kCodeRotated) || (a.noise == 2 && a.alpha_lnb == nullptr)))
+        return hipErrorInvalidValue;
     const bool conv = a.conv_mode != 0;
 #define QECMC_KC(code) (conv ? (const void *)ladder_colour_kernel<code, true> : (const void *)ladder_colour_kernel<code, false>)
-    const void *fn = a.code == kCodeToric ? QECMC_KC(kCodeToric) : a.code == kCodeXzzx ? QECMC_KC(kCodeXzzx)
+#define QECMC_KR(code, rule) (conv ? (const void *)ladder_colour_kernel<code, true, rule> : (const void *)ladder_colour_kernel<code, false, rule>)
+    const void *fn = a.noise == 1 ? (a.code == kCodeXzzx ? QECMC_KR(kCodeXzzx, 1) : QECMC_KR(kCodeRotated, 1))
+                   : a.noise == 2 ? (a.code == kCodeXzzx ? QECMC_KR(kCodeXzzx, 2) : QECMC_KR(kCodeRotated, 2))
+                   : a.code == kCodeToric ? QECMC_KC(kCodeToric) : a.code == kCodeXzzx ? QECMC_KC(kCodeXzzx)
                    : a.code == kCodeRotated ? QECMC_KC(kCodeRotated) : a.code == kCodePlanar ? QECMC_KC(kCodePlanar) : nullptr;
 #undef QECMC_KC
+#undef QECMC_KR
     if (!fn) return hipErrorInvalidValue;
-    const size_t lds = sizeof(uint32_t) * colour_lds_dwords(a.Nc, a.W, a.ncls, a.n_phases, a.n_gen, a.L, a.nq, a.swap_fast_ok != 0);
+    const size_t lds = sizeof(uint32_t) * colour_lds_dwords(a.Nc, a.W, a.ncls, a.n_phases, a.n_gen, a.L, a.nq, a.swap_fast_ok != 0, a.noise);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

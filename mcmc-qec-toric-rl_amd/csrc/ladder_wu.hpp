@@ -477,32 +477,47 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
                 const wu_const_ptr e = desc + (off >> 2);
                 if constexpr (top) {
                     const uint32_t A = (uint32_t)__builtin_amdgcn_readlane((int)((P & 1u) ? pa1 : pa0), (int)(P >> 1));
-                    if (thr16 != 0 && (A >> 16) < thr16) {
-                        // a logical operator (mcmc.py:23-24; toric_model.py:228-253, xzzx_model.py:340-357): into the frame
-                        const uint32_t B = (uint32_t)__builtin_amdgcn_readlane((int)((P & 1u) ? pb1 : pb0), (int)(P >> 1));
-                        const int LW = (L + 1) * WV;
-                        if constexpr (CODE == kCodeToric) {
-                            const uint32_t op0 = (A >> 14) & 3u, op1 = (A >> 12) & 3u;
-                            const uint32_t dx0 = (op0 ^ (op0 >> 1)) & 1u, dz0 = op0 >> 1, dx1 = (op1 ^ (op1 >> 1)) & 1u, dz1 = op1 >> 1;
-                            if (dx0) maskv ^= lml[(((A & 0xFFFu) * (uint32_t)L) >> 12) * WV + lane];
-                            if (dz0) maskv ^= lml[LW + (((B >> 21) * (uint32_t)L) >> 11) * WV + lane];
-                            if (dx1) maskv ^= lml[2 * LW + ((((B >> 10) & 0x7FFu) * (uint32_t)L) >> 11) * WV + lane];
-                            if (dz1) maskv ^= lml[3 * LW + (((B & 0x3FFu) * (uint32_t)L) >> 10) * WV + lane];
-                            if (L & 1) cdelta ^= dx0 | (dz0 << 1) | (dx1 << 2) | (dz1 << 3);
-                        } else {
-                            const uint32_t op = (A >> 14) & 3u;
-                            const uint32_t hx = (op ^ (op >> 1)) & 1u, hz = op >> 1;
-                            const uint32_t xp = hx ? ((A & 0x3FFFu) * (uint32_t)L) >> 14 : 0u, zp = hz ? ((B >> 16) * (uint32_t)L) >> 16 : 0u;
-                            const uint32_t ax = CODE == kCodeXzzx ? hx : (op & 1u), az = hz;
-                            if (ax) maskv ^= lml[xp * WV + lane];
-                            if (az) maskv ^= lml[LW + zp * WV + lane];
-                            cdelta ^= ax | (az << 1);
+                    // a logical operator (mcmc.py:23-24; toric_model.py:228-253, xzzx_model.py:340-357) goes into the frame; a stabilizer is applied
+                    // unseen (mcmc.py:30)
+#define QECMC_WU_LOGICAL()                                                                                                       \
+                        const uint32_t B = (uint32_t)__builtin_amdgcn_readlane((int)((P & 1u) ? pb1 : pb0), (int)(P >> 1)); \
+                        const int LW = (L + 1) * WV; \
+                        if constexpr (CODE == kCodeToric) { \
+                            const uint32_t op0 = (A >> 14) & 3u, op1 = (A >> 12) & 3u; \
+                            const uint32_t dx0 = (op0 ^ (op0 >> 1)) & 1u, dz0 = op0 >> 1, dx1 = (op1 ^ (op1 >> 1)) & 1u, dz1 = op1 >> 1; \
+                            if (dx0) maskv ^= lml[(((A & 0xFFFu) * (uint32_t)L) >> 12) * WV + lane]; \
+                            if (dz0) maskv ^= lml[LW + (((B >> 21) * (uint32_t)L) >> 11) * WV + lane]; \
+                            if (dx1) maskv ^= lml[2 * LW + ((((B >> 10) & 0x7FFu) * (uint32_t)L) >> 11) * WV + lane]; \
+                            if (dz1) maskv ^= lml[3 * LW + (((B & 0x3FFu) * (uint32_t)L) >> 10) * WV + lane]; \
+                            if (L & 1) cdelta ^= dx0 | (dz0 << 1) | (dx1 << 2) | (dz1 << 3); \
+                        } else { \
+                            const uint32_t op = (A >> 14) & 3u; \
+                            const uint32_t hx = (op ^ (op >> 1)) & 1u, hz = op >> 1; \
+                            const uint32_t xp = hx ? ((A & 0x3FFFu) * (uint32_t)L) >> 14 : 0u, zp = hz ? ((B >> 16) * (uint32_t)L) >> 16 : 0u; \
+                            const uint32_t ax = CODE == kCodeXzzx ? hx : (op & 1u), az = hz; \
+                            if (ax) maskv ^= lml[xp * WV + lane]; \
+                            if (az) maskv ^= lml[LW + zp * WV + lane]; \
+                            cdelta ^= ax | (az << 1); \
                         }
-                    } else {
-                        // a stabilizer, accepted unseen (mcmc.py:30)
-                        const uint32_t d0 = e[0], d1 = e[1], d2 = e[2], d3 = e[3], x0 = e[4], x1 = e[5], x2 = e[6], x3 = e[7];
+                    if constexpr (WV == 32) {
+                        // (32 words: a logical proposal passes through the stabilizer's XOR too, with zeros, so that the state tuple has ONE path
+                        // through the loop body -- a branch around an asm statement that updates the tuple makes the compiler merge two copies of it
+                        // where the paths meet, which at 32 words is a round trip of the whole state through scratch per step.  The narrower
+                        // kernels keep the branch: their merge costs nothing, and the unified form costs the headline kernel 8 B of scratch.)
+                        const bool logical = thr16 != 0 && (A >> 16) < thr16;
+                        if (logical) { QECMC_WU_LOGICAL() }
+                        const uint32_t d0 = e[0], d1 = e[1], d2 = e[2], d3 = e[3];
+                        const uint32_t x0 = logical ? 0u : e[4], x1 = logical ? 0u : e[5], x2 = logical ? 0u : e[6], x3 = logical ? 0u : e[7];
                         wu_xor<WV>(st, d0, d1, d2, d3, x0, x1, x2, x3);
+                    } else {
+                        if (thr16 != 0 && (A >> 16) < thr16) {
+                            QECMC_WU_LOGICAL()
+                        } else {
+                            const uint32_t d0 = e[0], d1 = e[1], d2 = e[2], d3 = e[3], x0 = e[4], x1 = e[5], x2 = e[6], x3 = e[7];
+                            wu_xor<WV>(st, d0, d1, d2, d3, x0, x1, x2, x3);
+                        }
                     }
+#undef QECMC_WU_LOGICAL
                 } else {
                     const uint32_t j = c * 10u + (uint32_t)f;
                     if constexpr (IT == 10) {
@@ -1039,6 +1054,9 @@ inline const void *wu_pick(int variant, int Nc, int W, uint32_t iters)
     const bool it10 = CODE == kCodeToric && iters == 10u && Nc * 64 <= 512;
     if constexpr (CODE == kCodeToric) {
         if (it10) return variant == 2 ? wu_pick_it<CODE, true, true, 10>(Nc, W) : wu_pick_it<CODE, false, false, 10>(Nc, W);
+    } else if constexpr (CODE != kCodePlanar) {
+        // (the 32-word kernels of the one-layer codes -- rotated L = 21 is BASELINE config 5 -- have the unrolled loop too)
+        if (W > 16 && iters == 10u && variant == 0 && Nc * 64 <= 512) return (const void *)ladder_wu_kernel<512, 6, CODE, 32, false, false, 10>;
     }
     return variant == 2 ? wu_pick_it<CODE, true, true, 0>(Nc, W) : wu_pick_it<CODE, false, false, 0>(Nc, W);
 }

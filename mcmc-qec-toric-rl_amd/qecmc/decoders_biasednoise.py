@@ -4,13 +4,16 @@ from .decoders import _pteq
 
 
 def PTEQ_biased(init_code, p, eta=0.5, Nc=None, SEQ=2, TOPS=10, tops_burn=2, eps=0.1, steps=50000000, iters=10,
-                conv_criteria='error_based', seed=None, replicas=None):
-    return _pteq(init_code, p, eta, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, conv_criteria, seed, replicas=replicas)
+                conv_criteria='error_based', seed=None, replicas=None, scan="random"):
+    """decoders_biasednoise.PTEQ_biased (:28-90).  scan="colour": the one-syndrome latency layout (a workgroup per ladder, a colour phase of
+    generators per wavefront pass; every generator a Metropolis move for the biased weight -- the reference's rule at iters = 1)."""
+    return _pteq(init_code, p, eta, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, conv_criteria, seed, replicas=replicas, scan=scan)
 
 
 def PTEQ_alpha(init_code, pz_tilde, alpha=1, Nc=None, SEQ=2, TOPS=10, tops_burn=2, eps=0.1, steps=50000000, iters=10,
-               conv_criteria='error_based', seed=None, replicas=None):
-    return _pteq(init_code, pz_tilde, None, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, conv_criteria, seed, alpha=alpha, replicas=replicas)
+               conv_criteria='error_based', seed=None, replicas=None, scan="random"):
+    """decoders_biasednoise.PTEQ_alpha (:175-238).  scan="colour": the one-syndrome latency layout; scan="wave": the batched throughput layout."""
+    return _pteq(init_code, pz_tilde, None, Nc, SEQ, TOPS, tops_burn, eps, steps, iters, conv_criteria, seed, alpha=alpha, replicas=replicas, scan=scan)
 
 
 def _shortest_loop(ladder, pz_tilde, SEQ, TOPS, tops_burn, eps, steps, iters, conv_criteria):

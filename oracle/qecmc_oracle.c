@@ -642,6 +642,52 @@ static double biased_weight(const uint8_t *s, int nq, double px, double py, doub
     return pow(px, (double)nx) * pow(py, (double)ny) * pow(pz, (double)nz) * pow(1 - px - py - pz, (double)(nq - nx - ny - nz));
 }
 
+/* scan = 2 (colour phases) under the biased / alpha rules.  The members of a phase are tested "at once", so the rule cannot carry Q3's
+ * frozen p_b (a member's ratio would depend on what the members before it did): every generator is a Metropolis move for the noise
+ * model's own weight, u < w(s ^ g) / w(s) = (px / pI)^dxy (pz / pI)^dz with (dxy, dz) the change of n_x + n_y and n_z of that generator
+ * alone (px = py in both models; mcmc_biased.py:25-31, mcmc_alpha.py:31-36) -- the law the reference's rule has at iters = 1, where Q3 is
+ * vacuous.  `coin`: a rung whose ratios are all 1 (Ladder_alpha's top, pz_tilde = 1) applies every generator with probability 1/2 and
+ * its logical operators unseen, like the depolarizing top rung; any other top rung tests a logical operator like every move,
+ * u = word 0 of block (k, 1) < w(new) / w(old) on the power tables' products (biased_weight).  Returns whether a move was accepted. */
+static int chain_update_colour_rule(const orc_model *m, uint8_t *state, double px, double py, double pz, int coin, double p_logical,
+                                    uint64_t iters, orc_rng *rng, uint32_t slot, uint64_t k0, uint8_t *scratch)
+{
+    const size_t nq = (size_t)orc_nq(m->code, m->L);
+    const double pi = 1 - px - py - pz;
+    const double fxy = px / pi, fz = pz / pi;
+    const colour_phases_t *ph = colour_phases(m);
+    int accepted = 0;
+    if (!ph) abort();
+    for (uint64_t j = 0; j < iters; ++j) {
+        const uint64_t k = k0 + j;
+        if (p_logical != 0 && orc_draw(rng, slot, k, 0, 0) < p_logical) {
+            model_random_logical(m, state, scratch, rng, slot, k);
+            if (coin || orc_draw(rng, slot, k, 1, 0) < biased_weight(scratch, (int)nq, px, py, pz) / biased_weight(state, (int)nq, px, py, pz)) {
+                memcpy(state, scratch, nq);
+                accepted = 1;
+            }
+        }
+        const int *members = ph->tab + (size_t)(k % (uint64_t)ph->n_phases) * 64;
+        for (int i = 0; i < 64; ++i) {
+            if (members[i] < 0) continue;
+            model_sweep_stabilizer(m, state, scratch, (uint64_t)members[i]);
+            const double u = orc_draw(rng, slot, k >> 2, 8u + (uint32_t)i, (int)(k & 3));
+            int acc;
+            if (coin) acc = u >= 0.5;
+            else {
+                int dz = 0, dxy = 0;
+                for (size_t q = 0; q < nq; ++q) {
+                    dz += (scratch[q] == 3) - (state[q] == 3);
+                    dxy += (scratch[q] == 1 || scratch[q] == 2) - (state[q] == 1 || state[q] == 2);
+                }
+                acc = u < pow(fxy, (double)dxy) * pow(fz, (double)dz);
+            }
+            if (acc) { memcpy(state, scratch, nq); accepted = 1; }
+        }
+    }
+    return accepted;
+}
+
 /* exp(y) for y <= 0 from IEEE add / multiply / fma only, so the GPU (same operation sequence) returns the same bits.
  * y >= 0 returns 1 (the callers only need to know the value is >= 1); results below 2^-1022 flush to 0. */
 double orc_det_exp(double y)
@@ -733,6 +779,16 @@ int orc_chain_update_alpha(const orc_model *m, uint8_t *state, double pz_tilde, 
     const double p = p_tilde / (1 + p_tilde);                                           /* :34 */
     const double pz = pz_tilde * (1 - p), px = pow(pz_tilde, alpha) * (1 - p), py = px; /* :35-36 */
     if (m->scan == 3) return chain_update_wave_alpha(m, state, pz_tilde, p_logical, iters, rng, slot, k0, scratch, n_eff);
+    if (m->scan == 2) {
+        /* (the attribute follows an accepted move, :58,:70: after the call it is the final configuration's if any move was accepted) */
+        const int acc = chain_update_colour_rule(m, state, px, py, pz, pz_tilde >= 1.0, p_logical, iters, rng, slot, k0, scratch);
+        if (acc) {
+            int nx = 0, ny = 0, nz = 0;
+            for (size_t i = 0; i < nq; ++i) { nx += state[i] == 1; ny += state[i] == 2; nz += state[i] == 3; }
+            *n_eff = nz + alpha * (nx + ny);
+        }
+        return acc;
+    }
     const double pb = biased_weight(state, (int)nq, px, py, pz);                        /* :38-41 */
     int accepted = 0;
     for (uint64_t j = 0; j < iters; ++j) {
@@ -778,6 +834,7 @@ void orc_chain_update(const orc_model *m, uint8_t *state, double p, double p_log
          * refreshed after an accept (reference quirk Q3, reproduced). */
         const double eta = m->eta;
         const double pz = p * eta / (eta + 1), px = p / (2 * (eta + 1)), py = px;      /* :25-27 */
+        if (m->scan == 2) { chain_update_colour_rule(m, state, px, py, pz, 0, p_logical, iters, rng, slot, k0, scratch); return; }
         const double pb = biased_weight(state, (int)nq, px, py, pz);                    /* :28-31 */
         for (uint64_t j = 0; j < iters; ++j) {
             uint64_t k = k0 + j;

@@ -47,7 +47,10 @@ CASES = [  # name, L, Nc, N, steps, iters, p, p_logical, replicas, first_syndrom
     ("toric", 5, 5, 3, 300, 10, 0.10, 0.0, 1, 0),                                                     # no logical moves (PTDC's ladders)
     ("toric", 10, 4, 2, 40, 25, 0.15, 0.5, 1, 0), ("toric", 9, 9, 3, 80, 10, 0.15, 0.5, 1, 0),        # 13 of 16 words; 9 rungs: 1024-thread groups
     ("xzzx", 9, 8, 5, 150, 10, 0.15, 0.5, 1, 0), ("rotated", 7, 7, 4, 150, 10, 0.17, 0.5, 1, 0), ("rotated", 15, 8, 2, 30, 10, 0.17, 0.5, 1, 0),
-    ("planar", 5, 5, 4, 150, 10, 0.12, 0.5, 1, 0), ("xzzx", 3, 2, 7, 300, 5, 0.2, 0.5, 2, 64), ("planar", 9, 8, 3, 100, 10, 0.12, 0.5, 1, 0)]
+    ("planar", 5, 5, 4, 150, 10, 0.12, 0.5, 1, 0), ("xzzx", 3, 2, 7, 300, 5, 0.2, 0.5, 2, 64), ("planar", 9, 8, 3, 100, 10, 0.12, 0.5, 1, 0),
+    # 17 .. 32 state words per rung: the 32-word kernels (6 waves per SIMD, the state through the exchange buffer in two halves)
+    ("toric", 15, 8, 3, 40, 10, 0.18, 0.5, 1, 0), ("toric", 16, 6, 2, 30, 7, 0.15, 0.5, 1, 64), ("toric", 12, 8, 70, 30, 10, 0.15, 0.5, 1, 0),   # W = 29, 32, 18
+    ("rotated", 21, 8, 3, 40, 10, 0.17, 0.5, 1, 0), ("xzzx", 17, 5, 2, 40, 10, 0.15, 0.5, 2, 0), ("rotated", 19, 2, 3, 50, 3, 0.1, 1.0, 1, 128)]
 
 
 @pytest.mark.parametrize("name,L,Nc,N,steps,iters,p,p_logical,R,first", CASES)
@@ -155,7 +158,11 @@ def test_wave_scan_rejects_what_it_does_not_do(q):
     with pytest.raises(q.QecmcError):
         q.pteq_batch(init, 0.1, Nc=5, steps=100, scan="wave", first_syndrome=7)       # a wavefront is one pick group
     with pytest.raises(q.QecmcError):
-        q.pteq_batch(np.zeros((2, 2, 15, 15), np.uint8), 0.18, Nc=8, steps=10, scan="wave")   # 29 words per rung: the scan = 0 kernels' ground
+        q.pteq_batch(np.zeros((2, 2, 15, 15), np.uint8), 0.18, Nc=8, steps=10, scan="wave", conv_criteria="error_based")   # 29 words per rung: fixed-length runs only
+    with pytest.raises(q.QecmcError):
+        q.pteq_batch(np.zeros((2, 2, 15, 15), np.uint8), 0.18, Nc=9, steps=10, scan="wave")   # ... of at most 8 rungs
+    with pytest.raises(q.QecmcError):
+        q.pteq_batch(np.zeros((2, 2, 17, 17), np.uint8), 0.18, Nc=4, steps=10, scan="wave")   # 37 words per rung
     with pytest.raises(q.QecmcError):                                                  # the criterion runs reuse lanes: no final states
         q.pteq_batch(init, 0.1, Nc=5, steps=100, scan="wave", conv_criteria="error_based", return_states=True)
 

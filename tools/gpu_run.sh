@@ -13,11 +13,11 @@ import json,sys; d=json.loads(sys.stdin.read()); print('$tag', '%.3e prop/s' % d
 case "$1" in
   wave-first)   # first contact of the scan = wave kernel: its parity tests, then A/B against the random scan on the headline shape
     timeout -k 10 900 python -m pytest tests/test_gpu_wave.py -x -q > gpurun_out/wave_tests.log 2>&1; rc=$?; tail -15 gpurun_out/wave_tests.log
-    [ $rc -eq 0 ] && b cfg2_random --config 2 && b cfg2_wave --config 2 --scan wave && b cfg2_random_b --config 2 && b cfg2_wave_b --config 2 --scan wave
+    [ $rc -eq 0 ] && b cfg2_random --config 2 --scan random && b cfg2_wave --config 2 --scan wave && b cfg2_random_b --config 2 --scan random && b cfg2_wave_b --config 2 --scan wave
     ;;
   wave-cfgs)    # scan = wave against the random scan on BASELINE configurations 2, 3, 5 (same box, alternating)
     timeout -k 10 900 python -m pytest tests/test_gpu_wave.py -x -q > gpurun_out/wave_tests.log 2>&1; rc=$?; tail -5 gpurun_out/wave_tests.log
-    [ $rc -eq 0 ] && for c in 2 3 5; do b cfg${c}_random --config $c && b cfg${c}_wave --config $c --scan wave || exit 1; done
+    [ $rc -eq 0 ] && for c in 2 3 5; do b cfg${c}_random --config $c --scan random && b cfg${c}_wave --config $c --scan wave || exit 1; done
     ;;
   tests)        # tests [pytest args]: the GPU suite (or part of it)
     shift
