@@ -50,15 +50,19 @@ typedef enum qecmc_code { QECMC_TORIC = 0, QECMC_XZZX = 1, QECMC_ROTATED = 2, QE
 /* COLOUR: the latency layout -- one workgroup per ladder, one wavefront per rung, the lanes of a wavefront = the generators of
  * one colour phase (mutually disjoint, so their Metropolis tests are independent), proposed at once: a sweep is n_phases wavefront
  * passes instead of G sequential proposals.  A systematic scan like SWEEP (same stationary law, not the reference's chain);
- * depolarizing rule; `iters` counts phases; fixed-length runs report the first step with tops0 >= TOPS in steps_done / converged,
- * conv_mode error_based runs the reference's criterion. */
+ * `iters` counts phases; fixed-length runs report the first step with tops0 >= TOPS in steps_done / converged,
+ * conv_mode error_based runs the reference's criterion.  Under the biased and alpha rules (xzzx / rotated codes) every
+ * generator is a Metropolis move for the noise model's own weight px^nx py^ny pz^nz pI^nI -- the reference's rule at iters = 1: the members
+ * of a phase are tested at once, so the p_b that mcmc_biased.py:28-31 / mcmc_alpha.py:38-41 freeze per update_chain call cannot be
+ * carried --; the biased top rung tests its logical operators, Ladder_alpha's top rung (pz_tilde = 1) takes the coin. */
 /* WAVE: the reference's random scan (src/mcmc.py:19-43) with ONE generator pick per proposal shared by the 64 ladders of a wavefront
  * (global ladder indices that agree above bit 6), every ladder keeping its own acceptance uniform.  toric_model.py:287-296 picks the
  * generator independently of the state and syndromes never interact, so each ladder's chain has exactly the reference's law -- unlike
  * SWEEP / COLOUR this IS the reference's Markov chain per syndrome; only the noise of different syndromes is correlated.  What it buys:
- * a proposal's sites are wave-uniform, so the rungs' states live in registers.  Depolarizing rule, a top rung at
- * p = 0.75 (Nc >= 2), first_syndrome a multiple of 64, at most 16 packed state words per rung (toric / planar L <= 11, xzzx / rotated
- * L <= 16: beyond, the RANDOM kernels are as fast), 1 <= iters <= 128.  With conv_mode error_based the launch runs on a persistent grid
+ * a proposal's sites are wave-uniform, so the rungs' states live in registers.  Depolarizing rule with a top rung at
+ * p = 0.75 (Nc >= 2), at most 16 packed state words per rung (toric / planar L <= 11, xzzx / rotated L <= 16) -- fixed-length runs of
+ * up to 8 rungs also 17 .. 32 words (toric L <= 16, xzzx / rotated L <= 22) --, and the alpha rule (xzzx / rotated L <= 11, Nc <= 8);
+ * first_syndrome a multiple of 64, 1 <= iters <= 128.  With conv_mode error_based the launch runs on a persistent grid
  * whose workgroups own contiguous shares of the batch and reuse the lane of a stopped ladder for the next one of their share: the
  * generator picks then belong to the lane's position in the grid, so results are reproducible for a given (batch size, grid,
  * first_syndrome) and equal to the one-ladder-per-lane layout whenever the batch fits the grid; no final states in that mode. */

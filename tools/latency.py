@@ -42,6 +42,34 @@ def default_stop(init, p, Nc, **kw):
                 kernel_ms_all_horizons=tot_k, wall_ms=(time.perf_counter() - t0) * 1e3, argmax=int(np.argmax(r["counts"][0])))
 
 
+def biased_rows():
+    """--biased: config 4's shape as the reference decodes it, one syndrome per call (generate_data.py:136-150): xzzx L = 9, errors at p = 0.15, eta = 100,
+    decoded by PTEQ_biased (eta) and by PTEQ_alpha with (pz_tilde, alpha) derived from them -- lane-per-chain against the colour phases"""
+    from qecmc import harness
+    res = {"note": "xzzx L=9, errors at p=0.15 eta=100, Nc=9 (the reference's default Nc = L); one syndrome per call; kernel_ms = the kernel alone"}
+    rng = np.random.default_rng(7)
+    raw = harness.draw_errors(q.XZZX, 9, 4, 0.15, rng, eta=100.0)
+    inits = harness.hide_class(q.XZZX, raw, rng)
+    pzt, al = harness.biased_as_alpha(0.15, 100.0)
+    q.pteq_batch(inits[:1], 0.15, Nc=5, steps=10, code=q.XZZX, eta=100.0)
+    for label, pdec, kw in (("PTEQ_biased(eta=100)", 0.15, dict(code=q.XZZX, eta=100.0)), ("PTEQ_alpha(pz_tilde=%.4g, alpha=%.4g)" % (pzt, al), float(pzt), dict(code=q.XZZX, alpha=float(al)))):
+        rows = []
+        for s in range(4):
+            init = inits[s:s + 1]
+            row = {"syndrome": s}
+            for name, extra in (("lane_per_chain", {}), ("colour_parallel", dict(scan="colour"))):
+                if name == "lane_per_chain" and "--only-colour" in sys.argv:
+                    continue
+                row[name] = {"to_tops0_ge_10": first_step_with_tops(init, pdec, 9, 10, **kw, **extra), "default_stop": default_stop(init, pdec, 9, **kw, **extra)}
+            rows.append(row)
+            print(label, json.dumps(row), file=sys.stderr, flush=True)
+        res[label] = rows
+    return res
+
+
+if "--biased" in sys.argv:
+    print(json.dumps(biased_rows(), indent=1))
+    sys.exit(0)
 out = {"note": "one syndrome per call; lane-per-chain layout = the reference's random scan (scan=random); times include the "
                "host-pointer boundary (H2D, launch, D2H) in wall_ms and the kernel alone in kernel_ms"}
 q.pteq_batch(bench.synth_batch(1, 5, 0.1, 1), 0.1, Nc=5, steps=10)          # load the library, warm the context
