@@ -58,8 +58,10 @@ __device__ __forceinline__ int wave_sum(int v)
 #define QECMC_CSTAMP(k) ((void)0)
 #endif
 
-template <int CODE, bool CONV, int RULE = 0>
-__global__ __launch_bounds__(1024) void ladder_colour_kernel(const LadderArgs a)
+// MAXT / MINW: ladders of up to 8 rungs are built for 512 threads at 8 waves per SIMD (64 VGPRs: four workgroups per CU instead of two -- a lone
+// workgroup's step is a dependent chain, so the throughput of many ladders is what the CU can keep resident), longer ladders for 1 024 at 4
+template <int CODE, bool CONV, int RULE = 0, int MAXT = 1024, int MINW = 4>
+__global__ __launch_bounds__(MAXT, MINW) void ladder_colour_kernel(const LadderArgs a)
 {
     static_assert(RULE == 0 || CODE == kCodeXzzx || CODE == kCodeRotated, "the biased / alpha rules: xzzx and rotated codes");
     extern __shared__ uint32_t lds[];
@@ -475,8 +477,13 @@ hipError_t launch_ladder_colour(const LadderArgs &a, hipStream_t stream)
     if (a.noise != 0 && (a.col_thr == nullptr || a.bias_tbl == nullptr || (a.code != kCodeXzzx && a.code != kCodeRotated) || (a.noise == 2 && a.alpha_lnb == nullptr)))
         return hipErrorInvalidValue;
     const bool conv = a.conv_mode != 0;
-#define QECMC_KC(code) (conv ? (const void *)ladder_colour_kernel<code, true> : (const void *)ladder_colour_kernel<code, false>)
-#define QECMC_KR(code, rule) (conv ? (const void *)ladder_colour_kernel<code, true, rule> : (const void *)ladder_colour_kernel<code, false, rule>)
+#ifndef QECMC_COLOUR_SMALL_MINW
+#define QECMC_COLOUR_SMALL_MINW 8
+#endif
+    const bool small = a.Nc <= 8 && QECMC_COLOUR_SMALL_MINW != 4;
+#define QECMC_KR(code, rule) (small ? (conv ? (const void *)ladder_colour_kernel<code, true, rule, 512, QECMC_COLOUR_SMALL_MINW> : (const void *)ladder_colour_kernel<code, false, rule, 512, QECMC_COLOUR_SMALL_MINW>) \
+                                    : (conv ? (const void *)ladder_colour_kernel<code, true, rule> : (const void *)ladder_colour_kernel<code, false, rule>))
+#define QECMC_KC(code) QECMC_KR(code, 0)
     const void *fn = a.noise == 1 ? (a.code == kCodeXzzx ? QECMC_KR(kCodeXzzx, 1) : QECMC_KR(kCodeRotated, 1))
                    : a.noise == 2 ? (a.code == kCodeXzzx ? QECMC_KR(kCodeXzzx, 2) : QECMC_KR(kCodeRotated, 2))
                    : a.code == kCodeToric ? QECMC_KC(kCodeToric) : a.code == kCodeXzzx ? QECMC_KC(kCodeXzzx)

@@ -36,6 +36,9 @@ def draw_case(rng):
         noise = rng.choice(["biased", "alpha"])
     u = rng.random()
     scan = "random" if noise != "depolarizing" else "sweep" if u < 0.15 else "colour" if (u < 0.3 and Nc >= 2) else "random"
+    # (round 4) the colour phases under the biased / alpha rules (Ladder_alpha needs its top rung: Nc >= 2)
+    if noise != "depolarizing" and (noise == "biased" or Nc >= 2) and rng.random() < 0.3:
+        scan = "colour"
     # (round 4) scan = wave where it is built: the depolarizing rule up to 16 state words per rung, the alpha rule up to 8 words and 8 rungs
     W = (nq + 15) // 16
     if Nc >= 2 and ((noise == "depolarizing" and W <= 16) or (noise == "alpha" and W <= 8 and Nc <= 8)) and rng.random() < (0.6 if noise == "alpha" else 0.3):
