@@ -58,8 +58,7 @@ __device__ __forceinline__ int wave_sum(int v)
 #define QECMC_CSTAMP(k) ((void)0)
 #endif
 
-// MAXT / MINW: ladders of up to 8 rungs are built for 512 threads at 8 waves per SIMD (64 VGPRs: four workgroups per CU instead of two -- a lone
-// workgroup's step is a dependent chain, so the throughput of many ladders is what the CU can keep resident), longer ladders for 1 024 at 4
+// MAXT / MINW: 1 024 threads at 4 waves per SIMD (a development build can give ladders of up to 8 rungs 512 threads at 6 or 8: launch_ladder_colour)
 template <int CODE, bool CONV, int RULE = 0, int MAXT = 1024, int MINW = 4>
 __global__ __launch_bounds__(MAXT, MINW) void ladder_colour_kernel(const LadderArgs a)
 {
@@ -477,12 +476,19 @@ hipError_t launch_ladder_colour(const LadderArgs &a, hipStream_t stream)
     if (a.noise != 0 && (a.col_thr == nullptr || a.bias_tbl == nullptr || (a.code != kCodeXzzx && a.code != kCodeRotated) || (a.noise == 2 && a.alpha_lnb == nullptr)))
         return hipErrorInvalidValue;
     const bool conv = a.conv_mode != 0;
+    // (development knob: -DQECMC_COLOUR_SMALL_MINW=6|8 builds ladders of up to 8 rungs for 512 threads at that many waves per SIMD -- three / four
+    // workgroups per CU instead of two.  Measured, profiles/r04_colour_occupancy_ab.json: +15 ... 28 % ladder steps per second from 1 024 ladders on,
+    // -8 % at 256 and below (20-160 B of scratch on a lone workgroup's path): the layout exists for few syndromes, so the default stays 4.)
 #ifndef QECMC_COLOUR_SMALL_MINW
-#define QECMC_COLOUR_SMALL_MINW 8
+#define QECMC_COLOUR_SMALL_MINW 4
 #endif
-    const bool small = a.Nc <= 8 && QECMC_COLOUR_SMALL_MINW != 4;
+#if QECMC_COLOUR_SMALL_MINW != 4
+    const bool small = a.Nc <= 8;
 #define QECMC_KR(code, rule) (small ? (conv ? (const void *)ladder_colour_kernel<code, true, rule, 512, QECMC_COLOUR_SMALL_MINW> : (const void *)ladder_colour_kernel<code, false, rule, 512, QECMC_COLOUR_SMALL_MINW>) \
                                     : (conv ? (const void *)ladder_colour_kernel<code, true, rule> : (const void *)ladder_colour_kernel<code, false, rule>))
+#else
+#define QECMC_KR(code, rule) (conv ? (const void *)ladder_colour_kernel<code, true, rule> : (const void *)ladder_colour_kernel<code, false, rule>)
+#endif
 #define QECMC_KC(code) QECMC_KR(code, 0)
     const void *fn = a.noise == 1 ? (a.code == kCodeXzzx ? QECMC_KR(kCodeXzzx, 1) : QECMC_KR(kCodeRotated, 1))
                    : a.noise == 2 ? (a.code == kCodeXzzx ? QECMC_KR(kCodeXzzx, 2) : QECMC_KR(kCodeRotated, 2))
