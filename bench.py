@@ -535,7 +535,7 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": workload, "baseline_config": args.config,
                        "syndromes_per_gpu": N, "code": args.code, "L": L, "p": args.p, "eta": args.eta, "Nc": Nc, "iters": args.iters,
-                       "ladder_steps": args.ladder_steps, "tops_burn": 2, "seed": args.seed,
+                       "ladder_steps": args.ladder_steps, "tops_burn": 2, "seed": args.seed, "scan": args.scan,
                        "lds_bytes_per_workgroup": lds.value, "threads_per_workgroup": threads.value,
                        "parallelism": "syndrome shards x%d, RCCL gather of class counts" % world},
             "proposals_per_s": total_proposals / elapsed,
