@@ -19,11 +19,15 @@ import socket
 import numpy as np
 
 
-def shard_bounds(n_total, world_size, rank):
-    """Contiguous shard [lo, hi) of `rank`; sizes differ by at most one."""
-    base, extra = divmod(int(n_total), int(world_size))
+def shard_bounds(n_total, world_size, rank, align=1):
+    """Contiguous shard [lo, hi) of `rank`; sizes differ by at most one unit of `align` syndromes (align = 64 for scan = "wave", whose
+    wavefronts share their generator picks: a shard must begin on a multiple of 64 of the global index; the last shard takes the ragged end)."""
+    n_total, align = int(n_total), int(align)
+    units = (n_total + align - 1) // align
+    base, extra = divmod(units, int(world_size))
     lo = rank * base + min(rank, extra)
-    return lo, lo + base + (1 if rank < extra else 0)
+    hi = lo + base + (1 if rank < extra else 0)
+    return min(lo * align, n_total), min(hi * align, n_total)
 
 
 def free_port():
@@ -133,7 +137,11 @@ class PteqShard:
         L_.check(L_.lib().qecmc_plan_create(self.pr, C.byref(self.plan)))
         self.d_init = torch.from_numpy(a.reshape(self.n, int(np.prod(a.shape[1:])))).to(self.dev)
         self.n_total = int(n_total if n_total is not None else self.n * self.world)
-        self.max_rows = (self.n_total + self.world - 1) // self.world       # equal-size buffers for the collective
+        if isinstance(params.get("scan"), str):
+            params["scan"] = L_.SCANS[params["scan"]]
+        self.align = 64 if params.get("scan") == L_.SCAN_WAVE else 1
+        self.max_rows = max(shard_bounds(self.n_total, self.world, r, self.align)[1] - shard_bounds(self.n_total, self.world, r, self.align)[0]
+                            for r in range(self.world))                                # equal-size buffers for the collective
         self.rec = torch.zeros(self.max_rows * (self.ncls + 2), dtype=torch.int32, device=self.dev)
         self.gathered = ([torch.empty_like(self.rec) for _ in range(self.world)]
                          if (self.dist_on and self.rank == dst) else None)
@@ -177,7 +185,7 @@ class PteqShard:
         recs = self.gathered if self.dist_on else [self.rec]
         out = [[], [], []]
         for r, rec in enumerate(recs):
-            lo, hi = shard_bounds(self.n_total, self.world, r) if self.dist_on else (0, self.n)
+            lo, hi = shard_bounds(self.n_total, self.world, r, self.align) if self.dist_on else (0, self.n)
             for o, v in zip(out, self.views(rec, hi - lo)):
                 o.append(v.cpu().numpy().view(np.uint32))
         return dict(counts=np.concatenate(out[0]), samples=np.concatenate(out[1]), tops0=np.concatenate(out[2]))
@@ -208,7 +216,8 @@ def pteq_batch_sharded(init, p, compute=None, group=None, dst=0, **kw):
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     n_total = int(np.asarray(init).shape[0])
-    lo, hi = shard_bounds(n_total, world, rank)
+    align = 64 if kw.get("scan") in ("wave", 3) else 1
+    lo, hi = shard_bounds(n_total, world, rank, align)
     first = int(kw.pop("first_syndrome", 0))
     if compute is None:
         kw.pop("device", None)
@@ -224,7 +233,7 @@ def pteq_batch_sharded(init, p, compute=None, group=None, dst=0, **kw):
     # one packed record per syndrome: ncls class counts + samples + tops0 (uint32 -> int64-safe int32 view)
     rec = np.concatenate([res["counts"].astype(np.uint32), res["samples"].astype(np.uint32)[:, None],
                           res["tops0"].astype(np.uint32)[:, None]], axis=1)
-    max_rows = (n_total + world - 1) // world          # equal-size buffers for the collective
+    max_rows = max(shard_bounds(n_total, world, r, align)[1] - shard_bounds(n_total, world, r, align)[0] for r in range(world))   # equal-size buffers for the collective
     buf = np.zeros((max_rows, ncls + 2), dtype=np.uint32)
     buf[:hi - lo] = rec
     t = torch.from_numpy(buf.view(np.int32))
@@ -236,6 +245,6 @@ def pteq_batch_sharded(init, p, compute=None, group=None, dst=0, **kw):
         return None
     out = np.zeros((n_total, ncls + 2), dtype=np.uint32)
     for r in range(world):
-        rlo, rhi = shard_bounds(n_total, world, r)
+        rlo, rhi = shard_bounds(n_total, world, r, align)
         out[rlo:rhi] = gathered[r].cpu().numpy().view(np.uint32)[:rhi - rlo]
     return dict(counts=out[:, :ncls].copy(), samples=out[:, ncls].copy(), tops0=out[:, ncls + 1].copy())

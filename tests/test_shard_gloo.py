@@ -20,14 +20,16 @@ def _free_port():
     return p
 
 
-def _oracle_compute(init, p, first_syndrome=0, Nc=None, steps=100, iters=10, tops_burn=2, seed=0, **_):
+def _oracle_compute(init, p, first_syndrome=0, Nc=None, steps=100, iters=10, tops_burn=2, seed=0, scan=None, **_):
     from oracle import oracle as orc
-    r = orc.toric_pteq_batch(init, p, Nc, steps, iters=iters, tops_burn=tops_burn, seed=seed,
-                             first_syndrome=first_syndrome, n_threads=1)
+    if scan == "wave" and len(init):
+        assert first_syndrome % 64 == 0                 # a wavefront is one pick group: a shard begins on a multiple of 64
+    r = orc.pteq_batch(orc.TORIC, init, p, Nc, steps, iters=iters, tops_burn=tops_burn, seed=seed, first_syndrome=first_syndrome, n_threads=1,
+                       scan=3 if scan == "wave" else 0) if len(init) else dict(counts=np.zeros((0, 16), np.uint32), samples=np.zeros(0, np.uint64), tops0=np.zeros(0, np.uint64))
     return dict(counts=r["counts"], samples=r["samples"], tops0=r["tops0"])
 
 
-def _worker(rank, world, port, n_total, q):
+def _worker(rank, world, port, n_total, q, scan=None):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "mcmc-qec-toric-rl_amd"))
     import torch.distributed as dist
@@ -37,9 +39,10 @@ def _worker(rank, world, port, n_total, q):
     init = np.zeros((n_total, 2, 3, 3), dtype=np.uint8)
     err = rng.random(init.shape) < 0.15
     init[err] = rng.integers(1, 4, size=int(err.sum()), dtype=np.uint8)
-    out = pteq_batch_sharded(init, 0.1, compute=_oracle_compute, Nc=3, steps=60, tops_burn=0, seed=7)
+    kw = dict(scan=scan) if scan else {}
+    out = pteq_batch_sharded(init, 0.1, compute=_oracle_compute, Nc=3, steps=60, tops_burn=0, seed=7, **kw)
     if rank == 0:
-        full = _oracle_compute(init, 0.1, Nc=3, steps=60, tops_burn=0, seed=7)
+        full = _oracle_compute(init, 0.1, Nc=3, steps=60, tops_burn=0, seed=7, **kw)
         ok = all(np.array_equal(out[k], full[k].astype(np.uint32)) for k in ("counts", "samples", "tops0"))
         q.put(bool(ok))
     else:
@@ -48,12 +51,13 @@ def _worker(rank, world, port, n_total, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_total", [(2, 11), (2, 8), (3, 10)])
-def test_sharded_equals_unsharded(world, n_total):
+@pytest.mark.parametrize("world,n_total,scan", [(2, 11, None), (2, 8, None), (3, 10, None), (2, 200, "wave"), (3, 70, "wave")])
+def test_sharded_equals_unsharded(world, n_total, scan):
+    """(scan = "wave": shards of whole groups of 64, the ragged end in the last non-empty one; a rank may get nothing)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, q, scan)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -71,3 +75,8 @@ def test_shard_bounds_cover_everything():
             assert b[0][0] == 0 and b[-1][1] == n
             assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
             assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
+            # scan = "wave": shards begin on multiples of 64 of the global index (a wavefront is one pick group); the ragged end goes to the last one that has any
+            a = [shard_bounds(n, w, r, 64) for r in range(w)]
+            assert a[0][0] == 0 and a[-1][1] == n and all(a[i][1] == a[i + 1][0] for i in range(w - 1))
+            assert all(l % 64 == 0 or l == n for l, _ in a) and all(0 <= h - l for l, h in a)
+            assert max(h - l for l, h in a) - min(h - l for l, h in a) <= 64 + 63
