@@ -606,10 +606,21 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
         [[maybe_unused]] wu_lds_dptr const lnbd = (wu_lds_dptr)(ldsl + ol.lnb);
         const uint32_t xaddr = lds0l + (uint32_t)lane * 4u;
         const uint32_t xstride = (uint32_t)(WV == 32 ? kWuHalf : Wl) * 256u;          // bytes of one rung in the exchange buffer
+#ifdef QECMC_WU_TOP_SWAPS
+        // the swap uniforms -- block b = pairs 4 b .. 4 b + 3 -- are all drawn by the TOP rung's wave, whose step is the shortest
+        const int nblk = (NC - 1 + 3) >> 2;
+        u32x4 sbs[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+        if constexpr (TOP) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                if (b < nblk) sbs[b] = wu_philox(T, (uint32_t)b, syn, kSwapStream, a.seed_lo, a.seed_hi);
+        }
+#else
         const int swb = NC - 1 - (int)slot;                 // the top rungs draw the swap uniforms: block swb = pairs 4 swb .. 4 swb + 3
         u32x4 sb{0, 0, 0, 0};
         const bool duty = swb >= 0 && swb < 4 && swb * 4 < NC - 1;
         if (duty) sb = wu_philox(T, (uint32_t)swb, syn, kSwapStream, a.seed_lo, a.seed_hi);
+#endif
         __syncthreads();                                   // (everybody has read the exchange buffer and the swap uniforms of the step before)
         {
             const uint32_t xo = xaddr + slot * xstride;
@@ -619,6 +630,20 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
             WU_EACH(QECMC_WU_PUT)
             rec[slot * 64u + (uint32_t)lane] = pack_info(n4 >> 2, slot, cls, flag);
             if constexpr (ALPHA) nefd[slot * 64u] = wu_neff(nef, a.alpha);
+#ifdef QECMC_WU_TOP_SWAPS
+            if constexpr (TOP) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    if (b >= nblk) break;
+                    wu_lds_rw p = swd + (uint32_t)(b * 4) * 64u + (uint32_t)lane;
+                    const int left = NC - 1 - b * 4;
+                    p[0] = sbs[b].x;
+                    if (left > 1) p[64] = sbs[b].y;
+                    if (left > 2) p[128] = sbs[b].z;
+                    if (left > 3) p[192] = sbs[b].w;
+                }
+            }
+#else
             if (duty) {
                 wu_lds_rw p = swd + (uint32_t)(swb * 4) * 64u + (uint32_t)lane;
                 const int left = NC - 1 - swb * 4;
@@ -627,6 +652,7 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
                 if (left > 2) p[128] = sb.z;
                 if (left > 3) p[192] = sb.w;
             }
+#endif
         }
         wu_ds_wait<WV>(st);                                 // (the asm stores of the exchange are not in the compiler's count)
         __syncthreads();
