@@ -105,3 +105,22 @@ def test_bench_under_torchrun_initialises_rccl_and_gathers():
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert "nccl" in out["comm"]["backend"] and out["comm"]["world"] == 1
     assert out["ranks"][0]["first_syndrome"] == 0 and out["n_gpus"] == 1 and out["value"] > 0
+
+
+def test_bench_argument_defaults_of_the_criterion_and_alpha_routes():
+    """What the bench modes resolve to without a GPU: the default line is BASELINE config 2 on the scan = wave kernels; --criterion runs 8 ladders per lane of
+    the persistent grid to a horizon of 262 144; --alpha-route decodes biased xzzx noise with PTEQ_alpha's (pz_tilde, alpha) of generate_data.py:145-146;
+    `--scan auto` follows the same-box A/B runs (profiles/r04_wave_ab.json)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    a = bench.parse_args([])
+    assert (a.code, a.L, a.Nc, a.syndromes, a.ladder_steps, a.scan, a.steps, a.warmup) == ("toric", 9, 8, 65536, 10000, "wave", 5, 1)
+    c = bench.parse_args(["--criterion"])
+    assert (c.syndromes, c.ladder_steps, c.steps, c.warmup, c.scan) == (524288, 262144, 2, 0, "wave")
+    al = bench.parse_args(["--alpha-route", "--criterion"])
+    assert (al.code, al.L, al.Nc, al.eta, al.syndromes, al.ladder_steps, al.scan) == ("xzzx", 5, 5, 100.0, 16 * 98304, 65536, "wave")
+    pz, alpha = bench.rule(al)
+    assert abs(pz - (0.15 / (1 + 1 / 100.0)) / 0.85) < 1e-15 and abs(alpha - np.log(pz / 200.0) / np.log(pz)) < 1e-12
+    assert bench.parse_args(["--config", "3"]).scan == "wave" and bench.parse_args(["--config", "3", "--criterion"]).scan == "random"
+    assert bench.parse_args(["--config", "4"]).scan == "random" and bench.parse_args(["--config", "5"]).scan == "random"
+    assert bench.parse_args(["--config", "2", "--code", "xzzx"]).scan == "random" and bench.parse_args(["--syndromes", "1000"]).scan == "random"
