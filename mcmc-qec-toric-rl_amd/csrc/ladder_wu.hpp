@@ -472,9 +472,13 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
                 if constexpr (IT == 0) { if ((uint32_t)f >= left) break; }
                 const uint32_t P = pbase + c * 10u + (uint32_t)f;                  // proposal of the window: lane P >> 1, half P & 1
                 if constexpr (!top && IT == 10) { if (f & 1) continue; }           // (done with its pair)
-                const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)pk, (int)(P >> 1));
+                // (iters = 10: a step's first proposal sits at an even index of its window, so the lane that holds proposal P is half the step's
+                // base plus a constant)
+                const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)pk, IT == 10 ? (int)((pbase >> 1) + ((c * 10u + (uint32_t)f) >> 1)) : (int)(P >> 1));
                 const uint32_t off = (P & 1u) ? r >> 16 : r & 0xFFFFu;
-                const wu_const_ptr e = desc + (off >> 2);
+                // (byte offsets: multiples of 64 -- added to the table's address as they are)
+                typedef const char __attribute__((address_space(4))) *wu_const_bytes;
+                const wu_const_ptr e = (wu_const_ptr)((wu_const_bytes)desc + off);
                 if constexpr (top) {
                     const uint32_t A = (uint32_t)__builtin_amdgcn_readlane((int)((P & 1u) ? pa1 : pa0), (int)(P >> 1));
                     // a logical operator (mcmc.py:23-24; toric_model.py:228-253, xzzx_model.py:340-357) goes into the frame; a stabilizer is applied
@@ -525,7 +529,7 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
                         // fetched together, the second one's latency hidden behind the first proposal)
                         if constexpr (ALPHA) {
                           if ((f & 1) == 0) {
-                            const wu_const_ptr eb = desc + ((r >> 16) >> 2);
+                            const wu_const_ptr eb = (wu_const_ptr)((wu_const_bytes)desc + (r >> 16));
                             const uint32_t d0 = e[0], d1 = e[1], d2 = e[2], d3 = e[3], x0 = e[4], x1 = e[5], x2 = e[6], x3 = e[7];
                             const uint32_t am = e[11], tlo = e[12], thi = e[13], om = e[14], coff = e[15];
                             const uint32_t b0 = eb[0], b1 = eb[1], b2 = eb[2], b3 = eb[3], y0 = eb[4], y1 = eb[5], y2 = eb[6], y3 = eb[7];
@@ -538,7 +542,7 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
                           }
                         } else
                         if ((f & 1) == 0) {
-                            const wu_const_ptr eb = desc + ((r >> 16) >> 2);
+                            const wu_const_ptr eb = (wu_const_ptr)((wu_const_bytes)desc + (r >> 16));
                             const uint32_t d0 = e[0], d1 = e[1], d2 = e[2], d3 = e[3], x0 = e[4], x1 = e[5], x2 = e[6], x3 = e[7], tlo = e[8];
                             const uint32_t thi = CODE == kCodeToric ? 0u : e[9], om = CODE == kCodeToric ? 0u : e[10], am = CODE == kCodeToric ? 0u : e[11];
                             const uint32_t b0 = eb[0], b1 = eb[1], b2 = eb[2], b3 = eb[3], y0 = eb[4], y1 = eb[5], y2 = eb[6], y3 = eb[7], ulo = eb[8];
