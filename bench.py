@@ -392,11 +392,12 @@ def parse_args(argv=None):
         nq = (2 if args.code in ("toric", "planar") else 1) * args.L * args.L
         # scan = wave where same-box A/B runs have it ahead (profiles/r04_wave_ab.json): rung states of at most 16 words keep 8 waves per SIMD
         W = (nq + 15) // 16
-        # where same-box A/B runs have scan = wave ahead (profiles/r04_wave_ab.json): the toric code -- up to 16 state words per rung at 8 waves per
-        # SIMD, fixed-length runs of up to 32 words (L <= 16) at 6 -- and the alpha rule; on the one-layer codes and the planar code the
-        # random scan's kernels are (L = 9: 0.72-0.74 against 0.61; rotated L = 21 at BASELINE's 32 768 syndromes 0.51 against 0.46)
+        # where same-box A/B runs have scan = wave ahead (profiles/r04_wave_ab.json): up to 16 state words per rung -- the toric code always, the
+        # other codes with the unrolled loop of iters = 10 on up to 8 rungs (L = 9: 0.82-0.85 against 0.68-0.73; the general loop: 0.61) --, the
+        # toric code's fixed-length runs up to 32 words (config 3), the alpha rule; not rotated L = 21 at BASELINE's 32 768 syndromes (0.46 against 0.51)
         ok = W <= 8 and args.Nc <= 8 and args.code in ("xzzx", "rotated") if args.alpha_route else (
-            args.eta is None and args.code == "toric" and (W <= 16 or (W <= 32 and args.Nc <= 8 and not args.criterion)))
+            args.eta is None and (W <= 16 and (args.code == "toric" or (args.iters == 10 and args.Nc <= 8)) or
+                                  (args.code == "toric" and W <= 32 and args.Nc <= 8 and not args.criterion)))
         args.scan = "wave" if (ok and args.Nc >= 2 and args.iters <= 128 and args.syndromes % 64 == 0) else "random"
     return args
 

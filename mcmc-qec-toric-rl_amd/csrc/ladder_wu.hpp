@@ -1043,8 +1043,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_wu_kernel(const LadderArgs 
 }
 
 // the kernel for a shape: the padded state width (4, 8, 12 or 16 words: toric L <= 11, the one-layer codes L <= 16), 8 waves per SIMD up
-// to 8 rungs and 4 beyond; IT = 10: the unrolled proposal loop of `iters` = 10 (decoders.py:25), built for the toric code (the BASELINE
-// shapes); QUEUE: the criterion runs (every criterion launch takes the queue kernel: a batch no larger than the grid gives each ladder
+// to 8 rungs and 4 beyond; IT = 10: the unrolled proposal loop of `iters` = 10 (decoders.py:25) on up to 8 rungs; QUEUE: the criterion runs (every criterion launch takes the queue kernel: a batch no larger than the grid gives each ladder
 // a lane of its own)
 template <int CODE, bool CONV, bool QUEUE, int IT>
 inline const void *wu_pick_it(int Nc, int W)
@@ -1062,7 +1061,7 @@ inline const void *wu_pick_it(int Nc, int W)
         if (W <= 8) return (const void *)ladder_wu_kernel<512, 8, CODE, 8, CONV, QUEUE, IT>;
         if (W <= 12) return (const void *)ladder_wu_kernel<512, 8, CODE, 12, CONV, QUEUE, IT>;
         if (W <= 16) return (const void *)ladder_wu_kernel<512, 6, CODE, 16, CONV, QUEUE, IT>;      // (45 KB of LDS: three workgroups per CU anyway)
-        if constexpr (!CONV && !QUEUE) return (const void *)ladder_wu_kernel<512, 6, CODE, 32, false, false, IT>;   // (toric L = 12 .. 16: BASELINE config 3)
+        if constexpr (!CONV && !QUEUE && CODE != kCodePlanar) return (const void *)ladder_wu_kernel<512, 6, CODE, 32, false, false, IT>;   // (toric L = 12 .. 16: BASELINE config 3)
         return nullptr;
     } else {
         if (W <= 4) return big ? (const void *)ladder_wu_kernel<1024, 4, CODE, 4, CONV, QUEUE, IT> : (const void *)ladder_wu_kernel<512, 8, CODE, 4, CONV, QUEUE, IT>;
@@ -1081,13 +1080,9 @@ template <int CODE>
 inline const void *wu_pick(int variant, int Nc, int W, uint32_t iters)
 {
     if (W > 32 || (variant != 0 && variant != 2)) return nullptr;
-    const bool it10 = CODE == kCodeToric && iters == 10u && Nc * 64 <= 512;
-    if constexpr (CODE == kCodeToric) {
-        if (it10) return variant == 2 ? wu_pick_it<CODE, true, true, 10>(Nc, W) : wu_pick_it<CODE, false, false, 10>(Nc, W);
-    } else if constexpr (CODE != kCodePlanar) {
-        // (the 32-word kernels of the one-layer codes -- rotated L = 21 is BASELINE config 5 -- have the unrolled loop too)
-        if (W > 16 && iters == 10u && variant == 0 && Nc * 64 <= 512) return (const void *)ladder_wu_kernel<512, 6, CODE, 32, false, false, 10>;
-    }
+    // iters = 10 (decoders.py:25) on up to 8 rungs: the unrolled proposal loop, for every code (same-box A/B at L = 9, config 2's shape: xzzx 0.85 against
+    // 0.61 with the general loop -- and 0.73 with the random scan's kernel --, rotated 0.85 / 0.61 / 0.72, planar 0.82 / 0.60 / 0.68)
+    if (iters == 10u && Nc * 64 <= 512) return variant == 2 ? wu_pick_it<CODE, true, true, 10>(Nc, W) : wu_pick_it<CODE, false, false, 10>(Nc, W);
     return variant == 2 ? wu_pick_it<CODE, true, true, 0>(Nc, W) : wu_pick_it<CODE, false, false, 0>(Nc, W);
 }
 

@@ -66,6 +66,9 @@ ALLOWED_SCRATCH = {
     "wave<512,8,rotated: 8 words, conv, queue>": 12,
     "wave<512,8,rotated: 12 words, conv, queue>": 28,
     "wave<512,8,xzzx: 12 words, conv, queue>": 28,
+    "wave<512,8,planar: 8 words, conv, queue, iters 10>": 12, "wave<512,8,planar: 12 words, conv, queue, iters 10>": 28,
+    "wave<512,8,rotated: 8 words, conv, queue, iters 10>": 12, "wave<512,8,rotated: 12 words, conv, queue, iters 10>": 28,
+    "wave<512,8,xzzx: 12 words, conv, queue, iters 10>": 28,
     # scan = wave, 32 state words per rung (80 VGPRs at 6 waves per SIMD, 32 of them the pinned tuple): the tuple makes one round trip through scratch
     # where the kernel stages it and one where it writes it out -- once per launch; the step loops of both roles read and write no scratch
     # (`hipcc -S`: no scratch instruction between the first and the last barrier of either loop)
