@@ -123,4 +123,5 @@ def test_bench_argument_defaults_of_the_criterion_and_alpha_routes():
     assert abs(pz - (0.15 / (1 + 1 / 100.0)) / 0.85) < 1e-15 and abs(alpha - np.log(pz / 200.0) / np.log(pz)) < 1e-12
     assert bench.parse_args(["--config", "3"]).scan == "wave" and bench.parse_args(["--config", "3", "--criterion"]).scan == "random"
     assert bench.parse_args(["--config", "4"]).scan == "random" and bench.parse_args(["--config", "5"]).scan == "random"
-    assert bench.parse_args(["--config", "2", "--code", "xzzx"]).scan == "random" and bench.parse_args(["--syndromes", "1000"]).scan == "random"
+    assert bench.parse_args(["--config", "2", "--code", "xzzx"]).scan == "wave" and bench.parse_args(["--config", "2", "--code", "xzzx", "--iters", "7"]).scan == "random"
+    assert bench.parse_args(["--syndromes", "1000"]).scan == "random"
