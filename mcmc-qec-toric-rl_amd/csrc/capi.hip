@@ -225,7 +225,8 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
         // (waves per CU: 8 per SIMD for the 512-thread depolarizing kernels, 4 for the 1024-thread ones and for the biased / alpha
         // queue kernels, which run at 128 VGPRs: ladder_biased.hip)
         const size_t per_cu_lds = (160 * 1024) / pl->lds_bytes,
-                     per_cu_waves = (size_t)(wave_queue && alpha ? 4 * kWuAlphaQueueWaves : (Nc * 64 <= 512 && (!p->noise || wave_queue) && !(wave_queue && W > 16)) ? 32 : 16) / (size_t)Nc;
+                     per_cu_waves = (size_t)(wave_queue ? (alpha ? 4 * kWuAlphaQueueWaves : W > 12 ? 24 : 32)      // (ladder_wu.hpp wu_pick_it: 8 waves per SIMD, 6 at 16 words)
+                                                        : (Nc * 64 <= 512 && !p->noise) ? 32 : 16) / (size_t)Nc;
         size_t per_cu = per_cu_lds < per_cu_waves ? per_cu_lds : per_cu_waves;
         if (per_cu < 1) per_cu = 1;
         pl->queue_grid = (uint32_t)(per_cu * (size_t)prop.multiProcessorCount);

@@ -1055,24 +1055,16 @@ inline const void *wu_pick_it(int Nc, int W)
 #endif
     return (!big && W > 8 && W <= 12) ? (const void *)ladder_wu_kernel<512, (QUEUE ? QECMC_WU_DEV_QUEUE_MINW : 8), CODE, 12, CONV, QUEUE, IT> : nullptr;
 #else
-    if constexpr (IT == 10) {
-        if (big) return nullptr;
-        if (W <= 4) return (const void *)ladder_wu_kernel<512, 8, CODE, 4, CONV, QUEUE, IT>;
-        if (W <= 8) return (const void *)ladder_wu_kernel<512, 8, CODE, 8, CONV, QUEUE, IT>;
-        if (W <= 12) return (const void *)ladder_wu_kernel<512, 8, CODE, 12, CONV, QUEUE, IT>;
-        if (W <= 16) return (const void *)ladder_wu_kernel<512, 6, CODE, 16, CONV, QUEUE, IT>;      // (45 KB of LDS: three workgroups per CU anyway)
-        if constexpr (!CONV && !QUEUE && CODE != kCodePlanar) return (const void *)ladder_wu_kernel<512, 6, CODE, 32, false, false, IT>;   // (toric L = 12 .. 16: BASELINE config 3)
-        return nullptr;
-    } else {
-        if (W <= 4) return big ? (const void *)ladder_wu_kernel<1024, 4, CODE, 4, CONV, QUEUE, IT> : (const void *)ladder_wu_kernel<512, 8, CODE, 4, CONV, QUEUE, IT>;
-        if (W <= 8) return big ? (const void *)ladder_wu_kernel<1024, 4, CODE, 8, CONV, QUEUE, IT> : (const void *)ladder_wu_kernel<512, 8, CODE, 8, CONV, QUEUE, IT>;
-        if (W <= 12) return big ? (const void *)ladder_wu_kernel<1024, 4, CODE, 12, CONV, QUEUE, IT> : (const void *)ladder_wu_kernel<512, 8, CODE, 12, CONV, QUEUE, IT>;
-        if (W <= 16) return big ? (const void *)ladder_wu_kernel<1024, 4, CODE, 16, CONV, QUEUE, IT> : (const void *)ladder_wu_kernel<512, 6, CODE, 16, CONV, QUEUE, IT>;
-        // 17 .. 32 words (toric L <= 16, the one-layer codes L <= 22): fixed-length runs of up to 8 rungs, 80 VGPRs at 6 waves per SIMD, the state
-        // through the exchange buffer in two halves (52 KB of LDS: three workgroups per CU); not built for the planar code
-        if constexpr (!CONV && !QUEUE && CODE != kCodePlanar) { if (!big) return (const void *)ladder_wu_kernel<512, 6, CODE, 32, false, false, IT>; }
-        return nullptr;
-    }
+    // (9 .. 16 rungs: the same 64-VGPR code with a launch bound of 1 024 threads -- three workgroups of 9 waves, two of 12 .. 16 per CU.  The round's
+    // first build had given them 4 waves per SIMD: one workgroup per CU and 0.37 at toric L = 9 with the reference's default Nc = L = 9.)
+    if (W <= 4) return big ? (const void *)ladder_wu_kernel<1024, 8, CODE, 4, CONV, QUEUE, IT> : (const void *)ladder_wu_kernel<512, 8, CODE, 4, CONV, QUEUE, IT>;
+    if (W <= 8) return big ? (const void *)ladder_wu_kernel<1024, 8, CODE, 8, CONV, QUEUE, IT> : (const void *)ladder_wu_kernel<512, 8, CODE, 8, CONV, QUEUE, IT>;
+    if (W <= 12) return big ? (const void *)ladder_wu_kernel<1024, 8, CODE, 12, CONV, QUEUE, IT> : (const void *)ladder_wu_kernel<512, 8, CODE, 12, CONV, QUEUE, IT>;
+    if (W <= 16) return big ? (const void *)ladder_wu_kernel<1024, 6, CODE, 16, CONV, QUEUE, IT> : (const void *)ladder_wu_kernel<512, 6, CODE, 16, CONV, QUEUE, IT>;
+    // 17 .. 32 words (toric L <= 16, the one-layer codes L <= 22): fixed-length runs of up to 8 rungs, 80 VGPRs at 6 waves per SIMD, the state
+    // through the exchange buffer in two halves (52 KB of LDS: three workgroups per CU); not built for the planar code
+    if constexpr (!CONV && !QUEUE && CODE != kCodePlanar) { if (!big) return (const void *)ladder_wu_kernel<512, 6, CODE, 32, false, false, IT>; }
+    return nullptr;
 #endif
 }
 // variant: 0 fixed length, 2 criterion on the persistent grid
@@ -1080,9 +1072,9 @@ template <int CODE>
 inline const void *wu_pick(int variant, int Nc, int W, uint32_t iters)
 {
     if (W > 32 || (variant != 0 && variant != 2)) return nullptr;
-    // iters = 10 (decoders.py:25) on up to 8 rungs: the unrolled proposal loop, for every code (same-box A/B at L = 9, config 2's shape: xzzx 0.85 against
+    // iters = 10 (decoders.py:25): the unrolled proposal loop, for every code and ladder length (same-box A/B at L = 9, config 2's shape: xzzx 0.85 against
     // 0.61 with the general loop -- and 0.73 with the random scan's kernel --, rotated 0.85 / 0.61 / 0.72, planar 0.82 / 0.60 / 0.68)
-    if (iters == 10u && Nc * 64 <= 512) return variant == 2 ? wu_pick_it<CODE, true, true, 10>(Nc, W) : wu_pick_it<CODE, false, false, 10>(Nc, W);
+    if (iters == 10u) return variant == 2 ? wu_pick_it<CODE, true, true, 10>(Nc, W) : wu_pick_it<CODE, false, false, 10>(Nc, W);
     return variant == 2 ? wu_pick_it<CODE, true, true, 0>(Nc, W) : wu_pick_it<CODE, false, false, 0>(Nc, W);
 }
 

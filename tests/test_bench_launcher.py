@@ -125,3 +125,4 @@ def test_bench_argument_defaults_of_the_criterion_and_alpha_routes():
     assert bench.parse_args(["--config", "4"]).scan == "random" and bench.parse_args(["--config", "5"]).scan == "random"
     assert bench.parse_args(["--config", "2", "--code", "xzzx"]).scan == "wave" and bench.parse_args(["--config", "2", "--code", "xzzx", "--iters", "7"]).scan == "random"
     assert bench.parse_args(["--syndromes", "1000"]).scan == "random"
+    assert bench.parse_args(["--iters", "7"]).scan == "random" and bench.parse_args(["--iters", "7", "--Nc", "9"]).scan == "wave"

@@ -69,6 +69,22 @@ ALLOWED_SCRATCH = {
     "wave<512,8,planar: 8 words, conv, queue, iters 10>": 12, "wave<512,8,planar: 12 words, conv, queue, iters 10>": 28,
     "wave<512,8,rotated: 8 words, conv, queue, iters 10>": 12, "wave<512,8,rotated: 12 words, conv, queue, iters 10>": 28,
     "wave<512,8,xzzx: 12 words, conv, queue, iters 10>": 28,
+    # scan = wave, 9 .. 16 rungs (the 64-VGPR code of the 512-thread kernels under a launch bound of 1 024 threads): the same spills in the same places
+    "wave<1024,8,toric: 8 words, conv, queue, iters 10>": 28,
+    "wave<1024,8,toric: 12 words, conv, queue, iters 10>": 40,
+    "wave<1024,8,toric: 4 words, conv, queue>": 12,
+    "wave<1024,8,toric: 8 words, conv, queue>": 12,
+    "wave<1024,8,toric: 12 words, conv, queue>": 36,
+    "wave<1024,8,planar: 8 words, conv, queue, iters 10>": 12,
+    "wave<1024,8,planar: 12 words, conv, queue, iters 10>": 28,
+    "wave<1024,8,planar: 8 words, conv, queue>": 12,
+    "wave<1024,8,planar: 12 words, conv, queue>": 28,
+    "wave<1024,8,rotated: 8 words, conv, queue, iters 10>": 12,
+    "wave<1024,8,rotated: 12 words, conv, queue, iters 10>": 28,
+    "wave<1024,8,rotated: 8 words, conv, queue>": 12,
+    "wave<1024,8,rotated: 12 words, conv, queue>": 28,
+    "wave<1024,8,xzzx: 12 words, conv, queue, iters 10>": 28,
+    "wave<1024,8,xzzx: 12 words, conv, queue>": 28,
     # scan = wave, 32 state words per rung (80 VGPRs at 6 waves per SIMD, 32 of them the pinned tuple): the tuple makes one round trip through scratch
     # where the kernel stages it and one where it writes it out -- once per launch; the step loops of both roles read and write no scratch
     # (`hipcc -S`: no scratch instruction between the first and the last barrier of either loop)
