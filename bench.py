@@ -398,7 +398,7 @@ def parse_args(argv=None):
         # (config 3), the alpha rule; not rotated L = 21 at BASELINE's 32 768 syndromes (0.46 against 0.51)
         ok = W <= 8 and args.Nc <= 8 and args.code in ("xzzx", "rotated") if args.alpha_route else (
             args.eta is None and (W <= 16 and (args.iters == 10 or args.Nc > 8) or
-                                  (args.code == "toric" and W <= 32 and args.Nc <= 8 and not args.criterion)))
+                                  (args.code == "toric" and 16 < W <= 32 and args.Nc <= 8 and args.iters == 10 and not args.criterion)))
         args.scan = "wave" if (ok and args.Nc >= 2 and args.iters <= 128 and args.syndromes % 64 == 0) else "random"
     return args
 
