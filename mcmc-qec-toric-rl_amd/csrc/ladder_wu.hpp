@@ -469,7 +469,7 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
             if constexpr (IT == 0) asm volatile("" : "+s"(left));                  // (a scalar bound for the guards below)
 #pragma unroll
             for (int f = 0; f < 10; ++f) {
-                if constexpr (IT == 0) { if ((uint32_t)f >= left) break; }
+                if constexpr (IT == 0) { if ((uint32_t)f >= left) continue; }     // (skipped, not left: a loop with one exit unrolls)
                 const uint32_t P = pbase + c * 10u + (uint32_t)f;                  // proposal of the window: lane P >> 1, half P & 1
                 if constexpr (!top && IT == 10) { if (f & 1) continue; }           // (done with its pair)
                 // (iters = 10: a step's first proposal sits at an even index of its window, so the lane that holds proposal P is half the step's
