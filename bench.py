@@ -396,7 +396,7 @@ def parse_args(argv=None):
         # (L = 9: toric 0.81, xzzx / rotated / planar 0.82-0.85 against 0.66-0.73; the general loop of other iters: 0.51-0.61, behind the random scan) or on
         # more than 8 rungs (toric L = 9, Nc = 9 / 12 / 16: 0.71 / 0.76 / 0.79 against 0.31 / 0.38 / 0.43), the toric code's fixed-length runs up to 32 words
         # (config 3), the alpha rule; not rotated L = 21 at BASELINE's 32 768 syndromes (0.46 against 0.51)
-        ok = W <= 8 and args.Nc <= 8 and args.code in ("xzzx", "rotated") if args.alpha_route else (
+        ok = W <= 8 and args.code in ("xzzx", "rotated") if args.alpha_route else (
             args.eta is None and (W <= 16 and (args.iters == 10 or args.Nc > 8) or
                                   (args.code == "toric" and 16 < W <= 32 and args.Nc <= 8 and args.iters == 10 and not args.criterion)))
         args.scan = "wave" if (ok and args.Nc >= 2 and args.iters <= 128 and args.syndromes % 64 == 0) else "random"

@@ -61,7 +61,7 @@ typedef enum qecmc_code { QECMC_TORIC = 0, QECMC_XZZX = 1, QECMC_ROTATED = 2, QE
  * SWEEP / COLOUR this IS the reference's Markov chain per syndrome; only the noise of different syndromes is correlated.  What it buys:
  * a proposal's sites are wave-uniform, so the rungs' states live in registers.  Depolarizing rule with a top rung at
  * p = 0.75 (Nc >= 2), at most 16 packed state words per rung (toric / planar L <= 11, xzzx / rotated L <= 16) -- fixed-length runs of
- * up to 8 rungs also 17 .. 32 words (toric L <= 16, xzzx / rotated L <= 22) --, and the alpha rule (xzzx / rotated L <= 11, Nc <= 8);
+ * up to 8 rungs also 17 .. 32 words (toric L <= 16, xzzx / rotated L <= 22) --, and the alpha rule (xzzx / rotated L <= 11);
  * first_syndrome a multiple of 64, 1 <= iters <= 128.  With conv_mode error_based the launch runs on a persistent grid
  * whose workgroups own contiguous shares of the batch and reuse the lane of a stopped ladder for the next one of their share: the
  * generator picks then belong to the lane's position in the grid, so results are reproducible for a given (batch size, grid,

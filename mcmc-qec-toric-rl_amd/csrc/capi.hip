@@ -359,7 +359,7 @@ int build_plan(const qecmc_params *p, qecmc_plan *pl)
     a.lmask = pl->lmask.as<uint32_t>();
     if (p->scan == QECMC_SCAN_WAVE && (!wu_supported(a) || pl->lds_bytes > 160 * 1024))
         return fail(QECMC_ERR_UNSUPPORTED, "scan = wave: L=%d Nc=%d p=%g is outside what it is built for (depolarizing rule: a top rung that accepts every move, at most "
-                    "16 packed state words per rung -- toric / planar L <= 11, xzzx / rotated L <= 16 --, fixed-length runs of up to 8 rungs 32 words -- toric L <= 16, xzzx / rotated L <= 22; alpha rule: xzzx / rotated L <= 11, Nc <= 8, "
+                    "16 packed state words per rung -- toric / planar L <= 11, xzzx / rotated L <= 16 --, fixed-length runs of up to 8 rungs 32 words -- toric L <= 16, xzzx / rotated L <= 22; alpha rule: xzzx / rotated L <= 11, "
                     "4 iters max|log2 ratio| <= 2000 --, %zu B of LDS)", L, Nc, p->p, pl->lds_bytes);
     return 0;
 }

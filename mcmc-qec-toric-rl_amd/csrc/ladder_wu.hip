@@ -10,11 +10,11 @@ size_t wu_lds_bytes(int Nc, int W, int ncls, int L, bool conv, bool alpha) { ret
 // SIMD), fixed-length runs of up to 8 rungs also up to 32 words (toric L <= 16, xzzx / rotated L <= 22: 6 waves per SIMD, the exchange in two
 // halves), 1 <= iters <= 128, rungs at distinct temperatures (32-bit swap thresholds)
 // ... and the alpha noise model's ladder (noise = 2, whose top rung sits at pz_tilde = 1 and accepts every move) on the xzzx / rotated codes up to
-// 8 state words and 8 rungs, where the plan allows the single-precision estimate of the acceptance ratio on every rung below the top
+// 8 state words, where the plan allows the single-precision estimate of the acceptance ratio on every rung below the top
 bool wu_supported(const LadderArgs &a)
 {
     if (a.noise == 2)
-        return (a.code == kCodeXzzx || a.code == kCodeRotated) && a.Nc >= 2 && a.Nc <= 8 && a.W <= 8 && a.n_gen <= 1023u && a.iters >= 1u && a.iters <= 128u &&
+        return (a.code == kCodeXzzx || a.code == kCodeRotated) && a.Nc >= 2 && a.Nc <= 16 && a.W <= 8 && a.n_gen <= 1023u && a.iters >= 1u && a.iters <= 128u &&
                (a.bias_f32ok & ((1u << (a.Nc - 1)) - 1u)) == ((1u << (a.Nc - 1)) - 1u) && a.bias_tbl != nullptr && a.alpha_lnb != nullptr &&
                a.uset_tab == nullptr && a.swap_acc == nullptr && !a.resume && a.neff == nullptr &&
                wu_lds_bytes(a.Nc, a.W, a.ncls, a.L, a.conv_mode != 0, true) <= 160 * 1024;

@@ -1078,19 +1078,23 @@ inline const void *wu_pick(int variant, int Nc, int W, uint32_t iters)
     return variant == 2 ? wu_pick_it<CODE, true, true, 0>(Nc, W) : wu_pick_it<CODE, false, false, 0>(Nc, W);
 }
 
-// the alpha rule's kernels: xzzx / rotated codes up to 8 state words per rung (L <= 11) and 8 rungs
+// the alpha rule's kernels: xzzx / rotated codes up to 8 state words per rung (L <= 11)
 // (IT = 10: PTEQ_alpha's default iters, decoders_biasednoise.py:175)
 template <int CODE, int IT>
 inline const void *wu_pick_alpha(int variant, int Nc, int W)
 {
-    if (W > 8 || Nc * 64 > 512 || (variant != 0 && variant != 2)) return nullptr;
+    if (W > 8 || (variant != 0 && variant != 2)) return nullptr;
+    const bool big = Nc * 64 > 512;          // (9 .. 16 rungs -- Ladder_alpha's default is Nc = L, decoders_biasednoise.py:175 --: the same code under a 1 024-thread bound)
     // (the criterion kernels of the alpha rule at 6 waves per SIMD -- 80 VGPRs, 102 SGPRs --: 96-120 B of scratch reloaded every step at 8, 28-40 B at 6,
     // and 4 % faster on the PTEQ_alpha route, same-box A/B; kWuAlphaQueueWaves tells the plan how many workgroups a CU then holds)
 #ifndef QECMC_WU_ALPHA_CONV_MINW
 #define QECMC_WU_ALPHA_CONV_MINW kWuAlphaQueueWaves
 #endif
-    if (variant == 2)
+    if (variant == 2) {
+        if (big) return W <= 4 ? (const void *)ladder_wu_kernel<1024, QECMC_WU_ALPHA_CONV_MINW, CODE, 4, true, true, IT, true> : (const void *)ladder_wu_kernel<1024, QECMC_WU_ALPHA_CONV_MINW, CODE, 8, true, true, IT, true>;
         return W <= 4 ? (const void *)ladder_wu_kernel<512, QECMC_WU_ALPHA_CONV_MINW, CODE, 4, true, true, IT, true> : (const void *)ladder_wu_kernel<512, QECMC_WU_ALPHA_CONV_MINW, CODE, 8, true, true, IT, true>;
+    }
+    if (big) return W <= 4 ? (const void *)ladder_wu_kernel<1024, 8, CODE, 4, false, false, IT, true> : (const void *)ladder_wu_kernel<1024, 8, CODE, 8, false, false, IT, true>;
     return W <= 4 ? (const void *)ladder_wu_kernel<512, 8, CODE, 4, false, false, IT, true> : (const void *)ladder_wu_kernel<512, 8, CODE, 8, false, false, IT, true>;
 }
 

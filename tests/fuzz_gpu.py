@@ -41,7 +41,7 @@ def draw_case(rng):
         scan = "colour"
     # (round 4) scan = wave where it is built: the depolarizing rule up to 16 state words per rung, the alpha rule up to 8 words and 8 rungs
     W = (nq + 15) // 16
-    if Nc >= 2 and ((noise == "depolarizing" and W <= 16) or (noise == "alpha" and W <= 8 and Nc <= 8)) and rng.random() < (0.6 if noise == "alpha" else 0.3):
+    if Nc >= 2 and ((noise == "depolarizing" and W <= 16) or (noise == "alpha" and W <= 8)) and rng.random() < (0.6 if noise == "alpha" else 0.3):
         scan = "wave"
     conv = rng.random() < 0.3                             # (round 3: the alpha rule's criterion runs take the work queue too)
     iters = int(rng.choice([1, 2, 3, 5, 7, 8, 10, 10, 10, 12, 13, 25]))

@@ -214,7 +214,8 @@ def test_launch_dev_refuses_an_undersized_workspace(q, kind):
 ALPHA_CASES = [  # name, L, Nc, N, steps, iters, pz_tilde, alpha, replicas
     ("xzzx", 3, 3, 5, 300, 10, 0.20, 2.0, 1), ("xzzx", 5, 5, 70, 200, 10, 0.175, 4.04, 1), ("rotated", 5, 4, 6, 200, 7, 0.15, 3.0, 1),
     ("xzzx", 7, 7, 4, 150, 10, 0.12, 4.04, 1), ("rotated", 7, 8, 3, 100, 10, 0.2, 1.3, 2), ("xzzx", 9, 8, 3, 80, 10, 0.15, 2.5, 1),
-    ("xzzx", 11, 5, 2, 40, 25, 0.1, 6.0, 1), ("xzzx", 5, 2, 4, 200, 1, 0.3, 1.0, 1), ("rotated", 9, 6, 3, 60, 3, 0.25, 2.0, 1)]
+    ("xzzx", 11, 5, 2, 40, 25, 0.1, 6.0, 1), ("xzzx", 5, 2, 4, 200, 1, 0.3, 1.0, 1), ("rotated", 9, 6, 3, 60, 3, 0.25, 2.0, 1),
+    ("xzzx", 9, 9, 3, 80, 10, 0.175, 4.04, 1), ("rotated", 7, 16, 2, 40, 10, 0.2, 2.0, 1), ("xzzx", 5, 12, 3, 60, 7, 0.15, 3.0, 1)]      # Nc = L = 9 (the reference's default); 16 and 12 rungs
 
 
 @pytest.mark.parametrize("name,L,Nc,N,steps,iters,pzt,alpha,R", ALPHA_CASES)
@@ -236,7 +237,8 @@ def test_wave_scan_alpha_bit_exact(q, orc, name, L, Nc, N, steps, iters, pzt, al
 
 
 @pytest.mark.parametrize("name,L,Nc,N,steps,iters,grid,pzt,alpha", [("xzzx", 3, 3, 200, 2500, 10, 1, 0.2, 2.0), ("xzzx", 5, 5, 300, 3000, 10, 2, 0.175, 4.04),
-                                                                  ("rotated", 5, 4, 150, 2500, 7, 1, 0.15, 3.0), ("xzzx", 7, 7, 100, 1500, 10, 1, 0.15, 4.04)])
+                                                                  ("rotated", 5, 4, 150, 2500, 7, 1, 0.15, 3.0), ("xzzx", 7, 7, 100, 1500, 10, 1, 0.15, 4.04),
+                                                                  ("xzzx", 5, 9, 150, 2500, 10, 1, 0.175, 4.04)])
 def test_wave_scan_alpha_work_queue_bit_exact(q, orc, name, L, Nc, N, steps, iters, grid, pzt, alpha):
     """PTEQ_alpha's default route (decoders_biasednoise.py:175-238: error_based on chains[0].n_eff) on the deterministic work queue"""
     rng = np.random.default_rng(L + 19 * Nc + N)

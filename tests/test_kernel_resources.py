@@ -85,6 +85,23 @@ ALLOWED_SCRATCH = {
     "wave<1024,8,rotated: 12 words, conv, queue>": 28,
     "wave<1024,8,xzzx: 12 words, conv, queue, iters 10>": 28,
     "wave<1024,8,xzzx: 12 words, conv, queue>": 28,
+    # ... and the alpha rule's on 9 .. 16 rungs
+    "wave<1024,6,xzzx: 4 words, conv, queue, alpha, iters 10>": 28,
+    "wave<1024,6,xzzx: 8 words, conv, queue, alpha, iters 10>": 40,
+    "wave<1024,8,xzzx: 4 words, alpha, iters 10>": 44,
+    "wave<1024,8,xzzx: 8 words, alpha, iters 10>": 80,
+    "wave<1024,6,rotated: 4 words, conv, queue, alpha, iters 10>": 28,
+    "wave<1024,6,rotated: 8 words, conv, queue, alpha, iters 10>": 44,
+    "wave<1024,8,rotated: 4 words, alpha, iters 10>": 44,
+    "wave<1024,8,rotated: 8 words, alpha, iters 10>": 84,
+    "wave<1024,6,xzzx: 4 words, conv, queue, alpha>": 44,
+    "wave<1024,6,xzzx: 8 words, conv, queue, alpha>": 100,
+    "wave<1024,8,xzzx: 4 words, alpha>": 96,
+    "wave<1024,8,xzzx: 8 words, alpha>": 168,
+    "wave<1024,6,rotated: 4 words, conv, queue, alpha>": 44,
+    "wave<1024,6,rotated: 8 words, conv, queue, alpha>": 100,
+    "wave<1024,8,rotated: 4 words, alpha>": 92,
+    "wave<1024,8,rotated: 8 words, alpha>": 168,
     # scan = wave, 32 state words per rung (80 VGPRs at 6 waves per SIMD, 32 of them the pinned tuple): the tuple makes one round trip through scratch
     # where the kernel stages it and one where it writes it out -- once per launch; the step loops of both roles read and write no scratch
     # (`hipcc -S`: no scratch instruction between the first and the last barrier of either loop)
