@@ -170,7 +170,9 @@ constexpr int kWuBkAlpha = 17; // ... and the alpha rule's second pair of window
 __host__ __device__ inline int wu_words(int W) { return W <= 4 ? 4 : W <= 8 ? 8 : W <= 12 ? 12 : W <= 16 ? 16 : 32; }   // WV: state words per rung, padded
 __host__ __device__ inline int wu_words_min(int WV) { return WV == 4 ? 1 : WV == 32 ? 17 : WV - 3; }      // the narrowest W a WV-word kernel serves
 constexpr int kWuHalf = 16;                                                                               // rows per rung of a 32-word kernel's exchange buffer
-__host__ __device__ inline int wu_rows(int W) { return W > 16 ? kWuHalf : W; }                            // rows per rung of the exchange buffer
+// rows per rung of the exchange buffer: the kernel's padded width (16 per half of a 32-word state) -- the padding words travel with the rest (they
+// are zero), so that no transfer carries a run-time test of the lattice's width on the scalar unit, the busiest unit of these kernels
+__host__ __device__ inline int wu_rows(int W) { return W > 16 ? kWuHalf : wu_words(W); }
 // (alpha rule: the 9 x 9 table of a proposal's count change as two fp16 numbers, the slots' n_eff attributes as doubles [Nc][64], ln(pz_i / pz_i+1),
 // and -- criterion runs -- slot 0's n_eff record by step parity)
 __host__ __device__ inline WuLds wu_lds(int Nc, int W, int ncls, int L, bool conv, bool alpha = false)
@@ -382,7 +384,8 @@ __device__ __forceinline__ void wu_propose_alpha(const LadderArgs &a, typename W
 // then takes the words into its state registers with the exchange's own static reads.  Returns 4 x the error count and the class.
 // (a 32-word kernel stages words [w0, w1) = [0, 16) and [16, W) in two calls, each into rows 0 .. of the rung's region; the class comes with the first)
 template <int CODE>
-__device__ __forceinline__ void wu_stage_lds(const LadderArgs &a, uint64_t lad, uint32_t slot, wu_lds_rw xrow, uint32_t &n4, uint32_t &cls, int w0 = 0, int w1 = -1)
+// (rows: the rows of the region to fill -- those beyond the words of the range get zeros: the padding words of the state)
+__device__ __forceinline__ void wu_stage_lds(const LadderArgs &a, uint64_t lad, uint32_t slot, wu_lds_rw xrow, uint32_t &n4, uint32_t &cls, int w0 = 0, int w1 = -1, int rows = 0)
 {
     const int NC = a.Nc, W = a.W, L = a.L, nq = a.nq;
     const uint8_t *src = a.resume ? a.states + (lad * NC + slot) * (uint64_t)nq : a.init + (lad / a.replicas) * (uint64_t)nq;
@@ -399,6 +402,8 @@ __device__ __forceinline__ void wu_stage_lds(const LadderArgs &a, uint64_t lad, 
         xrow[(w - w0) * 64] = word;
         cnt += nnz2(word);
     }
+#pragma unroll 1
+    for (int r = w1 - w0; r < rows; ++r) xrow[r * 64] = 0u;
     if (w0 != 0) { n4 += 4u * cnt; return; }
     n4 = 4u * cnt;
     cls = (uint32_t)(CODE == kCodeToric ? toric_eq_class_b(L, src) : surf_eq_class_b(CODE, L, src));
@@ -609,7 +614,7 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
         [[maybe_unused]] wu_lds_drw const nefd = (wu_lds_drw)(ldsl + ol.nef) + (uint32_t)lane;
         [[maybe_unused]] wu_lds_dptr const lnbd = (wu_lds_dptr)(ldsl + ol.lnb);
         const uint32_t xaddr = lds0l + (uint32_t)lane * 4u;
-        const uint32_t xstride = (uint32_t)(WV == 32 ? kWuHalf : Wl) * 256u;          // bytes of one rung in the exchange buffer
+        const uint32_t xstride = (uint32_t)(WV == 32 ? kWuHalf : WV) * 256u;          // bytes of one rung in the exchange buffer
 #ifdef QECMC_WU_TOP_SWAPS
         // the swap uniforms -- block b = pairs 4 b .. 4 b + 3 -- are all drawn by the TOP rung's wave, whose step is the shortest
         const int nblk = (NC - 1 + 3) >> 2;
@@ -629,8 +634,8 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
         {
             const uint32_t xo = xaddr + slot * xstride;
             // (a 32-word state passes through the buffer in two halves: words 0-15 here, the rest behind two more barriers below)
-#define QECMC_WU_PUT(w) if constexpr (w < WV && w < kWuHalf) { if (w < wu_words_min(WV) || w < Wl) wu_ds_write<WV, w>(st, xo); }
-#define QECMC_WU_PUT_HI(w) if constexpr (w < WV && w >= kWuHalf) { if (w < wu_words_min(WV) || w < Wl) wu_ds_write<WV, w, w - kWuHalf>(st, xo); }
+#define QECMC_WU_PUT(w) if constexpr (w < WV && w < kWuHalf) wu_ds_write<WV, w>(st, xo);
+#define QECMC_WU_PUT_HI(w) if constexpr (w < WV && w >= kWuHalf) wu_ds_write<WV, w, w - kWuHalf>(st, xo);
             WU_EACH(QECMC_WU_PUT)
             rec[slot * 64u + (uint32_t)lane] = pack_info(n4 >> 2, slot, cls, flag);
             if constexpr (ALPHA) nefd[slot * 64u] = wu_neff(nef, a.alpha);
@@ -686,8 +691,8 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
             if (slot == 0) mine = car;
             // this rung's new state: the W words of the rung it comes from
             const uint32_t xin = xaddr + ((mine >> 16) & 0xFFu) * xstride;
-#define QECMC_WU_TAKE(w) if constexpr (w < WV && w < kWuHalf) { if (w < wu_words_min(WV) || w < Wl) wu_ds_read<WV, w>(st, xin); }
-#define QECMC_WU_TAKE_HI(w) if constexpr (w < WV && w >= kWuHalf) { if (w < wu_words_min(WV) || w < Wl) wu_ds_read<WV, w, w - kWuHalf>(st, xin); }
+#define QECMC_WU_TAKE(w) if constexpr (w < WV && w < kWuHalf) wu_ds_read<WV, w>(st, xin);
+#define QECMC_WU_TAKE_HI(w) if constexpr (w < WV && w >= kWuHalf) wu_ds_read<WV, w, w - kWuHalf>(st, xin);
             WU_EACH(QECMC_WU_TAKE)
             wu_ds_wait<WV>(st);
             if constexpr (WV == 32) {
@@ -856,9 +861,9 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
                         // for the same lane, whose state is being replaced in every wave)
                         syn = a.first_syndrome + give;
                         t0 = (uint32_t)t + 1u;
-                        wu_stage_lds<CODE>(a, (uint64_t)give, slot, ldsl + (slot * (uint32_t)Wl) * 64u + (uint32_t)lane, n4, cls);
+                        wu_stage_lds<CODE>(a, (uint64_t)give, slot, ldsl + (slot * (uint32_t)WV) * 64u + (uint32_t)lane, n4, cls, 0, -1, WV);
                         const uint32_t xme = xaddr + slot * xstride;
-#define QECMC_WU_MINE(w) if constexpr (w < WV) { if (w < wu_words_min(WV) || w < Wl) wu_ds_read<WV, w>(st, xme); }
+#define QECMC_WU_MINE(w) if constexpr (w < WV) wu_ds_read<WV, w>(st, xme);
                         WU_EACH(QECMC_WU_MINE)
 #undef QECMC_WU_MINE
                         wu_ds_wait<WV>(st);
@@ -940,17 +945,17 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_wu_kernel(const LadderArgs 
     if (cnt > 0) {
         const int rows = wu_rows(W);                                  // rows of a rung's region of the exchange buffer
         const wu_lds_rw xcol = (wu_lds_rw)(uintptr_t)lds0 + (slot * (uint32_t)rows) * 64u + (uint32_t)lane;
-        wu_stage_lds<CODE>(a, ladder, slot, xcol, n4, cls, 0, WV == 32 ? kWuHalf : W);
+        wu_stage_lds<CODE>(a, ladder, slot, xcol, n4, cls, 0, WV == 32 ? kWuHalf : W, rows);
         const uint32_t xme = lds0 + (uint32_t)lane * 4u + slot * (uint32_t)(rows * 256);
         const int Wl = W;
-#define QECMC_WU_MINE(w) if constexpr (w < WV && w < kWuHalf) { if (w < wu_words_min(WV) || w < Wl) wu_ds_read<WV, w>(st, xme); }
+#define QECMC_WU_MINE(w) if constexpr (w < WV && w < kWuHalf) wu_ds_read<WV, w>(st, xme);
         WU_EACH(QECMC_WU_MINE)
 #undef QECMC_WU_MINE
         wu_ds_wait<WV>(st);
         if constexpr (WV == 32) {
             // (the upper half through the same rows: this lane's own column, which nobody else reads)
-            wu_stage_lds<CODE>(a, ladder, slot, xcol, n4, cls, kWuHalf, W);
-#define QECMC_WU_MINE_HI(w) if constexpr (w < WV && w >= kWuHalf) { if (w < wu_words_min(WV) || w < Wl) wu_ds_read<WV, w, w - kWuHalf>(st, xme); }
+            wu_stage_lds<CODE>(a, ladder, slot, xcol, n4, cls, kWuHalf, W, rows);
+#define QECMC_WU_MINE_HI(w) if constexpr (w < WV && w >= kWuHalf) wu_ds_read<WV, w, w - kWuHalf>(st, xme);
             WU_EACH(QECMC_WU_MINE_HI)
 #undef QECMC_WU_MINE_HI
             wu_ds_wait<WV>(st);

@@ -59,7 +59,7 @@ ALLOWED_SCRATCH = {
     "wave<512,8,toric: 8 words, conv, queue, iters 10>": 28,
     "wave<512,8,toric: 12 words, conv, queue, iters 10>": 40,
     "wave<512,8,toric: 4 words, conv, queue>": 12,
-    "wave<512,8,toric: 8 words, conv, queue>": 20,
+    "wave<512,8,toric: 8 words, conv, queue>": 28,
     "wave<512,8,toric: 12 words, conv, queue>": 40,
     "wave<512,8,planar: 8 words, conv, queue>": 12,
     "wave<512,8,planar: 12 words, conv, queue>": 28,
@@ -73,7 +73,7 @@ ALLOWED_SCRATCH = {
     "wave<1024,8,toric: 8 words, conv, queue, iters 10>": 28,
     "wave<1024,8,toric: 12 words, conv, queue, iters 10>": 40,
     "wave<1024,8,toric: 4 words, conv, queue>": 12,
-    "wave<1024,8,toric: 8 words, conv, queue>": 20,
+    "wave<1024,8,toric: 8 words, conv, queue>": 28,
     "wave<1024,8,toric: 12 words, conv, queue>": 40,
     "wave<1024,8,planar: 8 words, conv, queue, iters 10>": 12,
     "wave<1024,8,planar: 12 words, conv, queue, iters 10>": 28,
@@ -87,7 +87,7 @@ ALLOWED_SCRATCH = {
     "wave<1024,8,xzzx: 12 words, conv, queue>": 28,
     # ... and the alpha rule's on 9 .. 16 rungs
     "wave<1024,6,xzzx: 4 words, conv, queue, alpha, iters 10>": 28,
-    "wave<1024,6,xzzx: 8 words, conv, queue, alpha, iters 10>": 40,
+    "wave<1024,6,xzzx: 8 words, conv, queue, alpha, iters 10>": 44,
     "wave<1024,8,xzzx: 4 words, alpha, iters 10>": 44,
     "wave<1024,8,xzzx: 8 words, alpha, iters 10>": 80,
     "wave<1024,6,rotated: 4 words, conv, queue, alpha, iters 10>": 28,
@@ -112,7 +112,7 @@ ALLOWED_SCRATCH = {
     # proposal loop itself reads no scratch (`hipcc -S`: 14 scratch instructions, none between the step's first proposal and its first barrier)
     "wave<512,8,xzzx: 4 words, alpha, iters 10>": 48, "wave<512,8,xzzx: 8 words, alpha, iters 10>": 84,
     "wave<512,8,rotated: 4 words, alpha, iters 10>": 48, "wave<512,8,rotated: 8 words, alpha, iters 10>": 84,
-    "wave<512,6,xzzx: 4 words, conv, queue, alpha, iters 10>": 28, "wave<512,6,xzzx: 8 words, conv, queue, alpha, iters 10>": 40,
+    "wave<512,6,xzzx: 4 words, conv, queue, alpha, iters 10>": 28, "wave<512,6,xzzx: 8 words, conv, queue, alpha, iters 10>": 44,
     "wave<512,6,rotated: 4 words, conv, queue, alpha, iters 10>": 28, "wave<512,6,rotated: 8 words, conv, queue, alpha, iters 10>": 44,
     "wave<512,8,xzzx: 4 words, alpha>": 96, "wave<512,8,xzzx: 8 words, alpha>": 168, "wave<512,8,rotated: 4 words, alpha>": 92, "wave<512,8,rotated: 8 words, alpha>": 168,
     "wave<512,6,xzzx: 4 words, conv, queue, alpha>": 44, "wave<512,6,xzzx: 8 words, conv, queue, alpha>": 100,
