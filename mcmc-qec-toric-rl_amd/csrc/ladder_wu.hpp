@@ -170,9 +170,11 @@ constexpr int kWuBkAlpha = 17; // ... and the alpha rule's second pair of window
 __host__ __device__ inline int wu_words(int W) { return W <= 4 ? 4 : W <= 8 ? 8 : W <= 12 ? 12 : W <= 16 ? 16 : 32; }   // WV: state words per rung, padded
 __host__ __device__ inline int wu_words_min(int WV) { return WV == 4 ? 1 : WV == 32 ? 17 : WV - 3; }      // the narrowest W a WV-word kernel serves
 constexpr int kWuHalf = 16;                                                                               // rows per rung of a 32-word kernel's exchange buffer
-// rows per rung of the exchange buffer: the kernel's padded width (16 per half of a 32-word state) -- the padding words travel with the rest (they
-// are zero), so that no transfer carries a run-time test of the lattice's width on the scalar unit, the busiest unit of these kernels
-__host__ __device__ inline int wu_rows(int W) { return W > 16 ? kWuHalf : wu_words(W); }
+// rows per rung of the exchange buffer.  The fixed-length kernels give a rung the kernel's padded width (16 per half of a 32-word state): the padding
+// words travel with the rest (they are zero), so that no transfer tests the lattice's width at run time on the scalar unit, the busiest unit of these
+// kernels (-30 tests per step at 29 words).  The criterion kernels keep the tight layout -- W rows, a transfer of a word at or beyond wu_words_min
+// tests the width --: padded rows cost the headline shape's criterion kernel its fourth workgroup per CU (42 KB instead of 39.9) and the route 11 %.
+__host__ __device__ inline int wu_rows(int W, bool conv) { return W > 16 ? kWuHalf : conv ? W : wu_words(W); }
 // (alpha rule: the 9 x 9 table of a proposal's count change as two fp16 numbers, the slots' n_eff attributes as doubles [Nc][64], ln(pz_i / pz_i+1),
 // and -- criterion runs -- slot 0's n_eff record by step parity)
 __host__ __device__ inline WuLds wu_lds(int Nc, int W, int ncls, int L, bool conv, bool alpha = false)
@@ -180,7 +182,7 @@ __host__ __device__ inline WuLds wu_lds(int Nc, int W, int ncls, int L, bool con
     const int WV = wu_words(W);
     WuLds o;
     o.xbuf = 0;
-    o.rec = o.xbuf + Nc * wu_rows(W) * 64;
+    o.rec = o.xbuf + Nc * wu_rows(W, conv) * 64;
     o.swd = o.rec + Nc * 64;
     o.hist = o.swd + Nc * 64;
     o.thr = o.hist + ncls * 64;               // [Nc][2][9]: high 13 / low 32 bits of ceil(f^dE 2^44), dE + 4 = 0 .. 8
@@ -614,7 +616,8 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
         [[maybe_unused]] wu_lds_drw const nefd = (wu_lds_drw)(ldsl + ol.nef) + (uint32_t)lane;
         [[maybe_unused]] wu_lds_dptr const lnbd = (wu_lds_dptr)(ldsl + ol.lnb);
         const uint32_t xaddr = lds0l + (uint32_t)lane * 4u;
-        const uint32_t xstride = (uint32_t)(WV == 32 ? kWuHalf : WV) * 256u;          // bytes of one rung in the exchange buffer
+        constexpr bool PAD = WV == 32 || !CONV;                                      // (wu_rows: padded rows, transfers without width tests)
+        const uint32_t xstride = (uint32_t)(WV == 32 ? kWuHalf : PAD ? WV : Wl) * 256u;  // bytes of one rung in the exchange buffer
 #ifdef QECMC_WU_TOP_SWAPS
         // the swap uniforms -- block b = pairs 4 b .. 4 b + 3 -- are all drawn by the TOP rung's wave, whose step is the shortest
         const int nblk = (NC - 1 + 3) >> 2;
@@ -634,7 +637,7 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
         {
             const uint32_t xo = xaddr + slot * xstride;
             // (a 32-word state passes through the buffer in two halves: words 0-15 here, the rest behind two more barriers below)
-#define QECMC_WU_PUT(w) if constexpr (w < WV && w < kWuHalf) wu_ds_write<WV, w>(st, xo);
+#define QECMC_WU_PUT(w) if constexpr (w < WV && w < kWuHalf) { if (WV == 32 || !CONV || w < wu_words_min(WV) || w < Wl) wu_ds_write<WV, w>(st, xo); }
 #define QECMC_WU_PUT_HI(w) if constexpr (w < WV && w >= kWuHalf) wu_ds_write<WV, w, w - kWuHalf>(st, xo);
             WU_EACH(QECMC_WU_PUT)
             rec[slot * 64u + (uint32_t)lane] = pack_info(n4 >> 2, slot, cls, flag);
@@ -691,7 +694,7 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
             if (slot == 0) mine = car;
             // this rung's new state: the W words of the rung it comes from
             const uint32_t xin = xaddr + ((mine >> 16) & 0xFFu) * xstride;
-#define QECMC_WU_TAKE(w) if constexpr (w < WV && w < kWuHalf) wu_ds_read<WV, w>(st, xin);
+#define QECMC_WU_TAKE(w) if constexpr (w < WV && w < kWuHalf) { if (WV == 32 || !CONV || w < wu_words_min(WV) || w < Wl) wu_ds_read<WV, w>(st, xin); }
 #define QECMC_WU_TAKE_HI(w) if constexpr (w < WV && w >= kWuHalf) wu_ds_read<WV, w, w - kWuHalf>(st, xin);
             WU_EACH(QECMC_WU_TAKE)
             wu_ds_wait<WV>(st);
@@ -861,9 +864,9 @@ __device__ __forceinline__ void wu_run(const LadderArgs &a, typename WuVec<WV>::
                         // for the same lane, whose state is being replaced in every wave)
                         syn = a.first_syndrome + give;
                         t0 = (uint32_t)t + 1u;
-                        wu_stage_lds<CODE>(a, (uint64_t)give, slot, ldsl + (slot * (uint32_t)WV) * 64u + (uint32_t)lane, n4, cls, 0, -1, WV);
+                        wu_stage_lds<CODE>(a, (uint64_t)give, slot, ldsl + (slot * (uint32_t)Wl) * 64u + (uint32_t)lane, n4, cls);
                         const uint32_t xme = xaddr + slot * xstride;
-#define QECMC_WU_MINE(w) if constexpr (w < WV) wu_ds_read<WV, w>(st, xme);
+#define QECMC_WU_MINE(w) if constexpr (w < WV) { if (w < wu_words_min(WV) || w < Wl) wu_ds_read<WV, w>(st, xme); }
                         WU_EACH(QECMC_WU_MINE)
 #undef QECMC_WU_MINE
                         wu_ds_wait<WV>(st);
@@ -943,12 +946,12 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_wu_kernel(const LadderArgs 
     WU_EACH(QECMC_WU_ZERO)
 #undef QECMC_WU_ZERO
     if (cnt > 0) {
-        const int rows = wu_rows(W);                                  // rows of a rung's region of the exchange buffer
+        const int rows = wu_rows(W, CONV);                            // rows of a rung's region of the exchange buffer
         const wu_lds_rw xcol = (wu_lds_rw)(uintptr_t)lds0 + (slot * (uint32_t)rows) * 64u + (uint32_t)lane;
         wu_stage_lds<CODE>(a, ladder, slot, xcol, n4, cls, 0, WV == 32 ? kWuHalf : W, rows);
         const uint32_t xme = lds0 + (uint32_t)lane * 4u + slot * (uint32_t)(rows * 256);
         const int Wl = W;
-#define QECMC_WU_MINE(w) if constexpr (w < WV && w < kWuHalf) wu_ds_read<WV, w>(st, xme);
+#define QECMC_WU_MINE(w) if constexpr (w < WV && w < kWuHalf) { if (WV == 32 || !CONV || w < wu_words_min(WV) || w < Wl) wu_ds_read<WV, w>(st, xme); }
         WU_EACH(QECMC_WU_MINE)
 #undef QECMC_WU_MINE
         wu_ds_wait<WV>(st);
@@ -987,7 +990,7 @@ __global__ __launch_bounds__(MAXT, MINW) void ladder_wu_kernel(const LadderArgs 
         const uint32_t *bk = lds + o.bk + lane;
         tops0 = bk[0]; samples = bk[64]; done = bk[576] & 1u; steps_done = bk[640]; conv_ok = bk[704];
     }
-    const int rows = wu_rows(W);
+    const int rows = wu_rows(W, CONV);
     {
         const int Wl = W;
         const uint32_t xo = xaddr + slot * (uint32_t)(rows * 256);
