@@ -38,6 +38,10 @@ case "$1" in
     shift
     timeout -k 10 1000 python bench.py --criterion "$@" > gpurun_out/criterion_bench.json 2> gpurun_out/criterion_bench.err; tail -c 1500 gpurun_out/criterion_bench.json
     ;;
+  bench-all)    # every bench mode once, condensed (a regression guard after a kernel change: a layout change that costs one mode a workgroup per CU shows here)
+    b cfg2 --config 2 && b cfg3 --config 3 && b cfg4 --config 4 && b cfg5 --config 5 && b nc9 --config 2 --Nc 9 && b xzzx9 --config 2 --code xzzx && \
+    b alpha --alpha-route && b crit --criterion --steps 1 --warmup 0 && b critalpha --alpha-route --criterion --steps 1 --warmup 0
+    ;;
   round-end)    # the driver's round-end sequence rehearsed: GPU tests, smoke(), the default bench line
     timeout -k 10 1000 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests.log 2>&1; rc=$?; tail -4 gpurun_out/gpu_tests.log
     [ $rc -eq 0 ] && python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" && python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err && tail -c 600 gpurun_out/bench_default.json
