@@ -2002,7 +2002,10 @@ inline size_t ladder_launch_lds(const LadderArgs &a)
 // ahead (PRE)
 inline bool ladder_wants_pre(const LadderArgs &a)
 {
-    return a.Nc >= 3 && (a.Nc * 64 > 512 || 3 * ladder_launch_lds(a) > 160 * 1024) && a.thr_logical != 0 && !(a.tune & 2u);
+    // (up to 8 rungs whose LDS footprint leaves a CU two workgroups anyway: the PRE kernels' 105-119 VGPRs mean 4 waves per SIMD, which is also two
+    // workgroups of 8 waves.  A longer ladder would get ONE: measured at toric L = 9, Nc = 9 / 12 / 16: 0.31 / 0.39 / 0.44 with PRE against
+    // 0.37 / 0.59 / 0.45 without -- round 4; those shapes took PRE until then)
+    return a.Nc >= 3 && a.Nc * 64 <= 512 && 3 * ladder_launch_lds(a) > 160 * 1024 && a.thr_logical != 0 && !(a.tune & 2u);
 }
 
 // launch `fn` (one of the instantiations above) on the grid the arguments imply

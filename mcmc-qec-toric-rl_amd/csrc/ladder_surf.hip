@@ -30,7 +30,7 @@ hipError_t launch_ladder_surf(const LadderArgs &a, hipStream_t stream)
     }
     const void *fn;
     if (pre)
-        fn = big ? LadderKernels<1024, 4, kGentop | kPre, kGentop | kPre | kConv, kGentop | kPre | kDelut, kGentop | kPre | kDelut | kConv>::of<X, R, P>(a.code, want)
+        fn = big ? nullptr      // (ladder_wants_pre: up to 8 rungs)
                  : LadderKernels<512, 4, kGentop | kPre, kGentop | kPre | kConv, kGentop | kPre | kDelut, kGentop | kPre | kDelut | kConv>::of<X, R, P>(a.code, want);
     else if (big)
         fn = LadderKernels<1024, 4, kGentop, kGentop | kConv, kGentop | kDelut, kGentop | kDelut | kConv, kGentop | kQueue | kConv>::of<X, R, P>(a.code, want);

@@ -35,8 +35,7 @@ hipError_t launch_ladder_toric(const LadderArgs &a, hipStream_t stream)
     }
     const void *fn;
     if (pre)   // 4 waves per SIMD by their LDS footprint: 128 VGPRs, the top chain's blocks drawn ahead
-        fn = big ? select_ladder_kernel<1024, 4, T, kPre, kPre | kConv, kPre | kGsplit, kPre | kGsplit | kConv, kPre | kDelut, kPre | kDelut | kConv,
-                                        kPre | kDelut | kGsplit, kPre | kDelut | kGsplit | kConv>(want)
+        fn = big ? nullptr      // (ladder_wants_pre: up to 8 rungs)
                  : select_ladder_kernel<512, 4, T, kPre, kPre | kConv, kPre | kGsplit, kPre | kGsplit | kConv, kPre | kDelut, kPre | kDelut | kConv,
                                         kPre | kDelut | kGsplit, kPre | kDelut | kGsplit | kConv>(want);
     else if (big)
