@@ -252,3 +252,26 @@ def test_wave_scan_alpha_work_queue_bit_exact(q, orc, name, L, Nc, N, steps, ite
         assert np.array_equal(got[k], ref[k].astype(got[k].dtype)), k
     assert np.array_equal(got["converged"], ref["converged"])
     assert ref["converged"].any()
+
+
+@pytest.mark.parametrize("L,N,steps", [(9, 65536, 50), (15, 131072, 12)])
+def test_wave_scan_at_the_full_size_of_baseline_configs_2_and_3(q, orc, L, N, steps):
+    """The bench lines' own shapes on their own kernels (shortened runs): 65 536 toric L = 9 syndromes (12 words, 8 waves per SIMD) and 131 072 toric L = 15
+    (32 words, the exchange in two halves), Nc = 8.  Size-independent properties -- every chain keeps its syndrome, the class counts add up to the samples --,
+    sharded equals whole on a slice, and whole wavefronts of the batch bit-identical to the oracle (the pick group is the global index >> 6)."""
+    from qecmc import toric_model as tm
+    rng = np.random.default_rng(2024 + L)
+    Nc = 8
+    init = _rand(rng, (N, 2, L, L), 0.15)
+    got = q.pteq_batch(init, 0.15, Nc=Nc, steps=steps, iters=10, tops_burn=0, seed=9, return_states=True, scan="wave")
+    assert np.array_equal(got["counts"].sum(axis=1), got["samples"]) and np.all(got["samples"] == steps)
+    syn0 = tm.syndrome(init)
+    for c in (0, Nc - 1):
+        assert np.array_equal(tm.syndrome(np.ascontiguousarray(got["states"][:, c])), syn0)
+    for g in rng.choice(N // 64, size=2, replace=False):          # two wavefronts of the batch, anywhere in it
+        lo = int(g) * 64
+        part = q.pteq_batch(init[lo:lo + 64], 0.15, Nc=Nc, steps=steps, iters=10, tops_burn=0, seed=9, return_states=True, scan="wave", first_syndrome=lo)
+        assert np.array_equal(part["counts"], got["counts"][lo:lo + 64]) and np.array_equal(part["states"], got["states"][lo:lo + 64])
+        for s in (lo, lo + 37):
+            ref = orc.pteq_batch(orc.TORIC, init[s:s + 1], 0.15, Nc, steps, iters=10, tops_burn=0, seed=9, first_syndrome=s, return_states=True, scan=3)
+            assert np.array_equal(got["counts"][s], ref["counts"][0]) and np.array_equal(got["states"][s], ref["states"][0])
